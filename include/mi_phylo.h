@@ -1,0 +1,199 @@
+/* mi_phylo.h -- C ABI of the MI355X-native phylogenetic likelihood + gradient
+ * engine.  This is the drop-in boundary for libsbn's Engine / FatBeagle path:
+ * plain pointers and sizes, no C++ or torch types.
+ *
+ * What it replaces in the reference (paths relative to the libsbn repo root):
+ *   Engine::Engine / FatBeagle::FatBeagle / CreateInstance / SetTipStates /
+ *   SetTipPartials                     src/engine.cpp:10-46, src/fat_beagle.cpp:13-29,207-271
+ *   Engine::LogLikelihoods (unrooted)  src/engine.cpp:54-60  -> fat_beagle.cpp:72-76
+ *   Engine::LogLikelihoods (rooted)    src/engine.cpp:62-68  -> fat_beagle.cpp:96-104
+ *   Engine::UnrootedLogLikelihoods     src/engine.cpp:70-76  -> fat_beagle.cpp:78-80
+ *   Engine::Gradients (unrooted)       src/engine.cpp:78-84  -> fat_beagle.cpp:467-503
+ *   Engine::Gradients (rooted)         src/engine.cpp:86-92  -> fat_beagle.cpp:505-545
+ *   Engine::GetPhyloModelBlockSpecification  src/engine.cpp:48-52
+ * together with everything those call: the 16 BEAGLE C-API calls
+ * (SURVEY.md section 2.1), PhyloModel::SetParameters (src/phylo_model.cpp:26-31),
+ * the GTR/JC69/Weibull models, Detrifurcate, SlideRootPosition, the rooted
+ * chain rule (src/rooted_gradient_transforms.cpp) and the finite-difference
+ * substitution gradient (src/fat_beagle.cpp:400-465).
+ *
+ * Conventions
+ *   n = taxon_count, N = 2n-1, P = pattern_count, s = state_count, K = category_count.
+ *   Trees arrive as the reference's own flat topology form, the parent-id vector
+ *   (Node::ParentIdVector, src/node.hpp:153): leaves 0..n-1, internal nodes in
+ *   post-order, root last and without an entry.  Children are ordered by max
+ *   leaf id as in src/node.cpp:32-59.
+ *     unrooted tree: 2n-2 nodes (trifurcating root), parent_ids[2n-3],
+ *                    branch_lengths[2n-2] (entry of the root unused).
+ *     rooted tree:   2n-1 nodes, parent_ids[2n-2], branch_lengths[2n-1].
+ *   Parameter rows follow BlockSpecification (src/block_specification.cpp:11-50,
+ *   src/phylo_model.cpp:13-15): [GTR rates(6) | frequencies(4)] [Weibull shape]
+ *   [clock rate]; query with mi_engine_block().
+ *   All arrays are row-major, FP64 / int32, caller-owned.  Results come back in
+ *   tree order.  Every function returns 0 on success; otherwise nonzero and
+ *   mi_last_error() holds the message (the C++ adapter rethrows it as
+ *   std::runtime_error, mirroring Failwith, src/sugar.hpp:67-78).
+ *   An engine is not re-entrant (neither is the reference's, engine.hpp:26-54).
+ *
+ * Two families of entry points:
+ *   mi_engine_*          host pointers in / host pointers out (what the cgo-like
+ *                        binding in the reference would call)
+ *   mi_engine_*_device   device pointers in / out, asynchronous on `stream`
+ *                        (a hipStream_t passed as void*; NULL = the engine's own
+ *                        stream).  Used by bench.py with inputs resident in HBM,
+ *                        and by multi-GPU callers that hand results to RCCL.
+ */
+#ifndef MI_PHYLO_H_
+#define MI_PHYLO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_PHYLO_ABI_VERSION 1
+
+typedef struct mi_engine mi_engine;
+
+enum { MI_SUBST_JC69 = 0, MI_SUBST_GTR = 1 };       /* src/substitution_model.cpp:6-15 */
+enum { MI_SITE_CONSTANT = 0, MI_SITE_WEIBULL = 1 }; /* src/site_model.cpp:10-25 */
+enum { MI_CLOCK_NONE = 0, MI_CLOCK_STRICT = 1 };    /* src/clock_model.cpp:6-15 */
+
+typedef struct {
+  int32_t taxon_count;    /* n >= 3 */
+  int32_t pattern_count;  /* P >= 1 */
+  int32_t state_count;    /* s: 4 */
+  int32_t category_count; /* K: 1 for constant, K of "weibull+K" */
+  int32_t subst_model;    /* MI_SUBST_* */
+  int32_t site_model;     /* MI_SITE_* */
+  int32_t clock_model;    /* MI_CLOCK_* */
+  int32_t use_tip_states; /* EngineSpecification::use_tip_states_, engine.hpp:20-24 */
+  int32_t device;         /* HIP device ordinal; -1 = current device */
+  int32_t reserved;
+} mi_engine_spec;
+
+int32_t mi_abi_version(void);
+const char* mi_last_error(void);
+
+/* Engine::Engine + FatBeagle::SetTipStates/SetTipPartials/SetPatternWeights.
+ * tip_states[n*P]: 0..s-1, >= s means gap (src/site_pattern.cpp:16-46).
+ * tip_partials[n*P*s] is read when use_tip_states == 0 (may be NULL: then the
+ * partials are derived from tip_states exactly as SitePattern::GetPartials does,
+ * src/site_pattern.cpp:117-131). */
+int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
+                         const double* tip_partials, const double* pattern_weights,
+                         mi_engine** out_engine);
+void mi_engine_destroy(mi_engine* engine);
+
+/* Engine::GetPhyloModelBlockSpecification: blocks in std::map (ASCII) order. */
+int32_t mi_engine_param_count(const mi_engine* engine);
+int32_t mi_engine_block_count(const mi_engine* engine);
+int32_t mi_engine_block(const mi_engine* engine, int32_t index, const char** name,
+                        int32_t* start, int32_t* length);
+
+/* ---- host-pointer entry points ------------------------------------------ */
+
+/* Engine::LogLikelihoods(const UnrootedTreeCollection&, params, rescaling) */
+int32_t mi_engine_log_likelihoods_unrooted(mi_engine* engine, int32_t tree_count,
+                                           const int32_t* parent_ids,     /* [T][2n-3] */
+                                           const double* branch_lengths,  /* [T][2n-2] */
+                                           const double* params,          /* [T][param_count] */
+                                           int32_t rescaling,
+                                           double* out_log_likelihoods /* [T] */);
+
+/* Engine::Gradients(const UnrootedTreeCollection&, ...): PhyloGradient per tree.
+ * out_branch_gradient[T][2n-1] = gradient_["branch_lengths"] (last two entries 0);
+ * out_site_gradient[T] = gradient_["site_model"] (K > 1, else untouched; may be NULL);
+ * out_subst_gradient[T][8] = gradient_["substitution_model"] (GTR; may be NULL). */
+int32_t mi_engine_gradients_unrooted(mi_engine* engine, int32_t tree_count,
+                                     const int32_t* parent_ids, const double* branch_lengths,
+                                     const double* params, int32_t rescaling,
+                                     double* out_log_likelihoods, double* out_branch_gradient,
+                                     double* out_site_gradient, double* out_subst_gradient);
+
+/* Engine::LogLikelihoods(const RootedTreeCollection&) when with_jacobian != 0
+ * (branch lengths x rates, + log-det-Jacobian, fat_beagle.cpp:82-104), or
+ * Engine::UnrootedLogLikelihoods(const RootedTreeCollection&) when 0
+ * (fat_beagle.cpp:78-80: raw branch lengths, no Jacobian; rates/heights/bounds
+ * may then be NULL). */
+int32_t mi_engine_log_likelihoods_rooted(mi_engine* engine, int32_t tree_count,
+                                         const int32_t* parent_ids,    /* [T][2n-2] */
+                                         const double* branch_lengths, /* [T][2n-1] */
+                                         const double* params,
+                                         const double* rates,        /* [T][2n-2] RootedTree::rates_ */
+                                         const double* node_heights, /* [T][2n-1] */
+                                         const double* node_bounds,  /* [T][2n-1] */
+                                         int32_t with_jacobian, int32_t rescaling,
+                                         double* out_log_likelihoods);
+
+/* Engine::Gradients(const RootedTreeCollection&, ...).
+ * out_log_likelihoods excludes the Jacobian (rooted_sbn_instance.hpp:285).
+ * out_ratios_root_height[T][n-1], out_clock_gradient[T][2n-2] (strict clock,
+ * rate_counts[t]==1: entry 0 holds the single value, rest 0; per-branch clock,
+ * rate_counts[t]==2n-2: all entries; anything else is an error,
+ * fat_beagle.cpp:375-386). */
+int32_t mi_engine_gradients_rooted(mi_engine* engine, int32_t tree_count,
+                                   const int32_t* parent_ids, const double* branch_lengths,
+                                   const double* params, const double* rates,
+                                   const int32_t* rate_counts, /* [T] */
+                                   const double* node_heights, const double* node_bounds,
+                                   const double* height_ratios, /* [T][n-1] */
+                                   int32_t rescaling, double* out_log_likelihoods,
+                                   double* out_ratios_root_height, double* out_clock_gradient,
+                                   double* out_site_gradient, double* out_subst_gradient);
+
+/* ---- device-pointer entry points (asynchronous) -------------------------- */
+/* Same arguments and meaning, but every array pointer is a device pointer on
+ * the engine's device and nothing is synchronised: the work is enqueued on
+ * `stream`.  Per-tree input errors (malformed parent ids, GTR sums off by
+ * >= 1e-3, bad rate_count) set a device-side status word that
+ * mi_engine_check_status() reads back (it synchronises the stream). */
+
+int32_t mi_engine_log_likelihoods_unrooted_device(mi_engine* engine, void* stream,
+                                                  int32_t tree_count, const int32_t* parent_ids,
+                                                  const double* branch_lengths,
+                                                  const double* params, int32_t rescaling,
+                                                  double* out_log_likelihoods);
+int32_t mi_engine_gradients_unrooted_device(mi_engine* engine, void* stream, int32_t tree_count,
+                                            const int32_t* parent_ids,
+                                            const double* branch_lengths, const double* params,
+                                            int32_t rescaling, double* out_log_likelihoods,
+                                            double* out_branch_gradient,
+                                            double* out_site_gradient,
+                                            double* out_subst_gradient);
+int32_t mi_engine_log_likelihoods_rooted_device(mi_engine* engine, void* stream,
+                                                int32_t tree_count, const int32_t* parent_ids,
+                                                const double* branch_lengths,
+                                                const double* params, const double* rates,
+                                                const double* node_heights,
+                                                const double* node_bounds,
+                                                int32_t with_jacobian, int32_t rescaling,
+                                                double* out_log_likelihoods);
+int32_t mi_engine_gradients_rooted_device(mi_engine* engine, void* stream, int32_t tree_count,
+                                          const int32_t* parent_ids,
+                                          const double* branch_lengths, const double* params,
+                                          const double* rates, const int32_t* rate_counts,
+                                          const double* node_heights, const double* node_bounds,
+                                          const double* height_ratios, int32_t rescaling,
+                                          double* out_log_likelihoods,
+                                          double* out_ratios_root_height,
+                                          double* out_clock_gradient, double* out_site_gradient,
+                                          double* out_subst_gradient);
+
+/* Make sure the workspace for `tree_count` trees exists (so that a following
+ * *_device call allocates nothing and can be captured in a hipGraph). */
+int32_t mi_engine_reserve(mi_engine* engine, int32_t tree_count, int32_t for_gradients);
+/* Synchronise `stream` and report the first per-tree error of the last call. */
+int32_t mi_engine_check_status(mi_engine* engine, void* stream);
+
+/* Introspection for the bench / profiles: name and launch count of the dominant
+ * kernel of the last call, and the algorithmic bytes it accounts for
+ * (DESIGN.md "Measurement"). */
+int32_t mi_engine_last_call_info(const mi_engine* engine, const char** dominant_kernel,
+                                 int64_t* evaluations, int64_t* gradient_evaluations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_PHYLO_H_ */

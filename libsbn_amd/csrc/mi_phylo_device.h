@@ -1,0 +1,48 @@
+// Device-side data layout shared by the kernels and the host engine.
+// Everything here lives in HBM for the duration of one engine call; see
+// DESIGN.md "Data layout in HBM".
+#pragma once
+#include <stdint.h>
+
+namespace miphylo {
+
+constexpr int kStates = 4;       // the reference is DNA-only (substitution_model.cpp:6-15)
+constexpr int kMaxCategories = 16;
+constexpr int kTile = 64;        // site patterns per wavefront
+constexpr int kFdModels = 17;    // base model + 2*(3 frequency + 5 rate) perturbed models
+
+// One substitution+site model instance (what FatBeagle::SetParameters pushes to
+// BEAGLE per tree: fat_beagle.cpp:273-300).
+struct DevModel {
+  double pi[kStates];
+  double Q[kStates * kStates];     // row-major
+  double V[kStates * kStates];     // eigenvectors
+  double Vinv[kStates * kStates];  // inverse eigenvectors
+  double lambda[kStates];
+  double cat_rate[kMaxCategories];
+  double cat_weight[kMaxCategories];
+  double cat_drate[kMaxCategories];  // d rate_k / d shape
+};
+
+// One entry of a tree's evaluation schedule: an internal node with its two
+// children (node ids as in node.cpp:341-357) and the LDS slots the on-chip
+// log-likelihood kernel keeps the partial-likelihood vectors in.
+struct SchedEntry {
+  int32_t node;
+  int32_t child0;
+  int32_t child1;
+  int32_t slots;  // dst | slot(child0) << 8 | slot(child1) << 16
+};
+
+enum StatusCode : int32_t {
+  kOk = 0,
+  kBadParentIds = 1,
+  kNotBifurcating = 2,
+  kNotTrifurcatingRoot = 3,
+  kGtrFrequencies = 4,
+  kGtrRates = 5,
+  kBadRateCount = 6,
+  kTooManySlots = 7,
+};
+
+}  // namespace miphylo

@@ -1,0 +1,718 @@
+// Host side of the C ABI declared in include/mi_phylo.h: device memory, the
+// per-call launch sequence, error reporting.  Compiled with hipcc; no torch.
+//
+// Per call (all on one HIP stream, no host synchronisation in the *_device path):
+//   tree_setup -> model_setup -> transition -> {loglik_onchip | gradient_hbm}* -> finalize
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_phylo.h"
+#include "mi_phylo_kernels.h"
+
+using namespace miphylo;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(const std::string& msg) {
+  g_error = msg;
+  return 1;
+}
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t err__ = (expr);                                                     \
+    if (err__ != hipSuccess)                                                       \
+      return fail(std::string("HIP error: ") + hipGetErrorString(err__) + " at " + \
+                  __FILE__ + ":" + std::to_string(__LINE__));                      \
+  } while (0)
+
+// A device buffer that only ever grows.
+struct Buffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return 0;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    HIP_TRY(hipMalloc(&ptr, need));
+    bytes = need;
+    return 0;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T* as() const { return static_cast<T*>(ptr); }
+};
+
+struct Block {
+  std::string name;
+  int start, length;
+};
+
+const char* status_message(int code) {
+  switch (code) {
+    case kBadParentIds: return "parent id vector is not in the reference's post-order id form";
+    case kNotBifurcating: return "expected a bifurcating tree (node.cpp:198,240)";
+    case kNotTrifurcatingRoot:
+      return "UnrootedTree::Detrifurcate given a non-trifurcating tree.";
+    case kGtrFrequencies: return "GTR frequencies do not sum to 1 +/- 0.001!";
+    case kGtrRates: return "GTR rates do not sum to 1 +/- 0.001!";
+    case kBadRateCount:
+      return "The number of rates should be equal to 1 (i.e. strict clock) or equal to the "
+             "number of branches.";
+    case kTooManySlots: return "internal error: evaluation schedule needs too many LDS slots";
+    default: return "unknown device status";
+  }
+}
+
+}  // namespace
+
+struct mi_engine {
+  mi_engine_spec spec;
+  int n, N, P, K, tiles, max_slots;
+  int param_count, rates_off, freqs_off, shape_off, clock_off;
+  std::vector<Block> blocks;
+  hipStream_t stream = nullptr;
+  // static device data
+  Buffer tip_states, tip_partials, weights;
+  // per-call workspace
+  Buffer tree_scratch, sched, bl_eff, models, mats, ll_part, plv, g_part, fin_scratch, status;
+  // staging for the host-pointer entry points
+  Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
+      in_ratios, out_ll, out_a, out_b, out_site, out_subst;
+  size_t plv_budget = (size_t)8 << 30;
+  // last-call info
+  const char* dominant = "";
+  int64_t last_evals = 0, last_grad_evals = 0;
+};
+
+namespace {
+
+struct CallShape {
+  int T, E, Eg, M, models_per_tree;
+  bool gradient, gtr, site_fused, site_separate;
+};
+
+CallShape call_shape(const mi_engine* e, int T, bool gradient) {
+  CallShape c{};
+  c.T = T;
+  c.gradient = gradient;
+  c.gtr = e->spec.subst_model == MI_SUBST_GTR;
+  c.site_fused = gradient && e->K > 1 && !c.gtr;
+  c.site_separate = gradient && e->K > 1 && c.gtr;
+  c.models_per_tree = (gradient && c.gtr) ? kFdModels : 1;
+  c.M = T * c.models_per_tree;
+  c.E = T;
+  c.Eg = gradient ? T : 0;
+  if (gradient && c.gtr) c.E += 16 * T;
+  if (c.site_separate) {
+    c.E += T;
+    c.Eg += T;
+  }
+  return c;
+}
+
+size_t plv_bytes_per_eval(const mi_engine* e) {
+  return (size_t)(e->n - 1) * e->K * e->tiles * kTile * 4 * sizeof(double);
+}
+
+int reserve(mi_engine* e, int T, bool gradient) {
+  const CallShape c = call_shape(e, T, gradient);
+  const int n = e->n, N = e->N;
+  if (e->tree_scratch.ensure(sizeof(int32_t) * (size_t)T * 12 * N)) return 1;
+  if (e->sched.ensure(sizeof(SchedEntry) * (size_t)T * (n - 1))) return 1;
+  if (e->bl_eff.ensure(sizeof(double) * (size_t)T * N)) return 1;
+  if (e->models.ensure(sizeof(DevModel) * (size_t)c.M)) return 1;
+  if (e->mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
+  if (e->ll_part.ensure(sizeof(double) * (size_t)c.E * e->tiles)) return 1;
+  if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
+  if (e->status.ensure(sizeof(int32_t) * 2)) return 1;
+  if (gradient) {
+    const size_t per = plv_bytes_per_eval(e);
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / per));
+    if (e->plv.ensure(per * chunk)) return 1;
+    if (e->g_part.ensure(sizeof(double) * (size_t)c.Eg * e->tiles * 2 * N)) return 1;
+  }
+  return 0;
+}
+
+struct DeviceCall {
+  bool gradient = false, rooted = false, with_jacobian = false, rescaling = false;
+  int T = 0;
+  const int32_t* parent_ids = nullptr;
+  const double* bl = nullptr;
+  const double* params = nullptr;
+  const double* rates = nullptr;
+  const int32_t* rate_counts = nullptr;
+  const double* heights = nullptr;
+  const double* bounds = nullptr;
+  const double* ratios = nullptr;
+  double* out_ll = nullptr;
+  double* out_branch = nullptr;
+  double* out_ratios = nullptr;
+  double* out_clock = nullptr;
+  double* out_site = nullptr;
+  double* out_subst = nullptr;
+};
+
+// Enqueue one engine call; every pointer in `d` is a device pointer.
+int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
+  if (d.T <= 0) return fail("tree_count must be positive");
+  if (!d.parent_ids || !d.bl || !d.out_ll) return fail("null tree / output pointer");
+  if (e->param_count > 0 && !d.params) return fail("null parameter matrix");
+  if (reserve(e, d.T, d.gradient)) return 1;
+  const CallShape c = call_shape(e, d.T, d.gradient);
+  const int n = e->n, N = e->N, T = d.T;
+  HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, s));
+
+  TreeSetupArgs ts{};
+  ts.n = n;
+  ts.T = T;
+  ts.rooted = d.rooted;
+  ts.parent_ids = d.parent_ids;
+  ts.bl = d.bl;
+  // rooted trees: LogLikelihood/Gradient scale by rates (fat_beagle.cpp:96-101,507-511);
+  // UnrootedLogLikelihood(RootedTree) does not (:78-80).
+  ts.rates = (d.rooted && (d.gradient || d.with_jacobian)) ? d.rates : nullptr;
+  ts.scratch = e->tree_scratch.as<int32_t>();
+  ts.sched = e->sched.as<SchedEntry>();
+  ts.bl_eff = e->bl_eff.as<double>();
+  ts.status = e->status.as<int32_t>();
+  ts.max_slots = e->max_slots;
+  launch_tree_setup(ts, s);
+
+  ModelSetupArgs ms{};
+  ms.T = T;
+  ms.models_per_tree = c.models_per_tree;
+  ms.subst = e->spec.subst_model;
+  ms.site = e->spec.site_model;
+  ms.K = e->K;
+  ms.param_count = e->param_count;
+  ms.rates_off = e->rates_off;
+  ms.freqs_off = e->freqs_off;
+  ms.shape_off = e->shape_off;
+  ms.params = d.params;
+  ms.models = e->models.as<DevModel>();
+  ms.status = e->status.as<int32_t>();
+  launch_model_setup(ms, s);
+
+  const EvalMap map{T, c.models_per_tree};
+  TransitionArgs tr{};
+  tr.E = c.E;
+  tr.N = N;
+  tr.K = e->K;
+  tr.map = map;
+  tr.models = e->models.as<DevModel>();
+  tr.bl_eff = e->bl_eff.as<double>();
+  tr.mats = e->mats.as<double>();
+  launch_transition(tr, s);
+
+  LikArgs la{};
+  la.n = n;
+  la.N = N;
+  la.P = e->P;
+  la.K = e->K;
+  la.tiles = e->tiles;
+  la.map = map;
+  la.models = e->models.as<DevModel>();
+  la.sched = e->sched.as<SchedEntry>();
+  la.mats = e->mats.as<double>();
+  la.tip_states = e->tip_states.as<int8_t>();
+  la.tip_partials = e->spec.use_tip_states ? nullptr : e->tip_partials.as<double>();
+  la.weights = e->weights.as<double>();
+  la.ll_part = e->ll_part.as<double>();
+  la.plv = e->plv.as<double>();
+  la.g_part = e->g_part.as<double>();
+
+  auto grad_range = [&](int eval_begin, int grad_begin, int count) {
+    const size_t per = plv_bytes_per_eval(e);
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(count, e->plv.bytes / per));
+    for (int done = 0; done < count; done += chunk) {
+      LikArgs g = la;
+      g.eval_offset = eval_begin + done;
+      g.grad_offset = grad_begin + done;
+      launch_gradient_hbm(g, std::min(chunk, count - done), d.rescaling, s);
+    }
+  };
+
+  if (!d.gradient) {
+    la.eval_offset = 0;
+    launch_loglik(la, T, d.rescaling, e->max_slots, s);
+    e->dominant = loglik_kernel_name();
+  } else {
+    grad_range(0, 0, T);
+    if (c.gtr) {
+      LikArgs l = la;
+      l.eval_offset = T;
+      launch_loglik(l, 16 * T, d.rescaling, e->max_slots, s);
+    }
+    if (c.site_separate) grad_range(17 * T, T, T);
+    e->dominant = gradient_kernel_name();
+  }
+  e->last_evals = c.E;
+  e->last_grad_evals = c.Eg;
+
+  FinalizeArgs fa{};
+  fa.n = n;
+  fa.N = N;
+  fa.T = T;
+  fa.K = e->K;
+  fa.tiles = e->tiles;
+  fa.gradient = d.gradient;
+  fa.rooted = d.rooted;
+  fa.with_jacobian = d.with_jacobian;
+  fa.gtr = c.gtr;
+  fa.site_fused = c.site_fused;
+  fa.site_separate = c.site_separate;
+  fa.ll_part = e->ll_part.as<double>();
+  fa.g_part = e->g_part.as<double>();
+  fa.bl_eff = e->bl_eff.as<double>();
+  fa.bl_raw = d.bl;
+  fa.rates = d.rates;
+  fa.rate_counts = d.rate_counts;
+  fa.node_heights = d.heights;
+  fa.node_bounds = d.bounds;
+  fa.height_ratios = d.ratios;
+  fa.sched = e->sched.as<SchedEntry>();
+  fa.scratch = e->fin_scratch.as<double>();
+  fa.out_ll = d.out_ll;
+  fa.out_branch = d.out_branch;
+  fa.out_ratios = d.out_ratios;
+  fa.out_clock = d.out_clock;
+  fa.out_site = d.out_site;
+  fa.out_subst = d.out_subst;
+  fa.status = e->status.as<int32_t>();
+  launch_finalize(fa, s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int check_status(mi_engine* e, hipStream_t s) {
+  int32_t st[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(st, e->status.ptr, sizeof st, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (st[0] != 0)
+    return fail(std::string(status_message(st[0])) + " (tree " + std::to_string(st[1]) + ")");
+  return 0;
+}
+
+template <typename T>
+int upload(Buffer& b, const T* host, size_t count, hipStream_t s) {
+  if (b.ensure(sizeof(T) * std::max<size_t>(count, 1))) return 1;
+  if (count) HIP_TRY(hipMemcpyAsync(b.ptr, host, sizeof(T) * count, hipMemcpyHostToDevice, s));
+  return 0;
+}
+
+int download(double* host, const Buffer& b, size_t count, hipStream_t s) {
+  if (host && count)
+    HIP_TRY(hipMemcpyAsync(host, b.ptr, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+void add_block(std::map<std::string, std::pair<int, int>>& m, const std::string& k, int start,
+               int len) {
+  m[k] = {start, len};
+}
+
+hipStream_t pick_stream(mi_engine* e, void* stream) {
+  return stream ? static_cast<hipStream_t>(stream) : e->stream;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mi_abi_version(void) { return MI_PHYLO_ABI_VERSION; }
+const char* mi_last_error(void) { return g_error.c_str(); }
+
+int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
+                         const double* tip_partials, const double* pattern_weights,
+                         mi_engine** out_engine) {
+  if (!spec || !out_engine) return fail("null spec / out_engine");
+  *out_engine = nullptr;
+  if (spec->taxon_count < 3) return fail("need at least 3 taxa");
+  if (spec->pattern_count < 1) return fail("need at least one site pattern");
+  if (spec->state_count != kStates)
+    return fail("only 4-state (DNA) models are implemented, as in the reference "
+                "(substitution_model.cpp:6-15)");
+  if (spec->subst_model != MI_SUBST_JC69 && spec->subst_model != MI_SUBST_GTR)
+    return fail("Substitution model not known");
+  if (spec->site_model != MI_SITE_CONSTANT && spec->site_model != MI_SITE_WEIBULL)
+    return fail("Site model not known");
+  if (spec->clock_model != MI_CLOCK_NONE && spec->clock_model != MI_CLOCK_STRICT)
+    return fail("Clock model not known");
+  if (spec->site_model == MI_SITE_CONSTANT && spec->category_count != 1)
+    return fail("the constant site model has exactly one rate category");
+  if (spec->category_count < 1 || spec->category_count > kMaxCategories)
+    return fail("category_count out of range (1..16)");
+  if (!tip_states && !(spec->use_tip_states == 0 && tip_partials))
+    return fail("tip_states is required");
+  if (!pattern_weights) return fail("pattern_weights is required");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    return fail("no HIP device available: the MI355X engine has no CPU fallback");
+  if (spec->device >= count) return fail("device ordinal out of range");
+  if (spec->device >= 0) HIP_TRY(hipSetDevice(spec->device));
+
+  mi_engine* e = new mi_engine();
+  e->spec = *spec;
+  if (spec->device < 0) HIP_TRY(hipGetDevice(&e->spec.device));
+  e->n = spec->taxon_count;
+  e->N = 2 * e->n - 1;
+  e->P = spec->pattern_count;
+  e->K = spec->category_count;
+  e->tiles = (e->P + kTile - 1) / kTile;
+  int lg = 0;
+  while ((2 << lg) <= e->n) lg++;
+  e->max_slots = lg + 1;
+  if (const char* env = getenv("MI_PHYLO_PLV_BYTES")) e->plv_budget = strtoull(env, nullptr, 10);
+
+  // BlockSpecification (block_specification.cpp:11-50, phylo_model.cpp:13-15)
+  std::map<std::string, std::pair<int, int>> bm;
+  int off = 0;
+  e->rates_off = e->freqs_off = e->shape_off = e->clock_off = -1;
+  if (spec->subst_model == MI_SUBST_GTR) {
+    e->rates_off = off;
+    add_block(bm, "GTR rates", off, 6);
+    off += 6;
+    e->freqs_off = off;
+    add_block(bm, "frequencies", off, 4);
+    off += 4;
+  }
+  add_block(bm, "entire substitution", 0, off);
+  const int site_start = off;
+  if (spec->site_model == MI_SITE_WEIBULL) {
+    e->shape_off = off;
+    add_block(bm, "Weibull shape", off, 1);
+    off += 1;
+  }
+  add_block(bm, "entire site", site_start, off - site_start);
+  const int clock_start = off;
+  if (spec->clock_model == MI_CLOCK_STRICT) {
+    e->clock_off = off;
+    add_block(bm, "clock rate", off, 1);
+    off += 1;
+  }
+  add_block(bm, "entire clock", clock_start, off - clock_start);
+  add_block(bm, "entire", 0, off);
+  e->param_count = off;
+  for (const auto& kv : bm) e->blocks.push_back({kv.first, kv.second.first, kv.second.second});
+
+  auto cleanup_fail = [&](int) {
+    mi_engine_destroy(e);
+    return 1;
+  };
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+    return cleanup_fail(fail("hipStreamCreate failed"));
+  const size_t np = (size_t)e->n * e->P;
+  std::vector<int8_t> st8(np, 4);
+  if (tip_states)
+    for (size_t i = 0; i < np; i++) {
+      const int32_t v = tip_states[i];
+      st8[i] = (v >= 0 && v < kStates) ? (int8_t)v : (int8_t)kStates;
+    }
+  if (upload(e->tip_states, st8.data(), np, e->stream)) return cleanup_fail(1);
+  if (!spec->use_tip_states) {
+    std::vector<double> tp(np * kStates);
+    if (tip_partials) {
+      std::copy(tip_partials, tip_partials + np * kStates, tp.begin());
+    } else {
+      for (size_t i = 0; i < np; i++)
+        for (int x = 0; x < kStates; x++)
+          tp[i * kStates + x] = (st8[i] >= kStates || st8[i] == x) ? 1.0 : 0.0;
+    }
+    if (upload(e->tip_partials, tp.data(), tp.size(), e->stream)) return cleanup_fail(1);
+  }
+  if (upload(e->weights, pattern_weights, (size_t)e->P, e->stream)) return cleanup_fail(1);
+  if (hipStreamSynchronize(e->stream) != hipSuccess)
+    return cleanup_fail(fail("upload of tips failed"));
+  *out_engine = e;
+  return 0;
+}
+
+void mi_engine_destroy(mi_engine* e) {
+  if (!e) return;
+  if (e->stream) {
+    (void)hipStreamSynchronize(e->stream);
+  }
+  for (Buffer* b :
+       {&e->tip_states, &e->tip_partials, &e->weights, &e->tree_scratch, &e->sched, &e->bl_eff,
+        &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->fin_scratch, &e->status,
+        &e->in_parent, &e->in_bl, &e->in_params, &e->in_rates, &e->in_rate_counts,
+        &e->in_heights, &e->in_bounds, &e->in_ratios, &e->out_ll, &e->out_a, &e->out_b,
+        &e->out_site, &e->out_subst})
+    b->release();
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int32_t mi_engine_param_count(const mi_engine* e) { return e ? e->param_count : -1; }
+int32_t mi_engine_block_count(const mi_engine* e) { return e ? (int32_t)e->blocks.size() : -1; }
+int32_t mi_engine_block(const mi_engine* e, int32_t index, const char** name, int32_t* start,
+                        int32_t* length) {
+  if (!e || index < 0 || index >= (int32_t)e->blocks.size()) return fail("block index out of range");
+  if (name) *name = e->blocks[index].name.c_str();
+  if (start) *start = e->blocks[index].start;
+  if (length) *length = e->blocks[index].length;
+  return 0;
+}
+
+int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradients) {
+  if (!e) return fail("null engine");
+  if (tree_count <= 0) return fail("tree_count must be positive");
+  HIP_TRY(hipSetDevice(e->spec.device));
+  return reserve(e, tree_count, for_gradients != 0);
+}
+
+int32_t mi_engine_check_status(mi_engine* e, void* stream) {
+  if (!e) return fail("null engine");
+  return check_status(e, pick_stream(e, stream));
+}
+
+int32_t mi_engine_last_call_info(const mi_engine* e, const char** dominant_kernel,
+                                 int64_t* evaluations, int64_t* gradient_evaluations) {
+  if (!e) return fail("null engine");
+  if (dominant_kernel) *dominant_kernel = e->dominant;
+  if (evaluations) *evaluations = e->last_evals;
+  if (gradient_evaluations) *gradient_evaluations = e->last_grad_evals;
+  return 0;
+}
+
+/* ---- device-pointer entry points ---------------------------------------- */
+
+int32_t mi_engine_log_likelihoods_unrooted_device(mi_engine* e, void* stream, int32_t T,
+                                                  const int32_t* parent_ids, const double* bl,
+                                                  const double* params, int32_t rescaling,
+                                                  double* out_ll) {
+  if (!e) return fail("null engine");
+  DeviceCall d;
+  d.T = T;
+  d.rescaling = rescaling != 0;
+  d.parent_ids = parent_ids;
+  d.bl = bl;
+  d.params = params;
+  d.out_ll = out_ll;
+  return run_device(e, pick_stream(e, stream), d);
+}
+
+int32_t mi_engine_gradients_unrooted_device(mi_engine* e, void* stream, int32_t T,
+                                            const int32_t* parent_ids, const double* bl,
+                                            const double* params, int32_t rescaling,
+                                            double* out_ll, double* out_branch,
+                                            double* out_site, double* out_subst) {
+  if (!e) return fail("null engine");
+  if (!out_branch) return fail("null branch-gradient output");
+  DeviceCall d;
+  d.gradient = true;
+  d.T = T;
+  d.rescaling = rescaling != 0;
+  d.parent_ids = parent_ids;
+  d.bl = bl;
+  d.params = params;
+  d.out_ll = out_ll;
+  d.out_branch = out_branch;
+  d.out_site = out_site;
+  d.out_subst = out_subst;
+  return run_device(e, pick_stream(e, stream), d);
+}
+
+int32_t mi_engine_log_likelihoods_rooted_device(mi_engine* e, void* stream, int32_t T,
+                                                const int32_t* parent_ids, const double* bl,
+                                                const double* params, const double* rates,
+                                                const double* heights, const double* bounds,
+                                                int32_t with_jacobian, int32_t rescaling,
+                                                double* out_ll) {
+  if (!e) return fail("null engine");
+  if (with_jacobian && (!rates || !heights || !bounds))
+    return fail("Attempted access of a time tree member that requires the time tree to be "
+                "initialized. Have you set dates for your time trees, and initialized the "
+                "time trees?");
+  DeviceCall d;
+  d.rooted = true;
+  d.with_jacobian = with_jacobian != 0;
+  d.T = T;
+  d.rescaling = rescaling != 0;
+  d.parent_ids = parent_ids;
+  d.bl = bl;
+  d.params = params;
+  d.rates = rates;
+  d.heights = heights;
+  d.bounds = bounds;
+  d.out_ll = out_ll;
+  return run_device(e, pick_stream(e, stream), d);
+}
+
+int32_t mi_engine_gradients_rooted_device(mi_engine* e, void* stream, int32_t T,
+                                          const int32_t* parent_ids, const double* bl,
+                                          const double* params, const double* rates,
+                                          const int32_t* rate_counts, const double* heights,
+                                          const double* bounds, const double* ratios,
+                                          int32_t rescaling, double* out_ll, double* out_ratios,
+                                          double* out_clock, double* out_site,
+                                          double* out_subst) {
+  if (!e) return fail("null engine");
+  if (!rates || !rate_counts || !heights || !bounds || !ratios)
+    return fail("Attempted access of a time tree member that requires the time tree to be "
+                "initialized. Have you set dates for your time trees, and initialized the "
+                "time trees?");
+  if (!out_ratios || !out_clock) return fail("null gradient output");
+  DeviceCall d;
+  d.gradient = true;
+  d.rooted = true;
+  d.T = T;
+  d.rescaling = rescaling != 0;
+  d.parent_ids = parent_ids;
+  d.bl = bl;
+  d.params = params;
+  d.rates = rates;
+  d.rate_counts = rate_counts;
+  d.heights = heights;
+  d.bounds = bounds;
+  d.ratios = ratios;
+  d.out_ll = out_ll;
+  d.out_ratios = out_ratios;
+  d.out_clock = out_clock;
+  d.out_site = out_site;
+  d.out_subst = out_subst;
+  return run_device(e, pick_stream(e, stream), d);
+}
+
+/* ---- host-pointer entry points ------------------------------------------ */
+
+static int stage_common(mi_engine* e, int T, bool rooted, const int32_t* parent_ids,
+                        const double* bl, const double* params) {
+  if (!e) return fail("null engine");
+  if (T <= 0) return fail("tree_count must be positive");
+  if (!parent_ids || !bl) return fail("null tree arrays");
+  if (e->param_count > 0 && !params) return fail("null parameter matrix");
+  HIP_TRY(hipSetDevice(e->spec.device));
+  const int n = e->n;
+  const size_t np = rooted ? 2 * n - 2 : 2 * n - 3, nb = np + 1;
+  if (upload(e->in_parent, parent_ids, (size_t)T * np, e->stream)) return 1;
+  if (upload(e->in_bl, bl, (size_t)T * nb, e->stream)) return 1;
+  if (upload(e->in_params, params, (size_t)T * e->param_count, e->stream)) return 1;
+  return 0;
+}
+
+int32_t mi_engine_log_likelihoods_unrooted(mi_engine* e, int32_t T, const int32_t* parent_ids,
+                                           const double* bl, const double* params,
+                                           int32_t rescaling, double* out_ll) {
+  if (!out_ll) return fail("null output");
+  if (stage_common(e, T, false, parent_ids, bl, params)) return 1;
+  if (e->out_ll.ensure(sizeof(double) * T)) return 1;
+  if (mi_engine_log_likelihoods_unrooted_device(e, e->stream, T, e->in_parent.as<int32_t>(),
+                                                e->in_bl.as<double>(),
+                                                e->in_params.as<double>(), rescaling,
+                                                e->out_ll.as<double>()))
+    return 1;
+  if (download(out_ll, e->out_ll, T, e->stream)) return 1;
+  return check_status(e, e->stream);
+}
+
+int32_t mi_engine_gradients_unrooted(mi_engine* e, int32_t T, const int32_t* parent_ids,
+                                     const double* bl, const double* params, int32_t rescaling,
+                                     double* out_ll, double* out_branch, double* out_site,
+                                     double* out_subst) {
+  if (!out_ll || !out_branch) return fail("null output");
+  if (stage_common(e, T, false, parent_ids, bl, params)) return 1;
+  const int N = e->N;
+  if (e->out_ll.ensure(sizeof(double) * T)) return 1;
+  if (e->out_a.ensure(sizeof(double) * (size_t)T * N)) return 1;
+  if (e->out_site.ensure(sizeof(double) * T)) return 1;
+  if (e->out_subst.ensure(sizeof(double) * (size_t)T * 8)) return 1;
+  if (mi_engine_gradients_unrooted_device(
+          e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
+          e->in_params.as<double>(), rescaling, e->out_ll.as<double>(), e->out_a.as<double>(),
+          e->out_site.as<double>(), e->out_subst.as<double>()))
+    return 1;
+  if (download(out_ll, e->out_ll, T, e->stream)) return 1;
+  if (download(out_branch, e->out_a, (size_t)T * N, e->stream)) return 1;
+  if (e->K > 1 && download(out_site, e->out_site, T, e->stream)) return 1;
+  if (e->spec.subst_model == MI_SUBST_GTR &&
+      download(out_subst, e->out_subst, (size_t)T * 8, e->stream))
+    return 1;
+  return check_status(e, e->stream);
+}
+
+int32_t mi_engine_log_likelihoods_rooted(mi_engine* e, int32_t T, const int32_t* parent_ids,
+                                         const double* bl, const double* params,
+                                         const double* rates, const double* heights,
+                                         const double* bounds, int32_t with_jacobian,
+                                         int32_t rescaling, double* out_ll) {
+  if (!out_ll) return fail("null output");
+  if (stage_common(e, T, true, parent_ids, bl, params)) return 1;
+  const int N = e->N;
+  const bool tt = rates && heights && bounds;
+  if (tt) {
+    if (upload(e->in_rates, rates, (size_t)T * (N - 1), e->stream)) return 1;
+    if (upload(e->in_heights, heights, (size_t)T * N, e->stream)) return 1;
+    if (upload(e->in_bounds, bounds, (size_t)T * N, e->stream)) return 1;
+  }
+  if (e->out_ll.ensure(sizeof(double) * T)) return 1;
+  if (mi_engine_log_likelihoods_rooted_device(
+          e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
+          e->in_params.as<double>(), tt ? e->in_rates.as<double>() : nullptr,
+          tt ? e->in_heights.as<double>() : nullptr, tt ? e->in_bounds.as<double>() : nullptr,
+          with_jacobian, rescaling, e->out_ll.as<double>()))
+    return 1;
+  if (download(out_ll, e->out_ll, T, e->stream)) return 1;
+  return check_status(e, e->stream);
+}
+
+int32_t mi_engine_gradients_rooted(mi_engine* e, int32_t T, const int32_t* parent_ids,
+                                   const double* bl, const double* params, const double* rates,
+                                   const int32_t* rate_counts, const double* heights,
+                                   const double* bounds, const double* ratios,
+                                   int32_t rescaling, double* out_ll, double* out_ratios,
+                                   double* out_clock, double* out_site, double* out_subst) {
+  if (!out_ll || !out_ratios || !out_clock) return fail("null output");
+  if (!rates || !rate_counts || !heights || !bounds || !ratios)
+    return fail("Attempted access of a time tree member that requires the time tree to be "
+                "initialized. Have you set dates for your time trees, and initialized the "
+                "time trees?");
+  if (stage_common(e, T, true, parent_ids, bl, params)) return 1;
+  const int n = e->n, N = e->N;
+  for (int t = 0; t < T; t++)
+    if (rate_counts[t] != 1 && rate_counts[t] != N - 1) return fail(status_message(kBadRateCount));
+  if (upload(e->in_rates, rates, (size_t)T * (N - 1), e->stream)) return 1;
+  if (upload(e->in_rate_counts, rate_counts, (size_t)T, e->stream)) return 1;
+  if (upload(e->in_heights, heights, (size_t)T * N, e->stream)) return 1;
+  if (upload(e->in_bounds, bounds, (size_t)T * N, e->stream)) return 1;
+  if (upload(e->in_ratios, ratios, (size_t)T * (n - 1), e->stream)) return 1;
+  if (e->out_ll.ensure(sizeof(double) * T)) return 1;
+  if (e->out_a.ensure(sizeof(double) * (size_t)T * (n - 1))) return 1;
+  if (e->out_b.ensure(sizeof(double) * (size_t)T * (N - 1))) return 1;
+  if (e->out_site.ensure(sizeof(double) * T)) return 1;
+  if (e->out_subst.ensure(sizeof(double) * (size_t)T * 8)) return 1;
+  if (mi_engine_gradients_rooted_device(
+          e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
+          e->in_params.as<double>(), e->in_rates.as<double>(),
+          e->in_rate_counts.as<int32_t>(), e->in_heights.as<double>(),
+          e->in_bounds.as<double>(), e->in_ratios.as<double>(), rescaling,
+          e->out_ll.as<double>(), e->out_a.as<double>(), e->out_b.as<double>(),
+          e->out_site.as<double>(), e->out_subst.as<double>()))
+    return 1;
+  if (download(out_ll, e->out_ll, T, e->stream)) return 1;
+  if (download(out_ratios, e->out_a, (size_t)T * (n - 1), e->stream)) return 1;
+  if (download(out_clock, e->out_b, (size_t)T * (N - 1), e->stream)) return 1;
+  if (e->K > 1 && download(out_site, e->out_site, T, e->stream)) return 1;
+  if (e->spec.subst_model == MI_SUBST_GTR &&
+      download(out_subst, e->out_subst, (size_t)T * 8, e->stream))
+    return 1;
+  return check_status(e, e->stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// Launch interface between the host engine (mi_phylo_engine.cpp) and the HIP
+// kernels (mi_phylo_kernels.hip).  Plain structs of device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mi_phylo_device.h"
+
+namespace miphylo {
+
+// Evaluations ("virtual trees") of one engine call, numbered
+//   [0, T)            main evaluation of tree t with its own model
+//   [T, 17T)          GTR gradient only: 16 finite-difference log-likelihoods
+//                     per tree (fat_beagle.cpp:400-465), eval T + 16 t + (j-1)
+//                     uses model 17 t + j
+//   [17T, 18T)        GTR + K>1 gradient only: site-model pass with the model the
+//                     reference is left in after the finite differences (j = 16)
+struct EvalMap {
+  int T;
+  int models_per_tree;  // 1, or kFdModels for a GTR gradient call
+  __host__ __device__ void decode(int e, int& tree, int& model) const {
+    if (e < T) {
+      tree = e;
+      model = e * models_per_tree;
+    } else if (e < 17 * T) {
+      tree = (e - T) / 16;
+      model = tree * kFdModels + 1 + (e - T) % 16;
+    } else {
+      tree = e - 17 * T;
+      model = tree * kFdModels + 16;
+    }
+  }
+};
+
+struct TreeSetupArgs {
+  int n, T, rooted;
+  const int32_t* parent_ids;  // [T][2n-3] unrooted, [T][2n-2] rooted
+  const double* bl;           // [T][2n-2] unrooted, [T][2n-1] rooted
+  const double* rates;        // [T][2n-2] or nullptr: branch length x rate
+  int32_t* scratch;           // [T][12 N]
+  SchedEntry* sched;          // [T][n-1]
+  double* bl_eff;             // [T][N]
+  int32_t* status;            // [2]: code, tree
+  int max_slots;
+};
+
+struct ModelSetupArgs {
+  int T, models_per_tree;
+  int subst, site, K;
+  int param_count, rates_off, freqs_off, shape_off;
+  const double* params;  // [T][param_count]
+  DevModel* models;      // [T * models_per_tree]
+  int32_t* status;
+};
+
+struct TransitionArgs {
+  int E, N, K;
+  EvalMap map;
+  const DevModel* models;
+  const double* bl_eff;  // [T][N]
+  double* mats;          // [E][N-1][K][16]
+};
+
+struct LikArgs {
+  int n, N, P, K, tiles;
+  int eval_offset;  // first evaluation of this launch
+  int grad_offset;  // gradient-workspace index of that evaluation
+  EvalMap map;
+  const DevModel* models;
+  const SchedEntry* sched;
+  const double* mats;
+  const int8_t* tip_states;    // [n][P]
+  const double* tip_partials;  // [n][P][4] or nullptr
+  const double* weights;       // [P]
+  double* ll_part;             // [E][tiles]
+  double* plv;                 // [Eg][n-1][K][tiles*64][4]   (gradient, v1)
+  double* g_part;              // [Eg][tiles][2][N]
+};
+
+struct FinalizeArgs {
+  int n, N, T, K, tiles;
+  int gradient, rooted, with_jacobian;
+  int gtr, site_fused, site_separate;
+  const double* ll_part;
+  const double* g_part;
+  const double* bl_eff;        // [T][N]
+  const double* bl_raw;        // rooted: [T][N]
+  const double* rates;         // rooted: [T][N-1]
+  const int32_t* rate_counts;  // rooted gradient: [T]
+  const double* node_heights;  // [T][N]
+  const double* node_bounds;   // [T][N]
+  const double* height_ratios; // [T][n-1]
+  const SchedEntry* sched;     // [T][n-1]
+  double* scratch;             // [T][6 n]
+  double* out_ll;              // [T]
+  double* out_branch;          // unrooted gradient: [T][N]
+  double* out_ratios;          // rooted gradient: [T][n-1]
+  double* out_clock;           // rooted gradient: [T][N-1]
+  double* out_site;            // [T] or nullptr
+  double* out_subst;           // [T][8] or nullptr
+  int32_t* status;
+};
+
+void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s);
+void launch_model_setup(const ModelSetupArgs& a, hipStream_t s);
+void launch_transition(const TransitionArgs& a, hipStream_t s);
+// On-chip (LDS-resident) log-likelihood: evaluations [eval_offset, eval_offset+count)
+void launch_loglik(const LikArgs& a, int count, bool rescale, int max_slots, hipStream_t s);
+// Gradient, partial-likelihood vectors streamed through HBM (v1)
+void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t s);
+void launch_finalize(const FinalizeArgs& a, hipStream_t s);
+
+const char* loglik_kernel_name();
+const char* gradient_kernel_name();
+
+}  // namespace miphylo

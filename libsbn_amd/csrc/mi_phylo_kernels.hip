@@ -1,0 +1,898 @@
+// HIP kernels (gfx950 / CDNA4, wave64) for the phylogenetic likelihood and
+// branch-gradient hot path.  See DESIGN.md for the mapping and rooflines.
+//
+// Mapping used by every compute kernel here: one wavefront = one tile of 64 site
+// patterns of one evaluation (tree x model); lane = site pattern.  Site patterns
+// are independent through the whole tree (Felsenstein pruning couples nodes, not
+// sites), so a wave walks the complete tree for its tile without any
+// inter-wave communication.  Transition matrices are wave-uniform and are read
+// with scalar loads into SGPRs; FP64 FMAs take them as scalar operands.
+#include <hip/hip_runtime.h>
+
+#include "mi_phylo_kernels.h"
+
+namespace miphylo {
+
+namespace {
+
+struct D4 {
+  double x0, x1, x2, x3;
+};
+
+__device__ __forceinline__ D4 mul4(D4 a, D4 b) {
+  return {a.x0 * b.x0, a.x1 * b.x1, a.x2 * b.x2, a.x3 * b.x3};
+}
+
+// a_i = sum_j M[i][j] L_j   (M row-major, wave-uniform)
+__device__ __forceinline__ D4 matvec(const double* __restrict__ M, D4 L) {
+  D4 a;
+  a.x0 = M[0] * L.x0 + M[1] * L.x1 + M[2] * L.x2 + M[3] * L.x3;
+  a.x1 = M[4] * L.x0 + M[5] * L.x1 + M[6] * L.x2 + M[7] * L.x3;
+  a.x2 = M[8] * L.x0 + M[9] * L.x1 + M[10] * L.x2 + M[11] * L.x3;
+  a.x3 = M[12] * L.x0 + M[13] * L.x1 + M[14] * L.x2 + M[15] * L.x3;
+  return a;
+}
+
+// q_j = sum_i M[i][j] u_i
+__device__ __forceinline__ D4 matTvec(const double* __restrict__ M, D4 u) {
+  D4 q;
+  q.x0 = M[0] * u.x0 + M[4] * u.x1 + M[8] * u.x2 + M[12] * u.x3;
+  q.x1 = M[1] * u.x0 + M[5] * u.x1 + M[9] * u.x2 + M[13] * u.x3;
+  q.x2 = M[2] * u.x0 + M[6] * u.x1 + M[10] * u.x2 + M[14] * u.x3;
+  q.x3 = M[3] * u.x0 + M[7] * u.x1 + M[11] * u.x2 + M[15] * u.x3;
+  return q;
+}
+
+__device__ __forceinline__ double dot4(D4 a, D4 b) {
+  return a.x0 * b.x0 + a.x1 * b.x1 + a.x2 * b.x2 + a.x3 * b.x3;
+}
+
+// Compact tip state -> partial vector: one-hot, or all ones for a gap
+// (site_pattern.cpp:117-131; BEAGLE treats compact states >= s the same way).
+__device__ __forceinline__ D4 tip_vector(int st) {
+  return {(st == 0 || st > 3) ? 1.0 : 0.0, (st == 1 || st > 3) ? 1.0 : 0.0,
+          (st == 2 || st > 3) ? 1.0 : 0.0, (st == 3 || st > 3) ? 1.0 : 0.0};
+}
+
+// P * tip_vector(st) without arithmetic: column st of P, or 1 (rows of P sum to 1).
+__device__ __forceinline__ D4 tip_column(const double* __restrict__ M, int st) {
+  D4 a;
+  a.x0 = st == 0 ? M[0] : st == 1 ? M[1] : st == 2 ? M[2] : st == 3 ? M[3] : 1.0;
+  a.x1 = st == 0 ? M[4] : st == 1 ? M[5] : st == 2 ? M[6] : st == 3 ? M[7] : 1.0;
+  a.x2 = st == 0 ? M[8] : st == 1 ? M[9] : st == 2 ? M[10] : st == 3 ? M[11] : 1.0;
+  a.x3 = st == 0 ? M[12] : st == 1 ? M[13] : st == 2 ? M[14] : st == 3 ? M[15] : 1.0;
+  return a;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Power-of-two rescaling: exact, so rescaled and unscaled results agree to the
+// last bit wherever the unscaled ones are representable.
+__device__ __forceinline__ int max_exponent(double m) { return m > 0.0 ? ilogb(m) : 0; }
+__device__ __forceinline__ D4 scale4(D4 a, int e) {
+  return {ldexp(a.x0, e), ldexp(a.x1, e), ldexp(a.x2, e), ldexp(a.x3, e)};
+}
+__device__ __forceinline__ double max4(D4 a) {
+  return fmax(fmax(a.x0, a.x1), fmax(a.x2, a.x3));
+}
+
+__device__ __forceinline__ void set_status(int32_t* status, int code, int tree) {
+  if (atomicCAS(status, 0, code) == 0) status[1] = tree;
+}
+
+// ------------------------------------------------------------------------
+// Tree setup: parent-id vector -> evaluation schedule (one thread per tree).
+// Restates node.cpp:32-59 (children ordered by max leaf id),
+// unrooted_tree.cpp:27-37 (Detrifurcate), tree.cpp:72-78 (SlideRootPosition, a
+// no-op on a detrifurcated tree), fat_beagle.cpp:96-101,507-511 (x rates).
+// The schedule lists internal nodes in a post-order chosen by Sethi-Ullman
+// labels so that the on-chip kernel needs at most floor(log2 n)+1 live
+// partial-likelihood vectors; any post-order gives bitwise the same vectors.
+// ------------------------------------------------------------------------
+__global__ void tree_setup_kernel(TreeSetupArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.T) return;
+  const int n = a.n, N = 2 * n - 1;
+  const int nodes_in = a.rooted ? N : N - 1;
+  const int32_t* par = a.parent_ids + (size_t)t * (nodes_in - 1);
+  int32_t* maxleaf = a.scratch + (size_t)t * 12 * N;
+  int32_t* cnt = maxleaf + N;
+  int32_t* kids = cnt + N;  // 3 per node
+  int32_t* c0 = kids + 3 * N;
+  int32_t* c1 = c0 + N;
+  int32_t* label = c1 + N;
+  int32_t* slot = label + N;
+  int32_t* stack = slot + N;  // 2N
+  SchedEntry* sched = a.sched + (size_t)t * (n - 1);
+  double* ble = a.bl_eff + (size_t)t * N;
+
+  for (int v = 0; v < N; v++) {
+    maxleaf[v] = v < n ? v : -1;
+    cnt[v] = 0;
+    label[v] = 0;
+    slot[v] = 0;
+    c0[v] = c1[v] = 0;
+  }
+  bool ok = true;
+  for (int v = 0; v < nodes_in - 1; v++) {
+    const int p = par[v];
+    if (p <= v || p >= nodes_in || p < n) {
+      ok = false;
+      break;
+    }
+    if (maxleaf[v] > maxleaf[p]) maxleaf[p] = maxleaf[v];
+  }
+  if (!ok) {
+    set_status(a.status, kBadParentIds, t);
+    for (int i = 0; i < n - 1; i++) sched[i] = {n + i, 0, 1, 0};
+    for (int v = 0; v < N; v++) ble[v] = 0.0;
+    return;
+  }
+  for (int v = 0; v < nodes_in - 1 && ok; v++) {
+    const int p = par[v];
+    int k = cnt[p];
+    if (k >= 3) {
+      ok = false;
+      break;
+    }
+    while (k > 0 && maxleaf[kids[3 * p + k - 1]] > maxleaf[v]) {
+      kids[3 * p + k] = kids[3 * p + k - 1];
+      k--;
+    }
+    kids[3 * p + k] = v;
+    cnt[p]++;
+  }
+  const int root_in = nodes_in - 1;
+  for (int v = n; v < nodes_in && ok; v++) {
+    const int want = (!a.rooted && v == root_in) ? 3 : 2;
+    if (cnt[v] != want) ok = false;
+  }
+  if (!ok) {
+    set_status(a.status, a.rooted ? kNotBifurcating : kNotTrifurcatingRoot, t);
+    for (int i = 0; i < n - 1; i++) sched[i] = {n + i, 0, 1, 0};
+    for (int v = 0; v < N; v++) ble[v] = 0.0;
+    return;
+  }
+  for (int v = n; v < nodes_in; v++) {
+    c0[v] = kids[3 * v];
+    c1[v] = kids[3 * v + 1];
+  }
+  if (!a.rooted) {
+    // (k0,k1,k2) at root r  ->  r = (k1,k2), r+1 = (k0, r)
+    const int r = root_in;
+    c0[r] = kids[3 * r + 1];
+    c1[r] = kids[3 * r + 2];
+    c0[r + 1] = kids[3 * r];
+    c1[r + 1] = r;
+    const double* bl = a.bl + (size_t)t * (N - 1);
+    for (int v = 0; v < N - 2; v++) ble[v] = bl[v];
+    ble[N - 2] = 0.0;
+    ble[N - 1] = 0.0;
+  } else {
+    const double* bl = a.bl + (size_t)t * N;
+    const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
+    for (int v = 0; v < N - 1; v++) ble[v] = rates ? bl[v] * rates[v] : bl[v];
+    ble[N - 1] = bl[N - 1];
+  }
+  // Sethi-Ullman labels (tips cost nothing: they are read in compact form).
+  for (int v = n; v < N; v++) {
+    const int l0 = label[c0[v]], l1 = label[c1[v]];
+    label[v] = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
+  }
+  // Post-order DFS, heavier child first; slots from a free bitmask.
+  uint32_t free_mask = 0xffffffffu;
+  int top = 0, out = 0;
+  stack[top++] = (N - 1) << 1;
+  int used_max = 0;
+  while (top) {
+    const int item = stack[--top];
+    const int v = item >> 1;
+    if (item & 1) {
+      const int a0 = c0[v], a1 = c1[v];
+      if (a0 >= n) free_mask |= 1u << slot[a0];
+      if (a1 >= n) free_mask |= 1u << slot[a1];
+      const int s = __ffs(free_mask) - 1;
+      free_mask &= ~(1u << s);
+      slot[v] = s;
+      if (s + 1 > used_max) used_max = s + 1;
+      sched[out++] = {v, a0, a1, s | (slot[a0] << 8) | (slot[a1] << 16)};
+    } else {
+      stack[top++] = (v << 1) | 1;
+      const int a0 = c0[v], a1 = c1[v];
+      const bool first0 = label[a0] >= label[a1];
+      const int lo = first0 ? a1 : a0, hi = first0 ? a0 : a1;
+      if (lo >= n) stack[top++] = lo << 1;
+      if (hi >= n) stack[top++] = hi << 1;  // popped first
+    }
+  }
+  if (used_max > a.max_slots) set_status(a.status, kTooManySlots, t);
+}
+
+// ------------------------------------------------------------------------
+// Model setup (one thread per model instance).
+// ------------------------------------------------------------------------
+__device__ void jacobi4(const double* A_in, double* evals, double* U) {
+  double A[16];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) A[i * 4 + j] = i >= j ? A_in[i * 4 + j] : A_in[j * 4 + i];
+  for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        const double x = A[i * 4 + j] * A[i * 4 + j];
+        if (i != j) off += x; else diag += x;
+      }
+    if (off <= 1e-40 * diag || off == 0.) break;
+    for (int p = 0; p < 3; p++)
+      for (int q = p + 1; q < 4; q++) {
+        const double apq = A[p * 4 + q];
+        if (apq == 0.) continue;
+        const double theta = (A[q * 4 + q] - A[p * 4 + p]) / (2. * apq);
+        const double tt = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+        const double c = 1. / sqrt(tt * tt + 1.), sn = tt * c;
+        for (int k = 0; k < 4; k++) {
+          const double akp = A[k * 4 + p], akq = A[k * 4 + q];
+          A[k * 4 + p] = c * akp - sn * akq;
+          A[k * 4 + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < 4; k++) {
+          const double apk = A[p * 4 + k], aqk = A[q * 4 + k];
+          A[p * 4 + k] = c * apk - sn * aqk;
+          A[q * 4 + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < 4; k++) {
+          const double ukp = U[k * 4 + p], ukq = U[k * 4 + q];
+          U[k * 4 + p] = c * ukp - sn * ukq;
+          U[k * 4 + q] = sn * ukp + c * ukq;
+        }
+      }
+  }
+  for (int i = 0; i < 4; i++) evals[i] = A[i * 4 + i];
+  for (int i = 0; i < 3; i++) {
+    int m = i;
+    for (int j = i + 1; j < 4; j++)
+      if (evals[j] < evals[m]) m = j;
+    if (m != i) {
+      const double tmp = evals[i]; evals[i] = evals[m]; evals[m] = tmp;
+      for (int k = 0; k < 4; k++) {
+        const double u = U[k * 4 + i]; U[k * 4 + i] = U[k * 4 + m]; U[k * 4 + m] = u;
+      }
+    }
+  }
+}
+
+// stick_breaking_transform.cpp:20-43
+__device__ void stick_breaking(int K, const double* y, double* x) {
+  double stick = 1.0;
+  for (int k = 0; k < K - 1; k++) {
+    const double z = 1.0 / (1 + exp(-(y[k] - log((double)(K - k - 1)))));
+    x[k] = stick * z;
+    stick -= x[k];
+  }
+  x[K - 1] = stick;
+}
+__device__ void stick_breaking_inverse(int K, const double* x, double* y) {
+  double sum = 0;
+  for (int k = 0; k < K - 1; k++) {
+    const double z = x[k] / (1.0 - sum);
+    y[k] = log(z / (1.0 - z)) + log((double)(K - k - 1));
+    sum += x[k];
+  }
+}
+
+__global__ void model_setup_kernel(ModelSetupArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.T * a.models_per_tree) return;
+  const int t = idx / a.models_per_tree, j = idx % a.models_per_tree;
+  const double* row = a.params + (size_t)t * a.param_count;
+  DevModel& m = a.models[idx];
+  if (a.subst == 0) {
+    // substitution_model.hpp:59-74 (JC69 eigensystem as hard-coded there)
+    const double V[16] = {1.0, 2.0, 0.0, 0.5, 1.0, -2.0, 0.5, 0.0,
+                          1.0, 2.0, 0.0, -0.5, 1.0, -2.0, -0.5, 0.0};
+    const double Vi[16] = {0.25, 0.25, 0.25, 0.25, 0.125, -0.125, 0.125, -0.125,
+                           0.0,  1.0,  0.0,  -1.0, 1.0,   0.0,    -1.0,  0.0};
+    for (int i = 0; i < 4; i++) {
+      m.pi[i] = 0.25;
+      m.lambda[i] = i == 0 ? 0.0 : -1.3333333333333333;
+      for (int k = 0; k < 4; k++) m.Q[i * 4 + k] = i == k ? -1.0 : 1.0 / 3.0;
+    }
+    for (int i = 0; i < 16; i++) {
+      m.V[i] = V[i];
+      m.Vinv[i] = Vi[i];
+    }
+  } else {
+    // substitution_model.cpp:17-80, with the finite-difference perturbation of
+    // fat_beagle.cpp:400-438 applied for j > 0: coordinate c of the
+    // stick-breaking image of (frequencies | rates), sign +/-.
+    double rates[6], freqs[4];
+    for (int i = 0; i < 6; i++) rates[i] = row[a.rates_off + i];
+    for (int i = 0; i < 4; i++) freqs[i] = row[a.freqs_off + i];
+    double fsum = 0, rsum = 0;
+    for (int i = 0; i < 4; i++) fsum += freqs[i];
+    for (int i = 0; i < 6; i++) rsum += rates[i];
+    if (j == 0) {
+      if (fabs(fsum - 1.) >= 0.001) set_status(a.status, kGtrFrequencies, t);
+      if (fabs(rsum - 1.) >= 0.001) set_status(a.status, kGtrRates, t);
+    }
+    if (j > 0) {
+      const int coord = (j - 1) >> 1;
+      const double delta = ((j - 1) & 1) ? -1.e-6 : 1.e-6;
+      double y[5];
+      if (coord < 3) {
+        stick_breaking_inverse(4, freqs, y);
+        y[coord] += delta;
+        stick_breaking(4, y, freqs);
+      } else {
+        stick_breaking_inverse(6, rates, y);
+        y[coord - 3] += delta;
+        stick_breaking(6, y, rates);
+      }
+    }
+    double Q[16];
+    int ri = 0;
+    for (int i = 0; i < 4; i++)
+      for (int k = i + 1; k < 4; k++) {
+        const double r = rates[ri++];
+        Q[i * 4 + k] = r * freqs[k];
+        Q[k * 4 + i] = r * freqs[i];
+      }
+    double total = 0;
+    for (int i = 0; i < 4; i++) {
+      double row_sum = 0;
+      for (int k = 0; k < 4; k++)
+        if (i != k) row_sum += Q[i * 4 + k];
+      Q[i * 4 + i] = -row_sum;
+      total += row_sum * freqs[i];
+    }
+    for (int i = 0; i < 16; i++) Q[i] /= total;
+    double sq[4], S[16], U[16], ev[4];
+    for (int i = 0; i < 4; i++) sq[i] = sqrt(freqs[i]);
+    for (int i = 0; i < 4; i++)
+      for (int k = 0; k < 4; k++) S[i * 4 + k] = sq[i] * Q[i * 4 + k] * (1.0 / sq[k]);
+    jacobi4(S, ev, U);
+    for (int i = 0; i < 4; i++) {
+      m.pi[i] = freqs[i];
+      m.lambda[i] = ev[i];
+      for (int k = 0; k < 4; k++) {
+        m.Q[i * 4 + k] = Q[i * 4 + k];
+        m.V[i * 4 + k] = (1.0 / sq[i]) * U[i * 4 + k];
+        m.Vinv[i * 4 + k] = U[k * 4 + i] * sq[k];
+      }
+    }
+  }
+  if (a.site == 0) {
+    m.cat_rate[0] = 1.0;
+    m.cat_weight[0] = 1.0;
+    m.cat_drate[0] = 0.0;
+  } else {
+    // site_model.cpp:37-62
+    const int K = a.K;
+    const double shape = row[a.shape_off];
+    double mean_rate = 0, mean_deriv = 0;
+    for (int i = 0; i < K; i++) {
+      const double quantile = (2.0 * i + 1.0) / (2.0 * K);
+      const double r = pow(-log(1.0 - quantile), 1.0 / shape);
+      m.cat_rate[i] = r;
+      mean_rate += r;
+      const double du = -r * log(-log(1.0 - quantile)) / (shape * shape);
+      m.cat_drate[i] = du;
+      mean_deriv += du;
+    }
+    mean_rate /= K;
+    mean_deriv /= K;
+    for (int i = 0; i < K; i++) {
+      m.cat_drate[i] =
+          (m.cat_drate[i] * mean_rate - m.cat_rate[i] * mean_deriv) / (mean_rate * mean_rate);
+      m.cat_rate[i] /= mean_rate;
+      m.cat_weight[i] = 1.0 / K;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
+// Transition matrices (beagleUpdateTransitionMatrices, fat_beagle.cpp:304-314):
+// one thread per (evaluation, edge, category).
+// BEAGLE evaluates P = V diag(exp(l r t)) V^-1.  We evaluate the algebraically
+// identical P = I + V diag(expm1(l r t)) V^-1: for small r t the BEAGLE form
+// obtains the O(r t) off-diagonal entries as a difference of O(1) terms and
+// loses ~1e-16/(r t) relative accuracy there (5e-14 relative in logL on the
+// reference's fluA test, which its 2e-6 finite-difference divisor turns into 1e-3
+// of gradient noise); the expm1 form agrees with an 80-bit evaluation to 1e-15.
+// See DESIGN.md "Accuracy".
+// ------------------------------------------------------------------------
+__global__ void transition_kernel(TransitionArgs a) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)a.E * (a.N - 1) * a.K;
+  if (idx >= total) return;
+  const int k = idx % a.K;
+  const int edge = (idx / a.K) % (a.N - 1);
+  const int e = idx / ((long)a.K * (a.N - 1));
+  int t, mi;
+  a.map.decode(e, t, mi);
+  const DevModel& m = a.models[mi];
+  const double bl = a.bl_eff[(size_t)t * a.N + edge];
+  const double rt = m.cat_rate[k] * bl;
+  double ex[4], W[16];
+  for (int x = 0; x < 4; x++) ex[x] = expm1(m.lambda[x] * rt);
+  for (int x = 0; x < 4; x++)
+    for (int j = 0; j < 4; j++) W[x * 4 + j] = ex[x] * m.Vinv[x * 4 + j];
+  double* out = a.mats + idx * 16;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double sum = i == j ? 1.0 : 0.0;
+      for (int x = 0; x < 4; x++) sum += m.V[i * 4 + x] * W[x * 4 + j];
+      out[i * 4 + j] = sum > 0 ? sum : 0;  // BEAGLE clamps negative probabilities to 0
+    }
+}
+
+// ------------------------------------------------------------------------
+// On-chip log-likelihood (B5, B6, B11 of SURVEY.md 2.1).
+// One wave per (evaluation, 64-pattern tile); rate categories are walked one
+// after the other so that only floor(log2 n)+1 partial-likelihood vectors of one
+// category are live, each in a lane-private LDS column (SoA: [slot][state][lane],
+// conflict-free ds_read_b64 / ds_write_b64).  HBM traffic: tip states, the
+// schedule and the transition matrices only.
+// ------------------------------------------------------------------------
+template <bool RESCALE, bool TIP_PARTIALS>
+__global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int e = a.eval_offset + blockIdx.y;
+  int t, mi;
+  a.map.decode(e, t, mi);
+  const DevModel* __restrict__ model = a.models + mi;
+  const SchedEntry* __restrict__ sched = a.sched + (size_t)t * (a.n - 1);
+  const int p = tile * kTile + lane;
+  const int pc = p < a.P ? p : a.P - 1;
+  const double w = p < a.P ? a.weights[pc] : 0.0;
+  const int K = a.K, n = a.n;
+  const double* __restrict__ mats_e = a.mats + (size_t)e * (a.N - 1) * K * 16;
+
+  double site = 0.0;
+  int site_exp = 0;
+  for (int k = 0; k < K; k++) {
+    int cum_exp = 0;
+    D4 L = {0, 0, 0, 0};
+    for (int i = 0; i < n - 1; i++) {
+      const SchedEntry s = sched[i];
+      const double* __restrict__ M0 = mats_e + ((size_t)s.child0 * K + k) * 16;
+      const double* __restrict__ M1 = mats_e + ((size_t)s.child1 * K + k) * 16;
+      D4 A, B;
+      if (s.child0 < n) {
+        if (TIP_PARTIALS) {
+          const double* tp = a.tip_partials + ((size_t)s.child0 * a.P + pc) * 4;
+          A = matvec(M0, D4{tp[0], tp[1], tp[2], tp[3]});
+        } else {
+          A = tip_column(M0, a.tip_states[(size_t)s.child0 * a.P + pc]);
+        }
+      } else {
+        const double* col = lds + ((s.slots >> 8) & 0xff) * 4 * kTile + lane;
+        A = matvec(M0, D4{col[0], col[kTile], col[2 * kTile], col[3 * kTile]});
+      }
+      if (s.child1 < n) {
+        if (TIP_PARTIALS) {
+          const double* tp = a.tip_partials + ((size_t)s.child1 * a.P + pc) * 4;
+          B = matvec(M1, D4{tp[0], tp[1], tp[2], tp[3]});
+        } else {
+          B = tip_column(M1, a.tip_states[(size_t)s.child1 * a.P + pc]);
+        }
+      } else {
+        const double* col = lds + ((s.slots >> 16) & 0xff) * 4 * kTile + lane;
+        B = matvec(M1, D4{col[0], col[kTile], col[2 * kTile], col[3 * kTile]});
+      }
+      L = mul4(A, B);
+      if (RESCALE) {
+        const int ex = max_exponent(max4(L));
+        L = scale4(L, -ex);
+        cum_exp += ex;
+      }
+      double* dst = lds + (s.slots & 0xff) * 4 * kTile + lane;
+      dst[0] = L.x0;
+      dst[kTile] = L.x1;
+      dst[2 * kTile] = L.x2;
+      dst[3 * kTile] = L.x3;
+    }
+    // the last schedule entry is the root
+    const double sk = model->cat_weight[k] * (model->pi[0] * L.x0 + model->pi[1] * L.x1 +
+                                              model->pi[2] * L.x2 + model->pi[3] * L.x3);
+    if (RESCALE) {
+      if (k == 0) {
+        site = sk;
+        site_exp = cum_exp;
+      } else if (cum_exp > site_exp) {
+        site = ldexp(site, site_exp - cum_exp) + sk;
+        site_exp = cum_exp;
+      } else {
+        site += ldexp(sk, cum_exp - site_exp);
+      }
+    } else {
+      site += sk;
+    }
+  }
+  double ll = log(site);
+  if (RESCALE) ll += site_exp * 0.6931471805599453;
+  ll = p < a.P ? w * ll : 0.0;
+  ll = wave_sum(ll);
+  if (lane == 0) a.ll_part[(size_t)e * a.tiles + tile] = ll;
+}
+
+// ------------------------------------------------------------------------
+// Gradient v1 (B4-B11): post-order, pre-order and edge derivatives in one
+// launch, partial-likelihood vectors streamed through HBM in the layout
+// [evaluation][node][category][pattern][state] (32 B per lane, a wave reads or
+// writes 2 KiB contiguous).  Each lane only ever re-reads what it wrote itself,
+// so no inter-wave synchronisation is needed.  The pre-order vector of a node
+// overwrites its post-order vector in place once the latter is dead.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ D4 load4(const double* __restrict__ ptr) {
+  const double2 lo = *reinterpret_cast<const double2*>(ptr);
+  const double2 hi = *reinterpret_cast<const double2*>(ptr + 2);
+  return {lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ void store4(double* ptr, D4 v) {
+  *reinterpret_cast<double2*>(ptr) = double2{v.x0, v.x1};
+  *reinterpret_cast<double2*>(ptr + 2) = double2{v.x2, v.x3};
+}
+
+template <bool RESCALE, bool TIP_PARTIALS>
+__global__ __launch_bounds__(kTile) void gradient_hbm_kernel(LikArgs a) {
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int e = a.eval_offset + blockIdx.y;
+  const int gi = a.grad_offset + blockIdx.y;
+  int t, mi;
+  a.map.decode(e, t, mi);
+  const DevModel* __restrict__ model = a.models + mi;
+  const SchedEntry* __restrict__ sched = a.sched + (size_t)t * (a.n - 1);
+  const int p = tile * kTile + lane;
+  const int pc = p < a.P ? p : a.P - 1;
+  const double w = p < a.P ? a.weights[pc] : 0.0;
+  const int K = a.K, n = a.n, N = a.N;
+  const size_t ppad = (size_t)a.tiles * kTile;
+  const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
+  double* plv_e = a.plv + (size_t)blockIdx.y * (n - 1) * K * ppad * 4 + (size_t)p * 4;
+  double* gout = a.g_part + ((size_t)gi * a.tiles + tile) * 2 * N;
+
+  auto plv_at = [&](int node, int k) { return plv_e + ((size_t)(node - n) * K + k) * ppad * 4; };
+  auto tip_L = [&](int node) {
+    if (TIP_PARTIALS) return load4(a.tip_partials + ((size_t)node * a.P + pc) * 4);
+    return tip_vector(a.tip_states[(size_t)node * a.P + pc]);
+  };
+
+  // ---- post-order ----
+  int cum_exp = 0;
+  double site = 0.0;
+  for (int i = 0; i < n - 1; i++) {
+    const SchedEntry s = sched[i];
+    const bool is_root = i == n - 2;
+    double mx = 0.0;
+    for (int k = 0; k < K; k++) {
+      const double* __restrict__ M0 = mats_e + ((size_t)s.child0 * K + k) * 16;
+      const double* __restrict__ M1 = mats_e + ((size_t)s.child1 * K + k) * 16;
+      const D4 L0 = s.child0 < n ? tip_L(s.child0) : load4(plv_at(s.child0, k));
+      const D4 L1 = s.child1 < n ? tip_L(s.child1) : load4(plv_at(s.child1, k));
+      const D4 L = mul4(matvec(M0, L0), matvec(M1, L1));
+      if (RESCALE) mx = fmax(mx, max4(L));
+      if (is_root && !RESCALE) {
+        site += model->cat_weight[k] * (model->pi[0] * L.x0 + model->pi[1] * L.x1 +
+                                        model->pi[2] * L.x2 + model->pi[3] * L.x3);
+      } else {
+        store4(plv_at(s.node, k), L);
+      }
+    }
+    if (RESCALE) {
+      // common exponent across categories (the ratio in the edge derivative needs it)
+      const int ex = max_exponent(mx);
+      cum_exp += ex;
+      for (int k = 0; k < K; k++) {
+        const D4 L = scale4(load4(plv_at(s.node, k)), -ex);
+        if (is_root)
+          site += model->cat_weight[k] * (model->pi[0] * L.x0 + model->pi[1] * L.x1 +
+                                          model->pi[2] * L.x2 + model->pi[3] * L.x3);
+        else
+          store4(plv_at(s.node, k), L);
+      }
+    }
+  }
+  {
+    double ll = log(site);
+    if (RESCALE) ll += cum_exp * 0.6931471805599453;
+    ll = p < a.P ? w * ll : 0.0;
+    ll = wave_sum(ll);
+    if (lane == 0) a.ll_part[(size_t)e * a.tiles + tile] = ll;
+  }
+
+  // ---- pre-order + edge derivatives, parents before children ----
+  for (int i = n - 2; i >= 0; i--) {
+    const SchedEntry s = sched[i];
+    const bool is_root = i == n - 2;
+    double nb0 = 0, ns0 = 0, den0 = 0, nb1 = 0, ns1 = 0, den1 = 0;
+    double mx0 = 0, mx1 = 0;
+    for (int k = 0; k < K; k++) {
+      const double* __restrict__ M0 = mats_e + ((size_t)s.child0 * K + k) * 16;
+      const double* __restrict__ M1 = mats_e + ((size_t)s.child1 * K + k) * 16;
+      const D4 qv = is_root ? D4{model->pi[0], model->pi[1], model->pi[2], model->pi[3]}
+                            : load4(plv_at(s.node, k));
+      const D4 L0 = s.child0 < n ? tip_L(s.child0) : load4(plv_at(s.child0, k));
+      const D4 L1 = s.child1 < n ? tip_L(s.child1) : load4(plv_at(s.child1, k));
+      const D4 A = matvec(M0, L0), B = matvec(M1, L1);
+      const D4 q0 = matTvec(M0, mul4(qv, B));
+      const D4 q1 = matTvec(M1, mul4(qv, A));
+      const double cw = model->cat_weight[k];
+      const double n0 = cw * dot4(q0, matvec(model->Q, L0));
+      const double n1 = cw * dot4(q1, matvec(model->Q, L1));
+      nb0 += model->cat_rate[k] * n0;
+      ns0 += model->cat_drate[k] * n0;
+      den0 += cw * dot4(q0, L0);
+      nb1 += model->cat_rate[k] * n1;
+      ns1 += model->cat_drate[k] * n1;
+      den1 += cw * dot4(q1, L1);
+      if (s.child0 >= n) {
+        store4(plv_at(s.child0, k), q0);
+        if (RESCALE) mx0 = fmax(mx0, max4(q0));
+      }
+      if (s.child1 >= n) {
+        store4(plv_at(s.child1, k), q1);
+        if (RESCALE) mx1 = fmax(mx1, max4(q1));
+      }
+    }
+    if (RESCALE) {
+      if (s.child0 >= n) {
+        const int ex = max_exponent(mx0);
+        for (int k = 0; k < K; k++)
+          store4(plv_at(s.child0, k), scale4(load4(plv_at(s.child0, k)), -ex));
+      }
+      if (s.child1 >= n) {
+        const int ex = max_exponent(mx1);
+        for (int k = 0; k < K; k++)
+          store4(plv_at(s.child1, k), scale4(load4(plv_at(s.child1, k)), -ex));
+      }
+    }
+    const double gb0 = wave_sum(p < a.P ? w * (nb0 / den0) : 0.0);
+    const double gs0 = wave_sum(p < a.P ? w * (ns0 / den0) : 0.0);
+    const double gb1 = wave_sum(p < a.P ? w * (nb1 / den1) : 0.0);
+    const double gs1 = wave_sum(p < a.P ? w * (ns1 / den1) : 0.0);
+    if (lane == 0) {
+      gout[s.child0] = gb0;
+      gout[N + s.child0] = gs0;
+      gout[s.child1] = gb1;
+      gout[N + s.child1] = gs1;
+    }
+  }
+  if (lane == 0) {
+    gout[N - 1] = 0.0;
+    gout[N + N - 1] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------
+// Finalize (one thread per tree): sum tile partials in a fixed order
+// (deterministic), assemble PhyloGradient, rooted chain rule.
+// ------------------------------------------------------------------------
+__device__ double sum_tiles(const double* part, int tiles) {
+  double s = 0;
+  for (int i = 0; i < tiles; i++) s += part[i];
+  return s;
+}
+
+__device__ double node_partial(int v, int n, const double* h, const double* ratios,
+                               const double* bound) {
+  return (h[v] - bound[v]) / ratios[v - n];
+}
+__device__ double epoch_addition(int v, int c, int n, const double* h, const double* ratios,
+                                 const double* bound, const double* acc) {
+  if (c < n) return 0.0;
+  if (bound[v] == bound[c]) return acc[c - n] * ratios[c - n] / ratios[v - n];
+  return acc[c - n] * ratios[c - n] / (h[v] - bound[c]) * node_partial(v, n, h, ratios, bound);
+}
+
+// rooted_gradient_transforms.cpp:78-130 for one input vector gh -> out (+ root entry)
+__device__ void ratio_transform(int n, const int32_t* c0, const int32_t* c1, const double* h,
+                                const double* ratios, const double* bound, const double* gh,
+                                double* mult, double* out) {
+  const int N = 2 * n - 1, root = N - 1;
+  for (int i = 0; i < n - 1; i++) out[i] = 0;
+  for (int v = n; v < root; v++) {
+    out[v - n] += node_partial(v, n, h, ratios, bound) * gh[v - n];
+    out[v - n] += epoch_addition(v, c0[v - n], n, h, ratios, bound, out);
+    out[v - n] += epoch_addition(v, c1[v - n], n, h, ratios, bound, out);
+  }
+  mult[root - n] = 1.0;
+  for (int v = root; v >= n; v--) {
+    const int a = c0[v - n], b = c1[v - n];
+    if (a >= n) mult[a - n] = ratios[a - n] * mult[v - n];
+    if (b >= n) mult[b - n] = ratios[b - n] * mult[v - n];
+  }
+  double sum = 0;
+  for (int i = 0; i < n - 1; i++) sum += gh[i] * mult[i];
+  out[root - n] = sum;
+}
+
+__global__ void finalize_kernel(FinalizeArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.T) return;
+  const int n = a.n, N = a.N, T = a.T, tiles = a.tiles;
+  const double ll = sum_tiles(a.ll_part + (size_t)t * tiles, tiles);
+
+  // children by node id (the schedule is a permutation of the internal nodes)
+  // kept in scratch as doubles-sized ints is wasteful; use the int view.
+  int32_t* c0 = reinterpret_cast<int32_t*>(a.scratch + (size_t)t * 6 * n);
+  int32_t* c1 = c0 + n;
+  double* work = a.scratch + (size_t)t * 6 * n + n;  // 5n doubles
+  const SchedEntry* sched = a.sched + (size_t)t * (n - 1);
+  for (int i = 0; i < n - 1; i++) {
+    c0[sched[i].node - n] = sched[i].child0;
+    c1[sched[i].node - n] = sched[i].child1;
+  }
+
+  double jac = 0.0;
+  if (a.rooted && (a.with_jacobian || (a.gradient && a.gtr))) {
+    // fat_beagle.cpp:82-94; iteration order of TripleIdPreorderBifurcating
+    // (node.cpp:226-261) reproduced with an explicit stack in `work`.
+    const double* h = a.node_heights + (size_t)t * N;
+    const double* bd = a.node_bounds + (size_t)t * N;
+    int32_t* st = reinterpret_cast<int32_t*>(work);
+    int top = 0;
+    st[top++] = (N - 1) << 1;
+    while (top) {
+      const int item = st[--top];
+      const int v = item >> 1;
+      const int a0 = c0[v - n], a1 = c1[v - n];
+      if (item & 1) {
+        if (a1 >= n) {
+          jac += log(h[v] - bd[a1]);
+          st[top++] = a1 << 1;
+        }
+      } else {
+        st[top++] = (v << 1) | 1;
+        if (a0 >= n) {
+          jac += log(h[v] - bd[a0]);
+          st[top++] = a0 << 1;
+        }
+      }
+    }
+  }
+
+  if (!a.gradient) {
+    a.out_ll[t] = a.with_jacobian ? ll + jac : ll;
+    return;
+  }
+  a.out_ll[t] = ll;
+  const double* ble = a.bl_eff + (size_t)t * N;
+  // branch gradient of the main evaluation, tile partials summed in order
+  double* bg = work;  // N doubles (N < 2n)
+  for (int v = 0; v < N; v++) {
+    double s = 0;
+    for (int i = 0; i < tiles; i++) s += a.g_part[(((size_t)t * tiles + i) * 2) * N + v];
+    bg[v] = s;
+  }
+  if (a.out_site && (a.site_fused || a.site_separate)) {
+    // DiscreteSiteModelGradient fat_beagle.cpp:389-398
+    const size_t gi = a.site_separate ? (size_t)T + t : (size_t)t;
+    double r = 0;
+    for (int v = 0; v < N - 1; v++) {
+      double s = 0;
+      for (int i = 0; i < tiles; i++) s += a.g_part[((gi * tiles + i) * 2 + 1) * N + v];
+      r += s * ble[v];
+    }
+    a.out_site[t] = r;
+  }
+  if (a.gtr && a.out_subst) {
+    // fat_beagle.cpp:431,455-464: rates (5) then frequencies (3)
+    for (int i = 0; i < 8; i++) {
+      const int coord = i < 5 ? 3 + i : i - 5;
+      const size_t ep = (size_t)T + (size_t)t * 16 + 2 * coord;
+      double lp = sum_tiles(a.ll_part + ep * tiles, tiles);
+      double lm = sum_tiles(a.ll_part + (ep + 1) * tiles, tiles);
+      if (a.rooted) {
+        lp += jac;
+        lm += jac;
+      }
+      a.out_subst[(size_t)t * 8 + i] = (lp - lm) / (2. * 1.e-6);
+    }
+  }
+  if (!a.rooted) {
+    double* ob = a.out_branch + (size_t)t * N;
+    for (int v = 0; v < N; v++) ob[v] = bg[v];
+    ob[N - 2] = 0.0;  // fixed node = second child of the root (fat_beagle.cpp:499)
+    ob[N - 1] = 0.0;
+    return;
+  }
+  // ---- rooted: clock + ratios/root-height gradients ----
+  const double* tb = a.bl_raw + (size_t)t * N;
+  const double* rates = a.rates + (size_t)t * (N - 1);
+  double* oc = a.out_clock + (size_t)t * (N - 1);
+  const int rc = a.rate_counts[t];
+  if (rc == 1) {
+    double acc = 0;
+    for (int v = 0; v < N - 1; v++) acc += bg[v] * tb[v];
+    for (int v = 0; v < N - 1; v++) oc[v] = 0;
+    oc[0] = acc;
+  } else if (rc == N - 1) {
+    for (int v = 0; v < N - 1; v++) oc[v] = bg[v] * tb[v];
+  } else {
+    set_status(a.status, kBadRateCount, t);
+    for (int v = 0; v < N - 1; v++) oc[v] = 0;
+  }
+  const double* h = a.node_heights + (size_t)t * N;
+  const double* bd = a.node_bounds + (size_t)t * N;
+  const double* ratios = a.height_ratios + (size_t)t * (n - 1);
+  double* hg = work + 2 * n;       // n-1
+  double* aux = work + 3 * n;      // n-1 (log_time, then multipliers)
+  double* jacg = work + 4 * n;     // n-1
+  double* outr = a.out_ratios + (size_t)t * (n - 1);
+  // HeightGradient rooted_gradient_transforms.cpp:17-37
+  for (int v = N - 1; v >= n; v--) {
+    double x = v != N - 1 ? -bg[v] * rates[v] : 0.0;
+    x += bg[c0[v - n]] * rates[c0[v - n]];
+    x += bg[c1[v - n]] * rates[c1[v - n]];
+    hg[v - n] = x;
+  }
+  // work[0..2n) (bg) is dead from here on except nothing below reads it; use
+  // work[0..n) as the multiplier array.
+  double* mult = work;
+  ratio_transform(n, c0, c1, h, ratios, bd, hg, mult, outr);
+  for (int i = 0; i < n - 1; i++) aux[i] = 0;
+  for (int i = 0; i < n - 2; i++) aux[i] = 1.0 / (h[n + i] - bd[n + i]);
+  ratio_transform(n, c0, c1, h, ratios, bd, aux, mult, jacg);
+  for (int i = 0; i < n - 2; i++) outr[i] += jacg[i] - 1.0 / ratios[i];
+  outr[n - 2] += jacg[n - 2];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------
+// Launch wrappers
+// ------------------------------------------------------------------------
+void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(tree_setup_kernel, dim3((a.T + 63) / 64), dim3(64), 0, s, a);
+}
+void launch_model_setup(const ModelSetupArgs& a, hipStream_t s) {
+  const int total = a.T * a.models_per_tree;
+  hipLaunchKernelGGL(model_setup_kernel, dim3((total + 63) / 64), dim3(64), 0, s, a);
+}
+void launch_transition(const TransitionArgs& a, hipStream_t s) {
+  const long total = (long)a.E * (a.N - 1) * a.K;
+  hipLaunchKernelGGL(transition_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                     a);
+}
+void launch_loglik(const LikArgs& a, int count, bool rescale, int max_slots, hipStream_t s) {
+  if (count <= 0) return;
+  const dim3 grid(a.tiles, count), block(kTile);
+  const size_t lds = (size_t)max_slots * 4 * kTile * sizeof(double);
+  const bool tp = a.tip_partials != nullptr;
+  if (rescale) {
+    if (tp) hipLaunchKernelGGL((loglik_onchip_kernel<true, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((loglik_onchip_kernel<true, false>), grid, block, lds, s, a);
+  } else {
+    if (tp) hipLaunchKernelGGL((loglik_onchip_kernel<false, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((loglik_onchip_kernel<false, false>), grid, block, lds, s, a);
+  }
+}
+void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t s) {
+  if (count <= 0) return;
+  const dim3 grid(a.tiles, count), block(kTile);
+  const bool tp = a.tip_partials != nullptr;
+  if (rescale) {
+    if (tp) hipLaunchKernelGGL((gradient_hbm_kernel<true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gradient_hbm_kernel<true, false>), grid, block, 0, s, a);
+  } else {
+    if (tp) hipLaunchKernelGGL((gradient_hbm_kernel<false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gradient_hbm_kernel<false, false>), grid, block, 0, s, a);
+  }
+}
+void launch_finalize(const FinalizeArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(finalize_kernel, dim3((a.T + 63) / 64), dim3(64), 0, s, a);
+}
+
+const char* loglik_kernel_name() { return "loglik_onchip_kernel"; }
+const char* gradient_kernel_name() { return "gradient_hbm_kernel"; }
+
+}  // namespace miphylo

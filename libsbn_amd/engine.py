@@ -1,0 +1,229 @@
+"""Python mirror of libsbn's Engine (src/engine.hpp:26-54) on top of the C ABI.
+
+Names follow the reference: PhyloModelSpecification(substitution, site, clock),
+Engine.log_likelihoods / gradients return what Engine::LogLikelihoods /
+Engine::Gradients return (a vector of doubles / one PhyloGradient per tree with
+the gradient map keys "branch_lengths", "site_model", "substitution_model",
+"ratios_root_height", "clock_model").  Errors surface as RuntimeError, as
+pybind11 does for the reference's Failwith (src/sugar.hpp:67-78).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+
+SUBST = {"JC69": 0, "GTR": 1}
+CLOCK = {"none": 0, "strict": 1}
+
+
+@dataclass
+class PhyloModelSpecification:
+    """src/phylo_model.hpp:13-17."""
+    substitution: str = "JC69"
+    site: str = "constant"
+    clock: str = "strict"
+
+
+@dataclass
+class PhyloGradient:
+    """src/tree_gradient.hpp:10-19."""
+    log_likelihood: float
+    gradient: dict
+
+
+def _parse_site(site):
+    # src/site_model.cpp:10-25
+    if site == "constant":
+        return 0, 1
+    if site.startswith("weibull"):
+        idx = site.find("+")
+        return 1, (int(site[idx + 1:]) if idx >= 0 else 4)
+    raise RuntimeError("Site model not known: " + site)
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Engine:
+    """One MI355X engine: tips + pattern weights resident in HBM."""
+
+    def __init__(self, model_specification, patterns, weights, use_tip_states=True,
+                 device=-1, thread_count=1):
+        if thread_count == 0:  # src/engine.cpp:14-16
+            raise RuntimeError("Thread count needs to be strictly positive.")
+        self._lib = _capi.load()
+        self._h = None
+        if model_specification.substitution not in SUBST:
+            raise RuntimeError("Substitution model not known: " +
+                               model_specification.substitution)
+        if model_specification.clock not in CLOCK:
+            raise RuntimeError("Clock model not known: " + model_specification.clock)
+        site_kind, K = _parse_site(model_specification.site)
+        patterns = _np(patterns, np.int32)
+        weights = _np(weights, np.float64)
+        n, P = patterns.shape
+        if weights.shape != (P,):
+            raise RuntimeError("pattern weights must have one entry per site pattern")
+        self.taxon_count, self.pattern_count, self.category_count = n, P, K
+        self.node_count = 2 * n - 1
+        self.spec = _capi.EngineSpec(n, P, 4, K, SUBST[model_specification.substitution],
+                                     site_kind, CLOCK[model_specification.clock],
+                                     1 if use_tip_states else 0, device, 0)
+        h = C.c_void_p()
+        rc = self._lib.mi_engine_create(C.byref(self.spec), _ptr(patterns), None, _ptr(weights),
+                                        C.byref(h))
+        self._check(rc)
+        self._h = h
+        self.param_count = self._lib.mi_engine_param_count(h)
+        self.is_gtr = model_specification.substitution == "GTR"
+
+    def close(self):
+        if self._h is not None:
+            self._lib.mi_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(_capi.last_error())
+
+    # Engine::GetPhyloModelBlockSpecification (src/engine.cpp:48-52)
+    def block_specification(self):
+        out = {}
+        for i in range(self._lib.mi_engine_block_count(self._h)):
+            name, start, length = C.c_char_p(), C.c_int32(), C.c_int32()
+            self._check(self._lib.mi_engine_block(self._h, i, C.byref(name), C.byref(start),
+                                                  C.byref(length)))
+            out[name.value.decode()] = (start.value, length.value)
+        return out
+
+    def _params(self, params, T):
+        pr = _np(params if params is not None else np.zeros((T, self.param_count)), np.float64)
+        if pr.ndim == 1 and self.param_count:
+            pr = pr.reshape(-1, self.param_count) if pr.size % self.param_count == 0 else pr
+        if self.param_count == 0:
+            pr = np.zeros((T, 0))
+        if pr.shape != (T, self.param_count):
+            # fat_beagle.hpp:138 / block_specification.cpp:72-81
+            raise RuntimeError("We param_matrix needs as many rows as we have trees "
+                               f"and {self.param_count} columns; got {pr.shape}.")
+        return np.ascontiguousarray(pr)
+
+    # ---- host-pointer path (numpy in, numpy out) -------------------------------
+    def log_likelihoods(self, parent_ids, branch_lengths, params=None, rescaling=False):
+        """Engine::LogLikelihoods(const UnrootedTreeCollection&, ...)."""
+        n = self.taxon_count
+        pid = _np(parent_ids, np.int32).reshape(-1, 2 * n - 3)
+        T = pid.shape[0]
+        bl = _np(branch_lengths, np.float64).reshape(T, 2 * n - 2)
+        pr = self._params(params, T)
+        out = np.empty(T)
+        self._check(self._lib.mi_engine_log_likelihoods_unrooted(
+            self._h, T, _ptr(pid), _ptr(bl), _ptr(pr), int(rescaling), _ptr(out)))
+        return out
+
+    def gradients(self, parent_ids, branch_lengths, params=None, rescaling=False):
+        """Engine::Gradients(const UnrootedTreeCollection&, ...) -> [PhyloGradient]."""
+        n, N = self.taxon_count, self.node_count
+        pid = _np(parent_ids, np.int32).reshape(-1, 2 * n - 3)
+        T = pid.shape[0]
+        bl = _np(branch_lengths, np.float64).reshape(T, 2 * n - 2)
+        pr = self._params(params, T)
+        ll, g = np.empty(T), np.empty((T, N))
+        site, subst = np.empty(T), np.empty((T, 8))
+        self._check(self._lib.mi_engine_gradients_unrooted(
+            self._h, T, _ptr(pid), _ptr(bl), _ptr(pr), int(rescaling), _ptr(ll), _ptr(g),
+            _ptr(site), _ptr(subst)))
+        out = []
+        for t in range(T):
+            gm = {"branch_lengths": g[t].copy()}
+            if self.category_count > 1:
+                gm["site_model"] = site[t:t + 1].copy()
+            if self.is_gtr:
+                gm["substitution_model"] = subst[t].copy()
+            out.append(PhyloGradient(float(ll[t]), gm))
+        return out
+
+    def rooted_log_likelihoods(self, parent_ids, branch_lengths, params=None, rates=None,
+                               node_heights=None, node_bounds=None, rescaling=False,
+                               with_jacobian=True):
+        """Engine::LogLikelihoods(const RootedTreeCollection&) (with_jacobian=True) or
+        Engine::UnrootedLogLikelihoods(const RootedTreeCollection&) (False)."""
+        n, N = self.taxon_count, self.node_count
+        pid = _np(parent_ids, np.int32).reshape(-1, N - 1)
+        T = pid.shape[0]
+        bl = _np(branch_lengths, np.float64).reshape(T, N)
+        pr = self._params(params, T)
+        r = None if rates is None else _np(rates, np.float64).reshape(T, N - 1)
+        h = None if node_heights is None else _np(node_heights, np.float64).reshape(T, N)
+        b = None if node_bounds is None else _np(node_bounds, np.float64).reshape(T, N)
+        out = np.empty(T)
+        self._check(self._lib.mi_engine_log_likelihoods_rooted(
+            self._h, T, _ptr(pid), _ptr(bl), _ptr(pr), _ptr(r), _ptr(h), _ptr(b),
+            int(with_jacobian), int(rescaling), _ptr(out)))
+        return out
+
+    def rooted_gradients(self, parent_ids, branch_lengths, params, rates, rate_counts,
+                         node_heights, node_bounds, height_ratios, rescaling=False):
+        """Engine::Gradients(const RootedTreeCollection&, ...) -> [PhyloGradient]."""
+        n, N = self.taxon_count, self.node_count
+        pid = _np(parent_ids, np.int32).reshape(-1, N - 1)
+        T = pid.shape[0]
+        bl = _np(branch_lengths, np.float64).reshape(T, N)
+        pr = self._params(params, T)
+        r = _np(rates, np.float64).reshape(T, N - 1)
+        rc = _np(rate_counts, np.int32).reshape(T)
+        h = _np(node_heights, np.float64).reshape(T, N)
+        b = _np(node_bounds, np.float64).reshape(T, N)
+        ra = _np(height_ratios, np.float64).reshape(T, n - 1)
+        ll, gr, gc = np.empty(T), np.empty((T, n - 1)), np.empty((T, N - 1))
+        site, subst = np.empty(T), np.empty((T, 8))
+        self._check(self._lib.mi_engine_gradients_rooted(
+            self._h, T, _ptr(pid), _ptr(bl), _ptr(pr), _ptr(r), _ptr(rc), _ptr(h), _ptr(b),
+            _ptr(ra), int(rescaling), _ptr(ll), _ptr(gr), _ptr(gc), _ptr(site), _ptr(subst)))
+        out = []
+        for t in range(T):
+            gm = {"ratios_root_height": gr[t].copy(),
+                  "clock_model": gc[t, :1].copy() if rc[t] == 1 else gc[t].copy()}
+            if self.category_count > 1:
+                gm["site_model"] = site[t:t + 1].copy()
+            if self.is_gtr:
+                gm["substitution_model"] = subst[t].copy()
+            out.append(PhyloGradient(float(ll[t]), gm))
+        return out
+
+    # ---- device-pointer path (raw pointers, e.g. torch tensors' data_ptr()) ------
+    def reserve(self, tree_count, for_gradients):
+        self._check(self._lib.mi_engine_reserve(self._h, tree_count, int(for_gradients)))
+
+    def log_likelihoods_device(self, stream, T, parent_ids, branch_lengths, params, out_ll,
+                               rescaling=False):
+        self._check(self._lib.mi_engine_log_likelihoods_unrooted_device(
+            self._h, stream, T, parent_ids, branch_lengths, params, int(rescaling), out_ll))
+
+    def gradients_device(self, stream, T, parent_ids, branch_lengths, params, out_ll,
+                         out_branch, out_site=None, out_subst=None, rescaling=False):
+        self._check(self._lib.mi_engine_gradients_unrooted_device(
+            self._h, stream, T, parent_ids, branch_lengths, params, int(rescaling), out_ll,
+            out_branch, out_site, out_subst))
+
+    def check_status(self, stream=None):
+        self._check(self._lib.mi_engine_check_status(self._h, stream))
+
+    def last_call_info(self):
+        name, ev, gev = C.c_char_p(), C.c_int64(), C.c_int64()
+        self._check(self._lib.mi_engine_last_call_info(self._h, C.byref(name), C.byref(ev),
+                                                       C.byref(gev)))
+        return name.value.decode(), ev.value, gev.value

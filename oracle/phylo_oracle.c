@@ -19,6 +19,37 @@
 #include <omp.h>
 #endif
 
+/* Internal arithmetic type.  The default build (liboracle.so) is FP64 like the
+ * reference; `make liboracle_ld.so` (-DORC_LONG_DOUBLE) runs the identical code in
+ * x87 80-bit long double (64-bit mantissa) as the extended-precision check that
+ * backs the 1e-10 parity claim.  The C API stays double in both builds. */
+#ifdef ORC_LONG_DOUBLE
+typedef long double real;
+#define R_EXP expl
+#define R_LOG logl
+#define R_POW powl
+#define R_SQRT sqrtl
+#define R_FABS fabsl
+#define R_EXPM1 expm1l
+#else
+typedef double real;
+#define R_EXP exp
+#define R_LOG log
+#define R_POW pow
+#define R_SQRT sqrt
+#define R_FABS fabs
+#define R_EXPM1 expm1
+#endif
+
+/* Transition-matrix formula: 0 = P = V diag(exp(l r t)) V^-1 exactly as BEAGLE
+ * evaluates it (default, the reference's behaviour); 1 = I + V diag(expm1(l r t))
+ * V^-1, algebraically identical but free of the cancellation that costs the
+ * BEAGLE form ~1e-16/(r t) relative accuracy in the off-diagonal entries when
+ * r t is small.  Mode 1 is what the HIP engine uses; tests use it to bound the
+ * noise floor of mode 0 (see DESIGN.md "Accuracy"). */
+static int g_transition_mode = 0;
+void orc_set_transition_mode(int mode) { g_transition_mode = mode; }
+
 static _Thread_local char g_err[512];
 const char* orc_last_error(void) { return g_err; }
 static int fail(const char* msg) {
@@ -315,11 +346,26 @@ int orc_param_count(const orc_spec_t* spec) {
   return count;
 }
 
+/* internal model, in the working precision */
+typedef struct {
+  int s, K;
+  real pi[ORC_MAX_STATES];
+  real Q[ORC_MAX_STATES * ORC_MAX_STATES];
+  real V[ORC_MAX_STATES * ORC_MAX_STATES];
+  real Vinv[ORC_MAX_STATES * ORC_MAX_STATES];
+  real lambda[ORC_MAX_STATES];
+  real gtr_rates[ORC_MAX_STATES * (ORC_MAX_STATES - 1) / 2];
+  int n_gtr_rates;
+  real cat_rates[ORC_MAX_CATEGORIES];
+  real cat_weights[ORC_MAX_CATEGORIES];
+  real cat_rate_derivs[ORC_MAX_CATEGORIES];
+} model_t;
+
 /* stick_breaking_transform.cpp:20-32 */
-void orc_stick_breaking(int K, const double* y, double* x) {
-  double stick = 1.0;
+static void sb_forward(int K, const real* y, real* x) {
+  real stick = 1.0;
   for (int k = 0; k < K - 1; k++) {
-    double z = 1.0 / (1 + exp(-(y[k] - log((double)(K - k - 1)))));
+    real z = 1.0 / (1 + R_EXP(-(y[k] - R_LOG((real)(K - k - 1)))));
     x[k] = stick * z;
     stick -= x[k];
   }
@@ -327,23 +373,37 @@ void orc_stick_breaking(int K, const double* y, double* x) {
 }
 
 /* stick_breaking_transform.cpp:34-43 */
-void orc_stick_breaking_inverse(int K, const double* x, double* y) {
-  double sum = 0;
+static void sb_inverse(int K, const real* x, real* y) {
+  real sum = 0;
   for (int k = 0; k < K - 1; k++) {
-    double z = x[k] / (1.0 - sum);
-    y[k] = log(z / (1.0 - z)) + log((double)(K - k - 1));
+    real z = x[k] / (1.0 - sum);
+    y[k] = R_LOG(z / (1.0 - z)) + R_LOG((real)(K - k - 1));
     sum += x[k];
   }
 }
 
+void orc_stick_breaking(int K, const double* y, double* x) {
+  real yy[ORC_MAX_STATES * ORC_MAX_STATES], xx[ORC_MAX_STATES * ORC_MAX_STATES];
+  for (int i = 0; i < K - 1; i++) yy[i] = y[i];
+  sb_forward(K, yy, xx);
+  for (int i = 0; i < K; i++) x[i] = (double)xx[i];
+}
+
+void orc_stick_breaking_inverse(int K, const double* x, double* y) {
+  real yy[ORC_MAX_STATES * ORC_MAX_STATES], xx[ORC_MAX_STATES * ORC_MAX_STATES];
+  for (int i = 0; i < K; i++) xx[i] = x[i];
+  sb_inverse(K, xx, yy);
+  for (int i = 0; i < K - 1; i++) y[i] = (double)yy[i];
+}
+
 /* site_model.cpp:37-62 */
-void orc_weibull_rates(int K, double shape, double* rates, double* weights, double* derivs) {
-  double mean_rate = 0, mean_deriv = 0, du[ORC_MAX_CATEGORIES];
+static void weibull(int K, real shape, real* rates, real* weights, real* derivs) {
+  real mean_rate = 0, mean_deriv = 0, du[ORC_MAX_CATEGORIES];
   for (int i = 0; i < K; i++) {
-    double quantile = (2.0 * i + 1.0) / (2.0 * K);
-    rates[i] = pow(-log(1.0 - quantile), 1.0 / shape);
+    real quantile = (2.0 * i + 1.0) / (2.0 * K);
+    rates[i] = R_POW(-R_LOG(1.0 - quantile), 1.0 / shape);
     mean_rate += rates[i];
-    du[i] = -rates[i] * log(-log(1.0 - quantile)) / (shape * shape);
+    du[i] = -rates[i] * R_LOG(-R_LOG(1.0 - quantile)) / (shape * shape);
     mean_deriv += du[i];
   }
   mean_rate /= K;
@@ -351,7 +411,17 @@ void orc_weibull_rates(int K, double shape, double* rates, double* weights, doub
   for (int i = 0; i < K; i++) {
     derivs[i] = (du[i] * mean_rate - rates[i] * mean_deriv) / (mean_rate * mean_rate);
     rates[i] /= mean_rate;
-    weights[i] = 1.0 / K;
+    weights[i] = (real)1.0 / K;
+  }
+}
+
+void orc_weibull_rates(int K, double shape, double* rates, double* weights, double* derivs) {
+  real r[ORC_MAX_CATEGORIES], w[ORC_MAX_CATEGORIES], d[ORC_MAX_CATEGORIES];
+  weibull(K, shape, r, w, d);
+  for (int i = 0; i < K; i++) {
+    rates[i] = (double)r[i];
+    weights[i] = (double)w[i];
+    derivs[i] = (double)d[i];
   }
 }
 
@@ -361,39 +431,39 @@ void orc_weibull_rates(int K, double shape, double* rates, double* weights, doub
  * submodule in the reference (lib/eigen), so this is an independent solver: the
  * decomposition is unique only up to sign/rotation inside eigenspaces, and
  * P(t) = V exp(Lt) V^-1 does not depend on that choice. */
-static void jacobi_eigh(int s, const double* A_in, double* evals, double* U) {
-  double A[ORC_MAX_STATES * ORC_MAX_STATES];
+static void jacobi_eigh(int s, const real* A_in, real* evals, real* U) {
+  real A[ORC_MAX_STATES * ORC_MAX_STATES];
   for (int i = 0; i < s; i++)
     for (int j = 0; j < s; j++) A[i * s + j] = i >= j ? A_in[i * s + j] : A_in[j * s + i];
   for (int i = 0; i < s; i++)
     for (int j = 0; j < s; j++) U[i * s + j] = i == j;
   for (int sweep = 0; sweep < 100; sweep++) {
-    double off = 0, diag = 0;
+    real off = 0, diag = 0;
     for (int i = 0; i < s; i++)
       for (int j = 0; j < s; j++) {
         if (i != j) off += A[i * s + j] * A[i * s + j];
         else diag += A[i * s + j] * A[i * s + j];
       }
-    if (off <= 1e-40 * diag || off == 0.) break;
+    if (off <= 1e-45 * diag || off == 0.) break;
     for (int p = 0; p < s - 1; p++)
       for (int q = p + 1; q < s; q++) {
-        double apq = A[p * s + q];
+        real apq = A[p * s + q];
         if (apq == 0.) continue;
-        double theta = (A[q * s + q] - A[p * s + p]) / (2. * apq);
-        double t = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
-        double c = 1. / sqrt(t * t + 1.), sn = t * c;
+        real theta = (A[q * s + q] - A[p * s + p]) / (2. * apq);
+        real t = (theta >= 0 ? 1. : -1.) / (R_FABS(theta) + R_SQRT(theta * theta + 1.));
+        real c = 1. / R_SQRT(t * t + 1.), sn = t * c;
         for (int k = 0; k < s; k++) {
-          double akp = A[k * s + p], akq = A[k * s + q];
+          real akp = A[k * s + p], akq = A[k * s + q];
           A[k * s + p] = c * akp - sn * akq;
           A[k * s + q] = sn * akp + c * akq;
         }
         for (int k = 0; k < s; k++) {
-          double apk = A[p * s + k], aqk = A[q * s + k];
+          real apk = A[p * s + k], aqk = A[q * s + k];
           A[p * s + k] = c * apk - sn * aqk;
           A[q * s + k] = sn * apk + c * aqk;
         }
         for (int k = 0; k < s; k++) {
-          double ukp = U[k * s + p], ukq = U[k * s + q];
+          real ukp = U[k * s + p], ukq = U[k * s + q];
           U[k * s + p] = c * ukp - sn * ukq;
           U[k * s + q] = sn * ukp + c * ukq;
         }
@@ -406,9 +476,9 @@ static void jacobi_eigh(int s, const double* A_in, double* evals, double* U) {
     for (int j = i + 1; j < s; j++)
       if (evals[j] < evals[m]) m = j;
     if (m != i) {
-      double t = evals[i]; evals[i] = evals[m]; evals[m] = t;
+      real t = evals[i]; evals[i] = evals[m]; evals[m] = t;
       for (int k = 0; k < s; k++) {
-        double u = U[k * s + i]; U[k * s + i] = U[k * s + m]; U[k * s + m] = u;
+        real u = U[k * s + i]; U[k * s + i] = U[k * s + m]; U[k * s + m] = u;
       }
     }
   }
@@ -416,28 +486,28 @@ static void jacobi_eigh(int s, const double* A_in, double* evals, double* U) {
 
 /* substitution_model.cpp:39-80 (UpdateQMatrix + Update), generalised from 4 to
  * s states (rate order = upper triangle row by row: AC,AG,AT,CG,CT,GT). */
-static void gtr_update(orc_model_t* m) {
+static void gtr_update(model_t* m) {
   int s = m->s;
-  double* Q = m->Q;
+  real* Q = m->Q;
   int ri = 0;
   for (int i = 0; i < s; i++)
     for (int j = i + 1; j < s; j++) {
-      double rate = m->gtr_rates[ri++];
+      real rate = m->gtr_rates[ri++];
       Q[i * s + j] = rate * m->pi[j];
       Q[j * s + i] = rate * m->pi[i];
     }
-  double total = 0;
+  real total = 0;
   for (int i = 0; i < s; i++) {
-    double row_sum = 0;
+    real row_sum = 0;
     for (int j = 0; j < s; j++)
       if (i != j) row_sum += Q[i * s + j];
     Q[i * s + i] = -row_sum;
     total += row_sum * m->pi[i];
   }
   for (int i = 0; i < s * s; i++) Q[i] /= total;
-  double sq[ORC_MAX_STATES], S[ORC_MAX_STATES * ORC_MAX_STATES],
+  real sq[ORC_MAX_STATES], S[ORC_MAX_STATES * ORC_MAX_STATES],
       U[ORC_MAX_STATES * ORC_MAX_STATES];
-  for (int i = 0; i < s; i++) sq[i] = sqrt(m->pi[i]);
+  for (int i = 0; i < s; i++) sq[i] = R_SQRT(m->pi[i]);
   for (int i = 0; i < s; i++)
     for (int j = 0; j < s; j++) S[i * s + j] = sq[i] * Q[i * s + j] * (1.0 / sq[j]);
   jacobi_eigh(s, S, m->lambda, U);
@@ -449,11 +519,12 @@ static void gtr_update(orc_model_t* m) {
 }
 
 /* substitution_model.hpp:59-74: the hard-coded JC69 eigensystem. */
-static void jc69_set(orc_model_t* m) {
+static void jc69_set(model_t* m) {
   static const double V[16] = {1.0, 2.0, 0.0, 0.5, 1.0, -2.0, 0.5, 0.0,
                                1.0, 2.0, 0.0, -0.5, 1.0, -2.0, -0.5, 0.0};
   static const double Vi[16] = {0.25, 0.25, 0.25, 0.25, 0.125, -0.125, 0.125, -0.125,
                                 0.0,  1.0,  0.0,  -1.0, 1.0,   0.0,    -1.0,  0.0};
+  /* the reference writes the literal -1.3333333333333333 (a double) */
   static const double ev[4] = {0.0, -1.3333333333333333, -1.3333333333333333,
                                -1.3333333333333333};
   for (int i = 0; i < 4; i++) {
@@ -461,15 +532,17 @@ static void jc69_set(orc_model_t* m) {
     m->lambda[i] = ev[i];
     for (int j = 0; j < 4; j++) m->Q[i * 4 + j] = i == j ? -1.0 : 1.0 / 3.0;
   }
-  memcpy(m->V, V, sizeof V);
-  memcpy(m->Vinv, Vi, sizeof Vi);
+  for (int i = 0; i < 16; i++) {
+    m->V[i] = V[i];
+    m->Vinv[i] = Vi[i];
+  }
   m->n_gtr_rates = 0;
 }
 
 /* phylo_model.cpp:26-31 -> substitution_model.cpp:17-37, site_model.cpp:27-32.
  * The clock block is parsed but never used by the likelihood
  * (fat_beagle.cpp:296-300, "Issue #146"). */
-int orc_model_set(const orc_spec_t* spec, const double* params, orc_model_t* m) {
+static int model_set(const orc_spec_t* spec, const real* params, model_t* m) {
   int ro, fo, so, co, s = spec->state_count, K = spec->category_count;
   if (s > ORC_MAX_STATES || K > ORC_MAX_CATEGORIES) return fail("too many states/categories");
   orc_param_layout(spec, &ro, &fo, &so, &co);
@@ -480,12 +553,12 @@ int orc_model_set(const orc_spec_t* spec, const double* params, orc_model_t* m) 
     jc69_set(m);
   } else if (spec->subst_model == ORC_SUBST_GTR) {
     int nr = s * (s - 1) / 2;
-    double fsum = 0, rsum = 0;
+    real fsum = 0, rsum = 0;
     m->n_gtr_rates = nr;
     for (int i = 0; i < nr; i++) rsum += (m->gtr_rates[i] = params[ro + i]);
     for (int i = 0; i < s; i++) fsum += (m->pi[i] = params[fo + i]);
-    if (fabs(fsum - 1.) >= 0.001) return fail("GTR frequencies do not sum to 1 +/- 0.001!");
-    if (fabs(rsum - 1.) >= 0.001) return fail("GTR rates do not sum to 1 +/- 0.001!");
+    if (R_FABS(fsum - 1.) >= 0.001) return fail("GTR frequencies do not sum to 1 +/- 0.001!");
+    if (R_FABS(rsum - 1.) >= 0.001) return fail("GTR rates do not sum to 1 +/- 0.001!");
     gtr_update(m);
   } else {
     return fail("Substitution model not known");
@@ -496,11 +569,58 @@ int orc_model_set(const orc_spec_t* spec, const double* params, orc_model_t* m) 
     m->cat_weights[0] = 1.;
     m->cat_rate_derivs[0] = 0.;
   } else if (spec->site_model == ORC_SITE_WEIBULL) {
-    orc_weibull_rates(K, params[so], m->cat_rates, m->cat_weights, m->cat_rate_derivs);
+    weibull(K, params[so], m->cat_rates, m->cat_weights, m->cat_rate_derivs);
   } else {
     return fail("Site model not known");
   }
   return 0;
+}
+
+static real* to_real(const double* x, size_t count) {
+  real* r = (real*)malloc(sizeof(real) * (count ? count : 1));
+  for (size_t i = 0; i < count; i++) r[i] = x[i];
+  return r;
+}
+
+static void model_to_public(const model_t* m, orc_model_t* o) {
+  int s = m->s;
+  o->s = s;
+  o->K = m->K;
+  o->n_gtr_rates = m->n_gtr_rates;
+  for (int i = 0; i < s; i++) { o->pi[i] = (double)m->pi[i]; o->lambda[i] = (double)m->lambda[i]; }
+  for (int i = 0; i < s * s; i++) {
+    o->Q[i] = (double)m->Q[i]; o->V[i] = (double)m->V[i]; o->Vinv[i] = (double)m->Vinv[i];
+  }
+  for (int i = 0; i < m->n_gtr_rates; i++) o->gtr_rates[i] = (double)m->gtr_rates[i];
+  for (int k = 0; k < m->K; k++) {
+    o->cat_rates[k] = (double)m->cat_rates[k];
+    o->cat_weights[k] = (double)m->cat_weights[k];
+    o->cat_rate_derivs[k] = (double)m->cat_rate_derivs[k];
+  }
+}
+
+static void model_from_public(const orc_model_t* o, model_t* m) {
+  int s = o->s;
+  m->s = s;
+  m->K = o->K;
+  m->n_gtr_rates = o->n_gtr_rates;
+  for (int i = 0; i < s; i++) { m->pi[i] = o->pi[i]; m->lambda[i] = o->lambda[i]; }
+  for (int i = 0; i < s * s; i++) { m->Q[i] = o->Q[i]; m->V[i] = o->V[i]; m->Vinv[i] = o->Vinv[i]; }
+  for (int i = 0; i < o->n_gtr_rates; i++) m->gtr_rates[i] = o->gtr_rates[i];
+  for (int k = 0; k < o->K; k++) {
+    m->cat_rates[k] = o->cat_rates[k];
+    m->cat_weights[k] = o->cat_weights[k];
+    m->cat_rate_derivs[k] = o->cat_rate_derivs[k];
+  }
+}
+
+int orc_model_set(const orc_spec_t* spec, const double* params, orc_model_t* out) {
+  model_t m;
+  real* pr = to_real(params, (size_t)orc_param_count(spec));
+  int rc = model_set(spec, pr, &m);
+  free(pr);
+  if (!rc) model_to_public(&m, out);
+  return rc;
 }
 
 /* ======================================================================== *
@@ -510,18 +630,21 @@ int orc_model_set(const orc_spec_t* spec, const double* params, orc_model_t* m) 
 /* beagleUpdateTransitionMatrices (fat_beagle.cpp:304-314): P = V diag(exp(l r t)) V^-1
  * per edge and category.  BEAGLE's CPU EigenDecompositionCube clamps negative
  * entries to 0; restated here. out: [edge][k][s][s]. */
-static void transition_matrices(const orc_model_t* m, int n_edges, const double* bl,
-                                double* out) {
+static void transition_matrices(const model_t* m, int n_edges, const real* bl, real* out) {
   int s = m->s, K = m->K;
   for (int e = 0; e < n_edges; e++)
     for (int k = 0; k < K; k++) {
-      double ex[ORC_MAX_STATES];
-      for (int a = 0; a < s; a++) ex[a] = exp(m->lambda[a] * m->cat_rates[k] * bl[e]);
-      double* P = out + ((size_t)e * K + k) * s * s;
+      real ex[ORC_MAX_STATES];
+      for (int a = 0; a < s; a++) {
+        real x = m->lambda[a] * m->cat_rates[k] * bl[e];
+        ex[a] = g_transition_mode ? R_EXPM1(x) : R_EXP(x);
+      }
+      real* P = out + ((size_t)e * K + k) * s * s;
       for (int i = 0; i < s; i++)
         for (int j = 0; j < s; j++) {
-          double sum = 0;
+          real sum = 0;
           for (int a = 0; a < s; a++) sum += m->V[i * s + a] * ex[a] * m->Vinv[a * s + j];
+          if (g_transition_mode && i == j) sum += 1.0;
           P[i * s + j] = sum > 0 ? sum : 0;
         }
     }
@@ -530,10 +653,10 @@ static void transition_matrices(const orc_model_t* m, int n_edges, const double*
 typedef struct {
   int n, N, P, s, K;
   const int32_t* tips;
-  double* post; /* [N][K][P][s] (tip rows filled with one-hot / all-ones) */
-  double* pre;  /* [N][K][P][s] or NULL */
-  double* mats; /* [N-1][K][s][s] */
-  double* cum_log_scale; /* [P] */
+  real* post; /* [N][K][P][s] (tip rows filled with one-hot / all-ones) */
+  real* pre;  /* [N][K][P][s] or NULL */
+  real* mats; /* [N-1][K][s][s] */
+  real* cum_log_scale; /* [P] */
 } core_ws_t;
 
 static core_ws_t ws_alloc(const orc_spec_t* spec, const int32_t* tips, int need_pre) {
@@ -541,15 +664,15 @@ static core_ws_t ws_alloc(const orc_spec_t* spec, const int32_t* tips, int need_
   w.n = spec->taxon_count; w.N = 2 * w.n - 1; w.P = spec->pattern_count;
   w.s = spec->state_count; w.K = spec->category_count; w.tips = tips;
   size_t plv = (size_t)w.K * w.P * w.s;
-  w.post = (double*)malloc(sizeof(double) * plv * w.N);
-  w.pre = need_pre ? (double*)malloc(sizeof(double) * plv * w.N) : NULL;
-  w.mats = (double*)malloc(sizeof(double) * (size_t)(w.N - 1) * w.K * w.s * w.s);
-  w.cum_log_scale = (double*)calloc(w.P, sizeof(double));
+  w.post = (real*)malloc(sizeof(real) * plv * w.N);
+  w.pre = need_pre ? (real*)malloc(sizeof(real) * plv * w.N) : NULL;
+  w.mats = (real*)malloc(sizeof(real) * (size_t)(w.N - 1) * w.K * w.s * w.s);
+  w.cum_log_scale = (real*)calloc(w.P, sizeof(real));
   /* tips: site_pattern.cpp:117-131 (GetPartials) == BEAGLE compact states >= s */
   for (int t = 0; t < w.n; t++)
     for (int k = 0; k < w.K; k++)
       for (int p = 0; p < w.P; p++) {
-        double* L = w.post + (((size_t)t * w.K + k) * w.P + p) * w.s;
+        real* L = w.post + (((size_t)t * w.K + k) * w.P + p) * w.s;
         int st = tips[(size_t)t * w.P + p];
         for (int i = 0; i < w.s; i++) L[i] = (st >= w.s || st < 0 || st == i) ? 1.0 : 0.0;
       }
@@ -566,16 +689,16 @@ static void post_order(core_ws_t* w, const int32_t* child0, const int32_t* child
   size_t plv = (size_t)K * P * s;
   for (int v = w->n; v < w->N; v++) {
     int c0 = child0[v - w->n], c1 = child1[v - w->n];
-    double* dst = w->post + plv * v;
+    real* dst = w->post + plv * v;
     for (int k = 0; k < K; k++) {
-      const double* M0 = w->mats + ((size_t)c0 * K + k) * s * s;
-      const double* M1 = w->mats + ((size_t)c1 * K + k) * s * s;
+      const real* M0 = w->mats + ((size_t)c0 * K + k) * s * s;
+      const real* M1 = w->mats + ((size_t)c1 * K + k) * s * s;
       for (int p = 0; p < P; p++) {
-        const double* L0 = w->post + plv * c0 + ((size_t)k * P + p) * s;
-        const double* L1 = w->post + plv * c1 + ((size_t)k * P + p) * s;
-        double* D = dst + ((size_t)k * P + p) * s;
+        const real* L0 = w->post + plv * c0 + ((size_t)k * P + p) * s;
+        const real* L1 = w->post + plv * c1 + ((size_t)k * P + p) * s;
+        real* D = dst + ((size_t)k * P + p) * s;
         for (int i = 0; i < s; i++) {
-          double a = 0, b = 0;
+          real a = 0, b = 0;
           for (int j = 0; j < s; j++) {
             a += M0[i * s + j] * L0[j];
             b += M1[i * s + j] * L1[j];
@@ -586,47 +709,46 @@ static void post_order(core_ws_t* w, const int32_t* child0, const int32_t* child
     }
     if (rescaling) {
       for (int p = 0; p < P; p++) {
-        double mx = 0;
+        real mx = 0;
         for (int k = 0; k < K; k++)
           for (int i = 0; i < s; i++) {
-            double x = dst[((size_t)k * P + p) * s + i];
+            real x = dst[((size_t)k * P + p) * s + i];
             if (x > mx) mx = x;
           }
         if (mx == 0) mx = 1.0;
         for (int k = 0; k < K; k++)
           for (int i = 0; i < s; i++) dst[((size_t)k * P + p) * s + i] /= mx;
-        w->cum_log_scale[p] += log(mx);
+        w->cum_log_scale[p] += R_LOG(mx);
       }
     }
   }
 }
 
 /* beagleCalculateRootLogLikelihoods (fat_beagle.cpp:65-68,170-173). */
-static double root_log_likelihood(const core_ws_t* w, const orc_model_t* m,
-                                  const double* weights) {
+static real root_log_likelihood(const core_ws_t* w, const model_t* m, const double* weights) {
   int s = w->s, K = w->K, P = w->P;
-  const double* R = w->post + (size_t)K * P * s * (w->N - 1);
-  double total = 0;
+  const real* R = w->post + (size_t)K * P * s * (w->N - 1);
+  real total = 0;
   for (int p = 0; p < P; p++) {
-    double site = 0;
+    real site = 0;
     for (int k = 0; k < K; k++) {
-      double sk = 0;
+      real sk = 0;
       for (int i = 0; i < s; i++) sk += m->pi[i] * R[((size_t)k * P + p) * s + i];
       site += m->cat_weights[k] * sk;
     }
-    total += weights[p] * (log(site) + w->cum_log_scale[p]);
+    total += weights[p] * (R_LOG(site) + w->cum_log_scale[p]);
   }
   return total;
 }
 
-double orc_core_log_likelihood(const orc_spec_t* spec, const orc_model_t* model,
-                               const int32_t* tip_states, const double* pattern_weights,
-                               const int32_t* child0, const int32_t* child1,
-                               const double* bl, int rescaling) {
+static real core_log_likelihood(const orc_spec_t* spec, const model_t* model,
+                                const int32_t* tip_states, const double* pattern_weights,
+                                const int32_t* child0, const int32_t* child1, const real* bl,
+                                int rescaling) {
   core_ws_t w = ws_alloc(spec, tip_states, 0);
   transition_matrices(model, w.N - 1, bl, w.mats);
   post_order(&w, child0, child1, rescaling);
-  double ll = root_log_likelihood(&w, model, pattern_weights);
+  real ll = root_log_likelihood(&w, model, pattern_weights);
   ws_free(&w);
   return ll;
 }
@@ -636,32 +758,32 @@ double orc_core_log_likelihood(const orc_spec_t* spec, const orc_model_t* model,
  * q_x[j] = sum_i P_x[i][j] * ( q_parent[i] * sum_m P_sis[i][m] L_sis[m] ).
  * Per-node scalers (when rescaling) are written but never accumulated
  * (cumulative index BEAGLE_OP_NONE); they cancel in the derivative ratio. */
-static void pre_order(core_ws_t* w, const orc_model_t* m, const int32_t* child0,
+static void pre_order(core_ws_t* w, const model_t* m, const int32_t* child0,
                       const int32_t* child1, int rescaling) {
   int s = w->s, K = w->K, P = w->P, n = w->n;
   size_t plv = (size_t)K * P * s;
   int32_t* tr = (int32_t*)malloc(sizeof(int32_t) * 3 * (2 * n - 2));
   orc_preorder_triples(n, child0, child1, tr);
-  double* root = w->pre + plv * (w->N - 1);
+  real* root = w->pre + plv * (w->N - 1);
   for (size_t x = 0; x < plv; x++) root[x] = m->pi[x % s];
   for (int op = 0; op < 2 * n - 2; op++) {
     int node = tr[3 * op], sis = tr[3 * op + 1], par = tr[3 * op + 2];
-    double* dst = w->pre + plv * node;
+    real* dst = w->pre + plv * node;
     for (int k = 0; k < K; k++) {
-      const double* Mn = w->mats + ((size_t)node * K + k) * s * s;
-      const double* Ms = w->mats + ((size_t)sis * K + k) * s * s;
+      const real* Mn = w->mats + ((size_t)node * K + k) * s * s;
+      const real* Ms = w->mats + ((size_t)sis * K + k) * s * s;
       for (int p = 0; p < P; p++) {
-        const double* qp = w->pre + plv * par + ((size_t)k * P + p) * s;
-        const double* Ls = w->post + plv * sis + ((size_t)k * P + p) * s;
-        double u[ORC_MAX_STATES];
+        const real* qp = w->pre + plv * par + ((size_t)k * P + p) * s;
+        const real* Ls = w->post + plv * sis + ((size_t)k * P + p) * s;
+        real u[ORC_MAX_STATES];
         for (int i = 0; i < s; i++) {
-          double a = 0;
+          real a = 0;
           for (int mm = 0; mm < s; mm++) a += Ms[i * s + mm] * Ls[mm];
           u[i] = qp[i] * a;
         }
-        double* D = dst + ((size_t)k * P + p) * s;
+        real* D = dst + ((size_t)k * P + p) * s;
         for (int j = 0; j < s; j++) {
-          double acc = 0;
+          real acc = 0;
           for (int i = 0; i < s; i++) acc += Mn[i * s + j] * u[i];
           D[j] = acc;
         }
@@ -669,10 +791,10 @@ static void pre_order(core_ws_t* w, const orc_model_t* m, const int32_t* child0,
     }
     if (rescaling) {
       for (int p = 0; p < P; p++) {
-        double mx = 0;
+        real mx = 0;
         for (int k = 0; k < K; k++)
           for (int i = 0; i < s; i++) {
-            double x = dst[((size_t)k * P + p) * s + i];
+            real x = dst[((size_t)k * P + p) * s + i];
             if (x > mx) mx = x;
           }
         if (mx == 0) mx = 1.0;
@@ -686,20 +808,20 @@ static void pre_order(core_ws_t* w, const orc_model_t* m, const int32_t* child0,
 
 /* beagleCalculateEdgeDerivatives (fat_beagle.cpp:153-166) with the differential
  * matrix of BuildDifferentialMatrices (:107-117): D_k = dscale[k] * Q. */
-static void edge_derivatives(const core_ws_t* w, const orc_model_t* m, const double* weights,
-                             const double* dscale, double* grad) {
+static void edge_derivatives(const core_ws_t* w, const model_t* m, const double* weights,
+                             const real* dscale, real* grad) {
   int s = w->s, K = w->K, P = w->P;
   size_t plv = (size_t)K * P * s;
   for (int node = 0; node < w->N - 1; node++) {
-    double g = 0;
+    real g = 0;
     for (int p = 0; p < P; p++) {
-      double num = 0, den = 0;
+      real num = 0, den = 0;
       for (int k = 0; k < K; k++) {
-        const double* q = w->pre + plv * node + ((size_t)k * P + p) * s;
-        const double* L = w->post + plv * node + ((size_t)k * P + p) * s;
-        double nk = 0, dk = 0;
+        const real* q = w->pre + plv * node + ((size_t)k * P + p) * s;
+        const real* L = w->post + plv * node + ((size_t)k * P + p) * s;
+        real nk = 0, dk = 0;
         for (int a = 0; a < s; a++) {
-          double dl = 0;
+          real dl = 0;
           for (int j = 0; j < s; j++) dl += (dscale[k] * m->Q[a * s + j]) * L[j];
           nk += q[a] * dl;
           dk += q[a] * L[a];
@@ -714,19 +836,49 @@ static void edge_derivatives(const core_ws_t* w, const orc_model_t* m, const dou
   grad[w->N - 1] = 0.;
 }
 
-double orc_core_branch_gradient(const orc_spec_t* spec, const orc_model_t* model,
-                                const int32_t* tip_states, const double* pattern_weights,
-                                const int32_t* child0, const int32_t* child1,
-                                const double* bl, const double* dscale, int rescaling,
-                                double* grad) {
+static real core_branch_gradient(const orc_spec_t* spec, const model_t* model,
+                                 const int32_t* tip_states, const double* pattern_weights,
+                                 const int32_t* child0, const int32_t* child1, const real* bl,
+                                 const real* dscale, int rescaling, real* grad) {
   core_ws_t w = ws_alloc(spec, tip_states, 1);
   transition_matrices(model, w.N - 1, bl, w.mats);
   post_order(&w, child0, child1, rescaling);
   pre_order(&w, model, child0, child1, rescaling);
   edge_derivatives(&w, model, pattern_weights, dscale, grad);
-  double ll = root_log_likelihood(&w, model, pattern_weights);
+  real ll = root_log_likelihood(&w, model, pattern_weights);
   ws_free(&w);
   return ll;
+}
+
+double orc_core_log_likelihood(const orc_spec_t* spec, const orc_model_t* model,
+                               const int32_t* tip_states, const double* pattern_weights,
+                               const int32_t* child0, const int32_t* child1,
+                               const double* bl, int rescaling) {
+  model_t m;
+  model_from_public(model, &m);
+  real* b = to_real(bl, (size_t)(2 * spec->taxon_count - 1));
+  real ll = core_log_likelihood(spec, &m, tip_states, pattern_weights, child0, child1, b,
+                                rescaling);
+  free(b);
+  return (double)ll;
+}
+
+double orc_core_branch_gradient(const orc_spec_t* spec, const orc_model_t* model,
+                                const int32_t* tip_states, const double* pattern_weights,
+                                const int32_t* child0, const int32_t* child1,
+                                const double* bl, const double* dscale, int rescaling,
+                                double* grad) {
+  int N = 2 * spec->taxon_count - 1;
+  model_t m;
+  model_from_public(model, &m);
+  real* b = to_real(bl, (size_t)N);
+  real* ds = to_real(dscale, (size_t)spec->category_count);
+  real* g = (real*)malloc(sizeof(real) * N);
+  real ll = core_branch_gradient(spec, &m, tip_states, pattern_weights, child0, child1, b, ds,
+                                 rescaling, g);
+  for (int i = 0; i < N; i++) grad[i] = (double)g[i];
+  free(b); free(ds); free(g);
+  return (double)ll;
 }
 
 /* ======================================================================== *
@@ -741,39 +893,39 @@ double orc_core_branch_gradient(const orc_spec_t* spec, const orc_model_t* model
  * SetParameters(param_vector) re-applies the minus-perturbed vector,
  * fat_beagle.cpp:433-436).  The site-model pass that follows in
  * FatBeagle::Gradient therefore sees that model; restated as is. */
-typedef double (*loglik_fn)(const orc_model_t* model, void* ctx);
+typedef real (*loglik_fn)(const model_t* model, void* ctx);
 
-static int subst_gradient_fd(const orc_spec_t* spec, const double* params, orc_model_t* model,
+static int subst_gradient_fd(const orc_spec_t* spec, const real* params, model_t* model,
                              loglik_fn f, void* ctx, double* out8) {
   int ro, fo, so, co, s = spec->state_count, nr = s * (s - 1) / 2;
   orc_param_layout(spec, &ro, &fo, &so, &co);
   int pc = orc_param_count(spec);
-  double* base = (double*)malloc(sizeof(double) * pc);
-  double* pv = (double*)malloc(sizeof(double) * pc);
-  memcpy(base, params, sizeof(double) * pc);
+  real* base = (real*)malloc(sizeof(real) * pc);
+  real* pv = (real*)malloc(sizeof(real) * pc);
+  memcpy(base, params, sizeof(real) * pc);
   /* SubstitutionModelGradient rebuilds param_vector from the model's own
    * frequencies and rates (fat_beagle.cpp:445-452). */
   for (int i = 0; i < nr; i++) base[ro + i] = model->gtr_rates[i];
   for (int i = 0; i < s; i++) base[fo + i] = model->pi[i];
-  const double delta = 1.e-6;
-  double y[ORC_MAX_STATES * ORC_MAX_STATES];
+  const real delta = 1.e-6;
+  real y[ORC_MAX_STATES * ORC_MAX_STATES];
   int rc = 0;
   for (int which = 0; which < 2 && !rc; which++) { /* 0: frequencies, 1: rates */
     int off = which == 0 ? fo : ro, len = which == 0 ? s : nr;
     double* gout = which == 0 ? out8 + (nr - 1) : out8;
-    memcpy(pv, base, sizeof(double) * pc);
-    orc_stick_breaking_inverse(len, pv + off, y);
+    memcpy(pv, base, sizeof(real) * pc);
+    sb_inverse(len, pv + off, y);
     for (int idx = 0; idx < len - 1 && !rc; idx++) {
-      double orig = y[idx];
+      real orig = y[idx];
       y[idx] = orig + delta;
-      orc_stick_breaking(len, y, pv + off);
-      if ((rc = orc_model_set(spec, pv, model))) break;
-      double lp = f(model, ctx);
+      sb_forward(len, y, pv + off);
+      if ((rc = model_set(spec, pv, model))) break;
+      real lp = f(model, ctx);
       y[idx] = orig - delta;
-      orc_stick_breaking(len, y, pv + off);
-      if ((rc = orc_model_set(spec, pv, model))) break;
-      double lm = f(model, ctx);
-      gout[idx] = (lp - lm) / (2. * delta);
+      sb_forward(len, y, pv + off);
+      if ((rc = model_set(spec, pv, model))) break;
+      real lm = f(model, ctx);
+      gout[idx] = (double)((lp - lm) / (2. * delta));
       y[idx] = orig;
       /* reference: subst_model->SetParameters(param_vector) with the minus
        * vector still in param_vector -> model already in that state. */
@@ -788,22 +940,31 @@ typedef struct {
   const int32_t* tips;
   const double* weights;
   const int32_t *child0, *child1;
-  const double* bl;
+  const real* bl;
   int rescaling;
-  double add; /* log-det-Jacobian for rooted trees */
+  real add; /* log-det-Jacobian for rooted trees */
 } ll_ctx_t;
 
-static double ll_of_model(const orc_model_t* model, void* vctx) {
+static real ll_of_model(const model_t* model, void* vctx) {
   ll_ctx_t* c = (ll_ctx_t*)vctx;
-  return orc_core_log_likelihood(c->spec, model, c->tips, c->weights, c->child0, c->child1,
-                                 c->bl, c->rescaling) + c->add;
+  return core_log_likelihood(c->spec, model, c->tips, c->weights, c->child0, c->child1,
+                             c->bl, c->rescaling) + c->add;
 }
 
 /* fat_beagle.cpp:389-398 */
-static double discrete_site_model_gradient(int N, const double* bl, const double* g) {
-  double r = 0;
+static real discrete_site_model_gradient(int N, const real* bl, const real* g) {
+  real r = 0;
   for (int i = 0; i < N - 1; i++) r += g[i] * bl[i];
   return r;
+}
+
+static int detrifurcate_real(int n, const int32_t* parent_ids, const double* bl, int32_t* c0,
+                             int32_t* c1, real* b) {
+  double* tmp = (double*)malloc(sizeof(double) * (2 * n - 1));
+  int rc = orc_detrifurcate(n, parent_ids, bl, c0, c1, tmp);
+  for (int i = 0; i < 2 * n - 1; i++) b[i] = tmp[i];
+  free(tmp);
+  return rc;
 }
 
 int orc_unrooted_log_likelihoods(const orc_spec_t* spec, const int32_t* tip_states,
@@ -816,20 +977,22 @@ int orc_unrooted_log_likelihoods(const orc_spec_t* spec, const int32_t* tip_stat
   for (int t = 0; t < T; t++) {
     int32_t* c0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (n - 1));
     int32_t* c1 = c0 + (n - 1);
-    double* b = (double*)malloc(sizeof(double) * (2 * n - 1));
-    orc_model_t model;
-    int rc = orc_detrifurcate(n, parent_ids + (size_t)t * (2 * n - 3), bl + (size_t)t * (2 * n - 2),
-                              c0, c1, b);
-    if (!rc) rc = orc_model_set(spec, params + (size_t)t * pc, &model);
+    real* b = (real*)malloc(sizeof(real) * (2 * n - 1));
+    real* pr = to_real(params + (size_t)t * pc, (size_t)pc);
+    model_t model;
+    int rc = detrifurcate_real(n, parent_ids + (size_t)t * (2 * n - 3),
+                               bl + (size_t)t * (2 * n - 2), c0, c1, b);
+    if (!rc) rc = model_set(spec, pr, &model);
     if (!rc)
-      out_logl[t] = orc_core_log_likelihood(spec, &model, tip_states, pattern_weights, c0, c1,
-                                            b, rescaling);
+      out_logl[t] = (double)core_log_likelihood(spec, &model, tip_states, pattern_weights, c0,
+                                                c1, b, rescaling);
     if (rc) {
 #pragma omp critical
-      { rc_all = 1; snprintf(g_err, sizeof g_err, "tree %d failed", t); }
+      { rc_all = 1; }
     }
-    free(c0); free(b);
+    free(c0); free(b); free(pr);
   }
+  if (rc_all && !g_err[0]) fail("a tree failed");
   return rc_all;
 }
 
@@ -844,43 +1007,44 @@ int orc_unrooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
   for (int t = 0; t < T; t++) {
     int32_t* c0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (n - 1));
     int32_t* c1 = c0 + (n - 1);
-    double* b = (double*)malloc(sizeof(double) * N);
-    double* g2 = (double*)malloc(sizeof(double) * N);
-    orc_model_t model;
-    int rc = orc_detrifurcate(n, parent_ids + (size_t)t * (2 * n - 3), bl + (size_t)t * (2 * n - 2),
-                              c0, c1, b);
-    if (!rc) rc = orc_model_set(spec, params + (size_t)t * pc, &model);
+    real* b = (real*)malloc(sizeof(real) * 3 * N);
+    real* g = b + N;
+    real* g2 = g + N;
+    real* pr = to_real(params + (size_t)t * pc, (size_t)pc);
+    model_t model;
+    const int32_t* pid = parent_ids + (size_t)t * (2 * n - 3);
+    const double* tbl = bl + (size_t)t * (2 * n - 2);
+    int rc = detrifurcate_real(n, pid, tbl, c0, c1, b);
+    if (!rc) rc = model_set(spec, pr, &model);
     if (!rc) {
       int root = N - 1, root_child = c0[root - n], fixed = c1[root - n];
       /* Tree::SlideRootPosition tree.cpp:72-78 */
       b[root_child] = b[root_child] + b[fixed];
       b[fixed] = 0.0;
-      double* g = out_branch + (size_t)t * N;
-      out_logl[t] = orc_core_branch_gradient(spec, &model, tip_states, pattern_weights, c0, c1,
-                                             b, model.cat_rates, rescaling, g);
+      out_logl[t] = (double)core_branch_gradient(spec, &model, tip_states, pattern_weights, c0,
+                                                 c1, b, model.cat_rates, rescaling, g);
       if (model.n_gtr_rates > 0 && out_subst) {
         /* f = StaticUnrootedLogLikelihood(in_tree): Detrifurcate without the slide */
-        double* b0 = (double*)malloc(sizeof(double) * N);
+        real* b0 = (real*)malloc(sizeof(real) * N);
         int32_t* d0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (n - 1));
-        orc_detrifurcate(n, parent_ids + (size_t)t * (2 * n - 3), bl + (size_t)t * (2 * n - 2), d0,
-                         d0 + (n - 1), b0);
+        detrifurcate_real(n, pid, tbl, d0, d0 + (n - 1), b0);
         ll_ctx_t ctx = {spec, tip_states, pattern_weights, d0, d0 + (n - 1), b0, rescaling, 0.};
-        rc = subst_gradient_fd(spec, params + (size_t)t * pc, &model, ll_of_model, &ctx,
-                               out_subst + (size_t)t * 8);
+        rc = subst_gradient_fd(spec, pr, &model, ll_of_model, &ctx, out_subst + (size_t)t * 8);
         free(b0); free(d0);
       }
       if (!rc && spec->category_count > 1 && out_site) {
-        orc_core_branch_gradient(spec, &model, tip_states, pattern_weights, c0, c1, b,
-                                 model.cat_rate_derivs, rescaling, g2);
-        out_site[t] = discrete_site_model_gradient(N, b, g2);
+        core_branch_gradient(spec, &model, tip_states, pattern_weights, c0, c1, b,
+                             model.cat_rate_derivs, rescaling, g2);
+        out_site[t] = (double)discrete_site_model_gradient(N, b, g2);
       }
       g[fixed] = 0.; /* fat_beagle.cpp:499 */
+      for (int i = 0; i < N; i++) out_branch[(size_t)t * N + i] = (double)g[i];
     }
     if (rc) {
 #pragma omp critical
       { rc_all = 1; }
     }
-    free(c0); free(b); free(g2);
+    free(c0); free(b); free(pr);
   }
   return rc_all;
 }
@@ -888,7 +1052,8 @@ int orc_unrooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
 /* ---- rooted -------------------------------------------------------------- */
 
 /* rooted_tree.cpp:20-81: SetTipDates/SetNodeBoundsUsingDates +
- * InitializeTimeTreeUsingBranchLengths. */
+ * InitializeTimeTreeUsingBranchLengths.  (Plain double: this is input
+ * preparation done by the caller of the engine, not engine arithmetic.) */
 int orc_time_tree_init(int n, const int32_t* parent_ids, const double* bl,
                        const double* tip_dates, double* h, double* bound, double* ratios) {
   int N = 2 * n - 1;
@@ -912,14 +1077,14 @@ int orc_time_tree_init(int n, const int32_t* parent_ids, const double* bl,
 }
 
 /* fat_beagle.cpp:82-94 (iteration order = TripleIdPreorderBifurcating). */
-static double log_det_jacobian(int n, const int32_t* child0, const int32_t* child1,
-                               const double* h, const double* bound) {
+static real log_det_jacobian(int n, const int32_t* child0, const int32_t* child1,
+                             const double* h, const double* bound) {
   int32_t* tr = (int32_t*)malloc(sizeof(int32_t) * 3 * (2 * n - 2));
   orc_preorder_triples(n, child0, child1, tr);
-  double s = 0;
+  real s = 0;
   for (int op = 0; op < 2 * n - 2; op++) {
     int node = tr[3 * op], par = tr[3 * op + 2];
-    if (node >= n) s += log(h[par] - bound[node]);
+    if (node >= n) s += R_LOG((real)h[par] - (real)bound[node]);
   }
   free(tr);
   return s;
@@ -937,25 +1102,25 @@ int orc_rooted_log_likelihoods(const orc_spec_t* spec, const int32_t* tip_states
   for (int t = 0; t < T; t++) {
     int32_t* c0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (n - 1));
     int32_t* c1 = c0 + (n - 1);
-    double* b = (double*)malloc(sizeof(double) * N);
-    orc_model_t model;
+    real* b = to_real(bl + (size_t)t * N, (size_t)N);
+    real* pr = to_real(params + (size_t)t * pc, (size_t)pc);
+    model_t model;
     int rc = rooted_children(n, parent_ids + (size_t)t * (N - 1), c0, c1);
-    if (!rc) rc = orc_model_set(spec, params + (size_t)t * pc, &model);
+    if (!rc) rc = model_set(spec, pr, &model);
     if (!rc) {
-      memcpy(b, bl + (size_t)t * N, sizeof(double) * N);
-      double add = 0;
+      real add = 0;
       if (with_jacobian) { /* fat_beagle.cpp:96-104; else :78-80 */
         for (int i = 0; i < N - 1; i++) b[i] *= rates[(size_t)t * (N - 1) + i];
         add = log_det_jacobian(n, c0, c1, node_heights + (size_t)t * N, node_bounds + (size_t)t * N);
       }
-      out_logl[t] = orc_core_log_likelihood(spec, &model, tip_states, pattern_weights, c0, c1,
-                                            b, rescaling) + add;
+      out_logl[t] = (double)(core_log_likelihood(spec, &model, tip_states, pattern_weights, c0,
+                                                 c1, b, rescaling) + add);
     }
     if (rc) {
 #pragma omp critical
       { rc_all = 1; }
     }
-    free(c0); free(b);
+    free(c0); free(b); free(pr);
   }
   return rc_all;
 }
@@ -964,7 +1129,7 @@ int orc_rooted_log_likelihoods(const orc_spec_t* spec, const int32_t* tip_states
  * nodes only (node.cpp:194-207), so the "node_id >= leaf_count" test is always
  * true there; the order does not matter for the result. */
 static void height_gradient(int n, const int32_t* c0, const int32_t* c1, const double* rates,
-                            const double* bg, double* hg) {
+                            const real* bg, real* hg) {
   int N = 2 * n - 1, root = N - 1;
   for (int i = 0; i < n - 1; i++) hg[i] = 0;
   for (int v = root; v >= n; v--) {
@@ -975,21 +1140,22 @@ static void height_gradient(int n, const int32_t* c0, const int32_t* c1, const d
 }
 
 /* rooted_gradient_transforms.cpp:39-64 */
-static double node_partial(int v, int n, const double* h, const double* ratios,
-                           const double* bound) {
-  return (h[v] - bound[v]) / ratios[v - n];
+static real node_partial(int v, int n, const double* h, const double* ratios,
+                         const double* bound) {
+  return ((real)h[v] - bound[v]) / ratios[v - n];
 }
-static double epoch_addition(int v, int c, int n, const double* h, const double* ratios,
-                             const double* bound, const double* acc) {
+static real epoch_addition(int v, int c, int n, const double* h, const double* ratios,
+                           const double* bound, const real* acc) {
   if (c < n) return 0.0;
   if (bound[v] == bound[c]) return acc[c - n] * ratios[c - n] / ratios[v - n];
-  return acc[c - n] * ratios[c - n] / (h[v] - bound[c]) * node_partial(v, n, h, ratios, bound);
+  return acc[c - n] * ratios[c - n] / ((real)h[v] - bound[c]) *
+         node_partial(v, n, h, ratios, bound);
 }
 
 /* rooted_gradient_transforms.cpp:78-100 (post-order over internal non-root nodes) */
 static void ratio_gradient_unweighted(int n, const int32_t* c0, const int32_t* c1,
                                       const double* h, const double* ratios,
-                                      const double* bound, const double* gh, double* out) {
+                                      const double* bound, const real* gh, real* out) {
   int N = 2 * n - 1, root = N - 1;
   for (int i = 0; i < n - 1; i++) out[i] = 0;
   for (int v = n; v < N; v++) {
@@ -1001,17 +1167,17 @@ static void ratio_gradient_unweighted(int n, const int32_t* c0, const int32_t* c
 }
 
 /* rooted_gradient_transforms.cpp:102-130 */
-static double root_height_gradient(int n, const int32_t* c0, const int32_t* c1,
-                                   const double* ratios, const double* gh) {
+static real root_height_gradient(int n, const int32_t* c0, const int32_t* c1,
+                                 const double* ratios, const real* gh) {
   int N = 2 * n - 1, root = N - 1;
-  double* mult = (double*)malloc(sizeof(double) * (n - 1));
+  real* mult = (real*)malloc(sizeof(real) * (n - 1));
   mult[root - n] = 1.0;
   for (int v = root; v >= n; v--) { /* any top-down order */
     int a = c0[v - n], b = c1[v - n];
     if (a >= n) mult[a - n] = ratios[a - n] * mult[v - n];
     if (b >= n) mult[b - n] = ratios[b - n] * mult[v - n];
   }
-  double sum = 0;
+  real sum = 0;
   for (int i = 0; i < n - 1; i++) sum += gh[i] * mult[i];
   free(mult);
   return sum;
@@ -1021,16 +1187,16 @@ static double root_height_gradient(int n, const int32_t* c0, const int32_t* c1,
 static void ratio_gradient_of_branch_gradient(int n, const int32_t* c0, const int32_t* c1,
                                               const double* rates, const double* h,
                                               const double* bound, const double* ratios,
-                                              const double* bg, double* out) {
+                                              const real* bg, real* out) {
   int root_i = n - 2;
-  double* hg = (double*)malloc(sizeof(double) * (n - 1) * 3);
-  double* log_time = hg + (n - 1);
-  double* jac = log_time + (n - 1);
+  real* hg = (real*)malloc(sizeof(real) * (n - 1) * 3);
+  real* log_time = hg + (n - 1);
+  real* jac = log_time + (n - 1);
   height_gradient(n, c0, c1, rates, bg, hg);
   ratio_gradient_unweighted(n, c0, c1, h, ratios, bound, hg, out);
   out[root_i] = root_height_gradient(n, c0, c1, ratios, hg);
   for (int i = 0; i < n - 1; i++) log_time[i] = 0;
-  for (int i = 0; i < n - 2; i++) log_time[i] = 1.0 / (h[n + i] - bound[n + i]);
+  for (int i = 0; i < n - 2; i++) log_time[i] = 1.0 / ((real)h[n + i] - bound[n + i]);
   ratio_gradient_unweighted(n, c0, c1, h, ratios, bound, log_time, jac);
   jac[root_i] = root_height_gradient(n, c0, c1, ratios, log_time);
   for (int i = 0; i < n - 2; i++) out[i] += jac[i] - 1.0 / ratios[i];
@@ -1052,16 +1218,18 @@ int orc_rooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
   for (int t = 0; t < T; t++) {
     int32_t* c0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (n - 1));
     int32_t* c1 = c0 + (n - 1);
-    double* b = (double*)malloc(sizeof(double) * 3 * N);
-    double* bg = b + N;
-    double* g2 = bg + N;
+    real* b = (real*)malloc(sizeof(real) * 4 * N);
+    real* bg = b + N;
+    real* g2 = bg + N;
+    real* og = g2 + N;
     const double* tb = bl + (size_t)t * N;
     const double* r = rates + (size_t)t * (N - 1);
     const double* h = node_heights + (size_t)t * N;
     const double* bd = node_bounds + (size_t)t * N;
-    orc_model_t model;
+    real* pr = to_real(params + (size_t)t * pc, (size_t)pc);
+    model_t model;
     int rc = rooted_children(n, parent_ids + (size_t)t * (N - 1), c0, c1);
-    if (!rc) rc = orc_model_set(spec, params + (size_t)t * pc, &model);
+    if (!rc) rc = model_set(spec, pr, &model);
     if (!rc && !(rate_counts[t] == 1 || rate_counts[t] == N - 1)) {
       fail("The number of rates should be equal to 1 (i.e. strict clock) or equal to the "
            "number of branches.");
@@ -1070,37 +1238,38 @@ int orc_rooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
     if (!rc) {
       for (int i = 0; i < N; i++) b[i] = tb[i];
       for (int i = 0; i < N - 1; i++) b[i] *= r[i];
-      out_logl[t] = orc_core_branch_gradient(spec, &model, tip_states, pattern_weights, c0, c1,
-                                             b, model.cat_rates, rescaling, bg);
+      out_logl[t] = (double)core_branch_gradient(spec, &model, tip_states, pattern_weights, c0,
+                                                 c1, b, model.cat_rates, rescaling, bg);
       if (model.n_gtr_rates > 0 && out_subst) {
         ll_ctx_t ctx = {spec, tip_states, pattern_weights, c0, c1, b, rescaling,
                         log_det_jacobian(n, c0, c1, h, bd)};
-        rc = subst_gradient_fd(spec, params + (size_t)t * pc, &model, ll_of_model, &ctx,
-                               out_subst + (size_t)t * 8);
+        rc = subst_gradient_fd(spec, pr, &model, ll_of_model, &ctx, out_subst + (size_t)t * 8);
       }
       if (!rc && spec->category_count > 1 && out_site) {
-        orc_core_branch_gradient(spec, &model, tip_states, pattern_weights, c0, c1, b,
-                                 model.cat_rate_derivs, rescaling, g2);
-        out_site[t] = discrete_site_model_gradient(N, b, g2);
+        core_branch_gradient(spec, &model, tip_states, pattern_weights, c0, c1, b,
+                             model.cat_rate_derivs, rescaling, g2);
+        out_site[t] = (double)discrete_site_model_gradient(N, b, g2);
       }
       ratio_gradient_of_branch_gradient(n, c0, c1, r, h, bd, height_ratios + (size_t)t * (n - 1),
-                                        bg, out_ratios_root_height + (size_t)t * (n - 1));
+                                        bg, og);
+      for (int i = 0; i < n - 1; i++)
+        out_ratios_root_height[(size_t)t * (n - 1) + i] = (double)og[i];
       /* ClockGradient fat_beagle.cpp:367-387: unscaled times */
       double* oc = out_clock + (size_t)t * (N - 1);
       if (rate_counts[t] == 1) {
-        double acc = 0;
+        real acc = 0;
         for (int i = 0; i < N - 1; i++) acc += bg[i] * tb[i];
         for (int i = 0; i < N - 1; i++) oc[i] = 0;
-        oc[0] = acc;
+        oc[0] = (double)acc;
       } else {
-        for (int i = 0; i < N - 1; i++) oc[i] = bg[i] * tb[i];
+        for (int i = 0; i < N - 1; i++) oc[i] = (double)(bg[i] * tb[i]);
       }
     }
     if (rc) {
 #pragma omp critical
       { rc_all = 1; }
     }
-    free(c0); free(b);
+    free(c0); free(b); free(pr);
   }
   return rc_all;
 }

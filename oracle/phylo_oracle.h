@@ -62,6 +62,8 @@ typedef struct {
 } orc_model_t;
 
 const char* orc_last_error(void);
+/* 0 (default): BEAGLE's P = V exp(L t) V^-1;  1: I + V expm1(L t) V^-1 (see .c) */
+void orc_set_transition_mode(int mode);
 
 /* ---- integer half ------------------------------------------------------- */
 

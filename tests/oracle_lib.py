@@ -25,21 +25,56 @@ class Spec(C.Structure):
         "subst_model", "site_model", "clock_model", "use_tip_states")]
 
 
-_lib = None
+def _host_stamp():
+    """liboracle.so is built -march=native; rebuild when the host CPU changes (the
+    snapshot travels from the build container to the GPU box with the .so in it)."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as fh:
+            txt = fh.read()
+        keep = [ln for ln in txt.splitlines() if ln.startswith(("model name", "flags"))][:2]
+    except OSError:
+        keep = []
+    return hashlib.sha1("\n".join(keep).encode()).hexdigest()
+
+
+_variant = "f64"
+_libs = {}
+
+
+def select(variant):
+    """'f64' (default; the reference's precision) or 'ld' (same code, x87 long double)."""
+    global _variant
+    assert variant in ("f64", "ld")
+    _variant = variant
+
+
+def set_transition_mode(mode):
+    """0: BEAGLE's exp form (default); 1: expm1 form. Applies to the selected variant."""
+    lib().orc_set_transition_mode(int(mode))
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        so = os.path.join(ORACLE_DIR, "liboracle.so")
-        if not os.path.exists(so):
-            subprocess.run(["make", "-C", ORACLE_DIR, "liboracle.so"], check=True,
-                           capture_output=True)
-        _lib = C.CDLL(so)
-        _lib.orc_last_error.restype = C.c_char_p
-        _lib.orc_core_log_likelihood.restype = C.c_double
-        _lib.orc_core_branch_gradient.restype = C.c_double
-    return _lib
+    if _variant in _libs:
+        return _libs[_variant]
+    name = "liboracle.so" if _variant == "f64" else "liboracle_ld.so"
+    so = os.path.join(ORACLE_DIR, name)
+    stamp_path = os.path.join(ORACLE_DIR, "." + name + ".stamp")
+    stamp = _host_stamp()
+    have = open(stamp_path).read() if os.path.exists(stamp_path) else ""
+    src_newer = (not os.path.exists(so) or os.path.getmtime(so) < max(
+        os.path.getmtime(os.path.join(ORACLE_DIR, f))
+        for f in ("phylo_oracle.c", "phylo_oracle.h")))
+    if src_newer or have != stamp:
+        subprocess.run(["make", "-B", "-C", ORACLE_DIR, name], check=True, capture_output=True)
+        with open(stamp_path, "w") as fh:
+            fh.write(stamp)
+    L = C.CDLL(so)
+    L.orc_last_error.restype = C.c_char_p
+    L.orc_core_log_likelihood.restype = C.c_double
+    L.orc_core_branch_gradient.restype = C.c_double
+    _libs[_variant] = L
+    return L
 
 
 def _p(a, t):

@@ -1,0 +1,390 @@
+"""Parity tests proper: the HIP engine, called through the C ABI
+(libsbn_amd/libmi_phylo.so via ctypes), against the CPU oracle on the same
+inputs, against the reference's golden values, and -- at BASELINE.json's full
+sizes -- through size-independent properties.
+
+Tolerance (north_star): log-likelihoods and gradients within 1e-10 relative of
+the oracle in its default mode (= the reference's algorithm, BEAGLE's
+P = V exp(Lt) V^-1).  The engine evaluates the algebraically identical
+I + V expm1(Lt) V^-1 (more accurate for short branches, DESIGN.md "Accuracy");
+against the oracle in that mode, and against the 80-bit long-double build of the
+oracle, the bound checked is 1e-12.  For gradient vectors "relative" is taken against the largest
+magnitude in the vector (components that cancel to ~0 have no meaningful
+relative error).  The finite-difference substitution gradient divides a
+difference of two ~1e4-sized log-likelihoods by 2e-6, which amplifies rounding
+noise by 5e5; it is compared with the oracle in expm1 mode at 1e-4 abs + 1e-6
+rel (the reference's own test uses 1e-3; the oracle in BEAGLE mode carries up to
+1e-3 of such noise itself on fluA).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import tree_utils as TU
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def _engine(subst, site, clock, tips, weights, **kw):
+    import libsbn_amd as L
+    return L.Engine(L.PhyloModelSpecification(subst, site, clock), tips, weights, **kw)
+
+
+def _close(a, b, rtol=RTOL):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    scale = max(np.max(np.abs(b)), 1e-300)
+    return np.max(np.abs(a - b)) <= rtol * scale
+
+
+def _params(spec, T, **blocks):
+    pc = O.param_count(spec)
+    lay = O.param_layout(spec)
+    pr = np.zeros((T, pc))
+    for key, val in blocks.items():
+        val = np.asarray(val, float)
+        off = lay[key]
+        pr[:, off:off + (val.shape[-1] if val.ndim else 1)] = val if val.ndim else val
+    if lay["clock rate"] >= 0 and "clock rate" not in blocks:
+        pr[:, lay["clock rate"]] = 1.0
+    return pr
+
+
+def _grad_matrix(grads, key):
+    return np.stack([g.gradient[key] for g in grads])
+
+
+K = O.load_kats()
+
+
+def test_hello_golden_and_oracle():
+    for name, key in (("hello", "hello_jc69"), ("hello_out", "hello_out_jc69")):
+        st = O.load_struct(name)
+        tips, w, pids, bls = O.struct_arrays(st)
+        eng = _engine("JC69", "constant", "strict", tips, w)
+        spec = O.make_spec(3, st["pattern_count"])
+        pr = _params(spec, 1)
+        ll = eng.log_likelihoods(pids, bls, pr)
+        assert abs(ll[0] - K[key]["log_likelihood"]) < 1e-6 * abs(ll[0])
+        assert _close(ll, O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr))
+        g = eng.gradients(pids, bls, pr)
+        og = O.unrooted_gradients(spec, tips, w, pids, bls, pr)
+        assert _close(_grad_matrix(g, "branch_lengths"), og["branch_lengths"])
+
+
+@pytest.mark.parametrize("use_tip_states", [True, False])
+@pytest.mark.parametrize("rescaling", [False, True])
+def test_ds1_jc69_goldens_and_oracle(use_tip_states, rescaling):
+    st = O.load_struct("ds1_sub10")
+    k = K["ds1_sub10_jc69"]
+    tips, w, pids, bls = O.struct_arrays(st)
+    eng = _engine("JC69", "constant", "strict", tips, w, use_tip_states=use_tip_states)
+    spec = O.make_spec(27, 934)
+    pr = _params(spec, 10)
+    ll = eng.log_likelihoods(pids, bls, pr, rescaling)
+    assert np.all(np.abs(ll - k["log_likelihoods"]) < k["ll_tol"])
+    oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, rescaling, 4)
+    assert np.all(np.abs(ll - oll) <= RTOL * np.abs(oll))
+    g = eng.gradients(pids, bls, pr, rescaling)
+    og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, rescaling, 4)
+    gll = np.array([x.log_likelihood for x in g])
+    assert np.all(np.abs(gll - oll) <= RTOL * np.abs(oll))
+    gb = _grad_matrix(g, "branch_lengths")
+    assert gb.shape == (10, 53)
+    for t in range(10):
+        assert _close(gb[t], og["branch_lengths"][t])
+    assert np.all(gb[:, -2:] == 0.0)
+    assert np.all(np.abs(np.sort(gb[-1]) - k["last_tree_sorted_branch_gradient"])
+                  < k["grad_tol"])
+    assert set(g[0].gradient) == {"branch_lengths"}
+
+
+@pytest.mark.parametrize("rescaling", [False, True])
+def test_ds1_weibull_goldens_and_oracle(rescaling):
+    st = O.load_struct("ds1_sub10")
+    k = K["ds1_sub10_jc69_weibull4_shape0.1"]
+    tips, w, pids, bls = O.struct_arrays(st)
+    eng = _engine("JC69", "weibull+4", "strict", tips, w)
+    spec = O.make_spec(27, 934, "JC69", "weibull+4")
+    pr = _params(spec, 10, **{"Weibull shape": k["shape"]})
+    ll = eng.log_likelihoods(pids, bls, pr, rescaling)
+    assert np.all(np.abs(ll - k["log_likelihoods"]) < k["tol"])
+    oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, rescaling, 4)
+    assert np.all(np.abs(ll - oll) <= RTOL * np.abs(oll))
+    g = eng.gradients(pids, bls, pr, rescaling)
+    og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, rescaling, 4)
+    gb = _grad_matrix(g, "branch_lengths")
+    assert np.all(np.abs(gb[:, 0] - k["branch_gradient_0"]) < k["tol"])
+    for t in range(10):
+        assert _close(gb[t], og["branch_lengths"][t])
+    gs = _grad_matrix(g, "site_model")[:, 0]
+    assert np.all(np.abs(gs - og["site_model"]) <= RTOL * np.abs(og["site_model"]).max())
+    assert set(g[0].gradient) == {"branch_lengths", "site_model"}
+
+
+def test_ds1_gtr_weibull_per_tree_params():
+    """Config 3 shape: per-tree GTR + Weibull parameters (fat_beagle.hpp:138-147)."""
+    rng = np.random.default_rng(45)
+    st = O.load_struct("ds1_top100")
+    tips, w, pids, bls = O.struct_arrays(st)
+    T = 6
+    pids, bls = pids[:T], rng.exponential(0.1, size=(T, 52))
+    bls[:, -1] = 0
+    rates, freqs = TU.random_gtr_params(T, rng)
+    eng = _engine("GTR", "weibull+4", "strict", tips, w)
+    spec = O.make_spec(27, 934, "GTR", "weibull+4")
+    pr = _params(spec, T, **{"GTR rates": rates, "frequencies": freqs,
+                             "Weibull shape": rng.uniform(0.3, 2.0, size=(T, 1))})
+    assert eng.block_specification() == {
+        "GTR rates": (0, 6), "Weibull shape": (10, 1), "clock rate": (11, 1),
+        "entire": (0, 12), "entire clock": (11, 1), "entire site": (10, 1),
+        "entire substitution": (0, 10), "frequencies": (6, 4)}
+    ll = eng.log_likelihoods(pids, bls, pr)
+    oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, False, 4)
+    assert np.all(np.abs(ll - oll) <= RTOL * np.abs(oll))
+    g = eng.gradients(pids, bls, pr)
+    og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, False, 4)
+    O.set_transition_mode(1)
+    og1 = O.unrooted_gradients(spec, tips, w, pids, bls, pr, False, 4)
+    O.set_transition_mode(0)
+    for t in range(T):
+        assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t])
+        assert _close(g[t].gradient["branch_lengths"], og1["branch_lengths"][t], 1e-12)
+        assert abs(g[t].gradient["site_model"][0] - og["site_model"][t]) <= \
+            1e-9 * max(1.0, abs(og["site_model"][t]))
+        assert np.allclose(g[t].gradient["substitution_model"], og1["substitution_model"][t],
+                           rtol=1e-6, atol=1e-4)
+    assert set(g[0].gradient) == {"branch_lengths", "site_model", "substitution_model"}
+
+
+def test_extended_precision_check():
+    """logL and branch gradients against the 80-bit long-double build of the oracle
+    and against the FP64 oracle in expm1 mode: 1e-12 relative.  This is the check
+    that backs the 1e-10 claim."""
+    rng = np.random.default_rng(99)
+    st = O.load_struct("ds1_sub10")
+    tips, w, pids, bls = O.struct_arrays(st)
+    rates, freqs = TU.random_gtr_params(10, rng)
+    eng = _engine("GTR", "weibull+4", "strict", tips, w)
+    spec = O.make_spec(27, 934, "GTR", "weibull+4")
+    pr = _params(spec, 10, **{"GTR rates": rates, "frequencies": freqs, "Weibull shape": 0.6})
+    ll = eng.log_likelihoods(pids, bls, pr)
+    gb = _grad_matrix(eng.gradients(pids, bls, pr), "branch_lengths")
+    try:
+        for variant, mode in (("f64", 1), ("ld", 0), ("ld", 1)):
+            O.select(variant)
+            O.set_transition_mode(mode)
+            oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, False, 4)
+            assert np.all(np.abs(ll - oll) <= 1e-12 * np.abs(oll)), (variant, mode)
+            if variant == "ld" and mode == 1:
+                continue
+            og = O.unrooted_gradients(spec, tips, w, pids[:3], bls[:3], pr[:3], False, 3)
+            for t in range(3):
+                assert _close(gb[t], og["branch_lengths"][t], 1e-12), (variant, mode)
+    finally:
+        O.set_transition_mode(0)
+        O.select("f64")
+        O.set_transition_mode(0)
+
+
+def _flua(subst="JC69", site="constant"):
+    st = O.load_struct("flua")
+    n = st["taxon_count"]
+    tips, w, pids, bls = O.struct_arrays(st)
+    dates = O.parse_dates_from_names(st["taxon_names"])
+    h, bd, ra = O.time_tree_init(n, pids[0], bls[0], dates)
+    spec = O.make_spec(n, st["pattern_count"], subst, site, "strict")
+    rates = np.full((1, 2 * n - 2), 0.001)
+    eng = _engine(subst, site, "strict", tips, w)
+    return eng, spec, tips, w, pids, bls, rates, h[None], bd[None], ra[None]
+
+
+def test_flua_rooted_jc69():
+    k = K["flua_jc69_strict"]
+    eng, spec, tips, w, pids, bls, rates, h, bd, ra = _flua()
+    pr = _params(spec, 1)
+    ll = eng.rooted_log_likelihoods(pids, bls, pr, rates, h, bd)
+    assert abs(ll[0] - (k["log_likelihood_no_jacobian"] + k["log_det_jacobian"])) < k["tol"]
+    assert _close(ll, O.rooted_log_likelihoods(spec, tips, w, pids, bls, pr, rates, h, bd))
+    ll_u = eng.rooted_log_likelihoods(pids, bls, pr, with_jacobian=False)
+    assert _close(ll_u, O.rooted_log_likelihoods(spec, tips, w, pids, bls, pr, rates, h, bd,
+                                                 False))
+    g = eng.rooted_gradients(pids, bls, pr, rates, [1], h, bd, ra)
+    og = O.rooted_gradients(spec, tips, w, pids, bls, pr, rates, [1], h, bd, ra)
+    assert abs(g[0].log_likelihood - k["log_likelihood_no_jacobian"]) < k["tol"]
+    assert abs(g[0].log_likelihood - og["log_likelihood"][0]) <= RTOL * abs(og["log_likelihood"][0])
+    assert np.all(np.abs(g[0].gradient["ratios_root_height"]
+                         - k["ratios_root_height_gradient"]) < k["tol"])
+    assert _close(g[0].gradient["ratios_root_height"], og["ratios_root_height"][0])
+    assert g[0].gradient["clock_model"].shape == (1,)
+    assert _close(g[0].gradient["clock_model"], og["clock_model"][0, :1])
+    assert set(g[0].gradient) == {"ratios_root_height", "clock_model"}
+    # per-branch ("relaxed") clock, rooted_sbn_instance.hpp:306-323
+    n = spec.taxon_count
+    rel = rates * (np.arange(2 * n - 2) % 3 + 1.0)
+    g2 = eng.rooted_gradients(pids, bls, pr, rel, [2 * n - 2], h, bd, ra)
+    og2 = O.rooted_gradients(spec, tips, w, pids, bls, pr, rel, [2 * n - 2], h, bd, ra)
+    assert g2[0].gradient["clock_model"].shape == (2 * n - 2,)
+    assert _close(g2[0].gradient["clock_model"], og2["clock_model"][0])
+    assert _close(g2[0].gradient["ratios_root_height"], og2["ratios_root_height"][0])
+    with pytest.raises(RuntimeError, match="number of rates"):
+        eng.rooted_gradients(pids, bls, pr, rel, [3], h, bd, ra)
+    with pytest.raises(RuntimeError, match="time tree"):
+        eng.rooted_log_likelihoods(pids, bls, pr)  # dates never set: error, not UB
+
+
+def test_flua_gtr_and_weibull():
+    k = K["flua_gtr"]
+    eng, spec, tips, w, pids, bls, rates, h, bd, ra = _flua("GTR")
+    pr = _params(spec, 1, **{"GTR rates": k["rates"], "frequencies": k["frequencies"]})
+    g = eng.rooted_gradients(pids, bls, pr, rates, [1], h, bd, ra)
+    O.set_transition_mode(1)
+    og = O.rooted_gradients(spec, tips, w, pids, bls, pr, rates, [1], h, bd, ra)
+    O.set_transition_mode(0)
+    assert abs(g[0].log_likelihood - k["log_likelihood_no_jacobian"]) < k["tol"]
+    assert np.all(np.abs(g[0].gradient["substitution_model"]
+                         - k["substitution_model_gradient"]) < k["tol"])
+    assert np.allclose(g[0].gradient["substitution_model"], og["substitution_model"][0],
+                       rtol=1e-6, atol=1e-4)
+    assert _close(g[0].gradient["ratios_root_height"], og["ratios_root_height"][0])
+    k = K["flua_jc69_weibull4_shape0.1"]
+    eng, spec, tips, w, pids, bls, rates, h, bd, ra = _flua("JC69", "weibull+4")
+    pr = _params(spec, 1, **{"Weibull shape": k["shape"]})
+    ll = eng.rooted_log_likelihoods(pids, bls, pr, rates, h, bd)
+    jac = K["flua_jc69_strict"]["log_det_jacobian"]
+    assert abs(ll[0] - (k["log_likelihood_no_jacobian"] + jac)) < k["ll_tol"]
+    g = eng.rooted_gradients(pids, bls, pr, rates, [1], h, bd, ra)
+    og = O.rooted_gradients(spec, tips, w, pids, bls, pr, rates, [1], h, bd, ra)
+    assert abs(g[0].gradient["site_model"][0] - k["site_model_gradient"]) < k["grad_tol"]
+    assert abs(g[0].gradient["site_model"][0] - og["site_model"][0]) <= 1e-9
+
+
+@pytest.mark.parametrize("n,P,site", [(3, 1, "constant"), (4, 63, "weibull+4"),
+                                      (5, 64, "constant"), (8, 65, "weibull+3"),
+                                      (33, 200, "weibull+4"), (70, 129, "constant")])
+def test_random_unrooted_vs_oracle(n, P, site):
+    rng = np.random.default_rng(1000 + n)
+    tips, w = TU.random_alignment(n, P, rng)
+    T = 5
+    pids, bls = TU.random_trees(n, T, rng)
+    pids[-1] = TU.ladder_topology(n)
+    bls[0, 0] = 0.0  # zero-length branches are legal inputs
+    rates, freqs = TU.random_gtr_params(T, rng)
+    eng = _engine("GTR", site, "none", tips, w)
+    spec = O.make_spec(n, P, "GTR", site, "none")
+    blocks = {"GTR rates": rates, "frequencies": freqs}
+    if site != "constant":
+        blocks["Weibull shape"] = rng.uniform(0.2, 3.0, size=(T, 1))
+    pr = _params(spec, T, **blocks)
+    for resc in (False, True):
+        ll = eng.log_likelihoods(pids, bls, pr, resc)
+        oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, resc, 4)
+        assert np.all(np.abs(ll - oll) <= RTOL * np.abs(oll))
+        g = eng.gradients(pids, bls, pr, resc)
+        og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 4)
+        for t in range(T):
+            assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t])
+            assert abs(g[t].log_likelihood - oll[t]) <= RTOL * abs(oll[t])
+
+
+def test_random_rooted_vs_oracle():
+    rng = np.random.default_rng(7)
+    n, P, T = 12, 77, 4
+    tips, w = TU.random_alignment(n, P, rng)
+    N = 2 * n - 1
+    pids, bls, hs, bds, ras = [], [], [], [], []
+    for _ in range(T):
+        pid, bl, dates = TU.clocklike_rooted_tree(n, rng)
+        h, bd, ra = O.time_tree_init(n, pid, bl, dates)
+        pids.append(pid); bls.append(bl); hs.append(h); bds.append(bd); ras.append(ra)
+    pids, bls, hs, bds, ras = map(np.stack, (pids, bls, hs, bds, ras))
+    rates = rng.uniform(0.01, 0.1, size=(T, N - 1))
+    rcounts = [N - 1, 1, N - 1, 1]
+    rates[1] = rates[1, 0]
+    rates[3] = rates[3, 0]
+    eng = _engine("JC69", "weibull+4", "strict", tips, w)
+    spec = O.make_spec(n, P, "JC69", "weibull+4", "strict")
+    pr = _params(spec, T, **{"Weibull shape": rng.uniform(0.3, 2, size=(T, 1))})
+    ll = eng.rooted_log_likelihoods(pids, bls, pr, rates, hs, bds)
+    assert _close(ll, O.rooted_log_likelihoods(spec, tips, w, pids, bls, pr, rates, hs, bds))
+    g = eng.rooted_gradients(pids, bls, pr, rates, rcounts, hs, bds, ras)
+    og = O.rooted_gradients(spec, tips, w, pids, bls, pr, rates, rcounts, hs, bds, ras)
+    for t in range(T):
+        assert _close(g[t].gradient["ratios_root_height"], og["ratios_root_height"][t])
+        oc = og["clock_model"][t, :1] if rcounts[t] == 1 else og["clock_model"][t]
+        assert _close(g[t].gradient["clock_model"], oc)
+        assert abs(g[t].gradient["site_model"][0] - og["site_model"][t]) <= \
+            1e-9 * max(1.0, abs(og["site_model"][t]))
+
+
+def test_input_errors_are_reported_not_ub():
+    rng = np.random.default_rng(3)
+    tips, w = TU.random_alignment(5, 10, rng)
+    pids, bls = TU.random_trees(5, 3, rng)
+    eng = _engine("GTR", "constant", "strict", tips, w)
+    spec = O.make_spec(5, 10, "GTR")
+    good = _params(spec, 3, **{"GTR rates": [1 / 6] * 6, "frequencies": [0.25] * 4})
+    bad = good.copy()
+    bad[1, 6:10] = 0.3
+    with pytest.raises(RuntimeError, match="frequencies do not sum"):
+        eng.log_likelihoods(pids, bls, bad)
+    bad = good.copy()
+    bad[2, 0:6] = 0.2
+    with pytest.raises(RuntimeError, match="rates do not sum"):
+        eng.log_likelihoods(pids, bls, bad)
+    broken = pids.copy()
+    broken[0, 0] = 0
+    with pytest.raises(RuntimeError, match="parent id"):
+        eng.log_likelihoods(broken, bls, good)
+    with pytest.raises(RuntimeError, match="as many rows"):
+        eng.log_likelihoods(pids, bls, good[:2])
+    # engine still usable afterwards
+    assert np.all(np.isfinite(eng.log_likelihoods(pids, bls, good)))
+    import libsbn_amd as L
+    with pytest.raises(RuntimeError, match="Thread count"):
+        L.Engine(L.PhyloModelSpecification(), tips, w, thread_count=0)
+    with pytest.raises(RuntimeError, match="not known"):
+        L.Engine(L.PhyloModelSpecification("HKY", "constant", "strict"), tips, w)
+
+
+def test_full_size_properties_ds1_1000_trees():
+    """BASELINE config 2/3 size: DS1 x 1000 trees (100 topologies x 10 branch-length
+    draws), JC69 + weibull+4.  Size-independent properties + an oracle sample."""
+    rng = np.random.default_rng(43)
+    st = O.load_struct("ds1_top100")
+    tips, w, pids100, _ = O.struct_arrays(st)
+    T = 1000
+    pids = np.tile(pids100, (10, 1))
+    bls = rng.exponential(0.1, size=(T, 52))
+    bls[:, -1] = 0
+    eng = _engine("JC69", "weibull+4", "strict", tips, w)
+    spec = O.make_spec(27, 934, "JC69", "weibull+4")
+    pr = _params(spec, T, **{"Weibull shape": 1.0})
+    ll = eng.log_likelihoods(pids, bls, pr)
+    g = eng.gradients(pids, bls, pr)
+    gll = np.array([x.log_likelihood for x in g])
+    gb = _grad_matrix(g, "branch_lengths")
+    # (1) both entry points agree on logL
+    assert np.all(np.abs(ll - gll) <= 1e-12 * np.abs(ll))
+    # (2) permutation equivariance / determinism: reversed batch gives reversed results
+    ll_rev = eng.log_likelihoods(pids[::-1], bls[::-1], pr)
+    assert np.array_equal(ll_rev[::-1], ll)
+    # (3) rescaling is result-neutral
+    ll_resc = eng.log_likelihoods(pids, bls, pr, True)
+    assert np.all(np.abs(ll_resc - ll) <= 1e-12 * np.abs(ll))
+    # (4) directional derivative: logL(bl + eps d) - logL(bl - eps d) ~ 2 eps g.d
+    d = rng.normal(size=bls.shape) * bls  # relative perturbation: lengths stay positive
+    eps = 1e-6
+    lp = eng.log_likelihoods(pids, bls + eps * d, pr)
+    lm = eng.log_likelihoods(pids, bls - eps * d, pr)
+    fd = (lp - lm) / (2 * eps)
+    an = np.sum(gb[:, :52] * d, axis=1)
+    assert np.all(np.abs(fd - an) <= 1e-5 * np.maximum(1.0, np.abs(an)))
+    # (5) oracle on a sample of the batch
+    idx = rng.choice(T, size=12, replace=False)
+    oll = O.unrooted_log_likelihoods(spec, tips, w, pids[idx], bls[idx], pr[idx], False, 4)
+    assert np.all(np.abs(ll[idx] - oll) <= RTOL * np.abs(oll))
+    og = O.unrooted_gradients(spec, tips, w, pids[idx], bls[idx], pr[idx], False, 4)
+    for j, t in enumerate(idx):
+        assert _close(gb[t], og["branch_lengths"][j])

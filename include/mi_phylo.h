@@ -193,6 +193,15 @@ int32_t mi_engine_check_status(mi_engine* engine, void* stream);
 int32_t mi_engine_last_call_info(const mi_engine* engine, const char** dominant_kernel,
                                  int64_t* evaluations, int64_t* gradient_evaluations);
 
+/* Kernel timing for bench.py: after mi_engine_profile_begin(engine, max_calls)
+ * every call brackets its dominant kernel launch(es) with a pair of HIP events on
+ * the call's stream (no synchronisation).  mi_engine_profile_collect()
+ * synchronises on the recorded events, writes one duration in milliseconds per
+ * profiled call and stops profiling. */
+int32_t mi_engine_profile_begin(mi_engine* engine, int32_t max_calls);
+int32_t mi_engine_profile_collect(mi_engine* engine, double* out_ms, int32_t capacity,
+                                  int32_t* out_count);
+
 #ifdef __cplusplus
 }
 #endif

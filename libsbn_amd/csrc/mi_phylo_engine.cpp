@@ -94,6 +94,9 @@ struct mi_engine {
   Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
       in_ratios, out_ll, out_a, out_b, out_site, out_subst;
   size_t plv_budget = (size_t)8 << 30;
+  // kernel timing (bench.py)
+  std::vector<hipEvent_t> prof_events;  // pairs
+  int prof_capacity = 0, prof_used = 0;
   // last-call info
   const char* dominant = "";
   int64_t last_evals = 0, last_grad_evals = 0;
@@ -248,12 +251,16 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     }
   };
 
+  const bool prof = e->prof_used < e->prof_capacity;
+  if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used], s));
   if (!d.gradient) {
     la.eval_offset = 0;
     launch_loglik(la, T, d.rescaling, e->max_slots, s);
     e->dominant = loglik_kernel_name();
+    if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used + 1], s));
   } else {
     grad_range(0, 0, T);
+    if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used + 1], s));
     if (c.gtr) {
       LikArgs l = la;
       l.eval_offset = T;
@@ -262,6 +269,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     if (c.site_separate) grad_range(17 * T, T, T);
     e->dominant = gradient_kernel_name();
   }
+  if (prof) e->prof_used++;
   e->last_evals = c.E;
   e->last_grad_evals = c.Eg;
 
@@ -455,6 +463,7 @@ void mi_engine_destroy(mi_engine* e) {
         &e->in_heights, &e->in_bounds, &e->in_ratios, &e->out_ll, &e->out_a, &e->out_b,
         &e->out_site, &e->out_subst})
     b->release();
+  for (hipEvent_t ev : e->prof_events) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -480,6 +489,36 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
 int32_t mi_engine_check_status(mi_engine* e, void* stream) {
   if (!e) return fail("null engine");
   return check_status(e, pick_stream(e, stream));
+}
+
+int32_t mi_engine_profile_begin(mi_engine* e, int32_t max_calls) {
+  if (!e) return fail("null engine");
+  if (max_calls < 0) return fail("max_calls must be >= 0");
+  HIP_TRY(hipSetDevice(e->spec.device));
+  while ((int)e->prof_events.size() < 2 * max_calls) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreate(&ev));
+    e->prof_events.push_back(ev);
+  }
+  e->prof_capacity = max_calls;
+  e->prof_used = 0;
+  return 0;
+}
+
+int32_t mi_engine_profile_collect(mi_engine* e, double* out_ms, int32_t capacity,
+                                  int32_t* out_count) {
+  if (!e) return fail("null engine");
+  const int count = std::min(e->prof_used, capacity);
+  for (int i = 0; i < count; i++) {
+    HIP_TRY(hipEventSynchronize(e->prof_events[2 * i + 1]));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e->prof_events[2 * i], e->prof_events[2 * i + 1]));
+    if (out_ms) out_ms[i] = ms;
+  }
+  if (out_count) *out_count = count;
+  e->prof_capacity = 0;
+  e->prof_used = 0;
+  return 0;
 }
 
 int32_t mi_engine_last_call_info(const mi_engine* e, const char** dominant_kernel,

@@ -222,6 +222,15 @@ class Engine:
     def check_status(self, stream=None):
         self._check(self._lib.mi_engine_check_status(self._h, stream))
 
+    def profile_begin(self, max_calls):
+        self._check(self._lib.mi_engine_profile_begin(self._h, max_calls))
+
+    def profile_collect(self, capacity):
+        out = (C.c_double * capacity)()
+        cnt = C.c_int32()
+        self._check(self._lib.mi_engine_profile_collect(self._h, out, capacity, C.byref(cnt)))
+        return [out[i] for i in range(cnt.value)]
+
     def last_call_info(self):
         name, ev, gev = C.c_char_p(), C.c_int64(), C.c_int64()
         self._check(self._lib.mi_engine_last_call_info(self._h, C.byref(name), C.byref(ev),

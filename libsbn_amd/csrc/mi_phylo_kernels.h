@@ -41,6 +41,7 @@ struct TreeSetupArgs {
   double* bl_eff;             // [T][N]
   int32_t* status;            // [2]: code, tree
   int max_slots;
+  int use_lds;  // set by the launcher
 };
 
 struct ModelSetupArgs {
@@ -98,6 +99,7 @@ struct FinalizeArgs {
   double* out_site;            // [T] or nullptr
   double* out_subst;           // [T][8] or nullptr
   int32_t* status;
+  int use_lds;  // set by the launcher
 };
 
 void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s);

@@ -93,13 +93,17 @@ __device__ __forceinline__ void set_status(int32_t* status, int code, int tree) 
 // labels so that the on-chip kernel needs at most floor(log2 n)+1 live
 // partial-likelihood vectors; any post-order gives bitwise the same vectors.
 // ------------------------------------------------------------------------
-__global__ void tree_setup_kernel(TreeSetupArgs a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.T) return;
+__global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
+  // One wave per tree.  The walk itself is sequential (lane 0); its working set
+  // lives in LDS (12 N ints) unless the tree is too large, and the bulk copies
+  // (branch lengths, schedule) are done by all 64 lanes.
+  extern __shared__ int32_t ts_lds[];
+  const int t = blockIdx.x;
+  const int lane = threadIdx.x;
   const int n = a.n, N = 2 * n - 1;
   const int nodes_in = a.rooted ? N : N - 1;
   const int32_t* par = a.parent_ids + (size_t)t * (nodes_in - 1);
-  int32_t* maxleaf = a.scratch + (size_t)t * 12 * N;
+  int32_t* maxleaf = a.use_lds ? ts_lds : a.scratch + (size_t)t * 12 * N;
   int32_t* cnt = maxleaf + N;
   int32_t* kids = cnt + N;  // 3 per node
   int32_t* c0 = kids + 3 * N;
@@ -107,109 +111,111 @@ __global__ void tree_setup_kernel(TreeSetupArgs a) {
   int32_t* label = c1 + N;
   int32_t* slot = label + N;
   int32_t* stack = slot + N;  // 2N
+  __shared__ int ok_flag;
   SchedEntry* sched = a.sched + (size_t)t * (n - 1);
   double* ble = a.bl_eff + (size_t)t * N;
 
-  for (int v = 0; v < N; v++) {
+  for (int v = lane; v < N; v += 64) {
     maxleaf[v] = v < n ? v : -1;
     cnt[v] = 0;
     label[v] = 0;
     slot[v] = 0;
     c0[v] = c1[v] = 0;
   }
-  bool ok = true;
-  for (int v = 0; v < nodes_in - 1; v++) {
-    const int p = par[v];
-    if (p <= v || p >= nodes_in || p < n) {
-      ok = false;
-      break;
+  __syncthreads();
+  if (lane == 0) {
+    int status = kOk;
+    for (int v = 0; v < nodes_in - 1; v++) {
+      const int p = par[v];
+      if (p <= v || p >= nodes_in || p < n) {
+        status = kBadParentIds;
+        break;
+      }
+      if (maxleaf[v] > maxleaf[p]) maxleaf[p] = maxleaf[v];
     }
-    if (maxleaf[v] > maxleaf[p]) maxleaf[p] = maxleaf[v];
+    for (int v = 0; v < nodes_in - 1 && status == kOk; v++) {
+      const int p = par[v];
+      int k = cnt[p];
+      if (k >= 3) {
+        status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
+        break;
+      }
+      while (k > 0 && maxleaf[kids[3 * p + k - 1]] > maxleaf[v]) {
+        kids[3 * p + k] = kids[3 * p + k - 1];
+        k--;
+      }
+      kids[3 * p + k] = v;
+      cnt[p]++;
+    }
+    const int root_in = nodes_in - 1;
+    for (int v = n; v < nodes_in && status == kOk; v++) {
+      const int want = (!a.rooted && v == root_in) ? 3 : 2;
+      if (cnt[v] != want) status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
+    }
+    if (status == kOk) {
+      for (int v = n; v < nodes_in; v++) {
+        c0[v] = kids[3 * v];
+        c1[v] = kids[3 * v + 1];
+      }
+      if (!a.rooted) {
+        // (k0,k1,k2) at root r  ->  r = (k1,k2), r+1 = (k0, r)
+        const int r = root_in;
+        c0[r] = kids[3 * r + 1];
+        c1[r] = kids[3 * r + 2];
+        c0[r + 1] = kids[3 * r];
+        c1[r + 1] = r;
+      }
+      // Sethi-Ullman labels (tips cost nothing: they are read in compact form).
+      for (int v = n; v < N; v++) {
+        const int l0 = label[c0[v]], l1 = label[c1[v]];
+        label[v] = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
+      }
+      // Post-order DFS, heavier child first; slots from a free bitmask.
+      uint32_t free_mask = 0xffffffffu;
+      int top = 0, out = 0;
+      stack[top++] = (N - 1) << 1;
+      int used_max = 0;
+      while (top) {
+        const int item = stack[--top];
+        const int v = item >> 1;
+        if (item & 1) {
+          const int a0 = c0[v], a1 = c1[v];
+          if (a0 >= n) free_mask |= 1u << slot[a0];
+          if (a1 >= n) free_mask |= 1u << slot[a1];
+          const int sl = __ffs(free_mask) - 1;
+          free_mask &= ~(1u << sl);
+          slot[v] = sl;
+          if (sl + 1 > used_max) used_max = sl + 1;
+          sched[out++] = {v, a0, a1, sl | (slot[a0] << 8) | (slot[a1] << 16)};
+        } else {
+          stack[top++] = (v << 1) | 1;
+          const int a0 = c0[v], a1 = c1[v];
+          const bool first0 = label[a0] >= label[a1];
+          const int lo = first0 ? a1 : a0, hi = first0 ? a0 : a1;
+          if (lo >= n) stack[top++] = lo << 1;
+          if (hi >= n) stack[top++] = hi << 1;  // popped first
+        }
+      }
+      if (used_max > a.max_slots) status = kTooManySlots;
+    }
+    if (status != kOk) set_status(a.status, status, t);
+    ok_flag = status == kOk || status == kTooManySlots;
   }
-  if (!ok) {
-    set_status(a.status, kBadParentIds, t);
-    for (int i = 0; i < n - 1; i++) sched[i] = {n + i, 0, 1, 0};
-    for (int v = 0; v < N; v++) ble[v] = 0.0;
+  __syncthreads();
+  if (!ok_flag) {
+    for (int i = lane; i < n - 1; i += 64) sched[i] = {n + i, 0, 1, 0};
+    for (int v = lane; v < N; v += 64) ble[v] = 0.0;
     return;
-  }
-  for (int v = 0; v < nodes_in - 1 && ok; v++) {
-    const int p = par[v];
-    int k = cnt[p];
-    if (k >= 3) {
-      ok = false;
-      break;
-    }
-    while (k > 0 && maxleaf[kids[3 * p + k - 1]] > maxleaf[v]) {
-      kids[3 * p + k] = kids[3 * p + k - 1];
-      k--;
-    }
-    kids[3 * p + k] = v;
-    cnt[p]++;
-  }
-  const int root_in = nodes_in - 1;
-  for (int v = n; v < nodes_in && ok; v++) {
-    const int want = (!a.rooted && v == root_in) ? 3 : 2;
-    if (cnt[v] != want) ok = false;
-  }
-  if (!ok) {
-    set_status(a.status, a.rooted ? kNotBifurcating : kNotTrifurcatingRoot, t);
-    for (int i = 0; i < n - 1; i++) sched[i] = {n + i, 0, 1, 0};
-    for (int v = 0; v < N; v++) ble[v] = 0.0;
-    return;
-  }
-  for (int v = n; v < nodes_in; v++) {
-    c0[v] = kids[3 * v];
-    c1[v] = kids[3 * v + 1];
   }
   if (!a.rooted) {
-    // (k0,k1,k2) at root r  ->  r = (k1,k2), r+1 = (k0, r)
-    const int r = root_in;
-    c0[r] = kids[3 * r + 1];
-    c1[r] = kids[3 * r + 2];
-    c0[r + 1] = kids[3 * r];
-    c1[r + 1] = r;
     const double* bl = a.bl + (size_t)t * (N - 1);
-    for (int v = 0; v < N - 2; v++) ble[v] = bl[v];
-    ble[N - 2] = 0.0;
-    ble[N - 1] = 0.0;
+    for (int v = lane; v < N; v += 64) ble[v] = v < N - 2 ? bl[v] : 0.0;
   } else {
     const double* bl = a.bl + (size_t)t * N;
     const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
-    for (int v = 0; v < N - 1; v++) ble[v] = rates ? bl[v] * rates[v] : bl[v];
-    ble[N - 1] = bl[N - 1];
+    for (int v = lane; v < N; v += 64)
+      ble[v] = (rates && v < N - 1) ? bl[v] * rates[v] : bl[v];
   }
-  // Sethi-Ullman labels (tips cost nothing: they are read in compact form).
-  for (int v = n; v < N; v++) {
-    const int l0 = label[c0[v]], l1 = label[c1[v]];
-    label[v] = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
-  }
-  // Post-order DFS, heavier child first; slots from a free bitmask.
-  uint32_t free_mask = 0xffffffffu;
-  int top = 0, out = 0;
-  stack[top++] = (N - 1) << 1;
-  int used_max = 0;
-  while (top) {
-    const int item = stack[--top];
-    const int v = item >> 1;
-    if (item & 1) {
-      const int a0 = c0[v], a1 = c1[v];
-      if (a0 >= n) free_mask |= 1u << slot[a0];
-      if (a1 >= n) free_mask |= 1u << slot[a1];
-      const int s = __ffs(free_mask) - 1;
-      free_mask &= ~(1u << s);
-      slot[v] = s;
-      if (s + 1 > used_max) used_max = s + 1;
-      sched[out++] = {v, a0, a1, s | (slot[a0] << 8) | (slot[a1] << 16)};
-    } else {
-      stack[top++] = (v << 1) | 1;
-      const int a0 = c0[v], a1 = c1[v];
-      const bool first0 = label[a0] >= label[a1];
-      const int lo = first0 ? a1 : a0, hi = first0 ? a0 : a1;
-      if (lo >= n) stack[top++] = lo << 1;
-      if (hi >= n) stack[top++] = hi << 1;  // popped first
-    }
-  }
-  if (used_max > a.max_slots) set_status(a.status, kTooManySlots, t);
 }
 
 // ------------------------------------------------------------------------
@@ -715,94 +721,100 @@ __device__ void ratio_transform(int n, const int32_t* c0, const int32_t* c1, con
   out[root - n] = sum;
 }
 
-__global__ void finalize_kernel(FinalizeArgs a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.T) return;
+__global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
+  // One wave per tree: lanes run over nodes / tiles for the reductions, lane 0
+  // walks the O(n) recurrences of the rooted chain rule.  Working set (6n
+  // doubles) in LDS unless the tree is too large.
+  extern __shared__ double fin_lds[];
+  const int t = blockIdx.x, lane = threadIdx.x;
   const int n = a.n, N = a.N, T = a.T, tiles = a.tiles;
-  const double ll = sum_tiles(a.ll_part + (size_t)t * tiles, tiles);
-
-  // children by node id (the schedule is a permutation of the internal nodes)
-  // kept in scratch as doubles-sized ints is wasteful; use the int view.
-  int32_t* c0 = reinterpret_cast<int32_t*>(a.scratch + (size_t)t * 6 * n);
+  double* base = a.use_lds ? fin_lds : a.scratch + (size_t)t * 6 * n;
+  int32_t* c0 = reinterpret_cast<int32_t*>(base);
   int32_t* c1 = c0 + n;
-  double* work = a.scratch + (size_t)t * 6 * n + n;  // 5n doubles
+  double* work = base + n;  // 5n doubles
   const SchedEntry* sched = a.sched + (size_t)t * (n - 1);
-  for (int i = 0; i < n - 1; i++) {
-    c0[sched[i].node - n] = sched[i].child0;
-    c1[sched[i].node - n] = sched[i].child1;
+  for (int i = lane; i < n - 1; i += 64) {
+    const SchedEntry se = sched[i];
+    c0[se.node - n] = se.child0;
+    c1[se.node - n] = se.child1;
   }
-
-  double jac = 0.0;
-  if (a.rooted && (a.with_jacobian || (a.gradient && a.gtr))) {
-    // fat_beagle.cpp:82-94; iteration order of TripleIdPreorderBifurcating
-    // (node.cpp:226-261) reproduced with an explicit stack in `work`.
-    const double* h = a.node_heights + (size_t)t * N;
-    const double* bd = a.node_bounds + (size_t)t * N;
-    int32_t* st = reinterpret_cast<int32_t*>(work);
-    int top = 0;
-    st[top++] = (N - 1) << 1;
-    while (top) {
-      const int item = st[--top];
-      const int v = item >> 1;
-      const int a0 = c0[v - n], a1 = c1[v - n];
-      if (item & 1) {
-        if (a1 >= n) {
-          jac += log(h[v] - bd[a1]);
-          st[top++] = a1 << 1;
-        }
-      } else {
-        st[top++] = (v << 1) | 1;
-        if (a0 >= n) {
-          jac += log(h[v] - bd[a0]);
-          st[top++] = a0 << 1;
+  __syncthreads();
+  __shared__ double sh_ll, sh_jac;
+  if (lane == 0) {
+    sh_ll = sum_tiles(a.ll_part + (size_t)t * tiles, tiles);
+    double jac = 0.0;
+    if (a.rooted && (a.with_jacobian || (a.gradient && a.gtr))) {
+      // fat_beagle.cpp:82-94; iteration order of TripleIdPreorderBifurcating
+      // (node.cpp:226-261) reproduced with an explicit stack in `work`.
+      const double* h = a.node_heights + (size_t)t * N;
+      const double* bd = a.node_bounds + (size_t)t * N;
+      int32_t* st = reinterpret_cast<int32_t*>(work);
+      int top = 0;
+      st[top++] = (N - 1) << 1;
+      while (top) {
+        const int item = st[--top];
+        const int v = item >> 1;
+        const int a0 = c0[v - n], a1 = c1[v - n];
+        if (item & 1) {
+          if (a1 >= n) {
+            jac += log(h[v] - bd[a1]);
+            st[top++] = a1 << 1;
+          }
+        } else {
+          st[top++] = (v << 1) | 1;
+          if (a0 >= n) {
+            jac += log(h[v] - bd[a0]);
+            st[top++] = a0 << 1;
+          }
         }
       }
     }
+    sh_jac = jac;
   }
-
+  __syncthreads();
+  const double ll = sh_ll, jac = sh_jac;
   if (!a.gradient) {
-    a.out_ll[t] = a.with_jacobian ? ll + jac : ll;
+    if (lane == 0) a.out_ll[t] = a.with_jacobian ? ll + jac : ll;
     return;
   }
-  a.out_ll[t] = ll;
+  if (lane == 0) a.out_ll[t] = ll;
   const double* ble = a.bl_eff + (size_t)t * N;
-  // branch gradient of the main evaluation, tile partials summed in order
+  // branch gradient of the main evaluation: tile partials summed in tile order
   double* bg = work;  // N doubles (N < 2n)
-  for (int v = 0; v < N; v++) {
-    double s = 0;
-    for (int i = 0; i < tiles; i++) s += a.g_part[(((size_t)t * tiles + i) * 2) * N + v];
-    bg[v] = s;
+  for (int v = lane; v < N; v += 64) {
+    double sum = 0;
+    for (int i = 0; i < tiles; i++) sum += a.g_part[(((size_t)t * tiles + i) * 2) * N + v];
+    bg[v] = sum;
   }
   if (a.out_site && (a.site_fused || a.site_separate)) {
     // DiscreteSiteModelGradient fat_beagle.cpp:389-398
     const size_t gi = a.site_separate ? (size_t)T + t : (size_t)t;
     double r = 0;
-    for (int v = 0; v < N - 1; v++) {
-      double s = 0;
-      for (int i = 0; i < tiles; i++) s += a.g_part[((gi * tiles + i) * 2 + 1) * N + v];
-      r += s * ble[v];
+    for (int v = lane; v < N - 1; v += 64) {
+      double sum = 0;
+      for (int i = 0; i < tiles; i++) sum += a.g_part[((gi * tiles + i) * 2 + 1) * N + v];
+      r += sum * ble[v];
     }
-    a.out_site[t] = r;
+    r = wave_sum(r);
+    if (lane == 0) a.out_site[t] = r;
   }
-  if (a.gtr && a.out_subst) {
+  if (a.gtr && a.out_subst && lane < 8) {
     // fat_beagle.cpp:431,455-464: rates (5) then frequencies (3)
-    for (int i = 0; i < 8; i++) {
-      const int coord = i < 5 ? 3 + i : i - 5;
-      const size_t ep = (size_t)T + (size_t)t * 16 + 2 * coord;
-      double lp = sum_tiles(a.ll_part + ep * tiles, tiles);
-      double lm = sum_tiles(a.ll_part + (ep + 1) * tiles, tiles);
-      if (a.rooted) {
-        lp += jac;
-        lm += jac;
-      }
-      a.out_subst[(size_t)t * 8 + i] = (lp - lm) / (2. * 1.e-6);
+    const int coord = lane < 5 ? 3 + lane : lane - 5;
+    const size_t ep = (size_t)T + (size_t)t * 16 + 2 * coord;
+    double lp = sum_tiles(a.ll_part + ep * tiles, tiles);
+    double lm = sum_tiles(a.ll_part + (ep + 1) * tiles, tiles);
+    if (a.rooted) {
+      lp += jac;
+      lm += jac;
     }
+    a.out_subst[(size_t)t * 8 + lane] = (lp - lm) / (2. * 1.e-6);
   }
+  __syncthreads();
   if (!a.rooted) {
     double* ob = a.out_branch + (size_t)t * N;
-    for (int v = 0; v < N; v++) ob[v] = bg[v];
-    ob[N - 2] = 0.0;  // fixed node = second child of the root (fat_beagle.cpp:499)
-    ob[N - 1] = 0.0;
+    // fixed node = second child of the root (fat_beagle.cpp:499); root entry is 0
+    for (int v = lane; v < N; v += 64) ob[v] = v < N - 2 ? bg[v] : 0.0;
     return;
   }
   // ---- rooted: clock + ratios/root-height gradients ----
@@ -811,22 +823,24 @@ __global__ void finalize_kernel(FinalizeArgs a) {
   double* oc = a.out_clock + (size_t)t * (N - 1);
   const int rc = a.rate_counts[t];
   if (rc == 1) {
+    // ClockGradient fat_beagle.cpp:367-387 (strict): sum_i g_i * t_i
     double acc = 0;
-    for (int v = 0; v < N - 1; v++) acc += bg[v] * tb[v];
-    for (int v = 0; v < N - 1; v++) oc[v] = 0;
-    oc[0] = acc;
+    for (int v = lane; v < N - 1; v += 64) acc += bg[v] * tb[v];
+    acc = wave_sum(acc);
+    for (int v = lane; v < N - 1; v += 64) oc[v] = v == 0 ? acc : 0.0;
   } else if (rc == N - 1) {
-    for (int v = 0; v < N - 1; v++) oc[v] = bg[v] * tb[v];
+    for (int v = lane; v < N - 1; v += 64) oc[v] = bg[v] * tb[v];
   } else {
-    set_status(a.status, kBadRateCount, t);
-    for (int v = 0; v < N - 1; v++) oc[v] = 0;
+    if (lane == 0) set_status(a.status, kBadRateCount, t);
+    for (int v = lane; v < N - 1; v += 64) oc[v] = 0;
   }
+  if (lane != 0) return;
   const double* h = a.node_heights + (size_t)t * N;
   const double* bd = a.node_bounds + (size_t)t * N;
   const double* ratios = a.height_ratios + (size_t)t * (n - 1);
-  double* hg = work + 2 * n;       // n-1
-  double* aux = work + 3 * n;      // n-1 (log_time, then multipliers)
-  double* jacg = work + 4 * n;     // n-1
+  double* hg = work + 2 * n;    // n-1
+  double* aux = work + 3 * n;   // n-1 (log_time)
+  double* jacg = work + 4 * n;  // n-1
   double* outr = a.out_ratios + (size_t)t * (n - 1);
   // HeightGradient rooted_gradient_transforms.cpp:17-37
   for (int v = N - 1; v >= n; v--) {
@@ -835,9 +849,7 @@ __global__ void finalize_kernel(FinalizeArgs a) {
     x += bg[c1[v - n]] * rates[c1[v - n]];
     hg[v - n] = x;
   }
-  // work[0..2n) (bg) is dead from here on except nothing below reads it; use
-  // work[0..n) as the multiplier array.
-  double* mult = work;
+  double* mult = work;  // bg is dead from here on
   ratio_transform(n, c0, c1, h, ratios, bd, hg, mult, outr);
   for (int i = 0; i < n - 1; i++) aux[i] = 0;
   for (int i = 0; i < n - 2; i++) aux[i] = 1.0 / (h[n + i] - bd[n + i]);
@@ -851,8 +863,11 @@ __global__ void finalize_kernel(FinalizeArgs a) {
 // ------------------------------------------------------------------------
 // Launch wrappers
 // ------------------------------------------------------------------------
-void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(tree_setup_kernel, dim3((a.T + 63) / 64), dim3(64), 0, s, a);
+void launch_tree_setup(const TreeSetupArgs& a_in, hipStream_t s) {
+  TreeSetupArgs a = a_in;
+  const size_t lds = sizeof(int32_t) * 12 * (size_t)(2 * a.n - 1);
+  a.use_lds = lds <= 48 * 1024;
+  hipLaunchKernelGGL(tree_setup_kernel, dim3(a.T), dim3(64), a.use_lds ? lds : 0, s, a);
 }
 void launch_model_setup(const ModelSetupArgs& a, hipStream_t s) {
   const int total = a.T * a.models_per_tree;
@@ -888,8 +903,11 @@ void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t 
     else hipLaunchKernelGGL((gradient_hbm_kernel<false, false>), grid, block, 0, s, a);
   }
 }
-void launch_finalize(const FinalizeArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(finalize_kernel, dim3((a.T + 63) / 64), dim3(64), 0, s, a);
+void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
+  FinalizeArgs a = a_in;
+  const size_t lds = sizeof(double) * 6 * (size_t)a.n;
+  a.use_lds = lds <= 48 * 1024;
+  hipLaunchKernelGGL(finalize_kernel, dim3(a.T), dim3(64), a.use_lds ? lds : 0, s, a);
 }
 
 const char* loglik_kernel_name() { return "loglik_onchip_kernel"; }

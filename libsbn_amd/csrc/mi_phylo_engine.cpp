@@ -89,7 +89,9 @@ struct mi_engine {
   // static device data
   Buffer tip_states, tip_partials, weights;
   // per-call workspace
-  Buffer tree_scratch, sched, bl_eff, models, mats, ll_part, plv, g_part, fin_scratch, status;
+  Buffer tree_scratch, sched, bl_eff, models, mats, ll_part, plv, g_part, site_lik, fin_scratch,
+      status;
+  bool allow_onchip_gradient = true;
   // staging for the host-pointer entry points
   Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
       in_ratios, out_ll, out_a, out_b, out_site, out_subst;
@@ -132,7 +134,7 @@ size_t plv_bytes_per_eval(const mi_engine* e) {
   return (size_t)(e->n - 1) * e->K * e->tiles * kTile * 4 * sizeof(double);
 }
 
-int reserve(mi_engine* e, int T, bool gradient) {
+int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
   const CallShape c = call_shape(e, T, gradient);
   const int n = e->n, N = e->N;
   if (e->tree_scratch.ensure(sizeof(int32_t) * (size_t)T * 12 * N)) return 1;
@@ -144,10 +146,13 @@ int reserve(mi_engine* e, int T, bool gradient) {
   if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
   if (e->status.ensure(sizeof(int32_t) * 2)) return 1;
   if (gradient) {
+    // the HBM-streamed kernel is the fallback for rescaling / trees that do not fit
+    // in LDS; its arena is only allocated when that path can be taken
     const size_t per = plv_bytes_per_eval(e);
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / per));
-    if (e->plv.ensure(per * chunk)) return 1;
+    if (need_hbm_path && e->plv.ensure(per * chunk)) return 1;
     if (e->g_part.ensure(sizeof(double) * (size_t)c.Eg * e->tiles * 2 * N)) return 1;
+    if (e->site_lik.ensure(sizeof(double) * (size_t)c.Eg * e->tiles * kTile)) return 1;
   }
   return 0;
 }
@@ -176,7 +181,9 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   if (d.T <= 0) return fail("tree_count must be positive");
   if (!d.parent_ids || !d.bl || !d.out_ll) return fail("null tree / output pointer");
   if (e->param_count > 0 && !d.params) return fail("null parameter matrix");
-  if (reserve(e, d.T, d.gradient)) return 1;
+  const bool onchip = d.gradient && !d.rescaling && e->allow_onchip_gradient &&
+                      e->spec.use_tip_states && gradient_onchip_fits(e->n);
+  if (reserve(e, d.T, d.gradient, !onchip)) return 1;
   const CallShape c = call_shape(e, d.T, d.gradient);
   const int n = e->n, N = e->N, T = d.T;
   HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, s));
@@ -240,7 +247,19 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.plv = e->plv.as<double>();
   la.g_part = e->g_part.as<double>();
 
+  la.site_lik = nullptr;
   auto grad_range = [&](int eval_begin, int grad_begin, int count) {
+    if (onchip) {
+      // phase A: on-chip log-likelihood (also writes per-pattern site likelihoods),
+      // phase B: on-chip pre-order / edge derivatives
+      LikArgs g = la;
+      g.eval_offset = eval_begin;
+      g.grad_offset = grad_begin;
+      g.site_lik = e->site_lik.as<double>();
+      launch_loglik(g, count, false, e->max_slots, s);
+      launch_gradient_onchip(g, count, s);
+      return;
+    }
     const size_t per = plv_bytes_per_eval(e);
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>(count, e->plv.bytes / per));
     for (int done = 0; done < count; done += chunk) {
@@ -267,7 +286,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
       launch_loglik(l, 16 * T, d.rescaling, e->max_slots, s);
     }
     if (c.site_separate) grad_range(17 * T, T, T);
-    e->dominant = gradient_kernel_name();
+    e->dominant = onchip ? gradient_onchip_kernel_name() : gradient_kernel_name();
   }
   if (prof) e->prof_used++;
   e->last_evals = c.E;
@@ -387,6 +406,8 @@ int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
   while ((2 << lg) <= e->n) lg++;
   e->max_slots = lg + 1;
   if (const char* env = getenv("MI_PHYLO_PLV_BYTES")) e->plv_budget = strtoull(env, nullptr, 10);
+  if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH"))  // "hbm" forces the streamed kernel
+    e->allow_onchip_gradient = std::string(env) != "hbm";
 
   // BlockSpecification (block_specification.cpp:11-50, phylo_model.cpp:13-15)
   std::map<std::string, std::pair<int, int>> bm;
@@ -458,7 +479,8 @@ void mi_engine_destroy(mi_engine* e) {
   }
   for (Buffer* b :
        {&e->tip_states, &e->tip_partials, &e->weights, &e->tree_scratch, &e->sched, &e->bl_eff,
-        &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->fin_scratch, &e->status,
+        &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->fin_scratch,
+        &e->status,
         &e->in_parent, &e->in_bl, &e->in_params, &e->in_rates, &e->in_rate_counts,
         &e->in_heights, &e->in_bounds, &e->in_ratios, &e->out_ll, &e->out_a, &e->out_b,
         &e->out_site, &e->out_subst})
@@ -483,7 +505,9 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
   if (!e) return fail("null engine");
   if (tree_count <= 0) return fail("tree_count must be positive");
   HIP_TRY(hipSetDevice(e->spec.device));
-  return reserve(e, tree_count, for_gradients != 0);
+  const bool onchip = e->allow_onchip_gradient && e->spec.use_tip_states &&
+                      gradient_onchip_fits(e->n);
+  return reserve(e, tree_count, for_gradients != 0, !onchip);
 }
 
 int32_t mi_engine_check_status(mi_engine* e, void* stream) {

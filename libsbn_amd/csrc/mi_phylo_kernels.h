@@ -75,6 +75,7 @@ struct LikArgs {
   double* ll_part;             // [E][tiles]
   double* plv;                 // [Eg][n-1][K][tiles*64][4]   (gradient, v1)
   double* g_part;              // [Eg][tiles][2][N]
+  double* site_lik;            // [Eg][tiles*64] per-pattern site likelihood (on-chip gradient)
 };
 
 struct FinalizeArgs {
@@ -107,11 +108,18 @@ void launch_model_setup(const ModelSetupArgs& a, hipStream_t s);
 void launch_transition(const TransitionArgs& a, hipStream_t s);
 // On-chip (LDS-resident) log-likelihood: evaluations [eval_offset, eval_offset+count)
 void launch_loglik(const LikArgs& a, int count, bool rescale, int max_slots, hipStream_t s);
-// Gradient, partial-likelihood vectors streamed through HBM (v1)
+// Gradient, partial-likelihood vectors streamed through HBM (any tree size, rescaling)
 void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t s);
+// Gradient with all partial-likelihood vectors resident in LDS (no rescaling;
+// needs the per-pattern site likelihoods written by launch_loglik with
+// a.site_lik set).  Returns false when the tree does not fit in LDS.
+size_t gradient_onchip_lds_bytes(int n);
+bool gradient_onchip_fits(int n);
+void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s);
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);
 
 const char* loglik_kernel_name();
 const char* gradient_kernel_name();
+const char* gradient_onchip_kernel_name();
 
 }  // namespace miphylo

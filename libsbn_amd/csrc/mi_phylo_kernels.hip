@@ -522,6 +522,8 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
       site += sk;
     }
   }
+  if (!RESCALE && a.site_lik)
+    a.site_lik[((size_t)a.grad_offset + blockIdx.y) * a.tiles * kTile + p] = site;
   double ll = log(site);
   if (RESCALE) ll += site_exp * 0.6931471805599453;
   ll = p < a.P ? w * ll : 0.0;
@@ -676,6 +678,150 @@ __global__ __launch_bounds__(kTile) void gradient_hbm_kernel(LikArgs a) {
     gout[N - 1] = 0.0;
     gout[N + N - 1] = 0.0;
   }
+}
+
+// ------------------------------------------------------------------------
+// Gradient v2: everything on chip.  One wave per (evaluation, 64-pattern tile),
+// rate categories one after the other.  For one category the wave keeps the
+// post-order vector of EVERY internal node in a lane-private LDS column
+// ([node][state][lane], (n-2) x 2 KiB), then walks the tree parents-first and
+// overwrites each node's vector with its pre-order vector once it is dead.
+// The per-pattern denominator of the edge derivative is the site likelihood
+// (q_x . L_x is the same for every edge x), which the log-likelihood kernel has
+// already written, so every (pattern, category) contributes additively:
+//   g_x = sum_p (w_p / site_p) sum_k cw_k r_k  q_x[k,p]^T Q L_x[k,p].
+// The four per-visit sums (2 edges x {branch, site}) are reduced across the
+// wave with a transposed butterfly (v_permlane32_swap, v_permlane16_swap, DPP
+// row shifts) and accumulated in LDS.  HBM traffic: tip states, schedule,
+// transition matrices, site likelihoods in; 2N doubles out.
+// ------------------------------------------------------------------------
+template <int SHIFT>
+__device__ __forceinline__ double row_shr_add(double v) {
+  // v[lane] += v[lane - SHIFT] within each 16-lane row (0 shifted in)
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int slo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + SHIFT, 0xf, 0xf, true);
+  const int shi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + SHIFT, 0xf, 0xf, true);
+  return v + __hiloint2double(shi, slo);
+}
+
+// Sums x0..x3 over the 64 lanes.  Afterwards lane 15 holds sum(x0), lane 31
+// sum(x2), lane 47 sum(x1), lane 63 sum(x3); returns this lane's value.
+__device__ __forceinline__ double reduce4_transposed(double x0, double x1, double x2,
+                                                     double x3) {
+  auto swap32 = [](double a, double b) {
+    // a' = {a[0:31], b[0:31]}, b' = {a[32:63], b[32:63]}  ->  a' + b'
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a),
+                                                     (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a),
+                                                     (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  };
+  const double y0 = swap32(x0, x1);  // lanes <32: x0 partial, >=32: x1 partial
+  const double y1 = swap32(x2, x3);  // lanes <32: x2 partial, >=32: x3 partial
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(y0),
+                                                   (unsigned)__double2loint(y1), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(y0),
+                                                   (unsigned)__double2hiint(y1), false, false);
+  // rows: 0 -> x0, 1 -> x2, 2 -> x1, 3 -> x3
+  double z = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  z = row_shr_add<8>(z);
+  z = row_shr_add<4>(z);
+  z = row_shr_add<2>(z);
+  z = row_shr_add<1>(z);
+  return z;
+}
+
+__global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
+  extern __shared__ double glds[];
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int e = a.eval_offset + blockIdx.y;
+  const int gi = a.grad_offset + blockIdx.y;
+  int t, mi;
+  a.map.decode(e, t, mi);
+  const DevModel* __restrict__ model = a.models + mi;
+  const SchedEntry* __restrict__ sched = a.sched + (size_t)t * (a.n - 1);
+  const int p = tile * kTile + lane;
+  const int pc = p < a.P ? p : a.P - 1;
+  const int K = a.K, n = a.n, N = a.N;
+  const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
+  // LDS carve-up: PLV columns | accumulators | tip states
+  double* plv = glds;                                 // [(n-2)][4][64]
+  double* gacc = glds + (size_t)(n - 2) * 4 * kTile;  // [2][N]
+  int8_t* tips = reinterpret_cast<int8_t*>(gacc + 2 * N);  // [n][64]
+  for (int i = lane; i < 2 * N; i += kTile) gacc[i] = 0.0;
+  for (int i = 0; i < n; i++) tips[i * kTile + lane] = a.tip_states[(size_t)i * a.P + pc];
+  const double site = a.site_lik[(size_t)gi * a.tiles * kTile + p];
+  const double coef = p < a.P ? a.weights[pc] / site : 0.0;
+  // Q stays in VGPRs (as wave-uniform values): the two transition matrices of a
+  // visit already take 64 of the ~100 SGPRs.
+  double Q[16];
+  for (int i = 0; i < 16; i++) {
+    Q[i] = model->Q[i];
+    asm volatile("" : "+v"(Q[i]));
+  }
+  __syncthreads();
+
+  auto col = [&](int node) { return plv + (size_t)(node - n) * 4 * kTile + lane; };
+  auto load_col = [&](int node) {
+    const double* c = col(node);
+    return D4{c[0], c[kTile], c[2 * kTile], c[3 * kTile]};
+  };
+  auto store_col = [&](int node, D4 v) {
+    double* c = col(node);
+    c[0] = v.x0;
+    c[kTile] = v.x1;
+    c[2 * kTile] = v.x2;
+    c[3 * kTile] = v.x3;
+  };
+  auto partial_of = [&](int node) {
+    return node < n ? tip_vector(tips[node * kTile + lane]) : load_col(node);
+  };
+
+  for (int k = 0; k < K; k++) {
+    // ---- post-order: L_v for every internal node except the root ----
+    for (int i = 0; i < n - 2; i++) {
+      const SchedEntry s = sched[i];
+      const double* __restrict__ M0 = mats_e + ((size_t)s.child0 * K + k) * 16;
+      const double* __restrict__ M1 = mats_e + ((size_t)s.child1 * K + k) * 16;
+      const D4 A = s.child0 < n ? tip_column(M0, tips[s.child0 * kTile + lane])
+                                : matvec(M0, load_col(s.child0));
+      const D4 B = s.child1 < n ? tip_column(M1, tips[s.child1 * kTile + lane])
+                                : matvec(M1, load_col(s.child1));
+      store_col(s.node, mul4(A, B));
+    }
+    // ---- pre-order + edge derivatives, parents before children ----
+    const double cw = model->cat_weight[k];
+    const double fb = coef * cw * model->cat_rate[k];
+    const double fs = coef * cw * model->cat_drate[k];
+    for (int i = n - 2; i >= 0; i--) {
+      const SchedEntry s = sched[i];
+      const double* __restrict__ M0 = mats_e + ((size_t)s.child0 * K + k) * 16;
+      const double* __restrict__ M1 = mats_e + ((size_t)s.child1 * K + k) * 16;
+      const D4 qv = i == n - 2 ? D4{model->pi[0], model->pi[1], model->pi[2], model->pi[3]}
+                               : load_col(s.node);
+      const D4 L0 = partial_of(s.child0);
+      const D4 L1 = partial_of(s.child1);
+      const D4 A = matvec(M0, L0), B = matvec(M1, L1);
+      const D4 q0 = matTvec(M0, mul4(qv, B));
+      const D4 q1 = matTvec(M1, mul4(qv, A));
+      const double n0 = dot4(q0, matvec(Q, L0));
+      const double n1 = dot4(q1, matvec(Q, L1));
+      if (s.child0 >= n) store_col(s.child0, q0);
+      if (s.child1 >= n) store_col(s.child1, q1);
+      const double r = reduce4_transposed(fb * n0, fb * n1, fs * n0, fs * n1);
+      // lane 15: branch c0, lane 31: site c0, lane 47: branch c1, lane 63: site c1
+      if ((lane & 15) == 15) {
+        const int which = lane >> 4;  // 0,1,2,3
+        const int edge = (which & 2) ? s.child1 : s.child0;
+        double* dst = gacc + ((which & 1) ? N : 0) + edge;
+        *dst += r;
+      }
+    }
+  }
+  __syncthreads();
+  double* gout = a.g_part + ((size_t)gi * a.tiles + tile) * 2 * N;
+  for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];
 }
 
 // ------------------------------------------------------------------------
@@ -903,6 +1049,22 @@ void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t 
     else hipLaunchKernelGGL((gradient_hbm_kernel<false, false>), grid, block, 0, s, a);
   }
 }
+size_t gradient_onchip_lds_bytes(int n) {
+  const int N = 2 * n - 1;
+  return sizeof(double) * ((size_t)(n - 2) * 4 * kTile + 2 * N) + (size_t)n * kTile;
+}
+bool gradient_onchip_fits(int n) { return n >= 3 && gradient_onchip_lds_bytes(n) <= 160 * 1024; }
+void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s) {
+  if (count <= 0) return;
+  const size_t lds = gradient_onchip_lds_bytes(a.n);
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gradient_onchip_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = lds;
+  }
+  hipLaunchKernelGGL(gradient_onchip_kernel, dim3(a.tiles, count), dim3(kTile), lds, s, a);
+}
 void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
   FinalizeArgs a = a_in;
   const size_t lds = sizeof(double) * 6 * (size_t)a.n;
@@ -912,5 +1074,6 @@ void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
 
 const char* loglik_kernel_name() { return "loglik_onchip_kernel"; }
 const char* gradient_kernel_name() { return "gradient_hbm_kernel"; }
+const char* gradient_onchip_kernel_name() { return "gradient_onchip_kernel"; }
 
 }  // namespace miphylo

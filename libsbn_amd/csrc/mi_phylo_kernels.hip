@@ -19,12 +19,24 @@ struct D4 {
   double x0, x1, x2, x3;
 };
 
+// Read-only data written by an EARLIER kernel (transition matrices, schedules,
+// models) is addressed through the constant address space: loads with a
+// wave-uniform address then become scalar loads (s_load_*) into SGPRs no matter
+// what else the kernel stores.
+typedef const double __attribute__((address_space(4))) * cdouble_ptr;
+typedef const int __attribute__((address_space(4))) * cint_ptr;
+__device__ __forceinline__ cdouble_ptr as_const(const double* p) {
+  return (cdouble_ptr)(uintptr_t)p;
+}
+__device__ __forceinline__ cint_ptr as_const(const int* p) { return (cint_ptr)(uintptr_t)p; }
+
 __device__ __forceinline__ D4 mul4(D4 a, D4 b) {
   return {a.x0 * b.x0, a.x1 * b.x1, a.x2 * b.x2, a.x3 * b.x3};
 }
 
 // a_i = sum_j M[i][j] L_j   (M row-major, wave-uniform)
-__device__ __forceinline__ D4 matvec(const double* __restrict__ M, D4 L) {
+template <typename MP>
+__device__ __forceinline__ D4 matvec(MP M, D4 L) {
   D4 a;
   a.x0 = M[0] * L.x0 + M[1] * L.x1 + M[2] * L.x2 + M[3] * L.x3;
   a.x1 = M[4] * L.x0 + M[5] * L.x1 + M[6] * L.x2 + M[7] * L.x3;
@@ -34,7 +46,8 @@ __device__ __forceinline__ D4 matvec(const double* __restrict__ M, D4 L) {
 }
 
 // q_j = sum_i M[i][j] u_i
-__device__ __forceinline__ D4 matTvec(const double* __restrict__ M, D4 u) {
+template <typename MP>
+__device__ __forceinline__ D4 matTvec(MP M, D4 u) {
   D4 q;
   q.x0 = M[0] * u.x0 + M[4] * u.x1 + M[8] * u.x2 + M[12] * u.x3;
   q.x1 = M[1] * u.x0 + M[5] * u.x1 + M[9] * u.x2 + M[13] * u.x3;
@@ -55,13 +68,22 @@ __device__ __forceinline__ D4 tip_vector(int st) {
 }
 
 // P * tip_vector(st) without arithmetic: column st of P, or 1 (rows of P sum to 1).
-__device__ __forceinline__ D4 tip_column(const double* __restrict__ M, int st) {
-  D4 a;
-  a.x0 = st == 0 ? M[0] : st == 1 ? M[1] : st == 2 ? M[2] : st == 3 ? M[3] : 1.0;
-  a.x1 = st == 0 ? M[4] : st == 1 ? M[5] : st == 2 ? M[6] : st == 3 ? M[7] : 1.0;
-  a.x2 = st == 0 ? M[8] : st == 1 ? M[9] : st == 2 ? M[10] : st == 3 ? M[11] : 1.0;
-  a.x3 = st == 0 ? M[12] : st == 1 ? M[13] : st == 2 ? M[14] : st == 3 ? M[15] : 1.0;
-  return a;
+// Written as a chain of selects so that it compiles to v_cndmask, never to branches.
+__device__ __forceinline__ double select_state(int st, double m0, double m1, double m2,
+                                               double m3, double other) {
+  double r = other;
+  r = st == 3 ? m3 : r;
+  r = st == 2 ? m2 : r;
+  r = st == 1 ? m1 : r;
+  r = st == 0 ? m0 : r;
+  return r;
+}
+template <typename MP>
+__device__ __forceinline__ D4 tip_column(MP M, int st) {
+  return {select_state(st, M[0], M[1], M[2], M[3], 1.0),
+          select_state(st, M[4], M[5], M[6], M[7], 1.0),
+          select_state(st, M[8], M[9], M[10], M[11], 1.0),
+          select_state(st, M[12], M[13], M[14], M[15], 1.0)};
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -731,6 +753,25 @@ __device__ __forceinline__ double reduce4_transposed(double x0, double x1, doubl
   return z;
 }
 
+// A wave-uniform 4x4 matrix held in VGPRs.  It is fetched with vector loads (every
+// lane the same address -> one L1 line, broadcast) rather than scalar loads so that
+// the next visit's matrices can be in flight while the current visit computes:
+// the SGPR file has no room for a second pair of matrices.
+struct M16 {
+  double m[16];
+};
+__device__ __forceinline__ M16 load_matrix_vgpr(const double* __restrict__ base, int vzero) {
+  const double2* __restrict__ q = reinterpret_cast<const double2*>(base + vzero);
+  M16 r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const double2 v = q[j];
+    r.m[2 * j] = v.x;
+    r.m[2 * j + 1] = v.y;
+  }
+  return r;
+}
+
 __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
   extern __shared__ double glds[];
   const int lane = threadIdx.x;
@@ -745,16 +786,18 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
   const int pc = p < a.P ? p : a.P - 1;
   const int K = a.K, n = a.n, N = a.N;
   const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
-  // LDS carve-up: PLV columns | accumulators | tip states
+  // LDS carve-up: PLV columns | accumulators.  (Tip states are read from global
+  // memory one visit ahead: keeping them in LDS would cost the third resident
+  // wave per CU at n = 27.)
   double* plv = glds;                                 // [(n-2)][4][64]
   double* gacc = glds + (size_t)(n - 2) * 4 * kTile;  // [2][N]
-  int8_t* tips = reinterpret_cast<int8_t*>(gacc + 2 * N);  // [n][64]
   for (int i = lane; i < 2 * N; i += kTile) gacc[i] = 0.0;
-  for (int i = 0; i < n; i++) tips[i * kTile + lane] = a.tip_states[(size_t)i * a.P + pc];
+  const int8_t* __restrict__ tips_p = a.tip_states + pc;
   const double site = a.site_lik[(size_t)gi * a.tiles * kTile + p];
   const double coef = p < a.P ? a.weights[pc] / site : 0.0;
-  // Q stays in VGPRs (as wave-uniform values): the two transition matrices of a
-  // visit already take 64 of the ~100 SGPRs.
+  int vzero = 0;
+  asm volatile("" : "+v"(vzero));  // a zero the compiler must treat as per-lane
+  // Q stays in VGPRs (as wave-uniform values)
   double Q[16];
   for (int i = 0; i < 16; i++) {
     Q[i] = model->Q[i];
@@ -774,51 +817,109 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
     c[2 * kTile] = v.x2;
     c[3 * kTile] = v.x3;
   };
-  auto partial_of = [&](int node) {
-    return node < n ? tip_vector(tips[node * kTile + lane]) : load_col(node);
+  // Branch-free operand fetch: at one wave per SIMD every taken branch serialises an
+  // LDS round trip, so both the tip byte and the PLV column are read
+  // unconditionally (clamped indices) and one of them is selected afterwards.
+  auto tip_state = [&](int node) { return (int)tips_p[(size_t)(node < n ? node : 0) * a.P]; };
+  auto partial_of = [&](int node, int st) {
+    const bool is_tip = node < n;
+    const D4 c = load_col(is_tip ? n : node);
+    const D4 tv = tip_vector(st);
+    return D4{is_tip ? tv.x0 : c.x0, is_tip ? tv.x1 : c.x1, is_tip ? tv.x2 : c.x2,
+              is_tip ? tv.x3 : c.x3};
   };
+  auto mat_ptr = [&](int child, int k) { return mats_e + ((size_t)child * K + k) * 16; };
+  D4 pi4 = {model->pi[0], model->pi[1], model->pi[2], model->pi[3]};
+  asm volatile("" : "+v"(pi4.x0), "+v"(pi4.x1), "+v"(pi4.x2), "+v"(pi4.x3));  // VGPRs: SGPRs are scarce
+
+  // Touching one dword of each 64-byte line of the NEXT visit's two matrices pulls
+  // them into the scalar data cache, so that the 4 x s_load_dwordx16 of that visit
+  // hit there instead of paying an L2 round trip with nothing to overlap it.
+  auto touch = [&](const double* m0, const double* m1) {
+    const cint_ptr a0 = as_const(reinterpret_cast<const int*>(m0));
+    const cint_ptr a1 = as_const(reinterpret_cast<const int*>(m1));
+    return a0[0] ^ a0[16] ^ a1[0] ^ a1[16];
+  };
+  int touched = 0;
 
   for (int k = 0; k < K; k++) {
     // ---- post-order: L_v for every internal node except the root ----
-    for (int i = 0; i < n - 2; i++) {
-      const SchedEntry s = sched[i];
-      const double* __restrict__ M0 = mats_e + ((size_t)s.child0 * K + k) * 16;
-      const double* __restrict__ M1 = mats_e + ((size_t)s.child1 * K + k) * 16;
-      const D4 A = s.child0 < n ? tip_column(M0, tips[s.child0 * kTile + lane])
-                                : matvec(M0, load_col(s.child0));
-      const D4 B = s.child1 < n ? tip_column(M1, tips[s.child1 * kTile + lane])
-                                : matvec(M1, load_col(s.child1));
-      store_col(s.node, mul4(A, B));
+    {
+      SchedEntry s_cur = sched[0];
+      SchedEntry s_nxt = sched[n > 3 ? 1 : 0];
+      int st0 = tip_state(s_cur.child0), st1 = tip_state(s_cur.child1);
+      for (int i = 0; i < n - 2; i++) {
+        const SchedEntry s_nn = sched[i + 2 < n - 1 ? i + 2 : n - 2];
+        asm volatile("" ::"s"(touched));  // previous touch has landed by now
+        touched = touch(mat_ptr(s_nxt.child0, k), mat_ptr(s_nxt.child1, k));
+        const int st0n = tip_state(s_nxt.child0), st1n = tip_state(s_nxt.child1);
+        const cdouble_ptr M0 = as_const(mat_ptr(s_cur.child0, k));
+        const cdouble_ptr M1 = as_const(mat_ptr(s_cur.child1, k));
+        const D4 L0 = partial_of(s_cur.child0, st0);
+        const D4 L1 = partial_of(s_cur.child1, st1);
+        store_col(s_cur.node, mul4(matvec(M0, L0), matvec(M1, L1)));
+        s_cur = s_nxt;
+        s_nxt = s_nn;
+        st0 = st0n;
+        st1 = st1n;
+      }
     }
-    // ---- pre-order + edge derivatives, parents before children ----
+    // ---- pre-order + edge derivatives, parents before children.  The wave
+    // reduction of visit i is issued during visit i-1 so that its dependent
+    // permute chain overlaps independent arithmetic.
     const double cw = model->cat_weight[k];
     const double fb = coef * cw * model->cat_rate[k];
     const double fs = coef * cw * model->cat_drate[k];
-    for (int i = n - 2; i >= 0; i--) {
-      const SchedEntry s = sched[i];
-      const double* __restrict__ M0 = mats_e + ((size_t)s.child0 * K + k) * 16;
-      const double* __restrict__ M1 = mats_e + ((size_t)s.child1 * K + k) * 16;
-      const D4 qv = i == n - 2 ? D4{model->pi[0], model->pi[1], model->pi[2], model->pi[3]}
-                               : load_col(s.node);
-      const D4 L0 = partial_of(s.child0);
-      const D4 L1 = partial_of(s.child1);
-      const D4 A = matvec(M0, L0), B = matvec(M1, L1);
-      const D4 q0 = matTvec(M0, mul4(qv, B));
-      const D4 q1 = matTvec(M1, mul4(qv, A));
-      const double n0 = dot4(q0, matvec(Q, L0));
-      const double n1 = dot4(q1, matvec(Q, L1));
-      if (s.child0 >= n) store_col(s.child0, q0);
-      if (s.child1 >= n) store_col(s.child1, q1);
-      const double r = reduce4_transposed(fb * n0, fb * n1, fs * n0, fs * n1);
-      // lane 15: branch c0, lane 31: site c0, lane 47: branch c1, lane 63: site c1
-      if ((lane & 15) == 15) {
-        const int which = lane >> 4;  // 0,1,2,3
-        const int edge = (which & 2) ? s.child1 : s.child0;
-        double* dst = gacc + ((which & 1) ? N : 0) + edge;
-        *dst += r;
+    {
+      SchedEntry s_cur = sched[n - 2];
+      SchedEntry s_nxt = sched[n > 2 ? n - 3 : 0];
+      int st0 = tip_state(s_cur.child0), st1 = tip_state(s_cur.child1);
+      double pend0 = 0, pend1 = 0;  // numerators of the previous visit
+      int pend_c0 = 0, pend_c1 = 0;
+      bool have_pending = false;
+      auto flush = [&]() {
+        const double r = reduce4_transposed(fb * pend0, fb * pend1, fs * pend0, fs * pend1);
+        // lane 15: branch c0, lane 31: site c0, lane 47: branch c1, lane 63: site c1
+        if ((lane & 15) == 15) {
+          const int which = lane >> 4;
+          const int edge = (which & 2) ? pend_c1 : pend_c0;
+          double* dst = gacc + ((which & 1) ? N : 0) + edge;
+          *dst += r;
+        }
+      };
+      for (int i = n - 2; i >= 0; i--) {
+        const SchedEntry s_nn = sched[i >= 2 ? i - 2 : 0];
+        asm volatile("" ::"s"(touched));
+        touched = touch(mat_ptr(s_nxt.child0, k), mat_ptr(s_nxt.child1, k));
+        const int st0n = tip_state(s_nxt.child0), st1n = tip_state(s_nxt.child1);
+        const cdouble_ptr M0 = as_const(mat_ptr(s_cur.child0, k));
+        const cdouble_ptr M1 = as_const(mat_ptr(s_cur.child1, k));
+        const D4 L0 = partial_of(s_cur.child0, st0);
+        const D4 L1 = partial_of(s_cur.child1, st1);
+        const bool is_root = i == n - 2;
+        const D4 qs = load_col(is_root ? n : s_cur.node);
+        const D4 qv = {is_root ? pi4.x0 : qs.x0, is_root ? pi4.x1 : qs.x1,
+                       is_root ? pi4.x2 : qs.x2, is_root ? pi4.x3 : qs.x3};
+        if (have_pending) flush();
+        const D4 A = matvec(M0, L0), B = matvec(M1, L1);
+        const D4 q0 = matTvec(M0, mul4(qv, B));
+        const D4 q1 = matTvec(M1, mul4(qv, A));
+        pend0 = dot4(q0, matvec(Q, L0));
+        pend1 = dot4(q1, matvec(Q, L1));
+        pend_c0 = s_cur.child0;
+        pend_c1 = s_cur.child1;
+        have_pending = true;
+        if (s_cur.child0 >= n) store_col(s_cur.child0, q0);
+        if (s_cur.child1 >= n) store_col(s_cur.child1, q1);
+        s_cur = s_nxt;
+        s_nxt = s_nn;
+        st0 = st0n;
+        st1 = st1n;
       }
+      flush();
     }
   }
+  asm volatile("" ::"s"(touched));
   __syncthreads();
   double* gout = a.g_part + ((size_t)gi * a.tiles + tile) * 2 * N;
   for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];
@@ -1051,7 +1152,7 @@ void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t 
 }
 size_t gradient_onchip_lds_bytes(int n) {
   const int N = 2 * n - 1;
-  return sizeof(double) * ((size_t)(n - 2) * 4 * kTile + 2 * N) + (size_t)n * kTile;
+  return sizeof(double) * ((size_t)(n - 2) * 4 * kTile + 2 * N);
 }
 bool gradient_onchip_fits(int n) { return n >= 3 && gradient_onchip_lds_bytes(n) <= 160 * 1024; }
 void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s) {

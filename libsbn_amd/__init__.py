@@ -3,5 +3,7 @@ libsbn's Engine / FatBeagle API.  The compute path is libmi_phylo.so (hand-writt
 HIP for gfx950, C ABI in include/mi_phylo.h); this package is a thin ctypes mirror
 of the reference's Engine interface.  No CPU fallback exists."""
 from .engine import Engine, PhyloGradient, PhyloModelSpecification  # noqa: F401
+from .instance import rooted_instance, unrooted_instance  # noqa: F401
 
-__all__ = ["Engine", "PhyloGradient", "PhyloModelSpecification"]
+__all__ = ["Engine", "PhyloGradient", "PhyloModelSpecification", "unrooted_instance",
+           "rooted_instance"]

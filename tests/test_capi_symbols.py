@@ -1,0 +1,53 @@
+"""The C-ABI shared library loads on a CPU-only machine and exports every symbol
+include/mi_phylo.h declares (no compute without a GPU: creating an engine must fail
+loudly, not fall back)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "mi_phylo.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from libsbn_amd import _capi
+    lib = _capi.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in mi_phylo.h but not exported"
+    assert sorted(_capi.SYMBOLS) == declared, "ctypes table out of sync with the header"
+    assert lib.mi_abi_version() == 1
+
+
+def test_spec_struct_layout_matches_header():
+    from libsbn_amd import _capi
+    assert ctypes.sizeof(_capi.EngineSpec) == 40  # ten int32 fields
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import libsbn_amd as L
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        L.Engine(L.PhyloModelSpecification(), np.zeros((3, 4), np.int32), np.ones(4))
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path must never route through oracle/ (test infrastructure)."""
+    pkg = os.path.join(REPO, "libsbn_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(root, f), errors="ignore").read()
+                assert "liboracle" not in text and "oracle_lib" not in text and \
+                    "phylo_oracle" not in text, f

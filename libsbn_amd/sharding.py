@@ -1,0 +1,81 @@
+"""Tree-batch sharding across the GPUs of one node (one process per GPU,
+torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in CPU tests).
+
+The reference parallelises over trees with a thread pool (FatBeagleParallelize,
+src/fat_beagle.hpp:119-149, TaskProcessor src/task_processor.hpp:43-112): trees are
+independent units, results come back in tree order.  Here every rank evaluates a
+contiguous block of the batch on its own GPU and ONE collective per engine call
+(all_gather of the packed per-tree results) rebuilds the per-tree vectors the
+Engine API returns.  No other data-path communication exists.
+"""
+import numpy as np
+
+
+def tree_shard(tree_count, rank, world_size):
+    """Contiguous block [lo, hi) of rank `rank`: sizes differ by <= 1."""
+    base, extra = divmod(tree_count, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_sizes(tree_count, world_size):
+    return [tree_shard(tree_count, r, world_size)[1] - tree_shard(tree_count, r, world_size)[0]
+            for r in range(world_size)]
+
+
+def pack_results(log_likelihoods, columns):
+    """[T] + list of [T, c_i] -> [T, 1 + sum c_i] (one buffer -> one collective)."""
+    import torch
+    parts = [log_likelihoods.reshape(-1, 1)] + [c.reshape(len(log_likelihoods), -1)
+                                                for c in columns]
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def all_gather_trees(local, tree_count, group=None):
+    """All-gather per-tree rows of every rank, back into tree order.
+
+    local: [T_local, C] tensor of this rank (rows of its tree_shard).  Uneven shards
+    are padded to the largest one so that a single all_gather_into_tensor is enough.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(tree_count, world)
+    width = max(sizes)
+    C = local.shape[1]
+    padded = local
+    if local.shape[0] < width:
+        padded = torch.zeros((width, C), dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
+    out = torch.empty((world * width, C), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if all(s == width for s in sizes):
+        return out
+    rows = [out[r * width:r * width + sizes[r]] for r in range(world)]
+    return torch.cat(rows, dim=0)
+
+
+class ShardedBatch:
+    """Splits the inputs of one Engine call by tree and reassembles the outputs.
+
+    `compute(lo, hi)` is whatever evaluates trees [lo, hi) on this rank (the HIP
+    engine in production) and returns a [hi-lo, C] tensor of packed per-tree results.
+    """
+
+    def __init__(self, tree_count, group=None):
+        import torch.distributed as dist
+        self.tree_count = tree_count
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.lo, self.hi = tree_shard(tree_count, self.rank, self.world)
+
+    def run(self, compute):
+        local = compute(self.lo, self.hi)
+        if self.world == 1:
+            return local
+        return all_gather_trees(local, self.tree_count, self.group)
+
+
+def numpy_shard(arrays, lo, hi):
+    return [np.ascontiguousarray(a[lo:hi]) for a in arrays]

@@ -741,14 +741,23 @@ static real root_log_likelihood(const core_ws_t* w, const model_t* m, const doub
   return total;
 }
 
+/* One workspace per worker thread, reused across trees -- the analogue of one
+ * BEAGLE instance per FatBeagle (fat_beagle.cpp:207-256). */
+static real core_log_likelihood_ws(core_ws_t* w, const model_t* model,
+                                   const double* pattern_weights, const int32_t* child0,
+                                   const int32_t* child1, const real* bl, int rescaling) {
+  memset(w->cum_log_scale, 0, sizeof(real) * w->P); /* beagleResetScaleFactors */
+  transition_matrices(model, w->N - 1, bl, w->mats);
+  post_order(w, child0, child1, rescaling);
+  return root_log_likelihood(w, model, pattern_weights);
+}
+
 static real core_log_likelihood(const orc_spec_t* spec, const model_t* model,
                                 const int32_t* tip_states, const double* pattern_weights,
                                 const int32_t* child0, const int32_t* child1, const real* bl,
                                 int rescaling) {
   core_ws_t w = ws_alloc(spec, tip_states, 0);
-  transition_matrices(model, w.N - 1, bl, w.mats);
-  post_order(&w, child0, child1, rescaling);
-  real ll = root_log_likelihood(&w, model, pattern_weights);
+  real ll = core_log_likelihood_ws(&w, model, pattern_weights, child0, child1, bl, rescaling);
   ws_free(&w);
   return ll;
 }
@@ -836,16 +845,25 @@ static void edge_derivatives(const core_ws_t* w, const model_t* m, const double*
   grad[w->N - 1] = 0.;
 }
 
+static real core_branch_gradient_ws(core_ws_t* w, const model_t* model,
+                                    const double* pattern_weights, const int32_t* child0,
+                                    const int32_t* child1, const real* bl, const real* dscale,
+                                    int rescaling, real* grad) {
+  memset(w->cum_log_scale, 0, sizeof(real) * w->P);
+  transition_matrices(model, w->N - 1, bl, w->mats);
+  post_order(w, child0, child1, rescaling);
+  pre_order(w, model, child0, child1, rescaling);
+  edge_derivatives(w, model, pattern_weights, dscale, grad);
+  return root_log_likelihood(w, model, pattern_weights);
+}
+
 static real core_branch_gradient(const orc_spec_t* spec, const model_t* model,
                                  const int32_t* tip_states, const double* pattern_weights,
                                  const int32_t* child0, const int32_t* child1, const real* bl,
                                  const real* dscale, int rescaling, real* grad) {
   core_ws_t w = ws_alloc(spec, tip_states, 1);
-  transition_matrices(model, w.N - 1, bl, w.mats);
-  post_order(&w, child0, child1, rescaling);
-  pre_order(&w, model, child0, child1, rescaling);
-  edge_derivatives(&w, model, pattern_weights, dscale, grad);
-  real ll = root_log_likelihood(&w, model, pattern_weights);
+  real ll = core_branch_gradient_ws(&w, model, pattern_weights, child0, child1, bl, dscale,
+                                    rescaling, grad);
   ws_free(&w);
   return ll;
 }
@@ -943,12 +961,13 @@ typedef struct {
   const real* bl;
   int rescaling;
   real add; /* log-det-Jacobian for rooted trees */
+  core_ws_t* ws;
 } ll_ctx_t;
 
 static real ll_of_model(const model_t* model, void* vctx) {
   ll_ctx_t* c = (ll_ctx_t*)vctx;
-  return core_log_likelihood(c->spec, model, c->tips, c->weights, c->child0, c->child1,
-                             c->bl, c->rescaling) + c->add;
+  return core_log_likelihood_ws(c->ws, model, c->weights, c->child0, c->child1, c->bl,
+                                c->rescaling) + c->add;
 }
 
 /* fat_beagle.cpp:389-398 */
@@ -973,7 +992,10 @@ int orc_unrooted_log_likelihoods(const orc_spec_t* spec, const int32_t* tip_stat
                                  const double* params, int rescaling, int nthreads,
                                  double* out_logl) {
   int n = spec->taxon_count, pc = orc_param_count(spec), rc_all = 0;
-#pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+  {
+  core_ws_t ws = ws_alloc(spec, tip_states, 0);
+#pragma omp for schedule(dynamic)
   for (int t = 0; t < T; t++) {
     int32_t* c0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (n - 1));
     int32_t* c1 = c0 + (n - 1);
@@ -984,13 +1006,15 @@ int orc_unrooted_log_likelihoods(const orc_spec_t* spec, const int32_t* tip_stat
                                bl + (size_t)t * (2 * n - 2), c0, c1, b);
     if (!rc) rc = model_set(spec, pr, &model);
     if (!rc)
-      out_logl[t] = (double)core_log_likelihood(spec, &model, tip_states, pattern_weights, c0,
-                                                c1, b, rescaling);
+      out_logl[t] = (double)core_log_likelihood_ws(&ws, &model, pattern_weights, c0, c1, b,
+                                                   rescaling);
     if (rc) {
 #pragma omp critical
       { rc_all = 1; }
     }
     free(c0); free(b); free(pr);
+  }
+  ws_free(&ws);
   }
   if (rc_all && !g_err[0]) fail("a tree failed");
   return rc_all;
@@ -1003,7 +1027,10 @@ int orc_unrooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
                            int nthreads, double* out_logl, double* out_branch,
                            double* out_site, double* out_subst) {
   int n = spec->taxon_count, N = 2 * n - 1, pc = orc_param_count(spec), rc_all = 0;
-#pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+  {
+  core_ws_t ws = ws_alloc(spec, tip_states, 1);
+#pragma omp for schedule(dynamic)
   for (int t = 0; t < T; t++) {
     int32_t* c0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (n - 1));
     int32_t* c1 = c0 + (n - 1);
@@ -1021,20 +1048,21 @@ int orc_unrooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
       /* Tree::SlideRootPosition tree.cpp:72-78 */
       b[root_child] = b[root_child] + b[fixed];
       b[fixed] = 0.0;
-      out_logl[t] = (double)core_branch_gradient(spec, &model, tip_states, pattern_weights, c0,
-                                                 c1, b, model.cat_rates, rescaling, g);
+      out_logl[t] = (double)core_branch_gradient_ws(&ws, &model, pattern_weights, c0, c1, b,
+                                                    model.cat_rates, rescaling, g);
       if (model.n_gtr_rates > 0 && out_subst) {
         /* f = StaticUnrootedLogLikelihood(in_tree): Detrifurcate without the slide */
         real* b0 = (real*)malloc(sizeof(real) * N);
         int32_t* d0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (n - 1));
         detrifurcate_real(n, pid, tbl, d0, d0 + (n - 1), b0);
-        ll_ctx_t ctx = {spec, tip_states, pattern_weights, d0, d0 + (n - 1), b0, rescaling, 0.};
+        ll_ctx_t ctx = {spec, tip_states, pattern_weights, d0, d0 + (n - 1), b0, rescaling, 0.,
+                        &ws};
         rc = subst_gradient_fd(spec, pr, &model, ll_of_model, &ctx, out_subst + (size_t)t * 8);
         free(b0); free(d0);
       }
       if (!rc && spec->category_count > 1 && out_site) {
-        core_branch_gradient(spec, &model, tip_states, pattern_weights, c0, c1, b,
-                             model.cat_rate_derivs, rescaling, g2);
+        core_branch_gradient_ws(&ws, &model, pattern_weights, c0, c1, b, model.cat_rate_derivs,
+                                rescaling, g2);
         out_site[t] = (double)discrete_site_model_gradient(N, b, g2);
       }
       g[fixed] = 0.; /* fat_beagle.cpp:499 */
@@ -1045,6 +1073,8 @@ int orc_unrooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
       { rc_all = 1; }
     }
     free(c0); free(b); free(pr);
+  }
+  ws_free(&ws);
   }
   return rc_all;
 }
@@ -1098,7 +1128,10 @@ int orc_rooted_log_likelihoods(const orc_spec_t* spec, const int32_t* tip_states
                                int with_jacobian, int rescaling, int nthreads,
                                double* out_logl) {
   int n = spec->taxon_count, N = 2 * n - 1, pc = orc_param_count(spec), rc_all = 0;
-#pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+  {
+  core_ws_t ws = ws_alloc(spec, tip_states, 0);
+#pragma omp for schedule(dynamic)
   for (int t = 0; t < T; t++) {
     int32_t* c0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (n - 1));
     int32_t* c1 = c0 + (n - 1);
@@ -1113,14 +1146,16 @@ int orc_rooted_log_likelihoods(const orc_spec_t* spec, const int32_t* tip_states
         for (int i = 0; i < N - 1; i++) b[i] *= rates[(size_t)t * (N - 1) + i];
         add = log_det_jacobian(n, c0, c1, node_heights + (size_t)t * N, node_bounds + (size_t)t * N);
       }
-      out_logl[t] = (double)(core_log_likelihood(spec, &model, tip_states, pattern_weights, c0,
-                                                 c1, b, rescaling) + add);
+      out_logl[t] = (double)(core_log_likelihood_ws(&ws, &model, pattern_weights, c0, c1, b,
+                                                    rescaling) + add);
     }
     if (rc) {
 #pragma omp critical
       { rc_all = 1; }
     }
     free(c0); free(b); free(pr);
+  }
+  ws_free(&ws);
   }
   return rc_all;
 }
@@ -1214,7 +1249,10 @@ int orc_rooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
                          double* out_ratios_root_height, double* out_clock, double* out_site,
                          double* out_subst) {
   int n = spec->taxon_count, N = 2 * n - 1, pc = orc_param_count(spec), rc_all = 0;
-#pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+  {
+  core_ws_t ws = ws_alloc(spec, tip_states, 1);
+#pragma omp for schedule(dynamic)
   for (int t = 0; t < T; t++) {
     int32_t* c0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (n - 1));
     int32_t* c1 = c0 + (n - 1);
@@ -1238,16 +1276,16 @@ int orc_rooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
     if (!rc) {
       for (int i = 0; i < N; i++) b[i] = tb[i];
       for (int i = 0; i < N - 1; i++) b[i] *= r[i];
-      out_logl[t] = (double)core_branch_gradient(spec, &model, tip_states, pattern_weights, c0,
-                                                 c1, b, model.cat_rates, rescaling, bg);
+      out_logl[t] = (double)core_branch_gradient_ws(&ws, &model, pattern_weights, c0, c1, b,
+                                                    model.cat_rates, rescaling, bg);
       if (model.n_gtr_rates > 0 && out_subst) {
         ll_ctx_t ctx = {spec, tip_states, pattern_weights, c0, c1, b, rescaling,
-                        log_det_jacobian(n, c0, c1, h, bd)};
+                        log_det_jacobian(n, c0, c1, h, bd), &ws};
         rc = subst_gradient_fd(spec, pr, &model, ll_of_model, &ctx, out_subst + (size_t)t * 8);
       }
       if (!rc && spec->category_count > 1 && out_site) {
-        core_branch_gradient(spec, &model, tip_states, pattern_weights, c0, c1, b,
-                             model.cat_rate_derivs, rescaling, g2);
+        core_branch_gradient_ws(&ws, &model, pattern_weights, c0, c1, b, model.cat_rate_derivs,
+                                rescaling, g2);
         out_site[t] = (double)discrete_site_model_gradient(N, b, g2);
       }
       ratio_gradient_of_branch_gradient(n, c0, c1, r, h, bd, height_ratios + (size_t)t * (n - 1),
@@ -1270,6 +1308,8 @@ int orc_rooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
       { rc_all = 1; }
     }
     free(c0); free(b); free(pr);
+  }
+  ws_free(&ws);
   }
   return rc_all;
 }

@@ -2,6 +2,7 @@
 // Everything here lives in HBM for the duration of one engine call; see
 // DESIGN.md "Data layout in HBM".
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace miphylo {
@@ -33,6 +34,24 @@ struct SchedEntry {
   int32_t child1;
   int32_t slots;  // dst | slot(child0) << 8 | slot(child1) << 16
 };
+
+// One entry of the on-chip gradient kernel's schedule: a node whose pre-order
+// vector is available (the root, or a "stored" node with an LDS slot) together
+// with its two children and, for children whose vectors are NOT stored, their
+// children.  kind: 0 = tip, 1 = stored internal node (has a slot), 2 = unstored
+// internal node (both of its children are tips or stored nodes).
+struct MacroEntry {
+  int32_t node;      // id of the node whose q is known
+  int32_t qslot;     // its LDS slot, -1 for the root (q = frequencies)
+  int32_t child[2];  // ids
+  int32_t kind[2];
+  int32_t cslot[2];  // slot of a stored child (else 0)
+  int32_t grand[4];  // children of child 0 (a0, b0) and of child 1 (a1, b1) when unstored
+  int32_t gslot[4];  // their slots (0 for tips)
+};
+
+inline __host__ __device__ int max_macros(int n) { return (n - 2) / 2 + 1; }
+inline __host__ __device__ int max_stored(int n) { return (n - 2) / 2 > 1 ? (n - 2) / 2 : 1; }
 
 enum StatusCode : int32_t {
   kOk = 0,

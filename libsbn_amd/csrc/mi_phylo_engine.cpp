@@ -89,7 +89,7 @@ struct mi_engine {
   // static device data
   Buffer tip_states, tip_partials, weights;
   // per-call workspace
-  Buffer tree_scratch, sched, bl_eff, models, mats, ll_part, plv, g_part, site_lik, fin_scratch,
+  Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, ll_part, plv, g_part, site_lik, fin_scratch,
       status;
   bool allow_onchip_gradient = true;
   // staging for the host-pointer entry points
@@ -139,6 +139,8 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
   const int n = e->n, N = e->N;
   if (e->tree_scratch.ensure(sizeof(int32_t) * (size_t)T * 12 * N)) return 1;
   if (e->sched.ensure(sizeof(SchedEntry) * (size_t)T * (n - 1))) return 1;
+  if (e->macros.ensure(sizeof(MacroEntry) * (size_t)T * max_macros(n))) return 1;
+  if (e->macro_count.ensure(sizeof(int32_t) * (size_t)T)) return 1;
   if (e->bl_eff.ensure(sizeof(double) * (size_t)T * N)) return 1;
   if (e->models.ensure(sizeof(DevModel) * (size_t)c.M)) return 1;
   if (e->mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
@@ -199,6 +201,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ts.rates = (d.rooted && (d.gradient || d.with_jacobian)) ? d.rates : nullptr;
   ts.scratch = e->tree_scratch.as<int32_t>();
   ts.sched = e->sched.as<SchedEntry>();
+  ts.macros = e->macros.as<MacroEntry>();
+  ts.macro_count = e->macro_count.as<int32_t>();
   ts.bl_eff = e->bl_eff.as<double>();
   ts.status = e->status.as<int32_t>();
   ts.max_slots = e->max_slots;
@@ -239,6 +243,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.map = map;
   la.models = e->models.as<DevModel>();
   la.sched = e->sched.as<SchedEntry>();
+  la.macros = e->macros.as<MacroEntry>();
+  la.macro_count = e->macro_count.as<int32_t>();
   la.mats = e->mats.as<double>();
   la.tip_states = e->tip_states.as<int8_t>();
   la.tip_partials = e->spec.use_tip_states ? nullptr : e->tip_partials.as<double>();
@@ -478,7 +484,8 @@ void mi_engine_destroy(mi_engine* e) {
     (void)hipStreamSynchronize(e->stream);
   }
   for (Buffer* b :
-       {&e->tip_states, &e->tip_partials, &e->weights, &e->tree_scratch, &e->sched, &e->bl_eff,
+       {&e->tip_states, &e->tip_partials, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
+        &e->macro_count, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->fin_scratch,
         &e->status,
         &e->in_parent, &e->in_bl, &e->in_params, &e->in_rates, &e->in_rate_counts,

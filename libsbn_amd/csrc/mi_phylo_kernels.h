@@ -38,6 +38,8 @@ struct TreeSetupArgs {
   const double* rates;        // [T][2n-2] or nullptr: branch length x rate
   int32_t* scratch;           // [T][12 N]
   SchedEntry* sched;          // [T][n-1]
+  MacroEntry* macros;         // [T][max_macros(n)] (may be nullptr)
+  int32_t* macro_count;       // [T]
   double* bl_eff;             // [T][N]
   int32_t* status;            // [2]: code, tree
   int max_slots;
@@ -68,6 +70,8 @@ struct LikArgs {
   EvalMap map;
   const DevModel* models;
   const SchedEntry* sched;
+  const MacroEntry* macros;    // [T][max_macros(n)]
+  const int32_t* macro_count;  // [T]
   const double* mats;
   const int8_t* tip_states;    // [n][P]
   const double* tip_partials;  // [n][P][4] or nullptr

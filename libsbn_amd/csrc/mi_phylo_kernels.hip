@@ -219,12 +219,54 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
         }
       }
       if (used_max > a.max_slots) status = kTooManySlots;
+      // ---- schedule of the on-chip gradient kernel ----
+      // A non-root internal node is UNSTORED (2) when all its internal children are
+      // stored, else STORED (1): every stored node then has an unstored child, so at
+      // most (n-2)/2 nodes need an LDS slot; an unstored node's vector is
+      // recomputed from its (stored or tip) children where it is needed.
+      if (a.macros) {
+        int32_t* cls = cnt;
+        int32_t* sslot = maxleaf;
+        int stored = 0;
+        for (int v = n; v < N - 1; v++) {
+          const int a0 = c0[v], a1 = c1[v];
+          const bool unstored = (a0 < n || cls[a0] == 1) && (a1 < n || cls[a1] == 1);
+          cls[v] = unstored ? 2 : 1;
+          sslot[v] = unstored ? 0 : stored++;
+        }
+        cls[N - 1] = 1;
+        sslot[N - 1] = -1;
+        MacroEntry* mac = a.macros + (size_t)t * max_macros(n);
+        int m = 0;
+        for (int v = n; v < N; v++) {
+          if (cls[v] != 1) continue;
+          MacroEntry me;
+          me.node = v;
+          me.qslot = sslot[v];
+          for (int j = 0; j < 2; j++) {
+            const int ch = j ? c1[v] : c0[v];
+            me.child[j] = ch;
+            me.kind[j] = ch < n ? 0 : cls[ch];
+            me.cslot[j] = (ch >= n && cls[ch] == 1) ? sslot[ch] : 0;
+            const bool expand = ch >= n && cls[ch] == 2;
+            const int ga = expand ? c0[ch] : 0, gb = expand ? c1[ch] : 0;
+            me.grand[2 * j] = ga;
+            me.grand[2 * j + 1] = gb;
+            me.gslot[2 * j] = ga >= n ? sslot[ga] : 0;
+            me.gslot[2 * j + 1] = gb >= n ? sslot[gb] : 0;
+          }
+          mac[m++] = me;
+        }
+        a.macro_count[t] = m;
+        if (stored > max_stored(n)) status = kTooManySlots;
+      }
     }
     if (status != kOk) set_status(a.status, status, t);
     ok_flag = status == kOk || status == kTooManySlots;
   }
   __syncthreads();
   if (!ok_flag) {
+    if (lane == 0 && a.macro_count) a.macro_count[t] = 0;
     for (int i = lane; i < n - 1; i += 64) sched[i] = {n + i, 0, 1, 0};
     for (int v = lane; v < N; v += 64) ble[v] = 0.0;
     return;
@@ -703,11 +745,14 @@ __global__ __launch_bounds__(kTile) void gradient_hbm_kernel(LikArgs a) {
 }
 
 // ------------------------------------------------------------------------
-// Gradient v2: everything on chip.  One wave per (evaluation, 64-pattern tile),
+// Gradient, everything on chip.  One wave per (evaluation, 64-pattern tile),
 // rate categories one after the other.  For one category the wave keeps the
-// post-order vector of EVERY internal node in a lane-private LDS column
-// ([node][state][lane], (n-2) x 2 KiB), then walks the tree parents-first and
-// overwrites each node's vector with its pre-order vector once it is dead.
+// post-order vectors of the STORED internal nodes (at most (n-2)/2 of them, see
+// tree_setup_kernel) in lane-private LDS columns ([slot][state][lane], 2 KiB
+// each), recomputes the others from their children where needed, then walks the
+// tree parents-first and overwrites each stored vector with the node's pre-order
+// vector once it is dead.  Halving the resident set doubles the waves per CU
+// (6 at n = 27), which is what this latency-bound walk needs.
 // The per-pattern denominator of the edge derivative is the site likelihood
 // (q_x . L_x is the same for every edge x), which the log-likelihood kernel has
 // already written, so every (pattern, category) contributes additively:
@@ -781,145 +826,163 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
   int t, mi;
   a.map.decode(e, t, mi);
   const DevModel* __restrict__ model = a.models + mi;
-  const SchedEntry* __restrict__ sched = a.sched + (size_t)t * (a.n - 1);
   const int p = tile * kTile + lane;
   const int pc = p < a.P ? p : a.P - 1;
   const int K = a.K, n = a.n, N = a.N;
   const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
-  // LDS carve-up: PLV columns | accumulators.  (Tip states are read from global
-  // memory one visit ahead: keeping them in LDS would cost the third resident
-  // wave per CU at n = 27.)
-  double* plv = glds;                                 // [(n-2)][4][64]
-  double* gacc = glds + (size_t)(n - 2) * 4 * kTile;  // [2][N]
+  const MacroEntry* __restrict__ macros = a.macros + (size_t)t * max_macros(n);
+  const int M = a.macro_count[t];
+  // LDS: one 2 KiB column block per STORED node ([slot][state][lane]) | accumulators
+  double* plv = glds;
+  double* gacc = glds + (size_t)max_stored(n) * 4 * kTile;  // [2][N]
   for (int i = lane; i < 2 * N; i += kTile) gacc[i] = 0.0;
   const int8_t* __restrict__ tips_p = a.tip_states + pc;
   const double site = a.site_lik[(size_t)gi * a.tiles * kTile + p];
   const double coef = p < a.P ? a.weights[pc] / site : 0.0;
-  int vzero = 0;
-  asm volatile("" : "+v"(vzero));  // a zero the compiler must treat as per-lane
-  // Q stays in VGPRs (as wave-uniform values)
+  // Q and pi stay in VGPRs (as wave-uniform values): the SGPR file is needed for
+  // the two transition matrices in flight.
   double Q[16];
   for (int i = 0; i < 16; i++) {
     Q[i] = model->Q[i];
     asm volatile("" : "+v"(Q[i]));
   }
+  D4 pi4 = {model->pi[0], model->pi[1], model->pi[2], model->pi[3]};
+  asm volatile("" : "+v"(pi4.x0), "+v"(pi4.x1), "+v"(pi4.x2), "+v"(pi4.x3));
   __syncthreads();
+  if (M <= 0) return;  // malformed tree: status already reported by tree_setup
 
-  auto col = [&](int node) { return plv + (size_t)(node - n) * 4 * kTile + lane; };
-  auto load_col = [&](int node) {
-    const double* c = col(node);
+  auto load_slot = [&](int slot) {
+    const double* c = plv + (size_t)slot * 4 * kTile + lane;
     return D4{c[0], c[kTile], c[2 * kTile], c[3 * kTile]};
   };
-  auto store_col = [&](int node, D4 v) {
-    double* c = col(node);
+  auto store_slot = [&](int slot, D4 v) {
+    double* c = plv + (size_t)slot * 4 * kTile + lane;
     c[0] = v.x0;
     c[kTile] = v.x1;
     c[2 * kTile] = v.x2;
     c[3 * kTile] = v.x3;
   };
-  // Branch-free operand fetch: at one wave per SIMD every taken branch serialises an
-  // LDS round trip, so both the tip byte and the PLV column are read
-  // unconditionally (clamped indices) and one of them is selected afterwards.
   auto tip_state = [&](int node) { return (int)tips_p[(size_t)(node < n ? node : 0) * a.P]; };
-  auto partial_of = [&](int node, int st) {
+  // partial vector of a tip (compact state) or of a stored node: both reads are
+  // issued unconditionally, one is selected (no branch, one LDS round trip)
+  auto operand = [&](int node, int slot, int st) {
     const bool is_tip = node < n;
-    const D4 c = load_col(is_tip ? n : node);
+    const D4 c = load_slot(slot);
     const D4 tv = tip_vector(st);
     return D4{is_tip ? tv.x0 : c.x0, is_tip ? tv.x1 : c.x1, is_tip ? tv.x2 : c.x2,
               is_tip ? tv.x3 : c.x3};
   };
-  auto mat_ptr = [&](int child, int k) { return mats_e + ((size_t)child * K + k) * 16; };
-  D4 pi4 = {model->pi[0], model->pi[1], model->pi[2], model->pi[3]};
-  asm volatile("" : "+v"(pi4.x0), "+v"(pi4.x1), "+v"(pi4.x2), "+v"(pi4.x3));  // VGPRs: SGPRs are scarce
-
-  // Touching one dword of each 64-byte line of the NEXT visit's two matrices pulls
-  // them into the scalar data cache, so that the 4 x s_load_dwordx16 of that visit
-  // hit there instead of paying an L2 round trip with nothing to overlap it.
-  auto touch = [&](const double* m0, const double* m1) {
-    const cint_ptr a0 = as_const(reinterpret_cast<const int*>(m0));
-    const cint_ptr a1 = as_const(reinterpret_cast<const int*>(m1));
-    return a0[0] ^ a0[16] ^ a1[0] ^ a1[16];
+  auto mat = [&](int node, int k) { return as_const(mats_e + ((size_t)node * K + k) * 16); };
+  struct TipStates {
+    int c[2], g[4];
   };
-  int touched = 0;
+  auto fetch_tips = [&](const MacroEntry& me) {
+    TipStates ts;
+    ts.c[0] = tip_state(me.child[0]);
+    ts.c[1] = tip_state(me.child[1]);
+    for (int j = 0; j < 4; j++) ts.g[j] = tip_state(me.grand[j]);
+    return ts;
+  };
+  auto accumulate = [&](double r, int edge_a, int edge_b) {
+    // after reduce4_transposed(x_a_branch, x_b_branch, x_a_site, x_b_site):
+    // lane 15: branch a, lane 31: site a, lane 47: branch b, lane 63: site b
+    if ((lane & 15) == 15) {
+      const int which = lane >> 4;
+      const int edge = (which & 2) ? edge_b : edge_a;
+      double* dst = gacc + ((which & 1) ? N : 0) + edge;
+      *dst += r;
+    }
+  };
 
   for (int k = 0; k < K; k++) {
-    // ---- post-order: L_v for every internal node except the root ----
+    // ================= post-order over the stored nodes =================
+    // (the root's macro is the last one; its vector is not needed here)
     {
-      SchedEntry s_cur = sched[0];
-      SchedEntry s_nxt = sched[n > 3 ? 1 : 0];
-      int st0 = tip_state(s_cur.child0), st1 = tip_state(s_cur.child1);
-      for (int i = 0; i < n - 2; i++) {
-        const SchedEntry s_nn = sched[i + 2 < n - 1 ? i + 2 : n - 2];
-        asm volatile("" ::"s"(touched));  // previous touch has landed by now
-        touched = touch(mat_ptr(s_nxt.child0, k), mat_ptr(s_nxt.child1, k));
-        const int st0n = tip_state(s_nxt.child0), st1n = tip_state(s_nxt.child1);
-        const cdouble_ptr M0 = as_const(mat_ptr(s_cur.child0, k));
-        const cdouble_ptr M1 = as_const(mat_ptr(s_cur.child1, k));
-        const D4 L0 = partial_of(s_cur.child0, st0);
-        const D4 L1 = partial_of(s_cur.child1, st1);
-        store_col(s_cur.node, mul4(matvec(M0, L0), matvec(M1, L1)));
-        s_cur = s_nxt;
-        s_nxt = s_nn;
-        st0 = st0n;
-        st1 = st1n;
+      MacroEntry cur = macros[0];
+      TipStates ts = fetch_tips(cur);
+      for (int m = 0; m < M - 1; m++) {
+        const MacroEntry nxt = macros[m + 1];
+        const TipStates tsn = fetch_tips(nxt);
+        D4 L[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          if (cur.kind[j] == 2) {
+            const D4 La = operand(cur.grand[2 * j], cur.gslot[2 * j], ts.g[2 * j]);
+            const D4 Lb = operand(cur.grand[2 * j + 1], cur.gslot[2 * j + 1], ts.g[2 * j + 1]);
+            L[j] = mul4(matvec(mat(cur.grand[2 * j], k), La),
+                        matvec(mat(cur.grand[2 * j + 1], k), Lb));
+          } else {
+            L[j] = operand(cur.child[j], cur.cslot[j], ts.c[j]);
+          }
+        }
+        store_slot(cur.qslot, mul4(matvec(mat(cur.child[0], k), L[0]),
+                                   matvec(mat(cur.child[1], k), L[1])));
+        cur = nxt;
+        ts = tsn;
       }
     }
-    // ---- pre-order + edge derivatives, parents before children.  The wave
-    // reduction of visit i is issued during visit i-1 so that its dependent
-    // permute chain overlaps independent arithmetic.
+    // ================= pre-order + edge derivatives =================
     const double cw = model->cat_weight[k];
     const double fb = coef * cw * model->cat_rate[k];
     const double fs = coef * cw * model->cat_drate[k];
     {
-      SchedEntry s_cur = sched[n - 2];
-      SchedEntry s_nxt = sched[n > 2 ? n - 3 : 0];
-      int st0 = tip_state(s_cur.child0), st1 = tip_state(s_cur.child1);
-      double pend0 = 0, pend1 = 0;  // numerators of the previous visit
-      int pend_c0 = 0, pend_c1 = 0;
-      bool have_pending = false;
-      auto flush = [&]() {
-        const double r = reduce4_transposed(fb * pend0, fb * pend1, fs * pend0, fs * pend1);
-        // lane 15: branch c0, lane 31: site c0, lane 47: branch c1, lane 63: site c1
-        if ((lane & 15) == 15) {
-          const int which = lane >> 4;
-          const int edge = (which & 2) ? pend_c1 : pend_c0;
-          double* dst = gacc + ((which & 1) ? N : 0) + edge;
-          *dst += r;
-        }
-      };
-      for (int i = n - 2; i >= 0; i--) {
-        const SchedEntry s_nn = sched[i >= 2 ? i - 2 : 0];
-        asm volatile("" ::"s"(touched));
-        touched = touch(mat_ptr(s_nxt.child0, k), mat_ptr(s_nxt.child1, k));
-        const int st0n = tip_state(s_nxt.child0), st1n = tip_state(s_nxt.child1);
-        const cdouble_ptr M0 = as_const(mat_ptr(s_cur.child0, k));
-        const cdouble_ptr M1 = as_const(mat_ptr(s_cur.child1, k));
-        const D4 L0 = partial_of(s_cur.child0, st0);
-        const D4 L1 = partial_of(s_cur.child1, st1);
-        const bool is_root = i == n - 2;
-        const D4 qs = load_col(is_root ? n : s_cur.node);
+      MacroEntry cur = macros[M - 1];
+      TipStates ts = fetch_tips(cur);
+      for (int m = M - 1; m >= 0; m--) {
+        const MacroEntry nxt = macros[m > 0 ? m - 1 : 0];
+        const TipStates tsn = fetch_tips(nxt);
+        const bool is_root = cur.qslot < 0;
+        const D4 qs = load_slot(is_root ? 0 : cur.qslot);
         const D4 qv = {is_root ? pi4.x0 : qs.x0, is_root ? pi4.x1 : qs.x1,
                        is_root ? pi4.x2 : qs.x2, is_root ? pi4.x3 : qs.x3};
-        if (have_pending) flush();
-        const D4 A = matvec(M0, L0), B = matvec(M1, L1);
-        const D4 q0 = matTvec(M0, mul4(qv, B));
-        const D4 q1 = matTvec(M1, mul4(qv, A));
-        pend0 = dot4(q0, matvec(Q, L0));
-        pend1 = dot4(q1, matvec(Q, L1));
-        pend_c0 = s_cur.child0;
-        pend_c1 = s_cur.child1;
-        have_pending = true;
-        if (s_cur.child0 >= n) store_col(s_cur.child0, q0);
-        if (s_cur.child1 >= n) store_col(s_cur.child1, q1);
-        s_cur = s_nxt;
-        s_nxt = s_nn;
-        st0 = st0n;
-        st1 = st1n;
+        D4 L[2], La[2], Lb[2], Ap[2], Bp[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          if (cur.kind[j] == 2) {
+            La[j] = operand(cur.grand[2 * j], cur.gslot[2 * j], ts.g[2 * j]);
+            Lb[j] = operand(cur.grand[2 * j + 1], cur.gslot[2 * j + 1], ts.g[2 * j + 1]);
+            Ap[j] = matvec(mat(cur.grand[2 * j], k), La[j]);
+            Bp[j] = matvec(mat(cur.grand[2 * j + 1], k), Lb[j]);
+            L[j] = mul4(Ap[j], Bp[j]);
+          } else {
+            L[j] = operand(cur.child[j], cur.cslot[j], ts.c[j]);
+            La[j] = Lb[j] = Ap[j] = Bp[j] = D4{0, 0, 0, 0};
+          }
+        }
+        D4 q[2];
+        {
+          const cdouble_ptr M0 = mat(cur.child[0], k);
+          const cdouble_ptr M1 = mat(cur.child[1], k);
+          const D4 A = matvec(M0, L[0]), B = matvec(M1, L[1]);
+          q[0] = matTvec(M0, mul4(qv, B));
+          q[1] = matTvec(M1, mul4(qv, A));
+        }
+        {
+          const double n0 = dot4(q[0], matvec(Q, L[0]));
+          const double n1 = dot4(q[1], matvec(Q, L[1]));
+          accumulate(reduce4_transposed(fb * n0, fb * n1, fs * n0, fs * n1), cur.child[0],
+                     cur.child[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          if (cur.kind[j] == 1) {
+            store_slot(cur.cslot[j], q[j]);
+          } else if (cur.kind[j] == 2) {
+            const int ga = cur.grand[2 * j], gb = cur.grand[2 * j + 1];
+            const D4 qa = matTvec(mat(ga, k), mul4(q[j], Bp[j]));
+            const D4 qb = matTvec(mat(gb, k), mul4(q[j], Ap[j]));
+            const double na = dot4(qa, matvec(Q, La[j]));
+            const double nb = dot4(qb, matvec(Q, Lb[j]));
+            accumulate(reduce4_transposed(fb * na, fb * nb, fs * na, fs * nb), ga, gb);
+            if (ga >= n) store_slot(cur.gslot[2 * j], qa);
+            if (gb >= n) store_slot(cur.gslot[2 * j + 1], qb);
+          }
+        }
+        cur = nxt;
+        ts = tsn;
       }
-      flush();
     }
   }
-  asm volatile("" ::"s"(touched));
   __syncthreads();
   double* gout = a.g_part + ((size_t)gi * a.tiles + tile) * 2 * N;
   for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];
@@ -1152,7 +1215,7 @@ void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t 
 }
 size_t gradient_onchip_lds_bytes(int n) {
   const int N = 2 * n - 1;
-  return sizeof(double) * ((size_t)(n - 2) * 4 * kTile + 2 * N);
+  return sizeof(double) * ((size_t)max_stored(n) * 4 * kTile + 2 * N);
 }
 bool gradient_onchip_fits(int n) { return n >= 3 && gradient_onchip_lds_bytes(n) <= 160 * 1024; }
 void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s) {

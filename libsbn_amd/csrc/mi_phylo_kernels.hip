@@ -86,6 +86,16 @@ __device__ __forceinline__ D4 tip_column(MP M, int st) {
           select_state(st, M[12], M[13], M[14], M[15], 1.0)};
 }
 
+__device__ __forceinline__ D4 load4(const double* __restrict__ ptr) {
+  const double2 lo = *reinterpret_cast<const double2*>(ptr);
+  const double2 hi = *reinterpret_cast<const double2*>(ptr + 2);
+  return {lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ void store4(double* ptr, D4 v) {
+  *reinterpret_cast<double2*>(ptr) = double2{v.x0, v.x1};
+  *reinterpret_cast<double2*>(ptr + 2) = double2{v.x2, v.x3};
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -524,50 +534,82 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
   const double w = p < a.P ? a.weights[pc] : 0.0;
   const int K = a.K, n = a.n;
   const double* __restrict__ mats_e = a.mats + (size_t)e * (a.N - 1) * K * 16;
+  const int8_t* __restrict__ tips_p = a.tip_states + pc;
+  const double* __restrict__ tipp_p = TIP_PARTIALS ? a.tip_partials + (size_t)pc * 4 : nullptr;
+
+  auto load_slot = [&](int slot) {
+    const double* c = lds + slot * 4 * kTile + lane;
+    return D4{c[0], c[kTile], c[2 * kTile], c[3 * kTile]};
+  };
+  auto mat = [&](int node, int k) { return as_const(mats_e + ((size_t)node * K + k) * 16); };
+  // Everything a visit needs from global memory is requested one visit ahead: the
+  // schedule entry two ahead, the tip states / tip partials and a touch of the
+  // transition matrices (scalar cache) one ahead.  The walk is a chain of short
+  // dependent steps; without this every visit pays an L2 round trip.
+  struct TipData {
+    int st[2];
+    D4 tp[2];
+  };
+  auto fetch_tip = [&](const SchedEntry& s) {
+    TipData d;
+    const int c0 = s.child0 < n ? s.child0 : 0, c1 = s.child1 < n ? s.child1 : 0;
+    if (TIP_PARTIALS) {
+      d.tp[0] = load4(tipp_p + (size_t)c0 * a.P * 4);
+      d.tp[1] = load4(tipp_p + (size_t)c1 * a.P * 4);
+      d.st[0] = d.st[1] = 0;
+    } else {
+      d.st[0] = tips_p[(size_t)c0 * a.P];
+      d.st[1] = tips_p[(size_t)c1 * a.P];
+      d.tp[0] = d.tp[1] = D4{0, 0, 0, 0};
+    }
+    return d;
+  };
+  auto touch = [&](const SchedEntry& s, int k) {
+    const cint_ptr a0 = (cint_ptr)(uintptr_t)(mats_e + ((size_t)s.child0 * K + k) * 16);
+    const cint_ptr a1 = (cint_ptr)(uintptr_t)(mats_e + ((size_t)s.child1 * K + k) * 16);
+    return a0[0] ^ a0[16] ^ a1[0] ^ a1[16];
+  };
+  int touched = 0;
 
   double site = 0.0;
   int site_exp = 0;
   for (int k = 0; k < K; k++) {
     int cum_exp = 0;
     D4 L = {0, 0, 0, 0};
+    SchedEntry s_cur = sched[0];
+    SchedEntry s_nxt = sched[n > 2 ? 1 : 0];
+    TipData td = fetch_tip(s_cur);
     for (int i = 0; i < n - 1; i++) {
-      const SchedEntry s = sched[i];
-      const double* __restrict__ M0 = mats_e + ((size_t)s.child0 * K + k) * 16;
-      const double* __restrict__ M1 = mats_e + ((size_t)s.child1 * K + k) * 16;
-      D4 A, B;
-      if (s.child0 < n) {
-        if (TIP_PARTIALS) {
-          const double* tp = a.tip_partials + ((size_t)s.child0 * a.P + pc) * 4;
-          A = matvec(M0, D4{tp[0], tp[1], tp[2], tp[3]});
-        } else {
-          A = tip_column(M0, a.tip_states[(size_t)s.child0 * a.P + pc]);
-        }
-      } else {
-        const double* col = lds + ((s.slots >> 8) & 0xff) * 4 * kTile + lane;
-        A = matvec(M0, D4{col[0], col[kTile], col[2 * kTile], col[3 * kTile]});
-      }
-      if (s.child1 < n) {
-        if (TIP_PARTIALS) {
-          const double* tp = a.tip_partials + ((size_t)s.child1 * a.P + pc) * 4;
-          B = matvec(M1, D4{tp[0], tp[1], tp[2], tp[3]});
-        } else {
-          B = tip_column(M1, a.tip_states[(size_t)s.child1 * a.P + pc]);
-        }
-      } else {
-        const double* col = lds + ((s.slots >> 16) & 0xff) * 4 * kTile + lane;
-        B = matvec(M1, D4{col[0], col[kTile], col[2 * kTile], col[3 * kTile]});
-      }
-      L = mul4(A, B);
+      const SchedEntry s_nn = sched[i + 2 < n - 1 ? i + 2 : n - 2];
+      asm volatile("" ::"s"(touched));
+      touched = touch(s_nxt, k);
+      const TipData tdn = fetch_tip(s_nxt);
+      const cdouble_ptr M0 = mat(s_cur.child0, k);
+      const cdouble_ptr M1 = mat(s_cur.child1, k);
+      const bool tip0 = s_cur.child0 < n, tip1 = s_cur.child1 < n;
+      // operands: both sources are read, one is selected (no LDS round trip behind a branch)
+      const D4 c0 = load_slot(tip0 ? 0 : (s_cur.slots >> 8) & 0xff);
+      const D4 c1 = load_slot(tip1 ? 0 : (s_cur.slots >> 16) & 0xff);
+      const D4 v0 = TIP_PARTIALS ? td.tp[0] : tip_vector(td.st[0]);
+      const D4 v1 = TIP_PARTIALS ? td.tp[1] : tip_vector(td.st[1]);
+      const D4 L0 = {tip0 ? v0.x0 : c0.x0, tip0 ? v0.x1 : c0.x1, tip0 ? v0.x2 : c0.x2,
+                     tip0 ? v0.x3 : c0.x3};
+      const D4 L1 = {tip1 ? v1.x0 : c1.x0, tip1 ? v1.x1 : c1.x1, tip1 ? v1.x2 : c1.x2,
+                     tip1 ? v1.x3 : c1.x3};
+      L = mul4(matvec(M0, L0), matvec(M1, L1));
       if (RESCALE) {
         const int ex = max_exponent(max4(L));
         L = scale4(L, -ex);
         cum_exp += ex;
       }
-      double* dst = lds + (s.slots & 0xff) * 4 * kTile + lane;
+      double* dst = lds + (s_cur.slots & 0xff) * 4 * kTile + lane;
       dst[0] = L.x0;
       dst[kTile] = L.x1;
       dst[2 * kTile] = L.x2;
       dst[3 * kTile] = L.x3;
+      s_cur = s_nxt;
+      s_nxt = s_nn;
+      td = tdn;
     }
     // the last schedule entry is the root
     const double sk = model->cat_weight[k] * (model->pi[0] * L.x0 + model->pi[1] * L.x1 +
@@ -586,6 +628,7 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
       site += sk;
     }
   }
+  asm volatile("" ::"s"(touched));
   if (!RESCALE && a.site_lik)
     a.site_lik[((size_t)a.grad_offset + blockIdx.y) * a.tiles * kTile + p] = site;
   double ll = log(site);
@@ -603,16 +646,6 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
 // so no inter-wave synchronisation is needed.  The pre-order vector of a node
 // overwrites its post-order vector in place once the latter is dead.
 // ------------------------------------------------------------------------
-__device__ __forceinline__ D4 load4(const double* __restrict__ ptr) {
-  const double2 lo = *reinterpret_cast<const double2*>(ptr);
-  const double2 hi = *reinterpret_cast<const double2*>(ptr + 2);
-  return {lo.x, lo.y, hi.x, hi.y};
-}
-__device__ __forceinline__ void store4(double* ptr, D4 v) {
-  *reinterpret_cast<double2*>(ptr) = double2{v.x0, v.x1};
-  *reinterpret_cast<double2*>(ptr + 2) = double2{v.x2, v.x3};
-}
-
 template <bool RESCALE, bool TIP_PARTIALS>
 __global__ __launch_bounds__(kTile) void gradient_hbm_kernel(LikArgs a) {
   const int lane = threadIdx.x;

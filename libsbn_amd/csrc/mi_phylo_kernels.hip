@@ -916,6 +916,24 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
     for (int j = 0; j < 4; j++) ts.g[j] = tip_state(me.grand[j]);
     return ts;
   };
+  // Pull the NEXT macro's transition matrices (up to six) into the scalar data
+  // cache: one dword from each 64-byte line.  The value is consumed an iteration
+  // later, so the loads are in flight behind this macro's arithmetic.
+  auto touch_macro = [&](const MacroEntry& me, int k) {
+    int acc = 0;
+    for (int j = 0; j < 2; j++) {
+      const cint_ptr pm = (cint_ptr)(uintptr_t)(
+          mats_e + ((size_t)__builtin_amdgcn_readfirstlane(me.child[j]) * K + k) * 16);
+      acc ^= pm[0] ^ pm[16];
+    }
+    for (int j = 0; j < 4; j++) {
+      const cint_ptr pm = (cint_ptr)(uintptr_t)(
+          mats_e + ((size_t)__builtin_amdgcn_readfirstlane(me.grand[j]) * K + k) * 16);
+      acc ^= pm[0] ^ pm[16];
+    }
+    return acc;
+  };
+  int touched = 0;
   auto accumulate = [&](double r, int edge_a, int edge_b) {
     // after reduce4_transposed(x_a_branch, x_b_branch, x_a_site, x_b_site):
     // lane 15: branch a, lane 31: site a, lane 47: branch b, lane 63: site b
@@ -936,6 +954,9 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
       for (int m = 0; m < M - 1; m++) {
         const MacroEntry nxt = macros[m + 1];
         const TipStates tsn = fetch_tips(nxt);
+        asm volatile("" ::"s"(touched));
+        touched = touch_macro(cur, k);  // cur's own matrices: first use is a few
+                                        // hundred cycles away (operands come first)
         D4 L[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
@@ -964,6 +985,8 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
       for (int m = M - 1; m >= 0; m--) {
         const MacroEntry nxt = macros[m > 0 ? m - 1 : 0];
         const TipStates tsn = fetch_tips(nxt);
+        asm volatile("" ::"s"(touched));
+        touched = touch_macro(cur, k);
         const bool is_root = cur.qslot < 0;
         const D4 qs = load_slot(is_root ? 0 : cur.qslot);
         const D4 qv = {is_root ? pi4.x0 : qs.x0, is_root ? pi4.x1 : qs.x1,
@@ -1016,6 +1039,7 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
       }
     }
   }
+  asm volatile("" ::"s"(touched));
   __syncthreads();
   double* gout = a.g_part + ((size_t)gi * a.tiles + tile) * 2 * N;
   for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];

@@ -89,7 +89,7 @@ struct mi_engine {
   // static device data
   Buffer tip_states, tip_partials, weights;
   // per-call workspace
-  Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, ll_part, plv, g_part, site_lik, fin_scratch,
+  Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, ll_part, plv, g_part, site_lik, fin_scratch,
       status;
   bool allow_onchip_gradient = true;
   // staging for the host-pointer entry points
@@ -144,6 +144,7 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
   if (e->bl_eff.ensure(sizeof(double) * (size_t)T * N)) return 1;
   if (e->models.ensure(sizeof(DevModel) * (size_t)c.M)) return 1;
   if (e->mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
+  if (e->tip_tables.ensure(sizeof(double) * (size_t)c.E * n * e->K * 40)) return 1;
   if (e->ll_part.ensure(sizeof(double) * (size_t)c.E * e->tiles)) return 1;
   if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
   if (e->status.ensure(sizeof(int32_t) * 2)) return 1;
@@ -232,6 +233,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   tr.models = e->models.as<DevModel>();
   tr.bl_eff = e->bl_eff.as<double>();
   tr.mats = e->mats.as<double>();
+  tr.tip_tables = e->tip_tables.as<double>();
+  tr.n = n;
   launch_transition(tr, s);
 
   LikArgs la{};
@@ -246,6 +249,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.macros = e->macros.as<MacroEntry>();
   la.macro_count = e->macro_count.as<int32_t>();
   la.mats = e->mats.as<double>();
+  la.tip_tables = e->tip_tables.as<double>();
   la.tip_states = e->tip_states.as<int8_t>();
   la.tip_partials = e->spec.use_tip_states ? nullptr : e->tip_partials.as<double>();
   la.weights = e->weights.as<double>();
@@ -485,7 +489,7 @@ void mi_engine_destroy(mi_engine* e) {
   }
   for (Buffer* b :
        {&e->tip_states, &e->tip_partials, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
-        &e->macro_count, &e->bl_eff,
+        &e->macro_count, &e->tip_tables, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->fin_scratch,
         &e->status,
         &e->in_parent, &e->in_bl, &e->in_params, &e->in_rates, &e->in_rate_counts,

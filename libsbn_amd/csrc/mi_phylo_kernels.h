@@ -61,10 +61,13 @@ struct TransitionArgs {
   const DevModel* models;
   const double* bl_eff;  // [T][N]
   double* mats;          // [E][N-1][K][16]
+  double* tip_tables;    // [E][n][K][2][5][4]: per tip edge, P columns (+ones row) and (P Q) columns (+zero row)
+  int n;
 };
 
 struct LikArgs {
   int n, N, P, K, tiles;
+  int lds_slots;    // PLV slots in LDS (set by the launcher)
   int eval_offset;  // first evaluation of this launch
   int grad_offset;  // gradient-workspace index of that evaluation
   EvalMap map;
@@ -73,6 +76,7 @@ struct LikArgs {
   const MacroEntry* macros;    // [T][max_macros(n)]
   const int32_t* macro_count;  // [T]
   const double* mats;
+  const double* tip_tables;    // see TransitionArgs
   const int8_t* tip_states;    // [n][P]
   const double* tip_partials;  // [n][P][4] or nullptr
   const double* weights;       // [P]

@@ -503,12 +503,33 @@ __global__ void transition_kernel(TransitionArgs a) {
   for (int x = 0; x < 4; x++)
     for (int j = 0; j < 4; j++) W[x * 4 + j] = ex[x] * m.Vinv[x * 4 + j];
   double* out = a.mats + idx * 16;
+  double Pm[16];
   for (int i = 0; i < 4; i++)
     for (int j = 0; j < 4; j++) {
       double sum = i == j ? 1.0 : 0.0;
       for (int x = 0; x < 4; x++) sum += m.V[i * 4 + x] * W[x * 4 + j];
-      out[i * 4 + j] = sum > 0 ? sum : 0;  // BEAGLE clamps negative probabilities to 0
+      Pm[i * 4 + j] = sum > 0 ? sum : 0;  // BEAGLE clamps negative probabilities to 0
+      out[i * 4 + j] = Pm[i * 4 + j];
     }
+  if (edge < a.n) {
+    // Tip edges: what a compact tip state st contributes is a COLUMN of P (forward
+    // sweep) or of P Q (edge derivative); a gap contributes 1 resp. 0 (rows of P sum
+    // to 1, rows of Q to 0).  Tabulated per state so that the walk kernels fetch
+    // them with one 32-byte gather instead of spending FP64 issue slots on one-hot
+    // vectors: table[0][st][i] = P[i][st], table[1][st][i] = (P Q)[i][st].
+    double* tab = a.tip_tables + (((size_t)e * a.n + edge) * a.K + k) * 40;
+    for (int st = 0; st < 4; st++)
+      for (int i = 0; i < 4; i++) {
+        tab[st * 4 + i] = Pm[i * 4 + st];
+        double pq = 0;
+        for (int x = 0; x < 4; x++) pq += Pm[i * 4 + x] * m.Q[x * 4 + st];
+        tab[20 + st * 4 + i] = pq;
+      }
+    for (int i = 0; i < 4; i++) {
+      tab[16 + i] = 1.0;
+      tab[36 + i] = 0.0;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------
@@ -534,33 +555,35 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
   const double w = p < a.P ? a.weights[pc] : 0.0;
   const int K = a.K, n = a.n;
   const double* __restrict__ mats_e = a.mats + (size_t)e * (a.N - 1) * K * 16;
-  const int8_t* __restrict__ tips_p = a.tip_states + pc;
-  const double* __restrict__ tipp_p = TIP_PARTIALS ? a.tip_partials + (size_t)pc * 4 : nullptr;
+  const double* __restrict__ tabs_e = a.tip_tables + (size_t)e * n * K * 40;
+  // LDS: PLV columns [slot][state][lane] | this tile's tip states [taxon][lane]
+  int8_t* tips = reinterpret_cast<int8_t*>(lds + (size_t)a.lds_slots * 4 * kTile);
+  if (!TIP_PARTIALS) {
+    for (int i = 0; i < n; i++) tips[i * kTile + lane] = a.tip_states[(size_t)i * a.P + pc];
+  }
+  __syncthreads();
 
   auto load_slot = [&](int slot) {
     const double* c = lds + slot * 4 * kTile + lane;
     return D4{c[0], c[kTile], c[2 * kTile], c[3 * kTile]};
   };
   auto mat = [&](int node, int k) { return as_const(mats_e + ((size_t)node * K + k) * 16); };
-  // Everything a visit needs from global memory is requested one visit ahead: the
-  // schedule entry two ahead, the tip states / tip partials and a touch of the
-  // transition matrices (scalar cache) one ahead.  The walk is a chain of short
-  // dependent steps; without this every visit pays an L2 round trip.
-  struct TipData {
-    int st[2];
-    D4 tp[2];
+  // What the tip children of a visit contribute is fetched one visit ahead:
+  // compact states -> one 32-byte gather from the tip table (column of P, no
+  // arithmetic); tip partials -> the partial vector itself.
+  struct TipPre {
+    D4 v[2];
   };
-  auto fetch_tip = [&](const SchedEntry& s) {
-    TipData d;
+  auto fetch_tip = [&](const SchedEntry& s, int k) {
+    TipPre d;
     const int c0 = s.child0 < n ? s.child0 : 0, c1 = s.child1 < n ? s.child1 : 0;
     if (TIP_PARTIALS) {
-      d.tp[0] = load4(tipp_p + (size_t)c0 * a.P * 4);
-      d.tp[1] = load4(tipp_p + (size_t)c1 * a.P * 4);
-      d.st[0] = d.st[1] = 0;
+      d.v[0] = load4(a.tip_partials + ((size_t)c0 * a.P + pc) * 4);
+      d.v[1] = load4(a.tip_partials + ((size_t)c1 * a.P + pc) * 4);
     } else {
-      d.st[0] = tips_p[(size_t)c0 * a.P];
-      d.st[1] = tips_p[(size_t)c1 * a.P];
-      d.tp[0] = d.tp[1] = D4{0, 0, 0, 0};
+      const int st0 = tips[c0 * kTile + lane], st1 = tips[c1 * kTile + lane];
+      d.v[0] = load4(tabs_e + ((size_t)c0 * K + k) * 40 + st0 * 4);
+      d.v[1] = load4(tabs_e + ((size_t)c1 * K + k) * 40 + st1 * 4);
     }
     return d;
   };
@@ -578,25 +601,24 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
     D4 L = {0, 0, 0, 0};
     SchedEntry s_cur = sched[0];
     SchedEntry s_nxt = sched[n > 2 ? 1 : 0];
-    TipData td = fetch_tip(s_cur);
+    TipPre td = fetch_tip(s_cur, k);
     for (int i = 0; i < n - 1; i++) {
       const SchedEntry s_nn = sched[i + 2 < n - 1 ? i + 2 : n - 2];
       asm volatile("" ::"s"(touched));
       touched = touch(s_nxt, k);
-      const TipData tdn = fetch_tip(s_nxt);
+      const TipPre tdn = fetch_tip(s_nxt, k);
       const cdouble_ptr M0 = mat(s_cur.child0, k);
       const cdouble_ptr M1 = mat(s_cur.child1, k);
       const bool tip0 = s_cur.child0 < n, tip1 = s_cur.child1 < n;
-      // operands: both sources are read, one is selected (no LDS round trip behind a branch)
+      // PLV columns are read unconditionally (slot 0 for a tip), before any branch
       const D4 c0 = load_slot(tip0 ? 0 : (s_cur.slots >> 8) & 0xff);
       const D4 c1 = load_slot(tip1 ? 0 : (s_cur.slots >> 16) & 0xff);
-      const D4 v0 = TIP_PARTIALS ? td.tp[0] : tip_vector(td.st[0]);
-      const D4 v1 = TIP_PARTIALS ? td.tp[1] : tip_vector(td.st[1]);
-      const D4 L0 = {tip0 ? v0.x0 : c0.x0, tip0 ? v0.x1 : c0.x1, tip0 ? v0.x2 : c0.x2,
-                     tip0 ? v0.x3 : c0.x3};
-      const D4 L1 = {tip1 ? v1.x0 : c1.x0, tip1 ? v1.x1 : c1.x1, tip1 ? v1.x2 : c1.x2,
-                     tip1 ? v1.x3 : c1.x3};
-      L = mul4(matvec(M0, L0), matvec(M1, L1));
+      D4 A, B;
+      if (tip0) A = TIP_PARTIALS ? matvec(M0, td.v[0]) : td.v[0];
+      else A = matvec(M0, c0);
+      if (tip1) B = TIP_PARTIALS ? matvec(M1, td.v[1]) : td.v[1];
+      else B = matvec(M1, c1);
+      L = mul4(A, B);
       if (RESCALE) {
         const int ex = max_exponent(max4(L));
         L = scale4(L, -ex);
@@ -1245,10 +1267,12 @@ void launch_transition(const TransitionArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(transition_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                      a);
 }
-void launch_loglik(const LikArgs& a, int count, bool rescale, int max_slots, hipStream_t s) {
+void launch_loglik(const LikArgs& a_in, int count, bool rescale, int max_slots, hipStream_t s) {
   if (count <= 0) return;
+  LikArgs a = a_in;
+  a.lds_slots = max_slots;
   const dim3 grid(a.tiles, count), block(kTile);
-  const size_t lds = (size_t)max_slots * 4 * kTile * sizeof(double);
+  const size_t lds = (size_t)max_slots * 4 * kTile * sizeof(double) + (size_t)a.n * kTile;
   const bool tp = a.tip_partials != nullptr;
   if (rescale) {
     if (tp) hipLaunchKernelGGL((loglik_onchip_kernel<true, true>), grid, block, lds, s, a);

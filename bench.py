@@ -109,9 +109,14 @@ def main():
         sys.exit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    # MI_BENCH_FORCE_DIST=1 runs the collective path even with one rank (smoke test of
+    # the RCCL branch on a 1-GPU box)
+    distributed = world > 1 or os.environ.get("MI_BENCH_FORCE_DIST") == "1"
     if distributed:
-        dist.init_process_group("nccl", device_id=dev)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     T = args.trees
     tips, w, pids, bls, params = build_workload(T, seed=43 + rank)
@@ -175,6 +180,7 @@ def main():
         lo = rank * T
         assert bool(torch.equal(gathered[0][lo:lo + T, 0], d_ll)), "gathered slice mismatch"
 
+    out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * T / (elapsed / args.steps)
@@ -216,10 +222,16 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(tips, w, pids, bls, params, args.mode)
-        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio, which is flushed at exit when
+        # stdout is a file: flush it now so that the JSON line is the last line.
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":

@@ -1,0 +1,237 @@
+// C++ adapter with the public shape of libsbn's Engine (src/engine.hpp:26-54) on
+// top of the C ABI (include/mi_phylo.h).  Header-only; links against
+// libmi_phylo.so (+ libmi_phylo_host.so for the tree / site-pattern types).
+//
+//   reference                               here
+//   EngineSpecification  engine.hpp:20-24   mihost::EngineSpecification
+//   PhyloModelSpecification phylo_model.hpp:13-17   mihost::PhyloModelSpecification
+//   PhyloGradient        tree_gradient.hpp:10-19    mihost::PhyloGradient
+//   {Unrooted,Rooted}TreeCollection         std::vector<FlatTree> / <RootedFlatTree>
+//   EigenMatrixXdRef (row-major)            mihost::ParamMatrix
+// Errors are std::runtime_error, like Failwith (src/sugar.hpp:67-78).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../../include/mi_phylo.h"
+#include "mi_host.hpp"
+
+namespace mihost {
+
+struct PhyloModelSpecification {
+  std::string substitution_, site_, clock_;
+};
+
+struct EngineSpecification {
+  size_t thread_count_;
+  std::vector<int> beagle_flag_vector_;  // accepted and ignored
+  bool use_tip_states_;
+};
+
+using GradientMap = std::map<std::string, std::vector<double>>;
+struct PhyloGradient {
+  double log_likelihood_ = 0.;
+  GradientMap gradient_;
+};
+
+struct ParamMatrix {  // row-major [rows x cols]
+  size_t rows = 0, cols = 0;
+  std::vector<double> data;
+  ParamMatrix() = default;
+  ParamMatrix(size_t r, size_t c) : rows(r), cols(c), data(r * c, 0.) {}
+  double& operator()(size_t r, size_t c) { return data[r * cols + c]; }
+  void SetBlock(size_t start, size_t length, const std::vector<double>& values) {
+    for (size_t r = 0; r < rows; r++)
+      for (size_t i = 0; i < length; i++) data[r * cols + start + i] = values[i % values.size()];
+  }
+};
+
+using UnrootedTreeCollection = std::vector<FlatTree>;
+using RootedTreeCollection = std::vector<RootedFlatTree>;
+using BlockSpecificationMap = std::map<std::string, std::pair<size_t, size_t>>;
+
+class Engine {
+ public:
+  Engine(const EngineSpecification& engine_specification,
+         const PhyloModelSpecification& specification, SitePattern site_pattern)
+      : site_pattern_(std::move(site_pattern)) {
+    if (engine_specification.thread_count_ == 0)
+      Failwith("Thread count needs to be strictly positive.");
+    mi_engine_spec spec{};
+    spec.taxon_count = static_cast<int32_t>(site_pattern_.SequenceCount());
+    spec.pattern_count = static_cast<int32_t>(site_pattern_.PatternCount());
+    spec.state_count = 4;
+    if (specification.substitution_ == "JC69") spec.subst_model = MI_SUBST_JC69;
+    else if (specification.substitution_ == "GTR") spec.subst_model = MI_SUBST_GTR;
+    else Failwith("Substitution model not known: " + specification.substitution_);
+    if (specification.site_ == "constant") {
+      spec.site_model = MI_SITE_CONSTANT;
+      spec.category_count = 1;
+    } else if (specification.site_.rfind("weibull", 0) == 0) {  // site_model.cpp:15-22
+      spec.site_model = MI_SITE_WEIBULL;
+      const auto plus = specification.site_.find("+");
+      spec.category_count =
+          plus == std::string::npos ? 4 : std::stoi(specification.site_.substr(plus + 1));
+    } else {
+      Failwith("Site model not known: " + specification.site_);
+    }
+    if (specification.clock_ == "none") spec.clock_model = MI_CLOCK_NONE;
+    else if (specification.clock_ == "strict") spec.clock_model = MI_CLOCK_STRICT;
+    else Failwith("Clock model not known: " + specification.clock_);
+    spec.use_tip_states = engine_specification.use_tip_states_;
+    spec.device = -1;
+    category_count_ = spec.category_count;
+    is_gtr_ = spec.subst_model == MI_SUBST_GTR;
+    const auto tips = site_pattern_.FlatPatterns();
+    Check(mi_engine_create(&spec, tips.data(), nullptr, site_pattern_.GetWeights().data(),
+                           &handle_));
+    for (int i = 0; i < mi_engine_block_count(handle_); i++) {
+      const char* name;
+      int32_t start, length;
+      Check(mi_engine_block(handle_, i, &name, &start, &length));
+      block_specification_[name] = {static_cast<size_t>(start), static_cast<size_t>(length)};
+    }
+  }
+  ~Engine() { mi_engine_destroy(handle_); }
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  const BlockSpecificationMap& GetPhyloModelBlockSpecification() const {
+    return block_specification_;
+  }
+  size_t ParameterCount() const { return block_specification_.at("entire").second; }
+
+  std::vector<double> LogLikelihoods(const UnrootedTreeCollection& trees,
+                                     const ParamMatrix& params, const bool rescaling) const {
+    std::vector<int32_t> parents;
+    std::vector<double> bl;
+    Flatten(trees, params, &parents, &bl);
+    std::vector<double> out(trees.size());
+    Check(mi_engine_log_likelihoods_unrooted(handle_, static_cast<int32_t>(trees.size()),
+                                             parents.data(), bl.data(), params.data.data(),
+                                             rescaling, out.data()));
+    return out;
+  }
+
+  std::vector<double> LogLikelihoods(const RootedTreeCollection& trees,
+                                     const ParamMatrix& params, const bool rescaling) const {
+    return RootedLogLikelihoods(trees, params, rescaling, true);
+  }
+
+  std::vector<double> UnrootedLogLikelihoods(const RootedTreeCollection& trees,
+                                             const ParamMatrix& params,
+                                             const bool rescaling) const {
+    return RootedLogLikelihoods(trees, params, rescaling, false);
+  }
+
+  std::vector<PhyloGradient> Gradients(const UnrootedTreeCollection& trees,
+                                       const ParamMatrix& params, const bool rescaling) const {
+    const size_t T = trees.size(), N = 2 * site_pattern_.SequenceCount() - 1;
+    std::vector<int32_t> parents;
+    std::vector<double> bl;
+    Flatten(trees, params, &parents, &bl);
+    std::vector<double> ll(T), g(T * N), site(T), subst(T * 8);
+    Check(mi_engine_gradients_unrooted(handle_, static_cast<int32_t>(T), parents.data(),
+                                       bl.data(), params.data.data(), rescaling, ll.data(),
+                                       g.data(), site.data(), subst.data()));
+    std::vector<PhyloGradient> out(T);
+    for (size_t t = 0; t < T; t++) {
+      out[t].log_likelihood_ = ll[t];
+      out[t].gradient_["branch_lengths"].assign(g.begin() + t * N, g.begin() + (t + 1) * N);
+      AddModelGradients(&out[t], site[t], &subst[8 * t]);
+    }
+    return out;
+  }
+
+  std::vector<PhyloGradient> Gradients(const RootedTreeCollection& trees,
+                                       const ParamMatrix& params, const bool rescaling) const {
+    const size_t T = trees.size(), n = site_pattern_.SequenceCount(), N = 2 * n - 1;
+    std::vector<int32_t> parents, rate_counts;
+    std::vector<double> bl, rates, heights, bounds, ratios;
+    Flatten(trees, params, &parents, &bl);
+    for (const auto& tree : trees) {
+      if (!tree.TimeTreeHasBeenInitialized())  // rooted_tree.hpp:50-53
+        Failwith("Attempted access of a time tree member that requires the time tree to be "
+                 "initialized. Have you set dates for your time trees, and initialized the "
+                 "time trees?");
+      rates.insert(rates.end(), tree.rates_.begin(), tree.rates_.end());
+      rate_counts.push_back(static_cast<int32_t>(tree.rate_count_));
+      heights.insert(heights.end(), tree.node_heights_.begin(), tree.node_heights_.end());
+      bounds.insert(bounds.end(), tree.node_bounds_.begin(), tree.node_bounds_.end());
+      ratios.insert(ratios.end(), tree.height_ratios_.begin(), tree.height_ratios_.end());
+    }
+    std::vector<double> ll(T), gr(T * (n - 1)), gc(T * (N - 1)), site(T), subst(T * 8);
+    Check(mi_engine_gradients_rooted(handle_, static_cast<int32_t>(T), parents.data(), bl.data(),
+                                     params.data.data(), rates.data(), rate_counts.data(),
+                                     heights.data(), bounds.data(), ratios.data(), rescaling,
+                                     ll.data(), gr.data(), gc.data(), site.data(),
+                                     subst.data()));
+    std::vector<PhyloGradient> out(T);
+    for (size_t t = 0; t < T; t++) {
+      out[t].log_likelihood_ = ll[t];
+      out[t].gradient_["ratios_root_height"].assign(gr.begin() + t * (n - 1),
+                                                    gr.begin() + (t + 1) * (n - 1));
+      const size_t clock_len = trees[t].rate_count_ == 1 ? 1 : N - 1;
+      out[t].gradient_["clock_model"].assign(gc.begin() + t * (N - 1),
+                                             gc.begin() + t * (N - 1) + clock_len);
+      AddModelGradients(&out[t], site[t], &subst[8 * t]);
+    }
+    return out;
+  }
+
+ private:
+  SitePattern site_pattern_;
+  mi_engine* handle_ = nullptr;
+  BlockSpecificationMap block_specification_;
+  int category_count_ = 1;
+  bool is_gtr_ = false;
+
+  static void Check(int rc) {
+    if (rc != 0) Failwith(mi_last_error());
+  }
+
+  template <class TColl>
+  void Flatten(const TColl& trees, const ParamMatrix& params, std::vector<int32_t>* parents,
+               std::vector<double>* bl) const {
+    if (trees.size() != params.rows)  // fat_beagle.hpp:138
+      Failwith("We param_matrix needs as many rows as we have trees.");
+    if (params.cols != ParameterCount()) Failwith("Parameters are the wrong dimension!");
+    for (const auto& tree : trees) {
+      parents->insert(parents->end(), tree.parent_ids.begin(), tree.parent_ids.end());
+      bl->insert(bl->end(), tree.branch_lengths.begin(), tree.branch_lengths.end());
+    }
+  }
+
+  std::vector<double> RootedLogLikelihoods(const RootedTreeCollection& trees,
+                                           const ParamMatrix& params, bool rescaling,
+                                           bool with_jacobian) const {
+    std::vector<int32_t> parents;
+    std::vector<double> bl, rates, heights, bounds;
+    Flatten(trees, params, &parents, &bl);
+    if (with_jacobian)
+      for (const auto& tree : trees) {
+        if (!tree.TimeTreeHasBeenInitialized())
+          Failwith("Attempted access of a time tree member that requires the time tree to be "
+                   "initialized. Have you set dates for your time trees, and initialized the "
+                   "time trees?");
+        rates.insert(rates.end(), tree.rates_.begin(), tree.rates_.end());
+        heights.insert(heights.end(), tree.node_heights_.begin(), tree.node_heights_.end());
+        bounds.insert(bounds.end(), tree.node_bounds_.begin(), tree.node_bounds_.end());
+      }
+    std::vector<double> out(trees.size());
+    Check(mi_engine_log_likelihoods_rooted(
+        handle_, static_cast<int32_t>(trees.size()), parents.data(), bl.data(),
+        params.data.data(), with_jacobian ? rates.data() : nullptr,
+        with_jacobian ? heights.data() : nullptr, with_jacobian ? bounds.data() : nullptr,
+        with_jacobian, rescaling, out.data()));
+    return out;
+  }
+
+  void AddModelGradients(PhyloGradient* g, double site, const double* subst) const {
+    if (category_count_ > 1) g->gradient_["site_model"] = {site};
+    if (is_gtr_) g->gradient_["substitution_model"].assign(subst, subst + 8);
+  }
+};
+
+}  // namespace mihost

@@ -288,6 +288,56 @@ def test_random_unrooted_vs_oracle(n, P, site):
             assert abs(g[t].log_likelihood - oll[t]) <= RTOL * abs(oll[t])
 
 
+@pytest.mark.parametrize("n,K", [(100, 2), (200, 4), (40, 8)])
+def test_large_trees_and_category_counts(n, K):
+    """n = 100 still fits the on-chip gradient kernel (49 LDS slots), n = 200 does not
+    and takes the HBM-streamed kernel; 200-taxon trees also need rescaling to stay
+    inside FP64 range for long alignments.  K = 2 and 8 exercise other category counts."""
+    rng = np.random.default_rng(n * 7 + K)
+    P = 150
+    tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.02)
+    T = 3
+    pids, bls = TU.random_trees(n, T, rng, mean_bl=0.05)
+    pids[1] = TU.ladder_topology(n)  # deepest possible tree: worst case for the schedules
+    site = f"weibull+{K}"
+    eng = _engine("JC69", site, "strict", tips, w)
+    spec = O.make_spec(n, P, "JC69", site, "strict")
+    pr = _params(spec, T, **{"Weibull shape": rng.uniform(0.4, 1.5, size=(T, 1))})
+    for resc in (False, True):
+        ll = eng.log_likelihoods(pids, bls, pr, resc)
+        oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, resc, 3)
+        assert np.all(np.isfinite(ll))
+        assert np.all(np.abs(ll - oll) <= RTOL * np.abs(oll))
+        g = eng.gradients(pids, bls, pr, resc)
+        og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 3)
+        for t in range(T):
+            assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t])
+            assert abs(g[t].gradient["site_model"][0] - og["site_model"][t]) <= \
+                1e-9 * max(1.0, abs(og["site_model"][t]))
+
+
+def test_rescaling_rescues_underflow():
+    """600 taxa x short alignment: unscaled site likelihoods underflow FP64 (logL = -inf
+    or NaN without rescaling); with rescaling the engine matches the oracle."""
+    rng = np.random.default_rng(5)
+    n, P, T = 600, 64, 2
+    tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.0)
+    pids, bls = TU.random_trees(n, T, rng, mean_bl=0.3)
+    eng = _engine("JC69", "constant", "strict", tips, w)
+    spec = O.make_spec(n, P)
+    pr = _params(spec, T)
+    ll = eng.log_likelihoods(pids, bls, pr, True)
+    oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, True, 2)
+    assert np.all(np.isfinite(oll)) and np.all(oll < -40000)
+    assert np.all(np.abs(ll - oll) <= RTOL * np.abs(oll))
+    unscaled = eng.log_likelihoods(pids, bls, pr, False)
+    assert not np.all(np.isfinite(unscaled))  # this is what rescaling is for
+    g = eng.gradients(pids, bls, pr, True)
+    og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, True, 2)
+    for t in range(T):
+        assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t], 1e-9)
+
+
 def test_random_rooted_vs_oracle():
     rng = np.random.default_rng(7)
     n, P, T = 12, 77, 4

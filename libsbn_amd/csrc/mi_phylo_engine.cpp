@@ -82,7 +82,7 @@ const char* status_message(int code) {
 
 struct mi_engine {
   mi_engine_spec spec;
-  int n, N, P, K, tiles, max_slots;
+  int n, N, P, K, tiles, max_slots, ll_stride;
   int param_count, rates_off, freqs_off, shape_off, clock_off;
   std::vector<Block> blocks;
   hipStream_t stream = nullptr;
@@ -145,7 +145,7 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
   if (e->models.ensure(sizeof(DevModel) * (size_t)c.M)) return 1;
   if (e->mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
   if (e->tip_tables.ensure(sizeof(double) * (size_t)c.E * n * e->K * 40)) return 1;
-  if (e->ll_part.ensure(sizeof(double) * (size_t)c.E * e->tiles)) return 1;
+  if (e->ll_part.ensure(sizeof(double) * (size_t)c.E * e->ll_stride)) return 1;
   if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
   if (e->status.ensure(sizeof(int32_t) * 2)) return 1;
   if (gradient) {
@@ -190,6 +190,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const CallShape c = call_shape(e, d.T, d.gradient);
   const int n = e->n, N = e->N, T = d.T;
   HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, s));
+  // kernels write different numbers of logL partial sums per evaluation; unused ones stay 0
+  HIP_TRY(hipMemsetAsync(e->ll_part.ptr, 0, sizeof(double) * (size_t)c.E * e->ll_stride, s));
 
   TreeSetupArgs ts{};
   ts.n = n;
@@ -243,6 +245,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.P = e->P;
   la.K = e->K;
   la.tiles = e->tiles;
+  la.ll_tiles = e->ll_stride;
   la.map = map;
   la.models = e->models.as<DevModel>();
   la.sched = e->sched.as<SchedEntry>();
@@ -308,6 +311,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   fa.T = T;
   fa.K = e->K;
   fa.tiles = e->tiles;
+  fa.ll_tiles = e->ll_stride;
   fa.gradient = d.gradient;
   fa.rooted = d.rooted;
   fa.with_jacobian = d.with_jacobian;
@@ -412,6 +416,7 @@ int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
   e->P = spec->pattern_count;
   e->K = spec->category_count;
   e->tiles = (e->P + kTile - 1) / kTile;
+  e->ll_stride = std::max(e->tiles, loglik_mfma_tiles(e->P, e->K));
   int lg = 0;
   while ((2 << lg) <= e->n) lg++;
   e->max_slots = lg + 1;

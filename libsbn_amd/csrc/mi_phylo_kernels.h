@@ -68,6 +68,9 @@ struct TransitionArgs {
 struct LikArgs {
   int n, N, P, K, tiles;
   int lds_slots;    // PLV slots in LDS (set by the launcher)
+  int debug;        // ablation switches for profiling builds (MI_PHYLO_DEBUG; 0 in production)
+  int kp;           // MFMA path: categories per instruction (1, 2 or 4; set by the launcher)
+  int ll_tiles;     // stride of ll_part per evaluation (>= partial sums any kernel writes)
   int eval_offset;  // first evaluation of this launch
   int grad_offset;  // gradient-workspace index of that evaluation
   EvalMap map;
@@ -88,6 +91,7 @@ struct LikArgs {
 
 struct FinalizeArgs {
   int n, N, T, K, tiles;
+  int ll_tiles;  // logL partial sums per evaluation
   int gradient, rooted, with_jacobian;
   int gtr, site_fused, site_separate;
   const double* ll_part;
@@ -116,6 +120,7 @@ void launch_model_setup(const ModelSetupArgs& a, hipStream_t s);
 void launch_transition(const TransitionArgs& a, hipStream_t s);
 // On-chip (LDS-resident) log-likelihood: evaluations [eval_offset, eval_offset+count)
 void launch_loglik(const LikArgs& a, int count, bool rescale, int max_slots, hipStream_t s);
+int loglik_mfma_tiles(int P, int K);
 // Gradient, partial-likelihood vectors streamed through HBM (any tree size, rescaling)
 void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t s);
 // Gradient with all partial-likelihood vectors resident in LDS (no rescaling;

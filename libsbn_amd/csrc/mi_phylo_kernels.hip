@@ -9,6 +9,9 @@
 // with scalar loads into SGPRs; FP64 FMAs take them as scalar operands.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <string>
+
 #include "mi_phylo_kernels.h"
 
 namespace miphylo {
@@ -657,7 +660,204 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
   if (RESCALE) ll += site_exp * 0.6931471805599453;
   ll = p < a.P ? w * ll : 0.0;
   ll = wave_sum(ll);
-  if (lane == 0) a.ll_part[(size_t)e * a.tiles + tile] = ll;
+  if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + tile] = ll;
+}
+
+// ------------------------------------------------------------------------
+// Log-likelihood on the FP64 matrix cores (v_mfma_f64_4x4x4_4b_f64).
+//
+// The instruction multiplies four independent 4x4 blocks: D_b = A_b * B_b.
+// Lane maps MEASURED on gfx950 (scratch probe): with lane =
+// 16*hi + 4*b + lo, A_b[i][k] sits at (hi = k, lo = i), B_b[k][j] at (hi = k,
+// lo = j) and D_b[i][j] at (hi = i, lo = j).  So a register holds, per lane, one
+// state (hi) of one of 16 "columns" (b, lo); a product D is already in the layout
+// the next product wants as B: partial-likelihood vectors flow from node to node
+// with no data movement.
+//   block b  = rate category (K = 4), or further pattern groups when K < 4
+//   A        = the child's transition matrices, one element per lane: ONE 8-byte
+//              load per lane fetches all categories' matrices (no SGPR traffic,
+//              trivially prefetched a visit ahead)
+//   R registers per node = R * 16/Kp site patterns per wave, all categories at once
+// Measured issue rate: 18 cycles per instruction from one wave, 9 with two waves
+// per SIMD (28 MAC/clk/SIMD, 1.8x the FP64 VALU peak), and the VALU stays free
+// for the element-wise products.
+// ------------------------------------------------------------------------
+template <int R, bool TIP_PARTIALS>
+__global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
+  const int e = a.eval_offset + blockIdx.y;
+  int t, mi;
+  a.map.decode(e, t, mi);
+  const DevModel* __restrict__ model = a.models + mi;
+  const SchedEntry* __restrict__ sched = a.sched + (size_t)t * (a.n - 1);
+  const int K = a.K, n = a.n, Kp = a.kp;       // Kp in {1, 2, 4}: categories per instruction
+  const int cat = b % Kp, pgrp = b / Kp, ppr = 16 / Kp;  // ppr = patterns per register
+  const int catc = cat < K ? cat : K - 1;      // padded category (weight 0) reads a valid matrix
+  const double* __restrict__ mats_e = a.mats + (size_t)e * (a.N - 1) * K * 16;
+  // per-lane element of a child's matrix block: A_b[i = lo][k = hi]
+  const int a_off = catc * 16 + lo * 4 + hi;
+  int pat[R], patc[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    pat[r] = (blockIdx.x * R + r) * ppr + pgrp * 4 + lo;
+    patc[r] = pat[r] < a.P ? pat[r] : a.P - 1;
+  }
+  // LDS: PLV registers [slot][r][lane] | tip states of this tile [taxon][r][16 columns]
+  double* plv = lds;
+  int8_t* tips = reinterpret_cast<int8_t*>(lds + (size_t)a.lds_slots * R * kTile);
+  // Every global value the epilogue needs is requested NOW, together with the
+  // staging loads below: a wave lives only a few tens of microseconds, so each
+  // serialized memory round trip (1-2 us under load) is a visible share of it.
+  const double wgt = (cat < K ? model->cat_weight[cat] : 0.0) * model->pi[hi];
+  double pw[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) pw[r] = a.weights[patc[r]];
+  // Stage this tile's tip states as [taxon][pattern in tile] bytes.  The byte loads
+  // are issued eight at a time per lane before any of them is stored: the prologue
+  // costs a few memory round trips instead of one per taxon.
+  const int TP = ppr * R;               // patterns per tile
+  const int tile_start = blockIdx.x * TP;
+  SchedEntry* sched_l = reinterpret_cast<SchedEntry*>(tips + (((size_t)n * R * 16 + 15) & ~(size_t)15));
+  for (int i = lane; i < n - 1; i += kTile) sched_l[i] = sched[i];
+  if (!TIP_PARTIALS && !(a.debug & 16)) {
+    const int total = n * TP;
+    for (int base = 0; base < total; base += 8 * kTile) {
+      int8_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int idx = base + u * kTile + lane;
+        const int taxon = idx / TP, q = idx - taxon * TP;
+        const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
+        v[u] = idx < total ? a.tip_states[(size_t)taxon * a.P + pp] : (int8_t)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int idx = base + u * kTile + lane;
+        if (idx < total) tips[idx] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  int tipcol[R];  // this lane's column inside a taxon's row of the staged tips
+#pragma unroll
+  for (int r = 0; r < R; r++) tipcol[r] = r * ppr + pgrp * 4 + lo;
+
+  auto matrix_reg = [&](int node) { return mats_e[(size_t)node * K * 16 + a_off]; };
+  double L[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) L[r] = 0.0;
+  // The matrix element of a visit is requested kAhead visits before it is used: the
+  // transition matrices are read once per (evaluation, XCD), i.e. every such load is
+  // a compulsory HBM miss, and a walk that waited for one per visit would run at
+  // memory latency.  The schedule itself sits in LDS so that future visits' children
+  // are known.  The loop is unrolled by kAhead so that the ring of in-flight
+  // registers is indexed statically.
+  constexpr int kAhead = 4;
+  double ringA0[kAhead], ringA1[kAhead];
+#pragma unroll
+  for (int j = 0; j < kAhead; j++) {
+    const SchedEntry sv = sched_l[j < n - 1 ? j : n - 2];
+    ringA0[j] = matrix_reg(sv.child0);
+    ringA1[j] = matrix_reg(sv.child1);
+  }
+  auto visit = [&](int i, double& A0, double& A1) {
+    const SchedEntry sv = sched_l[i];
+    const int child0 = __builtin_amdgcn_readfirstlane(sv.child0);
+    const int child1 = __builtin_amdgcn_readfirstlane(sv.child1);
+    const int slots = __builtin_amdgcn_readfirstlane(sv.slots);
+    const bool tip0 = child0 < n, tip1 = child1 < n;
+    const double* src0 = plv + (size_t)((slots >> 8) & 0xff) * R * kTile + lane;
+    const double* src1 = plv + (size_t)((slots >> 16) & 0xff) * R * kTile + lane;
+    double* dst = plv + (size_t)(slots & 0xff) * R * kTile + lane;
+    // all operand reads of the visit are issued before the first product: one LDS
+    // round trip per visit instead of one per register
+    double B0[R], B1[R];
+    if (a.debug & 1) {  // ablation: no operand reads at all
+#pragma unroll
+      for (int r = 0; r < R; r++) { B0[r] = 0.25 + r; B1[r] = 0.5 + r; }
+    } else {
+    if (tip0) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (TIP_PARTIALS) {
+          B0[r] = a.tip_partials[((size_t)child0 * a.P + patc[r]) * 4 + hi];
+        } else {
+          const int st = tips[child0 * TP + tipcol[r]];
+          B0[r] = (st == hi || st > 3) ? 1.0 : 0.0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) B0[r] = src0[r * kTile];
+    }
+    if (tip1) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (TIP_PARTIALS) {
+          B1[r] = a.tip_partials[((size_t)child1 * a.P + patc[r]) * 4 + hi];
+        } else {
+          const int st = tips[child1 * TP + tipcol[r]];
+          B1[r] = (st == hi || st > 3) ? 1.0 : 0.0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) B1[r] = src1[r * kTile];
+    }
+    }
+    if (a.debug & 2) {  // ablation: no matrix products
+#pragma unroll
+      for (int r = 0; r < R; r++) L[r] = (A0 + B0[r]) * (A1 + B1[r]);
+    } else {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const double D0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, B0[r], 0.0, 0, 0, 0);
+      const double D1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, B1[r], 0.0, 0, 0, 0);
+      L[r] = D0 * D1;
+    }
+    }
+    if (!(a.debug & 4)) {  // ablation: no PLV stores
+#pragma unroll
+    for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
+    }
+    // refill this ring slot with the matrices of visit i + kAhead
+    if (!(a.debug & 8)) {  // ablation: no matrix loads
+    const SchedEntry sf = sched_l[i + kAhead < n - 1 ? i + kAhead : n - 2];
+    A0 = matrix_reg(sf.child0);
+    A1 = matrix_reg(sf.child1);
+    }
+  };
+  if (!(a.debug & 64))
+  for (int i = 0; i < n - 1; i += kAhead) {
+#pragma unroll
+    for (int j = 0; j < kAhead; j++)
+      if (i + j < n - 1) visit(i + j, ringA0[j], ringA1[j]);
+  }
+  // root: site likelihood = sum over categories (blocks) and states (hi) of
+  // cw * pi * L; every lane of a pattern's 4*Kp lanes ends up with the sum
+  double ll = 0.0;
+  if (a.debug & 32) {
+    if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + blockIdx.x] = L[0] + L[R - 1] + wgt + pw[0];
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    double v = wgt * L[r];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (Kp >= 2) v += __shfl_xor(v, 4, 64);
+    if (Kp >= 4) v += __shfl_xor(v, 8, 64);
+    const bool owner = hi == 0 && cat == 0 && pat[r] < a.P;  // one lane per pattern
+    if (owner) {
+      if (a.site_lik)
+        a.site_lik[((size_t)a.grad_offset + blockIdx.y) * a.tiles * kTile + pat[r]] = v;
+      ll += pw[r] * log(v);
+    }
+  }
+  ll = wave_sum(ll);
+  if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + blockIdx.x] = ll;
 }
 
 // ------------------------------------------------------------------------
@@ -733,7 +933,7 @@ __global__ __launch_bounds__(kTile) void gradient_hbm_kernel(LikArgs a) {
     if (RESCALE) ll += cum_exp * 0.6931471805599453;
     ll = p < a.P ? w * ll : 0.0;
     ll = wave_sum(ll);
-    if (lane == 0) a.ll_part[(size_t)e * a.tiles + tile] = ll;
+    if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + tile] = ll;
   }
 
   // ---- pre-order + edge derivatives, parents before children ----
@@ -1130,7 +1330,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
   __syncthreads();
   __shared__ double sh_ll, sh_jac;
   if (lane == 0) {
-    sh_ll = sum_tiles(a.ll_part + (size_t)t * tiles, tiles);
+    sh_ll = sum_tiles(a.ll_part + (size_t)t * a.ll_tiles, a.ll_tiles);
     double jac = 0.0;
     if (a.rooted && (a.with_jacobian || (a.gradient && a.gtr))) {
       // fat_beagle.cpp:82-94; iteration order of TripleIdPreorderBifurcating
@@ -1191,8 +1391,8 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
     // fat_beagle.cpp:431,455-464: rates (5) then frequencies (3)
     const int coord = lane < 5 ? 3 + lane : lane - 5;
     const size_t ep = (size_t)T + (size_t)t * 16 + 2 * coord;
-    double lp = sum_tiles(a.ll_part + ep * tiles, tiles);
-    double lm = sum_tiles(a.ll_part + (ep + 1) * tiles, tiles);
+    double lp = sum_tiles(a.ll_part + ep * a.ll_tiles, a.ll_tiles);
+    double lm = sum_tiles(a.ll_part + (ep + 1) * a.ll_tiles, a.ll_tiles);
     if (a.rooted) {
       lp += jac;
       lm += jac;
@@ -1267,8 +1467,44 @@ void launch_transition(const TransitionArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(transition_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                      a);
 }
+static size_t loglik_mfma_lds_bytes(int n, int max_slots) {
+  return sizeof(double) * (size_t)max_slots * kLlR * kTile + (size_t)n * kLlR * 16 +
+         sizeof(SchedEntry) * (size_t)(n - 1) + 32;
+}
+int loglik_mfma_tiles(int P, int K) {
+  const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
+  const int per_wave = kLlR * (16 / kp);
+  return (P + per_wave - 1) / per_wave;
+}
+bool loglik_mfma_supported(int K, bool rescale) {
+  // Opt-in (MI_PHYLO_LOGLIK_PATH=mfma): parity-green, but at 0.46 ms per 1000 DS1
+  // trees it only ties the VALU kernel (0.45 ms) -- both are bound by the latency of
+  // the per-visit control chain at 6-13 waves per CU, not by arithmetic.
+  static const bool enabled = [] {
+    const char* env = getenv("MI_PHYLO_LOGLIK_PATH");
+    return env && std::string(env) == "mfma";
+  }();
+  return enabled && K <= 4 && !rescale;
+}
+static void launch_loglik_mfma(const LikArgs& a_in, int count, int max_slots, hipStream_t s) {
+  LikArgs a = a_in;
+  a.lds_slots = max_slots;
+  a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
+  if (const char* env = getenv("MI_PHYLO_DEBUG")) a.debug = atoi(env);
+  const dim3 grid(loglik_mfma_tiles(a.P, a.K), count), block(kTile);
+  const size_t lds = loglik_mfma_lds_bytes(a.n, max_slots);
+  if (a.tip_partials)
+    hipLaunchKernelGGL((loglik_mfma_kernel<kLlR, true>), grid, block, lds, s, a);
+  else
+    hipLaunchKernelGGL((loglik_mfma_kernel<kLlR, false>), grid, block, lds, s, a);
+}
 void launch_loglik(const LikArgs& a_in, int count, bool rescale, int max_slots, hipStream_t s) {
   if (count <= 0) return;
+  if (loglik_mfma_supported(a_in.K, rescale) &&
+      loglik_mfma_lds_bytes(a_in.n, max_slots) <= 64 * 1024) {
+    launch_loglik_mfma(a_in, count, max_slots, s);
+    return;
+  }
   LikArgs a = a_in;
   a.lds_slots = max_slots;
   const dim3 grid(a.tiles, count), block(kTile);

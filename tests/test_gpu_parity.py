@@ -16,6 +16,8 @@ noise by 5e5; it is compared with the oracle in expm1 mode at 1e-4 abs + 1e-6
 rel (the reference's own test uses 1e-3; the oracle in BEAGLE mode carries up to
 1e-3 of such noise itself on fluA).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -336,6 +338,37 @@ def test_rescaling_rescues_underflow():
     og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, True, 2)
     for t in range(T):
         assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t], 1e-9)
+
+
+def test_mfma_loglik_path_matches_oracle():
+    """The opt-in matrix-core log-likelihood kernel (v_mfma_f64_4x4x4_4b_f64): same
+    parity bar.  The path is chosen once per process, hence the subprocess."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import oracle_lib as O, libsbn_amd as L
+st = O.load_struct('ds1_sub10'); tips, w, pids, bls = O.struct_arrays(st)
+for site, K in (('constant', 1), ('weibull+2', 2), ('weibull+3', 3), ('weibull+4', 4)):
+    for subst in ('JC69', 'GTR'):
+        eng = L.Engine(L.PhyloModelSpecification(subst, site, 'strict'), tips, w)
+        spec = O.make_spec(27, 934, subst, site, 'strict')
+        lay = O.param_layout(spec); pr = np.zeros((10, O.param_count(spec)))
+        if subst == 'GTR':
+            pr[:, lay['GTR rates']:lay['GTR rates'] + 6] = [0.05, 0.1, 0.15, 0.2, 0.25, 0.25]
+            pr[:, lay['frequencies']:lay['frequencies'] + 4] = [0.1, 0.2, 0.3, 0.4]
+        if K > 1: pr[:, lay['Weibull shape']] = 0.7
+        ll = eng.log_likelihoods(pids, bls, pr)
+        oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, False, 4)
+        assert np.all(np.abs(ll - oll) <= 1e-10 * np.abs(oll)), (site, subst)
+        name = eng.last_call_info()[0]
+print('mfma-ok')
+"""
+    env = dict(os.environ, MI_PHYLO_LOGLIK_PATH="mfma")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "mfma-ok" in out.stdout, out.stdout + out.stderr
 
 
 def test_random_rooted_vs_oracle():

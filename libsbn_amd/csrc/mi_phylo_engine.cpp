@@ -92,6 +92,8 @@ struct mi_engine {
   Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, ll_part, plv, g_part, site_lik, fin_scratch,
       status;
   bool allow_onchip_gradient = true;
+  bool prefer_mfma_gradient = true;  // matrix-core gradient kernel when K <= 4 and it fits
+  int gradient_path = 0;  // 0 auto, 1 valu on-chip, 2 hbm, 3 mfma
   // staging for the host-pointer entry points
   Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
       in_ratios, out_ll, out_a, out_b, out_site, out_subst;
@@ -154,7 +156,7 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
     const size_t per = plv_bytes_per_eval(e);
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / per));
     if (need_hbm_path && e->plv.ensure(per * chunk)) return 1;
-    if (e->g_part.ensure(sizeof(double) * (size_t)c.Eg * e->tiles * 2 * N)) return 1;
+    if (e->g_part.ensure(sizeof(double) * (size_t)c.Eg * e->ll_stride * 2 * N)) return 1;
     if (e->site_lik.ensure(sizeof(double) * (size_t)c.Eg * e->tiles * kTile)) return 1;
   }
   return 0;
@@ -186,6 +188,9 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   if (e->param_count > 0 && !d.params) return fail("null parameter matrix");
   const bool onchip = d.gradient && !d.rescaling && e->allow_onchip_gradient &&
                       e->spec.use_tip_states && gradient_onchip_fits(e->n);
+  const bool mfma = onchip && e->gradient_path != 1 && gradient_mfma_fits(e->n, e->K) &&
+                    (e->gradient_path == 3 || e->prefer_mfma_gradient);
+  const int g_tiles = mfma ? loglik_mfma_tiles(e->P, e->K) : e->tiles;
   if (reserve(e, d.T, d.gradient, !onchip)) return 1;
   const CallShape c = call_shape(e, d.T, d.gradient);
   const int n = e->n, N = e->N, T = d.T;
@@ -246,6 +251,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.K = e->K;
   la.tiles = e->tiles;
   la.ll_tiles = e->ll_stride;
+  la.g_tiles = g_tiles;
   la.map = map;
   la.models = e->models.as<DevModel>();
   la.sched = e->sched.as<SchedEntry>();
@@ -262,6 +268,13 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
 
   la.site_lik = nullptr;
   auto grad_range = [&](int eval_begin, int grad_begin, int count) {
+    if (mfma) {
+      LikArgs g = la;
+      g.eval_offset = eval_begin;
+      g.grad_offset = grad_begin;
+      launch_gradient_mfma(g, count, s);
+      return;
+    }
     if (onchip) {
       // phase A: on-chip log-likelihood (also writes per-pattern site likelihoods),
       // phase B: on-chip pre-order / edge derivatives
@@ -299,7 +312,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
       launch_loglik(l, 16 * T, d.rescaling, e->max_slots, s);
     }
     if (c.site_separate) grad_range(17 * T, T, T);
-    e->dominant = onchip ? gradient_onchip_kernel_name() : gradient_kernel_name();
+    e->dominant = mfma ? gradient_mfma_kernel_name()
+                       : onchip ? gradient_onchip_kernel_name() : gradient_kernel_name();
   }
   if (prof) e->prof_used++;
   e->last_evals = c.E;
@@ -312,6 +326,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   fa.K = e->K;
   fa.tiles = e->tiles;
   fa.ll_tiles = e->ll_stride;
+  fa.g_tiles = g_tiles;
   fa.gradient = d.gradient;
   fa.rooted = d.rooted;
   fa.with_jacobian = d.with_jacobian;
@@ -421,8 +436,11 @@ int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
   while ((2 << lg) <= e->n) lg++;
   e->max_slots = lg + 1;
   if (const char* env = getenv("MI_PHYLO_PLV_BYTES")) e->plv_budget = strtoull(env, nullptr, 10);
-  if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH"))  // "hbm" forces the streamed kernel
-    e->allow_onchip_gradient = std::string(env) != "hbm";
+  if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH")) {  // force one gradient kernel
+    const std::string v(env);
+    e->gradient_path = v == "valu" ? 1 : v == "hbm" ? 2 : v == "mfma" ? 3 : 0;
+    e->allow_onchip_gradient = v != "hbm";
+  }
 
   // BlockSpecification (block_specification.cpp:11-50, phylo_model.cpp:13-15)
   std::map<std::string, std::pair<int, int>> bm;

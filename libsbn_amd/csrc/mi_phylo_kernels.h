@@ -71,6 +71,7 @@ struct LikArgs {
   int debug;        // ablation switches for profiling builds (MI_PHYLO_DEBUG; 0 in production)
   int kp;           // MFMA path: categories per instruction (1, 2 or 4; set by the launcher)
   int ll_tiles;     // stride of ll_part per evaluation (>= partial sums any kernel writes)
+  int g_tiles;      // stride of g_part per gradient evaluation = tiles of the gradient kernel used
   int eval_offset;  // first evaluation of this launch
   int grad_offset;  // gradient-workspace index of that evaluation
   EvalMap map;
@@ -92,6 +93,7 @@ struct LikArgs {
 struct FinalizeArgs {
   int n, N, T, K, tiles;
   int ll_tiles;  // logL partial sums per evaluation
+  int g_tiles;   // gradient partial sums per gradient evaluation
   int gradient, rooted, with_jacobian;
   int gtr, site_fused, site_separate;
   const double* ll_part;
@@ -129,10 +131,15 @@ void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t 
 size_t gradient_onchip_lds_bytes(int n);
 bool gradient_onchip_fits(int n);
 void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s);
+// Same walk on the FP64 matrix cores, all categories per instruction (K <= 4); also
+// writes the log-likelihood partial sums, so no separate logL pass is needed.
+bool gradient_mfma_fits(int n, int K);
+void launch_gradient_mfma(const LikArgs& a, int count, hipStream_t s);
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);
 
 const char* loglik_kernel_name();
 const char* gradient_kernel_name();
 const char* gradient_onchip_kernel_name();
+const char* gradient_mfma_kernel_name();
 
 }  // namespace miphylo

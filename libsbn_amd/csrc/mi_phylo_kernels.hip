@@ -885,7 +885,7 @@ __global__ __launch_bounds__(kTile) void gradient_hbm_kernel(LikArgs a) {
   const size_t ppad = (size_t)a.tiles * kTile;
   const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
   double* plv_e = a.plv + (size_t)blockIdx.y * (n - 1) * K * ppad * 4 + (size_t)p * 4;
-  double* gout = a.g_part + ((size_t)gi * a.tiles + tile) * 2 * N;
+  double* gout = a.g_part + ((size_t)gi * a.g_tiles + tile) * 2 * N;
 
   auto plv_at = [&](int node, int k) { return plv_e + ((size_t)(node - n) * K + k) * ppad * 4; };
   auto tip_L = [&](int node) {
@@ -1263,7 +1263,284 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
   }
   asm volatile("" ::"s"(touched));
   __syncthreads();
-  double* gout = a.g_part + ((size_t)gi * a.tiles + tile) * 2 * N;
+  double* gout = a.g_part + ((size_t)gi * a.g_tiles + tile) * 2 * N;
+  for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];
+}
+
+// ------------------------------------------------------------------------
+// Gradient on the FP64 matrix cores: same half-storage walk as
+// gradient_onchip_kernel, same register layout as loglik_mfma_kernel.
+//   * all rate categories sit in the four blocks of one instruction: no category
+//     loop, and the per-pattern site likelihood (the derivative's denominator) is
+//     computed by this kernel itself at the root -- no separate log-likelihood pass
+//   * a node's matrices are ONE register (forward) + ONE register (transposed),
+//     fetched with a single 8-byte load per lane a whole macro ahead
+//   * per edge: n = q (.) (Q L) lane-wise, weighted by w_p cw_k r_k / site_p and
+//     summed over the whole wave (states, categories, patterns) by the transposed
+//     butterfly; accumulators in LDS
+// LDS per wave: max_stored(n) * R * 512 B of vectors (+ accumulators, tips).
+// ------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
+  extern __shared__ double glds[];
+  const int lane = threadIdx.x;
+  const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
+  const int e = a.eval_offset + blockIdx.y;
+  const int gi = a.grad_offset + blockIdx.y;
+  int t, mi;
+  a.map.decode(e, t, mi);
+  const DevModel* __restrict__ model = a.models + mi;
+  const int K = a.K, n = a.n, N = a.N, Kp = a.kp;
+  const int cat = b % Kp, pgrp = b / Kp, ppr = 16 / Kp;
+  const int catc = cat < K ? cat : K - 1;
+  const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
+  const MacroEntry* __restrict__ macros = a.macros + (size_t)t * max_macros(n);
+  const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
+  const int f_off = catc * 16 + lo * 4 + hi;  // forward:    A[i=lo][k=hi] = P[lo][hi]
+  const int t_off = catc * 16 + hi * 4 + lo;  // transposed: A[i=lo][k=hi] = P[hi][lo]
+  const int TP = ppr * R, tile_start = blockIdx.x * TP;
+  int pat[R], patc[R], tipcol[R];
+  double pw[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    pat[r] = tile_start + r * ppr + pgrp * 4 + lo;
+    patc[r] = pat[r] < a.P ? pat[r] : a.P - 1;
+    tipcol[r] = r * ppr + pgrp * 4 + lo;
+    pw[r] = pat[r] < a.P ? a.weights[patc[r]] : 0.0;
+  }
+  const double pi_l = model->pi[hi];
+  const double cw_l = cat < K ? model->cat_weight[cat] : 0.0;
+  const double rate_l = model->cat_rate[catc], drate_l = model->cat_drate[catc];
+  const double AQ = model->Q[lo * 4 + hi];  // A operand for Q L (same in every block)
+  // LDS: vectors [slot][r][lane] | accumulators [2][N] | tips [taxon][TP]
+  double* plv = glds;
+  double* gacc = glds + (size_t)max_stored(n) * R * kTile;
+  int8_t* tips = reinterpret_cast<int8_t*>(gacc + 2 * N);
+  for (int i = lane; i < 2 * N; i += kTile) gacc[i] = 0.0;
+  {
+    const int total = n * TP;
+    for (int base = 0; base < total; base += 8 * kTile) {
+      int8_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int idx = base + u * kTile + lane;
+        const int taxon = idx / TP, q = idx - taxon * TP;
+        const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
+        v[u] = idx < total ? a.tip_states[(size_t)taxon * a.P + pp] : (int8_t)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int idx = base + u * kTile + lane;
+        if (idx < total) tips[idx] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  if (M <= 0) return;
+
+  struct V {
+    double v[R];
+  };
+  auto load_slot = [&](int slot) {
+    V x;
+    const double* c = plv + (size_t)slot * R * kTile + lane;
+#pragma unroll
+    for (int r = 0; r < R; r++) x.v[r] = c[r * kTile];
+    return x;
+  };
+  auto store_slot = [&](int slot, const V& x) {
+    double* c = plv + (size_t)slot * R * kTile + lane;
+#pragma unroll
+    for (int r = 0; r < R; r++) c[r * kTile] = x.v[r];
+  };
+  // partial vector of a tip (one-hot / all ones from its compact state) or of a stored node
+  auto operand = [&](int node, int slot) {
+    V x;
+    if (node < n) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const int st = tips[node * TP + tipcol[r]];
+        x.v[r] = (st == hi || st > 3) ? 1.0 : 0.0;
+      }
+    } else {
+      x = load_slot(slot);
+    }
+    return x;
+  };
+  auto mm = [&](double A, const V& x) {  // block-wise matrix product, R instructions
+    V y;
+#pragma unroll
+    for (int r = 0; r < R; r++) y.v[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(A, x.v[r], 0.0, 0, 0, 0);
+    return y;
+  };
+  auto mul = [&](const V& x, const V& y) {
+    V z;
+#pragma unroll
+    for (int r = 0; r < R; r++) z.v[r] = x.v[r] * y.v[r];
+    return z;
+  };
+  // matrix registers of one macro: children c0,c1 and grandchildren a0,b0,a1,b1
+  struct MacroMats {
+    double f[6], tr[6];
+  };
+  auto fetch_mats = [&](const MacroEntry& me) {
+    MacroMats mt;
+    const int nodes[6] = {me.child[0], me.child[1], me.grand[0], me.grand[1], me.grand[2],
+                          me.grand[3]};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const double* base = mats_e + (size_t)nodes[j] * K * 16;
+      mt.f[j] = base[f_off];
+      mt.tr[j] = base[t_off];
+    }
+    return mt;
+  };
+
+  // ================= post-order over the stored nodes (+ root: site likelihood) ====
+  double coefB[R], coefS[R];
+  {
+    MacroEntry cur = macros[0];
+    MacroMats cm = fetch_mats(cur);
+    for (int m = 0; m < M; m++) {
+      const MacroEntry nxt = macros[m + 1 < M ? m + 1 : m];
+      const MacroMats nm = fetch_mats(nxt);
+      const int kind0 = __builtin_amdgcn_readfirstlane(cur.kind[0]);
+      const int kind1 = __builtin_amdgcn_readfirstlane(cur.kind[1]);
+      V L0, L1;
+      if (kind0 == 2)
+        L0 = mul(mm(cm.f[2], operand(__builtin_amdgcn_readfirstlane(cur.grand[0]),
+                                     __builtin_amdgcn_readfirstlane(cur.gslot[0]))),
+                 mm(cm.f[3], operand(__builtin_amdgcn_readfirstlane(cur.grand[1]),
+                                     __builtin_amdgcn_readfirstlane(cur.gslot[1]))));
+      else
+        L0 = operand(__builtin_amdgcn_readfirstlane(cur.child[0]),
+                     __builtin_amdgcn_readfirstlane(cur.cslot[0]));
+      if (kind1 == 2)
+        L1 = mul(mm(cm.f[4], operand(__builtin_amdgcn_readfirstlane(cur.grand[2]),
+                                     __builtin_amdgcn_readfirstlane(cur.gslot[2]))),
+                 mm(cm.f[5], operand(__builtin_amdgcn_readfirstlane(cur.grand[3]),
+                                     __builtin_amdgcn_readfirstlane(cur.gslot[3]))));
+      else
+        L1 = operand(__builtin_amdgcn_readfirstlane(cur.child[1]),
+                     __builtin_amdgcn_readfirstlane(cur.cslot[1]));
+      const V Lv = mul(mm(cm.f[0], L0), mm(cm.f[1], L1));
+      const int qslot = __builtin_amdgcn_readfirstlane(cur.qslot);
+      if (qslot >= 0) {
+        store_slot(qslot, Lv);
+      } else {
+        // root: site likelihood per pattern, log-likelihood partial, derivative weights
+        double ll = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          double v = cw_l * pi_l * Lv.v[r];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (Kp >= 2) v += __shfl_xor(v, 4, 64);
+          if (Kp >= 4) v += __shfl_xor(v, 8, 64);
+          const double inv = pw[r] / v;  // pw = 0 for padding patterns
+          coefB[r] = inv * cw_l * rate_l;
+          coefS[r] = inv * cw_l * drate_l;
+          if (hi == 0 && cat == 0 && pat[r] < a.P) ll += pw[r] * log(v);
+        }
+        ll = wave_sum(ll);
+        if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + blockIdx.x] = ll;
+      }
+      cur = nxt;
+      cm = nm;
+    }
+  }
+  // ================= pre-order + edge derivatives =================
+  auto edge_sums = [&](const V& na, const V& nb, int edge_a, int edge_b) {
+    double xb0 = 0, xs0 = 0, xb1 = 0, xs1 = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      xb0 += coefB[r] * na.v[r];
+      xs0 += coefS[r] * na.v[r];
+      xb1 += coefB[r] * nb.v[r];
+      xs1 += coefS[r] * nb.v[r];
+    }
+    const double red = reduce4_transposed(xb0, xb1, xs0, xs1);
+    // lane 15: branch a, lane 31: site a, lane 47: branch b, lane 63: site b
+    if ((lane & 15) == 15) {
+      const int which = lane >> 4;
+      const int edge = (which & 2) ? edge_b : edge_a;
+      double* dst = gacc + ((which & 1) ? N : 0) + edge;
+      *dst += red;
+    }
+  };
+  {
+    MacroEntry cur = macros[M - 1];
+    MacroMats cm = fetch_mats(cur);
+    for (int m = M - 1; m >= 0; m--) {
+      const MacroEntry nxt = macros[m > 0 ? m - 1 : 0];
+      const MacroMats nm = fetch_mats(nxt);
+      const int kind0 = __builtin_amdgcn_readfirstlane(cur.kind[0]);
+      const int kind1 = __builtin_amdgcn_readfirstlane(cur.kind[1]);
+      const int c0 = __builtin_amdgcn_readfirstlane(cur.child[0]);
+      const int c1 = __builtin_amdgcn_readfirstlane(cur.child[1]);
+      const int qslot = __builtin_amdgcn_readfirstlane(cur.qslot);
+      V qv;
+      if (qslot < 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) qv.v[r] = pi_l;
+      } else {
+        qv = load_slot(qslot);
+      }
+      V L0, L1, La0, Lb0, La1, Lb1, Ap0, Bp0, Ap1, Bp1;
+      if (kind0 == 2) {
+        La0 = operand(__builtin_amdgcn_readfirstlane(cur.grand[0]),
+                      __builtin_amdgcn_readfirstlane(cur.gslot[0]));
+        Lb0 = operand(__builtin_amdgcn_readfirstlane(cur.grand[1]),
+                      __builtin_amdgcn_readfirstlane(cur.gslot[1]));
+        Ap0 = mm(cm.f[2], La0);
+        Bp0 = mm(cm.f[3], Lb0);
+        L0 = mul(Ap0, Bp0);
+      } else {
+        L0 = operand(c0, __builtin_amdgcn_readfirstlane(cur.cslot[0]));
+      }
+      if (kind1 == 2) {
+        La1 = operand(__builtin_amdgcn_readfirstlane(cur.grand[2]),
+                      __builtin_amdgcn_readfirstlane(cur.gslot[2]));
+        Lb1 = operand(__builtin_amdgcn_readfirstlane(cur.grand[3]),
+                      __builtin_amdgcn_readfirstlane(cur.gslot[3]));
+        Ap1 = mm(cm.f[4], La1);
+        Bp1 = mm(cm.f[5], Lb1);
+        L1 = mul(Ap1, Bp1);
+      } else {
+        L1 = operand(c1, __builtin_amdgcn_readfirstlane(cur.cslot[1]));
+      }
+      const V A = mm(cm.f[0], L0), B = mm(cm.f[1], L1);
+      const V q0 = mm(cm.tr[0], mul(qv, B));
+      const V q1 = mm(cm.tr[1], mul(qv, A));
+      edge_sums(mul(q0, mm(AQ, L0)), mul(q1, mm(AQ, L1)), c0, c1);
+      if (kind0 == 1) {
+        store_slot(__builtin_amdgcn_readfirstlane(cur.cslot[0]), q0);
+      } else if (kind0 == 2) {
+        const int ga = __builtin_amdgcn_readfirstlane(cur.grand[0]);
+        const int gb = __builtin_amdgcn_readfirstlane(cur.grand[1]);
+        const V qa = mm(cm.tr[2], mul(q0, Bp0));
+        const V qb = mm(cm.tr[3], mul(q0, Ap0));
+        edge_sums(mul(qa, mm(AQ, La0)), mul(qb, mm(AQ, Lb0)), ga, gb);
+        if (ga >= n) store_slot(__builtin_amdgcn_readfirstlane(cur.gslot[0]), qa);
+        if (gb >= n) store_slot(__builtin_amdgcn_readfirstlane(cur.gslot[1]), qb);
+      }
+      if (kind1 == 1) {
+        store_slot(__builtin_amdgcn_readfirstlane(cur.cslot[1]), q1);
+      } else if (kind1 == 2) {
+        const int ga = __builtin_amdgcn_readfirstlane(cur.grand[2]);
+        const int gb = __builtin_amdgcn_readfirstlane(cur.grand[3]);
+        const V qa = mm(cm.tr[4], mul(q1, Bp1));
+        const V qb = mm(cm.tr[5], mul(q1, Ap1));
+        edge_sums(mul(qa, mm(AQ, La1)), mul(qb, mm(AQ, Lb1)), ga, gb);
+        if (ga >= n) store_slot(__builtin_amdgcn_readfirstlane(cur.gslot[2]), qa);
+        if (gb >= n) store_slot(__builtin_amdgcn_readfirstlane(cur.gslot[3]), qb);
+      }
+      cur = nxt;
+      cm = nm;
+    }
+  }
+  __syncthreads();
+  double* gout = a.g_part + ((size_t)gi * a.g_tiles + blockIdx.x) * 2 * N;
   for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];
 }
 
@@ -1372,7 +1649,8 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
   double* bg = work;  // N doubles (N < 2n)
   for (int v = lane; v < N; v += 64) {
     double sum = 0;
-    for (int i = 0; i < tiles; i++) sum += a.g_part[(((size_t)t * tiles + i) * 2) * N + v];
+    for (int i = 0; i < a.g_tiles; i++)
+      sum += a.g_part[(((size_t)t * a.g_tiles + i) * 2) * N + v];
     bg[v] = sum;
   }
   if (a.out_site && (a.site_fused || a.site_separate)) {
@@ -1381,7 +1659,8 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
     double r = 0;
     for (int v = lane; v < N - 1; v += 64) {
       double sum = 0;
-      for (int i = 0; i < tiles; i++) sum += a.g_part[((gi * tiles + i) * 2 + 1) * N + v];
+      for (int i = 0; i < a.g_tiles; i++)
+        sum += a.g_part[((gi * a.g_tiles + i) * 2 + 1) * N + v];
       r += sum * ble[v];
     }
     r = wave_sum(r);
@@ -1546,6 +1825,29 @@ void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s) {
   }
   hipLaunchKernelGGL(gradient_onchip_kernel, dim3(a.tiles, count), dim3(kTile), lds, s, a);
 }
+size_t gradient_mfma_lds_bytes(int n, int K) {
+  const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
+  const int N = 2 * n - 1;
+  return sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile + 2 * N) +
+         (size_t)n * kLlR * (16 / kp) + 16;
+}
+bool gradient_mfma_fits(int n, int K) {
+  return n >= 3 && K <= 4 && gradient_mfma_lds_bytes(n, K) <= 160 * 1024;
+}
+void launch_gradient_mfma(const LikArgs& a_in, int count, hipStream_t s) {
+  if (count <= 0) return;
+  LikArgs a = a_in;
+  a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
+  const size_t lds = gradient_mfma_lds_bytes(a.n, a.K);
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = lds;
+  }
+  hipLaunchKernelGGL((gradient_mfma_kernel<kLlR>), dim3(loglik_mfma_tiles(a.P, a.K), count),
+                     dim3(kTile), lds, s, a);
+}
 void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
   FinalizeArgs a = a_in;
   const size_t lds = sizeof(double) * 6 * (size_t)a.n;
@@ -1556,5 +1858,6 @@ void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
 const char* loglik_kernel_name() { return "loglik_onchip_kernel"; }
 const char* gradient_kernel_name() { return "gradient_hbm_kernel"; }
 const char* gradient_onchip_kernel_name() { return "gradient_onchip_kernel"; }
+const char* gradient_mfma_kernel_name() { return "gradient_mfma_kernel"; }
 
 }  // namespace miphylo

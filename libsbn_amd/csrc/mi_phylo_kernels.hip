@@ -1396,57 +1396,76 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     return mt;
   };
 
+  // A macro entry made wave-uniform once (SGPRs are plentiful here: the matrices
+  // live in VGPRs), so every index derived from it is scalar arithmetic.
+  struct UMacro {
+    int qslot, c0, c1, kind0, kind1, cs0, cs1, g0, g1, g2, g3, gs0, gs1, gs2, gs3;
+  };
+  auto uniformize = [&](const MacroEntry& me) {
+    UMacro u;
+    u.qslot = __builtin_amdgcn_readfirstlane(me.qslot);
+    u.c0 = __builtin_amdgcn_readfirstlane(me.child[0]);
+    u.c1 = __builtin_amdgcn_readfirstlane(me.child[1]);
+    u.kind0 = __builtin_amdgcn_readfirstlane(me.kind[0]);
+    u.kind1 = __builtin_amdgcn_readfirstlane(me.kind[1]);
+    u.cs0 = __builtin_amdgcn_readfirstlane(me.cslot[0]);
+    u.cs1 = __builtin_amdgcn_readfirstlane(me.cslot[1]);
+    u.g0 = __builtin_amdgcn_readfirstlane(me.grand[0]);
+    u.g1 = __builtin_amdgcn_readfirstlane(me.grand[1]);
+    u.g2 = __builtin_amdgcn_readfirstlane(me.grand[2]);
+    u.g3 = __builtin_amdgcn_readfirstlane(me.grand[3]);
+    u.gs0 = __builtin_amdgcn_readfirstlane(me.gslot[0]);
+    u.gs1 = __builtin_amdgcn_readfirstlane(me.gslot[1]);
+    u.gs2 = __builtin_amdgcn_readfirstlane(me.gslot[2]);
+    u.gs3 = __builtin_amdgcn_readfirstlane(me.gslot[3]);
+    return u;
+  };
+
   // ================= post-order over the stored nodes (+ root: site likelihood) ====
   double coefB[R], coefS[R];
-  {
-    MacroEntry cur = macros[0];
-    MacroMats cm = fetch_mats(cur);
-    for (int m = 0; m < M; m++) {
-      const MacroEntry nxt = macros[m + 1 < M ? m + 1 : m];
-      const MacroMats nm = fetch_mats(nxt);
-      const int kind0 = __builtin_amdgcn_readfirstlane(cur.kind[0]);
-      const int kind1 = __builtin_amdgcn_readfirstlane(cur.kind[1]);
-      V L0, L1;
-      if (kind0 == 2)
-        L0 = mul(mm(cm.f[2], operand(__builtin_amdgcn_readfirstlane(cur.grand[0]),
-                                     __builtin_amdgcn_readfirstlane(cur.gslot[0]))),
-                 mm(cm.f[3], operand(__builtin_amdgcn_readfirstlane(cur.grand[1]),
-                                     __builtin_amdgcn_readfirstlane(cur.gslot[1]))));
-      else
-        L0 = operand(__builtin_amdgcn_readfirstlane(cur.child[0]),
-                     __builtin_amdgcn_readfirstlane(cur.cslot[0]));
-      if (kind1 == 2)
-        L1 = mul(mm(cm.f[4], operand(__builtin_amdgcn_readfirstlane(cur.grand[2]),
-                                     __builtin_amdgcn_readfirstlane(cur.gslot[2]))),
-                 mm(cm.f[5], operand(__builtin_amdgcn_readfirstlane(cur.grand[3]),
-                                     __builtin_amdgcn_readfirstlane(cur.gslot[3]))));
-      else
-        L1 = operand(__builtin_amdgcn_readfirstlane(cur.child[1]),
-                     __builtin_amdgcn_readfirstlane(cur.cslot[1]));
-      const V Lv = mul(mm(cm.f[0], L0), mm(cm.f[1], L1));
-      const int qslot = __builtin_amdgcn_readfirstlane(cur.qslot);
-      if (qslot >= 0) {
-        store_slot(qslot, Lv);
-      } else {
-        // root: site likelihood per pattern, log-likelihood partial, derivative weights
-        double ll = 0.0;
+  auto post_step = [&](const MacroEntry& raw, const MacroMats& cm) {
+    const UMacro u = uniformize(raw);
+    V L0, L1;
+    if (u.kind0 == 2) L0 = mul(mm(cm.f[2], operand(u.g0, u.gs0)), mm(cm.f[3], operand(u.g1, u.gs1)));
+    else L0 = operand(u.c0, u.cs0);
+    if (u.kind1 == 2) L1 = mul(mm(cm.f[4], operand(u.g2, u.gs2)), mm(cm.f[5], operand(u.g3, u.gs3)));
+    else L1 = operand(u.c1, u.cs1);
+    const V Lv = mul(mm(cm.f[0], L0), mm(cm.f[1], L1));
+    if (u.qslot >= 0) {
+      store_slot(u.qslot, Lv);
+    } else {
+      // root: site likelihood per pattern, log-likelihood partial, derivative weights
+      double ll = 0.0;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-          double v = cw_l * pi_l * Lv.v[r];
-          v += __shfl_xor(v, 16, 64);
-          v += __shfl_xor(v, 32, 64);
-          if (Kp >= 2) v += __shfl_xor(v, 4, 64);
-          if (Kp >= 4) v += __shfl_xor(v, 8, 64);
-          const double inv = pw[r] / v;  // pw = 0 for padding patterns
-          coefB[r] = inv * cw_l * rate_l;
-          coefS[r] = inv * cw_l * drate_l;
-          if (hi == 0 && cat == 0 && pat[r] < a.P) ll += pw[r] * log(v);
-        }
-        ll = wave_sum(ll);
-        if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + blockIdx.x] = ll;
+      for (int r = 0; r < R; r++) {
+        double v = cw_l * pi_l * Lv.v[r];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (Kp >= 2) v += __shfl_xor(v, 4, 64);
+        if (Kp >= 4) v += __shfl_xor(v, 8, 64);
+        const double inv = pw[r] / v;  // pw = 0 for padding patterns
+        coefB[r] = inv * cw_l * rate_l;
+        coefS[r] = inv * cw_l * drate_l;
+        if (hi == 0 && cat == 0 && pat[r] < a.P) ll += pw[r] * log(v);
       }
-      cur = nxt;
-      cm = nm;
+      ll = wave_sum(ll);
+      if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + blockIdx.x] = ll;
+    }
+  };
+  {
+    // two macros per iteration: entries and matrix registers ping-pong between two
+    // sets, so nothing is copied
+    MacroEntry ea = macros[0], eb;
+    MacroMats ma = fetch_mats(ea), mb;
+    for (int m = 0; m < M; m += 2) {
+      eb = macros[m + 1 < M ? m + 1 : m];
+      mb = fetch_mats(eb);
+      post_step(ea, ma);
+      if (m + 1 < M) {
+        ea = macros[m + 2 < M ? m + 2 : m + 1];
+        ma = fetch_mats(ea);
+        post_step(eb, mb);
+      }
     }
   }
   // ================= pre-order + edge derivatives =================
@@ -1468,75 +1487,69 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       *dst += red;
     }
   };
-  {
-    MacroEntry cur = macros[M - 1];
-    MacroMats cm = fetch_mats(cur);
-    for (int m = M - 1; m >= 0; m--) {
-      const MacroEntry nxt = macros[m > 0 ? m - 1 : 0];
-      const MacroMats nm = fetch_mats(nxt);
-      const int kind0 = __builtin_amdgcn_readfirstlane(cur.kind[0]);
-      const int kind1 = __builtin_amdgcn_readfirstlane(cur.kind[1]);
-      const int c0 = __builtin_amdgcn_readfirstlane(cur.child[0]);
-      const int c1 = __builtin_amdgcn_readfirstlane(cur.child[1]);
-      const int qslot = __builtin_amdgcn_readfirstlane(cur.qslot);
-      V qv;
-      if (qslot < 0) {
+  auto pre_step = [&](const MacroEntry& raw, const MacroMats& cm) {
+    const UMacro u = uniformize(raw);
+    V qv;
+    if (u.qslot < 0) {
 #pragma unroll
-        for (int r = 0; r < R; r++) qv.v[r] = pi_l;
-      } else {
-        qv = load_slot(qslot);
+      for (int r = 0; r < R; r++) qv.v[r] = pi_l;
+    } else {
+      qv = load_slot(u.qslot);
+    }
+    V L0, L1, La0, Lb0, La1, Lb1, Ap0, Bp0, Ap1, Bp1;
+    if (u.kind0 == 2) {
+      La0 = operand(u.g0, u.gs0);
+      Lb0 = operand(u.g1, u.gs1);
+      Ap0 = mm(cm.f[2], La0);
+      Bp0 = mm(cm.f[3], Lb0);
+      L0 = mul(Ap0, Bp0);
+    } else {
+      L0 = operand(u.c0, u.cs0);
+    }
+    if (u.kind1 == 2) {
+      La1 = operand(u.g2, u.gs2);
+      Lb1 = operand(u.g3, u.gs3);
+      Ap1 = mm(cm.f[4], La1);
+      Bp1 = mm(cm.f[5], Lb1);
+      L1 = mul(Ap1, Bp1);
+    } else {
+      L1 = operand(u.c1, u.cs1);
+    }
+    const V A = mm(cm.f[0], L0), B = mm(cm.f[1], L1);
+    const V q0 = mm(cm.tr[0], mul(qv, B));
+    const V q1 = mm(cm.tr[1], mul(qv, A));
+    edge_sums(mul(q0, mm(AQ, L0)), mul(q1, mm(AQ, L1)), u.c0, u.c1);
+    if (u.kind0 == 1) {
+      store_slot(u.cs0, q0);
+    } else if (u.kind0 == 2) {
+      const V qa = mm(cm.tr[2], mul(q0, Bp0));
+      const V qb = mm(cm.tr[3], mul(q0, Ap0));
+      edge_sums(mul(qa, mm(AQ, La0)), mul(qb, mm(AQ, Lb0)), u.g0, u.g1);
+      if (u.g0 >= n) store_slot(u.gs0, qa);
+      if (u.g1 >= n) store_slot(u.gs1, qb);
+    }
+    if (u.kind1 == 1) {
+      store_slot(u.cs1, q1);
+    } else if (u.kind1 == 2) {
+      const V qa = mm(cm.tr[4], mul(q1, Bp1));
+      const V qb = mm(cm.tr[5], mul(q1, Ap1));
+      edge_sums(mul(qa, mm(AQ, La1)), mul(qb, mm(AQ, Lb1)), u.g2, u.g3);
+      if (u.g2 >= n) store_slot(u.gs2, qa);
+      if (u.g3 >= n) store_slot(u.gs3, qb);
+    }
+  };
+  {
+    MacroEntry ea = macros[M - 1], eb;
+    MacroMats ma = fetch_mats(ea), mb;
+    for (int m = M - 1; m >= 0; m -= 2) {
+      eb = macros[m >= 1 ? m - 1 : 0];
+      mb = fetch_mats(eb);
+      pre_step(ea, ma);
+      if (m >= 1) {
+        ea = macros[m >= 2 ? m - 2 : 0];
+        ma = fetch_mats(ea);
+        pre_step(eb, mb);
       }
-      V L0, L1, La0, Lb0, La1, Lb1, Ap0, Bp0, Ap1, Bp1;
-      if (kind0 == 2) {
-        La0 = operand(__builtin_amdgcn_readfirstlane(cur.grand[0]),
-                      __builtin_amdgcn_readfirstlane(cur.gslot[0]));
-        Lb0 = operand(__builtin_amdgcn_readfirstlane(cur.grand[1]),
-                      __builtin_amdgcn_readfirstlane(cur.gslot[1]));
-        Ap0 = mm(cm.f[2], La0);
-        Bp0 = mm(cm.f[3], Lb0);
-        L0 = mul(Ap0, Bp0);
-      } else {
-        L0 = operand(c0, __builtin_amdgcn_readfirstlane(cur.cslot[0]));
-      }
-      if (kind1 == 2) {
-        La1 = operand(__builtin_amdgcn_readfirstlane(cur.grand[2]),
-                      __builtin_amdgcn_readfirstlane(cur.gslot[2]));
-        Lb1 = operand(__builtin_amdgcn_readfirstlane(cur.grand[3]),
-                      __builtin_amdgcn_readfirstlane(cur.gslot[3]));
-        Ap1 = mm(cm.f[4], La1);
-        Bp1 = mm(cm.f[5], Lb1);
-        L1 = mul(Ap1, Bp1);
-      } else {
-        L1 = operand(c1, __builtin_amdgcn_readfirstlane(cur.cslot[1]));
-      }
-      const V A = mm(cm.f[0], L0), B = mm(cm.f[1], L1);
-      const V q0 = mm(cm.tr[0], mul(qv, B));
-      const V q1 = mm(cm.tr[1], mul(qv, A));
-      edge_sums(mul(q0, mm(AQ, L0)), mul(q1, mm(AQ, L1)), c0, c1);
-      if (kind0 == 1) {
-        store_slot(__builtin_amdgcn_readfirstlane(cur.cslot[0]), q0);
-      } else if (kind0 == 2) {
-        const int ga = __builtin_amdgcn_readfirstlane(cur.grand[0]);
-        const int gb = __builtin_amdgcn_readfirstlane(cur.grand[1]);
-        const V qa = mm(cm.tr[2], mul(q0, Bp0));
-        const V qb = mm(cm.tr[3], mul(q0, Ap0));
-        edge_sums(mul(qa, mm(AQ, La0)), mul(qb, mm(AQ, Lb0)), ga, gb);
-        if (ga >= n) store_slot(__builtin_amdgcn_readfirstlane(cur.gslot[0]), qa);
-        if (gb >= n) store_slot(__builtin_amdgcn_readfirstlane(cur.gslot[1]), qb);
-      }
-      if (kind1 == 1) {
-        store_slot(__builtin_amdgcn_readfirstlane(cur.cslot[1]), q1);
-      } else if (kind1 == 2) {
-        const int ga = __builtin_amdgcn_readfirstlane(cur.grand[2]);
-        const int gb = __builtin_amdgcn_readfirstlane(cur.grand[3]);
-        const V qa = mm(cm.tr[4], mul(q1, Bp1));
-        const V qb = mm(cm.tr[5], mul(q1, Ap1));
-        edge_sums(mul(qa, mm(AQ, La1)), mul(qb, mm(AQ, Lb1)), ga, gb);
-        if (ga >= n) store_slot(__builtin_amdgcn_readfirstlane(cur.gslot[2]), qa);
-        if (gb >= n) store_slot(__builtin_amdgcn_readfirstlane(cur.gslot[3]), qb);
-      }
-      cur = nxt;
-      cm = nm;
     }
   }
   __syncthreads();

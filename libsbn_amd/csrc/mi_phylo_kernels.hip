@@ -1277,11 +1277,12 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
 //     fetched with a single 8-byte load per lane a whole macro ahead
 //   * per edge: n = q (.) (Q L) lane-wise, weighted by w_p cw_k r_k / site_p and
 //     summed over the whole wave (states, categories, patterns) by the transposed
-//     butterfly; accumulators in LDS
-// LDS per wave: max_stored(n) * R * 512 B of vectors (+ accumulators, tips).
+//     butterfly and stored straight to the per-tile partials (each edge is visited once)
+// LDS per wave: max_stored(n) * R * 512 B of vectors (+ tip state masks).
 // ------------------------------------------------------------------------
 template <int R>
 __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
+  static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
   extern __shared__ double glds[];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
@@ -1299,24 +1300,25 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   const int f_off = catc * 16 + lo * 4 + hi;  // forward:    A[i=lo][k=hi] = P[lo][hi]
   const int t_off = catc * 16 + hi * 4 + lo;  // transposed: A[i=lo][k=hi] = P[hi][lo]
   const int TP = ppr * R, tile_start = blockIdx.x * TP;
-  int pat[R], patc[R], tipcol[R];
+  const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
+  int pat[R], patc[R];
   double pw[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    pat[r] = tile_start + r * ppr + pgrp * 4 + lo;
+    pat[r] = tile_start + r * ppr + col;
     patc[r] = pat[r] < a.P ? pat[r] : a.P - 1;
-    tipcol[r] = r * ppr + pgrp * 4 + lo;
     pw[r] = pat[r] < a.P ? a.weights[patc[r]] : 0.0;
   }
   const double pi_l = model->pi[hi];
   const double cw_l = cat < K ? model->cat_weight[cat] : 0.0;
   const double rate_l = model->cat_rate[catc], drate_l = model->cat_drate[catc];
   const double AQ = model->Q[lo * 4 + hi];  // A operand for Q L (same in every block)
-  // LDS: vectors [slot][r][lane] | accumulators [2][N] | tips [taxon][TP]
+  // LDS: vectors [slot][r][lane] | tip state masks [taxon][column][r] (one byte each:
+  // bit s set when the tip is compatible with state s)
   double* plv = glds;
-  double* gacc = glds + (size_t)max_stored(n) * R * kTile;
-  int8_t* tips = reinterpret_cast<int8_t*>(gacc + 2 * N);
-  for (int i = lane; i < 2 * N; i += kTile) gacc[i] = 0.0;
+  uint8_t* tips = reinterpret_cast<uint8_t*>(glds + (size_t)max_stored(n) * R * kTile);
+  double* gout = a.g_part + ((size_t)gi * a.g_tiles + blockIdx.x) * 2 * N;
+  if (lane < 2) gout[lane * N + N - 1] = 0.0;  // the root has no edge
   {
     const int total = n * TP;
     for (int base = 0; base < total; base += 8 * kTile) {
@@ -1325,13 +1327,19 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       for (int u = 0; u < 8; u++) {
         const int idx = base + u * kTile + lane;
         const int taxon = idx / TP, q = idx - taxon * TP;
+        const int r = q / ppr, c = q - r * ppr;  // coalesced reads, transposed writes
         const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
+        (void)r;
+        (void)c;
         v[u] = idx < total ? a.tip_states[(size_t)taxon * a.P + pp] : (int8_t)0;
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int idx = base + u * kTile + lane;
-        if (idx < total) tips[idx] = v[u];
+        const int taxon = idx / TP, q = idx - taxon * TP;
+        const int r = q / ppr, c = q - r * ppr;
+        if (idx < total)
+          tips[(taxon * ppr + c) * 4 + r] = v[u] > 3 ? (uint8_t)0xF : (uint8_t)(1u << v[u]);
       }
     }
   }
@@ -1353,14 +1361,17 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
 #pragma unroll
     for (int r = 0; r < R; r++) c[r * kTile] = x.v[r];
   };
-  // partial vector of a tip (one-hot / all ones from its compact state) or of a stored node
+  // partial vector of a tip (0/1 from its state mask: one LDS word holds the R masks
+  // of this lane's column) or of a stored node
+  const uint32_t* tipw = reinterpret_cast<const uint32_t*>(tips) + col;
   auto operand = [&](int node, int slot) {
     V x;
     if (node < n) {
+      const int w = (int)tipw[node * ppr];
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const int st = tips[node * TP + tipcol[r]];
-        x.v[r] = (st == hi || st > 3) ? 1.0 : 0.0;
+        const int bit = (w << (31 - 8 * r - hi)) >> 31;  // 0 or -1
+        x.v[r] = __hiloint2double(bit & 0x3FF00000, 0);
       }
     } else {
       x = load_slot(slot);
@@ -1379,27 +1390,25 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     for (int r = 0; r < R; r++) z.v[r] = x.v[r] * y.v[r];
     return z;
   };
-  // matrix registers of one macro: children c0,c1 and grandchildren a0,b0,a1,b1
-  struct MacroMats {
-    double f[6], tr[6];
-  };
-  auto fetch_mats = [&](const MacroEntry& me) {
-    MacroMats mt;
-    const int nodes[6] = {me.child[0], me.child[1], me.grand[0], me.grand[1], me.grand[2],
-                          me.grand[3]};
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      const double* base = mats_e + (size_t)nodes[j] * K * 16;
-      mt.f[j] = base[f_off];
-      mt.tr[j] = base[t_off];
-    }
-    return mt;
-  };
-
   // A macro entry made wave-uniform once (SGPRs are plentiful here: the matrices
   // live in VGPRs), so every index derived from it is scalar arithmetic.
   struct UMacro {
     int qslot, c0, c1, kind0, kind1, cs0, cs1, g0, g1, g2, g3, gs0, gs1, gs2, gs3;
+  };
+  // matrix registers of one macro: children c0,c1 and grandchildren a0,b0,a1,b1
+  struct MacroMats {
+    double f[6], tr[6];
+  };
+  auto fetch_mats = [&](const UMacro& u) {
+    MacroMats mt;
+    const int nodes[6] = {u.c0, u.c1, u.g0, u.g1, u.g2, u.g3};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const double* base = mats_e + (unsigned)(nodes[j] * K * 16);  // scalar
+      mt.f[j] = base[f_off];
+      mt.tr[j] = base[t_off];
+    }
+    return mt;
   };
   auto uniformize = [&](const MacroEntry& me) {
     UMacro u;
@@ -1423,8 +1432,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
 
   // ================= post-order over the stored nodes (+ root: site likelihood) ====
   double coefB[R], coefS[R];
-  auto post_step = [&](const MacroEntry& raw, const MacroMats& cm) {
-    const UMacro u = uniformize(raw);
+  auto post_step = [&](const UMacro& u, const MacroMats& cm) {
     V L0, L1;
     if (u.kind0 == 2) L0 = mul(mm(cm.f[2], operand(u.g0, u.gs0)), mm(cm.f[3], operand(u.g1, u.gs1)));
     else L0 = operand(u.c0, u.cs0);
@@ -1455,16 +1463,22 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   {
     // two macros per iteration: entries and matrix registers ping-pong between two
     // sets, so nothing is copied
-    MacroEntry ea = macros[0], eb;
-    MacroMats ma = fetch_mats(ea), mb;
+    // three-stage pipeline: the raw entry is loaded two macros ahead, made uniform
+    // and its matrices fetched one macro ahead
+    MacroEntry raw = macros[0];
+    UMacro ua = uniformize(raw), ub;
+    MacroMats ma = fetch_mats(ua), mb;
+    raw = macros[M > 1 ? 1 : 0];
     for (int m = 0; m < M; m += 2) {
-      eb = macros[m + 1 < M ? m + 1 : m];
-      mb = fetch_mats(eb);
-      post_step(ea, ma);
+      ub = uniformize(raw);
+      mb = fetch_mats(ub);
+      raw = macros[m + 2 < M ? m + 2 : M - 1];
+      post_step(ua, ma);
       if (m + 1 < M) {
-        ea = macros[m + 2 < M ? m + 2 : m + 1];
-        ma = fetch_mats(ea);
-        post_step(eb, mb);
+        ua = uniformize(raw);
+        ma = fetch_mats(ua);
+        raw = macros[m + 3 < M ? m + 3 : M - 1];
+        post_step(ub, mb);
       }
     }
   }
@@ -1483,12 +1497,10 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     if ((lane & 15) == 15) {
       const int which = lane >> 4;
       const int edge = (which & 2) ? edge_b : edge_a;
-      double* dst = gacc + ((which & 1) ? N : 0) + edge;
-      *dst += red;
+      gout[((which & 1) ? N : 0) + edge] = red;  // every edge is visited exactly once
     }
   };
-  auto pre_step = [&](const MacroEntry& raw, const MacroMats& cm) {
-    const UMacro u = uniformize(raw);
+  auto pre_step = [&](const UMacro& u, const MacroMats& cm) {
     V qv;
     if (u.qslot < 0) {
 #pragma unroll
@@ -1539,22 +1551,23 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     }
   };
   {
-    MacroEntry ea = macros[M - 1], eb;
-    MacroMats ma = fetch_mats(ea), mb;
+    MacroEntry raw = macros[M - 1];
+    UMacro ua = uniformize(raw), ub;
+    MacroMats ma = fetch_mats(ua), mb;
+    raw = macros[M > 1 ? M - 2 : 0];
     for (int m = M - 1; m >= 0; m -= 2) {
-      eb = macros[m >= 1 ? m - 1 : 0];
-      mb = fetch_mats(eb);
-      pre_step(ea, ma);
+      ub = uniformize(raw);
+      mb = fetch_mats(ub);
+      raw = macros[m >= 2 ? m - 2 : 0];
+      pre_step(ua, ma);
       if (m >= 1) {
-        ea = macros[m >= 2 ? m - 2 : 0];
-        ma = fetch_mats(ea);
-        pre_step(eb, mb);
+        ua = uniformize(raw);
+        ma = fetch_mats(ua);
+        raw = macros[m >= 3 ? m - 3 : 0];
+        pre_step(ub, mb);
       }
     }
   }
-  __syncthreads();
-  double* gout = a.g_part + ((size_t)gi * a.g_tiles + blockIdx.x) * 2 * N;
-  for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];
 }
 
 // ------------------------------------------------------------------------
@@ -1841,8 +1854,8 @@ void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s) {
 size_t gradient_mfma_lds_bytes(int n, int K) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
   const int N = 2 * n - 1;
-  return sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile + 2 * N) +
-         (size_t)n * kLlR * (16 / kp) + 16;
+  (void)N;
+  return sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile) + (size_t)n * 4 * (16 / kp) + 16;
 }
 bool gradient_mfma_fits(int n, int K) {
   return n >= 3 && K <= 4 && gradient_mfma_lds_bytes(n, K) <= 160 * 1024;

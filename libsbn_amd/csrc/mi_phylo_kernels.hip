@@ -1297,8 +1297,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
   const MacroEntry* __restrict__ macros = a.macros + (size_t)t * max_macros(n);
   const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
-  const int f_off = catc * 16 + lo * 4 + hi;  // forward:    A[i=lo][k=hi] = P[lo][hi]
-  const int t_off = catc * 16 + hi * 4 + lo;  // transposed: A[i=lo][k=hi] = P[hi][lo]
+  // byte offsets (unsigned: scalar base + 32-bit lane offset addressing)
+  const unsigned f_off = 8u * (catc * 16 + lo * 4 + hi);  // forward:    A[i=lo][k=hi] = P[lo][hi]
+  const unsigned t_off = 8u * (catc * 16 + hi * 4 + lo);  // transposed: A[i=lo][k=hi] = P[hi][lo]
   const int TP = ppr * R, tile_start = blockIdx.x * TP;
   const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
   int pat[R], patc[R];
@@ -1313,12 +1314,12 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   const double cw_l = cat < K ? model->cat_weight[cat] : 0.0;
   const double rate_l = model->cat_rate[catc], drate_l = model->cat_drate[catc];
   const double AQ = model->Q[lo * 4 + hi];  // A operand for Q L (same in every block)
-  // LDS: vectors [slot][r][lane] | tip state masks [taxon][column][r] (one byte each:
-  // bit s set when the tip is compatible with state s)
+  // LDS: vectors [slot][r][lane] | edge sums [2][N] | tip state masks [taxon][column][r]
+  // (one byte each: bit s set when the tip is compatible with state s)
   double* plv = glds;
-  uint8_t* tips = reinterpret_cast<uint8_t*>(glds + (size_t)max_stored(n) * R * kTile);
-  double* gout = a.g_part + ((size_t)gi * a.g_tiles + blockIdx.x) * 2 * N;
-  if (lane < 2) gout[lane * N + N - 1] = 0.0;  // the root has no edge
+  double* gacc = glds + (size_t)max_stored(n) * R * kTile;
+  uint8_t* tips = reinterpret_cast<uint8_t*>(gacc + 2 * N);
+  if (lane < 2) gacc[lane * N + N - 1] = 0.0;  // the root has no edge
   {
     const int total = n * TP;
     for (int base = 0; base < total; base += 8 * kTile) {
@@ -1367,12 +1368,10 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   auto operand = [&](int node, int slot) {
     V x;
     if (node < n) {
-      const int w = (int)tipw[node * ppr];
+      const uint32_t w = tipw[node * ppr];
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        const int bit = (w << (31 - 8 * r - hi)) >> 31;  // 0 or -1
-        x.v[r] = __hiloint2double(bit & 0x3FF00000, 0);
-      }
+      for (int r = 0; r < R; r++)
+        x.v[r] = (double)__builtin_amdgcn_ubfe(w, (uint32_t)(8 * r + hi), 1u);
     } else {
       x = load_slot(slot);
     }
@@ -1404,9 +1403,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     const int nodes[6] = {u.c0, u.c1, u.g0, u.g1, u.g2, u.g3};
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      const double* base = mats_e + (unsigned)(nodes[j] * K * 16);  // scalar
-      mt.f[j] = base[f_off];
-      mt.tr[j] = base[t_off];
+      const char* base = reinterpret_cast<const char*>(mats_e + (unsigned)(nodes[j] * K * 16));
+      mt.f[j] = *reinterpret_cast<const double*>(base + f_off);
+      mt.tr[j] = *reinterpret_cast<const double*>(base + t_off);
     }
     return mt;
   };
@@ -1431,7 +1430,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   };
 
   // ================= post-order over the stored nodes (+ root: site likelihood) ====
-  double coefB[R], coefS[R];
+  double qroot[R];  // root pre-order vector: pi * category weight * w_p / site likelihood
   auto post_step = [&](const UMacro& u, const MacroMats& cm) {
     V L0, L1;
     if (u.kind0 == 2) L0 = mul(mm(cm.f[2], operand(u.g0, u.gs0)), mm(cm.f[3], operand(u.g1, u.gs1)));
@@ -1451,9 +1450,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
         v += __shfl_xor(v, 32, 64);
         if (Kp >= 2) v += __shfl_xor(v, 4, 64);
         if (Kp >= 4) v += __shfl_xor(v, 8, 64);
-        const double inv = pw[r] / v;  // pw = 0 for padding patterns
-        coefB[r] = inv * cw_l * rate_l;
-        coefS[r] = inv * cw_l * drate_l;
+        qroot[r] = pi_l * cw_l * (pw[r] / v);  // pw = 0 for padding patterns
         if (hi == 0 && cat == 0 && pat[r] < a.P) ll += pw[r] * log(v);
       }
       ll = wave_sum(ll);
@@ -1484,27 +1481,26 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   }
   // ================= pre-order + edge derivatives =================
   auto edge_sums = [&](const V& na, const V& nb, int edge_a, int edge_b) {
-    double xb0 = 0, xs0 = 0, xb1 = 0, xs1 = 0;
+    // the pattern and category weights ride along in q (linear in the root vector)
+    double sa = na.v[0], sb = nb.v[0];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      xb0 += coefB[r] * na.v[r];
-      xs0 += coefS[r] * na.v[r];
-      xb1 += coefB[r] * nb.v[r];
-      xs1 += coefS[r] * nb.v[r];
+    for (int r = 1; r < R; r++) {
+      sa += na.v[r];
+      sb += nb.v[r];
     }
-    const double red = reduce4_transposed(xb0, xb1, xs0, xs1);
+    const double red = reduce4_transposed(rate_l * sa, rate_l * sb, drate_l * sa, drate_l * sb);
     // lane 15: branch a, lane 31: site a, lane 47: branch b, lane 63: site b
     if ((lane & 15) == 15) {
       const int which = lane >> 4;
       const int edge = (which & 2) ? edge_b : edge_a;
-      gout[((which & 1) ? N : 0) + edge] = red;  // every edge is visited exactly once
+      gacc[((which & 1) ? N : 0) + edge] = red;  // every edge is visited exactly once
     }
   };
   auto pre_step = [&](const UMacro& u, const MacroMats& cm) {
     V qv;
     if (u.qslot < 0) {
 #pragma unroll
-      for (int r = 0; r < R; r++) qv.v[r] = pi_l;
+      for (int r = 0; r < R; r++) qv.v[r] = qroot[r];
     } else {
       qv = load_slot(u.qslot);
     }
@@ -1568,6 +1564,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       }
     }
   }
+  __syncthreads();
+  double* gout = a.g_part + ((size_t)gi * a.g_tiles + blockIdx.x) * 2 * N;
+  for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];
 }
 
 // ------------------------------------------------------------------------
@@ -1854,8 +1853,8 @@ void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s) {
 size_t gradient_mfma_lds_bytes(int n, int K) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
   const int N = 2 * n - 1;
-  (void)N;
-  return sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile) + (size_t)n * 4 * (16 / kp) + 16;
+  return sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile + 2 * N) +
+         (size_t)n * 4 * (16 / kp) + 16;
 }
 bool gradient_mfma_fits(int n, int K) {
   return n >= 3 && K <= 4 && gradient_mfma_lds_bytes(n, K) <= 160 * 1024;

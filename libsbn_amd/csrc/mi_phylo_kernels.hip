@@ -1364,11 +1364,11 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   };
   // partial vector of a tip (0/1 from its state mask: one LDS word holds the R masks
   // of this lane's column) or of a stored node
+  // (the word is fetched a macro ahead together with the matrices: tips never change)
   const uint32_t* tipw = reinterpret_cast<const uint32_t*>(tips) + col;
-  auto operand = [&](int node, int slot) {
+  auto operand = [&](int node, int slot, uint32_t w) {
     V x;
     if (node < n) {
-      const uint32_t w = tipw[node * ppr];
 #pragma unroll
       for (int r = 0; r < R; r++)
         x.v[r] = (double)__builtin_amdgcn_ubfe(w, (uint32_t)(8 * r + hi), 1u);
@@ -1389,6 +1389,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     for (int r = 0; r < R; r++) z.v[r] = x.v[r] * y.v[r];
     return z;
   };
+  double qroot[R];  // root pre-order vector: pi * category weight * w_p / site likelihood
   // A macro entry made wave-uniform once (SGPRs are plentiful here: the matrices
   // live in VGPRs), so every index derived from it is scalar arithmetic.
   struct UMacro {
@@ -1397,6 +1398,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   // matrix registers of one macro: children c0,c1 and grandchildren a0,b0,a1,b1
   struct MacroMats {
     double f[6], tr[6];
+    uint32_t tw[6];  // tip state masks of this lane's column (when the node is a tip)
   };
   auto fetch_mats = [&](const UMacro& u) {
     MacroMats mt;
@@ -1404,8 +1406,13 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       const char* base = reinterpret_cast<const char*>(mats_e + (unsigned)(nodes[j] * K * 16));
-      mt.f[j] = *reinterpret_cast<const double*>(base + f_off);
-      mt.tr[j] = *reinterpret_cast<const double*>(base + t_off);
+      // opaque copies keep "base + lane offset" from being re-associated into a hoisted
+      // 64-bit vector address: scalar base + 32-bit lane offset is one addressing mode
+      unsigned fo = f_off, to = t_off;
+      asm volatile("" : "+v"(fo), "+v"(to));
+      mt.f[j] = *reinterpret_cast<const double*>(base + fo);
+      mt.tr[j] = *reinterpret_cast<const double*>(base + to);
+      mt.tw[j] = tipw[(nodes[j] < n ? nodes[j] : 0) * ppr];
     }
     return mt;
   };
@@ -1430,13 +1437,41 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   };
 
   // ================= post-order over the stored nodes (+ root: site likelihood) ====
-  double qroot[R];  // root pre-order vector: pi * category weight * w_p / site likelihood
-  auto post_step = [&](const UMacro& u, const MacroMats& cm) {
+  // Operands of one macro: issued (LDS reads) before the next macro's entry is made
+  // uniform and its matrices are requested, consumed afterwards.
+  struct Ops {
+    V q, x0, y0, x1, y1;  // q: pre-order vector; child 0: x0 (,y0 when unstored); child 1
+  };
+  auto load_ops = [&](const UMacro& u, const MacroMats& cm, bool pre) {
+    Ops o;
+    if (pre) {
+      if (u.qslot < 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) o.q.v[r] = qroot[r];
+      } else {
+        o.q = load_slot(u.qslot);
+      }
+    }
+    if (u.kind0 == 2) {
+      o.x0 = operand(u.g0, u.gs0, cm.tw[2]);
+      o.y0 = operand(u.g1, u.gs1, cm.tw[3]);
+    } else {
+      o.x0 = operand(u.c0, u.cs0, cm.tw[0]);
+    }
+    if (u.kind1 == 2) {
+      o.x1 = operand(u.g2, u.gs2, cm.tw[4]);
+      o.y1 = operand(u.g3, u.gs3, cm.tw[5]);
+    } else {
+      o.x1 = operand(u.c1, u.cs1, cm.tw[1]);
+    }
+    return o;
+  };
+  auto post_step = [&](const UMacro& u, const MacroMats& cm, const Ops& o) {
     V L0, L1;
-    if (u.kind0 == 2) L0 = mul(mm(cm.f[2], operand(u.g0, u.gs0)), mm(cm.f[3], operand(u.g1, u.gs1)));
-    else L0 = operand(u.c0, u.cs0);
-    if (u.kind1 == 2) L1 = mul(mm(cm.f[4], operand(u.g2, u.gs2)), mm(cm.f[5], operand(u.g3, u.gs3)));
-    else L1 = operand(u.c1, u.cs1);
+    if (u.kind0 == 2) L0 = mul(mm(cm.f[2], o.x0), mm(cm.f[3], o.y0));
+    else L0 = o.x0;
+    if (u.kind1 == 2) L1 = mul(mm(cm.f[4], o.x1), mm(cm.f[5], o.y1));
+    else L1 = o.x1;
     const V Lv = mul(mm(cm.f[0], L0), mm(cm.f[1], L1));
     if (u.qslot >= 0) {
       store_slot(u.qslot, Lv);
@@ -1467,15 +1502,17 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     MacroMats ma = fetch_mats(ua), mb;
     raw = macros[M > 1 ? 1 : 0];
     for (int m = 0; m < M; m += 2) {
+      const Ops oa = load_ops(ua, ma, false);
       ub = uniformize(raw);
       mb = fetch_mats(ub);
       raw = macros[m + 2 < M ? m + 2 : M - 1];
-      post_step(ua, ma);
+      post_step(ua, ma, oa);
       if (m + 1 < M) {
+        const Ops ob = load_ops(ub, mb, false);
         ua = uniformize(raw);
         ma = fetch_mats(ua);
         raw = macros[m + 3 < M ? m + 3 : M - 1];
-        post_step(ub, mb);
+        post_step(ub, mb, ob);
       }
     }
   }
@@ -1496,32 +1533,23 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       gacc[((which & 1) ? N : 0) + edge] = red;  // every edge is visited exactly once
     }
   };
-  auto pre_step = [&](const UMacro& u, const MacroMats& cm) {
-    V qv;
-    if (u.qslot < 0) {
-#pragma unroll
-      for (int r = 0; r < R; r++) qv.v[r] = qroot[r];
-    } else {
-      qv = load_slot(u.qslot);
-    }
-    V L0, L1, La0, Lb0, La1, Lb1, Ap0, Bp0, Ap1, Bp1;
+  auto pre_step = [&](const UMacro& u, const MacroMats& cm, const Ops& o) {
+    const V& qv = o.q;
+    const V &La0 = o.x0, &Lb0 = o.y0, &La1 = o.x1, &Lb1 = o.y1;
+    V L0, L1, Ap0, Bp0, Ap1, Bp1;
     if (u.kind0 == 2) {
-      La0 = operand(u.g0, u.gs0);
-      Lb0 = operand(u.g1, u.gs1);
       Ap0 = mm(cm.f[2], La0);
       Bp0 = mm(cm.f[3], Lb0);
       L0 = mul(Ap0, Bp0);
     } else {
-      L0 = operand(u.c0, u.cs0);
+      L0 = o.x0;
     }
     if (u.kind1 == 2) {
-      La1 = operand(u.g2, u.gs2);
-      Lb1 = operand(u.g3, u.gs3);
       Ap1 = mm(cm.f[4], La1);
       Bp1 = mm(cm.f[5], Lb1);
       L1 = mul(Ap1, Bp1);
     } else {
-      L1 = operand(u.c1, u.cs1);
+      L1 = o.x1;
     }
     const V A = mm(cm.f[0], L0), B = mm(cm.f[1], L1);
     const V q0 = mm(cm.tr[0], mul(qv, B));
@@ -1552,15 +1580,17 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     MacroMats ma = fetch_mats(ua), mb;
     raw = macros[M > 1 ? M - 2 : 0];
     for (int m = M - 1; m >= 0; m -= 2) {
+      const Ops oa = load_ops(ua, ma, true);
       ub = uniformize(raw);
       mb = fetch_mats(ub);
       raw = macros[m >= 2 ? m - 2 : 0];
-      pre_step(ua, ma);
+      pre_step(ua, ma, oa);
       if (m >= 1) {
+        const Ops ob = load_ops(ub, mb, true);
         ua = uniformize(raw);
         ma = fetch_mats(ua);
         raw = macros[m >= 3 ? m - 3 : 0];
-        pre_step(ub, mb);
+        pre_step(ub, mb, ob);
       }
     }
   }

@@ -90,7 +90,7 @@ struct mi_engine {
   Buffer tip_states, tip_partials, weights;
   // per-call workspace
   Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, ll_part, plv, g_part, site_lik, fin_scratch,
-      status;
+      ll_sum, g_sum, status;
   bool allow_onchip_gradient = true;
   bool prefer_mfma_gradient = true;  // matrix-core gradient kernel when K <= 4 and it fits
   int gradient_path = 0;  // 0 auto, 1 valu on-chip, 2 hbm, 3 mfma
@@ -139,7 +139,7 @@ size_t plv_bytes_per_eval(const mi_engine* e) {
 int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
   const CallShape c = call_shape(e, T, gradient);
   const int n = e->n, N = e->N;
-  if (e->tree_scratch.ensure(sizeof(int32_t) * (size_t)T * 12 * N)) return 1;
+  if (e->tree_scratch.ensure(sizeof(int32_t) * (size_t)T * 13 * N)) return 1;
   if (e->sched.ensure(sizeof(SchedEntry) * (size_t)T * (n - 1))) return 1;
   if (e->macros.ensure(sizeof(MacroEntry) * (size_t)T * max_macros(n))) return 1;
   if (e->macro_count.ensure(sizeof(int32_t) * (size_t)T)) return 1;
@@ -150,6 +150,8 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
   if (e->ll_part.ensure(sizeof(double) * (size_t)c.E * e->ll_stride)) return 1;
   if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
   if (e->status.ensure(sizeof(int32_t) * 2)) return 1;
+  if (e->ll_sum.ensure(sizeof(double) * (size_t)c.E)) return 1;
+  if (gradient && e->g_sum.ensure(sizeof(double) * (size_t)c.Eg * 2 * N)) return 1;
   if (gradient) {
     // the HBM-streamed kernel is the fallback for rescaling / trees that do not fit
     // in LDS; its arena is only allocated when that path can be taken
@@ -240,7 +242,9 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   tr.models = e->models.as<DevModel>();
   tr.bl_eff = e->bl_eff.as<double>();
   tr.mats = e->mats.as<double>();
-  tr.tip_tables = e->tip_tables.as<double>();
+  // the per-state tip tables feed the VALU walk kernels only
+  const bool need_tip_tables = !(d.gradient && mfma && !c.gtr);
+  tr.tip_tables = need_tip_tables ? e->tip_tables.as<double>() : nullptr;
   tr.n = n;
   launch_transition(tr, s);
 
@@ -327,14 +331,32 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   fa.tiles = e->tiles;
   fa.ll_tiles = e->ll_stride;
   fa.g_tiles = g_tiles;
+  fa.ll_part = e->ll_part.as<double>();
+  fa.g_part = e->g_part.as<double>();
+  if (reduce_tiles_fits(N)) {
+    // sum the per-tile partials with one workgroup per evaluation first
+    ReduceArgs ra{};
+    ra.N = N;
+    ra.E = c.E;
+    ra.Eg = c.Eg;
+    ra.ll_tiles = e->ll_stride;
+    ra.g_tiles = g_tiles;
+    ra.ll_part = e->ll_part.as<double>();
+    ra.g_part = e->g_part.as<double>();
+    ra.ll_sum = e->ll_sum.as<double>();
+    ra.g_sum = e->g_sum.as<double>();
+    launch_reduce_tiles(ra, s);
+    fa.ll_tiles = 1;
+    fa.g_tiles = 1;
+    fa.ll_part = ra.ll_sum;
+    fa.g_part = ra.g_sum;
+  }
   fa.gradient = d.gradient;
   fa.rooted = d.rooted;
   fa.with_jacobian = d.with_jacobian;
   fa.gtr = c.gtr;
   fa.site_fused = c.site_fused;
   fa.site_separate = c.site_separate;
-  fa.ll_part = e->ll_part.as<double>();
-  fa.g_part = e->g_part.as<double>();
   fa.bl_eff = e->bl_eff.as<double>();
   fa.bl_raw = d.bl;
   fa.rates = d.rates;
@@ -514,7 +536,7 @@ void mi_engine_destroy(mi_engine* e) {
        {&e->tip_states, &e->tip_partials, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
         &e->macro_count, &e->tip_tables, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->fin_scratch,
-        &e->status,
+        &e->ll_sum, &e->g_sum, &e->status,
         &e->in_parent, &e->in_bl, &e->in_params, &e->in_rates, &e->in_rate_counts,
         &e->in_heights, &e->in_bounds, &e->in_ratios, &e->out_ll, &e->out_a, &e->out_b,
         &e->out_site, &e->out_subst})

@@ -36,7 +36,7 @@ struct TreeSetupArgs {
   const int32_t* parent_ids;  // [T][2n-3] unrooted, [T][2n-2] rooted
   const double* bl;           // [T][2n-2] unrooted, [T][2n-1] rooted
   const double* rates;        // [T][2n-2] or nullptr: branch length x rate
-  int32_t* scratch;           // [T][12 N]
+  int32_t* scratch;           // [T][13 N]
   SchedEntry* sched;          // [T][n-1]
   MacroEntry* macros;         // [T][max_macros(n)] (may be nullptr)
   int32_t* macro_count;       // [T]
@@ -135,6 +135,17 @@ void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s);
 // writes the log-likelihood partial sums, so no separate logL pass is needed.
 bool gradient_mfma_fits(int n, int K);
 void launch_gradient_mfma(const LikArgs& a, int count, hipStream_t s);
+// Sum of the per-tile partials: ll_sum[e] = sum_i ll_part[e][i] for e < E,
+// g_sum[gi][2N] = sum_i g_part[gi][i][2N] for gi < Eg (fixed order: deterministic).
+struct ReduceArgs {
+  int N, E, Eg, ll_tiles, g_tiles;
+  const double* ll_part;
+  const double* g_part;
+  double* ll_sum;
+  double* g_sum;
+};
+bool reduce_tiles_fits(int N);
+void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s);
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);
 
 const char* loglik_kernel_name();

@@ -130,15 +130,15 @@ __device__ __forceinline__ void set_status(int32_t* status, int code, int tree) 
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
   // One wave per tree.  The walk itself is sequential (lane 0); its working set
-  // lives in LDS (12 N ints) unless the tree is too large, and the bulk copies
+  // lives in LDS (13 N ints) unless the tree is too large, and the bulk copies
   // (branch lengths, schedule) are done by all 64 lanes.
   extern __shared__ int32_t ts_lds[];
   const int t = blockIdx.x;
   const int lane = threadIdx.x;
   const int n = a.n, N = 2 * n - 1;
   const int nodes_in = a.rooted ? N : N - 1;
-  const int32_t* par = a.parent_ids + (size_t)t * (nodes_in - 1);
-  int32_t* maxleaf = a.use_lds ? ts_lds : a.scratch + (size_t)t * 12 * N;
+  const int32_t* par_in = a.parent_ids + (size_t)t * (nodes_in - 1);
+  int32_t* maxleaf = a.use_lds ? ts_lds : a.scratch + (size_t)t * 13 * N;
   int32_t* cnt = maxleaf + N;
   int32_t* kids = cnt + N;  // 3 per node
   int32_t* c0 = kids + 3 * N;
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
   int32_t* label = c1 + N;
   int32_t* slot = label + N;
   int32_t* stack = slot + N;  // 2N
+  int32_t* par = stack + 2 * N;  // the parent ids, fetched by the whole wave at once
   __shared__ int ok_flag;
   SchedEntry* sched = a.sched + (size_t)t * (n - 1);
   double* ble = a.bl_eff + (size_t)t * N;
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
     label[v] = 0;
     slot[v] = 0;
     c0[v] = c1[v] = 0;
+    if (v < nodes_in - 1) par[v] = par_in[v];
   }
   __syncthreads();
   if (lane == 0) {
@@ -489,50 +491,60 @@ __global__ void model_setup_kernel(ModelSetupArgs a) {
 // of gradient noise); the expm1 form agrees with an 80-bit evaluation to 1e-15.
 // See DESIGN.md "Accuracy".
 // ------------------------------------------------------------------------
-__global__ void transition_kernel(TransitionArgs a) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int kTransitionBlock = 256;
+__global__ __launch_bounds__(kTransitionBlock) void transition_kernel(TransitionArgs a) {
+  // one thread per matrix; the 128-byte results are staged through LDS (row stride 17:
+  // conflict-free) so that the block writes its 32 KB of output as whole cache lines
+  __shared__ double stage[kTransitionBlock * 17];
+  const long first = (long)blockIdx.x * kTransitionBlock;
+  const long idx = first + threadIdx.x;
   const long total = (long)a.E * (a.N - 1) * a.K;
-  if (idx >= total) return;
-  const int k = idx % a.K;
-  const int edge = (idx / a.K) % (a.N - 1);
-  const int e = idx / ((long)a.K * (a.N - 1));
-  int t, mi;
-  a.map.decode(e, t, mi);
-  const DevModel& m = a.models[mi];
-  const double bl = a.bl_eff[(size_t)t * a.N + edge];
-  const double rt = m.cat_rate[k] * bl;
-  double ex[4], W[16];
-  for (int x = 0; x < 4; x++) ex[x] = expm1(m.lambda[x] * rt);
-  for (int x = 0; x < 4; x++)
-    for (int j = 0; j < 4; j++) W[x * 4 + j] = ex[x] * m.Vinv[x * 4 + j];
-  double* out = a.mats + idx * 16;
-  double Pm[16];
-  for (int i = 0; i < 4; i++)
-    for (int j = 0; j < 4; j++) {
-      double sum = i == j ? 1.0 : 0.0;
-      for (int x = 0; x < 4; x++) sum += m.V[i * 4 + x] * W[x * 4 + j];
-      Pm[i * 4 + j] = sum > 0 ? sum : 0;  // BEAGLE clamps negative probabilities to 0
-      out[i * 4 + j] = Pm[i * 4 + j];
-    }
-  if (edge < a.n) {
-    // Tip edges: what a compact tip state st contributes is a COLUMN of P (forward
-    // sweep) or of P Q (edge derivative); a gap contributes 1 resp. 0 (rows of P sum
-    // to 1, rows of Q to 0).  Tabulated per state so that the walk kernels fetch
-    // them with one 32-byte gather instead of spending FP64 issue slots on one-hot
-    // vectors: table[0][st][i] = P[i][st], table[1][st][i] = (P Q)[i][st].
-    double* tab = a.tip_tables + (((size_t)e * a.n + edge) * a.K + k) * 40;
-    for (int st = 0; st < 4; st++)
-      for (int i = 0; i < 4; i++) {
-        tab[st * 4 + i] = Pm[i * 4 + st];
-        double pq = 0;
-        for (int x = 0; x < 4; x++) pq += Pm[i * 4 + x] * m.Q[x * 4 + st];
-        tab[20 + st * 4 + i] = pq;
+  if (idx < total) {
+    const int k = idx % a.K;
+    const int edge = (idx / a.K) % (a.N - 1);
+    const int e = idx / ((long)a.K * (a.N - 1));
+    int t, mi;
+    a.map.decode(e, t, mi);
+    const DevModel& m = a.models[mi];
+    const double bl = a.bl_eff[(size_t)t * a.N + edge];
+    const double rt = m.cat_rate[k] * bl;
+    double ex[4], W[16];
+    for (int x = 0; x < 4; x++) ex[x] = expm1(m.lambda[x] * rt);
+    for (int x = 0; x < 4; x++)
+      for (int j = 0; j < 4; j++) W[x * 4 + j] = ex[x] * m.Vinv[x * 4 + j];
+    double Pm[16];
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        double sum = i == j ? 1.0 : 0.0;
+        for (int x = 0; x < 4; x++) sum += m.V[i * 4 + x] * W[x * 4 + j];
+        Pm[i * 4 + j] = sum > 0 ? sum : 0;  // BEAGLE clamps negative probabilities to 0
+        stage[threadIdx.x * 17 + i * 4 + j] = Pm[i * 4 + j];
       }
-    for (int i = 0; i < 4; i++) {
-      tab[16 + i] = 1.0;
-      tab[36 + i] = 0.0;
+    if (a.tip_tables != nullptr && edge < a.n) {
+      // Tip edges: what a compact tip state st contributes is a COLUMN of P (forward
+      // sweep) or of P Q (edge derivative); a gap contributes 1 resp. 0 (rows of P sum
+      // to 1, rows of Q to 0).  Tabulated per state so that the VALU walk kernels fetch
+      // them with one 32-byte gather instead of spending FP64 issue slots on one-hot
+      // vectors: table[0][st][i] = P[i][st], table[1][st][i] = (P Q)[i][st].
+      double* tab = a.tip_tables + (((size_t)e * a.n + edge) * a.K + k) * 40;
+      for (int st = 0; st < 4; st++)
+        for (int i = 0; i < 4; i++) {
+          tab[st * 4 + i] = Pm[i * 4 + st];
+          double pq = 0;
+          for (int x = 0; x < 4; x++) pq += Pm[i * 4 + x] * m.Q[x * 4 + st];
+          tab[20 + st * 4 + i] = pq;
+        }
+      for (int i = 0; i < 4; i++) {
+        tab[16 + i] = 1.0;
+        tab[36 + i] = 0.0;
+      }
     }
   }
+  __syncthreads();
+  const long left = total - first;
+  const int count = (int)(left < kTransitionBlock ? left : kTransitionBlock) * 16;
+  double* out = a.mats + first * 16;
+  for (int x = threadIdx.x; x < count; x += kTransitionBlock) out[x] = stage[(x >> 4) * 17 + (x & 15)];
 }
 
 // ------------------------------------------------------------------------
@@ -1600,6 +1612,40 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
 }
 
 // ------------------------------------------------------------------------
+// Tile reduction (one workgroup per evaluation): four waves split the tiles
+// (wave w takes tiles w, w+4, ...), combine through LDS in a fixed order.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
+  extern __shared__ double red_lds[];  // [4][2N]
+  __shared__ double llw[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int W = 2 * a.N;
+  double llp = 0;
+  for (int i = threadIdx.x; i < a.ll_tiles; i += 256) llp += a.ll_part[(size_t)b * a.ll_tiles + i];
+  llp = wave_sum(llp);
+  if (lane == 0) llw[wv] = llp;
+  if (b < a.Eg) {
+    const double* src = a.g_part + (size_t)b * a.g_tiles * W;
+    for (int v = lane; v < W; v += 64) {
+      double s0 = 0, s1 = 0;
+      int i = wv;
+      for (; i + 4 < a.g_tiles; i += 8) {
+        s0 += src[(size_t)i * W + v];
+        s1 += src[(size_t)(i + 4) * W + v];
+      }
+      if (i < a.g_tiles) s0 += src[(size_t)i * W + v];
+      red_lds[wv * W + v] = s0 + s1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.ll_sum[b] = (llw[0] + llw[1]) + (llw[2] + llw[3]);
+  if (b < a.Eg)
+    for (int v = threadIdx.x; v < W; v += 256)
+      a.g_sum[(size_t)b * W + v] =
+          (red_lds[v] + red_lds[W + v]) + (red_lds[2 * W + v] + red_lds[3 * W + v]);
+}
+
+// ------------------------------------------------------------------------
 // Finalize (one thread per tree): sum tile partials in a fixed order
 // (deterministic), assemble PhyloGradient, rooted chain rule.
 // ------------------------------------------------------------------------
@@ -1648,7 +1694,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
   // doubles) in LDS unless the tree is too large.
   extern __shared__ double fin_lds[];
   const int t = blockIdx.x, lane = threadIdx.x;
-  const int n = a.n, N = a.N, T = a.T, tiles = a.tiles;
+  const int n = a.n, N = a.N, T = a.T;
   double* base = a.use_lds ? fin_lds : a.scratch + (size_t)t * 6 * n;
   int32_t* c0 = reinterpret_cast<int32_t*>(base);
   int32_t* c1 = c0 + n;
@@ -1788,7 +1834,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
 // ------------------------------------------------------------------------
 void launch_tree_setup(const TreeSetupArgs& a_in, hipStream_t s) {
   TreeSetupArgs a = a_in;
-  const size_t lds = sizeof(int32_t) * 12 * (size_t)(2 * a.n - 1);
+  const size_t lds = sizeof(int32_t) * 13 * (size_t)(2 * a.n - 1);
   a.use_lds = lds <= 48 * 1024;
   hipLaunchKernelGGL(tree_setup_kernel, dim3(a.T), dim3(64), a.use_lds ? lds : 0, s, a);
 }
@@ -1902,6 +1948,12 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, hipStream_t s) {
   }
   hipLaunchKernelGGL((gradient_mfma_kernel<kLlR>), dim3(loglik_mfma_tiles(a.P, a.K), count),
                      dim3(kTile), lds, s, a);
+}
+bool reduce_tiles_fits(int N) { return sizeof(double) * 8 * (size_t)N <= 64 * 1024; }
+void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s) {
+  if (a.E <= 0) return;
+  hipLaunchKernelGGL(reduce_tiles_kernel, dim3(a.E), dim3(256), sizeof(double) * 8 * (size_t)a.N, s,
+                     a);
 }
 void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
   FinalizeArgs a = a_in;

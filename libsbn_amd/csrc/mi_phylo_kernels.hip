@@ -115,6 +115,30 @@ __device__ __forceinline__ double max4(D4 a) {
   return fmax(fmax(a.x0, a.x1), fmax(a.x2, a.x3));
 }
 
+// Workgroups are dealt to the 8 XCDs (each with a private 4 MiB L2) round-robin by
+// linear id: ids b and b+8 share an XCD.  The walk kernels launch (tiles x evaluations)
+// workgroups; this bijection hands each XCD whole evaluations, so that an evaluation's
+// transition matrices and schedule are fetched into ONE L2 instead of all eight.
+// Placement is a speed matter only.
+struct TileEval {
+  int tile, eval;
+};
+__device__ __forceinline__ TileEval xcd_tile_eval() {
+  const int tiles = gridDim.x, count = gridDim.y;
+  const int id = blockIdx.x + tiles * blockIdx.y;
+  const int full = count & ~7;  // evaluations in complete groups of 8
+  TileEval te;
+  if (id < full * tiles) {
+    const int s = id >> 3;  // s-th workgroup of its XCD
+    te.eval = (s / tiles) * 8 + (id & 7);
+    te.tile = s % tiles;
+  } else {
+    te.eval = blockIdx.y;
+    te.tile = blockIdx.x;
+  }
+  return te;
+}
+
 __device__ __forceinline__ void set_status(int32_t* status, int code, int tree) {
   if (atomicCAS(status, 0, code) == 0) status[1] = tree;
 }
@@ -559,8 +583,9 @@ template <bool RESCALE, bool TIP_PARTIALS>
 __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
-  const int tile = blockIdx.x;
-  const int e = a.eval_offset + blockIdx.y;
+  const TileEval te = xcd_tile_eval();
+  const int tile = te.tile;
+  const int e = a.eval_offset + te.eval;
   int t, mi;
   a.map.decode(e, t, mi);
   const DevModel* __restrict__ model = a.models + mi;
@@ -667,7 +692,7 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
   }
   asm volatile("" ::"s"(touched));
   if (!RESCALE && a.site_lik)
-    a.site_lik[((size_t)a.grad_offset + blockIdx.y) * a.tiles * kTile + p] = site;
+    a.site_lik[((size_t)a.grad_offset + te.eval) * a.tiles * kTile + p] = site;
   double ll = log(site);
   if (RESCALE) ll += site_exp * 0.6931471805599453;
   ll = p < a.P ? w * ll : 0.0;
@@ -699,7 +724,8 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
-  const int e = a.eval_offset + blockIdx.y;
+  const TileEval te = xcd_tile_eval();
+  const int e = a.eval_offset + te.eval;
   int t, mi;
   a.map.decode(e, t, mi);
   const DevModel* __restrict__ model = a.models + mi;
@@ -713,7 +739,7 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   int pat[R], patc[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    pat[r] = (blockIdx.x * R + r) * ppr + pgrp * 4 + lo;
+    pat[r] = (te.tile * R + r) * ppr + pgrp * 4 + lo;
     patc[r] = pat[r] < a.P ? pat[r] : a.P - 1;
   }
   // LDS: PLV registers [slot][r][lane] | tip states of this tile [taxon][r][16 columns]
@@ -730,7 +756,7 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   // are issued eight at a time per lane before any of them is stored: the prologue
   // costs a few memory round trips instead of one per taxon.
   const int TP = ppr * R;               // patterns per tile
-  const int tile_start = blockIdx.x * TP;
+  const int tile_start = te.tile * TP;
   SchedEntry* sched_l = reinterpret_cast<SchedEntry*>(tips + (((size_t)n * R * 16 + 15) & ~(size_t)15));
   for (int i = lane; i < n - 1; i += kTile) sched_l[i] = sched[i];
   if (!TIP_PARTIALS && !(a.debug & 16)) {
@@ -851,7 +877,7 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   // cw * pi * L; every lane of a pattern's 4*Kp lanes ends up with the sum
   double ll = 0.0;
   if (a.debug & 32) {
-    if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + blockIdx.x] = L[0] + L[R - 1] + wgt + pw[0];
+    if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = L[0] + L[R - 1] + wgt + pw[0];
     return;
   }
 #pragma unroll
@@ -864,12 +890,12 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
     const bool owner = hi == 0 && cat == 0 && pat[r] < a.P;  // one lane per pattern
     if (owner) {
       if (a.site_lik)
-        a.site_lik[((size_t)a.grad_offset + blockIdx.y) * a.tiles * kTile + pat[r]] = v;
+        a.site_lik[((size_t)a.grad_offset + te.eval) * a.tiles * kTile + pat[r]] = v;
       ll += pw[r] * log(v);
     }
   }
   ll = wave_sum(ll);
-  if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + blockIdx.x] = ll;
+  if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
 }
 
 // ------------------------------------------------------------------------
@@ -883,9 +909,10 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
 template <bool RESCALE, bool TIP_PARTIALS>
 __global__ __launch_bounds__(kTile) void gradient_hbm_kernel(LikArgs a) {
   const int lane = threadIdx.x;
-  const int tile = blockIdx.x;
-  const int e = a.eval_offset + blockIdx.y;
-  const int gi = a.grad_offset + blockIdx.y;
+  const TileEval te = xcd_tile_eval();
+  const int tile = te.tile;
+  const int e = a.eval_offset + te.eval;
+  const int gi = a.grad_offset + te.eval;
   int t, mi;
   a.map.decode(e, t, mi);
   const DevModel* __restrict__ model = a.models + mi;
@@ -896,7 +923,7 @@ __global__ __launch_bounds__(kTile) void gradient_hbm_kernel(LikArgs a) {
   const int K = a.K, n = a.n, N = a.N;
   const size_t ppad = (size_t)a.tiles * kTile;
   const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
-  double* plv_e = a.plv + (size_t)blockIdx.y * (n - 1) * K * ppad * 4 + (size_t)p * 4;
+  double* plv_e = a.plv + (size_t)te.eval * (n - 1) * K * ppad * 4 + (size_t)p * 4;
   double* gout = a.g_part + ((size_t)gi * a.g_tiles + tile) * 2 * N;
 
   auto plv_at = [&](int node, int k) { return plv_e + ((size_t)(node - n) * K + k) * ppad * 4; };
@@ -1087,9 +1114,10 @@ __device__ __forceinline__ M16 load_matrix_vgpr(const double* __restrict__ base,
 __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
   extern __shared__ double glds[];
   const int lane = threadIdx.x;
-  const int tile = blockIdx.x;
-  const int e = a.eval_offset + blockIdx.y;
-  const int gi = a.grad_offset + blockIdx.y;
+  const TileEval te = xcd_tile_eval();
+  const int tile = te.tile;
+  const int e = a.eval_offset + te.eval;
+  const int gi = a.grad_offset + te.eval;
   int t, mi;
   a.map.decode(e, t, mi);
   const DevModel* __restrict__ model = a.models + mi;
@@ -1298,8 +1326,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   extern __shared__ double glds[];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
-  const int e = a.eval_offset + blockIdx.y;
-  const int gi = a.grad_offset + blockIdx.y;
+  const TileEval te = xcd_tile_eval();
+  const int e = a.eval_offset + te.eval;
+  const int gi = a.grad_offset + te.eval;
   int t, mi;
   a.map.decode(e, t, mi);
   const DevModel* __restrict__ model = a.models + mi;
@@ -1312,7 +1341,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   // byte offsets (unsigned: scalar base + 32-bit lane offset addressing)
   const unsigned f_off = 8u * (catc * 16 + lo * 4 + hi);  // forward:    A[i=lo][k=hi] = P[lo][hi]
   const unsigned t_off = 8u * (catc * 16 + hi * 4 + lo);  // transposed: A[i=lo][k=hi] = P[hi][lo]
-  const int TP = ppr * R, tile_start = blockIdx.x * TP;
+  const int TP = ppr * R, tile_start = te.tile * TP;
   const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
   int pat[R], patc[R];
   double pw[R];
@@ -1501,7 +1530,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
         if (hi == 0 && cat == 0 && pat[r] < a.P) ll += pw[r] * log(v);
       }
       ll = wave_sum(ll);
-      if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + blockIdx.x] = ll;
+      if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
     }
   };
   {
@@ -1607,7 +1636,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     }
   }
   __syncthreads();
-  double* gout = a.g_part + ((size_t)gi * a.g_tiles + blockIdx.x) * 2 * N;
+  double* gout = a.g_part + ((size_t)gi * a.g_tiles + te.tile) * 2 * N;
   for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];
 }
 

@@ -146,7 +146,7 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
   if (e->bl_eff.ensure(sizeof(double) * (size_t)T * N)) return 1;
   if (e->models.ensure(sizeof(DevModel) * (size_t)c.M)) return 1;
   if (e->mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
-  if (e->tip_tables.ensure(sizeof(double) * (size_t)c.E * n * e->K * 40)) return 1;
+  if (e->tip_tables.ensure(sizeof(double) * (size_t)c.E * n * e->K * 20)) return 1;
   if (e->ll_part.ensure(sizeof(double) * (size_t)c.E * e->ll_stride)) return 1;
   if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
   if (e->status.ensure(sizeof(int32_t) * 2)) return 1;

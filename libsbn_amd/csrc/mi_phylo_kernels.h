@@ -61,7 +61,7 @@ struct TransitionArgs {
   const DevModel* models;
   const double* bl_eff;  // [T][N]
   double* mats;          // [E][N-1][K][16]
-  double* tip_tables;    // [E][n][K][2][5][4]: per tip edge, P columns (+ones row) and (P Q) columns (+zero row)
+  double* tip_tables;    // [E][n][K][5][4]: per tip edge and state (4 = gap), the column of P; may be nullptr
   int n;
 };
 

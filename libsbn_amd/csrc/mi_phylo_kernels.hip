@@ -322,6 +322,242 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
 }
 
 // ------------------------------------------------------------------------
+// Tree setup for N <= 64 nodes: the same walk with every per-node array held in ONE
+// vector register (lane = node id) and indexed with v_readlane / v_writelane.  The walk
+// is sequential and its cost is the latency of each dependent array access: a
+// cross-lane read is an order of magnitude quicker than an LDS round trip.  All
+// values are wave-uniform, so control flow is scalar.
+// ------------------------------------------------------------------------
+#define RDL(arr, i) __builtin_amdgcn_readlane((arr), (i))
+#define WRL(arr, i, val) (arr) = (lane == (i)) ? (val) : (arr)
+__global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
+  const int t = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int n = a.n, N = 2 * n - 1;
+  const int nodes_in = a.rooted ? N : N - 1;
+  const int root_in = nodes_in - 1;
+  const int32_t* par_in = a.parent_ids + (size_t)t * (nodes_in - 1);
+  SchedEntry* sched = a.sched + (size_t)t * (n - 1);
+  double* ble = a.bl_eff + (size_t)t * N;
+
+  int par = lane < nodes_in - 1 ? par_in[lane] : 0;
+  int maxleaf = lane < n ? lane : -1;
+  int cnt = 0, k0 = 0, k1 = 0, k2 = 0, c0 = 0, c1 = 0, label = 0, slot = 0;
+  int s_node = 0, s_c0 = 0, s_c1 = 0, s_sl = 0;  // schedule, lane = position
+  int status = kOk;
+  const bool bad_parent =
+      lane < nodes_in - 1 && (par <= lane || par >= nodes_in || par < n);
+  if (__any(bad_parent)) status = kBadParentIds;
+  if (status == kOk) {
+    for (int v = 0; v < nodes_in - 1; v++) {
+      const int p = RDL(par, v);
+      const int mv = RDL(maxleaf, v);
+      if (mv > RDL(maxleaf, p)) WRL(maxleaf, p, mv);
+    }
+    for (int v = 0; v < nodes_in - 1; v++) {
+      const int p = RDL(par, v);
+      const int k = RDL(cnt, p);
+      if (k >= 3) {
+        status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
+        break;
+      }
+      // insertion into the (at most 3) children of p, ascending max leaf id
+      const int mv = RDL(maxleaf, v);
+      int e0 = RDL(k0, p), e1 = RDL(k1, p), e2 = RDL(k2, p);
+      if (k == 0) {
+        e0 = v;
+      } else if (k == 1) {
+        if (RDL(maxleaf, e0) > mv) {
+          e1 = e0;
+          e0 = v;
+        } else {
+          e1 = v;
+        }
+      } else {
+        if (RDL(maxleaf, e1) > mv) {
+          e2 = e1;
+          if (RDL(maxleaf, e0) > mv) {
+            e1 = e0;
+            e0 = v;
+          } else {
+            e1 = v;
+          }
+        } else {
+          e2 = v;
+        }
+      }
+      WRL(k0, p, e0);
+      WRL(k1, p, e1);
+      WRL(k2, p, e2);
+      WRL(cnt, p, k + 1);
+    }
+  }
+  if (status == kOk) {
+    const int want = (!a.rooted && lane == root_in) ? 3 : 2;
+    if (__any(lane >= n && lane < nodes_in && cnt != want))
+      status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
+  }
+  int macro_total = 0;
+  // macro entries, lane = macro index
+  int m_node = 0, m_qslot = 0, m_c0 = 0, m_c1 = 0, m_k0 = 0, m_k1 = 0, m_cs0 = 0, m_cs1 = 0;
+  int m_g0 = 0, m_g1 = 0, m_g2 = 0, m_g3 = 0, m_gs0 = 0, m_gs1 = 0, m_gs2 = 0, m_gs3 = 0;
+  if (status == kOk) {
+    if (lane >= n && lane < nodes_in) {
+      c0 = k0;
+      c1 = k1;
+    }
+    if (!a.rooted) {
+      // (k0,k1,k2) at root r  ->  r = (k1,k2), r+1 = (k0, r)
+      const int r = root_in;
+      const int kr0 = RDL(k0, r);
+      if (lane == r) {
+        c0 = k1;
+        c1 = k2;
+      }
+      if (lane == r + 1) {
+        c0 = kr0;
+        c1 = r;
+      }
+    }
+    // Sethi-Ullman labels (tips cost nothing: they are read in compact form).
+    for (int v = n; v < N; v++) {
+      const int l0 = RDL(label, RDL(c0, v)), l1 = RDL(label, RDL(c1, v));
+      WRL(label, v, l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1));
+    }
+    // Post-order DFS, heavier child first; slots from a free bitmask.
+    int stk_lo = 0, stk_hi = 0;
+    auto push = [&](int top, int x) {
+      if (top < 64) WRL(stk_lo, top, x);
+      else WRL(stk_hi, top - 64, x);
+    };
+    uint32_t free_mask = 0xffffffffu;
+    int top = 0, out = 0, used_max = 0;
+    push(top++, (N - 1) << 1);
+    while (top) {
+      --top;
+      const int item = top < 64 ? RDL(stk_lo, top) : RDL(stk_hi, top - 64);
+      const int v = item >> 1;
+      const int a0 = RDL(c0, v), a1 = RDL(c1, v);
+      if (item & 1) {
+        const int sa0 = RDL(slot, a0), sa1 = RDL(slot, a1);
+        if (a0 >= n) free_mask |= 1u << sa0;
+        if (a1 >= n) free_mask |= 1u << sa1;
+        const int sl = __ffs(free_mask) - 1;
+        free_mask &= ~(1u << sl);
+        WRL(slot, v, sl);
+        if (sl + 1 > used_max) used_max = sl + 1;
+        WRL(s_node, out, v);
+        WRL(s_c0, out, a0);
+        WRL(s_c1, out, a1);
+        WRL(s_sl, out, sl | (sa0 << 8) | (sa1 << 16));
+        out++;
+      } else {
+        push(top++, (v << 1) | 1);
+        const bool first0 = RDL(label, a0) >= RDL(label, a1);
+        const int lo = first0 ? a1 : a0, hi = first0 ? a0 : a1;
+        if (lo >= n) push(top++, lo << 1);
+        if (hi >= n) push(top++, hi << 1);  // popped first
+      }
+    }
+    if (used_max > a.max_slots) status = kTooManySlots;
+    // ---- schedule of the on-chip gradient kernels (see tree_setup_kernel) ----
+    if (a.macros) {
+      int cls = 0, sslot = 0;
+      int stored = 0;
+      for (int v = n; v < N - 1; v++) {
+        const int a0 = RDL(c0, v), a1 = RDL(c1, v);
+        const bool unstored = (a0 < n || RDL(cls, a0) == 1) && (a1 < n || RDL(cls, a1) == 1);
+        WRL(cls, v, unstored ? 2 : 1);
+        WRL(sslot, v, unstored ? 0 : stored);
+        if (!unstored) stored++;
+      }
+      WRL(cls, N - 1, 1);
+      WRL(sslot, N - 1, -1);
+      int m = 0;
+      for (int v = n; v < N; v++) {
+        if (RDL(cls, v) != 1) continue;
+        int ch[2], kind[2], cs[2], g[4], gs[4];
+        for (int j = 0; j < 2; j++) {
+          const int c = j ? RDL(c1, v) : RDL(c0, v);
+          const int cc = c >= n ? RDL(cls, c) : 0;
+          ch[j] = c;
+          kind[j] = cc;
+          cs[j] = cc == 1 ? RDL(sslot, c) : 0;
+          const bool expand = cc == 2;
+          const int ga = expand ? RDL(c0, c) : 0, gb = expand ? RDL(c1, c) : 0;
+          g[2 * j] = ga;
+          g[2 * j + 1] = gb;
+          gs[2 * j] = ga >= n ? RDL(sslot, ga) : 0;
+          gs[2 * j + 1] = gb >= n ? RDL(sslot, gb) : 0;
+        }
+        WRL(m_node, m, v);
+        WRL(m_qslot, m, RDL(sslot, v));
+        WRL(m_c0, m, ch[0]);
+        WRL(m_c1, m, ch[1]);
+        WRL(m_k0, m, kind[0]);
+        WRL(m_k1, m, kind[1]);
+        WRL(m_cs0, m, cs[0]);
+        WRL(m_cs1, m, cs[1]);
+        WRL(m_g0, m, g[0]);
+        WRL(m_g1, m, g[1]);
+        WRL(m_g2, m, g[2]);
+        WRL(m_g3, m, g[3]);
+        WRL(m_gs0, m, gs[0]);
+        WRL(m_gs1, m, gs[1]);
+        WRL(m_gs2, m, gs[2]);
+        WRL(m_gs3, m, gs[3]);
+        m++;
+      }
+      macro_total = m;
+      if (stored > max_stored(n)) status = kTooManySlots;
+    }
+  }
+  if (status != kOk && lane == 0) set_status(a.status, status, t);
+  const bool ok = status == kOk || status == kTooManySlots;
+  if (!ok) {
+    if (lane == 0 && a.macro_count) a.macro_count[t] = 0;
+    for (int i = lane; i < n - 1; i += 64) sched[i] = {n + i, 0, 1, 0};
+    for (int v = lane; v < N; v += 64) ble[v] = 0.0;
+    return;
+  }
+  if (lane < n - 1) sched[lane] = {s_node, s_c0, s_c1, s_sl};
+  if (a.macros) {
+    MacroEntry* mac = a.macros + (size_t)t * max_macros(n);
+    if (lane < macro_total) {
+      MacroEntry me;
+      me.node = m_node;
+      me.qslot = m_qslot;
+      me.child[0] = m_c0;
+      me.child[1] = m_c1;
+      me.kind[0] = m_k0;
+      me.kind[1] = m_k1;
+      me.cslot[0] = m_cs0;
+      me.cslot[1] = m_cs1;
+      me.grand[0] = m_g0;
+      me.grand[1] = m_g1;
+      me.grand[2] = m_g2;
+      me.grand[3] = m_g3;
+      me.gslot[0] = m_gs0;
+      me.gslot[1] = m_gs1;
+      me.gslot[2] = m_gs2;
+      me.gslot[3] = m_gs3;
+      mac[lane] = me;
+    }
+    if (lane == 0) a.macro_count[t] = macro_total;
+  }
+  if (!a.rooted) {
+    const double* bl = a.bl + (size_t)t * (N - 1);
+    if (lane < N) ble[lane] = lane < N - 2 ? bl[lane] : 0.0;
+  } else {
+    const double* bl = a.bl + (size_t)t * N;
+    const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
+    if (lane < N) ble[lane] = (rates && lane < N - 1) ? bl[lane] * rates[lane] : bl[lane];
+  }
+}
+#undef RDL
+#undef WRL
+
+// ------------------------------------------------------------------------
 // Model setup (one thread per model instance).
 // ------------------------------------------------------------------------
 __device__ void jacobi4(const double* A_in, double* evals, double* U) {
@@ -536,39 +772,36 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
     for (int x = 0; x < 4; x++) ex[x] = expm1(m.lambda[x] * rt);
     for (int x = 0; x < 4; x++)
       for (int j = 0; j < 4; j++) W[x * 4 + j] = ex[x] * m.Vinv[x * 4 + j];
-    double Pm[16];
     for (int i = 0; i < 4; i++)
       for (int j = 0; j < 4; j++) {
         double sum = i == j ? 1.0 : 0.0;
         for (int x = 0; x < 4; x++) sum += m.V[i * 4 + x] * W[x * 4 + j];
-        Pm[i * 4 + j] = sum > 0 ? sum : 0;  // BEAGLE clamps negative probabilities to 0
-        stage[threadIdx.x * 17 + i * 4 + j] = Pm[i * 4 + j];
+        // BEAGLE clamps negative probabilities to 0
+        stage[threadIdx.x * 17 + i * 4 + j] = sum > 0 ? sum : 0;
       }
-    if (a.tip_tables != nullptr && edge < a.n) {
-      // Tip edges: what a compact tip state st contributes is a COLUMN of P (forward
-      // sweep) or of P Q (edge derivative); a gap contributes 1 resp. 0 (rows of P sum
-      // to 1, rows of Q to 0).  Tabulated per state so that the VALU walk kernels fetch
-      // them with one 32-byte gather instead of spending FP64 issue slots on one-hot
-      // vectors: table[0][st][i] = P[i][st], table[1][st][i] = (P Q)[i][st].
-      double* tab = a.tip_tables + (((size_t)e * a.n + edge) * a.K + k) * 40;
-      for (int st = 0; st < 4; st++)
-        for (int i = 0; i < 4; i++) {
-          tab[st * 4 + i] = Pm[i * 4 + st];
-          double pq = 0;
-          for (int x = 0; x < 4; x++) pq += Pm[i * 4 + x] * m.Q[x * 4 + st];
-          tab[20 + st * 4 + i] = pq;
-        }
-      for (int i = 0; i < 4; i++) {
-        tab[16 + i] = 1.0;
-        tab[36 + i] = 0.0;
-      }
-    }
   }
   __syncthreads();
   const long left = total - first;
   const int count = (int)(left < kTransitionBlock ? left : kTransitionBlock) * 16;
   double* out = a.mats + first * 16;
   for (int x = threadIdx.x; x < count; x += kTransitionBlock) out[x] = stage[(x >> 4) * 17 + (x & 15)];
+  if (a.tip_tables != nullptr) {
+    // Tip edges: what a compact tip state st contributes to the forward sweep is a
+    // COLUMN of P; a gap contributes 1 (rows of P sum to 1).  Tabulated per state so
+    // that the VALU log-likelihood kernel fetches it with one 32-byte gather instead of
+    // spending FP64 issue slots on one-hot vectors: table[st][i] = P[i][st], st = 0..4.
+    // Written by the whole block from the staged matrices (contiguous destinations).
+    for (int x = threadIdx.x; x < (count >> 4) * 20; x += kTransitionBlock) {
+      const int m = x / 20, j = x - m * 20;
+      const long id = first + m;
+      const int k = id % a.K;
+      const int edge = (id / a.K) % (a.N - 1);
+      const int e = id / ((long)a.K * (a.N - 1));
+      if (edge < a.n)
+        a.tip_tables[(((size_t)e * a.n + edge) * a.K + k) * 20 + j] =
+            j < 16 ? stage[m * 17 + (j & 3) * 4 + (j >> 2)] : 1.0;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------
@@ -595,7 +828,7 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
   const double w = p < a.P ? a.weights[pc] : 0.0;
   const int K = a.K, n = a.n;
   const double* __restrict__ mats_e = a.mats + (size_t)e * (a.N - 1) * K * 16;
-  const double* __restrict__ tabs_e = a.tip_tables + (size_t)e * n * K * 40;
+  const double* __restrict__ tabs_e = a.tip_tables + (size_t)e * n * K * 20;
   // LDS: PLV columns [slot][state][lane] | this tile's tip states [taxon][lane]
   int8_t* tips = reinterpret_cast<int8_t*>(lds + (size_t)a.lds_slots * 4 * kTile);
   if (!TIP_PARTIALS) {
@@ -622,8 +855,8 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
       d.v[1] = load4(a.tip_partials + ((size_t)c1 * a.P + pc) * 4);
     } else {
       const int st0 = tips[c0 * kTile + lane], st1 = tips[c1 * kTile + lane];
-      d.v[0] = load4(tabs_e + ((size_t)c0 * K + k) * 40 + st0 * 4);
-      d.v[1] = load4(tabs_e + ((size_t)c1 * K + k) * 40 + st1 * 4);
+      d.v[0] = load4(tabs_e + ((size_t)c0 * K + k) * 20 + st0 * 4);
+      d.v[1] = load4(tabs_e + ((size_t)c1 * K + k) * 20 + st1 * 4);
     }
     return d;
   };
@@ -1865,6 +2098,10 @@ void launch_tree_setup(const TreeSetupArgs& a_in, hipStream_t s) {
   TreeSetupArgs a = a_in;
   const size_t lds = sizeof(int32_t) * 13 * (size_t)(2 * a.n - 1);
   a.use_lds = lds <= 48 * 1024;
+  if (2 * a.n - 1 <= 64 && a.n >= 3) {
+    hipLaunchKernelGGL(tree_setup_small_kernel, dim3(a.T), dim3(64), 0, s, a);
+    return;
+  }
   hipLaunchKernelGGL(tree_setup_kernel, dim3(a.T), dim3(64), a.use_lds ? lds : 0, s, a);
 }
 void launch_model_setup(const ModelSetupArgs& a, hipStream_t s) {

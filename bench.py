@@ -40,6 +40,13 @@ def algorithmic_bytes(n, P, K, s=4):
     return b_ll, b_g
 
 
+def algorithmic_flops(n, P, K, s=4):
+    """F_LL = (n-1) K P 4s^2, F_G = F_LL + (2n-2) K P (4s^2 + 2s^2 + 4s)."""
+    f_ll = (n - 1) * K * P * 4 * s * s
+    f_g = f_ll + (2 * n - 2) * K * P * (4 * s * s + 2 * s * s + 4 * s)
+    return f_ll, f_g
+
+
 def build_workload(T, seed=43):
     import oracle_lib as O  # fixtures loader only (no oracle compute here)
     st = O.load_struct("ds1_top100")
@@ -189,6 +196,8 @@ def main():
         kname, evals, gevals = eng.last_call_info()
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = per_tree * T / (k_ms * 1e-3) / 1e9
+        f_ll, f_g = algorithmic_flops(n, P, K)
+        tflops = (f_g if grad else f_ll) * T / (k_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -216,9 +225,14 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": kname, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_tree": per_tree,
+                         "fp64": {"achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
+                                  "frac": tflops / 78.6,
+                                  "algorithmic_flops_per_tree": f_g if grad else f_ll},
                          "note": "algorithmic bytes = SURVEY 8(d) PLV-streaming model for ONE "
                                  "pass (B_G gradient / B_LL logL); the kernel produces branch "
-                                 "and site gradients in that one pass"},
+                                 "and site gradients in that one pass and keeps partial "
+                                 "vectors in LDS, so frac > 1 is expected: traffic (PMC) is "
+                                 "the real HBM-side byte count, fp64 the compute-side view"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(tips, w, pids, bls, params, args.mode)

@@ -62,6 +62,7 @@ struct TransitionArgs {
   const double* bl_eff;  // [T][N]
   double* mats;          // [E][N-1][K][16]
   double* tip_tables;    // [E][n][K][5][4]: per tip edge and state (4 = gap), the column of P; may be nullptr
+  double* tip_pq;        // [E][n][K][4][4]: per tip edge, (P Q) transposed (matrix-core gradient); may be nullptr
   int n;
 };
 
@@ -81,6 +82,7 @@ struct LikArgs {
   const int32_t* macro_count;  // [T]
   const double* mats;
   const double* tip_tables;    // see TransitionArgs
+  const double* tip_pq;        // see TransitionArgs
   const int8_t* tip_states;    // [n][P]
   const double* tip_partials;  // [n][P][4] or nullptr
   const double* weights;       // [P]

@@ -759,6 +759,9 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
   const long first = (long)blockIdx.x * kTransitionBlock;
   const long idx = first + threadIdx.x;
   const long total = (long)a.E * (a.N - 1) * a.K;
+  double Pm[16];
+  bool tip_edge = false;
+  int mi_keep = 0;
   if (idx < total) {
     const int k = idx % a.K;
     const int edge = (idx / a.K) % (a.N - 1);
@@ -776,9 +779,11 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
       for (int j = 0; j < 4; j++) {
         double sum = i == j ? 1.0 : 0.0;
         for (int x = 0; x < 4; x++) sum += m.V[i * 4 + x] * W[x * 4 + j];
-        // BEAGLE clamps negative probabilities to 0
-        stage[threadIdx.x * 17 + i * 4 + j] = sum > 0 ? sum : 0;
+        Pm[i * 4 + j] = sum > 0 ? sum : 0;  // BEAGLE clamps negative probabilities to 0
+        stage[threadIdx.x * 17 + i * 4 + j] = Pm[i * 4 + j];
       }
+    tip_edge = edge < a.n;
+    mi_keep = mi;
   }
   __syncthreads();
   const long left = total - first;
@@ -800,6 +805,32 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
       if (edge < a.n)
         a.tip_tables[(((size_t)e * a.n + edge) * a.K + k) * 20 + j] =
             j < 16 ? stage[m * 17 + (j & 3) * 4 + (j >> 2)] : 1.0;
+    }
+  }
+  if (a.tip_pq != nullptr) {
+    // Tip edges of the matrix-core gradient kernel: the edge derivative of a tip child
+    // is (q_parent o sibling) . (P Q) e_state, one product instead of two, so the kernel
+    // wants P Q in place of the (unused) transposed P.  Stored transposed so that the
+    // kernel's transposed-operand lane offsets pick it up in forward layout.
+    __syncthreads();
+    if (tip_edge) {
+      const DevModel& m = a.models[mi_keep];
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+          double pq = 0;
+          for (int x = 0; x < 4; x++) pq += Pm[i * 4 + x] * m.Q[x * 4 + j];
+          stage[threadIdx.x * 17 + j * 4 + i] = pq;
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < count; x += kTransitionBlock) {
+      const int m = x >> 4;
+      const long id = first + m;
+      const int k = id % a.K;
+      const int edge = (id / a.K) % (a.N - 1);
+      const int e = id / ((long)a.K * (a.N - 1));
+      if (edge < a.n)
+        a.tip_pq[(((size_t)e * a.n + edge) * a.K + k) * 16 + (x & 15)] = stage[m * 17 + (x & 15)];
     }
   }
 }
@@ -1569,6 +1600,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   const int cat = b % Kp, pgrp = b / Kp, ppr = 16 / Kp;
   const int catc = cat < K ? cat : K - 1;
   const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
+  const double* __restrict__ pq_e = a.tip_pq + (size_t)e * n * K * 16;
   const MacroEntry* __restrict__ macros = a.macros + (size_t)t * max_macros(n);
   const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
   // byte offsets (unsigned: scalar base + 32-bit lane offset addressing)
@@ -1679,13 +1711,16 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     const int nodes[6] = {u.c0, u.c1, u.g0, u.g1, u.g2, u.g3};
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      const char* base = reinterpret_cast<const char*>(mats_e + (unsigned)(nodes[j] * K * 16));
+      const unsigned moff = (unsigned)(nodes[j] * K * 16);
+      const char* base = reinterpret_cast<const char*>(mats_e + moff);
+      // a tip has no use for its transposed matrix: fetch (P Q) there instead
+      const char* tbase = nodes[j] < n ? reinterpret_cast<const char*>(pq_e + moff) : base;
       // opaque copies keep "base + lane offset" from being re-associated into a hoisted
       // 64-bit vector address: scalar base + 32-bit lane offset is one addressing mode
       unsigned fo = f_off, to = t_off;
       asm volatile("" : "+v"(fo), "+v"(to));
       mt.f[j] = *reinterpret_cast<const double*>(base + fo);
-      mt.tr[j] = *reinterpret_cast<const double*>(base + to);
+      mt.tr[j] = *reinterpret_cast<const double*>(tbase + to);
       mt.tw[j] = tipw[(nodes[j] < n ? nodes[j] : 0) * ppr];
     }
     return mt;
@@ -1826,26 +1861,32 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       L1 = o.x1;
     }
     const V A = mm(cm.f[0], L0), B = mm(cm.f[1], L1);
-    const V q0 = mm(cm.tr[0], mul(qv, B));
-    const V q1 = mm(cm.tr[1], mul(qv, A));
-    edge_sums(mul(q0, mm(AQ, L0)), mul(q1, mm(AQ, L1)), u.c0, u.c1);
-    if (u.kind0 == 1) {
-      store_slot(u.cs0, q0);
-    } else if (u.kind0 == 2) {
-      const V qa = mm(cm.tr[2], mul(q0, Bp0));
-      const V qb = mm(cm.tr[3], mul(q0, Ap0));
-      edge_sums(mul(qa, mm(AQ, La0)), mul(qb, mm(AQ, Lb0)), u.g0, u.g1);
-      if (u.g0 >= n) store_slot(u.gs0, qa);
-      if (u.g1 >= n) store_slot(u.gs1, qb);
+    // Edge of child c below a node with pre-order vector q and sibling product S:
+    //   internal child: q_c = P_c^T (q o S), numerator q_c o (Q L_c), q_c kept if stored
+    //   tip child:      numerator (q o S) o ((P_c Q) L_c)  -- `trm` is then (P_c Q)
+    auto edge = [&](double trm, const V& qs, const V& Lc, int node, int slot, bool keep, V& qc) {
+      if (node < n) return mul(qs, mm(trm, Lc));
+      qc = mm(trm, qs);
+      if (keep) store_slot(slot, qc);
+      return mul(qc, mm(AQ, Lc));
+    };
+    V q0, q1;
+    {
+      const V n0 = edge(cm.tr[0], mul(qv, B), L0, u.c0, u.cs0, u.kind0 == 1, q0);
+      const V n1 = edge(cm.tr[1], mul(qv, A), L1, u.c1, u.cs1, u.kind1 == 1, q1);
+      edge_sums(n0, n1, u.c0, u.c1);
     }
-    if (u.kind1 == 1) {
-      store_slot(u.cs1, q1);
-    } else if (u.kind1 == 2) {
-      const V qa = mm(cm.tr[4], mul(q1, Bp1));
-      const V qb = mm(cm.tr[5], mul(q1, Ap1));
-      edge_sums(mul(qa, mm(AQ, La1)), mul(qb, mm(AQ, Lb1)), u.g2, u.g3);
-      if (u.g2 >= n) store_slot(u.gs2, qa);
-      if (u.g3 >= n) store_slot(u.gs3, qb);
+    if (u.kind0 == 2) {
+      V qa, qb;
+      const V na = edge(cm.tr[2], mul(q0, Bp0), La0, u.g0, u.gs0, true, qa);
+      const V nb = edge(cm.tr[3], mul(q0, Ap0), Lb0, u.g1, u.gs1, true, qb);
+      edge_sums(na, nb, u.g0, u.g1);
+    }
+    if (u.kind1 == 2) {
+      V qa, qb;
+      const V na = edge(cm.tr[4], mul(q1, Bp1), La1, u.g2, u.gs2, true, qa);
+      const V nb = edge(cm.tr[5], mul(q1, Ap1), Lb1, u.g3, u.gs3, true, qb);
+      edge_sums(na, nb, u.g2, u.g3);
     }
   };
   {

@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
 //     butterfly and stored straight to the per-tile partials (each edge is visited once)
 // LDS per wave: max_stored(n) * R * 512 B of vectors (+ tip state masks).
 // ------------------------------------------------------------------------
-template <int R>
+template <int R, int DBG = 0>
 __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
   extern __shared__ double glds[];
@@ -1652,18 +1652,31 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   }
   __syncthreads();
   if (M <= 0) return;
+  if (DBG & 64) {
+    if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = pw[0] + pi_l + cw_l + rate_l + drate_l + AQ;
+    return;
+  }
 
   struct V {
     double v[R];
   };
   auto load_slot = [&](int slot) {
     V x;
+    if (DBG & 8) {
+#pragma unroll
+      for (int r = 0; r < R; r++) x.v[r] = pi_l + slot;
+      return x;
+    }
     const double* c = plv + (size_t)slot * R * kTile + lane;
 #pragma unroll
     for (int r = 0; r < R; r++) x.v[r] = c[r * kTile];
     return x;
   };
   auto store_slot = [&](int slot, const V& x) {
+    if (DBG & 8) {
+      asm volatile("" ::"v"(x.v[0]), "v"(x.v[R - 1]));
+      return;
+    }
     double* c = plv + (size_t)slot * R * kTile + lane;
 #pragma unroll
     for (int r = 0; r < R; r++) c[r * kTile] = x.v[r];
@@ -1686,13 +1699,15 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   auto mm = [&](double A, const V& x) {  // block-wise matrix product, R instructions
     V y;
 #pragma unroll
-    for (int r = 0; r < R; r++) y.v[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(A, x.v[r], 0.0, 0, 0, 0);
+    for (int r = 0; r < R; r++)
+      y.v[r] = (DBG & 1) ? x.v[r] + A : __builtin_amdgcn_mfma_f64_4x4x4f64(A, x.v[r], 0.0, 0, 0, 0);
     return y;
   };
   auto mul = [&](const V& x, const V& y) {
     V z;
 #pragma unroll
-    for (int r = 0; r < R; r++) z.v[r] = x.v[r] * y.v[r];
+    for (int r = 0; r < R; r++) z.v[r] = (DBG & 4) ? x.v[r] : x.v[r] * y.v[r];
+    if (DBG & 4) asm volatile("" ::"v"(y.v[0]));
     return z;
   };
   double qroot[R];  // root pre-order vector: pi * category weight * w_p / site likelihood
@@ -1719,9 +1734,16 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       // 64-bit vector address: scalar base + 32-bit lane offset is one addressing mode
       unsigned fo = f_off, to = t_off;
       asm volatile("" : "+v"(fo), "+v"(to));
-      mt.f[j] = *reinterpret_cast<const double*>(base + fo);
-      mt.tr[j] = *reinterpret_cast<const double*>(tbase + to);
-      mt.tw[j] = tipw[(nodes[j] < n ? nodes[j] : 0) * ppr];
+      if (DBG & 16) {
+        mt.f[j] = pi_l + nodes[j];
+        mt.tr[j] = pi_l - nodes[j];
+        (void)base;
+        (void)tbase;
+      } else {
+        mt.f[j] = *reinterpret_cast<const double*>(base + fo);
+        mt.tr[j] = *reinterpret_cast<const double*>(tbase + to);
+      }
+      mt.tw[j] = (DBG & 32) ? 0x01020408u : tipw[(nodes[j] < n ? nodes[j] : 0) * ppr];
     }
     return mt;
   };
@@ -1834,7 +1856,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       sa += na.v[r];
       sb += nb.v[r];
     }
-    const double red = reduce4_transposed(rate_l * sa, rate_l * sb, drate_l * sa, drate_l * sb);
+    const double red = (DBG & 2) ? rate_l * sa + drate_l * sb
+                                 : reduce4_transposed(rate_l * sa, rate_l * sb, drate_l * sa, drate_l * sb);
     // lane 15: branch a, lane 31: site a, lane 47: branch b, lane 63: site b
     if ((lane & 15) == 15) {
       const int which = lane >> 4;
@@ -2253,8 +2276,22 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = lds;
   }
-  hipLaunchKernelGGL((gradient_mfma_kernel<kLlR>), dim3(loglik_mfma_tiles(a.P, a.K), count),
-                     dim3(kTile), lds, s, a);
+  static const int dbg = getenv("MI_PHYLO_DEBUG") ? atoi(getenv("MI_PHYLO_DEBUG")) : 0;
+  const dim3 grid(loglik_mfma_tiles(a.P, a.K), count);
+  switch (dbg) {
+    case 1: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 1>), grid, dim3(kTile), lds, s, a); return;
+    case 2: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 2>), grid, dim3(kTile), lds, s, a); return;
+    case 4: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 4>), grid, dim3(kTile), lds, s, a); return;
+    case 8: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 8>), grid, dim3(kTile), lds, s, a); return;
+    case 7: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 7>), grid, dim3(kTile), lds, s, a); return;
+    case 15: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 15>), grid, dim3(kTile), lds, s, a); return;
+    case 31: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 31>), grid, dim3(kTile), lds, s, a); return;
+    case 63: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 63>), grid, dim3(kTile), lds, s, a); return;
+    case 16: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 16>), grid, dim3(kTile), lds, s, a); return;
+    case 64: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 64>), grid, dim3(kTile), lds, s, a); return;
+    default: break;
+  }
+  hipLaunchKernelGGL((gradient_mfma_kernel<kLlR>), grid, dim3(kTile), lds, s, a);
 }
 bool reduce_tiles_fits(int N) { return sizeof(double) * 8 * (size_t)N <= 64 * 1024; }
 void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s) {

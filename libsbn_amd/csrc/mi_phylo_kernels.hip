@@ -1627,26 +1627,19 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   uint8_t* tips = reinterpret_cast<uint8_t*>(gacc + 2 * N);
   if (lane < 2) gacc[lane * N + N - 1] = 0.0;  // the root has no edge
   {
-    const int total = n * TP;
-    for (int base = 0; base < total; base += 8 * kTile) {
-      int8_t v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int idx = base + u * kTile + lane;
-        const int taxon = idx / TP, q = idx - taxon * TP;
-        const int r = q / ppr, c = q - r * ppr;  // coalesced reads, transposed writes
-        const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
-        (void)r;
-        (void)c;
-        v[u] = idx < total ? a.tip_states[(size_t)taxon * a.P + pp] : (int8_t)0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int idx = base + u * kTile + lane;
-        const int taxon = idx / TP, q = idx - taxon * TP;
-        const int r = q / ppr, c = q - r * ppr;
-        if (idx < total)
-          tips[(taxon * ppr + c) * 4 + r] = v[u] > 3 ? (uint8_t)0xF : (uint8_t)(1u << v[u]);
+    // tip staging without divisions: the 64 lanes are (taxon group, pattern column) with
+    // the column count rounded up to a power of two (TP = 4R, 8R or 16R, R <= 4)
+    const int tp_shift = TP <= 16 ? 4 : (TP <= 32 ? 5 : 6);
+    const int q = lane & ((1 << tp_shift) - 1), group = 64 >> tp_shift;
+    const int ppr_shift = Kp == 4 ? 2 : (Kp == 2 ? 3 : 4);
+    const int r = q >> ppr_shift, c = q & (ppr - 1);  // pattern tile_start + q = r * ppr + c
+    if (q < TP) {
+      const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
+      const int8_t* src = a.tip_states + pp;
+#pragma unroll 4
+      for (int taxon = lane >> tp_shift; taxon < n; taxon += group) {
+        const int v = src[(size_t)taxon * a.P];
+        tips[(taxon * ppr + c) * 4 + r] = v > 3 ? (uint8_t)0xF : (uint8_t)(1u << v);
       }
     }
   }

@@ -1760,6 +1760,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     return u;
   };
 
+  long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // DBG 256: cycle counts per phase
+  const long long t_start = (DBG & 256) ? clock64() : 0;
   // ================= post-order over the stored nodes (+ root: site likelihood) ====
   // Operands of one macro: issued (LDS reads) before the next macro's entry is made
   // uniform and its matrices are requested, consumed afterwards.
@@ -1826,11 +1828,23 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     MacroMats ma = fetch_mats(ua), mb;
     raw = macros[M > 1 ? 1 : 0];
     for (int m = 0; m < M; m += 2) {
+      long long tA = 0, tB = 0, tC = 0, tD = 0;
+      if (DBG & 256) tA = clock64();
       const Ops oa = load_ops(ua, ma, false);
+      if (DBG & 256) tB = clock64();
       ub = uniformize(raw);
+      if (DBG & 256) tC = clock64();
       mb = fetch_mats(ub);
       raw = macros[m + 2 < M ? m + 2 : M - 1];
+      if (DBG & 256) tD = clock64();
       post_step(ua, ma, oa);
+      if (DBG & 256) {
+        const long long tE = clock64();
+        tacc[0] += tB - tA;
+        tacc[1] += tC - tB;
+        tacc[2] += tD - tC;
+        tacc[3] += tE - tD;
+      }
       if (m + 1 < M) {
         const Ops ob = load_ops(ub, mb, false);
         ua = uniformize(raw);
@@ -1840,6 +1854,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       }
     }
   }
+  if (DBG & 128) return;
+  const long long t_mid = (DBG & 256) ? clock64() : 0;
   // ================= pre-order + edge derivatives =================
   auto edge_sums = [&](const V& na, const V& nb, int edge_a, int edge_b) {
     // the pattern and category weights ride along in q (linear in the root vector)
@@ -1911,11 +1927,23 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     MacroMats ma = fetch_mats(ua), mb;
     raw = macros[M > 1 ? M - 2 : 0];
     for (int m = M - 1; m >= 0; m -= 2) {
+      long long tA = 0, tB = 0, tC = 0, tD = 0;
+      if (DBG & 256) tA = clock64();
       const Ops oa = load_ops(ua, ma, true);
+      if (DBG & 256) tB = clock64();
       ub = uniformize(raw);
+      if (DBG & 256) tC = clock64();
       mb = fetch_mats(ub);
       raw = macros[m >= 2 ? m - 2 : 0];
+      if (DBG & 256) tD = clock64();
       pre_step(ua, ma, oa);
+      if (DBG & 256) {
+        const long long tE = clock64();
+        tacc[4] += tB - tA;
+        tacc[5] += tC - tB;
+        tacc[6] += tD - tC;
+        tacc[7] += tE - tD;
+      }
       if (m >= 1) {
         const Ops ob = load_ops(ub, mb, true);
         ua = uniformize(raw);
@@ -1926,6 +1954,15 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     }
   }
   __syncthreads();
+  if (DBG & 256) {
+    // profiling build: the first entries of the "gradient" are cycle counts
+    const long long t_end = clock64();
+    tacc[8] = t_mid - t_start;
+    tacc[9] = t_end - t_mid;
+    if (lane == 0)
+      for (int i = 0; i < 10; i++) gacc[i] = (double)tacc[i];
+    __syncthreads();
+  }
   double* gout = a.g_part + ((size_t)gi * a.g_tiles + te.tile) * 2 * N;
   for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];
 }
@@ -2282,6 +2319,8 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, hipStream_t s) {
     case 63: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 63>), grid, dim3(kTile), lds, s, a); return;
     case 16: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 16>), grid, dim3(kTile), lds, s, a); return;
     case 64: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 64>), grid, dim3(kTile), lds, s, a); return;
+    case 128: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 128>), grid, dim3(kTile), lds, s, a); return;
+    case 256: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 256>), grid, dim3(kTile), lds, s, a); return;
     default: break;
   }
   hipLaunchKernelGGL((gradient_mfma_kernel<kLlR>), grid, dim3(kTile), lds, s, a);

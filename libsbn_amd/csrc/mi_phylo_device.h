@@ -36,20 +36,34 @@ struct SchedEntry {
   int32_t slots;  // dst | slot(child0) << 8 | slot(child1) << 16
 };
 
-// One entry of the on-chip gradient kernel's schedule: a node whose pre-order
+// One entry of the on-chip gradient kernels' schedule: a node whose pre-order
 // vector is available (the root, or a "stored" node with an LDS slot) together
 // with its two children and, for children whose vectors are NOT stored, their
 // children.  kind: 0 = tip, 1 = stored internal node (has a slot), 2 = unstored
 // internal node (both of its children are tips or stored nodes).
+// Two 32-byte halves: the first is what the matrix-core kernel needs a macro AHEAD
+// (node ids for the matrix / tip fetches, `shape` for its scalar control flow), the
+// second (LDS slots) only during the macro itself.
 struct MacroEntry {
+  int32_t shape;     // kind[0] | kind[1] << 2 | root << 4 | (tip flags of child0, child1,
+                     // grand0..3) << 8   (unused grand entries are node 0, flagged as tips)
+  int32_t child[2];  // ids
+  int32_t grand[4];  // children of child 0 (a0, b0) and of child 1 (a1, b1) when unstored
   int32_t node;      // id of the node whose q is known
   int32_t qslot;     // its LDS slot, -1 for the root (q = frequencies)
-  int32_t child[2];  // ids
-  int32_t kind[2];
   int32_t cslot[2];  // slot of a stored child (else 0)
-  int32_t grand[4];  // children of child 0 (a0, b0) and of child 1 (a1, b1) when unstored
-  int32_t gslot[4];  // their slots (0 for tips)
+  int32_t gslot[4];  // slots of the grandchildren (0 for tips)
+  int32_t pad;
 };
+constexpr int kMacroPositions = 6;  // edges a macro can own: child0, child1, grand0..3
+
+__host__ __device__ inline int macro_shape(int kind0, int kind1, bool root, const int32_t* child,
+                                            const int32_t* grand, int n) {
+  int s = kind0 | (kind1 << 2) | (root ? 16 : 0);
+  for (int j = 0; j < 2; j++) s |= (child[j] < n ? 1 : 0) << (8 + j);
+  for (int j = 0; j < 4; j++) s |= (grand[j] < n ? 1 : 0) << (10 + j);
+  return s;
+}
 
 inline __host__ __device__ int max_macros(int n) { return (n - 2) / 2 + 1; }
 inline __host__ __device__ int max_stored(int n) { return (n - 2) / 2 > 1 ? (n - 2) / 2 : 1; }

@@ -89,7 +89,7 @@ struct mi_engine {
   // static device data
   Buffer tip_states, tip_partials, weights;
   // per-call workspace
-  Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tip_pq, ll_part, plv, g_part, site_lik, fin_scratch,
+  Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, ll_part, plv, g_part, site_lik, fin_scratch,
       ll_sum, g_sum, status;
   bool allow_onchip_gradient = true;
   bool prefer_mfma_gradient = true;  // matrix-core gradient kernel when K <= 4 and it fits
@@ -147,7 +147,7 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
   if (e->models.ensure(sizeof(DevModel) * (size_t)c.M)) return 1;
   if (e->mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
   if (e->tip_tables.ensure(sizeof(double) * (size_t)c.E * n * e->K * 20)) return 1;
-  if (gradient && e->tip_pq.ensure(sizeof(double) * (size_t)c.E * n * e->K * 16)) return 1;
+  if (gradient && e->tr_mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
   if (e->ll_part.ensure(sizeof(double) * (size_t)c.E * e->ll_stride)) return 1;
   if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
   if (e->status.ensure(sizeof(int32_t) * 2)) return 1;
@@ -159,7 +159,8 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
     const size_t per = plv_bytes_per_eval(e);
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / per));
     if (need_hbm_path && e->plv.ensure(per * chunk)) return 1;
-    if (e->g_part.ensure(sizeof(double) * (size_t)c.Eg * e->ll_stride * 2 * N)) return 1;
+    const size_t g_width = std::max<size_t>(2 * (size_t)N, (size_t)gradient_mfma_width(n));
+    if (e->g_part.ensure(sizeof(double) * (size_t)c.Eg * e->ll_stride * g_width)) return 1;
     if (e->site_lik.ensure(sizeof(double) * (size_t)c.Eg * e->tiles * kTile)) return 1;
   }
   return 0;
@@ -192,6 +193,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool onchip = d.gradient && !d.rescaling && e->allow_onchip_gradient &&
                       e->spec.use_tip_states && gradient_onchip_fits(e->n);
   const bool mfma = onchip && e->gradient_path != 1 && gradient_mfma_fits(e->n, e->K) &&
+                    reduce_tiles_fits(e->N) &&
                     (e->gradient_path == 3 || e->prefer_mfma_gradient);
   const int g_tiles = mfma ? loglik_mfma_tiles(e->P, e->K) : e->tiles;
   if (reserve(e, d.T, d.gradient, !onchip)) return 1;
@@ -246,7 +248,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // the per-state tip tables feed the VALU walk kernels only
   const bool need_tip_tables = !(d.gradient && mfma && !c.gtr);
   tr.tip_tables = need_tip_tables ? e->tip_tables.as<double>() : nullptr;
-  tr.tip_pq = mfma ? e->tip_pq.as<double>() : nullptr;
+  tr.tr_mats = mfma ? e->tr_mats.as<double>() : nullptr;
   tr.n = n;
   launch_transition(tr, s);
 
@@ -265,7 +267,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.macro_count = e->macro_count.as<int32_t>();
   la.mats = e->mats.as<double>();
   la.tip_tables = e->tip_tables.as<double>();
-  la.tip_pq = e->tip_pq.as<double>();
+  la.tr_mats = e->tr_mats.as<double>();
   la.tip_states = e->tip_states.as<int8_t>();
   la.tip_partials = e->spec.use_tip_states ? nullptr : e->tip_partials.as<double>();
   la.weights = e->weights.as<double>();
@@ -348,6 +350,11 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     ra.g_part = e->g_part.as<double>();
     ra.ll_sum = e->ll_sum.as<double>();
     ra.g_sum = e->g_sum.as<double>();
+    ra.g_width = (d.gradient && mfma) ? gradient_mfma_width(n) : 0;
+    ra.n = n;
+    ra.T = T;
+    ra.macros = e->macros.as<MacroEntry>();
+    ra.macro_count = e->macro_count.as<int32_t>();
     launch_reduce_tiles(ra, s);
     fa.ll_tiles = 1;
     fa.g_tiles = 1;
@@ -537,7 +544,7 @@ void mi_engine_destroy(mi_engine* e) {
   }
   for (Buffer* b :
        {&e->tip_states, &e->tip_partials, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
-        &e->macro_count, &e->tip_tables, &e->tip_pq, &e->bl_eff,
+        &e->macro_count, &e->tip_tables, &e->tr_mats, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->fin_scratch,
         &e->ll_sum, &e->g_sum, &e->status,
         &e->in_parent, &e->in_bl, &e->in_params, &e->in_rates, &e->in_rate_counts,

@@ -62,7 +62,7 @@ struct TransitionArgs {
   const double* bl_eff;  // [T][N]
   double* mats;          // [E][N-1][K][16]
   double* tip_tables;    // [E][n][K][5][4]: per tip edge and state (4 = gap), the column of P; may be nullptr
-  double* tip_pq;        // [E][n][K][4][4]: per tip edge, (P Q) transposed (matrix-core gradient); may be nullptr
+  double* tr_mats;       // [E][N-1][K][4][4]: matrix of the matrix-core pre-order step (P, or (P Q)^T for tips); may be nullptr
   int n;
 };
 
@@ -82,7 +82,7 @@ struct LikArgs {
   const int32_t* macro_count;  // [T]
   const double* mats;
   const double* tip_tables;    // see TransitionArgs
-  const double* tip_pq;        // see TransitionArgs
+  const double* tr_mats;       // see TransitionArgs
   const int8_t* tip_states;    // [n][P]
   const double* tip_partials;  // [n][P][4] or nullptr
   const double* weights;       // [P]
@@ -136,6 +136,7 @@ void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s);
 // Same walk on the FP64 matrix cores, all categories per instruction (K <= 4); also
 // writes the log-likelihood partial sums, so no separate logL pass is needed.
 bool gradient_mfma_fits(int n, int K);
+int gradient_mfma_width(int n);  // doubles per (gradient evaluation, tile) of its partial sums
 void launch_gradient_mfma(const LikArgs& a, int count, hipStream_t s);
 // Sum of the per-tile partials: ll_sum[e] = sum_i ll_part[e][i] for e < E,
 // g_sum[gi][2N] = sum_i g_part[gi][i][2N] for gi < Eg (fixed order: deterministic).
@@ -145,6 +146,12 @@ struct ReduceArgs {
   const double* g_part;
   double* ll_sum;
   double* g_sum;
+  // positional partial sums (matrix-core gradient kernel): g_part is
+  // [Eg][g_tiles][g_width] indexed by (macro, position, {branch, site}); the schedule maps
+  // positions to node ids.  g_width == 0: g_part is [Eg][g_tiles][2N] indexed by node id.
+  int g_width, n, T;
+  const MacroEntry* macros;
+  const int32_t* macro_count;
 };
 bool reduce_tiles_fits(int N);
 void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s);

@@ -280,12 +280,14 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
         for (int v = n; v < N; v++) {
           if (cls[v] != 1) continue;
           MacroEntry me;
+          int kind[2];
           me.node = v;
+          me.pad = 0;
           me.qslot = sslot[v];
           for (int j = 0; j < 2; j++) {
             const int ch = j ? c1[v] : c0[v];
             me.child[j] = ch;
-            me.kind[j] = ch < n ? 0 : cls[ch];
+            kind[j] = ch < n ? 0 : cls[ch];
             me.cslot[j] = (ch >= n && cls[ch] == 1) ? sslot[ch] : 0;
             const bool expand = ch >= n && cls[ch] == 2;
             const int ga = expand ? c0[ch] : 0, gb = expand ? c1[ch] : 0;
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
             me.gslot[2 * j] = ga >= n ? sslot[ga] : 0;
             me.gslot[2 * j + 1] = gb >= n ? sslot[gb] : 0;
           }
+          me.shape = macro_shape(kind[0], kind[1], v == N - 1, me.child, me.grand, n);
           mac[m++] = me;
         }
         a.macro_count[t] = m;
@@ -529,8 +532,6 @@ __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
       me.qslot = m_qslot;
       me.child[0] = m_c0;
       me.child[1] = m_c1;
-      me.kind[0] = m_k0;
-      me.kind[1] = m_k1;
       me.cslot[0] = m_cs0;
       me.cslot[1] = m_cs1;
       me.grand[0] = m_g0;
@@ -541,6 +542,8 @@ __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
       me.gslot[1] = m_gs1;
       me.gslot[2] = m_gs2;
       me.gslot[3] = m_gs3;
+      me.pad = 0;
+      me.shape = macro_shape(m_k0, m_k1, m_node == N - 1, me.child, me.grand, n);
       mac[lane] = me;
     }
     if (lane == 0) a.macro_count[t] = macro_total;
@@ -807,11 +810,11 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
             j < 16 ? stage[m * 17 + (j & 3) * 4 + (j >> 2)] : 1.0;
     }
   }
-  if (a.tip_pq != nullptr) {
-    // Tip edges of the matrix-core gradient kernel: the edge derivative of a tip child
-    // is (q_parent o sibling) . (P Q) e_state, one product instead of two, so the kernel
-    // wants P Q in place of the (unused) transposed P.  Stored transposed so that the
-    // kernel's transposed-operand lane offsets pick it up in forward layout.
+  if (a.tr_mats != nullptr) {
+    // Matrix of the matrix-core kernel's pre-order step, per edge: P again for an
+    // internal edge (the kernel reads it transposed), and for a tip edge -- whose
+    // derivative is (q_parent o sibling) . (P Q) e_state, one product instead of two --
+    // (P Q) stored transposed so that the same transposed read yields it in forward layout.
     __syncthreads();
     if (tip_edge) {
       const DevModel& m = a.models[mi_keep];
@@ -823,15 +826,9 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
         }
     }
     __syncthreads();
-    for (int x = threadIdx.x; x < count; x += kTransitionBlock) {
-      const int m = x >> 4;
-      const long id = first + m;
-      const int k = id % a.K;
-      const int edge = (id / a.K) % (a.N - 1);
-      const int e = id / ((long)a.K * (a.N - 1));
-      if (edge < a.n)
-        a.tip_pq[(((size_t)e * a.n + edge) * a.K + k) * 16 + (x & 15)] = stage[m * 17 + (x & 15)];
-    }
+    double* out2 = a.tr_mats + first * 16;
+    for (int x = threadIdx.x; x < count; x += kTransitionBlock)
+      out2[x] = stage[(x >> 4) * 17 + (x & 15)];
   }
 }
 
@@ -1486,7 +1483,7 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
         D4 L[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-          if (cur.kind[j] == 2) {
+          if (((cur.shape >> (2 * j)) & 3) == 2) {
             const D4 La = operand(cur.grand[2 * j], cur.gslot[2 * j], ts.g[2 * j]);
             const D4 Lb = operand(cur.grand[2 * j + 1], cur.gslot[2 * j + 1], ts.g[2 * j + 1]);
             L[j] = mul4(matvec(mat(cur.grand[2 * j], k), La),
@@ -1520,7 +1517,7 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
         D4 L[2], La[2], Lb[2], Ap[2], Bp[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-          if (cur.kind[j] == 2) {
+          if (((cur.shape >> (2 * j)) & 3) == 2) {
             La[j] = operand(cur.grand[2 * j], cur.gslot[2 * j], ts.g[2 * j]);
             Lb[j] = operand(cur.grand[2 * j + 1], cur.gslot[2 * j + 1], ts.g[2 * j + 1]);
             Ap[j] = matvec(mat(cur.grand[2 * j], k), La[j]);
@@ -1547,9 +1544,9 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-          if (cur.kind[j] == 1) {
+          if (((cur.shape >> (2 * j)) & 3) == 1) {
             store_slot(cur.cslot[j], q[j]);
-          } else if (cur.kind[j] == 2) {
+          } else if (((cur.shape >> (2 * j)) & 3) == 2) {
             const int ga = cur.grand[2 * j], gb = cur.grand[2 * j + 1];
             const D4 qa = matTvec(mat(ga, k), mul4(q[j], Bp[j]));
             const D4 qb = matTvec(mat(gb, k), mul4(q[j], Ap[j]));
@@ -1577,12 +1574,18 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
 //   * all rate categories sit in the four blocks of one instruction: no category
 //     loop, and the per-pattern site likelihood (the derivative's denominator) is
 //     computed by this kernel itself at the root -- no separate log-likelihood pass
-//   * a node's matrices are ONE register (forward) + ONE register (transposed),
-//     fetched with a single 8-byte load per lane a whole macro ahead
+//   * a node's matrices are ONE register (forward) + ONE register (transposed, or
+//     (P Q) for a tip), fetched with a single 8-byte load per lane a whole macro ahead
 //   * per edge: n = q (.) (Q L) lane-wise, weighted by w_p cw_k r_k / site_p and
 //     summed over the whole wave (states, categories, patterns) by the transposed
-//     butterfly and stored straight to the per-tile partials (each edge is visited once)
-// LDS per wave: max_stored(n) * R * 512 B of vectors (+ tip state masks).
+//     butterfly; the four sums of an edge pair land in LDS at the pair's POSITION in
+//     the schedule (macro index, child/grandchild), reduce_tiles_kernel maps positions
+//     to node ids
+//   * per-macro bookkeeping costs as much as the arithmetic, so it is
+//     kept to a minimum: the schedule entry stays in vector registers (all lanes hold
+//     the same values; addresses are one multiply-add per use), only its `shape` word
+//     is made scalar for the control flow
+// LDS per wave: max_stored(n) * R * 512 B of vectors (+ edge sums, tip state masks).
 // ------------------------------------------------------------------------
 template <int R, int DBG = 0>
 __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
@@ -1599,13 +1602,18 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   const int K = a.K, n = a.n, N = a.N, Kp = a.kp;
   const int cat = b % Kp, pgrp = b / Kp, ppr = 16 / Kp;
   const int catc = cat < K ? cat : K - 1;
-  const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
-  const double* __restrict__ pq_e = a.tip_pq + (size_t)e * n * K * 16;
+  // forward matrices, and per edge the matrix of the pre-order step: P again (read
+  // transposed) for an internal edge, (P Q) transposed for a tip edge
+  const char* __restrict__ mats_e =
+      reinterpret_cast<const char*>(a.mats + (size_t)e * (N - 1) * K * 16);
+  const char* __restrict__ trm_e =
+      reinterpret_cast<const char*>(a.tr_mats + (size_t)e * (N - 1) * K * 16);
   const MacroEntry* __restrict__ macros = a.macros + (size_t)t * max_macros(n);
   const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
-  // byte offsets (unsigned: scalar base + 32-bit lane offset addressing)
+  // byte offsets inside one node's K matrices
   const unsigned f_off = 8u * (catc * 16 + lo * 4 + hi);  // forward:    A[i=lo][k=hi] = P[lo][hi]
   const unsigned t_off = 8u * (catc * 16 + hi * 4 + lo);  // transposed: A[i=lo][k=hi] = P[hi][lo]
+  const unsigned node_bytes = (unsigned)K * 128u;
   const int TP = ppr * R, tile_start = te.tile * TP;
   const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
   int pat[R], patc[R];
@@ -1620,12 +1628,15 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   const double cw_l = cat < K ? model->cat_weight[cat] : 0.0;
   const double rate_l = model->cat_rate[catc], drate_l = model->cat_drate[catc];
   const double AQ = model->Q[lo * 4 + hi];  // A operand for Q L (same in every block)
-  // LDS: vectors [slot][r][lane] | edge sums [2][N] | tip state masks [taxon][column][r]
-  // (one byte each: bit s set when the tip is compatible with state s)
-  double* plv = glds;
-  double* gacc = glds + (size_t)max_stored(n) * R * kTile;
-  uint8_t* tips = reinterpret_cast<uint8_t*>(gacc + 2 * N);
-  if (lane < 2) gacc[lane * N + N - 1] = 0.0;  // the root has no edge
+  // LDS: tip state masks [taxon][column][r] (one byte each: bit s set when the tip is
+  // compatible with state s) | edge sums [macro][position][branch, site] | vectors
+  // [slot][r][lane].  The masks come first so that the (ignored) mask fetch of an
+  // internal node id lands in valid memory without clamping: N * 4 * ppr bytes from
+  // the start is always inside the allocation.
+  uint8_t* tips = reinterpret_cast<uint8_t*>(glds);
+  const int gwidth = max_macros(n) * kMacroPositions * 2;
+  double* gacc = glds + ((n * ppr * 4 + 7) >> 3);
+  double* plv = gacc + gwidth;
   {
     // tip staging without divisions: the 64 lanes are (taxon group, pattern column) with
     // the column count rounded up to a power of two (TP = 4R, 8R or 16R, R <= 4)
@@ -1653,6 +1664,12 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   struct V {
     double v[R];
   };
+  // slots arrive as vector registers (the same value in every lane)
+  const unsigned lane8 = 8u * lane;
+  auto slot_ptr = [&](int slot) {
+    return reinterpret_cast<double*>(reinterpret_cast<char*>(plv) +
+                                     (__umul24((unsigned)slot, (unsigned)(R * kTile * 8)) + lane8));
+  };
   auto load_slot = [&](int slot) {
     V x;
     if (DBG & 8) {
@@ -1660,7 +1677,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       for (int r = 0; r < R; r++) x.v[r] = pi_l + slot;
       return x;
     }
-    const double* c = plv + (size_t)slot * R * kTile + lane;
+    const double* c = slot_ptr(slot);
 #pragma unroll
     for (int r = 0; r < R; r++) x.v[r] = c[r * kTile];
     return x;
@@ -1670,24 +1687,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       asm volatile("" ::"v"(x.v[0]), "v"(x.v[R - 1]));
       return;
     }
-    double* c = plv + (size_t)slot * R * kTile + lane;
+    double* c = slot_ptr(slot);
 #pragma unroll
     for (int r = 0; r < R; r++) c[r * kTile] = x.v[r];
-  };
-  // partial vector of a tip (0/1 from its state mask: one LDS word holds the R masks
-  // of this lane's column) or of a stored node
-  // (the word is fetched a macro ahead together with the matrices: tips never change)
-  const uint32_t* tipw = reinterpret_cast<const uint32_t*>(tips) + col;
-  auto operand = [&](int node, int slot, uint32_t w) {
-    V x;
-    if (node < n) {
-#pragma unroll
-      for (int r = 0; r < R; r++)
-        x.v[r] = (double)__builtin_amdgcn_ubfe(w, (uint32_t)(8 * r + hi), 1u);
-    } else {
-      x = load_slot(slot);
-    }
-    return x;
   };
   auto mm = [&](double A, const V& x) {  // block-wise matrix product, R instructions
     V y;
@@ -1699,108 +1701,112 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   auto mul = [&](const V& x, const V& y) {
     V z;
 #pragma unroll
-    for (int r = 0; r < R; r++) z.v[r] = (DBG & 4) ? x.v[r] : x.v[r] * y.v[r];
-    if (DBG & 4) asm volatile("" ::"v"(y.v[0]));
+    for (int r = 0; r < R; r++) z.v[r] = x.v[r] * y.v[r];
     return z;
   };
-  double qroot[R];  // root pre-order vector: pi * category weight * w_p / site likelihood
-  // A macro entry made wave-uniform once (SGPRs are plentiful here: the matrices
-  // live in VGPRs), so every index derived from it is scalar arithmetic.
-  struct UMacro {
-    int qslot, c0, c1, kind0, kind1, cs0, cs1, g0, g1, g2, g3, gs0, gs1, gs2, gs3;
+
+  // ---- schedule entries: two 32-byte halves, loaded by every lane from one address ----
+  struct Ids {  // first half: needed a macro ahead
+    int shape, c0, c1, g0, g1, g2, g3;
   };
-  // matrix registers of one macro: children c0,c1 and grandchildren a0,b0,a1,b1
+  struct Slots {  // second half: needed during the macro
+    int q, cs0, cs1, gs0, gs1, gs2, gs3;
+  };
+  auto load_ids = [&](int m) {
+    const int4* p = reinterpret_cast<const int4*>(macros + m);
+    const int4 x = p[0], y = p[1];
+    return Ids{x.x, x.y, x.z, x.w, y.x, y.y, y.z};
+  };
+  auto load_slots = [&](int m) {
+    const int4* p = reinterpret_cast<const int4*>(macros + m) + 2;
+    const int4 x = p[0], y = p[1];
+    return Slots{x.x, x.y, x.z, x.w, y.x, y.y, y.z};
+  };
+  // shape word, scalar: bits 0-1 kind0, 2-3 kind1, 4 root, 8.. tip flags
+  auto kind0 = [](int s) { return s & 3; };
+  auto kind1 = [](int s) { return (s >> 2) & 3; };
+  auto is_root = [](int s) { return (s & 16) != 0; };
+  auto is_tip = [](int s, int j) { return ((s >> (8 + j)) & 1) != 0; };
+
+  // matrix registers of one macro (children c0,c1 and grandchildren a0,b0,a1,b1) and the
+  // tip state masks of this lane's column, fetched a macro ahead
   struct MacroMats {
     double f[6], tr[6];
-    uint32_t tw[6];  // tip state masks of this lane's column (when the node is a tip)
+    uint32_t tw[6];
   };
-  auto fetch_mats = [&](const UMacro& u) {
+  const unsigned tt_delta = t_off - f_off;
+  const unsigned col4 = 4u * col;
+  auto fetch_mats = [&](const Ids& id) {
     MacroMats mt;
-    const int nodes[6] = {u.c0, u.c1, u.g0, u.g1, u.g2, u.g3};
+    const int nodes[6] = {id.c0, id.c1, id.g0, id.g1, id.g2, id.g3};
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      const unsigned moff = (unsigned)(nodes[j] * K * 16);
-      const char* base = reinterpret_cast<const char*>(mats_e + moff);
-      // a tip has no use for its transposed matrix: fetch (P Q) there instead
-      const char* tbase = nodes[j] < n ? reinterpret_cast<const char*>(pq_e + moff) : base;
-      // opaque copies keep "base + lane offset" from being re-associated into a hoisted
-      // 64-bit vector address: scalar base + 32-bit lane offset is one addressing mode
-      unsigned fo = f_off, to = t_off;
-      asm volatile("" : "+v"(fo), "+v"(to));
+      // one v_mad per node; kept opaque so that "scalar base + 32-bit lane offset" stays
+      // one addressing mode instead of being folded into 64-bit vector arithmetic
+      unsigned vf = __umul24((unsigned)nodes[j], node_bytes) + f_off;
+      unsigned vt = vf + tt_delta;
+      asm volatile("" : "+v"(vf), "+v"(vt));
       if (DBG & 16) {
         mt.f[j] = pi_l + nodes[j];
         mt.tr[j] = pi_l - nodes[j];
-        (void)base;
-        (void)tbase;
       } else {
-        mt.f[j] = *reinterpret_cast<const double*>(base + fo);
-        mt.tr[j] = *reinterpret_cast<const double*>(tbase + to);
+        mt.f[j] = *reinterpret_cast<const double*>(mats_e + vf);
+        mt.tr[j] = *reinterpret_cast<const double*>(trm_e + vt);
       }
-      mt.tw[j] = (DBG & 32) ? 0x01020408u : tipw[(nodes[j] < n ? nodes[j] : 0) * ppr];
+      mt.tw[j] = *reinterpret_cast<const uint32_t*>(
+          tips + (__umul24((unsigned)nodes[j], (unsigned)(ppr * 4)) + col4));
     }
     return mt;
   };
-  auto uniformize = [&](const MacroEntry& me) {
-    UMacro u;
-    u.qslot = __builtin_amdgcn_readfirstlane(me.qslot);
-    u.c0 = __builtin_amdgcn_readfirstlane(me.child[0]);
-    u.c1 = __builtin_amdgcn_readfirstlane(me.child[1]);
-    u.kind0 = __builtin_amdgcn_readfirstlane(me.kind[0]);
-    u.kind1 = __builtin_amdgcn_readfirstlane(me.kind[1]);
-    u.cs0 = __builtin_amdgcn_readfirstlane(me.cslot[0]);
-    u.cs1 = __builtin_amdgcn_readfirstlane(me.cslot[1]);
-    u.g0 = __builtin_amdgcn_readfirstlane(me.grand[0]);
-    u.g1 = __builtin_amdgcn_readfirstlane(me.grand[1]);
-    u.g2 = __builtin_amdgcn_readfirstlane(me.grand[2]);
-    u.g3 = __builtin_amdgcn_readfirstlane(me.grand[3]);
-    u.gs0 = __builtin_amdgcn_readfirstlane(me.gslot[0]);
-    u.gs1 = __builtin_amdgcn_readfirstlane(me.gslot[1]);
-    u.gs2 = __builtin_amdgcn_readfirstlane(me.gslot[2]);
-    u.gs3 = __builtin_amdgcn_readfirstlane(me.gslot[3]);
-    return u;
+  auto tip_vector = [&](uint32_t w) {
+    V x;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      x.v[r] = (double)__builtin_amdgcn_ubfe(w, (uint32_t)(8 * r + hi), 1u);
+    return x;
   };
 
-  long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // DBG 256: cycle counts per phase
-  const long long t_start = (DBG & 256) ? clock64() : 0;
-  // ================= post-order over the stored nodes (+ root: site likelihood) ====
-  // Operands of one macro: issued (LDS reads) before the next macro's entry is made
-  // uniform and its matrices are requested, consumed afterwards.
+  double qroot[R];  // root pre-order vector: pi * category weight * w_p / site likelihood
+  // Operands of one macro: issued (LDS reads) before the next macro's matrices are
+  // requested, consumed afterwards.
   struct Ops {
     V q, x0, y0, x1, y1;  // q: pre-order vector; child 0: x0 (,y0 when unstored); child 1
   };
-  auto load_ops = [&](const UMacro& u, const MacroMats& cm, bool pre) {
+  auto load_ops = [&](int sh, const Slots& sl, const MacroMats& cm, bool pre) {
     Ops o;
     if (pre) {
-      if (u.qslot < 0) {
+      if (is_root(sh)) {
 #pragma unroll
         for (int r = 0; r < R; r++) o.q.v[r] = qroot[r];
       } else {
-        o.q = load_slot(u.qslot);
+        o.q = load_slot(sl.q);
       }
     }
-    if (u.kind0 == 2) {
-      o.x0 = operand(u.g0, u.gs0, cm.tw[2]);
-      o.y0 = operand(u.g1, u.gs1, cm.tw[3]);
+    if (kind0(sh) == 2) {
+      o.x0 = is_tip(sh, 2) ? tip_vector(cm.tw[2]) : load_slot(sl.gs0);
+      o.y0 = is_tip(sh, 3) ? tip_vector(cm.tw[3]) : load_slot(sl.gs1);
     } else {
-      o.x0 = operand(u.c0, u.cs0, cm.tw[0]);
+      o.x0 = is_tip(sh, 0) ? tip_vector(cm.tw[0]) : load_slot(sl.cs0);
     }
-    if (u.kind1 == 2) {
-      o.x1 = operand(u.g2, u.gs2, cm.tw[4]);
-      o.y1 = operand(u.g3, u.gs3, cm.tw[5]);
+    if (kind1(sh) == 2) {
+      o.x1 = is_tip(sh, 4) ? tip_vector(cm.tw[4]) : load_slot(sl.gs2);
+      o.y1 = is_tip(sh, 5) ? tip_vector(cm.tw[5]) : load_slot(sl.gs3);
     } else {
-      o.x1 = operand(u.c1, u.cs1, cm.tw[1]);
+      o.x1 = is_tip(sh, 1) ? tip_vector(cm.tw[1]) : load_slot(sl.cs1);
     }
     return o;
   };
-  auto post_step = [&](const UMacro& u, const MacroMats& cm, const Ops& o) {
+
+  // ================= post-order over the stored nodes (+ root: site likelihood) ====
+  auto post_step = [&](int sh, const Slots& sl, const MacroMats& cm, const Ops& o) {
     V L0, L1;
-    if (u.kind0 == 2) L0 = mul(mm(cm.f[2], o.x0), mm(cm.f[3], o.y0));
+    if (kind0(sh) == 2) L0 = mul(mm(cm.f[2], o.x0), mm(cm.f[3], o.y0));
     else L0 = o.x0;
-    if (u.kind1 == 2) L1 = mul(mm(cm.f[4], o.x1), mm(cm.f[5], o.y1));
+    if (kind1(sh) == 2) L1 = mul(mm(cm.f[4], o.x1), mm(cm.f[5], o.y1));
     else L1 = o.x1;
     const V Lv = mul(mm(cm.f[0], L0), mm(cm.f[1], L1));
-    if (u.qslot >= 0) {
-      store_slot(u.qslot, Lv);
+    if (!is_root(sh)) {
+      store_slot(sl.q, Lv);
     } else {
       // root: site likelihood per pattern, log-likelihood partial, derivative weights
       double ll = 0.0;
@@ -1819,45 +1825,37 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     }
   };
   {
-    // two macros per iteration: entries and matrix registers ping-pong between two
-    // sets, so nothing is copied
-    // three-stage pipeline: the raw entry is loaded two macros ahead, made uniform
-    // and its matrices fetched one macro ahead
-    MacroEntry raw = macros[0];
-    UMacro ua = uniformize(raw), ub;
-    MacroMats ma = fetch_mats(ua), mb;
-    raw = macros[M > 1 ? 1 : 0];
+    // Two macros per iteration; everything ping-pongs between two register sets, so
+    // nothing is copied.  At the top of macro m: ids(m+1) have arrived (requested a macro
+    // ago) and give the addresses of the matrices / tip words of macro m+1; slots(m)
+    // have arrived too; ids(m+2) and slots(m+1) are requested.
+    Ids ia = load_ids(0), ib;
+    Slots sa = load_slots(0), sb;
+    int sha = __builtin_amdgcn_readfirstlane(ia.shape), shb = 0;
+    MacroMats ma = fetch_mats(ia), mb;
+    ib = load_ids(M > 1 ? 1 : 0);
     for (int m = 0; m < M; m += 2) {
-      long long tA = 0, tB = 0, tC = 0, tD = 0;
-      if (DBG & 256) tA = clock64();
-      const Ops oa = load_ops(ua, ma, false);
-      if (DBG & 256) tB = clock64();
-      ub = uniformize(raw);
-      if (DBG & 256) tC = clock64();
-      mb = fetch_mats(ub);
-      raw = macros[m + 2 < M ? m + 2 : M - 1];
-      if (DBG & 256) tD = clock64();
-      post_step(ua, ma, oa);
-      if (DBG & 256) {
-        const long long tE = clock64();
-        tacc[0] += tB - tA;
-        tacc[1] += tC - tB;
-        tacc[2] += tD - tC;
-        tacc[3] += tE - tD;
-      }
+      const Ops oa = load_ops(sha, sa, ma, false);
+      shb = __builtin_amdgcn_readfirstlane(ib.shape);
+      mb = fetch_mats(ib);
+      ia = load_ids(m + 2 < M ? m + 2 : M - 1);
+      sb = load_slots(m + 1 < M ? m + 1 : M - 1);
+      post_step(sha, sa, ma, oa);
       if (m + 1 < M) {
-        const Ops ob = load_ops(ub, mb, false);
-        ua = uniformize(raw);
-        ma = fetch_mats(ua);
-        raw = macros[m + 3 < M ? m + 3 : M - 1];
-        post_step(ub, mb, ob);
+        const Ops ob = load_ops(shb, sb, mb, false);
+        sha = __builtin_amdgcn_readfirstlane(ia.shape);
+        ma = fetch_mats(ia);
+        ib = load_ids(m + 3 < M ? m + 3 : M - 1);
+        sa = load_slots(m + 2 < M ? m + 2 : M - 1);
+        post_step(shb, sb, mb, ob);
       }
     }
   }
   if (DBG & 128) return;
-  const long long t_mid = (DBG & 256) ? clock64() : 0;
   // ================= pre-order + edge derivatives =================
-  auto edge_sums = [&](const V& na, const V& nb, int edge_a, int edge_b) {
+  // lanes 15 / 31 / 47 / 63 end up with (branch a, site a, branch b, site b) of an edge pair
+  const unsigned red_off = 8u * ((((unsigned)lane >> 5) & 1u) * 2u + (((unsigned)lane >> 4) & 1u));
+  auto edge_sums = [&](const V& na, const V& nb, int m, int pos_a) {
     // the pattern and category weights ride along in q (linear in the root vector)
     double sa = na.v[0], sb = nb.v[0];
 #pragma unroll
@@ -1867,25 +1865,23 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     }
     const double red = (DBG & 2) ? rate_l * sa + drate_l * sb
                                  : reduce4_transposed(rate_l * sa, rate_l * sb, drate_l * sa, drate_l * sb);
-    // lane 15: branch a, lane 31: site a, lane 47: branch b, lane 63: site b
     if ((lane & 15) == 15) {
-      const int which = lane >> 4;
-      const int edge = (which & 2) ? edge_b : edge_a;
-      gacc[((which & 1) ? N : 0) + edge] = red;  // every edge is visited exactly once
+      char* dst = reinterpret_cast<char*>(gacc) + (unsigned)((m * kMacroPositions + pos_a) * 16);
+      *reinterpret_cast<double*>(dst + red_off) = red;
     }
   };
-  auto pre_step = [&](const UMacro& u, const MacroMats& cm, const Ops& o) {
+  auto pre_step = [&](int sh, const Slots& sl, const MacroMats& cm, const Ops& o, int m) {
     const V& qv = o.q;
     const V &La0 = o.x0, &Lb0 = o.y0, &La1 = o.x1, &Lb1 = o.y1;
     V L0, L1, Ap0, Bp0, Ap1, Bp1;
-    if (u.kind0 == 2) {
+    if (kind0(sh) == 2) {
       Ap0 = mm(cm.f[2], La0);
       Bp0 = mm(cm.f[3], Lb0);
       L0 = mul(Ap0, Bp0);
     } else {
       L0 = o.x0;
     }
-    if (u.kind1 == 2) {
+    if (kind1(sh) == 2) {
       Ap1 = mm(cm.f[4], La1);
       Bp1 = mm(cm.f[5], Lb1);
       L1 = mul(Ap1, Bp1);
@@ -1896,75 +1892,58 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     // Edge of child c below a node with pre-order vector q and sibling product S:
     //   internal child: q_c = P_c^T (q o S), numerator q_c o (Q L_c), q_c kept if stored
     //   tip child:      numerator (q o S) o ((P_c Q) L_c)  -- `trm` is then (P_c Q)
-    auto edge = [&](double trm, const V& qs, const V& Lc, int node, int slot, bool keep, V& qc) {
-      if (node < n) return mul(qs, mm(trm, Lc));
+    auto edge = [&](double trm, const V& qs, const V& Lc, bool tip, int slot, bool keep, V& qc) {
+      if (tip) return mul(qs, mm(trm, Lc));
       qc = mm(trm, qs);
       if (keep) store_slot(slot, qc);
       return mul(qc, mm(AQ, Lc));
     };
     V q0, q1;
     {
-      const V n0 = edge(cm.tr[0], mul(qv, B), L0, u.c0, u.cs0, u.kind0 == 1, q0);
-      const V n1 = edge(cm.tr[1], mul(qv, A), L1, u.c1, u.cs1, u.kind1 == 1, q1);
-      edge_sums(n0, n1, u.c0, u.c1);
+      const V n0 = edge(cm.tr[0], mul(qv, B), L0, is_tip(sh, 0), sl.cs0, kind0(sh) == 1, q0);
+      const V n1 = edge(cm.tr[1], mul(qv, A), L1, is_tip(sh, 1), sl.cs1, kind1(sh) == 1, q1);
+      edge_sums(n0, n1, m, 0);
     }
-    if (u.kind0 == 2) {
+    if (kind0(sh) == 2) {
       V qa, qb;
-      const V na = edge(cm.tr[2], mul(q0, Bp0), La0, u.g0, u.gs0, true, qa);
-      const V nb = edge(cm.tr[3], mul(q0, Ap0), Lb0, u.g1, u.gs1, true, qb);
-      edge_sums(na, nb, u.g0, u.g1);
+      const V na = edge(cm.tr[2], mul(q0, Bp0), La0, is_tip(sh, 2), sl.gs0, true, qa);
+      const V nb = edge(cm.tr[3], mul(q0, Ap0), Lb0, is_tip(sh, 3), sl.gs1, true, qb);
+      edge_sums(na, nb, m, 2);
     }
-    if (u.kind1 == 2) {
+    if (kind1(sh) == 2) {
       V qa, qb;
-      const V na = edge(cm.tr[4], mul(q1, Bp1), La1, u.g2, u.gs2, true, qa);
-      const V nb = edge(cm.tr[5], mul(q1, Ap1), Lb1, u.g3, u.gs3, true, qb);
-      edge_sums(na, nb, u.g2, u.g3);
+      const V na = edge(cm.tr[4], mul(q1, Bp1), La1, is_tip(sh, 4), sl.gs2, true, qa);
+      const V nb = edge(cm.tr[5], mul(q1, Ap1), Lb1, is_tip(sh, 5), sl.gs3, true, qb);
+      edge_sums(na, nb, m, 4);
     }
   };
   {
-    MacroEntry raw = macros[M - 1];
-    UMacro ua = uniformize(raw), ub;
-    MacroMats ma = fetch_mats(ua), mb;
-    raw = macros[M > 1 ? M - 2 : 0];
+    Ids ia = load_ids(M - 1), ib;
+    Slots sa = load_slots(M - 1), sb;
+    int sha = __builtin_amdgcn_readfirstlane(ia.shape), shb = 0;
+    MacroMats ma = fetch_mats(ia), mb;
+    ib = load_ids(M > 1 ? M - 2 : 0);
     for (int m = M - 1; m >= 0; m -= 2) {
-      long long tA = 0, tB = 0, tC = 0, tD = 0;
-      if (DBG & 256) tA = clock64();
-      const Ops oa = load_ops(ua, ma, true);
-      if (DBG & 256) tB = clock64();
-      ub = uniformize(raw);
-      if (DBG & 256) tC = clock64();
-      mb = fetch_mats(ub);
-      raw = macros[m >= 2 ? m - 2 : 0];
-      if (DBG & 256) tD = clock64();
-      pre_step(ua, ma, oa);
-      if (DBG & 256) {
-        const long long tE = clock64();
-        tacc[4] += tB - tA;
-        tacc[5] += tC - tB;
-        tacc[6] += tD - tC;
-        tacc[7] += tE - tD;
-      }
+      const Ops oa = load_ops(sha, sa, ma, true);
+      shb = __builtin_amdgcn_readfirstlane(ib.shape);
+      mb = fetch_mats(ib);
+      ia = load_ids(m >= 2 ? m - 2 : 0);
+      sb = load_slots(m >= 1 ? m - 1 : 0);
+      pre_step(sha, sa, ma, oa, m);
       if (m >= 1) {
-        const Ops ob = load_ops(ub, mb, true);
-        ua = uniformize(raw);
-        ma = fetch_mats(ua);
-        raw = macros[m >= 3 ? m - 3 : 0];
-        pre_step(ub, mb, ob);
+        const Ops ob = load_ops(shb, sb, mb, true);
+        sha = __builtin_amdgcn_readfirstlane(ia.shape);
+        ma = fetch_mats(ia);
+        ib = load_ids(m >= 3 ? m - 3 : 0);
+        sa = load_slots(m >= 2 ? m - 2 : 0);
+        pre_step(shb, sb, mb, ob, m - 1);
       }
     }
   }
   __syncthreads();
-  if (DBG & 256) {
-    // profiling build: the first entries of the "gradient" are cycle counts
-    const long long t_end = clock64();
-    tacc[8] = t_mid - t_start;
-    tacc[9] = t_end - t_mid;
-    if (lane == 0)
-      for (int i = 0; i < 10; i++) gacc[i] = (double)tacc[i];
-    __syncthreads();
-  }
-  double* gout = a.g_part + ((size_t)gi * a.g_tiles + te.tile) * 2 * N;
-  for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];
+  // positions that do not exist in a macro are never written nor read downstream
+  double* gout = a.g_part + ((size_t)gi * a.g_tiles + te.tile) * gwidth;
+  for (int i = lane; i < M * kMacroPositions * 2; i += kTile) gout[i] = gacc[i];
 }
 
 // ------------------------------------------------------------------------
@@ -1972,17 +1951,21 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
 // (wave w takes tiles w, w+4, ...), combine through LDS in a fixed order.
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
-  extern __shared__ double red_lds[];  // [4][2N]
+  extern __shared__ double red_lds[];  // [4][W]
   __shared__ double llw[4];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int W = 2 * a.N;
+  const int N2 = 2 * a.N;
+  const int W = a.g_width ? a.g_width : N2;  // doubles per (evaluation, tile)
   double llp = 0;
   for (int i = threadIdx.x; i < a.ll_tiles; i += 256) llp += a.ll_part[(size_t)b * a.ll_tiles + i];
   llp = wave_sum(llp);
   if (lane == 0) llw[wv] = llp;
+  const int t = b < a.T ? b : b - a.T;  // gradient evaluations: [0,T) main, [T,2T) site pass
+  int used = W;
+  if (b < a.Eg && a.g_width) used = a.macro_count[t] * kMacroPositions * 2;
   if (b < a.Eg) {
     const double* src = a.g_part + (size_t)b * a.g_tiles * W;
-    for (int v = lane; v < W; v += 64) {
+    for (int v = lane; v < used; v += 64) {
       double s0 = 0, s1 = 0;
       int i = wv;
       for (; i + 4 < a.g_tiles; i += 8) {
@@ -1995,10 +1978,26 @@ __global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
   }
   __syncthreads();
   if (threadIdx.x == 0) a.ll_sum[b] = (llw[0] + llw[1]) + (llw[2] + llw[3]);
-  if (b < a.Eg)
-    for (int v = threadIdx.x; v < W; v += 256)
-      a.g_sum[(size_t)b * W + v] =
-          (red_lds[v] + red_lds[W + v]) + (red_lds[2 * W + v] + red_lds[3 * W + v]);
+  if (b >= a.Eg) return;
+  double* out = a.g_sum + (size_t)b * N2;
+  if (!a.g_width) {
+    for (int v = threadIdx.x; v < N2; v += 256)
+      out[v] = (red_lds[v] + red_lds[W + v]) + (red_lds[2 * W + v] + red_lds[3 * W + v]);
+    return;
+  }
+  // positional: entry (m, pos, q) belongs to the edge above child/grandchild `pos` of macro m
+  const MacroEntry* mac = a.macros + (size_t)t * max_macros(a.n);
+  if (threadIdx.x < 2) out[threadIdx.x * a.N + a.N - 1] = 0.0;  // the root has no edge
+  for (int v = threadIdx.x; v < used; v += 256) {
+    const int m = v / (kMacroPositions * 2), r = v - m * (kMacroPositions * 2);
+    const int pos = r >> 1, q = r & 1;
+    const MacroEntry& me = mac[m];
+    const bool exists = pos < 2 || ((me.shape >> (2 * ((pos - 2) >> 1))) & 3) == 2;
+    if (!exists) continue;
+    const int node = pos < 2 ? me.child[pos] : me.grand[pos - 2];
+    out[q * a.N + node] =
+        (red_lds[v] + red_lds[W + v]) + (red_lds[2 * W + v] + red_lds[3 * W + v]);
+  }
 }
 
 // ------------------------------------------------------------------------
@@ -2288,10 +2287,13 @@ void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s) {
 }
 size_t gradient_mfma_lds_bytes(int n, int K) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
-  const int N = 2 * n - 1;
-  return sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile + 2 * N) +
-         (size_t)n * 4 * (16 / kp) + 16;
+  const size_t tip_bytes = (((size_t)n * 4 * (16 / kp) + 7) / 8) * 8;
+  const size_t bytes =
+      tip_bytes + sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile + gradient_mfma_width(n));
+  const size_t reach = (size_t)(2 * n - 1) * 4 * (16 / kp);  // mask fetches of internal ids
+  return bytes > reach ? bytes : reach;
 }
+int gradient_mfma_width(int n) { return max_macros(n) * kMacroPositions * 2; }
 bool gradient_mfma_fits(int n, int K) {
   return n >= 3 && K <= 4 && gradient_mfma_lds_bytes(n, K) <= 160 * 1024;
 }
@@ -2325,11 +2327,11 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, hipStream_t s) {
   }
   hipLaunchKernelGGL((gradient_mfma_kernel<kLlR>), grid, dim3(kTile), lds, s, a);
 }
-bool reduce_tiles_fits(int N) { return sizeof(double) * 8 * (size_t)N <= 64 * 1024; }
+bool reduce_tiles_fits(int N) { return sizeof(double) * 4 * (size_t)(3 * N + 12) <= 64 * 1024; }
 void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
-  hipLaunchKernelGGL(reduce_tiles_kernel, dim3(a.E), dim3(256), sizeof(double) * 8 * (size_t)a.N, s,
-                     a);
+  const size_t W = a.g_width ? a.g_width : 2 * (size_t)a.N;
+  hipLaunchKernelGGL(reduce_tiles_kernel, dim3(a.E), dim3(256), sizeof(double) * 4 * W, s, a);
 }
 void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
   FinalizeArgs a = a_in;

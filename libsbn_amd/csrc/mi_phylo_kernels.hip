@@ -1741,11 +1741,10 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     const int nodes[6] = {id.c0, id.c1, id.g0, id.g1, id.g2, id.g3};
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      // one v_mad per node; kept opaque so that "scalar base + 32-bit lane offset" stays
-      // one addressing mode instead of being folded into 64-bit vector arithmetic
-      unsigned vf = __umul24((unsigned)nodes[j], node_bytes) + f_off;
-      unsigned vt = vf + tt_delta;
-      asm volatile("" : "+v"(vf), "+v"(vt));
+      // (the compiler folds base + node * bytes + lane offset into one 64-bit multiply-add
+      // per address; forcing "scalar base + 32-bit lane offset" addressing measured slower)
+      const unsigned vf = __umul24((unsigned)nodes[j], node_bytes) + f_off;
+      const unsigned vt = vf + tt_delta;
       if (DBG & 16) {
         mt.f[j] = pi_l + nodes[j];
         mt.tr[j] = pi_l - nodes[j];

@@ -1667,6 +1667,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   // slots arrive as vector registers (the same value in every lane)
   const unsigned lane8 = 8u * lane;
   auto slot_ptr = [&](int slot) {
+    // keep the (wave-uniform) slot in its vector register: the compiler would otherwise
+    // move it to a scalar register first (a v_readfirstlane per field per macro)
+    asm volatile("" : "+v"(slot));
     return reinterpret_cast<double*>(reinterpret_cast<char*>(plv) +
                                      (__umul24((unsigned)slot, (unsigned)(R * kTile * 8)) + lane8));
   };
@@ -1738,9 +1741,10 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   const unsigned col4 = 4u * col;
   auto fetch_mats = [&](const Ids& id) {
     MacroMats mt;
-    const int nodes[6] = {id.c0, id.c1, id.g0, id.g1, id.g2, id.g3};
+    int nodes[6] = {id.c0, id.c1, id.g0, id.g1, id.g2, id.g3};
 #pragma unroll
     for (int j = 0; j < 6; j++) {
+      asm volatile("" : "+v"(nodes[j]));  // stays a vector register (see slot_ptr)
       // (the compiler folds base + node * bytes + lane offset into one 64-bit multiply-add
       // per address; forcing "scalar base + 32-bit lane offset" addressing measured slower)
       const unsigned vf = __umul24((unsigned)nodes[j], node_bytes) + f_off;

@@ -62,19 +62,35 @@ def build_workload(T, seed=43):
     return tips, w, pids, bls, params
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU
+    quota (running more threads than the quota only adds throttling stalls)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(tips, w, pids, bls, params, mode, budget_s=12.0):
     """The CPU oracle (a port of the reference's algorithm, NOT BEAGLE itself: BEAGLE
     is not available in this image) timed on the host cores with the reference's
     tree-level threading model (one worker per core, FatBeagleParallelize)."""
     import oracle_lib as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     spec = O.make_spec(tips.shape[0], tips.shape[1], "JC69", "weibull+4")
     fn = O.unrooted_gradients if mode == "gradient" else O.unrooted_log_likelihoods
     def take(count):  # the batch, cycled
         idx = np.arange(count) % len(pids)
         return pids[idx], bls[idx], params[idx]
 
-    S = 2 * cores
+    S = 4 * cores
     a, b, c = take(S)
     fn(spec, tips, w, a, b, c, False, cores)  # warm-up (page faults, thread start)
     t0 = time.perf_counter()
@@ -88,10 +104,11 @@ def cpu_baseline(tips, w, pids, bls, params, mode, budget_s=12.0):
     dt = time.perf_counter() - t0
     return {"value": S2 / dt, "unit": "trees/s", "cores": cores, "kind": "port",
             "sample": f"{S2} trees (the same batch, cycled), {mode} semantics, "
-                      f"{cores} OpenMP threads (one tree per thread, one workspace per "
-                      f"thread), {dt:.1f} s; "
-                      "CPU oracle = BEAGLE-equivalent algorithm in plain C -O3 "
-                      "-march=native, not BEAGLE"}
+                      f"{cores} OpenMP threads = usable cores (affinity mask capped by the "
+                      f"cgroup CPU quota; host has {os.cpu_count()} logical CPUs), one tree "
+                      f"per thread, one workspace per thread, {dt:.1f} s; "
+                      "CPU oracle = BEAGLE-equivalent algorithm (cache-blocked over site "
+                      "patterns) in plain C -O3 -march=native, not BEAGLE"}
 
 
 def main():

@@ -657,46 +657,60 @@ typedef struct {
   real* pre;  /* [N][K][P][s] or NULL */
   real* mats; /* [N-1][K][s][s] */
   real* cum_log_scale; /* [P] */
+  int p0, p1;          /* pattern block the sweeps work on (cache blocking; see below) */
 } core_ws_t;
+
+/* Site patterns are independent through the whole tree, so the sweeps run over one
+ * block of patterns at a time (post-order, pre-order, derivatives, root), keeping a
+ * block's vectors of all nodes in cache.  Sums over patterns are still accumulated
+ * pattern by pattern in ascending order, so the results are bitwise those of the
+ * unblocked sweeps. */
+#define ORC_PATTERN_BLOCK 64
 
 static core_ws_t ws_alloc(const orc_spec_t* spec, const int32_t* tips, int need_pre) {
   core_ws_t w;
   w.n = spec->taxon_count; w.N = 2 * w.n - 1; w.P = spec->pattern_count;
   w.s = spec->state_count; w.K = spec->category_count; w.tips = tips;
-  size_t plv = (size_t)w.K * w.P * w.s;
+  size_t plv = (size_t)w.K * ORC_PATTERN_BLOCK * w.s; /* one pattern block per node */
   w.post = (real*)malloc(sizeof(real) * plv * w.N);
   w.pre = need_pre ? (real*)malloc(sizeof(real) * plv * w.N) : NULL;
   w.mats = (real*)malloc(sizeof(real) * (size_t)(w.N - 1) * w.K * w.s * w.s);
   w.cum_log_scale = (real*)calloc(w.P, sizeof(real));
-  /* tips: site_pattern.cpp:117-131 (GetPartials) == BEAGLE compact states >= s */
-  for (int t = 0; t < w.n; t++)
-    for (int k = 0; k < w.K; k++)
-      for (int p = 0; p < w.P; p++) {
-        real* L = w.post + (((size_t)t * w.K + k) * w.P + p) * w.s;
-        int st = tips[(size_t)t * w.P + p];
-        for (int i = 0; i < w.s; i++) L[i] = (st >= w.s || st < 0 || st == i) ? 1.0 : 0.0;
-      }
+  w.p0 = 0; w.p1 = 0;
   return w;
 }
 static void ws_free(core_ws_t* w) { free(w->post); free(w->pre); free(w->mats); free(w->cum_log_scale); }
 
+/* Tip rows of the current pattern block: site_pattern.cpp:117-131 (GetPartials) ==
+ * BEAGLE compact states >= s. */
+static void fill_tips(core_ws_t* w) {
+  const int PB = ORC_PATTERN_BLOCK, p0 = w->p0;
+  for (int t = 0; t < w->n; t++)
+    for (int k = 0; k < w->K; k++)
+      for (int p = w->p0; p < w->p1; p++) {
+        real* L = w->post + (((size_t)t * w->K + k) * PB + (p - p0)) * w->s;
+        int st = w->tips[(size_t)t * w->P + p];
+        for (int i = 0; i < w->s; i++) L[i] = (st >= w->s || st < 0 || st == i) ? 1.0 : 0.0;
+      }
+}
+
 /* beagleUpdatePartials (fat_beagle.cpp:60-63,139-141) with
  * AddLowerPartialOperation (fat_beagle.cpp:327-342): per-pattern max rescaling
  * writes log(max) into the cumulative buffer when rescaling is on. */
-static void post_order(core_ws_t* w, const int32_t* child0, const int32_t* child1,
-                       int rescaling) {
-  int s = w->s, K = w->K, P = w->P;
-  size_t plv = (size_t)K * P * s;
+static inline __attribute__((always_inline)) void post_order_impl(
+    core_ws_t* w, const int32_t* child0, const int32_t* child1, int rescaling, const int s) {
+  int K = w->K, PB = ORC_PATTERN_BLOCK, p0 = w->p0;
+  size_t plv = (size_t)K * PB * s;
   for (int v = w->n; v < w->N; v++) {
     int c0 = child0[v - w->n], c1 = child1[v - w->n];
     real* dst = w->post + plv * v;
     for (int k = 0; k < K; k++) {
       const real* M0 = w->mats + ((size_t)c0 * K + k) * s * s;
       const real* M1 = w->mats + ((size_t)c1 * K + k) * s * s;
-      for (int p = 0; p < P; p++) {
-        const real* L0 = w->post + plv * c0 + ((size_t)k * P + p) * s;
-        const real* L1 = w->post + plv * c1 + ((size_t)k * P + p) * s;
-        real* D = dst + ((size_t)k * P + p) * s;
+      for (int p = w->p0; p < w->p1; p++) {
+        const real* L0 = w->post + plv * c0 + ((size_t)k * PB + (p - p0)) * s;
+        const real* L1 = w->post + plv * c1 + ((size_t)k * PB + (p - p0)) * s;
+        real* D = dst + ((size_t)k * PB + (p - p0)) * s;
         for (int i = 0; i < s; i++) {
           real a = 0, b = 0;
           for (int j = 0; j < s; j++) {
@@ -708,32 +722,37 @@ static void post_order(core_ws_t* w, const int32_t* child0, const int32_t* child
       }
     }
     if (rescaling) {
-      for (int p = 0; p < P; p++) {
+      for (int p = w->p0; p < w->p1; p++) {
         real mx = 0;
         for (int k = 0; k < K; k++)
           for (int i = 0; i < s; i++) {
-            real x = dst[((size_t)k * P + p) * s + i];
+            real x = dst[((size_t)k * PB + (p - p0)) * s + i];
             if (x > mx) mx = x;
           }
         if (mx == 0) mx = 1.0;
         for (int k = 0; k < K; k++)
-          for (int i = 0; i < s; i++) dst[((size_t)k * P + p) * s + i] /= mx;
+          for (int i = 0; i < s; i++) dst[((size_t)k * PB + (p - p0)) * s + i] /= mx;
         w->cum_log_scale[p] += R_LOG(mx);
       }
     }
   }
 }
+static void post_order(core_ws_t* w, const int32_t* child0, const int32_t* child1,
+                       int rescaling) {
+  if (w->s == 4) post_order_impl(w, child0, child1, rescaling, 4); /* unrolled by the compiler */
+  else post_order_impl(w, child0, child1, rescaling, w->s);
+}
 
 /* beagleCalculateRootLogLikelihoods (fat_beagle.cpp:65-68,170-173). */
-static real root_log_likelihood(const core_ws_t* w, const model_t* m, const double* weights) {
-  int s = w->s, K = w->K, P = w->P;
-  const real* R = w->post + (size_t)K * P * s * (w->N - 1);
-  real total = 0;
-  for (int p = 0; p < P; p++) {
+static real root_log_likelihood(const core_ws_t* w, const model_t* m, const double* weights,
+                                real total) {
+  int s = w->s, K = w->K, PB = ORC_PATTERN_BLOCK, p0 = w->p0;
+  const real* R = w->post + (size_t)K * PB * s * (w->N - 1);
+  for (int p = w->p0; p < w->p1; p++) {
     real site = 0;
     for (int k = 0; k < K; k++) {
       real sk = 0;
-      for (int i = 0; i < s; i++) sk += m->pi[i] * R[((size_t)k * P + p) * s + i];
+      for (int i = 0; i < s; i++) sk += m->pi[i] * R[((size_t)k * PB + (p - p0)) * s + i];
       site += m->cat_weights[k] * sk;
     }
     total += weights[p] * (R_LOG(site) + w->cum_log_scale[p]);
@@ -748,8 +767,15 @@ static real core_log_likelihood_ws(core_ws_t* w, const model_t* model,
                                    const int32_t* child1, const real* bl, int rescaling) {
   memset(w->cum_log_scale, 0, sizeof(real) * w->P); /* beagleResetScaleFactors */
   transition_matrices(model, w->N - 1, bl, w->mats);
-  post_order(w, child0, child1, rescaling);
-  return root_log_likelihood(w, model, pattern_weights);
+  real total = 0;
+  for (int pb = 0; pb < w->P; pb += ORC_PATTERN_BLOCK) {
+    w->p0 = pb;
+    w->p1 = pb + ORC_PATTERN_BLOCK < w->P ? pb + ORC_PATTERN_BLOCK : w->P;
+    fill_tips(w);
+    post_order(w, child0, child1, rescaling);
+    total = root_log_likelihood(w, model, pattern_weights, total);
+  }
+  return total;
 }
 
 static real core_log_likelihood(const orc_spec_t* spec, const model_t* model,
@@ -767,30 +793,30 @@ static real core_log_likelihood(const orc_spec_t* spec, const model_t* model,
  * q_x[j] = sum_i P_x[i][j] * ( q_parent[i] * sum_m P_sis[i][m] L_sis[m] ).
  * Per-node scalers (when rescaling) are written but never accumulated
  * (cumulative index BEAGLE_OP_NONE); they cancel in the derivative ratio. */
-static void pre_order(core_ws_t* w, const model_t* m, const int32_t* child0,
-                      const int32_t* child1, int rescaling) {
-  int s = w->s, K = w->K, P = w->P, n = w->n;
-  size_t plv = (size_t)K * P * s;
-  int32_t* tr = (int32_t*)malloc(sizeof(int32_t) * 3 * (2 * n - 2));
-  orc_preorder_triples(n, child0, child1, tr);
+static inline __attribute__((always_inline)) void pre_order_impl(
+    core_ws_t* w, const model_t* m, const int32_t* tr, int rescaling, const int s) {
+  int K = w->K, PB = ORC_PATTERN_BLOCK, p0 = w->p0;
+  size_t plv = (size_t)K * PB * s;
   real* root = w->pre + plv * (w->N - 1);
-  for (size_t x = 0; x < plv; x++) root[x] = m->pi[x % s];
-  for (int op = 0; op < 2 * n - 2; op++) {
+  for (int k = 0; k < K; k++)
+    for (int p = w->p0; p < w->p1; p++)
+      for (int i = 0; i < s; i++) root[((size_t)k * PB + (p - p0)) * s + i] = m->pi[i];
+  for (int op = 0; op < 2 * w->n - 2; op++) {
     int node = tr[3 * op], sis = tr[3 * op + 1], par = tr[3 * op + 2];
     real* dst = w->pre + plv * node;
     for (int k = 0; k < K; k++) {
       const real* Mn = w->mats + ((size_t)node * K + k) * s * s;
       const real* Ms = w->mats + ((size_t)sis * K + k) * s * s;
-      for (int p = 0; p < P; p++) {
-        const real* qp = w->pre + plv * par + ((size_t)k * P + p) * s;
-        const real* Ls = w->post + plv * sis + ((size_t)k * P + p) * s;
+      for (int p = w->p0; p < w->p1; p++) {
+        const real* qp = w->pre + plv * par + ((size_t)k * PB + (p - p0)) * s;
+        const real* Ls = w->post + plv * sis + ((size_t)k * PB + (p - p0)) * s;
         real u[ORC_MAX_STATES];
         for (int i = 0; i < s; i++) {
           real a = 0;
           for (int mm = 0; mm < s; mm++) a += Ms[i * s + mm] * Ls[mm];
           u[i] = qp[i] * a;
         }
-        real* D = dst + ((size_t)k * P + p) * s;
+        real* D = dst + ((size_t)k * PB + (p - p0)) * s;
         for (int j = 0; j < s; j++) {
           real acc = 0;
           for (int i = 0; i < s; i++) acc += Mn[i * s + j] * u[i];
@@ -799,35 +825,39 @@ static void pre_order(core_ws_t* w, const model_t* m, const int32_t* child0,
       }
     }
     if (rescaling) {
-      for (int p = 0; p < P; p++) {
+      for (int p = w->p0; p < w->p1; p++) {
         real mx = 0;
         for (int k = 0; k < K; k++)
           for (int i = 0; i < s; i++) {
-            real x = dst[((size_t)k * P + p) * s + i];
+            real x = dst[((size_t)k * PB + (p - p0)) * s + i];
             if (x > mx) mx = x;
           }
         if (mx == 0) mx = 1.0;
         for (int k = 0; k < K; k++)
-          for (int i = 0; i < s; i++) dst[((size_t)k * P + p) * s + i] /= mx;
+          for (int i = 0; i < s; i++) dst[((size_t)k * PB + (p - p0)) * s + i] /= mx;
       }
     }
   }
-  free(tr);
+}
+static void pre_order(core_ws_t* w, const model_t* m, const int32_t* tr, int rescaling) {
+  if (w->s == 4) pre_order_impl(w, m, tr, rescaling, 4);
+  else pre_order_impl(w, m, tr, rescaling, w->s);
 }
 
 /* beagleCalculateEdgeDerivatives (fat_beagle.cpp:153-166) with the differential
  * matrix of BuildDifferentialMatrices (:107-117): D_k = dscale[k] * Q. */
-static void edge_derivatives(const core_ws_t* w, const model_t* m, const double* weights,
-                             const real* dscale, real* grad) {
-  int s = w->s, K = w->K, P = w->P;
-  size_t plv = (size_t)K * P * s;
+static inline __attribute__((always_inline)) void edge_derivatives_impl(
+    const core_ws_t* w, const model_t* m, const double* weights, const real* dscale, real* grad,
+    const int s) {
+  int K = w->K, PB = ORC_PATTERN_BLOCK, p0 = w->p0;
+  size_t plv = (size_t)K * PB * s;
   for (int node = 0; node < w->N - 1; node++) {
-    real g = 0;
-    for (int p = 0; p < P; p++) {
+    real g = grad[node]; /* running sum over the pattern blocks, ascending patterns */
+    for (int p = w->p0; p < w->p1; p++) {
       real num = 0, den = 0;
       for (int k = 0; k < K; k++) {
-        const real* q = w->pre + plv * node + ((size_t)k * P + p) * s;
-        const real* L = w->post + plv * node + ((size_t)k * P + p) * s;
+        const real* q = w->pre + plv * node + ((size_t)k * PB + (p - p0)) * s;
+        const real* L = w->post + plv * node + ((size_t)k * PB + (p - p0)) * s;
         real nk = 0, dk = 0;
         for (int a = 0; a < s; a++) {
           real dl = 0;
@@ -844,6 +874,11 @@ static void edge_derivatives(const core_ws_t* w, const model_t* m, const double*
   }
   grad[w->N - 1] = 0.;
 }
+static void edge_derivatives(const core_ws_t* w, const model_t* m, const double* weights,
+                             const real* dscale, real* grad) {
+  if (w->s == 4) edge_derivatives_impl(w, m, weights, dscale, grad, 4);
+  else edge_derivatives_impl(w, m, weights, dscale, grad, w->s);
+}
 
 static real core_branch_gradient_ws(core_ws_t* w, const model_t* model,
                                     const double* pattern_weights, const int32_t* child0,
@@ -851,10 +886,21 @@ static real core_branch_gradient_ws(core_ws_t* w, const model_t* model,
                                     int rescaling, real* grad) {
   memset(w->cum_log_scale, 0, sizeof(real) * w->P);
   transition_matrices(model, w->N - 1, bl, w->mats);
-  post_order(w, child0, child1, rescaling);
-  pre_order(w, model, child0, child1, rescaling);
-  edge_derivatives(w, model, pattern_weights, dscale, grad);
-  return root_log_likelihood(w, model, pattern_weights);
+  int32_t* tr = (int32_t*)malloc(sizeof(int32_t) * 3 * (2 * w->n - 2));
+  orc_preorder_triples(w->n, child0, child1, tr);
+  for (int i = 0; i < w->N; i++) grad[i] = 0;
+  real total = 0;
+  for (int pb = 0; pb < w->P; pb += ORC_PATTERN_BLOCK) {
+    w->p0 = pb;
+    w->p1 = pb + ORC_PATTERN_BLOCK < w->P ? pb + ORC_PATTERN_BLOCK : w->P;
+    fill_tips(w);
+    post_order(w, child0, child1, rescaling);
+    pre_order(w, model, tr, rescaling);
+    edge_derivatives(w, model, pattern_weights, dscale, grad);
+    total = root_log_likelihood(w, model, pattern_weights, total);
+  }
+  free(tr);
+  return total;
 }
 
 static real core_branch_gradient(const orc_spec_t* spec, const model_t* model,

@@ -55,6 +55,44 @@ def all_gather_trees(local, tree_count, group=None):
     return torch.cat(rows, dim=0)
 
 
+def all_reduce_step_terms(log_likelihoods, branch_gradients, branch_index, parameter_count,
+                          tree_weights=None, group=None):
+    """The caller-side reductions of one variational-inference step folded into ONE
+    all-reduce (north_star: "a single RCCL all-reduce over xGMI for
+    the ELBO/gradient sum").
+
+    vip sums the per-tree log-likelihoods (vip/burrito.py:143-153) and scatter-adds each
+    tree's branch gradient into the shared branch-parameter vector by split index
+    (vip/branch_model.py:125-132).  Every rank does that for its own trees on its GPU;
+    the packed [1 + parameter_count] vector is then summed over ranks.
+
+      log_likelihoods  [T_local]       this rank's trees
+      branch_gradients [T_local, N]    d logL / d branch length, node-id order
+      branch_index     [T_local, N]    int64 index of each branch's parameter (split
+                                       index); negative entries are skipped (root, the
+                                       two trailing zeros of the unrooted gradient)
+      tree_weights     [T_local] or None   per-tree multipliers (e.g. VIMCO weights)
+    Returns (sum of weighted log-likelihoods, [parameter_count] gradient), identical on
+    every rank.
+    """
+    import torch
+    import torch.distributed as dist
+    ll = log_likelihoods.reshape(-1)
+    g = branch_gradients.reshape(len(ll), -1)
+    if tree_weights is not None:
+        wt = tree_weights.reshape(-1).to(ll.dtype)
+        ll = ll * wt
+        g = g * wt[:, None]
+    packed = torch.zeros(1 + parameter_count, dtype=ll.dtype, device=ll.device)
+    packed[0] = ll.sum()
+    idx = branch_index.reshape(-1).to(torch.int64)
+    keep = idx >= 0
+    packed[1:].index_add_(0, idx[keep], g.reshape(-1)[keep])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    return packed[0], packed[1:]
+
+
 class ShardedBatch:
     """Splits the inputs of one Engine call by tree and reassembles the outputs.
 

@@ -26,6 +26,14 @@ def _free_port():
     return port
 
 
+def _split_index(T):
+    """Deterministic stand-in for the split indexer: branch v of tree t -> parameter
+    (7 t + 3 v) mod 40; the root and the two trailing entries are skipped."""
+    idx = (7 * np.arange(T)[:, None] + 3 * np.arange(53)[None, :]) % 40
+    idx[:, 51:] = -1
+    return idx.astype(np.int64)
+
+
 def _worker(rank, world, port, T, out_dir):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
@@ -53,8 +61,17 @@ def _worker(rank, world, port, T, out_dir):
     assert (batch.lo, batch.hi) == S.tree_shard(T, rank, world)
     gathered = batch.run(compute)
     assert gathered.shape == (T, 55)
+    # the fused step reduction: sum of log-likelihoods + scatter-add of branch gradients by
+    # (here: synthetic) split index, one all-reduce
+    local = compute(batch.lo, batch.hi)
+    idx = _split_index(T)[batch.lo:batch.hi]
+    wts = torch.linspace(0.5, 1.5, T, dtype=torch.float64)[batch.lo:batch.hi]
+    total, grad = S.all_reduce_step_terms(local[:, 0], local[:, 2:], torch.from_numpy(idx), 40,
+                                          tree_weights=wts)
     if rank == 0:
         np.save(os.path.join(out_dir, "gathered.npy"), gathered.numpy())
+        np.save(os.path.join(out_dir, "reduced.npy"),
+                np.concatenate([[float(total)], grad.numpy()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,6 +91,17 @@ def test_two_rank_tree_sharding_matches_unsharded(T, tmp_path):
     assert np.array_equal(got[:, 0], g["log_likelihood"])
     assert np.array_equal(got[:, 1], g["site_model"])
     assert np.array_equal(got[:, 2:], g["branch_lengths"])
+    # fused reduction == the same sums done on the unsharded results
+    red = np.load(tmp_path / "reduced.npy")
+    wts = np.linspace(0.5, 1.5, T)
+    idx = _split_index(T)
+    want = np.zeros(40)
+    for t in range(T):
+        for v in range(53):
+            if idx[t, v] >= 0:
+                want[idx[t, v]] += wts[t] * g["branch_lengths"][t, v]
+    assert abs(red[0] - float(np.sum(wts * g["log_likelihood"]))) <= 1e-12 * abs(red[0])
+    assert np.allclose(red[1:], want, rtol=1e-12, atol=1e-12)
 
 
 def test_shard_arithmetic():

@@ -190,11 +190,14 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   if (d.T <= 0) return fail("tree_count must be positive");
   if (!d.parent_ids || !d.bl || !d.out_ll) return fail("null tree / output pointer");
   if (e->param_count > 0 && !d.params) return fail("null parameter matrix");
-  const bool onchip = d.gradient && !d.rescaling && e->allow_onchip_gradient &&
-                      e->spec.use_tip_states && gradient_onchip_fits(e->n);
-  const bool mfma = onchip && e->gradient_path != 1 && gradient_mfma_fits(e->n, e->K) &&
-                    reduce_tiles_fits(e->N) &&
+  // on-chip gradient kernels: the matrix-core one (K <= 4; rescaling supported) or the
+  // VALU one (no rescaling); everything else takes the HBM-streamed kernel
+  const bool fits_chip = d.gradient && e->allow_onchip_gradient && e->spec.use_tip_states &&
+                         gradient_onchip_fits(e->n);
+  const bool mfma = fits_chip && e->gradient_path != 1 &&
+                    gradient_mfma_fits(e->n, e->K, d.rescaling) && reduce_tiles_fits(e->N) &&
                     (e->gradient_path == 3 || e->prefer_mfma_gradient);
+  const bool onchip = fits_chip && (mfma || !d.rescaling);
   const int g_tiles = mfma ? loglik_mfma_tiles(e->P, e->K) : e->tiles;
   if (reserve(e, d.T, d.gradient, !onchip)) return 1;
   const CallShape c = call_shape(e, d.T, d.gradient);
@@ -281,7 +284,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
       LikArgs g = la;
       g.eval_offset = eval_begin;
       g.grad_offset = grad_begin;
-      launch_gradient_mfma(g, count, s);
+      launch_gradient_mfma(g, count, d.rescaling, s);
       return;
     }
     if (onchip) {

@@ -135,9 +135,9 @@ bool gradient_onchip_fits(int n);
 void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s);
 // Same walk on the FP64 matrix cores, all categories per instruction (K <= 4); also
 // writes the log-likelihood partial sums, so no separate logL pass is needed.
-bool gradient_mfma_fits(int n, int K);
+bool gradient_mfma_fits(int n, int K, bool rescale);
 int gradient_mfma_width(int n);  // doubles per (gradient evaluation, tile) of its partial sums
-void launch_gradient_mfma(const LikArgs& a, int count, hipStream_t s);
+void launch_gradient_mfma(const LikArgs& a, int count, bool rescale, hipStream_t s);
 // Sum of the per-tile partials: ll_sum[e] = sum_i ll_part[e][i] for e < E,
 // g_sum[gi][2N] = sum_i g_part[gi][i][2N] for gi < Eg (fixed order: deterministic).
 struct ReduceArgs {

@@ -1587,7 +1587,7 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
 //     is made scalar for the control flow
 // LDS per wave: max_stored(n) * R * 512 B of vectors (+ edge sums, tip state masks).
 // ------------------------------------------------------------------------
-template <int R, int DBG = 0>
+template <int R, int DBG = 0, bool RESCALE = false>
 __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
   extern __shared__ double glds[];
@@ -1637,6 +1637,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   const int gwidth = max_macros(n) * kMacroPositions * 2;
   double* gacc = glds + ((n * ppr * 4 + 7) >> 3);
   double* plv = gacc + gwidth;
+  // RESCALE: per (slot, pattern) power-of-two exponent taken out of a stored vector
+  int32_t* exps = reinterpret_cast<int32_t*>(plv + (size_t)max_stored(n) * R * kTile);
   {
     // tip staging without divisions: the 64 lanes are (taxon group, pattern column) with
     // the column count rounded up to a power of two (TP = 4R, 8R or 16R, R <= 4)
@@ -1770,6 +1772,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   };
 
   double qroot[R];  // root pre-order vector: pi * category weight * w_p / site likelihood
+  int esum[R];      // RESCALE: exponents removed so far, per pattern
+#pragma unroll
+  for (int r = 0; r < R; r++) esum[r] = 0;
   // Operands of one macro: issued (LDS reads) before the next macro's matrices are
   // requested, consumed afterwards.
   struct Ops {
@@ -1783,6 +1788,12 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
         for (int r = 0; r < R; r++) o.q.v[r] = qroot[r];
       } else {
         o.q = load_slot(sl.q);
+        if (RESCALE) {
+#pragma unroll
+          for (int r = 0; r < R; r++)
+            o.q.v[r] = ldexp(o.q.v[r], -exps[__umul24((unsigned)sl.q, (unsigned)TP) +
+                                              (unsigned)(r * ppr + col)]);
+        }
       }
     }
     if (kind0(sh) == 2) {
@@ -1807,8 +1818,28 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     else L0 = o.x0;
     if (kind1(sh) == 2) L1 = mul(mm(cm.f[4], o.x1), mm(cm.f[5], o.y1));
     else L1 = o.x1;
-    const V Lv = mul(mm(cm.f[0], L0), mm(cm.f[1], L1));
+    V Lv = mul(mm(cm.f[0], L0), mm(cm.f[1], L1));
     if (!is_root(sh)) {
+      if (RESCALE) {
+        // Per-pattern power-of-two rescaling of every STORED vector (exact): the
+        // exponent of the largest entry over states and categories is removed, summed
+        // per pattern for the log-likelihood, and remembered for the pre-order walk.
+        // With L_s = L 2^-E (E = exponents removed in the subtree) and q_s = q 2^E,
+        // q_s o L_s is scale-free and q_child_s = P^T(q_s o P L_sib_s) 2^-e_parent, so the
+        // only place an exponent re-enters is where a stored node's q is read back.
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          double mx = Lv.v[r];
+          mx = fmax(mx, __shfl_xor(mx, 16, 64));
+          mx = fmax(mx, __shfl_xor(mx, 32, 64));
+          if (Kp >= 2) mx = fmax(mx, __shfl_xor(mx, 4, 64));
+          if (Kp >= 4) mx = fmax(mx, __shfl_xor(mx, 8, 64));
+          const int ex = mx > 0.0 ? ilogb(mx) : 0;
+          Lv.v[r] = ldexp(Lv.v[r], -ex);
+          esum[r] += ex;
+          exps[__umul24((unsigned)sl.q, (unsigned)TP) + (unsigned)(r * ppr + col)] = ex;
+        }
+      }
       store_slot(sl.q, Lv);
     } else {
       // root: site likelihood per pattern, log-likelihood partial, derivative weights
@@ -1821,7 +1852,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
         if (Kp >= 2) v += __shfl_xor(v, 4, 64);
         if (Kp >= 4) v += __shfl_xor(v, 8, 64);
         qroot[r] = pi_l * cw_l * (pw[r] / v);  // pw = 0 for padding patterns
-        if (hi == 0 && cat == 0 && pat[r] < a.P) ll += pw[r] * log(v);
+        if (hi == 0 && cat == 0 && pat[r] < a.P)
+          ll += pw[r] * (RESCALE ? log(v) + esum[r] * 0.69314718055994530942 : log(v));
       }
       ll = wave_sum(ll);
       if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
@@ -2288,44 +2320,48 @@ void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s) {
   }
   hipLaunchKernelGGL(gradient_onchip_kernel, dim3(a.tiles, count), dim3(kTile), lds, s, a);
 }
-size_t gradient_mfma_lds_bytes(int n, int K) {
+size_t gradient_mfma_lds_bytes(int n, int K, bool rescale) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
   const size_t tip_bytes = (((size_t)n * 4 * (16 / kp) + 7) / 8) * 8;
-  const size_t bytes =
+  size_t bytes =
       tip_bytes + sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile + gradient_mfma_width(n));
+  if (rescale) bytes += sizeof(int32_t) * (size_t)max_stored(n) * kLlR * (16 / kp);
   const size_t reach = (size_t)(2 * n - 1) * 4 * (16 / kp);  // mask fetches of internal ids
   return bytes > reach ? bytes : reach;
 }
 int gradient_mfma_width(int n) { return max_macros(n) * kMacroPositions * 2; }
-bool gradient_mfma_fits(int n, int K) {
-  return n >= 3 && K <= 4 && gradient_mfma_lds_bytes(n, K) <= 160 * 1024;
+bool gradient_mfma_fits(int n, int K, bool rescale) {
+  return n >= 3 && K <= 4 && gradient_mfma_lds_bytes(n, K, rescale) <= 160 * 1024;
 }
-void launch_gradient_mfma(const LikArgs& a_in, int count, hipStream_t s) {
+void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, hipStream_t s) {
   if (count <= 0) return;
   LikArgs a = a_in;
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
-  const size_t lds = gradient_mfma_lds_bytes(a.n, a.K);
-  static size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = lds;
+  const size_t lds = gradient_mfma_lds_bytes(a.n, a.K, rescale);
+  static size_t configured[2] = {0, 0};
+  if (lds > 64 * 1024 && lds > configured[rescale]) {
+    (void)hipFuncSetAttribute(
+        rescale ? reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR, 0, true>)
+                : reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured[rescale] = lds;
   }
-  static const int dbg = getenv("MI_PHYLO_DEBUG") ? atoi(getenv("MI_PHYLO_DEBUG")) : 0;
   const dim3 grid(loglik_mfma_tiles(a.P, a.K), count);
+  if (rescale) {
+    hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 0, true>), grid, dim3(kTile), lds, s, a);
+    return;
+  }
+  // ablation builds: 1 no matrix products, 2 no cross-lane reductions,
+  // 8 no LDS vector traffic, 16 no matrix loads, 64 prologue only, 128 post-order only
+  static const int dbg = getenv("MI_PHYLO_DEBUG") ? atoi(getenv("MI_PHYLO_DEBUG")) : 0;
   switch (dbg) {
     case 1: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 1>), grid, dim3(kTile), lds, s, a); return;
     case 2: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 2>), grid, dim3(kTile), lds, s, a); return;
-    case 4: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 4>), grid, dim3(kTile), lds, s, a); return;
     case 8: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 8>), grid, dim3(kTile), lds, s, a); return;
-    case 7: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 7>), grid, dim3(kTile), lds, s, a); return;
-    case 15: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 15>), grid, dim3(kTile), lds, s, a); return;
-    case 31: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 31>), grid, dim3(kTile), lds, s, a); return;
-    case 63: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 63>), grid, dim3(kTile), lds, s, a); return;
     case 16: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 16>), grid, dim3(kTile), lds, s, a); return;
+    case 27: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 27>), grid, dim3(kTile), lds, s, a); return;
     case 64: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 64>), grid, dim3(kTile), lds, s, a); return;
     case 128: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 128>), grid, dim3(kTile), lds, s, a); return;
-    case 256: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 256>), grid, dim3(kTile), lds, s, a); return;
     default: break;
   }
   hipLaunchKernelGGL((gradient_mfma_kernel<kLlR>), grid, dim3(kTile), lds, s, a);

@@ -28,6 +28,19 @@ def test_header_symbols_are_exported_and_bound():
     assert lib.mi_abi_version() == 1
 
 
+def test_library_has_no_unresolved_internal_symbols():
+    """ctypes binds lazily, so a launcher that was declared but never defined would only
+    show up when a C++ caller links against the library: check the dynamic symbol table."""
+    import subprocess
+    for name in ("libmi_phylo.so", "libmi_phylo_host.so"):
+        path = os.path.join(REPO, "libsbn_amd", name)
+        out = subprocess.run(["nm", "-D", "-u", "-C", path], capture_output=True, text=True,
+                             check=True).stdout
+        internal = [line for line in out.splitlines() if "miphylo::" in line or " mih_" in line
+                    or " mi_" in line]
+        assert not internal, f"{name}: unresolved internal symbols: {internal}"
+
+
 def test_spec_struct_layout_matches_header():
     from libsbn_amd import _capi
     assert ctypes.sizeof(_capi.EngineSpec) == 40  # ten int32 fields

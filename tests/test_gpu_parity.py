@@ -340,6 +340,30 @@ def test_rescaling_rescues_underflow():
         assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t], 1e-9)
 
 
+def test_rescaled_gradients_stay_on_the_matrix_core_kernel():
+    """rescaling=True must not fall back to the HBM-streamed kernel when the tree fits on
+    chip: the matrix-core kernel rescales its stored vectors by exact powers of two, so
+    rescaled and unrescaled results agree to rounding."""
+    st = O.load_struct("ds1_sub10")
+    tips, w, pids, bls = O.struct_arrays(st)
+    eng = _engine("JC69", "weibull+4", "strict", tips, w)
+    spec = O.make_spec(27, 934, "JC69", "weibull+4")
+    pr = _params(spec, len(pids), **{"Weibull shape": np.full((len(pids), 1), 0.8)})
+    plain = eng.gradients(pids, bls, pr, False)
+    assert eng.last_call_info()[0] == "gradient_mfma_kernel"
+    scaled = eng.gradients(pids, bls, pr, True)
+    assert eng.last_call_info()[0] == "gradient_mfma_kernel"
+    og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, True, 4)
+    for t in range(len(pids)):
+        assert abs(scaled[t].log_likelihood - plain[t].log_likelihood) <= \
+            1e-12 * abs(plain[t].log_likelihood)
+        assert _close(scaled[t].gradient["branch_lengths"], plain[t].gradient["branch_lengths"],
+                      1e-11)
+        assert _close(scaled[t].gradient["branch_lengths"], og["branch_lengths"][t])
+        assert abs(scaled[t].gradient["site_model"][0] - og["site_model"][t]) <= \
+            1e-9 * max(1.0, abs(og["site_model"][t]))
+
+
 def test_mfma_loglik_path_matches_oracle():
     """The opt-in matrix-core log-likelihood kernel (v_mfma_f64_4x4x4_4b_f64): same
     parity bar.  The path is chosen once per process, hence the subprocess."""

@@ -868,7 +868,16 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
     const double* c = lds + slot * 4 * kTile + lane;
     return D4{c[0], c[kTile], c[2 * kTile], c[3 * kTile]};
   };
-  auto mat = [&](int node, int k) { return as_const(mats_e + ((size_t)node * K + k) * 16); };
+  // Addresses are "per-category base + 32-bit byte offset of the node": one scalar
+  // multiply per address instead of 64-bit index arithmetic (which was most of the
+  // scalar work of a visit).
+  const unsigned node_bytes = (unsigned)K * 128u, tab_bytes = (unsigned)K * 160u;
+  const char* mats_k = reinterpret_cast<const char*>(mats_e);  // advanced per category
+  const char* tabs_k = reinterpret_cast<const char*>(tabs_e);
+  auto mat = [&](int node) {
+    return as_const(reinterpret_cast<const double*>(
+        __builtin_assume_aligned(mats_k + (unsigned)node * node_bytes, 128)));
+  };
   // What the tip children of a visit contribute is fetched one visit ahead:
   // compact states -> one 32-byte gather from the tip table (column of P, no
   // arithmetic); tip partials -> the partial vector itself.
@@ -883,21 +892,23 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
       d.v[1] = load4(a.tip_partials + ((size_t)c1 * a.P + pc) * 4);
     } else {
       const int st0 = tips[c0 * kTile + lane], st1 = tips[c1 * kTile + lane];
-      d.v[0] = load4(tabs_e + ((size_t)c0 * K + k) * 20 + st0 * 4);
-      d.v[1] = load4(tabs_e + ((size_t)c1 * K + k) * 20 + st1 * 4);
+      d.v[0] = load4(reinterpret_cast<const double*>(
+          tabs_k + ((unsigned)c0 * tab_bytes + (unsigned)st0 * 32u)));
+      d.v[1] = load4(reinterpret_cast<const double*>(
+          tabs_k + ((unsigned)c1 * tab_bytes + (unsigned)st1 * 32u)));
     }
     return d;
   };
   auto touch = [&](const SchedEntry& s, int k) {
-    const cint_ptr a0 = (cint_ptr)(uintptr_t)(mats_e + ((size_t)s.child0 * K + k) * 16);
-    const cint_ptr a1 = (cint_ptr)(uintptr_t)(mats_e + ((size_t)s.child1 * K + k) * 16);
+    const cint_ptr a0 = (cint_ptr)(uintptr_t)(mats_k + (unsigned)s.child0 * node_bytes);
+    const cint_ptr a1 = (cint_ptr)(uintptr_t)(mats_k + (unsigned)s.child1 * node_bytes);
     return a0[0] ^ a0[16] ^ a1[0] ^ a1[16];
   };
   int touched = 0;
 
   double site = 0.0;
   int site_exp = 0;
-  for (int k = 0; k < K; k++) {
+  for (int k = 0; k < K; k++, mats_k += 128, tabs_k += 160) {
     int cum_exp = 0;
     D4 L = {0, 0, 0, 0};
     SchedEntry s_cur = sched[0];
@@ -908,8 +919,8 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
       asm volatile("" ::"s"(touched));
       touched = touch(s_nxt, k);
       const TipPre tdn = fetch_tip(s_nxt, k);
-      const cdouble_ptr M0 = mat(s_cur.child0, k);
-      const cdouble_ptr M1 = mat(s_cur.child1, k);
+      const cdouble_ptr M0 = mat(s_cur.child0);
+      const cdouble_ptr M1 = mat(s_cur.child1);
       const bool tip0 = s_cur.child0 < n, tip1 = s_cur.child1 < n;
       // PLV columns are read unconditionally (slot 0 for a tip), before any branch
       const D4 c0 = load_slot(tip0 ? 0 : (s_cur.slots >> 8) & 0xff);

@@ -330,27 +330,38 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.g_part = e->g_part.as<double>();
 
   la.site_lik = nullptr;
-  auto grad_range = [&](int eval_begin, int grad_begin, int count) {
-    if (mfma) {
-      LikArgs g = la;
-      g.eval_offset = eval_begin;
-      g.grad_offset = grad_begin;
-      launch_gradient_mfma(g, count, d.rescaling, s);
-      return;
+  // one launch covers at most kMaxEvals evaluations (grid y dimension: 65535; a multiple
+  // of 8 keeps whole evaluations per XCD)
+  constexpr int kMaxEvals = 32768;
+  auto loglik_range = [&](int eval_begin, int count) {
+    for (int done = 0; done < count; done += kMaxEvals) {
+      LikArgs l = la;
+      l.eval_offset = eval_begin + done;
+      launch_loglik(l, std::min(kMaxEvals, count - done), d.rescaling, e->max_slots, s);
     }
-    if (onchip) {
-      // phase A: on-chip log-likelihood (also writes per-pattern site likelihoods),
-      // phase B: on-chip pre-order / edge derivatives
-      LikArgs g = la;
-      g.eval_offset = eval_begin;
-      g.grad_offset = grad_begin;
-      g.site_lik = e->site_lik.as<double>();
-      launch_loglik(g, count, false, e->max_slots, s);
-      launch_gradient_onchip(g, count, s);
+  };
+  auto grad_range = [&](int eval_begin, int grad_begin, int count) {
+    if (mfma || onchip) {
+      for (int done = 0; done < count; done += kMaxEvals) {
+        const int part = std::min(kMaxEvals, count - done);
+        LikArgs g = la;
+        g.eval_offset = eval_begin + done;
+        g.grad_offset = grad_begin + done;
+        if (mfma) {
+          launch_gradient_mfma(g, part, d.rescaling, s);
+        } else {
+          // phase A: on-chip log-likelihood (also writes per-pattern site likelihoods),
+          // phase B: on-chip pre-order / edge derivatives
+          g.site_lik = e->site_lik.as<double>();
+          launch_loglik(g, part, false, e->max_slots, s);
+          launch_gradient_onchip(g, part, s);
+        }
+      }
       return;
     }
     const size_t per = plv_bytes_per_eval(e);
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(count, e->plv.bytes / per));
+    const int chunk = (int)std::max<size_t>(
+        1, std::min<size_t>(std::min(count, kMaxEvals), e->plv.bytes / per));
     for (int done = 0; done < count; done += chunk) {
       LikArgs g = la;
       g.eval_offset = eval_begin + done;
@@ -362,17 +373,14 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool prof = e->prof_used < e->prof_capacity;
   if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used], s));
   if (!d.gradient) {
-    la.eval_offset = 0;
-    launch_loglik(la, T, d.rescaling, e->max_slots, s);
+    loglik_range(0, T);
     e->dominant = loglik_kernel_name();
     if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used + 1], s));
   } else {
     grad_range(0, 0, T);
     if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used + 1], s));
     if (c.gtr) {
-      LikArgs l = la;
-      l.eval_offset = T;
-      launch_loglik(l, 16 * T, d.rescaling, e->max_slots, s);
+      loglik_range(T, 16 * T);
     }
     if (c.site_separate) grad_range(17 * T, T, T);
     e->dominant = mfma ? gradient_mfma_kernel_name()

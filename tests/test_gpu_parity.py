@@ -340,6 +340,30 @@ def test_rescaling_rescues_underflow():
         assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t], 1e-9)
 
 
+def test_batches_larger_than_one_launch():
+    """More evaluations than one kernel launch can address (grid y <= 65535): the engine
+    splits the batch; every tree still gets its own result, in tree order."""
+    rng = np.random.default_rng(77)
+    n, P, T = 5, 10, 70001
+    tips, w = TU.random_alignment(n, P, rng)
+    base_p, base_b = TU.random_trees(n, 16, rng)
+    idx = rng.integers(0, 16, size=T)
+    pids = base_p[idx]
+    bls = base_b[idx] * rng.uniform(0.5, 1.5, size=(T, 1))
+    eng = _engine("JC69", "constant", "strict", tips, w)
+    spec = O.make_spec(n, P)
+    pr = _params(spec, T)
+    ll = eng.log_likelihoods(pids, bls, pr)
+    oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, False, 8)
+    assert np.all(np.abs(ll - oll) <= RTOL * np.abs(oll))
+    g = eng.gradients(pids, bls, pr)
+    og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, False, 8)
+    got = np.array([x.gradient["branch_lengths"] for x in g])
+    scale = np.max(np.abs(og["branch_lengths"]), axis=1, keepdims=True)
+    assert np.all(np.abs(got - og["branch_lengths"]) <= RTOL * np.maximum(scale, 1e-300))
+    assert np.all(np.abs(np.array([x.log_likelihood for x in g]) - oll) <= RTOL * np.abs(oll))
+
+
 def test_rescaled_gradients_stay_on_the_matrix_core_kernel():
     """rescaling=True must not fall back to the HBM-streamed kernel when the tree fits on
     chip: the matrix-core kernel rescales its stored vectors by exact powers of two, so

@@ -273,6 +273,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ts.bl_eff = e->bl_eff.as<double>();
   ts.status = e->status.as<int32_t>();
   ts.max_slots = e->max_slots;
+  // the Sethi-Ullman schedule with LDS slots is what the log-likelihood kernels walk
+  ts.need_slots = !(d.gradient && mfma && !c.gtr);
   launch_tree_setup(ts, s);
 
   ModelSetupArgs ms{};

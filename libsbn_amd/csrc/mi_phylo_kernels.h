@@ -43,7 +43,8 @@ struct TreeSetupArgs {
   double* bl_eff;             // [T][N]
   int32_t* status;            // [2]: code, tree
   int max_slots;
-  int use_lds;  // set by the launcher
+  int use_lds;     // set by the launcher
+  int need_slots;  // 0: no log-likelihood kernel will run on this batch (node-id order, no LDS slots)
 };
 
 struct ModelSetupArgs {

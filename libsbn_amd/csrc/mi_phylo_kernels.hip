@@ -422,8 +422,17 @@ __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
         c1 = r;
       }
     }
+    if (!a.need_slots) {
+      // only the matrix-core gradient kernel and finalize will read this tree: the
+      // node-id order (already a post-order) with no slot assignment is enough, and it
+      // needs no sequential walk
+      s_node = n + lane;
+      s_c0 = __shfl(c0, n + lane, 64);
+      s_c1 = __shfl(c1, n + lane, 64);
+      s_sl = 0;
+    }
     // Sethi-Ullman labels (tips cost nothing: they are read in compact form).
-    for (int v = n; v < N; v++) {
+    for (int v = n; a.need_slots && v < N; v++) {
       const int l0 = RDL(label, RDL(c0, v)), l1 = RDL(label, RDL(c1, v));
       WRL(label, v, l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1));
     }
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
     };
     uint32_t free_mask = 0xffffffffu;
     int top = 0, out = 0, used_max = 0;
-    push(top++, (N - 1) << 1);
+    if (a.need_slots) push(top++, (N - 1) << 1);
     while (top) {
       --top;
       const int item = top < 64 ? RDL(stk_lo, top) : RDL(stk_hi, top - 64);

@@ -156,6 +156,7 @@ def main():
     d_site = torch.zeros(T, dtype=torch.float64, device=dev)
     d_g = torch.zeros((T, N), dtype=torch.float64, device=dev)
     gathered = [None]
+    pending = [None]  # all-gather in flight
     grad = args.mode == "gradient"
     eng.reserve(T, grad)
     stream = torch.cuda.current_stream().cuda_stream
@@ -168,12 +169,24 @@ def main():
             eng.log_likelihoods_device(stream, T, d_pid.data_ptr(), d_bl.data_ptr(),
                                        d_par.data_ptr(), d_ll.data_ptr())
         if distributed:
-            # the one collective of the call: every rank's per-tree results, tree order
+            # the one collective of the call: every rank's per-tree results, tree order.
+            # It is enqueued asynchronously (RCCL's stream) from a private copy of the
+            # results, so it overlaps the next step's kernels; its result is collected
+            # one step later (and, for the last step, before the timed region ends).
             packed = sharding.pack_results(d_ll, [d_site, d_g])
-            gathered[0] = sharding.all_gather_trees(packed, world * T)
+            handle = sharding.all_gather_trees(packed, world * T, async_op=True)
+            if pending[0] is not None:
+                gathered[0] = pending[0].result()
+            pending[0] = handle
+
+    def drain():
+        if pending[0] is not None:
+            gathered[0] = pending[0].result()
+            pending[0] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     eng.check_status(stream)
     torch.cuda.synchronize()
     if distributed:
@@ -183,6 +196,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()

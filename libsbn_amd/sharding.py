@@ -31,11 +31,35 @@ def pack_results(log_likelihoods, columns):
     return torch.cat(parts, dim=1).contiguous()
 
 
-def all_gather_trees(local, tree_count, group=None):
+class GatheredTrees:
+    """Handle of one all_gather_trees call.  `result()` waits for the collective (on the
+    current stream) and returns the [tree_count, C] rows in tree order."""
+
+    def __init__(self, work, out, keep, sizes, width):
+        self._work, self._out, self._keep = work, out, keep
+        self._sizes, self._width = sizes, width
+
+    def result(self):
+        import torch
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._keep = None
+        out, sizes, width = self._out, self._sizes, self._width
+        if all(s == width for s in sizes):
+            return out
+        rows = [out[r * width:r * width + sizes[r]] for r in range(len(sizes))]
+        return torch.cat(rows, dim=0)
+
+
+def all_gather_trees(local, tree_count, group=None, async_op=False):
     """All-gather per-tree rows of every rank, back into tree order.
 
     local: [T_local, C] tensor of this rank (rows of its tree_shard).  Uneven shards
     are padded to the largest one so that a single all_gather_into_tensor is enough.
+    With async_op=True the collective is only enqueued (RCCL runs it on its own stream,
+    so it overlaps whatever the caller launches next) and a GatheredTrees handle is
+    returned; otherwise the gathered tensor.
     """
     import torch
     import torch.distributed as dist
@@ -47,12 +71,11 @@ def all_gather_trees(local, tree_count, group=None):
     if local.shape[0] < width:
         padded = torch.zeros((width, C), dtype=local.dtype, device=local.device)
         padded[:local.shape[0]] = local
+    padded = padded.contiguous()
     out = torch.empty((world * width, C), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
-    if all(s == width for s in sizes):
-        return out
-    rows = [out[r * width:r * width + sizes[r]] for r in range(world)]
-    return torch.cat(rows, dim=0)
+    work = dist.all_gather_into_tensor(out, padded, group=group, async_op=async_op)
+    handle = GatheredTrees(work if async_op else None, out, padded, sizes, width)
+    return handle if async_op else handle.result()
 
 
 def all_reduce_step_terms(log_likelihoods, branch_gradients, branch_index, parameter_count,

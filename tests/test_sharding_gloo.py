@@ -61,6 +61,9 @@ def _worker(rank, world, port, T, out_dir):
     assert (batch.lo, batch.hi) == S.tree_shard(T, rank, world)
     gathered = batch.run(compute)
     assert gathered.shape == (T, 55)
+    # the asynchronous form (what bench.py overlaps with the next step) gives the same rows
+    handle = S.all_gather_trees(compute(batch.lo, batch.hi), T, async_op=True)
+    assert torch.equal(handle.result(), gathered)
     # the fused step reduction: sum of log-likelihoods + scatter-add of branch gradients by
     # (here: synthetic) split index, one all-reduce
     local = compute(batch.lo, batch.hi)

@@ -139,11 +139,12 @@ struct mi_engine {
   // static device data
   Buffer tip_states, tip_partials, weights;
   // per-call workspace
-  Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, ll_part, plv, g_part, site_lik, fin_scratch,
+  Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, x_sum, ll_part, plv, g_part, site_lik, fin_scratch,
       ll_sum, g_sum, status;
   PinnedArena pinned;
   bool allow_onchip_gradient = true;
   bool prefer_mfma_gradient = true;  // matrix-core gradient kernel when K <= 4 and it fits
+  bool analytic_subst = false;       // MI_PHYLO_SUBST_GRADIENT=analytic (opt-in)
   int gradient_path = 0;  // 0 auto, 1 valu on-chip, 2 hbm, 3 mfma
   // staging for the host-pointer entry points
   Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
@@ -164,18 +165,22 @@ struct CallShape {
   bool gradient, gtr, site_fused, site_separate;
 };
 
-CallShape call_shape(const mi_engine* e, int T, bool gradient) {
+// analytic: the opt-in analytic substitution gradient replaces the 16 finite-difference
+// evaluations (and with them the perturbed-model site pass): one gradient evaluation per
+// tree, as for JC69.
+CallShape call_shape(const mi_engine* e, int T, bool gradient, bool analytic = false) {
   CallShape c{};
   c.T = T;
   c.gradient = gradient;
   c.gtr = e->spec.subst_model == MI_SUBST_GTR;
-  c.site_fused = gradient && e->K > 1 && !c.gtr;
-  c.site_separate = gradient && e->K > 1 && c.gtr;
-  c.models_per_tree = (gradient && c.gtr) ? kFdModels : 1;
+  const bool fd = gradient && c.gtr && !analytic;
+  c.site_fused = gradient && e->K > 1 && !fd;
+  c.site_separate = gradient && e->K > 1 && fd;
+  c.models_per_tree = fd ? kFdModels : 1;
   c.M = T * c.models_per_tree;
   c.E = T;
   c.Eg = gradient ? T : 0;
-  if (gradient && c.gtr) c.E += 16 * T;
+  if (fd) c.E += 16 * T;
   if (c.site_separate) {
     c.E += T;
     c.Eg += T;
@@ -187,8 +192,9 @@ size_t plv_bytes_per_eval(const mi_engine* e) {
   return (size_t)(e->n - 1) * e->K * e->tiles * kTile * 4 * sizeof(double);
 }
 
-int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
-  const CallShape c = call_shape(e, T, gradient);
+int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
+            bool analytic = false) {
+  const CallShape c = call_shape(e, T, gradient, analytic);
   const int n = e->n, N = e->N;
   if (e->tree_scratch.ensure(sizeof(int32_t) * (size_t)T * 13 * N)) return 1;
   if (e->sched.ensure(sizeof(SchedEntry) * (size_t)T * (n - 1))) return 1;
@@ -199,6 +205,8 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
   if (e->mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
   if (e->tip_tables.ensure(sizeof(double) * (size_t)c.E * n * e->K * 20)) return 1;
   if (gradient && e->tr_mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
+  if (analytic && e->phi.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
+  if (analytic && e->x_sum.ensure(sizeof(double) * (size_t)c.Eg * kSubstExtra)) return 1;
   if (e->ll_part.ensure(sizeof(double) * (size_t)c.E * e->ll_stride)) return 1;
   if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
   if (e->status.ensure(sizeof(int32_t) * 2)) return 1;
@@ -210,7 +218,7 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true) {
     const size_t per = plv_bytes_per_eval(e);
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / per));
     if (need_hbm_path && e->plv.ensure(per * chunk)) return 1;
-    const size_t g_width = std::max<size_t>(2 * (size_t)N, (size_t)gradient_mfma_width(n));
+    const size_t g_width = std::max<size_t>(2 * (size_t)N, (size_t)gradient_mfma_width(n, true));
     if (e->g_part.ensure(sizeof(double) * (size_t)c.Eg * e->ll_stride * g_width)) return 1;
     if (e->site_lik.ensure(sizeof(double) * (size_t)c.Eg * e->tiles * kTile)) return 1;
   }
@@ -250,8 +258,9 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
                     (e->gradient_path == 3 || e->prefer_mfma_gradient);
   const bool onchip = fits_chip && (mfma || !d.rescaling);
   const int g_tiles = mfma ? loglik_mfma_tiles(e->P, e->K) : e->tiles;
-  if (reserve(e, d.T, d.gradient, !onchip)) return 1;
-  const CallShape c = call_shape(e, d.T, d.gradient);
+  const bool analytic = e->analytic_subst && mfma && e->spec.subst_model == MI_SUBST_GTR;
+  if (reserve(e, d.T, d.gradient, !onchip, analytic)) return 1;
+  const CallShape c = call_shape(e, d.T, d.gradient, analytic);
   const int n = e->n, N = e->N, T = d.T;
   HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, s));
   // kernels write different numbers of logL partial sums per evaluation; unused ones stay 0
@@ -274,7 +283,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ts.status = e->status.as<int32_t>();
   ts.max_slots = e->max_slots;
   // the Sethi-Ullman schedule with LDS slots is what the log-likelihood kernels walk
-  ts.need_slots = !(d.gradient && mfma && !c.gtr);
+  ts.need_slots = !(d.gradient && mfma && (!c.gtr || analytic));
   launch_tree_setup(ts, s);
 
   ModelSetupArgs ms{};
@@ -302,9 +311,10 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   tr.bl_eff = e->bl_eff.as<double>();
   tr.mats = e->mats.as<double>();
   // the per-state tip tables feed the VALU walk kernels only
-  const bool need_tip_tables = !(d.gradient && mfma && !c.gtr);
+  const bool need_tip_tables = !(d.gradient && mfma && (!c.gtr || analytic));
   tr.tip_tables = need_tip_tables ? e->tip_tables.as<double>() : nullptr;
   tr.tr_mats = mfma ? e->tr_mats.as<double>() : nullptr;
+  tr.phi = analytic ? e->phi.as<double>() : nullptr;
   tr.n = n;
   launch_transition(tr, s);
 
@@ -324,6 +334,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.mats = e->mats.as<double>();
   la.tip_tables = e->tip_tables.as<double>();
   la.tr_mats = e->tr_mats.as<double>();
+  la.phi = e->phi.as<double>();
   la.tip_states = e->tip_states.as<int8_t>();
   la.tip_partials = e->spec.use_tip_states ? nullptr : e->tip_partials.as<double>();
   la.weights = e->weights.as<double>();
@@ -350,7 +361,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
         g.eval_offset = eval_begin + done;
         g.grad_offset = grad_begin + done;
         if (mfma) {
-          launch_gradient_mfma(g, part, d.rescaling, s);
+          launch_gradient_mfma(g, part, d.rescaling, analytic, s);
         } else {
           // phase A: on-chip log-likelihood (also writes per-pattern site likelihoods),
           // phase B: on-chip pre-order / edge derivatives
@@ -381,7 +392,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   } else {
     grad_range(0, 0, T);
     if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used + 1], s));
-    if (c.gtr) {
+    if (c.gtr && !analytic) {
       loglik_range(T, 16 * T);
     }
     if (c.site_separate) grad_range(17 * T, T, T);
@@ -414,7 +425,9 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     ra.g_part = e->g_part.as<double>();
     ra.ll_sum = e->ll_sum.as<double>();
     ra.g_sum = e->g_sum.as<double>();
-    ra.g_width = (d.gradient && mfma) ? gradient_mfma_width(n) : 0;
+    ra.g_width = (d.gradient && mfma) ? gradient_mfma_width(n, analytic) : 0;
+    ra.extra = analytic ? kSubstExtra : 0;
+    ra.x_sum = e->x_sum.as<double>();
     ra.n = n;
     ra.T = T;
     ra.macros = e->macros.as<MacroEntry>();
@@ -428,7 +441,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   fa.gradient = d.gradient;
   fa.rooted = d.rooted;
   fa.with_jacobian = d.with_jacobian;
-  fa.gtr = c.gtr;
+  fa.gtr = c.gtr && !analytic;  // finite-difference assembly of the substitution gradient
   fa.site_fused = c.site_fused;
   fa.site_separate = c.site_separate;
   fa.bl_eff = e->bl_eff.as<double>();
@@ -448,6 +461,18 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   fa.out_subst = d.out_subst;
   fa.status = e->status.as<int32_t>();
   launch_finalize(fa, s);
+  if (analytic && d.out_subst) {
+    SubstGradArgs sg{};
+    sg.T = T;
+    sg.param_count = e->param_count;
+    sg.rates_off = e->rates_off;
+    sg.freqs_off = e->freqs_off;
+    sg.params = d.params;
+    sg.models = e->models.as<DevModel>();
+    sg.x_sum = e->x_sum.as<double>();
+    sg.out_subst = d.out_subst;
+    launch_subst_gradient(sg, s);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -555,6 +580,8 @@ int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
   while ((2 << lg) <= e->n) lg++;
   e->max_slots = lg + 1;
   if (const char* env = getenv("MI_PHYLO_PLV_BYTES")) e->plv_budget = strtoull(env, nullptr, 10);
+  if (const char* env = getenv("MI_PHYLO_SUBST_GRADIENT"))
+    e->analytic_subst = std::string(env) == "analytic";
   if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH")) {  // force one gradient kernel
     const std::string v(env);
     e->gradient_path = v == "valu" ? 1 : v == "hbm" ? 2 : v == "mfma" ? 3 : 0;
@@ -631,7 +658,7 @@ void mi_engine_destroy(mi_engine* e) {
   }
   for (Buffer* b :
        {&e->tip_states, &e->tip_partials, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
-        &e->macro_count, &e->tip_tables, &e->tr_mats, &e->bl_eff,
+        &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->fin_scratch,
         &e->ll_sum, &e->g_sum, &e->status,
         &e->in_parent, &e->in_bl, &e->in_params, &e->in_rates, &e->in_rate_counts,

@@ -64,6 +64,7 @@ struct TransitionArgs {
   double* mats;          // [E][N-1][K][16]
   double* tip_tables;    // [E][n][K][5][4]: per tip edge and state (4 = gap), the column of P; may be nullptr
   double* tr_mats;       // [E][N-1][K][4][4]: matrix of the matrix-core pre-order step (P, or (P Q)^T for tips); may be nullptr
+  double* phi;           // [E][N-1][K][4][4]: divided differences of exp(lambda r t) (analytic substitution gradient); may be nullptr
   int n;
 };
 
@@ -84,6 +85,7 @@ struct LikArgs {
   const double* mats;
   const double* tip_tables;    // see TransitionArgs
   const double* tr_mats;       // see TransitionArgs
+  const double* phi;           // see TransitionArgs
   const int8_t* tip_states;    // [n][P]
   const double* tip_partials;  // [n][P][4] or nullptr
   const double* weights;       // [P]
@@ -137,8 +139,9 @@ void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s);
 // Same walk on the FP64 matrix cores, all categories per instruction (K <= 4); also
 // writes the log-likelihood partial sums, so no separate logL pass is needed.
 bool gradient_mfma_fits(int n, int K, bool rescale);
-int gradient_mfma_width(int n);  // doubles per (gradient evaluation, tile) of its partial sums
-void launch_gradient_mfma(const LikArgs& a, int count, bool rescale, hipStream_t s);
+// subst: analytic substitution gradient statistics appended (kSubstExtra doubles)
+int gradient_mfma_width(int n, bool subst = false);  // doubles per (gradient evaluation, tile) of its partial sums
+void launch_gradient_mfma(const LikArgs& a, int count, bool rescale, bool subst, hipStream_t s);
 // Sum of the per-tile partials: ll_sum[e] = sum_i ll_part[e][i] for e < E,
 // g_sum[gi][2N] = sum_i g_part[gi][i][2N] for gi < Eg (fixed order: deterministic).
 struct ReduceArgs {
@@ -153,7 +156,23 @@ struct ReduceArgs {
   int g_width, n, T;
   const MacroEntry* macros;
   const int32_t* macro_count;
+  // the last `extra` doubles of each positional row are plain sums (analytic substitution
+  // gradient: 64 + 4), reduced into x_sum[Eg][extra]
+  int extra;
+  double* x_sum;
 };
+
+// Analytic substitution-model gradient (opt-in): one thread per tree turns the reduced
+// statistics into d logL / d (stick-breaking coordinates), 5 rate then 3 frequency ones.
+struct SubstGradArgs {
+  int T, param_count, rates_off, freqs_off;
+  const double* params;   // [T][param_count]
+  const DevModel* models; // [T] (one model per tree in this mode)
+  const double* x_sum;    // [T][68]
+  double* out_subst;      // [T][8]
+};
+void launch_subst_gradient(const SubstGradArgs& a, hipStream_t s);
+constexpr int kSubstExtra = 68;
 bool reduce_tiles_fits(int N);
 void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s);
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);

@@ -839,6 +839,32 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
     for (int x = threadIdx.x; x < count; x += kTransitionBlock)
       out2[x] = stage[(x >> 4) * 17 + (x & 15)];
   }
+  if (a.phi != nullptr) {
+    // Analytic substitution gradient: d exp(Q tau) = V ((V^-1 dQ V) o Phi) V^-1 with the
+    // divided differences Phi_ij = (e^{l_i tau} - e^{l_j tau}) / (l_i - l_j), Phi_ii =
+    // tau e^{l_i tau}, tau = r_k t.  Evaluated as tau e^{l_j tau} expm1(x)/x, x = (l_i -
+    // l_j) tau, which is stable for close and for equal eigenvalues.
+    __syncthreads();
+    if (idx < total) {
+      const int k = idx % a.K;
+      const int edge = (idx / a.K) % (a.N - 1);
+      const int e = idx / ((long)a.K * (a.N - 1));
+      int t, mi;
+      a.map.decode(e, t, mi);
+      const DevModel& m = a.models[mi];
+      const double tau = m.cat_rate[k] * a.bl_eff[(size_t)t * a.N + edge];
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+          const double x = (m.lambda[i] - m.lambda[j]) * tau;
+          const double r = fabs(x) < 1e-5 ? 1.0 + 0.5 * x + x * x * (1.0 / 6.0) : expm1(x) / x;
+          stage[threadIdx.x * 17 + i * 4 + j] = tau * exp(m.lambda[j] * tau) * r;
+        }
+    }
+    __syncthreads();
+    double* out3 = a.phi + first * 16;
+    for (int x = threadIdx.x; x < count; x += kTransitionBlock)
+      out3[x] = stage[(x >> 4) * 17 + (x & 15)];
+  }
 }
 
 // ------------------------------------------------------------------------
@@ -1607,7 +1633,7 @@ __global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
 //     is made scalar for the control flow
 // LDS per wave: max_stored(n) * R * 512 B of vectors (+ edge sums, tip state masks).
 // ------------------------------------------------------------------------
-template <int R, int DBG = 0, bool RESCALE = false>
+template <int R, int DBG = 0, bool RESCALE = false, bool SUBST = false>
 __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
   extern __shared__ double glds[];
@@ -1628,6 +1654,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       reinterpret_cast<const char*>(a.mats + (size_t)e * (N - 1) * K * 16);
   const char* __restrict__ trm_e =
       reinterpret_cast<const char*>(a.tr_mats + (size_t)e * (N - 1) * K * 16);
+  const char* __restrict__ phi_e =
+      SUBST ? reinterpret_cast<const char*>(a.phi + (size_t)e * (N - 1) * K * 16) : nullptr;
   const MacroEntry* __restrict__ macros = a.macros + (size_t)t * max_macros(n);
   const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
   // byte offsets inside one node's K matrices
@@ -1654,7 +1682,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   // internal node id lands in valid memory without clamping: N * 4 * ppr bytes from
   // the start is always inside the allocation.
   uint8_t* tips = reinterpret_cast<uint8_t*>(glds);
-  const int gwidth = max_macros(n) * kMacroPositions * 2;
+  const int gwidth = max_macros(n) * kMacroPositions * 2 + (SUBST ? kSubstExtra : 0);
   double* gacc = glds + ((n * ppr * 4 + 7) >> 3);
   double* plv = gacc + gwidth;
   // RESCALE: per (slot, pattern) power-of-two exponent taken out of a stored vector
@@ -1757,6 +1785,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   // tip state masks of this lane's column, fetched a macro ahead
   struct MacroMats {
     double f[6], tr[6];
+    double ph[SUBST ? 6 : 1];  // SUBST: divided differences Phi of the six edges
     uint32_t tw[6];
   };
   const unsigned tt_delta = t_off - f_off;
@@ -1777,6 +1806,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       } else {
         mt.f[j] = *reinterpret_cast<const double*>(mats_e + vf);
         mt.tr[j] = *reinterpret_cast<const double*>(trm_e + vt);
+        if (SUBST) mt.ph[j] = *reinterpret_cast<const double*>(phi_e + vt);
       }
       mt.tw[j] = *reinterpret_cast<const uint32_t*>(
           tips + (__umul24((unsigned)nodes[j], (unsigned)(ppr * 4)) + col4));
@@ -1877,6 +1907,19 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       }
       ll = wave_sum(ll);
       if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
+      if (SUBST) {
+        // d logL / d pi_c through the root: sum_p w_p sum_k cw_k L_root[c] / site_p;
+        // this lane's state is c = hi, the 16 lanes of a row hold (category, pattern)
+        double z = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) z += qroot[r] * Lv.v[r];  // qroot = pi cw w / site
+        z = z / pi_l;
+        z = row_shr_add<8>(z);
+        z = row_shr_add<4>(z);
+        z = row_shr_add<2>(z);
+        z = row_shr_add<1>(z);
+        if ((lane & 15) == 15) gacc[gwidth - 4 + hi] = z;
+      }
     }
   };
   {
@@ -1925,6 +1968,29 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       *reinterpret_cast<double*>(dst + red_off) = red;
     }
   };
+  // ---- analytic substitution gradient (SUBST) ----
+  // d logL = sum over edges, categories of <G, dP> with G = sum_p u L_c^T (u = q_parent o
+  // sibling product, carrying the pattern / category weights).  With P = V e^{L tau} V^-1:
+  // <G, dP> = <(V^T G V^-T) o Phi, V^-1 dQ V>, so one 4x4 per category,
+  //   H = sum_edges (V^T G V^-T) o Phi,
+  // accumulated in ONE register over the whole walk, is all the model gradient needs
+  // (subst_gradient_kernel finishes: dlogL/dQ = V^-T H V^T, chain rule to the
+  // parameters).  G is a matrix product over patterns, i.e. matrix-core work: operands
+  // are the 4x4-block transposes of u and L_c (lane (hi, lo) <-> (lo, hi)).
+  const int tr_lane = 16 * lo + 4 * b + hi;
+  auto blockT = [&](double x) { return __shfl(x, tr_lane, 64); };
+  const double AVt = SUBST ? model->V[hi * 4 + lo] : 0.0;     // A operand V^T: A[i][k] = V[k][i]
+  const double AVi = SUBST ? model->Vinv[lo * 4 + hi] : 0.0;  // A operand V^-1
+  double Ht = 0.0;  // (hi = i, lo = j) holds H^T[i][j] of this block's category
+  auto subst_stats = [&](const V& u, const V& Lc, double phi) {
+    double G = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      G = __builtin_amdgcn_mfma_f64_4x4x4f64(blockT(u.v[r]), blockT(Lc.v[r]), G, 0, 0, 0);
+    const double R1 = __builtin_amdgcn_mfma_f64_4x4x4f64(AVt, G, 0.0, 0, 0, 0);            // V^T G
+    const double R2 = __builtin_amdgcn_mfma_f64_4x4x4f64(AVi, blockT(R1), 0.0, 0, 0, 0);   // (V^T G V^-T)^T
+    Ht += R2 * phi;  // Phi is symmetric
+  };
   auto pre_step = [&](int sh, const Slots& sl, const MacroMats& cm, const Ops& o, int m) {
     const V& qv = o.q;
     const V &La0 = o.x0, &Lb0 = o.y0, &La1 = o.x1, &Lb1 = o.y1;
@@ -1947,7 +2013,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     // Edge of child c below a node with pre-order vector q and sibling product S:
     //   internal child: q_c = P_c^T (q o S), numerator q_c o (Q L_c), q_c kept if stored
     //   tip child:      numerator (q o S) o ((P_c Q) L_c)  -- `trm` is then (P_c Q)
-    auto edge = [&](double trm, const V& qs, const V& Lc, bool tip, int slot, bool keep, V& qc) {
+    auto edge = [&](double trm, const V& qs, const V& Lc, bool tip, int slot, bool keep, V& qc,
+                    double phi) {
+      if (SUBST) subst_stats(qs, Lc, phi);
       if (tip) return mul(qs, mm(trm, Lc));
       qc = mm(trm, qs);
       if (keep) store_slot(slot, qc);
@@ -1955,20 +2023,26 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     };
     V q0, q1;
     {
-      const V n0 = edge(cm.tr[0], mul(qv, B), L0, is_tip(sh, 0), sl.cs0, kind0(sh) == 1, q0);
-      const V n1 = edge(cm.tr[1], mul(qv, A), L1, is_tip(sh, 1), sl.cs1, kind1(sh) == 1, q1);
+      const V n0 = edge(cm.tr[0], mul(qv, B), L0, is_tip(sh, 0), sl.cs0, kind0(sh) == 1, q0,
+                        cm.ph[0]);
+      const V n1 = edge(cm.tr[1], mul(qv, A), L1, is_tip(sh, 1), sl.cs1, kind1(sh) == 1, q1,
+                        cm.ph[SUBST ? 1 : 0]);
       edge_sums(n0, n1, m, 0);
     }
     if (kind0(sh) == 2) {
       V qa, qb;
-      const V na = edge(cm.tr[2], mul(q0, Bp0), La0, is_tip(sh, 2), sl.gs0, true, qa);
-      const V nb = edge(cm.tr[3], mul(q0, Ap0), Lb0, is_tip(sh, 3), sl.gs1, true, qb);
+      const V na = edge(cm.tr[2], mul(q0, Bp0), La0, is_tip(sh, 2), sl.gs0, true, qa,
+                        cm.ph[SUBST ? 2 : 0]);
+      const V nb = edge(cm.tr[3], mul(q0, Ap0), Lb0, is_tip(sh, 3), sl.gs1, true, qb,
+                        cm.ph[SUBST ? 3 : 0]);
       edge_sums(na, nb, m, 2);
     }
     if (kind1(sh) == 2) {
       V qa, qb;
-      const V na = edge(cm.tr[4], mul(q1, Bp1), La1, is_tip(sh, 4), sl.gs2, true, qa);
-      const V nb = edge(cm.tr[5], mul(q1, Ap1), Lb1, is_tip(sh, 5), sl.gs3, true, qb);
+      const V na = edge(cm.tr[4], mul(q1, Bp1), La1, is_tip(sh, 4), sl.gs2, true, qa,
+                        cm.ph[SUBST ? 4 : 0]);
+      const V nb = edge(cm.tr[5], mul(q1, Ap1), Lb1, is_tip(sh, 5), sl.gs3, true, qb,
+                        cm.ph[SUBST ? 5 : 0]);
       edge_sums(na, nb, m, 4);
     }
   };
@@ -1999,6 +2073,10 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   // positions that do not exist in a macro are never written nor read downstream
   double* gout = a.g_part + ((size_t)gi * a.g_tiles + te.tile) * gwidth;
   for (int i = lane; i < M * kMacroPositions * 2; i += kTile) gout[i] = gacc[i];
+  if (SUBST) {
+    gout[gwidth - kSubstExtra + lane] = Ht;
+    if (lane < 4) gout[gwidth - 4 + lane] = gacc[gwidth - 4 + lane];
+  }
 }
 
 // ------------------------------------------------------------------------
@@ -2020,7 +2098,9 @@ __global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
   if (b < a.Eg && a.g_width) used = a.macro_count[t] * kMacroPositions * 2;
   if (b < a.Eg) {
     const double* src = a.g_part + (size_t)b * a.g_tiles * W;
-    for (int v = lane; v < used; v += 64) {
+    const int tail = a.g_width ? W - a.extra : W;  // plain sums after the positional part
+    for (int v = lane; v < used + a.extra; v += 64) {
+      if (v >= used) v = tail + (v - used);
       double s0 = 0, s1 = 0;
       int i = wv;
       for (; i + 4 < a.g_tiles; i += 8) {
@@ -2029,6 +2109,7 @@ __global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
       }
       if (i < a.g_tiles) s0 += src[(size_t)i * W + v];
       red_lds[wv * W + v] = s0 + s1;
+      if (v >= tail) v = used + (v - tail);
     }
   }
   __syncthreads();
@@ -2042,6 +2123,12 @@ __global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
   }
   // positional: entry (m, pos, q) belongs to the edge above child/grandchild `pos` of macro m
   const MacroEntry* mac = a.macros + (size_t)t * max_macros(a.n);
+  if (a.extra)
+    for (int v = threadIdx.x; v < a.extra; v += 256) {
+      const int c = W - a.extra + v;
+      a.x_sum[(size_t)b * a.extra + v] =
+          (red_lds[c] + red_lds[W + c]) + (red_lds[2 * W + c] + red_lds[3 * W + c]);
+    }
   if (threadIdx.x < 2) out[threadIdx.x * a.N + a.N - 1] = 0.0;  // the root has no edge
   for (int v = threadIdx.x; v < used; v += 256) {
     const int m = v / (kMacroPositions * 2), r = v - m * (kMacroPositions * 2);
@@ -2053,6 +2140,93 @@ __global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
     out[q * a.N + node] =
         (red_lds[v] + red_lds[W + v]) + (red_lds[2 * W + v] + red_lds[3 * W + v]);
   }
+}
+
+// ------------------------------------------------------------------------
+// Analytic substitution-model gradient, last step (one thread per tree).
+// In: H^T per category block (64 doubles, lane order of gradient_mfma_kernel) and the
+// root term d logL / d pi (4 doubles).  GTR as built by model_setup_kernel
+// (substitution_model.cpp:17-80): Qt_ab = rho_ab pi_b, mu = sum_a pi_a sum_{b != a} Qt_ab,
+// Q = Qt / mu.  Out: derivatives w.r.t. the stick-breaking coordinates of the rates (5)
+// and of the frequencies (3), the quantities the reference obtains by finite
+// differences (fat_beagle.cpp:400-465).
+// ------------------------------------------------------------------------
+__device__ void stick_breaking_chain(int K, const double* x, const double* g, double* out) {
+  // x = stick_breaking(y): x_k = s_k z_k, s_k = prod_{j<k} (1 - z_j), x_{K-1} = s_{K-1};
+  // dz_k/dy_k = z_k (1 - z_k)  =>  dL/dy_k = g_k x_k (1 - z_k) - z_k sum_{m>k} g_m x_m
+  double tail[8];
+  double acc = 0;
+  for (int m = K - 1; m >= 0; m--) {
+    tail[m] = acc;  // sum_{m' > m} g_m' x_m'
+    acc += g[m] * x[m];
+  }
+  double used = 0;
+  for (int k = 0; k < K - 1; k++) {
+    const double z = x[k] / (1.0 - used);
+    out[k] = g[k] * x[k] * (1.0 - z) - z * tail[k];
+    used += x[k];
+  }
+}
+
+__global__ void subst_gradient_kernel(SubstGradArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.T) return;
+  const DevModel& m = a.models[t];
+  const double* x = a.x_sum + (size_t)t * kSubstExtra;
+  const double* row = a.params + (size_t)t * a.param_count;
+  double H[16];  // H[i][j] = sum over blocks of H^T[j][i]
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double sum = 0;
+      for (int b = 0; b < 4; b++) sum += x[16 * j + 4 * b + i];
+      H[i * 4 + j] = sum;
+    }
+  // D = V^-T H V^T : D[a][b] = sum_ij Vinv[i][a] H[i][j] V[b][j]
+  double HV[16], D[16];
+  for (int i = 0; i < 4; i++)
+    for (int b = 0; b < 4; b++) {
+      double sum = 0;
+      for (int j = 0; j < 4; j++) sum += H[i * 4 + j] * m.V[b * 4 + j];
+      HV[i * 4 + b] = sum;
+    }
+  double S = 0;  // <D, Q>
+  for (int c = 0; c < 4; c++)
+    for (int b = 0; b < 4; b++) {
+      double sum = 0;
+      for (int i = 0; i < 4; i++) sum += m.Vinv[i * 4 + c] * HV[i * 4 + b];
+      D[c * 4 + b] = sum;
+      S += sum * m.Q[c * 4 + b];
+    }
+  double rates[6], pi[4];
+  for (int i = 0; i < 6; i++) rates[i] = row[a.rates_off + i];
+  for (int i = 0; i < 4; i++) pi[i] = row[a.freqs_off + i];
+  double mu = 0;
+  {
+    int ri = 0;
+    for (int i = 0; i < 4; i++)
+      for (int k = i + 1; k < 4; k++) {
+        const double r = rates[ri++];
+        mu += pi[i] * r * pi[k] + pi[k] * r * pi[i];
+      }
+  }
+  // d logL / d Qt_ab (a != b, diagonal follows) = (D_ab - D_aa - S pi_a) / mu
+  auto dQt = [&](int c, int b) { return (D[c * 4 + b] - D[c * 4 + c] - S * pi[c]) / mu; };
+  double g_rate[6], g_pi[4];
+  for (int c = 0; c < 4; c++) g_pi[c] = x[64 + c] + S * m.Q[c * 4 + c];  // root term, explicit pi in mu
+  {
+    int ri = 0;
+    for (int i = 0; i < 4; i++)
+      for (int k = i + 1; k < 4; k++) {
+        const double r = rates[ri];
+        g_rate[ri] = pi[k] * dQt(i, k) + pi[i] * dQt(k, i);
+        g_pi[k] += r * dQt(i, k);  // Qt_ik = r pi_k
+        g_pi[i] += r * dQt(k, i);  // Qt_ki = r pi_i
+        ri++;
+      }
+  }
+  double* out = a.out_subst + (size_t)t * 8;
+  stick_breaking_chain(6, rates, g_rate, out);
+  stick_breaking_chain(4, pi, g_pi, out + 5);
 }
 
 // ------------------------------------------------------------------------
@@ -2340,35 +2514,43 @@ void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s) {
   }
   hipLaunchKernelGGL(gradient_onchip_kernel, dim3(a.tiles, count), dim3(kTile), lds, s, a);
 }
-size_t gradient_mfma_lds_bytes(int n, int K, bool rescale) {
+size_t gradient_mfma_lds_bytes(int n, int K, bool rescale, bool subst) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
   const size_t tip_bytes = (((size_t)n * 4 * (16 / kp) + 7) / 8) * 8;
-  size_t bytes =
-      tip_bytes + sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile + gradient_mfma_width(n));
+  size_t bytes = tip_bytes + sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile +
+                                               gradient_mfma_width(n, subst));
   if (rescale) bytes += sizeof(int32_t) * (size_t)max_stored(n) * kLlR * (16 / kp);
   const size_t reach = (size_t)(2 * n - 1) * 4 * (16 / kp);  // mask fetches of internal ids
   return bytes > reach ? bytes : reach;
 }
-int gradient_mfma_width(int n) { return max_macros(n) * kMacroPositions * 2; }
-bool gradient_mfma_fits(int n, int K, bool rescale) {
-  return n >= 3 && K <= 4 && gradient_mfma_lds_bytes(n, K, rescale) <= 160 * 1024;
+int gradient_mfma_width(int n, bool subst) {
+  return max_macros(n) * kMacroPositions * 2 + (subst ? kSubstExtra : 0);
 }
-void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, hipStream_t s) {
+bool gradient_mfma_fits(int n, int K, bool rescale) {
+  return n >= 3 && K <= 4 && gradient_mfma_lds_bytes(n, K, rescale, true) <= 160 * 1024;
+}
+template <bool RESCALE, bool SUBST>
+static void launch_gradient_mfma_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR, 0, RESCALE, SUBST>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = lds;
+  }
+  hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 0, RESCALE, SUBST>), grid, dim3(kTile), lds, s, a);
+}
+void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool subst,
+                          hipStream_t s) {
   if (count <= 0) return;
   LikArgs a = a_in;
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
-  const size_t lds = gradient_mfma_lds_bytes(a.n, a.K, rescale);
-  static size_t configured[2] = {0, 0};
-  if (lds > 64 * 1024 && lds > configured[rescale]) {
-    (void)hipFuncSetAttribute(
-        rescale ? reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR, 0, true>)
-                : reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured[rescale] = lds;
-  }
+  const size_t lds = gradient_mfma_lds_bytes(a.n, a.K, rescale, subst);
   const dim3 grid(loglik_mfma_tiles(a.P, a.K), count);
-  if (rescale) {
-    hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 0, true>), grid, dim3(kTile), lds, s, a);
+  if (rescale || subst) {
+    if (rescale && subst) launch_gradient_mfma_variant<true, true>(a, grid, lds, s);
+    else if (rescale) launch_gradient_mfma_variant<true, false>(a, grid, lds, s);
+    else launch_gradient_mfma_variant<false, true>(a, grid, lds, s);
     return;
   }
   // ablation builds: 1 no matrix products, 2 no cross-lane reductions,
@@ -2384,9 +2566,15 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, hipStrea
     case 128: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 128>), grid, dim3(kTile), lds, s, a); return;
     default: break;
   }
-  hipLaunchKernelGGL((gradient_mfma_kernel<kLlR>), grid, dim3(kTile), lds, s, a);
+  launch_gradient_mfma_variant<false, false>(a, grid, lds, s);
 }
-bool reduce_tiles_fits(int N) { return sizeof(double) * 4 * (size_t)(3 * N + 12) <= 64 * 1024; }
+void launch_subst_gradient(const SubstGradArgs& a, hipStream_t s) {
+  if (a.T <= 0) return;
+  hipLaunchKernelGGL(subst_gradient_kernel, dim3((a.T + 63) / 64), dim3(64), 0, s, a);
+}
+bool reduce_tiles_fits(int N) {
+  return sizeof(double) * 4 * (size_t)(3 * N + 12 + kSubstExtra) <= 64 * 1024;
+}
 void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
   const size_t W = a.g_width ? a.g_width : 2 * (size_t)a.N;

@@ -1790,7 +1790,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   };
   const unsigned tt_delta = t_off - f_off;
   const unsigned col4 = 4u * col;
-  auto fetch_mats = [&](const Ids& id) {
+  auto fetch_mats = [&](const Ids& id, bool pre) {  // post-order needs the forward ones only
     MacroMats mt;
     int nodes[6] = {id.c0, id.c1, id.g0, id.g1, id.g2, id.g3};
 #pragma unroll
@@ -1805,8 +1805,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
         mt.tr[j] = pi_l - nodes[j];
       } else {
         mt.f[j] = *reinterpret_cast<const double*>(mats_e + vf);
-        mt.tr[j] = *reinterpret_cast<const double*>(trm_e + vt);
-        if (SUBST) mt.ph[j] = *reinterpret_cast<const double*>(phi_e + vt);
+        if (pre) mt.tr[j] = *reinterpret_cast<const double*>(trm_e + vt);
+        if (pre && SUBST) mt.ph[j] = *reinterpret_cast<const double*>(phi_e + vt);
       }
       mt.tw[j] = *reinterpret_cast<const uint32_t*>(
           tips + (__umul24((unsigned)nodes[j], (unsigned)(ppr * 4)) + col4));
@@ -1930,19 +1930,19 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     Ids ia = load_ids(0), ib;
     Slots sa = load_slots(0), sb;
     int sha = __builtin_amdgcn_readfirstlane(ia.shape), shb = 0;
-    MacroMats ma = fetch_mats(ia), mb;
+    MacroMats ma = fetch_mats(ia, false), mb;
     ib = load_ids(M > 1 ? 1 : 0);
     for (int m = 0; m < M; m += 2) {
       const Ops oa = load_ops(sha, sa, ma, false);
       shb = __builtin_amdgcn_readfirstlane(ib.shape);
-      mb = fetch_mats(ib);
+      mb = fetch_mats(ib, false);
       ia = load_ids(m + 2 < M ? m + 2 : M - 1);
       sb = load_slots(m + 1 < M ? m + 1 : M - 1);
       post_step(sha, sa, ma, oa);
       if (m + 1 < M) {
         const Ops ob = load_ops(shb, sb, mb, false);
         sha = __builtin_amdgcn_readfirstlane(ia.shape);
-        ma = fetch_mats(ia);
+        ma = fetch_mats(ia, false);
         ib = load_ids(m + 3 < M ? m + 3 : M - 1);
         sa = load_slots(m + 2 < M ? m + 2 : M - 1);
         post_step(shb, sb, mb, ob);
@@ -2050,19 +2050,19 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     Ids ia = load_ids(M - 1), ib;
     Slots sa = load_slots(M - 1), sb;
     int sha = __builtin_amdgcn_readfirstlane(ia.shape), shb = 0;
-    MacroMats ma = fetch_mats(ia), mb;
+    MacroMats ma = fetch_mats(ia, true), mb;
     ib = load_ids(M > 1 ? M - 2 : 0);
     for (int m = M - 1; m >= 0; m -= 2) {
       const Ops oa = load_ops(sha, sa, ma, true);
       shb = __builtin_amdgcn_readfirstlane(ib.shape);
-      mb = fetch_mats(ib);
+      mb = fetch_mats(ib, true);
       ia = load_ids(m >= 2 ? m - 2 : 0);
       sb = load_slots(m >= 1 ? m - 1 : 0);
       pre_step(sha, sa, ma, oa, m);
       if (m >= 1) {
         const Ops ob = load_ops(shb, sb, mb, true);
         sha = __builtin_amdgcn_readfirstlane(ia.shape);
-        ma = fetch_mats(ia);
+        ma = fetch_mats(ia, true);
         ib = load_ids(m >= 3 ? m - 3 : 0);
         sa = load_slots(m >= 2 ? m - 2 : 0);
         pre_step(shb, sb, mb, ob, m - 1);

@@ -202,6 +202,27 @@ int32_t mi_engine_profile_begin(mi_engine* engine, int32_t max_calls);
 int32_t mi_engine_profile_collect(mi_engine* engine, double* out_ms, int32_t capacity,
                                   int32_t* out_count);
 
+/* ---- site-pattern compression on the device (widening beyond the Engine boundary) ----
+ *
+ * Replaces SitePattern::Compress (src/site_pattern.cpp:77-115; called from the
+ * SitePattern constructor :9-14): the distinct columns of an alignment, their
+ * multiplicities, in the iteration order of the reference's
+ * std::unordered_map<std::vector<int>, double, IntVectorHasher> -- bit-exact.
+ *
+ *   codes        [taxon_count][site_count] symbol codes 0..3, 4 = gap/ambiguous
+ *                (SitePattern::SymbolVectorOf, site_pattern.cpp:16-46), rows in taxon-id
+ *                order, host memory
+ *   out_patterns [taxon_count][*out_pattern_count] (dense; capacity taxon_count *
+ *                site_count int32), out_weights [*out_pattern_count] (capacity site_count)
+ *   out_hash_kernel_ms  optional: HIP-event time of the column-hashing kernel
+ * Hashing, sorting and grouping run on the GPU; the P insertions that fix the order are
+ * replayed on the host.  A 64-bit grouping-hash collision (verified, never assumed absent)
+ * falls back to the CPU loop, so the result is always exact.  Fails without a GPU. */
+int32_t mi_site_pattern_compress(int32_t device, int32_t taxon_count, int64_t site_count,
+                                 const int8_t* codes, int32_t* out_pattern_count,
+                                 int32_t* out_patterns, double* out_weights,
+                                 double* out_hash_kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,13 +19,19 @@
 using namespace miphylo;
 
 namespace {
-
 thread_local std::string g_error;
+}
 
+namespace miphylo {
+// sets mi_last_error(); shared with mi_site_pattern.hip
 int fail(const std::string& msg) {
   g_error = msg;
   return 1;
 }
+}  // namespace miphylo
+
+namespace {
+using miphylo::fail;
 
 #define HIP_TRY(expr)                                                              \
   do {                                                                             \

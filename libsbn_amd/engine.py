@@ -239,3 +239,23 @@ class Engine:
         self._check(self._lib.mi_engine_last_call_info(self._h, C.byref(name), C.byref(ev),
                                                        C.byref(gev)))
         return name.value.decode(), ev.value, gev.value
+
+
+def site_pattern_compress_device(codes, device=0):
+    """SitePattern::Compress on the GPU (include/mi_phylo.h: mi_site_pattern_compress).
+
+    codes: [taxon][site] symbol codes 0..3, 4 = gap / ambiguous.  Returns (patterns
+    [taxon][P] int32, weights [P] float64, milliseconds of the column-hashing kernel) in
+    the reference's pattern order."""
+    lib = _capi.load()
+    c = _np(codes, np.int8)
+    n, L = c.shape
+    patterns = np.empty((n, L), dtype=np.int32)
+    weights = np.empty(L, dtype=np.float64)
+    count = C.c_int32(0)
+    ms = C.c_double(0.0)
+    if lib.mi_site_pattern_compress(int(device), n, L, _ptr(c), C.byref(count), _ptr(patterns),
+                                    _ptr(weights), C.byref(ms)):
+        raise RuntimeError(_capi.last_error())
+    P = count.value
+    return patterns.reshape(-1)[:n * P].reshape(n, P).copy(), weights[:P].copy(), ms.value

@@ -9,6 +9,10 @@
 // with scalar loads into SGPRs; FP64 FMAs take them as scalar operands.
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include <cstdlib>
 #include <string>
 
@@ -2416,6 +2420,22 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
 // ------------------------------------------------------------------------
 // Launch wrappers
 // ------------------------------------------------------------------------
+// Kernels that want more than 64 KiB of dynamic LDS have to opt in, per function AND per
+// device (a process may drive several GPUs): remembered per (function, device).
+static void allow_large_lds(const void* func, size_t lds) {
+  if (lds <= 64 * 1024) return;
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> configured;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = configured[{func, dev}];
+  if (lds > have) {
+    (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    have = lds;
+  }
+}
+
 void launch_tree_setup(const TreeSetupArgs& a_in, hipStream_t s) {
   TreeSetupArgs a = a_in;
   const size_t lds = sizeof(int32_t) * 13 * (size_t)(2 * a.n - 1);
@@ -2506,12 +2526,7 @@ bool gradient_onchip_fits(int n) { return n >= 3 && gradient_onchip_lds_bytes(n)
 void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s) {
   if (count <= 0) return;
   const size_t lds = gradient_onchip_lds_bytes(a.n);
-  static size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gradient_onchip_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = lds;
-  }
+  allow_large_lds(reinterpret_cast<const void*>(gradient_onchip_kernel), lds);
   hipLaunchKernelGGL(gradient_onchip_kernel, dim3(a.tiles, count), dim3(kTile), lds, s, a);
 }
 size_t gradient_mfma_lds_bytes(int n, int K, bool rescale, bool subst) {
@@ -2531,13 +2546,8 @@ bool gradient_mfma_fits(int n, int K, bool rescale) {
 }
 template <bool RESCALE, bool SUBST>
 static void launch_gradient_mfma_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR, 0, RESCALE, SUBST>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = lds;
-  }
+  allow_large_lds(reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR, 0, RESCALE, SUBST>),
+                  lds);
   hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 0, RESCALE, SUBST>), grid, dim3(kTile), lds, s, a);
 }
 void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool subst,

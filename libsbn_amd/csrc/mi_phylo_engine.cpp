@@ -143,7 +143,8 @@ struct mi_engine {
   std::vector<Block> blocks;
   hipStream_t stream = nullptr;
   // static device data
-  Buffer tip_states, tip_partials, weights;
+  Buffer tip_states, tip_partials, tip_masks, weights;
+  bool have_tip_masks = false;  // every tip vector is 0/1: the matrix-core kernel can run
   // per-call workspace
   Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, x_sum, ll_part, plv, g_part, site_lik, fin_scratch,
       ll_sum, g_sum, status;
@@ -257,12 +258,11 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   if (e->param_count > 0 && !d.params) return fail("null parameter matrix");
   // on-chip gradient kernels: the matrix-core one (K <= 4; rescaling supported) or the
   // VALU one (no rescaling); everything else takes the HBM-streamed kernel
-  const bool fits_chip = d.gradient && e->allow_onchip_gradient && e->spec.use_tip_states &&
-                         gradient_onchip_fits(e->n);
-  const bool mfma = fits_chip && e->gradient_path != 1 &&
+  const bool fits_chip = d.gradient && e->allow_onchip_gradient && gradient_onchip_fits(e->n);
+  const bool mfma = fits_chip && e->have_tip_masks && e->gradient_path != 1 &&
                     gradient_mfma_fits(e->n, e->K, d.rescaling) && reduce_tiles_fits(e->N) &&
                     (e->gradient_path == 3 || e->prefer_mfma_gradient);
-  const bool onchip = fits_chip && (mfma || !d.rescaling);
+  const bool onchip = mfma || (fits_chip && e->spec.use_tip_states && !d.rescaling);
   const int g_tiles = mfma ? loglik_mfma_tiles(e->P, e->K) : e->tiles;
   const bool analytic = e->analytic_subst && mfma && e->spec.subst_model == MI_SUBST_GTR;
   if (reserve(e, d.T, d.gradient, !onchip, analytic)) return 1;
@@ -342,6 +342,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.tr_mats = e->tr_mats.as<double>();
   la.phi = e->phi.as<double>();
   la.tip_states = e->tip_states.as<int8_t>();
+  la.tip_masks = e->tip_masks.as<uint8_t>();
   la.tip_partials = e->spec.use_tip_states ? nullptr : e->tip_partials.as<double>();
   la.weights = e->weights.as<double>();
   la.ll_part = e->ll_part.as<double>();
@@ -650,6 +651,28 @@ int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
     }
     if (upload(e->tip_partials, tp.data(), tp.size(), e->stream)) return cleanup_fail(1);
   }
+  {
+    // Tip vectors as state masks (bit s = compatible with state s) for the matrix-core
+    // kernel: from the compact states, or from the partials when every entry is exactly 0
+    // or 1 (what SitePattern::GetPartials produces, site_pattern.cpp:117-131); real-valued
+    // partials have no mask form and take the HBM-streamed kernel.
+    std::vector<uint8_t> masks(np);
+    e->have_tip_masks = true;
+    if (spec->use_tip_states || !tip_partials) {
+      for (size_t i = 0; i < np; i++) masks[i] = st8[i] >= kStates ? 0xF : (uint8_t)(1u << st8[i]);
+    } else {
+      for (size_t i = 0; i < np && e->have_tip_masks; i++) {
+        uint8_t m = 0;
+        for (int x = 0; x < kStates; x++) {
+          const double v = tip_partials[i * kStates + x];
+          if (v == 1.0) m |= (uint8_t)(1u << x);
+          else if (v != 0.0) e->have_tip_masks = false;
+        }
+        masks[i] = m;
+      }
+    }
+    if (e->have_tip_masks && upload(e->tip_masks, masks.data(), np, e->stream)) return cleanup_fail(1);
+  }
   if (upload(e->weights, pattern_weights, (size_t)e->P, e->stream)) return cleanup_fail(1);
   if (hipStreamSynchronize(e->stream) != hipSuccess)
     return cleanup_fail(fail("upload of tips failed"));
@@ -663,7 +686,7 @@ void mi_engine_destroy(mi_engine* e) {
     (void)hipStreamSynchronize(e->stream);
   }
   for (Buffer* b :
-       {&e->tip_states, &e->tip_partials, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
+       {&e->tip_states, &e->tip_partials, &e->tip_masks, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
         &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->fin_scratch,
         &e->ll_sum, &e->g_sum, &e->status,
@@ -692,8 +715,10 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
   if (!e) return fail("null engine");
   if (tree_count <= 0) return fail("tree_count must be positive");
   HIP_TRY(hipSetDevice(e->spec.device));
-  const bool onchip = e->allow_onchip_gradient && e->spec.use_tip_states &&
-                      gradient_onchip_fits(e->n);
+  // the HBM arena is only reserved when a later call may need it (rescaling with the VALU
+  // kernel or real-valued tip partials still can: reserve() grows on demand then)
+  const bool onchip = e->allow_onchip_gradient && gradient_onchip_fits(e->n) &&
+                      (e->have_tip_masks || e->spec.use_tip_states);
   return reserve(e, tree_count, for_gradients != 0, !onchip);
 }
 

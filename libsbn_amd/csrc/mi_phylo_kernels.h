@@ -87,6 +87,7 @@ struct LikArgs {
   const double* tr_mats;       // see TransitionArgs
   const double* phi;           // see TransitionArgs
   const int8_t* tip_states;    // [n][P]
+  const uint8_t* tip_masks;    // [n][P] bit s: compatible with state s (matrix-core gradient)
   const double* tip_partials;  // [n][P][4] or nullptr
   const double* weights;       // [P]
   double* ll_part;             // [E][tiles]

@@ -1700,12 +1700,10 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     const int r = q >> ppr_shift, c = q & (ppr - 1);  // pattern tile_start + q = r * ppr + c
     if (q < TP) {
       const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
-      const int8_t* src = a.tip_states + pp;
+      const uint8_t* src = a.tip_masks + pp;
 #pragma unroll 4
-      for (int taxon = lane >> tp_shift; taxon < n; taxon += group) {
-        const int v = src[(size_t)taxon * a.P];
-        tips[(taxon * ppr + c) * 4 + r] = v > 3 ? (uint8_t)0xF : (uint8_t)(1u << v);
-      }
+      for (int taxon = lane >> tp_shift; taxon < n; taxon += group)
+        tips[(taxon * ppr + c) * 4 + r] = src[(size_t)taxon * a.P];
     }
   }
   __syncthreads();

@@ -55,7 +55,10 @@ class Engine:
     """One MI355X engine: tips + pattern weights resident in HBM."""
 
     def __init__(self, model_specification, patterns, weights, use_tip_states=True,
-                 device=-1, thread_count=1):
+                 device=-1, thread_count=1, tip_partials=None):
+        """patterns: [taxon][pattern] compact states (SitePattern::GetPatterns), or None when
+        tip_partials ([taxon][pattern][4], SitePattern::GetPartials) is given with
+        use_tip_states=False."""
         if thread_count == 0:  # src/engine.cpp:14-16
             raise RuntimeError("Thread count needs to be strictly positive.")
         self._lib = _capi.load()
@@ -66,9 +69,15 @@ class Engine:
         if model_specification.clock not in CLOCK:
             raise RuntimeError("Clock model not known: " + model_specification.clock)
         site_kind, K = _parse_site(model_specification.site)
-        patterns = _np(patterns, np.int32)
         weights = _np(weights, np.float64)
-        n, P = patterns.shape
+        if tip_partials is not None:
+            tip_partials = _np(tip_partials, np.float64)
+            n, P = tip_partials.shape[:2]
+            if tip_partials.shape != (n, P, 4):
+                raise RuntimeError("tip partials must be [taxon][pattern][4]")
+        if patterns is not None:
+            patterns = _np(patterns, np.int32)
+            n, P = patterns.shape
         if weights.shape != (P,):
             raise RuntimeError("pattern weights must have one entry per site pattern")
         self.taxon_count, self.pattern_count, self.category_count = n, P, K
@@ -77,8 +86,8 @@ class Engine:
                                      site_kind, CLOCK[model_specification.clock],
                                      1 if use_tip_states else 0, device, 0)
         h = C.c_void_p()
-        rc = self._lib.mi_engine_create(C.byref(self.spec), _ptr(patterns), None, _ptr(weights),
-                                        C.byref(h))
+        rc = self._lib.mi_engine_create(C.byref(self.spec), _ptr(patterns), _ptr(tip_partials),
+                                        _ptr(weights), C.byref(h))
         self._check(rc)
         self._h = h
         self.param_count = self._lib.mi_engine_param_count(h)

@@ -340,6 +340,49 @@ def test_rescaling_rescues_underflow():
         assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t], 1e-9)
 
 
+def test_tip_partials_run_on_the_matrix_core_kernel():
+    """use_tip_states=False hands the engine 0/1 partial vectors (SitePattern::GetPartials);
+    those have an exact state-mask form, so the gradient stays on the matrix-core kernel.
+    Real-valued partials have none and take the HBM-streamed kernel; both match the oracle."""
+    import libsbn_amd as L
+    st = O.load_struct("ds1_sub10")
+    tips, w, pids, bls = O.struct_arrays(st)
+    n, P = tips.shape
+    T = len(pids)
+    spec = O.make_spec(n, P, "JC69", "weibull+4", use_tip_states=0)
+    pr = _params(spec, T, **{"Weibull shape": np.full((T, 1), 1.3)})
+    og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, False, 4)
+    eng = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w, device=0,
+                   use_tip_states=False)
+    g = eng.gradients(pids, bls, pr)
+    assert eng.last_call_info()[0] == "gradient_mfma_kernel"
+    for t in range(T):
+        assert abs(g[t].log_likelihood - og["log_likelihood"][t]) <= RTOL * abs(og["log_likelihood"][t])
+        assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t])
+    # explicit partials, ambiguity coded as a 0/1 set {A, G}: still mask-representable
+    partials = np.zeros((n, P, 4))
+    for i in range(n):
+        for p in range(P):
+            s = tips[i, p]
+            partials[i, p, :] = 1.0 if s > 3 else 0.0
+            if s <= 3:
+                partials[i, p, s] = 1.0
+    partials[0, :, :] = [1.0, 0.0, 1.0, 0.0]
+    eng2 = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), None, w, device=0,
+                    use_tip_states=False, tip_partials=partials)
+    g2 = eng2.gradients(pids, bls, pr)
+    assert eng2.last_call_info()[0] == "gradient_mfma_kernel"
+    soft = partials.copy()
+    soft[0, :, :] = [1.0, 0.0, 1.0 - 1e-13, 0.0]  # not 0/1 any more: no mask form
+    eng3 = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), None, w, device=0,
+                    use_tip_states=False, tip_partials=soft)
+    g3 = eng3.gradients(pids, bls, pr)
+    assert eng3.last_call_info()[0] == "gradient_hbm_kernel"
+    for t in range(T):
+        assert abs(g2[t].log_likelihood - g3[t].log_likelihood) <= 1e-11 * abs(g3[t].log_likelihood)
+        assert _close(g2[t].gradient["branch_lengths"], g3[t].gradient["branch_lengths"], 1e-9)
+
+
 def test_batches_larger_than_one_launch():
     """More evaluations than one kernel launch can address (grid y <= 65535): the engine
     splits the batch; every tree still gets its own result, in tree order."""

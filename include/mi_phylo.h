@@ -217,7 +217,8 @@ int32_t mi_engine_profile_collect(mi_engine* engine, double* out_ms, int32_t cap
  *   out_hash_kernel_ms  optional: HIP-event time of the column-hashing kernel
  * Hashing, sorting and grouping run on the GPU; the P insertions that fix the order are
  * replayed on the host.  A 64-bit grouping-hash collision (verified, never assumed absent)
- * falls back to the CPU loop, so the result is always exact.  Fails without a GPU. */
+ * is retried with another hash seed, so a returned result is always exact.  Fails without
+ * a GPU (libmi_phylo_host.so holds the CPU implementation). */
 int32_t mi_site_pattern_compress(int32_t device, int32_t taxon_count, int64_t site_count,
                                  const int8_t* codes, int32_t* out_pattern_count,
                                  int32_t* out_patterns, double* out_weights,

@@ -10,7 +10,8 @@
 // So the O(taxa x sites) part runs on the GPU --
 //   1. hash every column (the reference's 32-bit hash, and a 64-bit one for grouping),
 //   2. stable radix sort of (64-bit hash, site), group equal hashes, VERIFY that grouped
-//      columns really are equal (a 64-bit collision sends the call to the CPU fallback),
+//      columns really are equal (a 64-bit collision is retried with another seed; there is
+//      no CPU path in this library),
 //   3. per group: first site (its smallest, thanks to the stable sort) and size,
 //   4. groups ordered by first site,
 // and the host replays P insertions (P = distinct columns) into a real
@@ -50,13 +51,13 @@ __host__ __device__ inline int32_t ref_hash_step(int32_t h, int32_t c) {
   return (int32_t)((uint32_t)h ^ add);
 }
 
-__global__ void hash_columns_kernel(int n, long L, const int8_t* __restrict__ codes,
+__global__ void hash_columns_kernel(int n, long L, uint64_t seed, const int8_t* __restrict__ codes,
                                     int32_t* __restrict__ ref_hash, uint64_t* __restrict__ key,
                                     uint32_t* __restrict__ site) {
   const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= L) return;
   int32_t h = codes[s];
-  uint64_t k = 0xcbf29ce484222325ull ^ (uint64_t)(uint8_t)codes[s];
+  uint64_t k = (0xcbf29ce484222325ull + seed) ^ (uint64_t)(uint8_t)codes[s];
   k *= 0x100000001b3ull;
   // The hashes are sequential in the taxon index but the loads are not: fetch eight rows
   // at a time (consecutive sites of a row: coalesced) so that the memory latency is paid
@@ -161,36 +162,6 @@ std::vector<int> replay_unordered_map_order(const std::vector<int32_t>& hashes) 
   return order;
 }
 
-struct VecHash {
-  size_t operator()(const std::vector<int>& v) const {
-    int32_t h = v[0];
-    for (size_t i = 1; i < v.size(); i++) h = ref_hash_step(h, v[i]);
-    return (size_t)h;
-  }
-};
-
-// CPU fallback (and the definition of the result): the reference's loop as it stands.
-void compress_on_host(int n, long L, const int8_t* codes, std::vector<int32_t>* patterns,
-                      std::vector<double>* weights) {
-  std::unordered_map<std::vector<int>, double, VecHash> seen;
-  std::vector<int> column(n);
-  for (long s = 0; s < L; s++) {
-    for (int t = 0; t < n; t++) column[t] = codes[(size_t)t * L + s];
-    auto it = seen.find(column);
-    if (it == seen.end()) seen.insert({column, 1.});
-    else it->second += 1.;
-  }
-  const size_t P = seen.size();
-  patterns->assign((size_t)n * P, 0);
-  weights->clear();
-  size_t j = 0;
-  for (const auto& kv : seen) {
-    for (int t = 0; t < n; t++) (*patterns)[(size_t)t * P + j] = kv.first[t];
-    weights->push_back(kv.second);
-    j++;
-  }
-}
-
 struct DevMem {
   void* p = nullptr;
   ~DevMem() {
@@ -239,19 +210,8 @@ extern "C" int32_t mi_site_pattern_compress(int32_t device, int32_t taxon_count,
   SP_TRY(hipMalloc(&d_ohash.p, sizeof(int32_t) * L));
   SP_TRY(hipMalloc(&d_flag.p, sizeof(int32_t)));
   SP_TRY(hipMemcpy(d_codes.p, codes, (size_t)n * L, hipMemcpyHostToDevice));
-  SP_TRY(hipMemset(d_flag.p, 0, sizeof(int32_t)));
-
   const unsigned blocks = (unsigned)((L + 255) / 256);
-  hipEvent_t ev0, ev1;
-  SP_TRY(hipEventCreate(&ev0));
-  SP_TRY(hipEventCreate(&ev1));
-  SP_TRY(hipEventRecord(ev0, nullptr));
-  hipLaunchKernelGGL(hash_columns_kernel, dim3(blocks), dim3(256), 0, nullptr, n, L,
-                     d_codes.as<int8_t>(), d_ref.as<int32_t>(), d_key.as<uint64_t>(),
-                     d_site.as<uint32_t>());
-  SP_TRY(hipEventRecord(ev1, nullptr));
-
-  // stable sort by the 64-bit hash
+  // temporary storage of the rocPRIM calls (queried once)
   size_t tmp_bytes = 0, need = 0;
   SP_TRY(rocprim::radix_sort_pairs(nullptr, need, d_key.as<uint64_t>(), d_key2.as<uint64_t>(),
                                    d_site.as<uint32_t>(), d_site2.as<uint32_t>(), (size_t)L));
@@ -264,35 +224,40 @@ extern "C" int32_t mi_site_pattern_compress(int32_t device, int32_t taxon_count,
                                    d_gid2.as<uint32_t>(), (size_t)L));
   tmp_bytes = std::max(tmp_bytes, need);
   SP_TRY(hipMalloc(&d_tmp.p, tmp_bytes));
-  need = tmp_bytes;
-  SP_TRY(rocprim::radix_sort_pairs(d_tmp.p, need, d_key.as<uint64_t>(), d_key2.as<uint64_t>(),
-                                   d_site.as<uint32_t>(), d_site2.as<uint32_t>(), (size_t)L));
-  hipLaunchKernelGGL(mark_heads_kernel, dim3(blocks), dim3(256), 0, nullptr, n, L,
-                     d_codes.as<int8_t>(), d_key2.as<uint64_t>(), d_site2.as<uint32_t>(),
-                     d_head.as<uint32_t>(), d_flag.as<int32_t>());
-  need = tmp_bytes;
-  SP_TRY(rocprim::inclusive_scan(d_tmp.p, need, d_head.as<uint32_t>(), d_scan.as<uint32_t>(),
-                                 (size_t)L, rocprim::plus<uint32_t>()));
+
   uint32_t P = 0;
-  int32_t collision = 0;
-  SP_TRY(hipMemcpy(&P, d_scan.as<uint32_t>() + (L - 1), sizeof P, hipMemcpyDeviceToHost));
-  SP_TRY(hipMemcpy(&collision, d_flag.p, sizeof collision, hipMemcpyDeviceToHost));
+  hipEvent_t ev0, ev1;
+  SP_TRY(hipEventCreate(&ev0));
+  SP_TRY(hipEventCreate(&ev1));
+  bool grouped = false;
+  for (uint64_t seed = 0; seed < 4 && !grouped; seed++) {
+    SP_TRY(hipMemset(d_flag.p, 0, sizeof(int32_t)));
+    SP_TRY(hipEventRecord(ev0, nullptr));
+    hipLaunchKernelGGL(hash_columns_kernel, dim3(blocks), dim3(256), 0, nullptr, n, L,
+                       seed * 0x9e3779b97f4a7c15ull, d_codes.as<int8_t>(), d_ref.as<int32_t>(),
+                       d_key.as<uint64_t>(), d_site.as<uint32_t>());
+    SP_TRY(hipEventRecord(ev1, nullptr));
+    // stable sort by the 64-bit hash, run heads, verification
+    need = tmp_bytes;
+    SP_TRY(rocprim::radix_sort_pairs(d_tmp.p, need, d_key.as<uint64_t>(), d_key2.as<uint64_t>(),
+                                     d_site.as<uint32_t>(), d_site2.as<uint32_t>(), (size_t)L));
+    hipLaunchKernelGGL(mark_heads_kernel, dim3(blocks), dim3(256), 0, nullptr, n, L,
+                       d_codes.as<int8_t>(), d_key2.as<uint64_t>(), d_site2.as<uint32_t>(),
+                       d_head.as<uint32_t>(), d_flag.as<int32_t>());
+    need = tmp_bytes;
+    SP_TRY(rocprim::inclusive_scan(d_tmp.p, need, d_head.as<uint32_t>(), d_scan.as<uint32_t>(),
+                                   (size_t)L, rocprim::plus<uint32_t>()));
+    int32_t collision = 0;
+    SP_TRY(hipMemcpy(&P, d_scan.as<uint32_t>() + (L - 1), sizeof P, hipMemcpyDeviceToHost));
+    SP_TRY(hipMemcpy(&collision, d_flag.p, sizeof collision, hipMemcpyDeviceToHost));
+    grouped = collision == 0;  // two different columns with one 64-bit hash: other seed
+  }
   float hash_ms = 0;
   SP_TRY(hipEventElapsedTime(&hash_ms, ev0, ev1));
   (void)hipEventDestroy(ev0);
   (void)hipEventDestroy(ev1);
   if (out_hash_kernel_ms) *out_hash_kernel_ms = hash_ms;
-
-  if (collision) {
-    // two different columns share a 64-bit hash: exactness first
-    std::vector<int32_t> pat;
-    std::vector<double> wts;
-    compress_on_host(n, L, codes, &pat, &wts);
-    *out_pattern_count = (int32_t)wts.size();
-    memcpy(out_patterns, pat.data(), sizeof(int32_t) * pat.size());
-    memcpy(out_weights, wts.data(), sizeof(double) * wts.size());
-    return 0;
-  }
+  if (!grouped) return fail("site patterns: the grouping hash collided under every seed");
 
   hipLaunchKernelGGL(group_leaders_kernel, dim3(blocks), dim3(256), 0, nullptr, L,
                      d_head.as<uint32_t>(), d_scan.as<uint32_t>(), d_site2.as<uint32_t>(),

@@ -1,0 +1,55 @@
+"""Randomised parity sweep of the GPU engine against the CPU oracle (not part of the test
+suite: run on an MI355X box, optionally with MI_PHYLO_SUBST_GRADIENT=analytic).
+Random taxa / pattern / category counts, models, rescaling, branch-length scales, gaps."""
+import sys, os, itertools
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+import numpy as np
+import oracle_lib as O, libsbn_amd as L, tree_utils as TU
+import test_gpu_parity as TG
+RTOL = 1e-10
+rng = np.random.default_rng(2024)
+bad = 0; total = 0
+for trial in range(60):
+    n = int(rng.choice([3, 4, 5, 6, 7, 9, 12, 17, 26, 31, 32, 33, 45, 64, 80]))
+    P = int(rng.choice([1, 2, 3, 11, 12, 13, 16, 47, 48, 49, 64, 100, 257]))
+    K = int(rng.choice([1, 2, 3, 4]))
+    subst = str(rng.choice(["JC69", "GTR"]))
+    site = "constant" if K == 1 else f"weibull+{K}"
+    resc = bool(rng.integers(0, 2))
+    T = int(rng.choice([1, 2, 9]))
+    tips, w = TU.random_alignment(n, P, rng, gap_fraction=float(rng.choice([0.0, 0.05, 0.5])))
+    pids, bls = TU.random_trees(n, T, rng, mean_bl=float(rng.choice([0.001, 0.1, 1.0])))
+    if rng.integers(0, 3) == 0: pids[0] = TU.ladder_topology(n)
+    eng = L.Engine(L.PhyloModelSpecification(subst, site, "none"), tips, w, device=0)
+    spec = O.make_spec(n, P, subst, site, "none")
+    blocks = {}
+    if subst == "GTR":
+        r, f = TU.random_gtr_params(T, rng); blocks["GTR rates"] = r; blocks["frequencies"] = f
+    if K > 1: blocks["Weibull shape"] = rng.uniform(0.2, 3.0, size=(T, 1))
+    pr = TG._params(spec, T, **blocks)
+    g = eng.gradients(pids, bls, pr, resc)
+    kern = eng.last_call_info()[0]
+    O.set_transition_mode(1)
+    og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 4)
+    O.set_transition_mode(0)
+    ok = True
+    for t in range(T):
+        ok &= abs(g[t].log_likelihood - og["log_likelihood"][t]) <= RTOL * abs(og["log_likelihood"][t])
+        scale = max(np.max(np.abs(og["branch_lengths"][t])), 1e-300)
+        ok &= np.max(np.abs(g[t].gradient["branch_lengths"] - og["branch_lengths"][t])) <= 1e-9 * scale
+        if K > 1:
+            tol_site = 1e-4 if (subst == "GTR" and os.environ.get("MI_PHYLO_SUBST_GRADIENT")) else 1e-8
+            okk = abs(g[t].gradient["site_model"][0] - og["site_model"][t]) <= tol_site * max(1.0, abs(og["site_model"][t]))
+            if not okk: print("  site", g[t].gradient["site_model"][0], og["site_model"][t])
+            ok &= okk
+        if subst == "GTR":
+            a = g[t].gradient["substitution_model"]; f_ = og["substitution_model"][t]
+            okk = np.max(np.abs(a - f_) / np.maximum(np.abs(f_), 1.0)) <= 1e-4
+            if not okk: print("  subst", a, f_)
+            ok &= okk
+    total += 1
+    if not ok:
+        bad += 1
+        print("MISMATCH", dict(n=n, P=P, K=K, subst=subst, resc=resc, T=T, kern=kern))
+print("trials", total, "bad", bad, "analytic" if os.environ.get("MI_PHYLO_SUBST_GRADIENT") else "fd")

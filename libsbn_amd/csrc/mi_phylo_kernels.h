@@ -71,7 +71,6 @@ struct TransitionArgs {
 struct LikArgs {
   int n, N, P, K, tiles;
   int lds_slots;    // PLV slots in LDS (set by the launcher)
-  int debug;        // ablation switches for profiling builds (MI_PHYLO_DEBUG; 0 in production)
   int kp;           // MFMA path: categories per instruction (1, 2 or 4; set by the launcher)
   int ll_tiles;     // stride of ll_part per evaluation (>= partial sums any kernel writes)
   int g_tiles;      // stride of g_part per gradient evaluation = tiles of the gradient kernel used

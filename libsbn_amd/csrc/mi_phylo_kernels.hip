@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   const int tile_start = te.tile * TP;
   SchedEntry* sched_l = reinterpret_cast<SchedEntry*>(tips + (((size_t)n * R * 16 + 15) & ~(size_t)15));
   for (int i = lane; i < n - 1; i += kTile) sched_l[i] = sched[i];
-  if (!TIP_PARTIALS && !(a.debug & 16)) {
+  if (!TIP_PARTIALS) {
     const int total = n * TP;
     for (int base = 0; base < total; base += 8 * kTile) {
       int8_t v[8];
@@ -1123,10 +1123,6 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
     // all operand reads of the visit are issued before the first product: one LDS
     // round trip per visit instead of one per register
     double B0[R], B1[R];
-    if (a.debug & 1) {  // ablation: no operand reads at all
-#pragma unroll
-      for (int r = 0; r < R; r++) { B0[r] = 0.25 + r; B1[r] = 0.5 + r; }
-    } else {
     if (tip0) {
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -1155,30 +1151,19 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
 #pragma unroll
       for (int r = 0; r < R; r++) B1[r] = src1[r * kTile];
     }
-    }
-    if (a.debug & 2) {  // ablation: no matrix products
-#pragma unroll
-      for (int r = 0; r < R; r++) L[r] = (A0 + B0[r]) * (A1 + B1[r]);
-    } else {
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const double D0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, B0[r], 0.0, 0, 0, 0);
       const double D1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, B1[r], 0.0, 0, 0, 0);
       L[r] = D0 * D1;
     }
-    }
-    if (!(a.debug & 4)) {  // ablation: no PLV stores
 #pragma unroll
     for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
-    }
     // refill this ring slot with the matrices of visit i + kAhead
-    if (!(a.debug & 8)) {  // ablation: no matrix loads
     const SchedEntry sf = sched_l[i + kAhead < n - 1 ? i + kAhead : n - 2];
     A0 = matrix_reg(sf.child0);
     A1 = matrix_reg(sf.child1);
-    }
   };
-  if (!(a.debug & 64))
   for (int i = 0; i < n - 1; i += kAhead) {
 #pragma unroll
     for (int j = 0; j < kAhead; j++)
@@ -1187,10 +1172,6 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   // root: site likelihood = sum over categories (blocks) and states (hi) of
   // cw * pi * L; every lane of a pattern's 4*Kp lanes ends up with the sum
   double ll = 0.0;
-  if (a.debug & 32) {
-    if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = L[0] + L[R - 1] + wgt + pw[0];
-    return;
-  }
 #pragma unroll
   for (int r = 0; r < R; r++) {
     double v = wgt * L[r];
@@ -2476,7 +2457,6 @@ static void launch_loglik_mfma(const LikArgs& a_in, int count, int max_slots, hi
   LikArgs a = a_in;
   a.lds_slots = max_slots;
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
-  if (const char* env = getenv("MI_PHYLO_DEBUG")) a.debug = atoi(env);
   const dim3 grid(loglik_mfma_tiles(a.P, a.K), count), block(kTile);
   const size_t lds = loglik_mfma_lds_bytes(a.n, max_slots);
   if (a.tip_partials)

@@ -1934,8 +1934,15 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   }
   if (DBG & 128) return;
   // ================= pre-order + edge derivatives =================
-  // lanes 15 / 31 / 47 / 63 end up with (branch a, site a, branch b, site b) of an edge pair
-  const unsigned red_off = 8u * ((((unsigned)lane >> 5) & 1u) * 2u + (((unsigned)lane >> 4) & 1u));
+  // The four sums of an edge pair (branch a, site a, branch b, site b) over the whole wave,
+  // on the matrix cores: with the lane sums s (state = hi, pattern = lo) as A operand,
+  //   D1[pattern][j] = sum_state s[state][pattern] * coef[state][j]     (coef: rate in column
+  //                    0 / 2, d rate in column 1 / 3 for edge a / b; accumulated over both)
+  //   D2[i][j]       = sum_pattern D1[pattern][j]                        (A = ones)
+  // leaves, in every block, quantity j in the lanes with lo = j; two DPP row shifts add the
+  // four blocks.  3 MFMA + 6 VALU instead of a 25-instruction cross-lane butterfly.
+  const double coef_a = lo == 0 ? rate_l : (lo == 1 ? drate_l : 0.0);
+  const double coef_b = lo == 2 ? rate_l : (lo == 3 ? drate_l : 0.0);
   auto edge_sums = [&](const V& na, const V& nb, int m, int pos_a) {
     // the pattern and category weights ride along in q (linear in the root vector)
     double sa = na.v[0], sb = nb.v[0];
@@ -1944,11 +1951,20 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       sa += na.v[r];
       sb += nb.v[r];
     }
-    const double red = (DBG & 2) ? rate_l * sa + drate_l * sb
-                                 : reduce4_transposed(rate_l * sa, rate_l * sb, drate_l * sa, drate_l * sb);
-    if ((lane & 15) == 15) {
+    double red;
+    if (DBG & 2) {
+      red = rate_l * sa + drate_l * sb;
+    } else {
+      double d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sa, coef_a, 0.0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sb, coef_b, d1, 0, 0, 0);
+      red = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, d1, 0.0, 0, 0, 0);
+      red = row_shr_add<4>(red);
+      red = row_shr_add<8>(red);
+    }
+    // lanes 12..15 (block 3 of row 0) hold branch a, site a, branch b, site b
+    if (lane >= 12 && lane < 16) {
       char* dst = reinterpret_cast<char*>(gacc) + (unsigned)((m * kMacroPositions + pos_a) * 16);
-      *reinterpret_cast<double*>(dst + red_off) = red;
+      *reinterpret_cast<double*>(dst + 8u * (unsigned)lo) = red;
     }
   };
   // ---- analytic substitution gradient (SUBST) ----

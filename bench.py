@@ -256,6 +256,10 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": kname, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_tree": per_tree,
+                         # what a call cannot avoid moving per tree: parent ids, branch
+                         # lengths, parameters in; logL (+ gradient vectors) out
+                         "compulsory_bytes_per_tree": 4 * (N - 2) + 8 * (N - 1) + 8 * params.shape[1]
+                                                      + (8 * (N + 2) if grad else 8),
                          "fp64": {"achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
                                   "frac": tflops / 78.6,
                                   "algorithmic_flops_per_tree": f_g if grad else f_ll},

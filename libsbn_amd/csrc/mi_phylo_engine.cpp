@@ -317,7 +317,15 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   tr.bl_eff = e->bl_eff.as<double>();
   tr.mats = e->mats.as<double>();
   // the per-state tip tables feed the VALU walk kernels only
-  const bool need_tip_tables = !(d.gradient && mfma && (!c.gtr || analytic));
+  // (only the VALU log-likelihood kernel reads them)
+  LikArgs probe{};
+  probe.n = n;
+  probe.K = e->K;
+  probe.tip_masks = e->have_tip_masks ? e->tip_masks.as<uint8_t>() : nullptr;
+  const bool loglik_runs = !d.gradient || (c.gtr && !analytic) || (onchip && !mfma);
+  const bool loglik_is_valu =
+      std::string(loglik_kernel_name(probe, d.rescaling, e->max_slots)) == "loglik_onchip_kernel";
+  const bool need_tip_tables = loglik_runs && loglik_is_valu;
   tr.tip_tables = need_tip_tables ? e->tip_tables.as<double>() : nullptr;
   tr.tr_mats = mfma ? e->tr_mats.as<double>() : nullptr;
   tr.phi = analytic ? e->phi.as<double>() : nullptr;
@@ -342,7 +350,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.tr_mats = e->tr_mats.as<double>();
   la.phi = e->phi.as<double>();
   la.tip_states = e->tip_states.as<int8_t>();
-  la.tip_masks = e->tip_masks.as<uint8_t>();
+  la.tip_masks = e->have_tip_masks ? e->tip_masks.as<uint8_t>() : nullptr;
   la.tip_partials = e->spec.use_tip_states ? nullptr : e->tip_partials.as<double>();
   la.weights = e->weights.as<double>();
   la.ll_part = e->ll_part.as<double>();
@@ -394,7 +402,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used], s));
   if (!d.gradient) {
     loglik_range(0, T);
-    e->dominant = loglik_kernel_name();
+    e->dominant = loglik_kernel_name(la, d.rescaling, e->max_slots);
     if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used + 1], s));
   } else {
     grad_range(0, 0, T);

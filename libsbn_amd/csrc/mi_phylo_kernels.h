@@ -177,7 +177,7 @@ bool reduce_tiles_fits(int N);
 void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s);
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);
 
-const char* loglik_kernel_name();
+const char* loglik_kernel_name(const LikArgs& a, bool rescale, int max_slots);
 const char* gradient_kernel_name();
 const char* gradient_onchip_kernel_name();
 const char* gradient_mfma_kernel_name();

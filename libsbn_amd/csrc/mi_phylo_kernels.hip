@@ -251,7 +251,8 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
           free_mask &= ~(1u << sl);
           slot[v] = sl;
           if (sl + 1 > used_max) used_max = sl + 1;
-          sched[out++] = {v, a0, a1, sl | (slot[a0] << 8) | (slot[a1] << 16)};
+          sched[out++] = {v, a0, a1, sl | (slot[a0] << 8) | (slot[a1] << 16) |
+                                        ((a0 < n ? 1 : 0) << 24) | ((a1 < n ? 1 : 0) << 25)};
         } else {
           stack[top++] = (v << 1) | 1;
           const int a0 = c0[v], a1 = c1[v];
@@ -465,7 +466,8 @@ __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
         WRL(s_node, out, v);
         WRL(s_c0, out, a0);
         WRL(s_c1, out, a1);
-        WRL(s_sl, out, sl | (sa0 << 8) | (sa1 << 16));
+        WRL(s_sl, out, sl | (sa0 << 8) | (sa1 << 16) | ((a0 < n ? 1 : 0) << 24) |
+                           ((a1 < n ? 1 : 0) << 25));
         out++;
       } else {
         push(top++, (v << 1) | 1);
@@ -1030,8 +1032,9 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
 // per SIMD (28 MAC/clk/SIMD, 1.8x the FP64 VALU peak), and the VALU stays free
 // for the element-wise products.
 // ------------------------------------------------------------------------
-template <int R, bool TIP_PARTIALS>
+template <int R>
 __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
+  static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
@@ -1044,130 +1047,112 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   const int K = a.K, n = a.n, Kp = a.kp;       // Kp in {1, 2, 4}: categories per instruction
   const int cat = b % Kp, pgrp = b / Kp, ppr = 16 / Kp;  // ppr = patterns per register
   const int catc = cat < K ? cat : K - 1;      // padded category (weight 0) reads a valid matrix
-  const double* __restrict__ mats_e = a.mats + (size_t)e * (a.N - 1) * K * 16;
-  // per-lane element of a child's matrix block: A_b[i = lo][k = hi]
-  const int a_off = catc * 16 + lo * 4 + hi;
-  int pat[R], patc[R];
-#pragma unroll
-  for (int r = 0; r < R; r++) {
-    pat[r] = (te.tile * R + r) * ppr + pgrp * 4 + lo;
-    patc[r] = pat[r] < a.P ? pat[r] : a.P - 1;
-  }
-  // LDS: PLV registers [slot][r][lane] | tip states of this tile [taxon][r][16 columns]
-  double* plv = lds;
-  int8_t* tips = reinterpret_cast<int8_t*>(lds + (size_t)a.lds_slots * R * kTile);
-  // Every global value the epilogue needs is requested NOW, together with the
-  // staging loads below: a wave lives only a few tens of microseconds, so each
-  // serialized memory round trip (1-2 us under load) is a visible share of it.
-  const double wgt = (cat < K ? model->cat_weight[cat] : 0.0) * model->pi[hi];
+  const char* __restrict__ mats_e =
+      reinterpret_cast<const char*>(a.mats + (size_t)e * (a.N - 1) * K * 16);
+  // per-lane element of a child's matrix block: A_b[i = lo][k = hi], as a byte offset
+  const unsigned a_off = 8u * (catc * 16 + lo * 4 + hi);
+  const unsigned node_bytes = (unsigned)K * 128u;
+  const int TP = ppr * R, tile_start = te.tile * TP;
+  const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
+  int pat[R];
   double pw[R];
 #pragma unroll
-  for (int r = 0; r < R; r++) pw[r] = a.weights[patc[r]];
-  // Stage this tile's tip states as [taxon][pattern in tile] bytes.  The byte loads
-  // are issued eight at a time per lane before any of them is stored: the prologue
-  // costs a few memory round trips instead of one per taxon.
-  const int TP = ppr * R;               // patterns per tile
-  const int tile_start = te.tile * TP;
-  SchedEntry* sched_l = reinterpret_cast<SchedEntry*>(tips + (((size_t)n * R * 16 + 15) & ~(size_t)15));
+  for (int r = 0; r < R; r++) {
+    pat[r] = tile_start + r * ppr + col;
+    pw[r] = a.weights[pat[r] < a.P ? pat[r] : a.P - 1];
+  }
+  const double wgt = (cat < K ? model->cat_weight[cat] : 0.0) * model->pi[hi];
+  // LDS: tip state masks [taxon][column][r] (bit s: compatible with state s; first, so
+  // that the ignored mask fetch of an internal node id needs no clamping) | schedule |
+  // vectors [slot][r][lane]
+  uint8_t* tips = reinterpret_cast<uint8_t*>(lds);
+  SchedEntry* sched_l = reinterpret_cast<SchedEntry*>(lds + ((n * ppr * 4 + 7) >> 3));
+  double* plv = reinterpret_cast<double*>(sched_l + (n - 1));
   for (int i = lane; i < n - 1; i += kTile) sched_l[i] = sched[i];
-  if (!TIP_PARTIALS) {
-    const int total = n * TP;
-    for (int base = 0; base < total; base += 8 * kTile) {
-      int8_t v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int idx = base + u * kTile + lane;
-        const int taxon = idx / TP, q = idx - taxon * TP;
-        const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
-        v[u] = idx < total ? a.tip_states[(size_t)taxon * a.P + pp] : (int8_t)0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int idx = base + u * kTile + lane;
-        if (idx < total) tips[idx] = v[u];
-      }
+  {
+    const int tp_shift = TP <= 16 ? 4 : (TP <= 32 ? 5 : 6);
+    const int q = lane & ((1 << tp_shift) - 1), group = 64 >> tp_shift;
+    const int ppr_shift = Kp == 4 ? 2 : (Kp == 2 ? 3 : 4);
+    const int r = q >> ppr_shift, c = q & (ppr - 1);
+    if (q < TP) {
+      const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
+      const uint8_t* src = a.tip_masks + pp;
+#pragma unroll 4
+      for (int taxon = lane >> tp_shift; taxon < n; taxon += group)
+        tips[(taxon * ppr + c) * 4 + r] = src[(size_t)taxon * a.P];
     }
   }
   __syncthreads();
-  int tipcol[R];  // this lane's column inside a taxon's row of the staged tips
-#pragma unroll
-  for (int r = 0; r < R; r++) tipcol[r] = r * ppr + pgrp * 4 + lo;
 
-  auto matrix_reg = [&](int node) { return mats_e[(size_t)node * K * 16 + a_off]; };
+  // What a visit needs from memory is requested kAhead visits before it is used (the
+  // schedule sits in LDS, so future visits' children are known): the two matrix
+  // registers, the two tip words, and the entry itself.  Child ids stay vector
+  // registers (multiplicands of per-lane addresses); the `slots` word, which also
+  // carries the two is-a-tip flags, is the only scalar.
+  constexpr int kAhead = 4;
+  struct Ahead {
+    double A0, A1;
+    uint32_t w0, w1;
+    int slots;
+  };
+  const unsigned lane8 = 8u * lane, col4 = 4u * col;
+  auto request = [&](int i) {
+    const SchedEntry sv = sched_l[i < n - 1 ? i : n - 2];
+    int c0 = sv.child0, c1 = sv.child1;
+    asm volatile("" : "+v"(c0), "+v"(c1));  // stay vector operands (see gradient_mfma_kernel)
+    Ahead h;
+    h.A0 = *reinterpret_cast<const double*>(mats_e + (__umul24((unsigned)c0, node_bytes) + a_off));
+    h.A1 = *reinterpret_cast<const double*>(mats_e + (__umul24((unsigned)c1, node_bytes) + a_off));
+    h.w0 = *reinterpret_cast<const uint32_t*>(tips + (__umul24((unsigned)c0, (unsigned)(ppr * 4)) + col4));
+    h.w1 = *reinterpret_cast<const uint32_t*>(tips + (__umul24((unsigned)c1, (unsigned)(ppr * 4)) + col4));
+    h.slots = sv.slots;
+    return h;
+  };
+  auto slot_ptr = [&](int slot) {
+    return reinterpret_cast<double*>(reinterpret_cast<char*>(plv) +
+                                     ((unsigned)slot * (unsigned)(R * kTile * 8) + lane8));
+  };
+  Ahead ring[kAhead];
+#pragma unroll
+  for (int j = 0; j < kAhead; j++) ring[j] = request(j);
   double L[R];
 #pragma unroll
   for (int r = 0; r < R; r++) L[r] = 0.0;
-  // The matrix element of a visit is requested kAhead visits before it is used: the
-  // transition matrices are read once per (evaluation, XCD), i.e. every such load is
-  // a compulsory HBM miss, and a walk that waited for one per visit would run at
-  // memory latency.  The schedule itself sits in LDS so that future visits' children
-  // are known.  The loop is unrolled by kAhead so that the ring of in-flight
-  // registers is indexed statically.
-  constexpr int kAhead = 4;
-  double ringA0[kAhead], ringA1[kAhead];
-#pragma unroll
-  for (int j = 0; j < kAhead; j++) {
-    const SchedEntry sv = sched_l[j < n - 1 ? j : n - 2];
-    ringA0[j] = matrix_reg(sv.child0);
-    ringA1[j] = matrix_reg(sv.child1);
-  }
-  auto visit = [&](int i, double& A0, double& A1) {
-    const SchedEntry sv = sched_l[i];
-    const int child0 = __builtin_amdgcn_readfirstlane(sv.child0);
-    const int child1 = __builtin_amdgcn_readfirstlane(sv.child1);
-    const int slots = __builtin_amdgcn_readfirstlane(sv.slots);
-    const bool tip0 = child0 < n, tip1 = child1 < n;
-    const double* src0 = plv + (size_t)((slots >> 8) & 0xff) * R * kTile + lane;
-    const double* src1 = plv + (size_t)((slots >> 16) & 0xff) * R * kTile + lane;
-    double* dst = plv + (size_t)(slots & 0xff) * R * kTile + lane;
-    // all operand reads of the visit are issued before the first product: one LDS
-    // round trip per visit instead of one per register
+  auto visit = [&](int i, Ahead& h) {
+    const int slots = __builtin_amdgcn_readfirstlane(h.slots);
     double B0[R], B1[R];
-    if (tip0) {
+    if (slots & (1 << 24)) {
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        if (TIP_PARTIALS) {
-          B0[r] = a.tip_partials[((size_t)child0 * a.P + patc[r]) * 4 + hi];
-        } else {
-          const int st = tips[child0 * TP + tipcol[r]];
-          B0[r] = (st == hi || st > 3) ? 1.0 : 0.0;
-        }
-      }
+      for (int r = 0; r < R; r++) B0[r] = (double)__builtin_amdgcn_ubfe(h.w0, (uint32_t)(8 * r + hi), 1u);
     } else {
+      const double* src = slot_ptr((slots >> 8) & 0xff);
 #pragma unroll
-      for (int r = 0; r < R; r++) B0[r] = src0[r * kTile];
+      for (int r = 0; r < R; r++) B0[r] = src[r * kTile];
     }
-    if (tip1) {
+    if (slots & (1 << 25)) {
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        if (TIP_PARTIALS) {
-          B1[r] = a.tip_partials[((size_t)child1 * a.P + patc[r]) * 4 + hi];
-        } else {
-          const int st = tips[child1 * TP + tipcol[r]];
-          B1[r] = (st == hi || st > 3) ? 1.0 : 0.0;
-        }
-      }
+      for (int r = 0; r < R; r++) B1[r] = (double)__builtin_amdgcn_ubfe(h.w1, (uint32_t)(8 * r + hi), 1u);
     } else {
+      const double* src = slot_ptr((slots >> 16) & 0xff);
 #pragma unroll
-      for (int r = 0; r < R; r++) B1[r] = src1[r * kTile];
+      for (int r = 0; r < R; r++) B1[r] = src[r * kTile];
     }
+    const double A0 = h.A0, A1 = h.A1;
+    h = request(i + kAhead);  // refill this ring slot
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const double D0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, B0[r], 0.0, 0, 0, 0);
       const double D1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, B1[r], 0.0, 0, 0, 0);
       L[r] = D0 * D1;
     }
+    double* dst = slot_ptr(slots & 0xff);
 #pragma unroll
     for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
-    // refill this ring slot with the matrices of visit i + kAhead
-    const SchedEntry sf = sched_l[i + kAhead < n - 1 ? i + kAhead : n - 2];
-    A0 = matrix_reg(sf.child0);
-    A1 = matrix_reg(sf.child1);
   };
   for (int i = 0; i < n - 1; i += kAhead) {
 #pragma unroll
     for (int j = 0; j < kAhead; j++)
-      if (i + j < n - 1) visit(i + j, ringA0[j], ringA1[j]);
+      if (i + j < n - 1) visit(i + j, ring[j]);
   }
   // root: site likelihood = sum over categories (blocks) and states (hi) of
   // cw * pi * L; every lane of a pattern's 4*Kp lanes ends up with the sum
@@ -2450,40 +2435,50 @@ void launch_transition(const TransitionArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(transition_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                      a);
 }
-static size_t loglik_mfma_lds_bytes(int n, int max_slots) {
-  return sizeof(double) * (size_t)max_slots * kLlR * kTile + (size_t)n * kLlR * 16 +
-         sizeof(SchedEntry) * (size_t)(n - 1) + 32;
+// which log-likelihood kernel runs by default when both can (measured)
+constexpr bool kLoglikMfmaDefault = true;
+static size_t loglik_mfma_lds_bytes(int n, int K, int max_slots) {
+  const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
+  const size_t tip_bytes = (((size_t)n * 4 * (16 / kp) + 7) / 8) * 8;
+  const size_t bytes = tip_bytes + sizeof(SchedEntry) * (size_t)(n - 1) +
+                       sizeof(double) * (size_t)max_slots * kLlR * kTile;
+  const size_t reach = (size_t)(2 * n - 1) * 4 * (16 / kp);  // mask fetches of internal ids
+  return bytes > reach ? bytes : reach;
 }
 int loglik_mfma_tiles(int P, int K) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
   const int per_wave = kLlR * (16 / kp);
   return (P + per_wave - 1) / per_wave;
 }
-bool loglik_mfma_supported(int K, bool rescale) {
-  // Opt-in (MI_PHYLO_LOGLIK_PATH=mfma): parity-green, but at 0.46 ms per 1000 DS1
-  // trees it only ties the VALU kernel (0.45 ms) -- both are bound by the latency of
-  // the per-visit control chain at 6-13 waves per CU, not by arithmetic.
-  static const bool enabled = [] {
+bool loglik_mfma_supported(const LikArgs& a, bool rescale) {
+  // The matrix-core log-likelihood kernel needs K <= 4, tips in state-mask form and no
+  // rescaling.  MI_PHYLO_LOGLIK_PATH=valu|mfma forces one of the two kernels.
+  static const int forced = [] {
     const char* env = getenv("MI_PHYLO_LOGLIK_PATH");
-    return env && std::string(env) == "mfma";
+    if (!env) return 0;
+    return std::string(env) == "mfma" ? 2 : (std::string(env) == "valu" ? 1 : 0);
   }();
-  return enabled && K <= 4 && !rescale;
+  const bool possible = a.K <= 4 && !rescale && a.tip_masks != nullptr;
+  if (forced == 1) return false;
+  if (forced == 2) return possible;
+  return possible && kLoglikMfmaDefault;
+}
+static bool use_loglik_mfma(const LikArgs& a, bool rescale, int max_slots) {
+  return loglik_mfma_supported(a, rescale) &&
+         loglik_mfma_lds_bytes(a.n, a.K, max_slots) <= 160 * 1024;
 }
 static void launch_loglik_mfma(const LikArgs& a_in, int count, int max_slots, hipStream_t s) {
   LikArgs a = a_in;
   a.lds_slots = max_slots;
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
   const dim3 grid(loglik_mfma_tiles(a.P, a.K), count), block(kTile);
-  const size_t lds = loglik_mfma_lds_bytes(a.n, max_slots);
-  if (a.tip_partials)
-    hipLaunchKernelGGL((loglik_mfma_kernel<kLlR, true>), grid, block, lds, s, a);
-  else
-    hipLaunchKernelGGL((loglik_mfma_kernel<kLlR, false>), grid, block, lds, s, a);
+  const size_t lds = loglik_mfma_lds_bytes(a.n, a.K, max_slots);
+  allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLlR>), lds);
+  hipLaunchKernelGGL((loglik_mfma_kernel<kLlR>), grid, block, lds, s, a);
 }
 void launch_loglik(const LikArgs& a_in, int count, bool rescale, int max_slots, hipStream_t s) {
   if (count <= 0) return;
-  if (loglik_mfma_supported(a_in.K, rescale) &&
-      loglik_mfma_lds_bytes(a_in.n, max_slots) <= 64 * 1024) {
+  if (use_loglik_mfma(a_in, rescale, max_slots)) {
     launch_loglik_mfma(a_in, count, max_slots, s);
     return;
   }
@@ -2591,7 +2586,9 @@ void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
   hipLaunchKernelGGL(finalize_kernel, dim3(a.T), dim3(64), a.use_lds ? lds : 0, s, a);
 }
 
-const char* loglik_kernel_name() { return "loglik_onchip_kernel"; }
+const char* loglik_kernel_name(const LikArgs& a, bool rescale, int max_slots) {
+  return use_loglik_mfma(a, rescale, max_slots) ? "loglik_mfma_kernel" : "loglik_onchip_kernel";
+}
 const char* gradient_kernel_name() { return "gradient_hbm_kernel"; }
 const char* gradient_onchip_kernel_name() { return "gradient_onchip_kernel"; }
 const char* gradient_mfma_kernel_name() { return "gradient_mfma_kernel"; }

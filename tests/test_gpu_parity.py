@@ -431,9 +431,13 @@ def test_rescaled_gradients_stay_on_the_matrix_core_kernel():
             1e-9 * max(1.0, abs(og["site_model"][t]))
 
 
-def test_mfma_loglik_path_matches_oracle():
-    """The opt-in matrix-core log-likelihood kernel (v_mfma_f64_4x4x4_4b_f64): same
-    parity bar.  The path is chosen once per process, hence the subprocess."""
+@pytest.mark.parametrize("path,kernel", [("mfma", "loglik_mfma_kernel"),
+                                         ("valu", "loglik_onchip_kernel")])
+def test_both_loglik_kernels_match_oracle(path, kernel):
+    """The matrix-core log-likelihood kernel (default for K <= 4 without rescaling) and
+    the VALU kernel (rescaling, K > 4, real-valued tip partials) can each be forced with
+    MI_PHYLO_LOGLIK_PATH: same parity bar for both.  The path is chosen once per
+    process, hence the subprocess."""
     import subprocess
     import sys
     code = r"""
@@ -453,13 +457,13 @@ for site, K in (('constant', 1), ('weibull+2', 2), ('weibull+3', 3), ('weibull+4
         ll = eng.log_likelihoods(pids, bls, pr)
         oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, False, 4)
         assert np.all(np.abs(ll - oll) <= 1e-10 * np.abs(oll)), (site, subst)
-        name = eng.last_call_info()[0]
-print('mfma-ok')
+        assert eng.last_call_info()[0] == sys.argv[1], eng.last_call_info()
+print('path-ok')
 """
-    env = dict(os.environ, MI_PHYLO_LOGLIK_PATH="mfma")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
-                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert "mfma-ok" in out.stdout, out.stdout + out.stderr
+    env = dict(os.environ, MI_PHYLO_LOGLIK_PATH=path)
+    out = subprocess.run([sys.executable, "-c", code, kernel], capture_output=True, text=True,
+                         env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "path-ok" in out.stdout, out.stdout + out.stderr
 
 
 def test_random_rooted_vs_oracle():

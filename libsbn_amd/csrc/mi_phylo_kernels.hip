@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
 // per SIMD (28 MAC/clk/SIMD, 1.8x the FP64 VALU peak), and the VALU stays free
 // for the element-wise products.
 // ------------------------------------------------------------------------
-template <int R>
+template <int R, bool RESCALE>
 __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
   extern __shared__ double lds[];
@@ -1116,8 +1116,12 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
 #pragma unroll
   for (int j = 0; j < kAhead; j++) ring[j] = request(j);
   double L[R];
+  int esum[R];  // RESCALE: power-of-two exponents removed so far, per pattern
 #pragma unroll
-  for (int r = 0; r < R; r++) L[r] = 0.0;
+  for (int r = 0; r < R; r++) {
+    L[r] = 0.0;
+    esum[r] = 0;
+  }
   auto visit = [&](int i, Ahead& h) {
     const int slots = __builtin_amdgcn_readfirstlane(h.slots);
     double B0[R], B1[R];
@@ -1144,6 +1148,17 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
       const double D0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, B0[r], 0.0, 0, 0, 0);
       const double D1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, B1[r], 0.0, 0, 0, 0);
       L[r] = D0 * D1;
+      if (RESCALE) {
+        // exact per-pattern power-of-two rescaling (largest entry over states, categories)
+        double mx = L[r];
+        mx = fmax(mx, __shfl_xor(mx, 16, 64));
+        mx = fmax(mx, __shfl_xor(mx, 32, 64));
+        if (Kp >= 2) mx = fmax(mx, __shfl_xor(mx, 4, 64));
+        if (Kp >= 4) mx = fmax(mx, __shfl_xor(mx, 8, 64));
+        const int ex = mx > 0.0 ? ilogb(mx) : 0;
+        L[r] = ldexp(L[r], -ex);
+        esum[r] += ex;
+      }
     }
     double* dst = slot_ptr(slots & 0xff);
 #pragma unroll
@@ -1166,9 +1181,9 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
     if (Kp >= 4) v += __shfl_xor(v, 8, 64);
     const bool owner = hi == 0 && cat == 0 && pat[r] < a.P;  // one lane per pattern
     if (owner) {
-      if (a.site_lik)
+      if (!RESCALE && a.site_lik)
         a.site_lik[((size_t)a.grad_offset + te.eval) * a.tiles * kTile + pat[r]] = v;
-      ll += pw[r] * log(v);
+      ll += pw[r] * (RESCALE ? log(v) + esum[r] * 0.69314718055994530942 : log(v));
     }
   }
   ll = wave_sum(ll);
@@ -2451,14 +2466,14 @@ int loglik_mfma_tiles(int P, int K) {
   return (P + per_wave - 1) / per_wave;
 }
 bool loglik_mfma_supported(const LikArgs& a, bool rescale) {
-  // The matrix-core log-likelihood kernel needs K <= 4, tips in state-mask form and no
-  // rescaling.  MI_PHYLO_LOGLIK_PATH=valu|mfma forces one of the two kernels.
+  // The matrix-core log-likelihood kernel needs K <= 4 and tips in state-mask form.  MI_PHYLO_LOGLIK_PATH=valu|mfma forces one of the two kernels.
   static const int forced = [] {
     const char* env = getenv("MI_PHYLO_LOGLIK_PATH");
     if (!env) return 0;
     return std::string(env) == "mfma" ? 2 : (std::string(env) == "valu" ? 1 : 0);
   }();
-  const bool possible = a.K <= 4 && !rescale && a.tip_masks != nullptr;
+  (void)rescale;
+  const bool possible = a.K <= 4 && a.tip_masks != nullptr;
   if (forced == 1) return false;
   if (forced == 2) return possible;
   return possible && kLoglikMfmaDefault;
@@ -2467,19 +2482,25 @@ static bool use_loglik_mfma(const LikArgs& a, bool rescale, int max_slots) {
   return loglik_mfma_supported(a, rescale) &&
          loglik_mfma_lds_bytes(a.n, a.K, max_slots) <= 160 * 1024;
 }
-static void launch_loglik_mfma(const LikArgs& a_in, int count, int max_slots, hipStream_t s) {
+static void launch_loglik_mfma(const LikArgs& a_in, int count, bool rescale, int max_slots,
+                               hipStream_t s) {
   LikArgs a = a_in;
   a.lds_slots = max_slots;
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
   const dim3 grid(loglik_mfma_tiles(a.P, a.K), count), block(kTile);
   const size_t lds = loglik_mfma_lds_bytes(a.n, a.K, max_slots);
-  allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLlR>), lds);
-  hipLaunchKernelGGL((loglik_mfma_kernel<kLlR>), grid, block, lds, s, a);
+  if (rescale) {
+    allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLlR, true>), lds);
+    hipLaunchKernelGGL((loglik_mfma_kernel<kLlR, true>), grid, block, lds, s, a);
+  } else {
+    allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLlR, false>), lds);
+    hipLaunchKernelGGL((loglik_mfma_kernel<kLlR, false>), grid, block, lds, s, a);
+  }
 }
 void launch_loglik(const LikArgs& a_in, int count, bool rescale, int max_slots, hipStream_t s) {
   if (count <= 0) return;
   if (use_loglik_mfma(a_in, rescale, max_slots)) {
-    launch_loglik_mfma(a_in, count, max_slots, s);
+    launch_loglik_mfma(a_in, count, rescale, max_slots, s);
     return;
   }
   LikArgs a = a_in;

@@ -1046,11 +1046,13 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   const SchedEntry* __restrict__ sched = a.sched + (size_t)t * (a.n - 1);
   const int K = a.K, n = a.n, Kp = a.kp;       // Kp in {1, 2, 4}: categories per instruction
   const int cat = b % Kp, pgrp = b / Kp, ppr = 16 / Kp;  // ppr = patterns per register
-  const int catc = cat < K ? cat : K - 1;      // padded category (weight 0) reads a valid matrix
+  // K > 4: the categories are walked four at a time (`groups` complete walks that only
+  // meet in the per-pattern site likelihood); the per-group lane constants follow
+  const int groups = Kp == 4 ? (K + 3) / 4 : 1;
   const char* __restrict__ mats_e =
       reinterpret_cast<const char*>(a.mats + (size_t)e * (a.N - 1) * K * 16);
-  // per-lane element of a child's matrix block: A_b[i = lo][k = hi], as a byte offset
-  const unsigned a_off = 8u * (catc * 16 + lo * 4 + hi);
+  unsigned a_off = 0;  // per-lane element of a child's matrix block: A_b[i = lo][k = hi] (bytes)
+  double wgt = 0.0;    // category weight x stationary frequency of this lane
   const unsigned node_bytes = (unsigned)K * 128u;
   const int TP = ppr * R, tile_start = te.tile * TP;
   const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
@@ -1061,7 +1063,6 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
     pat[r] = tile_start + r * ppr + col;
     pw[r] = a.weights[pat[r] < a.P ? pat[r] : a.P - 1];
   }
-  const double wgt = (cat < K ? model->cat_weight[cat] : 0.0) * model->pi[hi];
   // LDS: tip state masks [taxon][column][r] (bit s: compatible with state s; first, so
   // that the ignored mask fetch of an internal node id needs no clamping) | schedule |
   // vectors [slot][r][lane]
@@ -1112,11 +1113,8 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
     return reinterpret_cast<double*>(reinterpret_cast<char*>(plv) +
                                      ((unsigned)slot * (unsigned)(R * kTile * 8) + lane8));
   };
-  Ahead ring[kAhead];
-#pragma unroll
-  for (int j = 0; j < kAhead; j++) ring[j] = request(j);
   double L[R];
-  int esum[R];  // RESCALE: power-of-two exponents removed so far, per pattern
+  int esum[R];  // RESCALE: power-of-two exponents removed so far in this walk, per pattern
 #pragma unroll
   for (int r = 0; r < R; r++) {
     L[r] = 0.0;
@@ -1164,26 +1162,58 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
 #pragma unroll
     for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
   };
-  for (int i = 0; i < n - 1; i += kAhead) {
+  double site[R];
+  int site_exp[R];
 #pragma unroll
-    for (int j = 0; j < kAhead; j++)
-      if (i + j < n - 1) visit(i + j, ring[j]);
+  for (int r = 0; r < R; r++) {
+    site[r] = 0.0;
+    site_exp[r] = 0;
   }
-  // root: site likelihood = sum over categories (blocks) and states (hi) of
-  // cw * pi * L; every lane of a pattern's 4*Kp lanes ends up with the sum
+  for (int g = 0; g < groups; g++) {
+    const int cat_g = 4 * g + cat;
+    const int catc = cat_g < K ? cat_g : K - 1;  // padded category (weight 0) reads a valid matrix
+    a_off = 8u * (catc * 16 + lo * 4 + hi);
+    wgt = (cat_g < K ? model->cat_weight[cat_g] : 0.0) * model->pi[hi];
+    Ahead ring[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) ring[j] = request(j);
+#pragma unroll
+    for (int r = 0; r < R; r++) esum[r] = 0;
+    for (int i = 0; i < n - 1; i += kAhead) {
+#pragma unroll
+      for (int j = 0; j < kAhead; j++)
+        if (i + j < n - 1) visit(i + j, ring[j]);
+    }
+    // root: this group's share of the site likelihood = sum over its categories (blocks)
+    // and the states (hi) of cw * pi * L; every lane of a pattern ends up with the sum
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      double v = wgt * L[r];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (Kp >= 2) v += __shfl_xor(v, 4, 64);
+      if (Kp >= 4) v += __shfl_xor(v, 8, 64);
+      if (!RESCALE) {
+        site[r] += v;
+      } else if (g == 0) {
+        site[r] = v;
+        site_exp[r] = esum[r];
+      } else if (esum[r] > site_exp[r]) {
+        site[r] = ldexp(site[r], site_exp[r] - esum[r]) + v;
+        site_exp[r] = esum[r];
+      } else {
+        site[r] += ldexp(v, esum[r] - site_exp[r]);
+      }
+    }
+  }
   double ll = 0.0;
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    double v = wgt * L[r];
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if (Kp >= 2) v += __shfl_xor(v, 4, 64);
-    if (Kp >= 4) v += __shfl_xor(v, 8, 64);
     const bool owner = hi == 0 && cat == 0 && pat[r] < a.P;  // one lane per pattern
     if (owner) {
       if (!RESCALE && a.site_lik)
-        a.site_lik[((size_t)a.grad_offset + te.eval) * a.tiles * kTile + pat[r]] = v;
-      ll += pw[r] * (RESCALE ? log(v) + esum[r] * 0.69314718055994530942 : log(v));
+        a.site_lik[((size_t)a.grad_offset + te.eval) * a.tiles * kTile + pat[r]] = site[r];
+      ll += pw[r] * (RESCALE ? log(site[r]) + site_exp[r] * 0.69314718055994530942 : log(site[r]));
     }
   }
   ll = wave_sum(ll);
@@ -2466,14 +2496,15 @@ int loglik_mfma_tiles(int P, int K) {
   return (P + per_wave - 1) / per_wave;
 }
 bool loglik_mfma_supported(const LikArgs& a, bool rescale) {
-  // The matrix-core log-likelihood kernel needs K <= 4 and tips in state-mask form.  MI_PHYLO_LOGLIK_PATH=valu|mfma forces one of the two kernels.
+  // The matrix-core log-likelihood kernel needs tips in state-mask form (K > 4: the
+  // categories are walked four at a time).  MI_PHYLO_LOGLIK_PATH=valu|mfma forces one of the two kernels.
   static const int forced = [] {
     const char* env = getenv("MI_PHYLO_LOGLIK_PATH");
     if (!env) return 0;
     return std::string(env) == "mfma" ? 2 : (std::string(env) == "valu" ? 1 : 0);
   }();
   (void)rescale;
-  const bool possible = a.K <= 4 && a.tip_masks != nullptr;
+  const bool possible = a.K <= kMaxCategories && a.tip_masks != nullptr;
   if (forced == 1) return false;
   if (forced == 2) return possible;
   return possible && kLoglikMfmaDefault;

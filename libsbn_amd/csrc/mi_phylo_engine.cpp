@@ -2,7 +2,8 @@
 // per-call launch sequence, error reporting.  Compiled with hipcc; no torch.
 //
 // Per call (all on one HIP stream, no host synchronisation in the *_device path):
-//   tree_setup -> model_setup -> transition -> {loglik_onchip | gradient_hbm}* -> finalize
+//   tree_setup -> model_setup -> transition -> {loglik_* | gradient_mfma | gradient_hbm}*
+//   -> reduce_tiles -> finalize
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -150,9 +151,8 @@ struct mi_engine {
       ll_sum, g_sum, status;
   PinnedArena pinned;
   bool allow_onchip_gradient = true;
-  bool prefer_mfma_gradient = true;  // matrix-core gradient kernel when K <= 4 and it fits
   bool analytic_subst = false;       // MI_PHYLO_SUBST_GRADIENT=analytic (opt-in)
-  int gradient_path = 0;  // 0 auto, 1 valu on-chip, 2 hbm, 3 mfma
+  int gradient_path = 0;  // 0 auto, 2 hbm, 3 mfma (MI_PHYLO_GRADIENT_PATH)
   // staging for the host-pointer entry points
   Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
       in_ratios, out_ll, out_a, out_b, out_site, out_subst;
@@ -226,7 +226,9 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / per));
     if (need_hbm_path && e->plv.ensure(per * chunk)) return 1;
     const size_t g_width = std::max<size_t>(2 * (size_t)N, (size_t)gradient_mfma_width(n, true));
-    if (e->g_part.ensure(sizeof(double) * (size_t)c.Eg * e->ll_stride * g_width)) return 1;
+    if (e->g_part.ensure(sizeof(double) * (size_t)c.Eg * e->ll_stride * gradient_mfma_groups(e->K) *
+                         g_width))
+      return 1;
     if (e->site_lik.ensure(sizeof(double) * (size_t)c.Eg * e->tiles * kTile)) return 1;
   }
   return 0;
@@ -258,12 +260,11 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   if (e->param_count > 0 && !d.params) return fail("null parameter matrix");
   // on-chip gradient kernels: the matrix-core one (K <= 4; rescaling supported) or the
   // VALU one (no rescaling); everything else takes the HBM-streamed kernel
-  const bool fits_chip = d.gradient && e->allow_onchip_gradient && gradient_onchip_fits(e->n);
-  const bool mfma = fits_chip && e->have_tip_masks && e->gradient_path != 1 &&
-                    gradient_mfma_fits(e->n, e->K, d.rescaling) && reduce_tiles_fits(e->N) &&
-                    (e->gradient_path == 3 || e->prefer_mfma_gradient);
-  const bool onchip = mfma || (fits_chip && e->spec.use_tip_states && !d.rescaling);
-  const int g_tiles = mfma ? loglik_mfma_tiles(e->P, e->K) : e->tiles;
+  const bool mfma = d.gradient && e->allow_onchip_gradient && e->have_tip_masks &&
+                    gradient_mfma_fits(e->n, e->K, d.rescaling) && reduce_tiles_fits(e->N);
+  const bool onchip = mfma;  // the only on-chip gradient kernel; everything else streams PLVs
+  const int groups = mfma ? gradient_mfma_groups(e->K) : 1;
+  const int g_tiles = mfma ? loglik_mfma_tiles(e->P, e->K) * groups : e->tiles;
   const bool analytic = e->analytic_subst && mfma && e->spec.subst_model == MI_SUBST_GTR;
   if (reserve(e, d.T, d.gradient, !onchip, analytic)) return 1;
   const CallShape c = call_shape(e, d.T, d.gradient, analytic);
@@ -289,7 +290,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ts.status = e->status.as<int32_t>();
   ts.max_slots = e->max_slots;
   // the Sethi-Ullman schedule with LDS slots is what the log-likelihood kernels walk
-  ts.need_slots = !(d.gradient && mfma && (!c.gtr || analytic));
+  ts.need_slots = !(d.gradient && mfma && groups == 1 && (!c.gtr || analytic));
   launch_tree_setup(ts, s);
 
   ModelSetupArgs ms{};
@@ -322,7 +323,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   probe.n = n;
   probe.K = e->K;
   probe.tip_masks = e->have_tip_masks ? e->tip_masks.as<uint8_t>() : nullptr;
-  const bool loglik_runs = !d.gradient || (c.gtr && !analytic) || (onchip && !mfma);
+  const bool loglik_runs =
+      !d.gradient || (c.gtr && !analytic) || (mfma && groups > 1);
   const bool loglik_is_valu =
       std::string(loglik_kernel_name(probe, d.rescaling, e->max_slots)) == "loglik_onchip_kernel";
   const bool need_tip_tables = loglik_runs && loglik_is_valu;
@@ -369,21 +371,18 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     }
   };
   auto grad_range = [&](int eval_begin, int grad_begin, int count) {
-    if (mfma || onchip) {
+    if (mfma) {
       for (int done = 0; done < count; done += kMaxEvals) {
         const int part = std::min(kMaxEvals, count - done);
         LikArgs g = la;
         g.eval_offset = eval_begin + done;
         g.grad_offset = grad_begin + done;
-        if (mfma) {
-          launch_gradient_mfma(g, part, d.rescaling, analytic, s);
-        } else {
-          // phase A: on-chip log-likelihood (also writes per-pattern site likelihoods),
-          // phase B: on-chip pre-order / edge derivatives
+        if (groups > 1) {
+          // K > 4: the site likelihoods (and logL) come from a log-likelihood pass
           g.site_lik = e->site_lik.as<double>();
           launch_loglik(g, part, false, e->max_slots, s);
-          launch_gradient_onchip(g, part, s);
         }
+        launch_gradient_mfma(g, part, d.rescaling, analytic, s);
       }
       return;
     }
@@ -411,8 +410,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
       loglik_range(T, 16 * T);
     }
     if (c.site_separate) grad_range(17 * T, T, T);
-    e->dominant = mfma ? gradient_mfma_kernel_name()
-                       : onchip ? gradient_onchip_kernel_name() : gradient_kernel_name();
+    e->dominant = mfma ? gradient_mfma_kernel_name() : gradient_kernel_name();
   }
   if (prof) e->prof_used++;
   e->last_evals = c.E;
@@ -599,7 +597,7 @@ int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
     e->analytic_subst = std::string(env) == "analytic";
   if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH")) {  // force one gradient kernel
     const std::string v(env);
-    e->gradient_path = v == "valu" ? 1 : v == "hbm" ? 2 : v == "mfma" ? 3 : 0;
+    e->gradient_path = v == "hbm" ? 2 : v == "mfma" ? 3 : 0;
     e->allow_onchip_gradient = v != "hbm";
   }
 
@@ -725,8 +723,8 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
   HIP_TRY(hipSetDevice(e->spec.device));
   // the HBM arena is only reserved when a later call may need it (rescaling with the VALU
   // kernel or real-valued tip partials still can: reserve() grows on demand then)
-  const bool onchip = e->allow_onchip_gradient && gradient_onchip_fits(e->n) &&
-                      (e->have_tip_masks || e->spec.use_tip_states);
+  const bool onchip = e->allow_onchip_gradient && e->have_tip_masks &&
+                      gradient_mfma_fits(e->n, e->K, false);
   return reserve(e, tree_count, for_gradients != 0, !onchip);
 }
 

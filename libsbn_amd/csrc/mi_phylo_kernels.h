@@ -72,6 +72,7 @@ struct LikArgs {
   int n, N, P, K, tiles;
   int lds_slots;    // PLV slots in LDS (set by the launcher)
   int kp;           // MFMA path: categories per instruction (1, 2 or 4; set by the launcher)
+  int cat_groups;   // matrix-core gradient: groups of four categories (K > 4; set by the launcher)
   int ll_tiles;     // stride of ll_part per evaluation (>= partial sums any kernel writes)
   int g_tiles;      // stride of g_part per gradient evaluation = tiles of the gradient kernel used
   int eval_offset;  // first evaluation of this launch
@@ -133,12 +134,10 @@ void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t 
 // Gradient with all partial-likelihood vectors resident in LDS (no rescaling;
 // needs the per-pattern site likelihoods written by launch_loglik with
 // a.site_lik set).  Returns false when the tree does not fit in LDS.
-size_t gradient_onchip_lds_bytes(int n);
-bool gradient_onchip_fits(int n);
-void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s);
 // Same walk on the FP64 matrix cores, all categories per instruction (K <= 4); also
 // writes the log-likelihood partial sums, so no separate logL pass is needed.
 bool gradient_mfma_fits(int n, int K, bool rescale);
+int gradient_mfma_groups(int K);  // waves per pattern tile (category groups of four)
 // subst: analytic substitution gradient statistics appended (kSubstExtra doubles)
 int gradient_mfma_width(int n, bool subst = false);  // doubles per (gradient evaluation, tile) of its partial sums
 void launch_gradient_mfma(const LikArgs& a, int count, bool rescale, bool subst, hipStream_t s);
@@ -179,7 +178,6 @@ void launch_finalize(const FinalizeArgs& a, hipStream_t s);
 
 const char* loglik_kernel_name(const LikArgs& a, bool rescale, int max_slots);
 const char* gradient_kernel_name();
-const char* gradient_onchip_kernel_name();
 const char* gradient_mfma_kernel_name();
 
 }  // namespace miphylo

@@ -1361,277 +1361,20 @@ __global__ __launch_bounds__(kTile) void gradient_hbm_kernel(LikArgs a) {
 }
 
 // ------------------------------------------------------------------------
-// Gradient, everything on chip.  One wave per (evaluation, 64-pattern tile),
-// rate categories one after the other.  For one category the wave keeps the
-// post-order vectors of the STORED internal nodes (at most (n-2)/2 of them, see
-// tree_setup_kernel) in lane-private LDS columns ([slot][state][lane], 2 KiB
-// each), recomputes the others from their children where needed, then walks the
-// tree parents-first and overwrites each stored vector with the node's pre-order
-// vector once it is dead.  Halving the resident set doubles the waves per CU
-// (6 at n = 27), which is what this latency-bound walk needs.
-// The per-pattern denominator of the edge derivative is the site likelihood
-// (q_x . L_x is the same for every edge x), which the log-likelihood kernel has
-// already written, so every (pattern, category) contributes additively:
-//   g_x = sum_p (w_p / site_p) sum_k cw_k r_k  q_x[k,p]^T Q L_x[k,p].
-// The four per-visit sums (2 edges x {branch, site}) are reduced across the
-// wave with a transposed butterfly (v_permlane32_swap, v_permlane16_swap, DPP
-// row shifts) and accumulated in LDS.  HBM traffic: tip states, schedule,
-// transition matrices, site likelihoods in; 2N doubles out.
+// DPP helper of the matrix-core kernels: v[lane] += v[lane - SHIFT] within each 16-lane
+// row (0 shifted in).
 // ------------------------------------------------------------------------
 template <int SHIFT>
 __device__ __forceinline__ double row_shr_add(double v) {
-  // v[lane] += v[lane - SHIFT] within each 16-lane row (0 shifted in)
   const int lo = __double2loint(v), hi = __double2hiint(v);
   const int slo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + SHIFT, 0xf, 0xf, true);
   const int shi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + SHIFT, 0xf, 0xf, true);
   return v + __hiloint2double(shi, slo);
 }
 
-// Sums x0..x3 over the 64 lanes.  Afterwards lane 15 holds sum(x0), lane 31
-// sum(x2), lane 47 sum(x1), lane 63 sum(x3); returns this lane's value.
-__device__ __forceinline__ double reduce4_transposed(double x0, double x1, double x2,
-                                                     double x3) {
-  auto swap32 = [](double a, double b) {
-    // a' = {a[0:31], b[0:31]}, b' = {a[32:63], b[32:63]}  ->  a' + b'
-    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a),
-                                                     (unsigned)__double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a),
-                                                     (unsigned)__double2hiint(b), false, false);
-    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-  };
-  const double y0 = swap32(x0, x1);  // lanes <32: x0 partial, >=32: x1 partial
-  const double y1 = swap32(x2, x3);  // lanes <32: x2 partial, >=32: x3 partial
-  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(y0),
-                                                   (unsigned)__double2loint(y1), false, false);
-  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(y0),
-                                                   (unsigned)__double2hiint(y1), false, false);
-  // rows: 0 -> x0, 1 -> x2, 2 -> x1, 3 -> x3
-  double z = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-  z = row_shr_add<8>(z);
-  z = row_shr_add<4>(z);
-  z = row_shr_add<2>(z);
-  z = row_shr_add<1>(z);
-  return z;
-}
-
-// A wave-uniform 4x4 matrix held in VGPRs.  It is fetched with vector loads (every
-// lane the same address -> one L1 line, broadcast) rather than scalar loads so that
-// the next visit's matrices can be in flight while the current visit computes:
-// the SGPR file has no room for a second pair of matrices.
-struct M16 {
-  double m[16];
-};
-__device__ __forceinline__ M16 load_matrix_vgpr(const double* __restrict__ base, int vzero) {
-  const double2* __restrict__ q = reinterpret_cast<const double2*>(base + vzero);
-  M16 r;
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const double2 v = q[j];
-    r.m[2 * j] = v.x;
-    r.m[2 * j + 1] = v.y;
-  }
-  return r;
-}
-
-__global__ __launch_bounds__(kTile) void gradient_onchip_kernel(LikArgs a) {
-  extern __shared__ double glds[];
-  const int lane = threadIdx.x;
-  const TileEval te = xcd_tile_eval();
-  const int tile = te.tile;
-  const int e = a.eval_offset + te.eval;
-  const int gi = a.grad_offset + te.eval;
-  int t, mi;
-  a.map.decode(e, t, mi);
-  const DevModel* __restrict__ model = a.models + mi;
-  const int p = tile * kTile + lane;
-  const int pc = p < a.P ? p : a.P - 1;
-  const int K = a.K, n = a.n, N = a.N;
-  const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
-  const MacroEntry* __restrict__ macros = a.macros + (size_t)t * max_macros(n);
-  const int M = a.macro_count[t];
-  // LDS: one 2 KiB column block per STORED node ([slot][state][lane]) | accumulators
-  double* plv = glds;
-  double* gacc = glds + (size_t)max_stored(n) * 4 * kTile;  // [2][N]
-  for (int i = lane; i < 2 * N; i += kTile) gacc[i] = 0.0;
-  const int8_t* __restrict__ tips_p = a.tip_states + pc;
-  const double site = a.site_lik[(size_t)gi * a.tiles * kTile + p];
-  const double coef = p < a.P ? a.weights[pc] / site : 0.0;
-  // Q and pi stay in VGPRs (as wave-uniform values): the SGPR file is needed for
-  // the two transition matrices in flight.
-  double Q[16];
-  for (int i = 0; i < 16; i++) {
-    Q[i] = model->Q[i];
-    asm volatile("" : "+v"(Q[i]));
-  }
-  D4 pi4 = {model->pi[0], model->pi[1], model->pi[2], model->pi[3]};
-  asm volatile("" : "+v"(pi4.x0), "+v"(pi4.x1), "+v"(pi4.x2), "+v"(pi4.x3));
-  __syncthreads();
-  if (M <= 0) return;  // malformed tree: status already reported by tree_setup
-
-  auto load_slot = [&](int slot) {
-    const double* c = plv + (size_t)slot * 4 * kTile + lane;
-    return D4{c[0], c[kTile], c[2 * kTile], c[3 * kTile]};
-  };
-  auto store_slot = [&](int slot, D4 v) {
-    double* c = plv + (size_t)slot * 4 * kTile + lane;
-    c[0] = v.x0;
-    c[kTile] = v.x1;
-    c[2 * kTile] = v.x2;
-    c[3 * kTile] = v.x3;
-  };
-  auto tip_state = [&](int node) { return (int)tips_p[(size_t)(node < n ? node : 0) * a.P]; };
-  // partial vector of a tip (compact state) or of a stored node: both reads are
-  // issued unconditionally, one is selected (no branch, one LDS round trip)
-  auto operand = [&](int node, int slot, int st) {
-    const bool is_tip = node < n;
-    const D4 c = load_slot(slot);
-    const D4 tv = tip_vector(st);
-    return D4{is_tip ? tv.x0 : c.x0, is_tip ? tv.x1 : c.x1, is_tip ? tv.x2 : c.x2,
-              is_tip ? tv.x3 : c.x3};
-  };
-  auto mat = [&](int node, int k) { return as_const(mats_e + ((size_t)node * K + k) * 16); };
-  struct TipStates {
-    int c[2], g[4];
-  };
-  auto fetch_tips = [&](const MacroEntry& me) {
-    TipStates ts;
-    ts.c[0] = tip_state(me.child[0]);
-    ts.c[1] = tip_state(me.child[1]);
-    for (int j = 0; j < 4; j++) ts.g[j] = tip_state(me.grand[j]);
-    return ts;
-  };
-  // Pull the NEXT macro's transition matrices (up to six) into the scalar data
-  // cache: one dword from each 64-byte line.  The value is consumed an iteration
-  // later, so the loads are in flight behind this macro's arithmetic.
-  auto touch_macro = [&](const MacroEntry& me, int k) {
-    int acc = 0;
-    for (int j = 0; j < 2; j++) {
-      const cint_ptr pm = (cint_ptr)(uintptr_t)(
-          mats_e + ((size_t)__builtin_amdgcn_readfirstlane(me.child[j]) * K + k) * 16);
-      acc ^= pm[0] ^ pm[16];
-    }
-    for (int j = 0; j < 4; j++) {
-      const cint_ptr pm = (cint_ptr)(uintptr_t)(
-          mats_e + ((size_t)__builtin_amdgcn_readfirstlane(me.grand[j]) * K + k) * 16);
-      acc ^= pm[0] ^ pm[16];
-    }
-    return acc;
-  };
-  int touched = 0;
-  auto accumulate = [&](double r, int edge_a, int edge_b) {
-    // after reduce4_transposed(x_a_branch, x_b_branch, x_a_site, x_b_site):
-    // lane 15: branch a, lane 31: site a, lane 47: branch b, lane 63: site b
-    if ((lane & 15) == 15) {
-      const int which = lane >> 4;
-      const int edge = (which & 2) ? edge_b : edge_a;
-      double* dst = gacc + ((which & 1) ? N : 0) + edge;
-      *dst += r;
-    }
-  };
-
-  for (int k = 0; k < K; k++) {
-    // ================= post-order over the stored nodes =================
-    // (the root's macro is the last one; its vector is not needed here)
-    {
-      MacroEntry cur = macros[0];
-      TipStates ts = fetch_tips(cur);
-      for (int m = 0; m < M - 1; m++) {
-        const MacroEntry nxt = macros[m + 1];
-        const TipStates tsn = fetch_tips(nxt);
-        asm volatile("" ::"s"(touched));
-        touched = touch_macro(cur, k);  // cur's own matrices: first use is a few
-                                        // hundred cycles away (operands come first)
-        D4 L[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          if (((cur.shape >> (2 * j)) & 3) == 2) {
-            const D4 La = operand(cur.grand[2 * j], cur.gslot[2 * j], ts.g[2 * j]);
-            const D4 Lb = operand(cur.grand[2 * j + 1], cur.gslot[2 * j + 1], ts.g[2 * j + 1]);
-            L[j] = mul4(matvec(mat(cur.grand[2 * j], k), La),
-                        matvec(mat(cur.grand[2 * j + 1], k), Lb));
-          } else {
-            L[j] = operand(cur.child[j], cur.cslot[j], ts.c[j]);
-          }
-        }
-        store_slot(cur.qslot, mul4(matvec(mat(cur.child[0], k), L[0]),
-                                   matvec(mat(cur.child[1], k), L[1])));
-        cur = nxt;
-        ts = tsn;
-      }
-    }
-    // ================= pre-order + edge derivatives =================
-    const double cw = model->cat_weight[k];
-    const double fb = coef * cw * model->cat_rate[k];
-    const double fs = coef * cw * model->cat_drate[k];
-    {
-      MacroEntry cur = macros[M - 1];
-      TipStates ts = fetch_tips(cur);
-      for (int m = M - 1; m >= 0; m--) {
-        const MacroEntry nxt = macros[m > 0 ? m - 1 : 0];
-        const TipStates tsn = fetch_tips(nxt);
-        asm volatile("" ::"s"(touched));
-        touched = touch_macro(cur, k);
-        const bool is_root = cur.qslot < 0;
-        const D4 qs = load_slot(is_root ? 0 : cur.qslot);
-        const D4 qv = {is_root ? pi4.x0 : qs.x0, is_root ? pi4.x1 : qs.x1,
-                       is_root ? pi4.x2 : qs.x2, is_root ? pi4.x3 : qs.x3};
-        D4 L[2], La[2], Lb[2], Ap[2], Bp[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          if (((cur.shape >> (2 * j)) & 3) == 2) {
-            La[j] = operand(cur.grand[2 * j], cur.gslot[2 * j], ts.g[2 * j]);
-            Lb[j] = operand(cur.grand[2 * j + 1], cur.gslot[2 * j + 1], ts.g[2 * j + 1]);
-            Ap[j] = matvec(mat(cur.grand[2 * j], k), La[j]);
-            Bp[j] = matvec(mat(cur.grand[2 * j + 1], k), Lb[j]);
-            L[j] = mul4(Ap[j], Bp[j]);
-          } else {
-            L[j] = operand(cur.child[j], cur.cslot[j], ts.c[j]);
-            La[j] = Lb[j] = Ap[j] = Bp[j] = D4{0, 0, 0, 0};
-          }
-        }
-        D4 q[2];
-        {
-          const cdouble_ptr M0 = mat(cur.child[0], k);
-          const cdouble_ptr M1 = mat(cur.child[1], k);
-          const D4 A = matvec(M0, L[0]), B = matvec(M1, L[1]);
-          q[0] = matTvec(M0, mul4(qv, B));
-          q[1] = matTvec(M1, mul4(qv, A));
-        }
-        {
-          const double n0 = dot4(q[0], matvec(Q, L[0]));
-          const double n1 = dot4(q[1], matvec(Q, L[1]));
-          accumulate(reduce4_transposed(fb * n0, fb * n1, fs * n0, fs * n1), cur.child[0],
-                     cur.child[1]);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          if (((cur.shape >> (2 * j)) & 3) == 1) {
-            store_slot(cur.cslot[j], q[j]);
-          } else if (((cur.shape >> (2 * j)) & 3) == 2) {
-            const int ga = cur.grand[2 * j], gb = cur.grand[2 * j + 1];
-            const D4 qa = matTvec(mat(ga, k), mul4(q[j], Bp[j]));
-            const D4 qb = matTvec(mat(gb, k), mul4(q[j], Ap[j]));
-            const double na = dot4(qa, matvec(Q, La[j]));
-            const double nb = dot4(qb, matvec(Q, Lb[j]));
-            accumulate(reduce4_transposed(fb * na, fb * nb, fs * na, fs * nb), ga, gb);
-            if (ga >= n) store_slot(cur.gslot[2 * j], qa);
-            if (gb >= n) store_slot(cur.gslot[2 * j + 1], qb);
-          }
-        }
-        cur = nxt;
-        ts = tsn;
-      }
-    }
-  }
-  asm volatile("" ::"s"(touched));
-  __syncthreads();
-  double* gout = a.g_part + ((size_t)gi * a.g_tiles + tile) * 2 * N;
-  for (int i = lane; i < 2 * N; i += kTile) gout[i] = gacc[i];
-}
-
 // ------------------------------------------------------------------------
 // Gradient on the FP64 matrix cores: same half-storage walk as
-// gradient_onchip_kernel, same register layout as loglik_mfma_kernel.
+// superseded VALU kernel of this round, same register layout as loglik_mfma_kernel.
 //   * all rate categories sit in the four blocks of one instruction: no category
 //     loop, and the per-pattern site likelihood (the derivative's denominator) is
 //     computed by this kernel itself at the root -- no separate log-likelihood pass
@@ -1661,7 +1404,12 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   a.map.decode(e, t, mi);
   const DevModel* __restrict__ model = a.models + mi;
   const int K = a.K, n = a.n, N = a.N, Kp = a.kp;
-  const int cat = b % Kp, pgrp = b / Kp, ppr = 16 / Kp;
+  // K > 4: a wave takes four categories (its category group) of its pattern tile; the
+  // per-pattern site likelihood, the one quantity that couples the groups, then comes
+  // from a preceding log-likelihood pass (a.site_lik) instead of this wave's own root.
+  const int groups = a.cat_groups, tiles_per_group = gridDim.x / groups;
+  const int group = te.tile / tiles_per_group, ptile = te.tile - group * tiles_per_group;
+  const int cat = 4 * group + b % Kp, pgrp = b / Kp, ppr = 16 / Kp;
   const int catc = cat < K ? cat : K - 1;
   // forward matrices, and per edge the matrix of the pre-order step: P again (read
   // transposed) for an internal edge, (P Q) transposed for a tip edge
@@ -1677,7 +1425,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   const unsigned f_off = 8u * (catc * 16 + lo * 4 + hi);  // forward:    A[i=lo][k=hi] = P[lo][hi]
   const unsigned t_off = 8u * (catc * 16 + hi * 4 + lo);  // transposed: A[i=lo][k=hi] = P[hi][lo]
   const unsigned node_bytes = (unsigned)K * 128u;
-  const int TP = ppr * R, tile_start = te.tile * TP;
+  const int TP = ppr * R, tile_start = ptile * TP;
   const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
   int pat[R], patc[R];
   double pw[R];
@@ -1909,17 +1657,22 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       double ll = 0.0;
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        double v = cw_l * pi_l * Lv.v[r];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (Kp >= 2) v += __shfl_xor(v, 4, 64);
-        if (Kp >= 4) v += __shfl_xor(v, 8, 64);
+        double v;
+        if (groups > 1) {
+          v = a.site_lik[((size_t)a.grad_offset + te.eval) * a.tiles * kTile + patc[r]];
+        } else {
+          v = cw_l * pi_l * Lv.v[r];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (Kp >= 2) v += __shfl_xor(v, 4, 64);
+          if (Kp >= 4) v += __shfl_xor(v, 8, 64);
+        }
         qroot[r] = pi_l * cw_l * (pw[r] / v);  // pw = 0 for padding patterns
-        if (hi == 0 && cat == 0 && pat[r] < a.P)
+        if (hi == 0 && (b % Kp) == 0 && pat[r] < a.P)
           ll += pw[r] * (RESCALE ? log(v) + esum[r] * 0.69314718055994530942 : log(v));
       }
       ll = wave_sum(ll);
-      if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
+      if (lane == 0 && groups == 1) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
       if (SUBST) {
         // d logL / d pi_c through the root: sum_p w_p sum_k cw_k L_root[c] / site_p;
         // this lane's state is c = hi, the 16 lanes of a row hold (category, pattern)
@@ -2559,17 +2312,6 @@ void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t 
     else hipLaunchKernelGGL((gradient_hbm_kernel<false, false>), grid, block, 0, s, a);
   }
 }
-size_t gradient_onchip_lds_bytes(int n) {
-  const int N = 2 * n - 1;
-  return sizeof(double) * ((size_t)max_stored(n) * 4 * kTile + 2 * N);
-}
-bool gradient_onchip_fits(int n) { return n >= 3 && gradient_onchip_lds_bytes(n) <= 160 * 1024; }
-void launch_gradient_onchip(const LikArgs& a, int count, hipStream_t s) {
-  if (count <= 0) return;
-  const size_t lds = gradient_onchip_lds_bytes(a.n);
-  allow_large_lds(reinterpret_cast<const void*>(gradient_onchip_kernel), lds);
-  hipLaunchKernelGGL(gradient_onchip_kernel, dim3(a.tiles, count), dim3(kTile), lds, s, a);
-}
 size_t gradient_mfma_lds_bytes(int n, int K, bool rescale, bool subst) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
   const size_t tip_bytes = (((size_t)n * 4 * (16 / kp) + 7) / 8) * 8;
@@ -2582,8 +2324,12 @@ size_t gradient_mfma_lds_bytes(int n, int K, bool rescale, bool subst) {
 int gradient_mfma_width(int n, bool subst) {
   return max_macros(n) * kMacroPositions * 2 + (subst ? kSubstExtra : 0);
 }
+int gradient_mfma_groups(int K) { return K <= 4 ? 1 : (K + 3) / 4; }
 bool gradient_mfma_fits(int n, int K, bool rescale) {
-  return n >= 3 && K <= 4 && gradient_mfma_lds_bytes(n, K, rescale, true) <= 160 * 1024;
+  // K > 4 takes its site likelihoods from a log-likelihood pass, which the rescaled
+  // variant (scaled vectors, no absolute site likelihood) cannot provide
+  return n >= 3 && K <= kMaxCategories && (K <= 4 || !rescale) &&
+         gradient_mfma_lds_bytes(n, K, rescale, true) <= 160 * 1024;
 }
 template <bool RESCALE, bool SUBST>
 static void launch_gradient_mfma_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s) {
@@ -2596,8 +2342,9 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool sub
   if (count <= 0) return;
   LikArgs a = a_in;
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
+  a.cat_groups = gradient_mfma_groups(a.K);
   const size_t lds = gradient_mfma_lds_bytes(a.n, a.K, rescale, subst);
-  const dim3 grid(loglik_mfma_tiles(a.P, a.K), count);
+  const dim3 grid(loglik_mfma_tiles(a.P, a.K) * a.cat_groups, count);
   if (rescale || subst) {
     if (rescale && subst) launch_gradient_mfma_variant<true, true>(a, grid, lds, s);
     else if (rescale) launch_gradient_mfma_variant<true, false>(a, grid, lds, s);
@@ -2642,7 +2389,6 @@ const char* loglik_kernel_name(const LikArgs& a, bool rescale, int max_slots) {
   return use_loglik_mfma(a, rescale, max_slots) ? "loglik_mfma_kernel" : "loglik_onchip_kernel";
 }
 const char* gradient_kernel_name() { return "gradient_hbm_kernel"; }
-const char* gradient_onchip_kernel_name() { return "gradient_onchip_kernel"; }
 const char* gradient_mfma_kernel_name() { return "gradient_mfma_kernel"; }
 
 }  // namespace miphylo

@@ -10,10 +10,10 @@ import test_gpu_parity as TG
 RTOL = 1e-10
 rng = np.random.default_rng(2024)
 bad = 0; total = 0
-for trial in range(60):
+for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
     n = int(rng.choice([3, 4, 5, 6, 7, 9, 12, 17, 26, 31, 32, 33, 45, 64, 80]))
     P = int(rng.choice([1, 2, 3, 11, 12, 13, 16, 47, 48, 49, 64, 100, 257]))
-    K = int(rng.choice([1, 2, 3, 4]))
+    K = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 11, 16]))
     subst = str(rng.choice(["JC69", "GTR"]))
     site = "constant" if K == 1 else f"weibull+{K}"
     resc = bool(rng.integers(0, 2))
@@ -35,9 +35,13 @@ for trial in range(60):
     O.set_transition_mode(0)
     ok = True
     for t in range(T):
-        ok &= abs(g[t].log_likelihood - og["log_likelihood"][t]) <= RTOL * abs(og["log_likelihood"][t])
-        scale = max(np.max(np.abs(og["branch_lengths"][t])), 1e-300)
-        ok &= np.max(np.abs(g[t].gradient["branch_lengths"] - og["branch_lengths"][t])) <= 1e-9 * scale
+        okl = abs(g[t].log_likelihood - og["log_likelihood"][t]) <= RTOL * abs(og["log_likelihood"][t]) + 1e-13
+        if not okl: print("  ll", g[t].log_likelihood, og["log_likelihood"][t])
+        # (a gradient that is zero up to rounding -- all-gap columns -- has no relative scale)
+        scale = max(np.max(np.abs(og["branch_lengths"][t])), 1e-6)
+        okb = np.max(np.abs(g[t].gradient["branch_lengths"] - og["branch_lengths"][t])) <= 1e-9 * scale
+        if not okb: print("  bl", g[t].gradient["branch_lengths"], og["branch_lengths"][t])
+        ok &= okl and okb
         if K > 1:
             tol_site = 1e-4 if (subst == "GTR" and os.environ.get("MI_PHYLO_SUBST_GRADIENT")) else 1e-8
             okk = abs(g[t].gradient["site_model"][0] - og["site_model"][t]) <= tol_site * max(1.0, abs(og["site_model"][t]))

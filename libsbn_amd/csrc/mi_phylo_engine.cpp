@@ -147,7 +147,7 @@ struct mi_engine {
   Buffer tip_states, tip_partials, tip_masks, weights;
   bool have_tip_masks = false;  // every tip vector is 0/1: the matrix-core kernel can run
   // per-call workspace
-  Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, x_sum, ll_part, plv, g_part, site_lik, fin_scratch,
+  Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
       ll_sum, g_sum, status;
   PinnedArena pinned;
   bool allow_onchip_gradient = true;
@@ -230,6 +230,7 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
                          g_width))
       return 1;
     if (e->site_lik.ensure(sizeof(double) * (size_t)c.Eg * e->tiles * kTile)) return 1;
+    if (e->site_exp.ensure(sizeof(int32_t) * (size_t)c.Eg * e->tiles * kTile)) return 1;
   }
   return 0;
 }
@@ -380,7 +381,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
         if (groups > 1) {
           // K > 4: the site likelihoods (and logL) come from a log-likelihood pass
           g.site_lik = e->site_lik.as<double>();
-          launch_loglik(g, part, false, e->max_slots, s);
+          g.site_exp = e->site_exp.as<int32_t>();
+          launch_loglik(g, part, d.rescaling, e->max_slots, s);
         }
         launch_gradient_mfma(g, part, d.rescaling, analytic, s);
       }
@@ -694,7 +696,7 @@ void mi_engine_destroy(mi_engine* e) {
   for (Buffer* b :
        {&e->tip_states, &e->tip_partials, &e->tip_masks, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
         &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->x_sum, &e->bl_eff,
-        &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->fin_scratch,
+        &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,
         &e->ll_sum, &e->g_sum, &e->status,
         &e->in_parent, &e->in_bl, &e->in_params, &e->in_rates, &e->in_rate_counts,
         &e->in_heights, &e->in_bounds, &e->in_ratios, &e->out_ll, &e->out_a, &e->out_b,

@@ -93,7 +93,8 @@ struct LikArgs {
   double* ll_part;             // [E][tiles]
   double* plv;                 // [Eg][n-1][K][tiles*64][4]   (gradient, v1)
   double* g_part;              // [Eg][tiles][2][N]
-  double* site_lik;            // [Eg][tiles*64] per-pattern site likelihood (on-chip gradient)
+  double* site_lik;            // [Eg][tiles*64] per-pattern site likelihood (K > 4 gradient: from the logL pass)
+  int32_t* site_exp;           // [Eg][tiles*64] its power of two when rescaling
 };
 
 struct FinalizeArgs {

@@ -1211,8 +1211,13 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   for (int r = 0; r < R; r++) {
     const bool owner = hi == 0 && cat == 0 && pat[r] < a.P;  // one lane per pattern
     if (owner) {
-      if (!RESCALE && a.site_lik)
-        a.site_lik[((size_t)a.grad_offset + te.eval) * a.tiles * kTile + pat[r]] = site[r];
+      if (a.site_lik) {
+        // per-pattern site likelihood for a following gradient pass (rescaled: the
+        // mantissa here, the power of two in site_exp)
+        const size_t at = ((size_t)a.grad_offset + te.eval) * a.tiles * kTile + pat[r];
+        a.site_lik[at] = site[r];
+        if (RESCALE) a.site_exp[at] = site_exp[r];
+      }
       ll += pw[r] * (RESCALE ? log(site[r]) + site_exp[r] * 0.69314718055994530942 : log(site[r]));
     }
   }
@@ -1659,7 +1664,10 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       for (int r = 0; r < R; r++) {
         double v;
         if (groups > 1) {
-          v = a.site_lik[((size_t)a.grad_offset + te.eval) * a.tiles * kTile + patc[r]];
+          const size_t at = ((size_t)a.grad_offset + te.eval) * a.tiles * kTile + patc[r];
+          v = a.site_lik[at];
+          // rescaled: q_root 2^(E of this group's walk) = pi cw w 2^(E - site_exp) / mantissa
+          if (RESCALE) v = ldexp(v, a.site_exp[at] - esum[r]);
         } else {
           v = cw_l * pi_l * Lv.v[r];
           v += __shfl_xor(v, 16, 64);
@@ -2326,9 +2334,7 @@ int gradient_mfma_width(int n, bool subst) {
 }
 int gradient_mfma_groups(int K) { return K <= 4 ? 1 : (K + 3) / 4; }
 bool gradient_mfma_fits(int n, int K, bool rescale) {
-  // K > 4 takes its site likelihoods from a log-likelihood pass, which the rescaled
-  // variant (scaled vectors, no absolute site likelihood) cannot provide
-  return n >= 3 && K <= kMaxCategories && (K <= 4 || !rescale) &&
+  return n >= 3 && K <= kMaxCategories &&
          gradient_mfma_lds_bytes(n, K, rescale, true) <= 160 * 1024;
 }
 template <bool RESCALE, bool SUBST>

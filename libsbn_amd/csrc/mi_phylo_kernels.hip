@@ -339,6 +339,10 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
 #define RDL(arr, i) __builtin_amdgcn_readlane((arr), (i))
 #define WRL(arr, i, val) (arr) = (lane == (i)) ? (val) : (arr)
 __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
+  // Branch-free by construction: the tree walks are dependent chains, and on this machine
+  // a taken scalar branch costs more than the handful of instructions it would skip, so
+  // every loop body is straight-line code (lane selects / scalar selects) and whatever can
+  // be done by all lanes at once (child lists, sorting, the macro entries) is.
   const int t = blockIdx.x;
   const int lane = threadIdx.x;
   const int n = a.n, N = 2 * n - 1;
@@ -348,67 +352,51 @@ __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
   SchedEntry* sched = a.sched + (size_t)t * (n - 1);
   double* ble = a.bl_eff + (size_t)t * N;
 
-  int par = lane < nodes_in - 1 ? par_in[lane] : 0;
-  int maxleaf = lane < n ? lane : -1;
-  int cnt = 0, k0 = 0, k1 = 0, k2 = 0, c0 = 0, c1 = 0, label = 0, slot = 0;
-  int s_node = 0, s_c0 = 0, s_c1 = 0, s_sl = 0;  // schedule, lane = position
+  const int par = lane < nodes_in - 1 ? par_in[lane] : -1;
   int status = kOk;
-  const bool bad_parent =
-      lane < nodes_in - 1 && (par <= lane || par >= nodes_in || par < n);
+  const bool bad_parent = lane < nodes_in - 1 && (par <= lane || par >= nodes_in || par < n);
   if (__any(bad_parent)) status = kBadParentIds;
-  if (status == kOk) {
+
+  // max leaf id below every node, bottom-up (ids are a post-order: children first)
+  int maxleaf = lane < n ? lane : -1;
+  if (status == kOk)
     for (int v = 0; v < nodes_in - 1; v++) {
-      const int p = RDL(par, v);
-      const int mv = RDL(maxleaf, v);
-      if (mv > RDL(maxleaf, p)) WRL(maxleaf, p, mv);
+      const int p = RDL(par, v), mv = RDL(maxleaf, v);
+      maxleaf = (lane == p && mv > maxleaf) ? mv : maxleaf;
     }
+  // every lane collects its own children (at most three), ascending max leaf id, by
+  // looking at each node once
+  int cnt = 0, k0 = 0, k1 = 0, k2 = 0, m0 = 0, m1 = 0;
+  if (status == kOk)
     for (int v = 0; v < nodes_in - 1; v++) {
-      const int p = RDL(par, v);
-      const int k = RDL(cnt, p);
-      if (k >= 3) {
-        status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
-        break;
-      }
-      // insertion into the (at most 3) children of p, ascending max leaf id
-      const int mv = RDL(maxleaf, v);
-      int e0 = RDL(k0, p), e1 = RDL(k1, p), e2 = RDL(k2, p);
-      if (k == 0) {
-        e0 = v;
-      } else if (k == 1) {
-        if (RDL(maxleaf, e0) > mv) {
-          e1 = e0;
-          e0 = v;
-        } else {
-          e1 = v;
-        }
-      } else {
-        if (RDL(maxleaf, e1) > mv) {
-          e2 = e1;
-          if (RDL(maxleaf, e0) > mv) {
-            e1 = e0;
-            e0 = v;
-          } else {
-            e1 = v;
-          }
-        } else {
-          e2 = v;
-        }
-      }
-      WRL(k0, p, e0);
-      WRL(k1, p, e1);
-      WRL(k2, p, e2);
-      WRL(cnt, p, k + 1);
+      const int p = RDL(par, v), mv = RDL(maxleaf, v);
+      const bool mine = lane == p;
+      // sorted insert of (v, mv) into (k0 | m0), (k1 | m1), k2; children arrive with
+      // increasing ids, equal keys cannot occur (disjoint leaf sets)
+      const bool lt0 = cnt >= 1 && m0 > mv, lt1 = cnt >= 2 && m1 > mv;
+      const int n0 = cnt == 0 || lt0 ? v : k0;
+      const int n1 = cnt == 0 ? k1 : (lt0 ? k0 : (cnt == 1 || lt1 ? v : k1));
+      const int n2 = cnt < 2 ? k2 : (lt1 ? k1 : v);
+      const int nm0 = cnt == 0 || lt0 ? mv : m0;
+      const int nm1 = cnt == 0 ? m1 : (lt0 ? m0 : (cnt == 1 || lt1 ? mv : m1));
+      k0 = mine ? n0 : k0;
+      k1 = mine ? n1 : k1;
+      k2 = mine && cnt <= 2 ? n2 : k2;
+      m0 = mine ? nm0 : m0;
+      m1 = mine ? nm1 : m1;
+      cnt += mine ? 1 : 0;
     }
-  }
   if (status == kOk) {
     const int want = (!a.rooted && lane == root_in) ? 3 : 2;
     if (__any(lane >= n && lane < nodes_in && cnt != want))
       status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
   }
-  int macro_total = 0;
-  // macro entries, lane = macro index
-  int m_node = 0, m_qslot = 0, m_c0 = 0, m_c1 = 0, m_k0 = 0, m_k1 = 0, m_cs0 = 0, m_cs1 = 0;
-  int m_g0 = 0, m_g1 = 0, m_g2 = 0, m_g3 = 0, m_gs0 = 0, m_gs1 = 0, m_gs2 = 0, m_gs3 = 0;
+  int c0 = 0, c1 = 0;
+  int s_node = 0, s_c0 = 0, s_c1 = 0, s_sl = 0;  // schedule, lane = position
+  int macro_total = 0, stored_total = 0;
+  MacroEntry me{};
+  bool is_macro = false;
+  int macro_rank = 0;
   if (status == kOk) {
     if (lane >= n && lane < nodes_in) {
       c0 = k0;
@@ -427,107 +415,108 @@ __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
         c1 = r;
       }
     }
+    const bool internal = lane >= n && lane < N;
     if (!a.need_slots) {
       // only the matrix-core gradient kernel and finalize will read this tree: the
-      // node-id order (already a post-order) with no slot assignment is enough, and it
-      // needs no sequential walk
+      // node-id order (already a post-order) with no slot assignment is enough
       s_node = n + lane;
       s_c0 = __shfl(c0, n + lane, 64);
       s_c1 = __shfl(c1, n + lane, 64);
       s_sl = 0;
-    }
-    // Sethi-Ullman labels (tips cost nothing: they are read in compact form).
-    for (int v = n; a.need_slots && v < N; v++) {
-      const int l0 = RDL(label, RDL(c0, v)), l1 = RDL(label, RDL(c1, v));
-      WRL(label, v, l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1));
-    }
-    // Post-order DFS, heavier child first; slots from a free bitmask.
-    int stk_lo = 0, stk_hi = 0;
-    auto push = [&](int top, int x) {
-      if (top < 64) WRL(stk_lo, top, x);
-      else WRL(stk_hi, top - 64, x);
-    };
-    uint32_t free_mask = 0xffffffffu;
-    int top = 0, out = 0, used_max = 0;
-    if (a.need_slots) push(top++, (N - 1) << 1);
-    while (top) {
-      --top;
-      const int item = top < 64 ? RDL(stk_lo, top) : RDL(stk_hi, top - 64);
-      const int v = item >> 1;
-      const int a0 = RDL(c0, v), a1 = RDL(c1, v);
-      if (item & 1) {
+    } else {
+      // Sethi-Ullman labels and internal-subtree sizes, bottom-up (tips cost nothing)
+      int label = 0, size = 0;
+      for (int v = n; v < N; v++) {
+        const int a0 = RDL(c0, v), a1 = RDL(c1, v);
+        const int l0 = RDL(label, a0), l1 = RDL(label, a1);
+        const int sz = 1 + RDL(size, a0) + RDL(size, a1);
+        const int lb = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
+        label = lane == v ? lb : label;
+        size = lane == v ? sz : size;
+      }
+      // position in the post-order that visits the heavier child first: top-down, a
+      // node's subtree occupies [start, start + size), the node itself comes last
+      const int lab0 = __shfl(label, c0, 64), lab1 = __shfl(label, c1, 64);
+      const bool first0 = lab0 >= lab1;
+      const int first = first0 ? c0 : c1, second = first0 ? c1 : c0;
+      const int size_first = __shfl(size, first, 64);
+      int start = 0;
+      for (int v = N - 1; v >= n; v--) {
+        const int st = RDL(start, v), f = RDL(first, v), sc = RDL(second, v);
+        const int sf = RDL(size_first, v);
+        start = lane == f ? st : (lane == sc ? st + sf : start);
+      }
+      const int pos = start + size - 1;
+      // node_at[position] = node (internal lanes send their id to lane `pos`)
+      const int node_at = __builtin_amdgcn_ds_permute((internal ? pos : 63) * 4, lane);
+      // LDS slots in schedule order from a free bitmask
+      int slot = 0;
+      uint32_t free_mask = 0xffffffffu;
+      int used_max = 0;
+      for (int out = 0; out < n - 1; out++) {
+        const int v = RDL(node_at, out);
+        const int a0 = RDL(c0, v), a1 = RDL(c1, v);
         const int sa0 = RDL(slot, a0), sa1 = RDL(slot, a1);
-        if (a0 >= n) free_mask |= 1u << sa0;
-        if (a1 >= n) free_mask |= 1u << sa1;
+        free_mask |= (a0 >= n ? 1u << sa0 : 0u) | (a1 >= n ? 1u << sa1 : 0u);
         const int sl = __ffs(free_mask) - 1;
         free_mask &= ~(1u << sl);
-        WRL(slot, v, sl);
-        if (sl + 1 > used_max) used_max = sl + 1;
-        WRL(s_node, out, v);
-        WRL(s_c0, out, a0);
-        WRL(s_c1, out, a1);
-        WRL(s_sl, out, sl | (sa0 << 8) | (sa1 << 16) | ((a0 < n ? 1 : 0) << 24) |
-                           ((a1 < n ? 1 : 0) << 25));
-        out++;
-      } else {
-        push(top++, (v << 1) | 1);
-        const bool first0 = RDL(label, a0) >= RDL(label, a1);
-        const int lo = first0 ? a1 : a0, hi = first0 ? a0 : a1;
-        if (lo >= n) push(top++, lo << 1);
-        if (hi >= n) push(top++, hi << 1);  // popped first
+        slot = lane == v ? sl : slot;
+        used_max = sl + 1 > used_max ? sl + 1 : used_max;
       }
+      if (used_max > a.max_slots) status = kTooManySlots;
+      s_node = node_at;
+      s_c0 = __shfl(c0, node_at, 64);
+      s_c1 = __shfl(c1, node_at, 64);
+      s_sl = __shfl(slot, node_at, 64) | (__shfl(slot, s_c0, 64) << 8) |
+             (__shfl(slot, s_c1, 64) << 16) | ((s_c0 < n ? 1 : 0) << 24) | ((s_c1 < n ? 1 : 0) << 25);
     }
-    if (used_max > a.max_slots) status = kTooManySlots;
-    // ---- schedule of the on-chip gradient kernels (see tree_setup_kernel) ----
+    // ---- schedule of the on-chip gradient kernel (see tree_setup_kernel) ----
     if (a.macros) {
-      int cls = 0, sslot = 0;
-      int stored = 0;
+      // stored (1) / unstored (2) classes, bottom-up
+      int cls = 0;
       for (int v = n; v < N - 1; v++) {
         const int a0 = RDL(c0, v), a1 = RDL(c1, v);
-        const bool unstored = (a0 < n || RDL(cls, a0) == 1) && (a1 < n || RDL(cls, a1) == 1);
-        WRL(cls, v, unstored ? 2 : 1);
-        WRL(sslot, v, unstored ? 0 : stored);
-        if (!unstored) stored++;
+        const int k0c = RDL(cls, a0), k1c = RDL(cls, a1);
+        const bool unstored = (a0 < n || k0c == 1) && (a1 < n || k1c == 1);
+        cls = lane == v ? (unstored ? 2 : 1) : cls;
       }
-      WRL(cls, N - 1, 1);
-      WRL(sslot, N - 1, -1);
-      int m = 0;
-      for (int v = n; v < N; v++) {
-        if (RDL(cls, v) != 1) continue;
-        int ch[2], kind[2], cs[2], g[4], gs[4];
-        for (int j = 0; j < 2; j++) {
-          const int c = j ? RDL(c1, v) : RDL(c0, v);
-          const int cc = c >= n ? RDL(cls, c) : 0;
-          ch[j] = c;
-          kind[j] = cc;
-          cs[j] = cc == 1 ? RDL(sslot, c) : 0;
-          const bool expand = cc == 2;
-          const int ga = expand ? RDL(c0, c) : 0, gb = expand ? RDL(c1, c) : 0;
-          g[2 * j] = ga;
-          g[2 * j + 1] = gb;
-          gs[2 * j] = ga >= n ? RDL(sslot, ga) : 0;
-          gs[2 * j + 1] = gb >= n ? RDL(sslot, gb) : 0;
-        }
-        WRL(m_node, m, v);
-        WRL(m_qslot, m, RDL(sslot, v));
-        WRL(m_c0, m, ch[0]);
-        WRL(m_c1, m, ch[1]);
-        WRL(m_k0, m, kind[0]);
-        WRL(m_k1, m, kind[1]);
-        WRL(m_cs0, m, cs[0]);
-        WRL(m_cs1, m, cs[1]);
-        WRL(m_g0, m, g[0]);
-        WRL(m_g1, m, g[1]);
-        WRL(m_g2, m, g[2]);
-        WRL(m_g3, m, g[3]);
-        WRL(m_gs0, m, gs[0]);
-        WRL(m_gs1, m, gs[1]);
-        WRL(m_gs2, m, gs[2]);
-        WRL(m_gs3, m, gs[3]);
-        m++;
+      cls = lane == N - 1 ? 1 : cls;
+      const bool stored = internal && cls == 1 && lane != N - 1;
+      const uint64_t stored_mask = __ballot(stored);
+      const uint64_t macro_mask = __ballot(internal && cls == 1);
+      const uint64_t below = (1ull << lane) - 1;
+      const int sslot = lane == N - 1 ? -1 : __popcll(stored_mask & below);  // slots in id order
+      stored_total = __popcll(stored_mask);
+      macro_total = __popcll(macro_mask);
+      is_macro = internal && cls == 1;
+      macro_rank = __popcll(macro_mask & below);
+      // every lane that owns a macro assembles it from its children's lanes
+      int kind[2];
+      me.node = lane;
+      me.pad = 0;
+      me.qslot = sslot;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int ch = j ? c1 : c0;
+        // (cross-lane reads stay outside lane-dependent conditions: an inactive source
+        // lane would read as 0)
+        const int cls_ch = __shfl(cls, ch, 64);
+        const int cc = ch >= n ? cls_ch : 0;
+        const int chs = __shfl(sslot, ch, 64);
+        const int ga_ = __shfl(c0, ch, 64), gb_ = __shfl(c1, ch, 64);
+        me.child[j] = ch;
+        kind[j] = cc;
+        me.cslot[j] = cc == 1 ? chs : 0;
+        const bool expand = cc == 2;
+        const int ga = expand ? ga_ : 0, gb = expand ? gb_ : 0;
+        const int gas = __shfl(sslot, ga, 64), gbs = __shfl(sslot, gb, 64);
+        me.grand[2 * j] = ga;
+        me.grand[2 * j + 1] = gb;
+        me.gslot[2 * j] = ga >= n ? gas : 0;
+        me.gslot[2 * j + 1] = gb >= n ? gbs : 0;
       }
-      macro_total = m;
-      if (stored > max_stored(n)) status = kTooManySlots;
+      me.shape = macro_shape(kind[0], kind[1], lane == N - 1, me.child, me.grand, n);
+      if (stored_total > max_stored(n)) status = kTooManySlots;
     }
   }
   if (status != kOk && lane == 0) set_status(a.status, status, t);
@@ -541,26 +530,7 @@ __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
   if (lane < n - 1) sched[lane] = {s_node, s_c0, s_c1, s_sl};
   if (a.macros) {
     MacroEntry* mac = a.macros + (size_t)t * max_macros(n);
-    if (lane < macro_total) {
-      MacroEntry me;
-      me.node = m_node;
-      me.qslot = m_qslot;
-      me.child[0] = m_c0;
-      me.child[1] = m_c1;
-      me.cslot[0] = m_cs0;
-      me.cslot[1] = m_cs1;
-      me.grand[0] = m_g0;
-      me.grand[1] = m_g1;
-      me.grand[2] = m_g2;
-      me.grand[3] = m_g3;
-      me.gslot[0] = m_gs0;
-      me.gslot[1] = m_gs1;
-      me.gslot[2] = m_gs2;
-      me.gslot[3] = m_gs3;
-      me.pad = 0;
-      me.shape = macro_shape(m_k0, m_k1, m_node == N - 1, me.child, me.grand, n);
-      mac[lane] = me;
-    }
+    if (is_macro) mac[macro_rank] = me;
     if (lane == 0) a.macro_count[t] = macro_total;
   }
   if (!a.rooted) {
@@ -2226,7 +2196,12 @@ void launch_tree_setup(const TreeSetupArgs& a_in, hipStream_t s) {
   TreeSetupArgs a = a_in;
   const size_t lds = sizeof(int32_t) * 13 * (size_t)(2 * a.n - 1);
   a.use_lds = lds <= 48 * 1024;
-  if (2 * a.n - 1 <= 64 && a.n >= 3) {
+  // MI_PHYLO_TREE_SETUP=lds forces the general kernel (testing)
+  static const bool force_lds = [] {
+    const char* env = getenv("MI_PHYLO_TREE_SETUP");
+    return env && std::string(env) == "lds";
+  }();
+  if (2 * a.n - 1 <= 64 && a.n >= 3 && !force_lds) {
     hipLaunchKernelGGL(tree_setup_small_kernel, dim3(a.T), dim3(64), 0, s, a);
     return;
   }

@@ -2034,8 +2034,10 @@ __device__ void ratio_transform(int n, const int32_t* c0, const int32_t* c1, con
 
 __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
   // One wave per tree: lanes run over nodes / tiles for the reductions, lane 0
-  // walks the O(n) recurrences of the rooted chain rule.  Working set (6n
-  // doubles) in LDS unless the tree is too large.
+  // walks the O(n) recurrences of the rooted chain rule.  Working set (6n doubles, for
+  // rooted trees also the tree's heights, bounds, ratios, rates and the ratio gradient
+  // being built: each access of those recurrences is on a dependent chain, and a global
+  // load there costs ten LDS reads) in LDS unless the tree is too large.
   extern __shared__ double fin_lds[];
   const int t = blockIdx.x, lane = threadIdx.x;
   const int n = a.n, N = a.N, T = a.T;
@@ -2049,6 +2051,25 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
     c0[se.node - n] = se.child0;
     c1[se.node - n] = se.child1;
   }
+  const double* h = a.node_heights ? a.node_heights + (size_t)t * N : nullptr;
+  const double* bd = a.node_bounds ? a.node_bounds + (size_t)t * N : nullptr;
+  const double* ratios = a.height_ratios ? a.height_ratios + (size_t)t * (n - 1) : nullptr;
+  const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
+  double* outr_stage = nullptr;
+  if (a.rooted && a.use_lds) {
+    double* stage = fin_lds + 6 * n;  // h[N] | bd[N] | rates[N] | ratios[n] | out[n]
+    for (int v = lane; v < N; v += 64) {
+      if (h) stage[v] = h[v];
+      if (bd) stage[N + v] = bd[v];
+      if (rates && v < N - 1) stage[2 * N + v] = rates[v];
+      if (ratios && v < n - 1) stage[3 * N + v] = ratios[v];
+    }
+    if (h) h = stage;
+    if (bd) bd = stage + N;
+    if (rates) rates = stage + 2 * N;
+    if (ratios) ratios = stage + 3 * N;
+    outr_stage = stage + 3 * N + n;
+  }
   __syncthreads();
   __shared__ double sh_ll, sh_jac;
   if (lane == 0) {
@@ -2057,8 +2078,6 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
     if (a.rooted && (a.with_jacobian || (a.gradient && a.gtr))) {
       // fat_beagle.cpp:82-94; iteration order of TripleIdPreorderBifurcating
       // (node.cpp:226-261) reproduced with an explicit stack in `work`.
-      const double* h = a.node_heights + (size_t)t * N;
-      const double* bd = a.node_bounds + (size_t)t * N;
       int32_t* st = reinterpret_cast<int32_t*>(work);
       int top = 0;
       st[top++] = (N - 1) << 1;
@@ -2132,7 +2151,6 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
   }
   // ---- rooted: clock + ratios/root-height gradients ----
   const double* tb = a.bl_raw + (size_t)t * N;
-  const double* rates = a.rates + (size_t)t * (N - 1);
   double* oc = a.out_clock + (size_t)t * (N - 1);
   const int rc = a.rate_counts[t];
   if (rc == 1) {
@@ -2147,14 +2165,12 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
     if (lane == 0) set_status(a.status, kBadRateCount, t);
     for (int v = lane; v < N - 1; v += 64) oc[v] = 0;
   }
-  if (lane != 0) return;
-  const double* h = a.node_heights + (size_t)t * N;
-  const double* bd = a.node_bounds + (size_t)t * N;
-  const double* ratios = a.height_ratios + (size_t)t * (n - 1);
+  double* out_global = a.out_ratios + (size_t)t * (n - 1);
+  double* outr = outr_stage ? outr_stage : out_global;
+  if (lane == 0) {
   double* hg = work + 2 * n;    // n-1
   double* aux = work + 3 * n;   // n-1 (log_time)
   double* jacg = work + 4 * n;  // n-1
-  double* outr = a.out_ratios + (size_t)t * (n - 1);
   // HeightGradient rooted_gradient_transforms.cpp:17-37
   for (int v = N - 1; v >= n; v--) {
     double x = v != N - 1 ? -bg[v] * rates[v] : 0.0;
@@ -2169,6 +2185,11 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
   ratio_transform(n, c0, c1, h, ratios, bd, aux, mult, jacg);
   for (int i = 0; i < n - 2; i++) outr[i] += jacg[i] - 1.0 / ratios[i];
   outr[n - 2] += jacg[n - 2];
+  }
+  if (outr_stage) {
+    __syncthreads();
+    for (int i = lane; i < n - 1; i += 64) out_global[i] = outr_stage[i];
+  }
 }
 
 }  // namespace
@@ -2361,7 +2382,8 @@ void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s) {
 }
 void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
   FinalizeArgs a = a_in;
-  const size_t lds = sizeof(double) * 6 * (size_t)a.n;
+  // 6n of working set (+ the staged tree state of a rooted tree: 3N + 2n)
+  const size_t lds = sizeof(double) * (a.rooted ? 14 * (size_t)a.n : 6 * (size_t)a.n);
   a.use_lds = lds <= 48 * 1024;
   hipLaunchKernelGGL(finalize_kernel, dim3(a.T), dim3(64), a.use_lds ? lds : 0, s, a);
 }

@@ -338,11 +338,45 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
 // ------------------------------------------------------------------------
 #define RDL(arr, i) __builtin_amdgcn_readlane((arr), (i))
 #define WRL(arr, i, val) (arr) = (lane == (i)) ? (val) : (arr)
+// A per-node array of up to NB * 64 entries held in NB vector registers: entry i lives in
+// lane i % 64 of register i / 64.  `rd` reads an entry with a wave-uniform index (two or
+// four v_readlane and scalar selects, no branch), `own(nb)` is the node id this lane holds
+// in register nb.
+template <int NB>
+struct NodeArray {
+  int r[NB];
+  __device__ __forceinline__ void fill(int v) {
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) r[nb] = v;
+  }
+  __device__ __forceinline__ int rd(int i) const {
+    int out = __builtin_amdgcn_readlane(r[0], i & 63);
+#pragma unroll
+    for (int nb = 1; nb < NB; nb++) {
+      const int x = __builtin_amdgcn_readlane(r[nb], i & 63);
+      out = (i >> 6) == nb ? x : out;
+    }
+    return out;
+  }
+  // lane-varying index (gather): every lane reads entry idx
+  __device__ __forceinline__ int gather(int idx) const {
+    int out = __shfl(r[0], idx & 63, 64);
+#pragma unroll
+    for (int nb = 1; nb < NB; nb++) {
+      const int x = __shfl(r[nb], idx & 63, 64);
+      out = (idx >> 6) == nb ? x : out;
+    }
+    return out;
+  }
+};
+
+template <int NB>
 __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
   // Branch-free by construction: the tree walks are dependent chains, and on this machine
   // a taken scalar branch costs more than the handful of instructions it would skip, so
   // every loop body is straight-line code (lane selects / scalar selects) and whatever can
   // be done by all lanes at once (child lists, sorting, the macro entries) is.
+  using Arr = NodeArray<NB>;
   const int t = blockIdx.x;
   const int lane = threadIdx.x;
   const int n = a.n, N = 2 * n - 1;
@@ -351,171 +385,241 @@ __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
   const int32_t* par_in = a.parent_ids + (size_t)t * (nodes_in - 1);
   SchedEntry* sched = a.sched + (size_t)t * (n - 1);
   double* ble = a.bl_eff + (size_t)t * N;
+  auto own = [&](int nb) { return lane + 64 * nb; };
 
-  const int par = lane < nodes_in - 1 ? par_in[lane] : -1;
+  Arr par, maxleaf;
   int status = kOk;
-  const bool bad_parent = lane < nodes_in - 1 && (par <= lane || par >= nodes_in || par < n);
+  bool bad_parent = false;
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) {
+    const int v = own(nb);
+    par.r[nb] = v < nodes_in - 1 ? par_in[v] : -1;
+    maxleaf.r[nb] = v < n ? v : -1;
+    bad_parent |= v < nodes_in - 1 && (par.r[nb] <= v || par.r[nb] >= nodes_in || par.r[nb] < n);
+  }
   if (__any(bad_parent)) status = kBadParentIds;
 
   // max leaf id below every node, bottom-up (ids are a post-order: children first)
-  int maxleaf = lane < n ? lane : -1;
   if (status == kOk)
     for (int v = 0; v < nodes_in - 1; v++) {
-      const int p = RDL(par, v), mv = RDL(maxleaf, v);
-      maxleaf = (lane == p && mv > maxleaf) ? mv : maxleaf;
+      const int p = par.rd(v), mv = maxleaf.rd(v);
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++)
+        maxleaf.r[nb] = (own(nb) == p && mv > maxleaf.r[nb]) ? mv : maxleaf.r[nb];
     }
-  // every lane collects its own children (at most three), ascending max leaf id, by
-  // looking at each node once
-  int cnt = 0, k0 = 0, k1 = 0, k2 = 0, m0 = 0, m1 = 0;
+  // every lane collects the children (at most three) of the nodes it holds, ascending max
+  // leaf id, by looking at each node once
+  Arr cnt, k0, k1, k2, m0, m1;
+  cnt.fill(0); k0.fill(0); k1.fill(0); k2.fill(0); m0.fill(0); m1.fill(0);
   if (status == kOk)
     for (int v = 0; v < nodes_in - 1; v++) {
-      const int p = RDL(par, v), mv = RDL(maxleaf, v);
-      const bool mine = lane == p;
-      // sorted insert of (v, mv) into (k0 | m0), (k1 | m1), k2; children arrive with
-      // increasing ids, equal keys cannot occur (disjoint leaf sets)
-      const bool lt0 = cnt >= 1 && m0 > mv, lt1 = cnt >= 2 && m1 > mv;
-      const int n0 = cnt == 0 || lt0 ? v : k0;
-      const int n1 = cnt == 0 ? k1 : (lt0 ? k0 : (cnt == 1 || lt1 ? v : k1));
-      const int n2 = cnt < 2 ? k2 : (lt1 ? k1 : v);
-      const int nm0 = cnt == 0 || lt0 ? mv : m0;
-      const int nm1 = cnt == 0 ? m1 : (lt0 ? m0 : (cnt == 1 || lt1 ? mv : m1));
-      k0 = mine ? n0 : k0;
-      k1 = mine ? n1 : k1;
-      k2 = mine && cnt <= 2 ? n2 : k2;
-      m0 = mine ? nm0 : m0;
-      m1 = mine ? nm1 : m1;
-      cnt += mine ? 1 : 0;
+      const int p = par.rd(v), mv = maxleaf.rd(v);
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const bool mine = own(nb) == p;
+        const int c = cnt.r[nb];
+        // sorted insert of (v, mv) into (k0 | m0), (k1 | m1), k2; equal keys cannot occur
+        // (disjoint leaf sets)
+        const bool lt0 = c >= 1 && m0.r[nb] > mv, lt1 = c >= 2 && m1.r[nb] > mv;
+        const int n0 = c == 0 || lt0 ? v : k0.r[nb];
+        const int n1 = c == 0 ? k1.r[nb] : (lt0 ? k0.r[nb] : (c == 1 || lt1 ? v : k1.r[nb]));
+        const int n2 = c < 2 ? k2.r[nb] : (lt1 ? k1.r[nb] : v);
+        const int nm0 = c == 0 || lt0 ? mv : m0.r[nb];
+        const int nm1 = c == 0 ? m1.r[nb] : (lt0 ? m0.r[nb] : (c == 1 || lt1 ? mv : m1.r[nb]));
+        k0.r[nb] = mine ? n0 : k0.r[nb];
+        k1.r[nb] = mine ? n1 : k1.r[nb];
+        k2.r[nb] = (mine && c <= 2) ? n2 : k2.r[nb];
+        m0.r[nb] = mine ? nm0 : m0.r[nb];
+        m1.r[nb] = mine ? nm1 : m1.r[nb];
+        cnt.r[nb] += mine ? 1 : 0;
+      }
     }
   if (status == kOk) {
-    const int want = (!a.rooted && lane == root_in) ? 3 : 2;
-    if (__any(lane >= n && lane < nodes_in && cnt != want))
-      status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
+    bool wrong = false;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const int v = own(nb);
+      const int want = (!a.rooted && v == root_in) ? 3 : 2;
+      wrong |= v >= n && v < nodes_in && cnt.r[nb] != want;
+    }
+    if (__any(wrong)) status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
   }
-  int c0 = 0, c1 = 0;
-  int s_node = 0, s_c0 = 0, s_c1 = 0, s_sl = 0;  // schedule, lane = position
+  Arr c0, c1;
+  c0.fill(0);
+  c1.fill(0);
+  // schedule, entry i in lane i % 64 of register i / 64
+  Arr s_node, s_c0, s_c1, s_sl;
+  s_node.fill(0); s_c0.fill(0); s_c1.fill(0); s_sl.fill(0);
   int macro_total = 0, stored_total = 0;
-  MacroEntry me{};
-  bool is_macro = false;
-  int macro_rank = 0;
+  MacroEntry me[NB];
+  bool is_macro[NB];
+  int macro_rank[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) {
+    me[nb] = MacroEntry{};
+    is_macro[nb] = false;
+    macro_rank[nb] = 0;
+  }
   if (status == kOk) {
-    if (lane >= n && lane < nodes_in) {
-      c0 = k0;
-      c1 = k1;
-    }
-    if (!a.rooted) {
-      // (k0,k1,k2) at root r  ->  r = (k1,k2), r+1 = (k0, r)
-      const int r = root_in;
-      const int kr0 = RDL(k0, r);
-      if (lane == r) {
-        c0 = k1;
-        c1 = k2;
+    const int kr0 = a.rooted ? 0 : k0.rd(root_in);
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const int v = own(nb);
+      if (v >= n && v < nodes_in) {
+        c0.r[nb] = k0.r[nb];
+        c1.r[nb] = k1.r[nb];
       }
-      if (lane == r + 1) {
-        c0 = kr0;
-        c1 = r;
+      if (!a.rooted) {
+        // (k0,k1,k2) at root r  ->  r = (k1,k2), r+1 = (k0, r)
+        if (v == root_in) {
+          c0.r[nb] = k1.r[nb];
+          c1.r[nb] = k2.r[nb];
+        }
+        if (v == root_in + 1) {
+          c0.r[nb] = kr0;
+          c1.r[nb] = root_in;
+        }
       }
     }
-    const bool internal = lane >= n && lane < N;
     if (!a.need_slots) {
       // only the matrix-core gradient kernel and finalize will read this tree: the
       // node-id order (already a post-order) with no slot assignment is enough
-      s_node = n + lane;
-      s_c0 = __shfl(c0, n + lane, 64);
-      s_c1 = __shfl(c1, n + lane, 64);
-      s_sl = 0;
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const int node = n + own(nb);
+        s_node.r[nb] = node;
+        s_c0.r[nb] = c0.gather(node < N ? node : 0);
+        s_c1.r[nb] = c1.gather(node < N ? node : 0);
+      }
     } else {
       // Sethi-Ullman labels and internal-subtree sizes, bottom-up (tips cost nothing)
-      int label = 0, size = 0;
+      Arr label, size;
+      label.fill(0);
+      size.fill(0);
       for (int v = n; v < N; v++) {
-        const int a0 = RDL(c0, v), a1 = RDL(c1, v);
-        const int l0 = RDL(label, a0), l1 = RDL(label, a1);
-        const int sz = 1 + RDL(size, a0) + RDL(size, a1);
+        const int a0 = c0.rd(v), a1 = c1.rd(v);
+        const int l0 = label.rd(a0), l1 = label.rd(a1);
+        const int sz = 1 + size.rd(a0) + size.rd(a1);
         const int lb = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
-        label = lane == v ? lb : label;
-        size = lane == v ? sz : size;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+          label.r[nb] = own(nb) == v ? lb : label.r[nb];
+          size.r[nb] = own(nb) == v ? sz : size.r[nb];
+        }
       }
       // position in the post-order that visits the heavier child first: top-down, a
       // node's subtree occupies [start, start + size), the node itself comes last
-      const int lab0 = __shfl(label, c0, 64), lab1 = __shfl(label, c1, 64);
-      const bool first0 = lab0 >= lab1;
-      const int first = first0 ? c0 : c1, second = first0 ? c1 : c0;
-      const int size_first = __shfl(size, first, 64);
-      int start = 0;
-      for (int v = N - 1; v >= n; v--) {
-        const int st = RDL(start, v), f = RDL(first, v), sc = RDL(second, v);
-        const int sf = RDL(size_first, v);
-        start = lane == f ? st : (lane == sc ? st + sf : start);
+      Arr first, second, size_first, start;
+      start.fill(0);
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const int lab0 = label.gather(c0.r[nb]), lab1 = label.gather(c1.r[nb]);
+        const bool first0 = lab0 >= lab1;
+        first.r[nb] = first0 ? c0.r[nb] : c1.r[nb];
+        second.r[nb] = first0 ? c1.r[nb] : c0.r[nb];
       }
-      const int pos = start + size - 1;
-      // node_at[position] = node (internal lanes send their id to lane `pos`)
-      const int node_at = __builtin_amdgcn_ds_permute((internal ? pos : 63) * 4, lane);
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) size_first.r[nb] = size.gather(first.r[nb]);
+      // (the same loop fills node_at[position] = node)
+      Arr node_at;
+      node_at.fill(0);
+      for (int v = N - 1; v >= n; v--) {
+        const int st = start.rd(v), f = first.rd(v), sc = second.rd(v), sf = size_first.rd(v);
+        const int pos = st + size.rd(v) - 1;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+          start.r[nb] = own(nb) == f ? st : (own(nb) == sc ? st + sf : start.r[nb]);
+          node_at.r[nb] = own(nb) == pos ? v : node_at.r[nb];
+        }
+      }
       // LDS slots in schedule order from a free bitmask
-      int slot = 0;
+      Arr slot;
+      slot.fill(0);
       uint32_t free_mask = 0xffffffffu;
       int used_max = 0;
       for (int out = 0; out < n - 1; out++) {
-        const int v = RDL(node_at, out);
-        const int a0 = RDL(c0, v), a1 = RDL(c1, v);
-        const int sa0 = RDL(slot, a0), sa1 = RDL(slot, a1);
+        const int v = node_at.rd(out);
+        const int a0 = c0.rd(v), a1 = c1.rd(v);
+        const int sa0 = slot.rd(a0), sa1 = slot.rd(a1);
         free_mask |= (a0 >= n ? 1u << sa0 : 0u) | (a1 >= n ? 1u << sa1 : 0u);
         const int sl = __ffs(free_mask) - 1;
         free_mask &= ~(1u << sl);
-        slot = lane == v ? sl : slot;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) slot.r[nb] = own(nb) == v ? sl : slot.r[nb];
         used_max = sl + 1 > used_max ? sl + 1 : used_max;
       }
       if (used_max > a.max_slots) status = kTooManySlots;
-      s_node = node_at;
-      s_c0 = __shfl(c0, node_at, 64);
-      s_c1 = __shfl(c1, node_at, 64);
-      s_sl = __shfl(slot, node_at, 64) | (__shfl(slot, s_c0, 64) << 8) |
-             (__shfl(slot, s_c1, 64) << 16) | ((s_c0 < n ? 1 : 0) << 24) | ((s_c1 < n ? 1 : 0) << 25);
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const int node = node_at.r[nb];
+        const int ch0 = c0.gather(node), ch1 = c1.gather(node);
+        s_node.r[nb] = node;
+        s_c0.r[nb] = ch0;
+        s_c1.r[nb] = ch1;
+        s_sl.r[nb] = slot.gather(node) | (slot.gather(ch0) << 8) | (slot.gather(ch1) << 16) |
+                     ((ch0 < n ? 1 : 0) << 24) | ((ch1 < n ? 1 : 0) << 25);
+      }
     }
     // ---- schedule of the on-chip gradient kernel (see tree_setup_kernel) ----
     if (a.macros) {
       // stored (1) / unstored (2) classes, bottom-up
-      int cls = 0;
+      Arr cls;
+      cls.fill(0);
       for (int v = n; v < N - 1; v++) {
-        const int a0 = RDL(c0, v), a1 = RDL(c1, v);
-        const int k0c = RDL(cls, a0), k1c = RDL(cls, a1);
+        const int a0 = c0.rd(v), a1 = c1.rd(v);
+        const int k0c = cls.rd(a0), k1c = cls.rd(a1);
         const bool unstored = (a0 < n || k0c == 1) && (a1 < n || k1c == 1);
-        cls = lane == v ? (unstored ? 2 : 1) : cls;
-      }
-      cls = lane == N - 1 ? 1 : cls;
-      const bool stored = internal && cls == 1 && lane != N - 1;
-      const uint64_t stored_mask = __ballot(stored);
-      const uint64_t macro_mask = __ballot(internal && cls == 1);
-      const uint64_t below = (1ull << lane) - 1;
-      const int sslot = lane == N - 1 ? -1 : __popcll(stored_mask & below);  // slots in id order
-      stored_total = __popcll(stored_mask);
-      macro_total = __popcll(macro_mask);
-      is_macro = internal && cls == 1;
-      macro_rank = __popcll(macro_mask & below);
-      // every lane that owns a macro assembles it from its children's lanes
-      int kind[2];
-      me.node = lane;
-      me.pad = 0;
-      me.qslot = sslot;
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int ch = j ? c1 : c0;
-        // (cross-lane reads stay outside lane-dependent conditions: an inactive source
-        // lane would read as 0)
-        const int cls_ch = __shfl(cls, ch, 64);
-        const int cc = ch >= n ? cls_ch : 0;
-        const int chs = __shfl(sslot, ch, 64);
-        const int ga_ = __shfl(c0, ch, 64), gb_ = __shfl(c1, ch, 64);
-        me.child[j] = ch;
-        kind[j] = cc;
-        me.cslot[j] = cc == 1 ? chs : 0;
-        const bool expand = cc == 2;
-        const int ga = expand ? ga_ : 0, gb = expand ? gb_ : 0;
-        const int gas = __shfl(sslot, ga, 64), gbs = __shfl(sslot, gb, 64);
-        me.grand[2 * j] = ga;
-        me.grand[2 * j + 1] = gb;
-        me.gslot[2 * j] = ga >= n ? gas : 0;
-        me.gslot[2 * j + 1] = gb >= n ? gbs : 0;
+        for (int nb = 0; nb < NB; nb++) cls.r[nb] = own(nb) == v ? (unstored ? 2 : 1) : cls.r[nb];
       }
-      me.shape = macro_shape(kind[0], kind[1], lane == N - 1, me.child, me.grand, n);
+      Arr sslot;
+      int stored_before = 0, macros_before = 0;
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const int v = own(nb);
+        cls.r[nb] = v == N - 1 ? 1 : cls.r[nb];
+        const bool internal = v >= n && v < N;
+        const bool stored = internal && cls.r[nb] == 1 && v != N - 1;
+        const uint64_t stored_mask = __ballot(stored);
+        const uint64_t macro_mask = __ballot(internal && cls.r[nb] == 1);
+        const uint64_t below = (1ull << lane) - 1;
+        // slots and macro indices in node-id order
+        sslot.r[nb] = v == N - 1 ? -1 : stored_before + __popcll(stored_mask & below);
+        is_macro[nb] = internal && cls.r[nb] == 1;
+        macro_rank[nb] = macros_before + __popcll(macro_mask & below);
+        stored_before += __popcll(stored_mask);
+        macros_before += __popcll(macro_mask);
+      }
+      stored_total = stored_before;
+      macro_total = macros_before;
+      // every lane that owns a macro assembles it from its children's lanes (cross-lane
+      // reads stay outside lane-dependent conditions: an inactive source lane reads as 0)
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        int kind[2];
+        me[nb].node = own(nb);
+        me[nb].pad = 0;
+        me[nb].qslot = sslot.r[nb];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int ch = j ? c1.r[nb] : c0.r[nb];
+          const int cls_ch = cls.gather(ch), chs = sslot.gather(ch);
+          const int ga_ = c0.gather(ch), gb_ = c1.gather(ch);
+          const int cc = ch >= n ? cls_ch : 0;
+          me[nb].child[j] = ch;
+          kind[j] = cc;
+          me[nb].cslot[j] = cc == 1 ? chs : 0;
+          const bool expand = cc == 2;
+          const int ga = expand ? ga_ : 0, gb = expand ? gb_ : 0;
+          const int gas = sslot.gather(ga), gbs = sslot.gather(gb);
+          me[nb].grand[2 * j] = ga;
+          me[nb].grand[2 * j + 1] = gb;
+          me[nb].gslot[2 * j] = ga >= n ? gas : 0;
+          me[nb].gslot[2 * j + 1] = gb >= n ? gbs : 0;
+        }
+        me[nb].shape =
+            macro_shape(kind[0], kind[1], own(nb) == N - 1, me[nb].child, me[nb].grand, n);
+      }
       if (stored_total > max_stored(n)) status = kTooManySlots;
     }
   }
@@ -527,19 +631,23 @@ __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
     for (int v = lane; v < N; v += 64) ble[v] = 0.0;
     return;
   }
-  if (lane < n - 1) sched[lane] = {s_node, s_c0, s_c1, s_sl};
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++)
+    if (own(nb) < n - 1) sched[own(nb)] = {s_node.r[nb], s_c0.r[nb], s_c1.r[nb], s_sl.r[nb]};
   if (a.macros) {
     MacroEntry* mac = a.macros + (size_t)t * max_macros(n);
-    if (is_macro) mac[macro_rank] = me;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+      if (is_macro[nb]) mac[macro_rank[nb]] = me[nb];
     if (lane == 0) a.macro_count[t] = macro_total;
   }
   if (!a.rooted) {
     const double* bl = a.bl + (size_t)t * (N - 1);
-    if (lane < N) ble[lane] = lane < N - 2 ? bl[lane] : 0.0;
+    for (int v = lane; v < N; v += 64) ble[v] = v < N - 2 ? bl[v] : 0.0;
   } else {
     const double* bl = a.bl + (size_t)t * N;
     const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
-    if (lane < N) ble[lane] = (rates && lane < N - 1) ? bl[lane] * rates[lane] : bl[lane];
+    for (int v = lane; v < N; v += 64) ble[v] = (rates && v < N - 1) ? bl[v] * rates[v] : bl[v];
   }
 }
 #undef RDL
@@ -2222,8 +2330,12 @@ void launch_tree_setup(const TreeSetupArgs& a_in, hipStream_t s) {
     const char* env = getenv("MI_PHYLO_TREE_SETUP");
     return env && std::string(env) == "lds";
   }();
-  if (2 * a.n - 1 <= 64 && a.n >= 3 && !force_lds) {
-    hipLaunchKernelGGL(tree_setup_small_kernel, dim3(a.T), dim3(64), 0, s, a);
+  const int N = 2 * a.n - 1;
+  if (a.n >= 3 && N <= 256 && !force_lds) {
+    if (N <= 64) hipLaunchKernelGGL(tree_setup_small_kernel<1>, dim3(a.T), dim3(64), 0, s, a);
+    else if (N <= 128) hipLaunchKernelGGL(tree_setup_small_kernel<2>, dim3(a.T), dim3(64), 0, s, a);
+    else if (N <= 192) hipLaunchKernelGGL(tree_setup_small_kernel<3>, dim3(a.T), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(tree_setup_small_kernel<4>, dim3(a.T), dim3(64), 0, s, a);
     return;
   }
   hipLaunchKernelGGL(tree_setup_kernel, dim3(a.T), dim3(64), a.use_lds ? lds : 0, s, a);

@@ -22,7 +22,7 @@ def test_cpp_engine_adapter(tmp_path):
 
 
 def test_tree_setup_kernels_agree(tmp_path):
-    """The register-array tree-setup kernel (N <= 64, branch-free) must produce exactly
+    """The register-array tree-setup kernel (N <= 256, branch-free) must produce exactly
     what the general LDS kernel produces: status, macro counts, the Sethi-Ullman schedule
     with its LDS slots, and the half-storage gradient schedule."""
     import numpy as np
@@ -34,7 +34,7 @@ def test_tree_setup_kernels_agree(tmp_path):
                     os.path.join(REPO, "tests/cpp/tree_setup_compare.hip"),
                     "-L" + lib, "-lmi_phylo", "-Wl,-rpath," + lib, "-o", str(exe)], check=True)
     rng = np.random.default_rng(11)
-    for n in (3, 4, 5, 6, 9, 17, 27, 32):
+    for n in (3, 4, 5, 6, 9, 17, 27, 32, 33, 50, 64, 65, 69, 100, 128):
         T = 40
         pids, _ = TU.random_trees(n, T, rng)
         pids[0] = TU.ladder_topology(n)

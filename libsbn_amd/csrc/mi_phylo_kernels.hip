@@ -2274,7 +2274,62 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
     for (int v = lane; v < N - 1; v += 64) oc[v] = 0;
   }
   double* out_global = a.out_ratios + (size_t)t * (n - 1);
-  double* outr = outr_stage ? outr_stage : out_global;
+  if (outr_stage) {
+    // Working set in LDS: everything that is not a recurrence is done by all lanes (height
+    // gradient, the per-node coefficients of the ratio transform, the root sums), and the
+    // two ratio transforms (height gradient, log-Jacobian) share ONE bottom-up and one
+    // top-down chain of multiply-adds (rooted_gradient_transforms.cpp:17-170).
+    const int root = N - 1;
+    double* rw = outr_stage + n;  // 8n doubles
+    double *hg = rw, *aux = rw + n, *Pv = rw + 2 * n, *E0 = rw + 3 * n, *E1 = rw + 4 * n;
+    double *outA = rw + 5 * n, *outB = rw + 6 * n, *mult = rw + 7 * n;
+    for (int i = lane; i < n - 1; i += 64) {
+      const int v = n + i, a0 = c0[i], a1 = c1[i];
+      // HeightGradient :17-37
+      double x = v != root ? -bg[v] * rates[v] : 0.0;
+      x += bg[a0] * rates[a0];
+      x += bg[a1] * rates[a1];
+      hg[i] = x;
+      aux[i] = i < n - 2 ? 1.0 / (h[v] - bd[v]) : 0.0;  // d log|J| / d height
+      // out_v = partial_v gh_v + sum over internal children c of out_c * epoch(v, c) :47-64
+      const double partial = v != root ? (h[v] - bd[v]) / ratios[i] : 0.0;
+      auto epoch = [&](int c) {
+        if (c < n || v == root) return 0.0;
+        if (bd[v] == bd[c]) return ratios[c - n] / ratios[i];
+        return ratios[c - n] / (h[v] - bd[c]) * partial;
+      };
+      Pv[i] = partial;
+      E0[i] = epoch(a0);
+      E1[i] = epoch(a1);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      for (int i = 0; i < n - 2; i++) {
+        const int a0 = c0[i] >= n ? c0[i] - n : 0, a1 = c1[i] >= n ? c1[i] - n : 0;
+        outA[i] = Pv[i] * hg[i] + E0[i] * outA[a0] + E1[i] * outA[a1];
+        outB[i] = Pv[i] * aux[i] + E0[i] * outB[a0] + E1[i] * outB[a1];
+      }
+      mult[root - n] = 1.0;  // :102-130
+      for (int v = root; v >= n; v--) {
+        const int a0 = c0[v - n], a1 = c1[v - n];
+        const double m = mult[v - n];
+        if (a0 >= n) mult[a0 - n] = ratios[a0 - n] * m;
+        if (a1 >= n) mult[a1 - n] = ratios[a1 - n] * m;
+      }
+    }
+    __syncthreads();
+    double ra = 0, rb = 0;
+    for (int i = lane; i < n - 1; i += 64) {
+      ra += hg[i] * mult[i];
+      rb += aux[i] * mult[i];
+    }
+    ra = wave_sum(ra);
+    rb = wave_sum(rb);
+    for (int i = lane; i < n - 2; i += 64) out_global[i] = outA[i] + (outB[i] - 1.0 / ratios[i]);
+    if (lane == 0) out_global[n - 2] = ra + rb;
+    return;
+  }
+  double* outr = out_global;
   if (lane == 0) {
   double* hg = work + 2 * n;    // n-1
   double* aux = work + 3 * n;   // n-1 (log_time)
@@ -2293,10 +2348,6 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
   ratio_transform(n, c0, c1, h, ratios, bd, aux, mult, jacg);
   for (int i = 0; i < n - 2; i++) outr[i] += jacg[i] - 1.0 / ratios[i];
   outr[n - 2] += jacg[n - 2];
-  }
-  if (outr_stage) {
-    __syncthreads();
-    for (int i = lane; i < n - 1; i += 64) out_global[i] = outr_stage[i];
   }
 }
 
@@ -2494,8 +2545,9 @@ void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s) {
 }
 void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
   FinalizeArgs a = a_in;
-  // 6n of working set (+ the staged tree state of a rooted tree: 3N + 2n)
-  const size_t lds = sizeof(double) * (a.rooted ? 14 * (size_t)a.n : 6 * (size_t)a.n);
+  // 6n of working set (+ for a rooted tree its staged state, 3N + 2n, and 8n of
+  // coefficients and partial results)
+  const size_t lds = sizeof(double) * (a.rooted ? 22 * (size_t)a.n : 6 * (size_t)a.n);
   a.use_lds = lds <= 48 * 1024;
   hipLaunchKernelGGL(finalize_kernel, dim3(a.T), dim3(64), a.use_lds ? lds : 0, s, a);
 }

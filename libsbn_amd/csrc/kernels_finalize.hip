@@ -1,0 +1,446 @@
+// Tile reduction, analytic substitution-gradient finish, per-tree finalize.
+// (gfx950 / CDNA4, wave64; see DESIGN.md for the mapping and what bounds each kernel.)
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <string>
+
+#include "mi_phylo_device_utils.h"
+#include "mi_phylo_kernels.h"
+
+namespace miphylo {
+
+namespace {
+using namespace dev;
+
+// ------------------------------------------------------------------------
+// Tile reduction (one workgroup per evaluation): four waves split the tiles
+// (wave w takes tiles w, w+4, ...), combine through LDS in a fixed order.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
+  extern __shared__ double red_lds[];  // [4][W]
+  __shared__ double llw[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int N2 = 2 * a.N;
+  const int W = a.g_width ? a.g_width : N2;  // doubles per (evaluation, tile)
+  double llp = 0;
+  for (int i = threadIdx.x; i < a.ll_tiles; i += 256) llp += a.ll_part[(size_t)b * a.ll_tiles + i];
+  llp = wave_sum(llp);
+  if (lane == 0) llw[wv] = llp;
+  const int t = b < a.T ? b : b - a.T;  // gradient evaluations: [0,T) main, [T,2T) site pass
+  int used = W;
+  if (b < a.Eg && a.g_width) used = a.macro_count[t] * kMacroPositions * 2;
+  if (b < a.Eg) {
+    const double* src = a.g_part + (size_t)b * a.g_tiles * W;
+    const int tail = a.g_width ? W - a.extra : W;  // plain sums after the positional part
+    for (int v = lane; v < used + a.extra; v += 64) {
+      if (v >= used) v = tail + (v - used);
+      double s0 = 0, s1 = 0;
+      int i = wv;
+      for (; i + 4 < a.g_tiles; i += 8) {
+        s0 += src[(size_t)i * W + v];
+        s1 += src[(size_t)(i + 4) * W + v];
+      }
+      if (i < a.g_tiles) s0 += src[(size_t)i * W + v];
+      red_lds[wv * W + v] = s0 + s1;
+      if (v >= tail) v = used + (v - tail);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.ll_sum[b] = (llw[0] + llw[1]) + (llw[2] + llw[3]);
+  if (b >= a.Eg) return;
+  double* out = a.g_sum + (size_t)b * N2;
+  if (!a.g_width) {
+    for (int v = threadIdx.x; v < N2; v += 256)
+      out[v] = (red_lds[v] + red_lds[W + v]) + (red_lds[2 * W + v] + red_lds[3 * W + v]);
+    return;
+  }
+  // positional: entry (m, pos, q) belongs to the edge above child/grandchild `pos` of macro m
+  const MacroEntry* mac = a.macros + (size_t)t * max_macros(a.n);
+  if (a.extra)
+    for (int v = threadIdx.x; v < a.extra; v += 256) {
+      const int c = W - a.extra + v;
+      a.x_sum[(size_t)b * a.extra + v] =
+          (red_lds[c] + red_lds[W + c]) + (red_lds[2 * W + c] + red_lds[3 * W + c]);
+    }
+  if (threadIdx.x < 2) out[threadIdx.x * a.N + a.N - 1] = 0.0;  // the root has no edge
+  for (int v = threadIdx.x; v < used; v += 256) {
+    const int m = v / (kMacroPositions * 2), r = v - m * (kMacroPositions * 2);
+    const int pos = r >> 1, q = r & 1;
+    const MacroEntry& me = mac[m];
+    const bool exists = pos < 2 || ((me.shape >> (2 * ((pos - 2) >> 1))) & 3) == 2;
+    if (!exists) continue;
+    const int node = pos < 2 ? me.child[pos] : me.grand[pos - 2];
+    out[q * a.N + node] =
+        (red_lds[v] + red_lds[W + v]) + (red_lds[2 * W + v] + red_lds[3 * W + v]);
+  }
+}
+
+// ------------------------------------------------------------------------
+// Analytic substitution-model gradient, last step (one thread per tree).
+// In: H^T per category block (64 doubles, lane order of gradient_mfma_kernel) and the
+// root term d logL / d pi (4 doubles).  GTR as built by model_setup_kernel
+// (substitution_model.cpp:17-80): Qt_ab = rho_ab pi_b, mu = sum_a pi_a sum_{b != a} Qt_ab,
+// Q = Qt / mu.  Out: derivatives w.r.t. the stick-breaking coordinates of the rates (5)
+// and of the frequencies (3), the quantities the reference obtains by finite
+// differences (fat_beagle.cpp:400-465).
+// ------------------------------------------------------------------------
+__device__ void stick_breaking_chain(int K, const double* x, const double* g, double* out) {
+  // x = stick_breaking(y): x_k = s_k z_k, s_k = prod_{j<k} (1 - z_j), x_{K-1} = s_{K-1};
+  // dz_k/dy_k = z_k (1 - z_k)  =>  dL/dy_k = g_k x_k (1 - z_k) - z_k sum_{m>k} g_m x_m
+  double tail[8];
+  double acc = 0;
+  for (int m = K - 1; m >= 0; m--) {
+    tail[m] = acc;  // sum_{m' > m} g_m' x_m'
+    acc += g[m] * x[m];
+  }
+  double used = 0;
+  for (int k = 0; k < K - 1; k++) {
+    const double z = x[k] / (1.0 - used);
+    out[k] = g[k] * x[k] * (1.0 - z) - z * tail[k];
+    used += x[k];
+  }
+}
+
+__global__ void subst_gradient_kernel(SubstGradArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.T) return;
+  const DevModel& m = a.models[t];
+  const double* x = a.x_sum + (size_t)t * kSubstExtra;
+  const double* row = a.params + (size_t)t * a.param_count;
+  double H[16];  // H[i][j] = sum over blocks of H^T[j][i]
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double sum = 0;
+      for (int b = 0; b < 4; b++) sum += x[16 * j + 4 * b + i];
+      H[i * 4 + j] = sum;
+    }
+  // D = V^-T H V^T : D[a][b] = sum_ij Vinv[i][a] H[i][j] V[b][j]
+  double HV[16], D[16];
+  for (int i = 0; i < 4; i++)
+    for (int b = 0; b < 4; b++) {
+      double sum = 0;
+      for (int j = 0; j < 4; j++) sum += H[i * 4 + j] * m.V[b * 4 + j];
+      HV[i * 4 + b] = sum;
+    }
+  double S = 0;  // <D, Q>
+  for (int c = 0; c < 4; c++)
+    for (int b = 0; b < 4; b++) {
+      double sum = 0;
+      for (int i = 0; i < 4; i++) sum += m.Vinv[i * 4 + c] * HV[i * 4 + b];
+      D[c * 4 + b] = sum;
+      S += sum * m.Q[c * 4 + b];
+    }
+  double rates[6], pi[4];
+  for (int i = 0; i < 6; i++) rates[i] = row[a.rates_off + i];
+  for (int i = 0; i < 4; i++) pi[i] = row[a.freqs_off + i];
+  double mu = 0;
+  {
+    int ri = 0;
+    for (int i = 0; i < 4; i++)
+      for (int k = i + 1; k < 4; k++) {
+        const double r = rates[ri++];
+        mu += pi[i] * r * pi[k] + pi[k] * r * pi[i];
+      }
+  }
+  // d logL / d Qt_ab (a != b, diagonal follows) = (D_ab - D_aa - S pi_a) / mu
+  auto dQt = [&](int c, int b) { return (D[c * 4 + b] - D[c * 4 + c] - S * pi[c]) / mu; };
+  double g_rate[6], g_pi[4];
+  for (int c = 0; c < 4; c++) g_pi[c] = x[64 + c] + S * m.Q[c * 4 + c];  // root term, explicit pi in mu
+  {
+    int ri = 0;
+    for (int i = 0; i < 4; i++)
+      for (int k = i + 1; k < 4; k++) {
+        const double r = rates[ri];
+        g_rate[ri] = pi[k] * dQt(i, k) + pi[i] * dQt(k, i);
+        g_pi[k] += r * dQt(i, k);  // Qt_ik = r pi_k
+        g_pi[i] += r * dQt(k, i);  // Qt_ki = r pi_i
+        ri++;
+      }
+  }
+  double* out = a.out_subst + (size_t)t * 8;
+  stick_breaking_chain(6, rates, g_rate, out);
+  stick_breaking_chain(4, pi, g_pi, out + 5);
+}
+
+// ------------------------------------------------------------------------
+// Finalize (one thread per tree): sum tile partials in a fixed order
+// (deterministic), assemble PhyloGradient, rooted chain rule.
+// ------------------------------------------------------------------------
+__device__ double sum_tiles(const double* part, int tiles) {
+  double s = 0;
+  for (int i = 0; i < tiles; i++) s += part[i];
+  return s;
+}
+
+__device__ double node_partial(int v, int n, const double* h, const double* ratios,
+                               const double* bound) {
+  return (h[v] - bound[v]) / ratios[v - n];
+}
+__device__ double epoch_addition(int v, int c, int n, const double* h, const double* ratios,
+                                 const double* bound, const double* acc) {
+  if (c < n) return 0.0;
+  if (bound[v] == bound[c]) return acc[c - n] * ratios[c - n] / ratios[v - n];
+  return acc[c - n] * ratios[c - n] / (h[v] - bound[c]) * node_partial(v, n, h, ratios, bound);
+}
+
+// rooted_gradient_transforms.cpp:78-130 for one input vector gh -> out (+ root entry)
+__device__ void ratio_transform(int n, const int32_t* c0, const int32_t* c1, const double* h,
+                                const double* ratios, const double* bound, const double* gh,
+                                double* mult, double* out) {
+  const int N = 2 * n - 1, root = N - 1;
+  for (int i = 0; i < n - 1; i++) out[i] = 0;
+  for (int v = n; v < root; v++) {
+    out[v - n] += node_partial(v, n, h, ratios, bound) * gh[v - n];
+    out[v - n] += epoch_addition(v, c0[v - n], n, h, ratios, bound, out);
+    out[v - n] += epoch_addition(v, c1[v - n], n, h, ratios, bound, out);
+  }
+  mult[root - n] = 1.0;
+  for (int v = root; v >= n; v--) {
+    const int a = c0[v - n], b = c1[v - n];
+    if (a >= n) mult[a - n] = ratios[a - n] * mult[v - n];
+    if (b >= n) mult[b - n] = ratios[b - n] * mult[v - n];
+  }
+  double sum = 0;
+  for (int i = 0; i < n - 1; i++) sum += gh[i] * mult[i];
+  out[root - n] = sum;
+}
+
+__global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
+  // One wave per tree: lanes run over nodes / tiles for the reductions, lane 0
+  // walks the O(n) recurrences of the rooted chain rule.  Working set (6n doubles, for
+  // rooted trees also the tree's heights, bounds, ratios, rates and the ratio gradient
+  // being built: each access of those recurrences is on a dependent chain, and a global
+  // load there costs ten LDS reads) in LDS unless the tree is too large.
+  extern __shared__ double fin_lds[];
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int n = a.n, N = a.N, T = a.T;
+  double* base = a.use_lds ? fin_lds : a.scratch + (size_t)t * 6 * n;
+  int32_t* c0 = reinterpret_cast<int32_t*>(base);
+  int32_t* c1 = c0 + n;
+  double* work = base + n;  // 5n doubles
+  const SchedEntry* sched = a.sched + (size_t)t * (n - 1);
+  for (int i = lane; i < n - 1; i += 64) {
+    const SchedEntry se = sched[i];
+    c0[se.node - n] = se.child0;
+    c1[se.node - n] = se.child1;
+  }
+  const double* h = a.node_heights ? a.node_heights + (size_t)t * N : nullptr;
+  const double* bd = a.node_bounds ? a.node_bounds + (size_t)t * N : nullptr;
+  const double* ratios = a.height_ratios ? a.height_ratios + (size_t)t * (n - 1) : nullptr;
+  const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
+  double* outr_stage = nullptr;
+  if (a.rooted && a.use_lds) {
+    double* stage = fin_lds + 6 * n;  // h[N] | bd[N] | rates[N] | ratios[n] | out[n]
+    for (int v = lane; v < N; v += 64) {
+      if (h) stage[v] = h[v];
+      if (bd) stage[N + v] = bd[v];
+      if (rates && v < N - 1) stage[2 * N + v] = rates[v];
+      if (ratios && v < n - 1) stage[3 * N + v] = ratios[v];
+    }
+    if (h) h = stage;
+    if (bd) bd = stage + N;
+    if (rates) rates = stage + 2 * N;
+    if (ratios) ratios = stage + 3 * N;
+    outr_stage = stage + 3 * N + n;
+  }
+  __syncthreads();
+  __shared__ double sh_ll, sh_jac;
+  if (lane == 0) {
+    sh_ll = sum_tiles(a.ll_part + (size_t)t * a.ll_tiles, a.ll_tiles);
+    double jac = 0.0;
+    if (a.rooted && (a.with_jacobian || (a.gradient && a.gtr))) {
+      // fat_beagle.cpp:82-94; iteration order of TripleIdPreorderBifurcating
+      // (node.cpp:226-261) reproduced with an explicit stack in `work`.
+      int32_t* st = reinterpret_cast<int32_t*>(work);
+      int top = 0;
+      st[top++] = (N - 1) << 1;
+      while (top) {
+        const int item = st[--top];
+        const int v = item >> 1;
+        const int a0 = c0[v - n], a1 = c1[v - n];
+        if (item & 1) {
+          if (a1 >= n) {
+            jac += log(h[v] - bd[a1]);
+            st[top++] = a1 << 1;
+          }
+        } else {
+          st[top++] = (v << 1) | 1;
+          if (a0 >= n) {
+            jac += log(h[v] - bd[a0]);
+            st[top++] = a0 << 1;
+          }
+        }
+      }
+    }
+    sh_jac = jac;
+  }
+  __syncthreads();
+  const double ll = sh_ll, jac = sh_jac;
+  if (!a.gradient) {
+    if (lane == 0) a.out_ll[t] = a.with_jacobian ? ll + jac : ll;
+    return;
+  }
+  if (lane == 0) a.out_ll[t] = ll;
+  const double* ble = a.bl_eff + (size_t)t * N;
+  // branch gradient of the main evaluation: tile partials summed in tile order
+  double* bg = work;  // N doubles (N < 2n)
+  for (int v = lane; v < N; v += 64) {
+    double sum = 0;
+    for (int i = 0; i < a.g_tiles; i++)
+      sum += a.g_part[(((size_t)t * a.g_tiles + i) * 2) * N + v];
+    bg[v] = sum;
+  }
+  if (a.out_site && (a.site_fused || a.site_separate)) {
+    // DiscreteSiteModelGradient fat_beagle.cpp:389-398
+    const size_t gi = a.site_separate ? (size_t)T + t : (size_t)t;
+    double r = 0;
+    for (int v = lane; v < N - 1; v += 64) {
+      double sum = 0;
+      for (int i = 0; i < a.g_tiles; i++)
+        sum += a.g_part[((gi * a.g_tiles + i) * 2 + 1) * N + v];
+      r += sum * ble[v];
+    }
+    r = wave_sum(r);
+    if (lane == 0) a.out_site[t] = r;
+  }
+  if (a.gtr && a.out_subst && lane < 8) {
+    // fat_beagle.cpp:431,455-464: rates (5) then frequencies (3)
+    const int coord = lane < 5 ? 3 + lane : lane - 5;
+    const size_t ep = (size_t)T + (size_t)t * 16 + 2 * coord;
+    double lp = sum_tiles(a.ll_part + ep * a.ll_tiles, a.ll_tiles);
+    double lm = sum_tiles(a.ll_part + (ep + 1) * a.ll_tiles, a.ll_tiles);
+    if (a.rooted) {
+      lp += jac;
+      lm += jac;
+    }
+    a.out_subst[(size_t)t * 8 + lane] = (lp - lm) / (2. * 1.e-6);
+  }
+  __syncthreads();
+  if (!a.rooted) {
+    double* ob = a.out_branch + (size_t)t * N;
+    // fixed node = second child of the root (fat_beagle.cpp:499); root entry is 0
+    for (int v = lane; v < N; v += 64) ob[v] = v < N - 2 ? bg[v] : 0.0;
+    return;
+  }
+  // ---- rooted: clock + ratios/root-height gradients ----
+  const double* tb = a.bl_raw + (size_t)t * N;
+  double* oc = a.out_clock + (size_t)t * (N - 1);
+  const int rc = a.rate_counts[t];
+  if (rc == 1) {
+    // ClockGradient fat_beagle.cpp:367-387 (strict): sum_i g_i * t_i
+    double acc = 0;
+    for (int v = lane; v < N - 1; v += 64) acc += bg[v] * tb[v];
+    acc = wave_sum(acc);
+    for (int v = lane; v < N - 1; v += 64) oc[v] = v == 0 ? acc : 0.0;
+  } else if (rc == N - 1) {
+    for (int v = lane; v < N - 1; v += 64) oc[v] = bg[v] * tb[v];
+  } else {
+    if (lane == 0) set_status(a.status, kBadRateCount, t);
+    for (int v = lane; v < N - 1; v += 64) oc[v] = 0;
+  }
+  double* out_global = a.out_ratios + (size_t)t * (n - 1);
+  if (outr_stage) {
+    // Working set in LDS: everything that is not a recurrence is done by all lanes (height
+    // gradient, the per-node coefficients of the ratio transform, the root sums), and the
+    // two ratio transforms (height gradient, log-Jacobian) share ONE bottom-up and one
+    // top-down chain of multiply-adds (rooted_gradient_transforms.cpp:17-170).
+    const int root = N - 1;
+    double* rw = outr_stage + n;  // 8n doubles
+    double *hg = rw, *aux = rw + n, *Pv = rw + 2 * n, *E0 = rw + 3 * n, *E1 = rw + 4 * n;
+    double *outA = rw + 5 * n, *outB = rw + 6 * n, *mult = rw + 7 * n;
+    for (int i = lane; i < n - 1; i += 64) {
+      const int v = n + i, a0 = c0[i], a1 = c1[i];
+      // HeightGradient :17-37
+      double x = v != root ? -bg[v] * rates[v] : 0.0;
+      x += bg[a0] * rates[a0];
+      x += bg[a1] * rates[a1];
+      hg[i] = x;
+      aux[i] = i < n - 2 ? 1.0 / (h[v] - bd[v]) : 0.0;  // d log|J| / d height
+      // out_v = partial_v gh_v + sum over internal children c of out_c * epoch(v, c) :47-64
+      const double partial = v != root ? (h[v] - bd[v]) / ratios[i] : 0.0;
+      auto epoch = [&](int c) {
+        if (c < n || v == root) return 0.0;
+        if (bd[v] == bd[c]) return ratios[c - n] / ratios[i];
+        return ratios[c - n] / (h[v] - bd[c]) * partial;
+      };
+      Pv[i] = partial;
+      E0[i] = epoch(a0);
+      E1[i] = epoch(a1);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      for (int i = 0; i < n - 2; i++) {
+        const int a0 = c0[i] >= n ? c0[i] - n : 0, a1 = c1[i] >= n ? c1[i] - n : 0;
+        outA[i] = Pv[i] * hg[i] + E0[i] * outA[a0] + E1[i] * outA[a1];
+        outB[i] = Pv[i] * aux[i] + E0[i] * outB[a0] + E1[i] * outB[a1];
+      }
+      mult[root - n] = 1.0;  // :102-130
+      for (int v = root; v >= n; v--) {
+        const int a0 = c0[v - n], a1 = c1[v - n];
+        const double m = mult[v - n];
+        if (a0 >= n) mult[a0 - n] = ratios[a0 - n] * m;
+        if (a1 >= n) mult[a1 - n] = ratios[a1 - n] * m;
+      }
+    }
+    __syncthreads();
+    double ra = 0, rb = 0;
+    for (int i = lane; i < n - 1; i += 64) {
+      ra += hg[i] * mult[i];
+      rb += aux[i] * mult[i];
+    }
+    ra = wave_sum(ra);
+    rb = wave_sum(rb);
+    for (int i = lane; i < n - 2; i += 64) out_global[i] = outA[i] + (outB[i] - 1.0 / ratios[i]);
+    if (lane == 0) out_global[n - 2] = ra + rb;
+    return;
+  }
+  double* outr = out_global;
+  if (lane == 0) {
+  double* hg = work + 2 * n;    // n-1
+  double* aux = work + 3 * n;   // n-1 (log_time)
+  double* jacg = work + 4 * n;  // n-1
+  // HeightGradient rooted_gradient_transforms.cpp:17-37
+  for (int v = N - 1; v >= n; v--) {
+    double x = v != N - 1 ? -bg[v] * rates[v] : 0.0;
+    x += bg[c0[v - n]] * rates[c0[v - n]];
+    x += bg[c1[v - n]] * rates[c1[v - n]];
+    hg[v - n] = x;
+  }
+  double* mult = work;  // bg is dead from here on
+  ratio_transform(n, c0, c1, h, ratios, bd, hg, mult, outr);
+  for (int i = 0; i < n - 1; i++) aux[i] = 0;
+  for (int i = 0; i < n - 2; i++) aux[i] = 1.0 / (h[n + i] - bd[n + i]);
+  ratio_transform(n, c0, c1, h, ratios, bd, aux, mult, jacg);
+  for (int i = 0; i < n - 2; i++) outr[i] += jacg[i] - 1.0 / ratios[i];
+  outr[n - 2] += jacg[n - 2];
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------
+// Launch wrappers
+// ------------------------------------------------------------------------
+void launch_subst_gradient(const SubstGradArgs& a, hipStream_t s) {
+  if (a.T <= 0) return;
+  hipLaunchKernelGGL(subst_gradient_kernel, dim3((a.T + 63) / 64), dim3(64), 0, s, a);
+}
+bool reduce_tiles_fits(int N) {
+  return sizeof(double) * 4 * (size_t)(3 * N + 12 + kSubstExtra) <= 64 * 1024;
+}
+void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s) {
+  if (a.E <= 0) return;
+  const size_t W = a.g_width ? a.g_width : 2 * (size_t)a.N;
+  hipLaunchKernelGGL(reduce_tiles_kernel, dim3(a.E), dim3(256), sizeof(double) * 4 * W, s, a);
+}
+void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
+  FinalizeArgs a = a_in;
+  // 6n of working set (+ for a rooted tree its staged state, 3N + 2n, and 8n of
+  // coefficients and partial results)
+  const size_t lds = sizeof(double) * (a.rooted ? 22 * (size_t)a.n : 6 * (size_t)a.n);
+  a.use_lds = lds <= 48 * 1024;
+  hipLaunchKernelGGL(finalize_kernel, dim3(a.T), dim3(64), a.use_lds ? lds : 0, s, a);
+}
+
+}  // namespace miphylo

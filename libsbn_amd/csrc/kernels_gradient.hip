@@ -1,0 +1,732 @@
+// Gradient kernels: matrix-core on-chip (default) and HBM-streamed.
+// (gfx950 / CDNA4, wave64; see DESIGN.md for the mapping and what bounds each kernel.)
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <string>
+
+#include "mi_phylo_device_utils.h"
+#include "mi_phylo_kernels.h"
+
+namespace miphylo {
+
+namespace {
+using namespace dev;
+
+// ------------------------------------------------------------------------
+// Gradient v1 (B4-B11): post-order, pre-order and edge derivatives in one
+// launch, partial-likelihood vectors streamed through HBM in the layout
+// [evaluation][node][category][pattern][state] (32 B per lane, a wave reads or
+// writes 2 KiB contiguous).  Each lane only ever re-reads what it wrote itself,
+// so no inter-wave synchronisation is needed.  The pre-order vector of a node
+// overwrites its post-order vector in place once the latter is dead.
+// ------------------------------------------------------------------------
+template <bool RESCALE, bool TIP_PARTIALS>
+__global__ __launch_bounds__(kTile) void gradient_hbm_kernel(LikArgs a) {
+  const int lane = threadIdx.x;
+  const TileEval te = xcd_tile_eval();
+  const int tile = te.tile;
+  const int e = a.eval_offset + te.eval;
+  const int gi = a.grad_offset + te.eval;
+  int t, mi;
+  a.map.decode(e, t, mi);
+  const DevModel* __restrict__ model = a.models + mi;
+  const SchedEntry* __restrict__ sched = a.sched + (size_t)t * (a.n - 1);
+  const int p = tile * kTile + lane;
+  const int pc = p < a.P ? p : a.P - 1;
+  const double w = p < a.P ? a.weights[pc] : 0.0;
+  const int K = a.K, n = a.n, N = a.N;
+  const size_t ppad = (size_t)a.tiles * kTile;
+  const double* __restrict__ mats_e = a.mats + (size_t)e * (N - 1) * K * 16;
+  double* plv_e = a.plv + (size_t)te.eval * (n - 1) * K * ppad * 4 + (size_t)p * 4;
+  double* gout = a.g_part + ((size_t)gi * a.g_tiles + tile) * 2 * N;
+
+  auto plv_at = [&](int node, int k) { return plv_e + ((size_t)(node - n) * K + k) * ppad * 4; };
+  auto tip_L = [&](int node) {
+    if (TIP_PARTIALS) return load4(a.tip_partials + ((size_t)node * a.P + pc) * 4);
+    return tip_vector(a.tip_states[(size_t)node * a.P + pc]);
+  };
+
+  // ---- post-order ----
+  int cum_exp = 0;
+  double site = 0.0;
+  for (int i = 0; i < n - 1; i++) {
+    const SchedEntry s = sched[i];
+    const bool is_root = i == n - 2;
+    double mx = 0.0;
+    for (int k = 0; k < K; k++) {
+      const double* __restrict__ M0 = mats_e + ((size_t)s.child0 * K + k) * 16;
+      const double* __restrict__ M1 = mats_e + ((size_t)s.child1 * K + k) * 16;
+      const D4 L0 = s.child0 < n ? tip_L(s.child0) : load4(plv_at(s.child0, k));
+      const D4 L1 = s.child1 < n ? tip_L(s.child1) : load4(plv_at(s.child1, k));
+      const D4 L = mul4(matvec(M0, L0), matvec(M1, L1));
+      if (RESCALE) mx = fmax(mx, max4(L));
+      if (is_root && !RESCALE) {
+        site += model->cat_weight[k] * (model->pi[0] * L.x0 + model->pi[1] * L.x1 +
+                                        model->pi[2] * L.x2 + model->pi[3] * L.x3);
+      } else {
+        store4(plv_at(s.node, k), L);
+      }
+    }
+    if (RESCALE) {
+      // common exponent across categories (the ratio in the edge derivative needs it)
+      const int ex = max_exponent(mx);
+      cum_exp += ex;
+      for (int k = 0; k < K; k++) {
+        const D4 L = scale4(load4(plv_at(s.node, k)), -ex);
+        if (is_root)
+          site += model->cat_weight[k] * (model->pi[0] * L.x0 + model->pi[1] * L.x1 +
+                                          model->pi[2] * L.x2 + model->pi[3] * L.x3);
+        else
+          store4(plv_at(s.node, k), L);
+      }
+    }
+  }
+  {
+    double ll = log(site);
+    if (RESCALE) ll += cum_exp * 0.6931471805599453;
+    ll = p < a.P ? w * ll : 0.0;
+    ll = wave_sum(ll);
+    if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + tile] = ll;
+  }
+
+  // ---- pre-order + edge derivatives, parents before children ----
+  for (int i = n - 2; i >= 0; i--) {
+    const SchedEntry s = sched[i];
+    const bool is_root = i == n - 2;
+    double nb0 = 0, ns0 = 0, den0 = 0, nb1 = 0, ns1 = 0, den1 = 0;
+    double mx0 = 0, mx1 = 0;
+    for (int k = 0; k < K; k++) {
+      const double* __restrict__ M0 = mats_e + ((size_t)s.child0 * K + k) * 16;
+      const double* __restrict__ M1 = mats_e + ((size_t)s.child1 * K + k) * 16;
+      const D4 qv = is_root ? D4{model->pi[0], model->pi[1], model->pi[2], model->pi[3]}
+                            : load4(plv_at(s.node, k));
+      const D4 L0 = s.child0 < n ? tip_L(s.child0) : load4(plv_at(s.child0, k));
+      const D4 L1 = s.child1 < n ? tip_L(s.child1) : load4(plv_at(s.child1, k));
+      const D4 A = matvec(M0, L0), B = matvec(M1, L1);
+      const D4 q0 = matTvec(M0, mul4(qv, B));
+      const D4 q1 = matTvec(M1, mul4(qv, A));
+      const double cw = model->cat_weight[k];
+      const double n0 = cw * dot4(q0, matvec(model->Q, L0));
+      const double n1 = cw * dot4(q1, matvec(model->Q, L1));
+      nb0 += model->cat_rate[k] * n0;
+      ns0 += model->cat_drate[k] * n0;
+      den0 += cw * dot4(q0, L0);
+      nb1 += model->cat_rate[k] * n1;
+      ns1 += model->cat_drate[k] * n1;
+      den1 += cw * dot4(q1, L1);
+      if (s.child0 >= n) {
+        store4(plv_at(s.child0, k), q0);
+        if (RESCALE) mx0 = fmax(mx0, max4(q0));
+      }
+      if (s.child1 >= n) {
+        store4(plv_at(s.child1, k), q1);
+        if (RESCALE) mx1 = fmax(mx1, max4(q1));
+      }
+    }
+    if (RESCALE) {
+      if (s.child0 >= n) {
+        const int ex = max_exponent(mx0);
+        for (int k = 0; k < K; k++)
+          store4(plv_at(s.child0, k), scale4(load4(plv_at(s.child0, k)), -ex));
+      }
+      if (s.child1 >= n) {
+        const int ex = max_exponent(mx1);
+        for (int k = 0; k < K; k++)
+          store4(plv_at(s.child1, k), scale4(load4(plv_at(s.child1, k)), -ex));
+      }
+    }
+    const double gb0 = wave_sum(p < a.P ? w * (nb0 / den0) : 0.0);
+    const double gs0 = wave_sum(p < a.P ? w * (ns0 / den0) : 0.0);
+    const double gb1 = wave_sum(p < a.P ? w * (nb1 / den1) : 0.0);
+    const double gs1 = wave_sum(p < a.P ? w * (ns1 / den1) : 0.0);
+    if (lane == 0) {
+      gout[s.child0] = gb0;
+      gout[N + s.child0] = gs0;
+      gout[s.child1] = gb1;
+      gout[N + s.child1] = gs1;
+    }
+  }
+  if (lane == 0) {
+    gout[N - 1] = 0.0;
+    gout[N + N - 1] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------
+// DPP helper of the matrix-core kernels: v[lane] += v[lane - SHIFT] within each 16-lane
+// row (0 shifted in).
+// ------------------------------------------------------------------------
+template <int SHIFT>
+__device__ __forceinline__ double row_shr_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int slo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + SHIFT, 0xf, 0xf, true);
+  const int shi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + SHIFT, 0xf, 0xf, true);
+  return v + __hiloint2double(shi, slo);
+}
+
+// ------------------------------------------------------------------------
+// Gradient on the FP64 matrix cores: same half-storage walk as
+// superseded VALU kernel of this round, same register layout as loglik_mfma_kernel.
+//   * all rate categories sit in the four blocks of one instruction: no category
+//     loop, and the per-pattern site likelihood (the derivative's denominator) is
+//     computed by this kernel itself at the root -- no separate log-likelihood pass
+//   * a node's matrices are ONE register (forward) + ONE register (transposed, or
+//     (P Q) for a tip), fetched with a single 8-byte load per lane a whole macro ahead
+//   * per edge: n = q (.) (Q L) lane-wise, weighted by w_p cw_k r_k / site_p and
+//     summed over the whole wave (states, categories, patterns) by the transposed
+//     butterfly; the four sums of an edge pair land in LDS at the pair's POSITION in
+//     the schedule (macro index, child/grandchild), reduce_tiles_kernel maps positions
+//     to node ids
+//   * per-macro bookkeeping costs as much as the arithmetic, so it is
+//     kept to a minimum: the schedule entry stays in vector registers (all lanes hold
+//     the same values; addresses are one multiply-add per use), only its `shape` word
+//     is made scalar for the control flow
+// LDS per wave: max_stored(n) * R * 512 B of vectors (+ edge sums, tip state masks).
+// ------------------------------------------------------------------------
+template <int R, int DBG = 0, bool RESCALE = false, bool SUBST = false>
+__global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
+  static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
+  extern __shared__ double glds[];
+  const int lane = threadIdx.x;
+  const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
+  const TileEval te = xcd_tile_eval();
+  const int e = a.eval_offset + te.eval;
+  const int gi = a.grad_offset + te.eval;
+  int t, mi;
+  a.map.decode(e, t, mi);
+  const DevModel* __restrict__ model = a.models + mi;
+  const int K = a.K, n = a.n, N = a.N, Kp = a.kp;
+  // K > 4: a wave takes four categories (its category group) of its pattern tile; the
+  // per-pattern site likelihood, the one quantity that couples the groups, then comes
+  // from a preceding log-likelihood pass (a.site_lik) instead of this wave's own root.
+  const int groups = a.cat_groups, tiles_per_group = gridDim.x / groups;
+  const int group = te.tile / tiles_per_group, ptile = te.tile - group * tiles_per_group;
+  const int cat = 4 * group + b % Kp, pgrp = b / Kp, ppr = 16 / Kp;
+  const int catc = cat < K ? cat : K - 1;
+  // forward matrices, and per edge the matrix of the pre-order step: P again (read
+  // transposed) for an internal edge, (P Q) transposed for a tip edge
+  const char* __restrict__ mats_e =
+      reinterpret_cast<const char*>(a.mats + (size_t)e * (N - 1) * K * 16);
+  const char* __restrict__ trm_e =
+      reinterpret_cast<const char*>(a.tr_mats + (size_t)e * (N - 1) * K * 16);
+  const char* __restrict__ phi_e =
+      SUBST ? reinterpret_cast<const char*>(a.phi + (size_t)e * (N - 1) * K * 16) : nullptr;
+  const MacroEntry* __restrict__ macros = a.macros + (size_t)t * max_macros(n);
+  const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
+  // byte offsets inside one node's K matrices
+  const unsigned f_off = 8u * (catc * 16 + lo * 4 + hi);  // forward:    A[i=lo][k=hi] = P[lo][hi]
+  const unsigned t_off = 8u * (catc * 16 + hi * 4 + lo);  // transposed: A[i=lo][k=hi] = P[hi][lo]
+  const unsigned node_bytes = (unsigned)K * 128u;
+  const int TP = ppr * R, tile_start = ptile * TP;
+  const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
+  int pat[R], patc[R];
+  double pw[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    pat[r] = tile_start + r * ppr + col;
+    patc[r] = pat[r] < a.P ? pat[r] : a.P - 1;
+    pw[r] = pat[r] < a.P ? a.weights[patc[r]] : 0.0;
+  }
+  const double pi_l = model->pi[hi];
+  const double cw_l = cat < K ? model->cat_weight[cat] : 0.0;
+  const double rate_l = model->cat_rate[catc], drate_l = model->cat_drate[catc];
+  const double AQ = model->Q[lo * 4 + hi];  // A operand for Q L (same in every block)
+  // LDS: tip state masks [taxon][column][r] (one byte each: bit s set when the tip is
+  // compatible with state s) | edge sums [macro][position][branch, site] | vectors
+  // [slot][r][lane].  The masks come first so that the (ignored) mask fetch of an
+  // internal node id lands in valid memory without clamping: N * 4 * ppr bytes from
+  // the start is always inside the allocation.
+  uint8_t* tips = reinterpret_cast<uint8_t*>(glds);
+  const int gwidth = max_macros(n) * kMacroPositions * 2 + (SUBST ? kSubstExtra : 0);
+  double* gacc = glds + ((n * ppr * 4 + 7) >> 3);
+  double* plv = gacc + gwidth;
+  // RESCALE: per (slot, pattern) power-of-two exponent taken out of a stored vector
+  int32_t* exps = reinterpret_cast<int32_t*>(plv + (size_t)max_stored(n) * R * kTile);
+  {
+    // tip staging without divisions: the 64 lanes are (taxon group, pattern column) with
+    // the column count rounded up to a power of two (TP = 4R, 8R or 16R, R <= 4)
+    const int tp_shift = TP <= 16 ? 4 : (TP <= 32 ? 5 : 6);
+    const int q = lane & ((1 << tp_shift) - 1), group = 64 >> tp_shift;
+    const int ppr_shift = Kp == 4 ? 2 : (Kp == 2 ? 3 : 4);
+    const int r = q >> ppr_shift, c = q & (ppr - 1);  // pattern tile_start + q = r * ppr + c
+    if (q < TP) {
+      const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
+      const uint8_t* src = a.tip_masks + pp;
+#pragma unroll 4
+      for (int taxon = lane >> tp_shift; taxon < n; taxon += group)
+        tips[(taxon * ppr + c) * 4 + r] = src[(size_t)taxon * a.P];
+    }
+  }
+  __syncthreads();
+  if (M <= 0) return;
+  if (DBG & 64) {
+    if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = pw[0] + pi_l + cw_l + rate_l + drate_l + AQ;
+    return;
+  }
+
+  struct V {
+    double v[R];
+  };
+  // slots arrive as vector registers (the same value in every lane)
+  const unsigned lane8 = 8u * lane;
+  auto slot_ptr = [&](int slot) {
+    // keep the (wave-uniform) slot in its vector register: the compiler would otherwise
+    // move it to a scalar register first (a v_readfirstlane per field per macro)
+    asm volatile("" : "+v"(slot));
+    return reinterpret_cast<double*>(reinterpret_cast<char*>(plv) +
+                                     (__umul24((unsigned)slot, (unsigned)(R * kTile * 8)) + lane8));
+  };
+  auto load_slot = [&](int slot) {
+    V x;
+    if (DBG & 8) {
+#pragma unroll
+      for (int r = 0; r < R; r++) x.v[r] = pi_l + slot;
+      return x;
+    }
+    const double* c = slot_ptr(slot);
+#pragma unroll
+    for (int r = 0; r < R; r++) x.v[r] = c[r * kTile];
+    return x;
+  };
+  auto store_slot = [&](int slot, const V& x) {
+    if (DBG & 8) {
+      asm volatile("" ::"v"(x.v[0]), "v"(x.v[R - 1]));
+      return;
+    }
+    double* c = slot_ptr(slot);
+#pragma unroll
+    for (int r = 0; r < R; r++) c[r * kTile] = x.v[r];
+  };
+  auto mm = [&](double A, const V& x) {  // block-wise matrix product, R instructions
+    V y;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      y.v[r] = (DBG & 1) ? x.v[r] + A : __builtin_amdgcn_mfma_f64_4x4x4f64(A, x.v[r], 0.0, 0, 0, 0);
+    return y;
+  };
+  auto mul = [&](const V& x, const V& y) {
+    V z;
+#pragma unroll
+    for (int r = 0; r < R; r++) z.v[r] = x.v[r] * y.v[r];
+    return z;
+  };
+
+  // ---- schedule entries: two 32-byte halves, loaded by every lane from one address ----
+  struct Ids {  // first half: needed a macro ahead
+    int shape, c0, c1, g0, g1, g2, g3;
+  };
+  struct Slots {  // second half: needed during the macro
+    int q, cs0, cs1, gs0, gs1, gs2, gs3;
+  };
+  auto load_ids = [&](int m) {
+    const int4* p = reinterpret_cast<const int4*>(macros + m);
+    const int4 x = p[0], y = p[1];
+    return Ids{x.x, x.y, x.z, x.w, y.x, y.y, y.z};
+  };
+  auto load_slots = [&](int m) {
+    const int4* p = reinterpret_cast<const int4*>(macros + m) + 2;
+    const int4 x = p[0], y = p[1];
+    return Slots{x.x, x.y, x.z, x.w, y.x, y.y, y.z};
+  };
+  // shape word, scalar: bits 0-1 kind0, 2-3 kind1, 4 root, 8.. tip flags
+  auto kind0 = [](int s) { return s & 3; };
+  auto kind1 = [](int s) { return (s >> 2) & 3; };
+  auto is_root = [](int s) { return (s & 16) != 0; };
+  auto is_tip = [](int s, int j) { return ((s >> (8 + j)) & 1) != 0; };
+
+  // matrix registers of one macro (children c0,c1 and grandchildren a0,b0,a1,b1) and the
+  // tip state masks of this lane's column, fetched a macro ahead
+  struct MacroMats {
+    double f[6], tr[6];
+    double ph[SUBST ? 6 : 1];  // SUBST: divided differences Phi of the six edges
+    uint32_t tw[6];
+  };
+  const unsigned tt_delta = t_off - f_off;
+  const unsigned col4 = 4u * col;
+  auto fetch_mats = [&](const Ids& id, bool pre) {  // post-order needs the forward ones only
+    MacroMats mt;
+    int nodes[6] = {id.c0, id.c1, id.g0, id.g1, id.g2, id.g3};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      asm volatile("" : "+v"(nodes[j]));  // stays a vector register (see slot_ptr)
+      // (the compiler folds base + node * bytes + lane offset into one 64-bit multiply-add
+      // per address; forcing "scalar base + 32-bit lane offset" addressing measured slower)
+      const unsigned vf = __umul24((unsigned)nodes[j], node_bytes) + f_off;
+      const unsigned vt = vf + tt_delta;
+      if (DBG & 16) {
+        mt.f[j] = pi_l + nodes[j];
+        mt.tr[j] = pi_l - nodes[j];
+      } else {
+        mt.f[j] = *reinterpret_cast<const double*>(mats_e + vf);
+        if (pre) mt.tr[j] = *reinterpret_cast<const double*>(trm_e + vt);
+        if (pre && SUBST) mt.ph[j] = *reinterpret_cast<const double*>(phi_e + vt);
+      }
+      mt.tw[j] = *reinterpret_cast<const uint32_t*>(
+          tips + (__umul24((unsigned)nodes[j], (unsigned)(ppr * 4)) + col4));
+    }
+    return mt;
+  };
+  auto tip_vector = [&](uint32_t w) {
+    V x;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      x.v[r] = (double)__builtin_amdgcn_ubfe(w, (uint32_t)(8 * r + hi), 1u);
+    return x;
+  };
+
+  double qroot[R];  // root pre-order vector: pi * category weight * w_p / site likelihood
+  int esum[R];      // RESCALE: exponents removed so far, per pattern
+#pragma unroll
+  for (int r = 0; r < R; r++) esum[r] = 0;
+  // Operands of one macro: issued (LDS reads) before the next macro's matrices are
+  // requested, consumed afterwards.
+  struct Ops {
+    V q, x0, y0, x1, y1;  // q: pre-order vector; child 0: x0 (,y0 when unstored); child 1
+  };
+  auto load_ops = [&](int sh, const Slots& sl, const MacroMats& cm, bool pre) {
+    Ops o;
+    if (pre) {
+      if (is_root(sh)) {
+#pragma unroll
+        for (int r = 0; r < R; r++) o.q.v[r] = qroot[r];
+      } else {
+        o.q = load_slot(sl.q);
+        if (RESCALE) {
+#pragma unroll
+          for (int r = 0; r < R; r++)
+            o.q.v[r] = ldexp(o.q.v[r], -exps[__umul24((unsigned)sl.q, (unsigned)TP) +
+                                              (unsigned)(r * ppr + col)]);
+        }
+      }
+    }
+    if (kind0(sh) == 2) {
+      o.x0 = is_tip(sh, 2) ? tip_vector(cm.tw[2]) : load_slot(sl.gs0);
+      o.y0 = is_tip(sh, 3) ? tip_vector(cm.tw[3]) : load_slot(sl.gs1);
+    } else {
+      o.x0 = is_tip(sh, 0) ? tip_vector(cm.tw[0]) : load_slot(sl.cs0);
+    }
+    if (kind1(sh) == 2) {
+      o.x1 = is_tip(sh, 4) ? tip_vector(cm.tw[4]) : load_slot(sl.gs2);
+      o.y1 = is_tip(sh, 5) ? tip_vector(cm.tw[5]) : load_slot(sl.gs3);
+    } else {
+      o.x1 = is_tip(sh, 1) ? tip_vector(cm.tw[1]) : load_slot(sl.cs1);
+    }
+    return o;
+  };
+
+  // ================= post-order over the stored nodes (+ root: site likelihood) ====
+  auto post_step = [&](int sh, const Slots& sl, const MacroMats& cm, const Ops& o) {
+    V L0, L1;
+    if (kind0(sh) == 2) L0 = mul(mm(cm.f[2], o.x0), mm(cm.f[3], o.y0));
+    else L0 = o.x0;
+    if (kind1(sh) == 2) L1 = mul(mm(cm.f[4], o.x1), mm(cm.f[5], o.y1));
+    else L1 = o.x1;
+    V Lv = mul(mm(cm.f[0], L0), mm(cm.f[1], L1));
+    if (!is_root(sh)) {
+      if (RESCALE) {
+        // Per-pattern power-of-two rescaling of every STORED vector (exact): the
+        // exponent of the largest entry over states and categories is removed, summed
+        // per pattern for the log-likelihood, and remembered for the pre-order walk.
+        // With L_s = L 2^-E (E = exponents removed in the subtree) and q_s = q 2^E,
+        // q_s o L_s is scale-free and q_child_s = P^T(q_s o P L_sib_s) 2^-e_parent, so the
+        // only place an exponent re-enters is where a stored node's q is read back.
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          double mx = Lv.v[r];
+          mx = fmax(mx, __shfl_xor(mx, 16, 64));
+          mx = fmax(mx, __shfl_xor(mx, 32, 64));
+          if (Kp >= 2) mx = fmax(mx, __shfl_xor(mx, 4, 64));
+          if (Kp >= 4) mx = fmax(mx, __shfl_xor(mx, 8, 64));
+          const int ex = mx > 0.0 ? ilogb(mx) : 0;
+          Lv.v[r] = ldexp(Lv.v[r], -ex);
+          esum[r] += ex;
+          exps[__umul24((unsigned)sl.q, (unsigned)TP) + (unsigned)(r * ppr + col)] = ex;
+        }
+      }
+      store_slot(sl.q, Lv);
+    } else {
+      // root: site likelihood per pattern, log-likelihood partial, derivative weights
+      double ll = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        double v;
+        if (groups > 1) {
+          const size_t at = ((size_t)a.grad_offset + te.eval) * a.tiles * kTile + patc[r];
+          v = a.site_lik[at];
+          // rescaled: q_root 2^(E of this group's walk) = pi cw w 2^(E - site_exp) / mantissa
+          if (RESCALE) v = ldexp(v, a.site_exp[at] - esum[r]);
+        } else {
+          v = cw_l * pi_l * Lv.v[r];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (Kp >= 2) v += __shfl_xor(v, 4, 64);
+          if (Kp >= 4) v += __shfl_xor(v, 8, 64);
+        }
+        qroot[r] = pi_l * cw_l * (pw[r] / v);  // pw = 0 for padding patterns
+        if (hi == 0 && (b % Kp) == 0 && pat[r] < a.P)
+          ll += pw[r] * (RESCALE ? log(v) + esum[r] * 0.69314718055994530942 : log(v));
+      }
+      ll = wave_sum(ll);
+      if (lane == 0 && groups == 1) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
+      if (SUBST) {
+        // d logL / d pi_c through the root: sum_p w_p sum_k cw_k L_root[c] / site_p;
+        // this lane's state is c = hi, the 16 lanes of a row hold (category, pattern)
+        double z = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) z += qroot[r] * Lv.v[r];  // qroot = pi cw w / site
+        z = z / pi_l;
+        z = row_shr_add<8>(z);
+        z = row_shr_add<4>(z);
+        z = row_shr_add<2>(z);
+        z = row_shr_add<1>(z);
+        if ((lane & 15) == 15) gacc[gwidth - 4 + hi] = z;
+      }
+    }
+  };
+  {
+    // Two macros per iteration; everything ping-pongs between two register sets, so
+    // nothing is copied.  At the top of macro m: ids(m+1) have arrived (requested a macro
+    // ago) and give the addresses of the matrices / tip words of macro m+1; slots(m)
+    // have arrived too; ids(m+2) and slots(m+1) are requested.
+    Ids ia = load_ids(0), ib;
+    Slots sa = load_slots(0), sb;
+    int sha = __builtin_amdgcn_readfirstlane(ia.shape), shb = 0;
+    MacroMats ma = fetch_mats(ia, false), mb;
+    ib = load_ids(M > 1 ? 1 : 0);
+    for (int m = 0; m < M; m += 2) {
+      const Ops oa = load_ops(sha, sa, ma, false);
+      shb = __builtin_amdgcn_readfirstlane(ib.shape);
+      mb = fetch_mats(ib, false);
+      ia = load_ids(m + 2 < M ? m + 2 : M - 1);
+      sb = load_slots(m + 1 < M ? m + 1 : M - 1);
+      post_step(sha, sa, ma, oa);
+      if (m + 1 < M) {
+        const Ops ob = load_ops(shb, sb, mb, false);
+        sha = __builtin_amdgcn_readfirstlane(ia.shape);
+        ma = fetch_mats(ia, false);
+        ib = load_ids(m + 3 < M ? m + 3 : M - 1);
+        sa = load_slots(m + 2 < M ? m + 2 : M - 1);
+        post_step(shb, sb, mb, ob);
+      }
+    }
+  }
+  if (DBG & 128) return;
+  // ================= pre-order + edge derivatives =================
+  // The four sums of an edge pair (branch a, site a, branch b, site b) over the whole wave,
+  // on the matrix cores: with the lane sums s (state = hi, pattern = lo) as A operand,
+  //   D1[pattern][j] = sum_state s[state][pattern] * coef[state][j]     (coef: rate in column
+  //                    0 / 2, d rate in column 1 / 3 for edge a / b; accumulated over both)
+  //   D2[i][j]       = sum_pattern D1[pattern][j]                        (A = ones)
+  // leaves, in every block, quantity j in the lanes with lo = j; two DPP row shifts add the
+  // four blocks.  3 MFMA + 6 VALU instead of a 25-instruction cross-lane butterfly.
+  const double coef_a = lo == 0 ? rate_l : (lo == 1 ? drate_l : 0.0);
+  const double coef_b = lo == 2 ? rate_l : (lo == 3 ? drate_l : 0.0);
+  auto edge_sums = [&](const V& na, const V& nb, int m, int pos_a) {
+    // the pattern and category weights ride along in q (linear in the root vector)
+    double sa = na.v[0], sb = nb.v[0];
+#pragma unroll
+    for (int r = 1; r < R; r++) {
+      sa += na.v[r];
+      sb += nb.v[r];
+    }
+    double red;
+    if (DBG & 2) {
+      red = rate_l * sa + drate_l * sb;
+    } else {
+      double d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sa, coef_a, 0.0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sb, coef_b, d1, 0, 0, 0);
+      red = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, d1, 0.0, 0, 0, 0);
+      red = row_shr_add<4>(red);
+      red = row_shr_add<8>(red);
+    }
+    // lanes 12..15 (block 3 of row 0) hold branch a, site a, branch b, site b
+    if (lane >= 12 && lane < 16) {
+      char* dst = reinterpret_cast<char*>(gacc) + (unsigned)((m * kMacroPositions + pos_a) * 16);
+      *reinterpret_cast<double*>(dst + 8u * (unsigned)lo) = red;
+    }
+  };
+  // ---- analytic substitution gradient (SUBST) ----
+  // d logL = sum over edges, categories of <G, dP> with G = sum_p u L_c^T (u = q_parent o
+  // sibling product, carrying the pattern / category weights).  With P = V e^{L tau} V^-1:
+  // <G, dP> = <(V^T G V^-T) o Phi, V^-1 dQ V>, so one 4x4 per category,
+  //   H = sum_edges (V^T G V^-T) o Phi,
+  // accumulated in ONE register over the whole walk, is all the model gradient needs
+  // (subst_gradient_kernel finishes: dlogL/dQ = V^-T H V^T, chain rule to the
+  // parameters).  G is a matrix product over patterns, i.e. matrix-core work: operands
+  // are the 4x4-block transposes of u and L_c (lane (hi, lo) <-> (lo, hi)).
+  const int tr_lane = 16 * lo + 4 * b + hi;
+  auto blockT = [&](double x) { return __shfl(x, tr_lane, 64); };
+  const double AVt = SUBST ? model->V[hi * 4 + lo] : 0.0;     // A operand V^T: A[i][k] = V[k][i]
+  const double AVi = SUBST ? model->Vinv[lo * 4 + hi] : 0.0;  // A operand V^-1
+  double Ht = 0.0;  // (hi = i, lo = j) holds H^T[i][j] of this block's category
+  auto subst_stats = [&](const V& u, const V& Lc, double phi) {
+    double G = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      G = __builtin_amdgcn_mfma_f64_4x4x4f64(blockT(u.v[r]), blockT(Lc.v[r]), G, 0, 0, 0);
+    const double R1 = __builtin_amdgcn_mfma_f64_4x4x4f64(AVt, G, 0.0, 0, 0, 0);            // V^T G
+    const double R2 = __builtin_amdgcn_mfma_f64_4x4x4f64(AVi, blockT(R1), 0.0, 0, 0, 0);   // (V^T G V^-T)^T
+    Ht += R2 * phi;  // Phi is symmetric
+  };
+  auto pre_step = [&](int sh, const Slots& sl, const MacroMats& cm, const Ops& o, int m) {
+    const V& qv = o.q;
+    const V &La0 = o.x0, &Lb0 = o.y0, &La1 = o.x1, &Lb1 = o.y1;
+    V L0, L1, Ap0, Bp0, Ap1, Bp1;
+    if (kind0(sh) == 2) {
+      Ap0 = mm(cm.f[2], La0);
+      Bp0 = mm(cm.f[3], Lb0);
+      L0 = mul(Ap0, Bp0);
+    } else {
+      L0 = o.x0;
+    }
+    if (kind1(sh) == 2) {
+      Ap1 = mm(cm.f[4], La1);
+      Bp1 = mm(cm.f[5], Lb1);
+      L1 = mul(Ap1, Bp1);
+    } else {
+      L1 = o.x1;
+    }
+    const V A = mm(cm.f[0], L0), B = mm(cm.f[1], L1);
+    // Edge of child c below a node with pre-order vector q and sibling product S:
+    //   internal child: q_c = P_c^T (q o S), numerator q_c o (Q L_c), q_c kept if stored
+    //   tip child:      numerator (q o S) o ((P_c Q) L_c)  -- `trm` is then (P_c Q)
+    auto edge = [&](double trm, const V& qs, const V& Lc, bool tip, int slot, bool keep, V& qc,
+                    double phi) {
+      if (SUBST) subst_stats(qs, Lc, phi);
+      if (tip) return mul(qs, mm(trm, Lc));
+      qc = mm(trm, qs);
+      if (keep) store_slot(slot, qc);
+      return mul(qc, mm(AQ, Lc));
+    };
+    V q0, q1;
+    {
+      const V n0 = edge(cm.tr[0], mul(qv, B), L0, is_tip(sh, 0), sl.cs0, kind0(sh) == 1, q0,
+                        cm.ph[0]);
+      const V n1 = edge(cm.tr[1], mul(qv, A), L1, is_tip(sh, 1), sl.cs1, kind1(sh) == 1, q1,
+                        cm.ph[SUBST ? 1 : 0]);
+      edge_sums(n0, n1, m, 0);
+    }
+    if (kind0(sh) == 2) {
+      V qa, qb;
+      const V na = edge(cm.tr[2], mul(q0, Bp0), La0, is_tip(sh, 2), sl.gs0, true, qa,
+                        cm.ph[SUBST ? 2 : 0]);
+      const V nb = edge(cm.tr[3], mul(q0, Ap0), Lb0, is_tip(sh, 3), sl.gs1, true, qb,
+                        cm.ph[SUBST ? 3 : 0]);
+      edge_sums(na, nb, m, 2);
+    }
+    if (kind1(sh) == 2) {
+      V qa, qb;
+      const V na = edge(cm.tr[4], mul(q1, Bp1), La1, is_tip(sh, 4), sl.gs2, true, qa,
+                        cm.ph[SUBST ? 4 : 0]);
+      const V nb = edge(cm.tr[5], mul(q1, Ap1), Lb1, is_tip(sh, 5), sl.gs3, true, qb,
+                        cm.ph[SUBST ? 5 : 0]);
+      edge_sums(na, nb, m, 4);
+    }
+  };
+  {
+    Ids ia = load_ids(M - 1), ib;
+    Slots sa = load_slots(M - 1), sb;
+    int sha = __builtin_amdgcn_readfirstlane(ia.shape), shb = 0;
+    MacroMats ma = fetch_mats(ia, true), mb;
+    ib = load_ids(M > 1 ? M - 2 : 0);
+    for (int m = M - 1; m >= 0; m -= 2) {
+      const Ops oa = load_ops(sha, sa, ma, true);
+      shb = __builtin_amdgcn_readfirstlane(ib.shape);
+      mb = fetch_mats(ib, true);
+      ia = load_ids(m >= 2 ? m - 2 : 0);
+      sb = load_slots(m >= 1 ? m - 1 : 0);
+      pre_step(sha, sa, ma, oa, m);
+      if (m >= 1) {
+        const Ops ob = load_ops(shb, sb, mb, true);
+        sha = __builtin_amdgcn_readfirstlane(ia.shape);
+        ma = fetch_mats(ia, true);
+        ib = load_ids(m >= 3 ? m - 3 : 0);
+        sa = load_slots(m >= 2 ? m - 2 : 0);
+        pre_step(shb, sb, mb, ob, m - 1);
+      }
+    }
+  }
+  __syncthreads();
+  // positions that do not exist in a macro are never written nor read downstream
+  double* gout = a.g_part + ((size_t)gi * a.g_tiles + te.tile) * gwidth;
+  for (int i = lane; i < M * kMacroPositions * 2; i += kTile) gout[i] = gacc[i];
+  if (SUBST) {
+    gout[gwidth - kSubstExtra + lane] = Ht;
+    if (lane < 4) gout[gwidth - 4 + lane] = gacc[gwidth - 4 + lane];
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------
+// Launch wrappers
+// ------------------------------------------------------------------------
+void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t s) {
+  if (count <= 0) return;
+  const dim3 grid(a.tiles, count), block(kTile);
+  const bool tp = a.tip_partials != nullptr;
+  if (rescale) {
+    if (tp) hipLaunchKernelGGL((gradient_hbm_kernel<true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gradient_hbm_kernel<true, false>), grid, block, 0, s, a);
+  } else {
+    if (tp) hipLaunchKernelGGL((gradient_hbm_kernel<false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gradient_hbm_kernel<false, false>), grid, block, 0, s, a);
+  }
+}
+size_t gradient_mfma_lds_bytes(int n, int K, bool rescale, bool subst) {
+  const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
+  const size_t tip_bytes = (((size_t)n * 4 * (16 / kp) + 7) / 8) * 8;
+  size_t bytes = tip_bytes + sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile +
+                                               gradient_mfma_width(n, subst));
+  if (rescale) bytes += sizeof(int32_t) * (size_t)max_stored(n) * kLlR * (16 / kp);
+  const size_t reach = (size_t)(2 * n - 1) * 4 * (16 / kp);  // mask fetches of internal ids
+  return bytes > reach ? bytes : reach;
+}
+int gradient_mfma_width(int n, bool subst) {
+  return max_macros(n) * kMacroPositions * 2 + (subst ? kSubstExtra : 0);
+}
+int gradient_mfma_groups(int K) { return K <= 4 ? 1 : (K + 3) / 4; }
+bool gradient_mfma_fits(int n, int K, bool rescale) {
+  return n >= 3 && K <= kMaxCategories &&
+         gradient_mfma_lds_bytes(n, K, rescale, true) <= 160 * 1024;
+}
+template <bool RESCALE, bool SUBST>
+static void launch_gradient_mfma_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  allow_large_lds(reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR, 0, RESCALE, SUBST>),
+                  lds);
+  hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 0, RESCALE, SUBST>), grid, dim3(kTile), lds, s, a);
+}
+void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool subst,
+                          hipStream_t s) {
+  if (count <= 0) return;
+  LikArgs a = a_in;
+  a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
+  a.cat_groups = gradient_mfma_groups(a.K);
+  const size_t lds = gradient_mfma_lds_bytes(a.n, a.K, rescale, subst);
+  const dim3 grid(loglik_mfma_tiles(a.P, a.K) * a.cat_groups, count);
+  if (rescale || subst) {
+    if (rescale && subst) launch_gradient_mfma_variant<true, true>(a, grid, lds, s);
+    else if (rescale) launch_gradient_mfma_variant<true, false>(a, grid, lds, s);
+    else launch_gradient_mfma_variant<false, true>(a, grid, lds, s);
+    return;
+  }
+  // ablation builds: 1 no matrix products, 2 no cross-lane reductions,
+  // 8 no LDS vector traffic, 16 no matrix loads, 64 prologue only, 128 post-order only
+  static const int dbg = getenv("MI_PHYLO_DEBUG") ? atoi(getenv("MI_PHYLO_DEBUG")) : 0;
+  switch (dbg) {
+    case 1: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 1>), grid, dim3(kTile), lds, s, a); return;
+    case 2: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 2>), grid, dim3(kTile), lds, s, a); return;
+    case 8: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 8>), grid, dim3(kTile), lds, s, a); return;
+    case 16: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 16>), grid, dim3(kTile), lds, s, a); return;
+    case 27: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 27>), grid, dim3(kTile), lds, s, a); return;
+    case 64: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 64>), grid, dim3(kTile), lds, s, a); return;
+    case 128: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 128>), grid, dim3(kTile), lds, s, a); return;
+    default: break;
+  }
+  launch_gradient_mfma_variant<false, false>(a, grid, lds, s);
+}
+const char* gradient_kernel_name() { return "gradient_hbm_kernel"; }
+const char* gradient_mfma_kernel_name() { return "gradient_mfma_kernel"; }
+
+}  // namespace miphylo

@@ -1,0 +1,444 @@
+// Log-likelihood kernels: matrix-core (default) and VALU.
+// (gfx950 / CDNA4, wave64; see DESIGN.md for the mapping and what bounds each kernel.)
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <string>
+
+#include "mi_phylo_device_utils.h"
+#include "mi_phylo_kernels.h"
+
+namespace miphylo {
+
+namespace {
+using namespace dev;
+
+// ------------------------------------------------------------------------
+// On-chip log-likelihood (B5, B6, B11 of SURVEY.md 2.1).
+// One wave per (evaluation, 64-pattern tile); rate categories are walked one
+// after the other so that only floor(log2 n)+1 partial-likelihood vectors of one
+// category are live, each in a lane-private LDS column (SoA: [slot][state][lane],
+// conflict-free ds_read_b64 / ds_write_b64).  HBM traffic: tip states, the
+// schedule and the transition matrices only.
+// ------------------------------------------------------------------------
+template <bool RESCALE, bool TIP_PARTIALS>
+__global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const TileEval te = xcd_tile_eval();
+  const int tile = te.tile;
+  const int e = a.eval_offset + te.eval;
+  int t, mi;
+  a.map.decode(e, t, mi);
+  const DevModel* __restrict__ model = a.models + mi;
+  const SchedEntry* __restrict__ sched = a.sched + (size_t)t * (a.n - 1);
+  const int p = tile * kTile + lane;
+  const int pc = p < a.P ? p : a.P - 1;
+  const double w = p < a.P ? a.weights[pc] : 0.0;
+  const int K = a.K, n = a.n;
+  const double* __restrict__ mats_e = a.mats + (size_t)e * (a.N - 1) * K * 16;
+  const double* __restrict__ tabs_e = a.tip_tables + (size_t)e * n * K * 20;
+  // LDS: PLV columns [slot][state][lane] | this tile's tip states [taxon][lane]
+  int8_t* tips = reinterpret_cast<int8_t*>(lds + (size_t)a.lds_slots * 4 * kTile);
+  if (!TIP_PARTIALS) {
+    for (int i = 0; i < n; i++) tips[i * kTile + lane] = a.tip_states[(size_t)i * a.P + pc];
+  }
+  __syncthreads();
+
+  auto load_slot = [&](int slot) {
+    const double* c = lds + slot * 4 * kTile + lane;
+    return D4{c[0], c[kTile], c[2 * kTile], c[3 * kTile]};
+  };
+  // Addresses are "per-category base + 32-bit byte offset of the node": one scalar
+  // multiply per address instead of 64-bit index arithmetic (which was most of the
+  // scalar work of a visit).
+  const unsigned node_bytes = (unsigned)K * 128u, tab_bytes = (unsigned)K * 160u;
+  const char* mats_k = reinterpret_cast<const char*>(mats_e);  // advanced per category
+  const char* tabs_k = reinterpret_cast<const char*>(tabs_e);
+  auto mat = [&](int node) {
+    return as_const(reinterpret_cast<const double*>(
+        __builtin_assume_aligned(mats_k + (unsigned)node * node_bytes, 128)));
+  };
+  // What the tip children of a visit contribute is fetched one visit ahead:
+  // compact states -> one 32-byte gather from the tip table (column of P, no
+  // arithmetic); tip partials -> the partial vector itself.
+  struct TipPre {
+    D4 v[2];
+  };
+  auto fetch_tip = [&](const SchedEntry& s, int k) {
+    TipPre d;
+    const int c0 = s.child0 < n ? s.child0 : 0, c1 = s.child1 < n ? s.child1 : 0;
+    if (TIP_PARTIALS) {
+      d.v[0] = load4(a.tip_partials + ((size_t)c0 * a.P + pc) * 4);
+      d.v[1] = load4(a.tip_partials + ((size_t)c1 * a.P + pc) * 4);
+    } else {
+      const int st0 = tips[c0 * kTile + lane], st1 = tips[c1 * kTile + lane];
+      d.v[0] = load4(reinterpret_cast<const double*>(
+          tabs_k + ((unsigned)c0 * tab_bytes + (unsigned)st0 * 32u)));
+      d.v[1] = load4(reinterpret_cast<const double*>(
+          tabs_k + ((unsigned)c1 * tab_bytes + (unsigned)st1 * 32u)));
+    }
+    return d;
+  };
+  auto touch = [&](const SchedEntry& s, int k) {
+    const cint_ptr a0 = (cint_ptr)(uintptr_t)(mats_k + (unsigned)s.child0 * node_bytes);
+    const cint_ptr a1 = (cint_ptr)(uintptr_t)(mats_k + (unsigned)s.child1 * node_bytes);
+    return a0[0] ^ a0[16] ^ a1[0] ^ a1[16];
+  };
+  int touched = 0;
+
+  double site = 0.0;
+  int site_exp = 0;
+  for (int k = 0; k < K; k++, mats_k += 128, tabs_k += 160) {
+    int cum_exp = 0;
+    D4 L = {0, 0, 0, 0};
+    SchedEntry s_cur = sched[0];
+    SchedEntry s_nxt = sched[n > 2 ? 1 : 0];
+    TipPre td = fetch_tip(s_cur, k);
+    for (int i = 0; i < n - 1; i++) {
+      const SchedEntry s_nn = sched[i + 2 < n - 1 ? i + 2 : n - 2];
+      asm volatile("" ::"s"(touched));
+      touched = touch(s_nxt, k);
+      const TipPre tdn = fetch_tip(s_nxt, k);
+      const cdouble_ptr M0 = mat(s_cur.child0);
+      const cdouble_ptr M1 = mat(s_cur.child1);
+      const bool tip0 = s_cur.child0 < n, tip1 = s_cur.child1 < n;
+      // PLV columns are read unconditionally (slot 0 for a tip), before any branch
+      const D4 c0 = load_slot(tip0 ? 0 : (s_cur.slots >> 8) & 0xff);
+      const D4 c1 = load_slot(tip1 ? 0 : (s_cur.slots >> 16) & 0xff);
+      D4 A, B;
+      if (tip0) A = TIP_PARTIALS ? matvec(M0, td.v[0]) : td.v[0];
+      else A = matvec(M0, c0);
+      if (tip1) B = TIP_PARTIALS ? matvec(M1, td.v[1]) : td.v[1];
+      else B = matvec(M1, c1);
+      L = mul4(A, B);
+      if (RESCALE) {
+        const int ex = max_exponent(max4(L));
+        L = scale4(L, -ex);
+        cum_exp += ex;
+      }
+      double* dst = lds + (s_cur.slots & 0xff) * 4 * kTile + lane;
+      dst[0] = L.x0;
+      dst[kTile] = L.x1;
+      dst[2 * kTile] = L.x2;
+      dst[3 * kTile] = L.x3;
+      s_cur = s_nxt;
+      s_nxt = s_nn;
+      td = tdn;
+    }
+    // the last schedule entry is the root
+    const double sk = model->cat_weight[k] * (model->pi[0] * L.x0 + model->pi[1] * L.x1 +
+                                              model->pi[2] * L.x2 + model->pi[3] * L.x3);
+    if (RESCALE) {
+      if (k == 0) {
+        site = sk;
+        site_exp = cum_exp;
+      } else if (cum_exp > site_exp) {
+        site = ldexp(site, site_exp - cum_exp) + sk;
+        site_exp = cum_exp;
+      } else {
+        site += ldexp(sk, cum_exp - site_exp);
+      }
+    } else {
+      site += sk;
+    }
+  }
+  asm volatile("" ::"s"(touched));
+  if (!RESCALE && a.site_lik)
+    a.site_lik[((size_t)a.grad_offset + te.eval) * a.tiles * kTile + p] = site;
+  double ll = log(site);
+  if (RESCALE) ll += site_exp * 0.6931471805599453;
+  ll = p < a.P ? w * ll : 0.0;
+  ll = wave_sum(ll);
+  if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + tile] = ll;
+}
+
+// ------------------------------------------------------------------------
+// Log-likelihood on the FP64 matrix cores (v_mfma_f64_4x4x4_4b_f64).
+//
+// The instruction multiplies four independent 4x4 blocks: D_b = A_b * B_b.
+// Lane maps MEASURED on gfx950 (scratch probe): with lane =
+// 16*hi + 4*b + lo, A_b[i][k] sits at (hi = k, lo = i), B_b[k][j] at (hi = k,
+// lo = j) and D_b[i][j] at (hi = i, lo = j).  So a register holds, per lane, one
+// state (hi) of one of 16 "columns" (b, lo); a product D is already in the layout
+// the next product wants as B: partial-likelihood vectors flow from node to node
+// with no data movement.
+//   block b  = rate category (K = 4), or further pattern groups when K < 4
+//   A        = the child's transition matrices, one element per lane: ONE 8-byte
+//              load per lane fetches all categories' matrices (no SGPR traffic,
+//              trivially prefetched a visit ahead)
+//   R registers per node = R * 16/Kp site patterns per wave, all categories at once
+// Measured issue rate: 18 cycles per instruction from one wave, 9 with two waves
+// per SIMD (28 MAC/clk/SIMD, 1.8x the FP64 VALU peak), and the VALU stays free
+// for the element-wise products.
+// ------------------------------------------------------------------------
+template <int R, bool RESCALE>
+__global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
+  static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
+  const TileEval te = xcd_tile_eval();
+  const int e = a.eval_offset + te.eval;
+  int t, mi;
+  a.map.decode(e, t, mi);
+  const DevModel* __restrict__ model = a.models + mi;
+  const SchedEntry* __restrict__ sched = a.sched + (size_t)t * (a.n - 1);
+  const int K = a.K, n = a.n, Kp = a.kp;       // Kp in {1, 2, 4}: categories per instruction
+  const int cat = b % Kp, pgrp = b / Kp, ppr = 16 / Kp;  // ppr = patterns per register
+  // K > 4: the categories are walked four at a time (`groups` complete walks that only
+  // meet in the per-pattern site likelihood); the per-group lane constants follow
+  const int groups = Kp == 4 ? (K + 3) / 4 : 1;
+  const char* __restrict__ mats_e =
+      reinterpret_cast<const char*>(a.mats + (size_t)e * (a.N - 1) * K * 16);
+  unsigned a_off = 0;  // per-lane element of a child's matrix block: A_b[i = lo][k = hi] (bytes)
+  double wgt = 0.0;    // category weight x stationary frequency of this lane
+  const unsigned node_bytes = (unsigned)K * 128u;
+  const int TP = ppr * R, tile_start = te.tile * TP;
+  const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
+  int pat[R];
+  double pw[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    pat[r] = tile_start + r * ppr + col;
+    pw[r] = a.weights[pat[r] < a.P ? pat[r] : a.P - 1];
+  }
+  // LDS: tip state masks [taxon][column][r] (bit s: compatible with state s; first, so
+  // that the ignored mask fetch of an internal node id needs no clamping) | schedule |
+  // vectors [slot][r][lane]
+  uint8_t* tips = reinterpret_cast<uint8_t*>(lds);
+  SchedEntry* sched_l = reinterpret_cast<SchedEntry*>(lds + ((n * ppr * 4 + 7) >> 3));
+  double* plv = reinterpret_cast<double*>(sched_l + (n - 1));
+  for (int i = lane; i < n - 1; i += kTile) sched_l[i] = sched[i];
+  {
+    const int tp_shift = TP <= 16 ? 4 : (TP <= 32 ? 5 : 6);
+    const int q = lane & ((1 << tp_shift) - 1), group = 64 >> tp_shift;
+    const int ppr_shift = Kp == 4 ? 2 : (Kp == 2 ? 3 : 4);
+    const int r = q >> ppr_shift, c = q & (ppr - 1);
+    if (q < TP) {
+      const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
+      const uint8_t* src = a.tip_masks + pp;
+#pragma unroll 4
+      for (int taxon = lane >> tp_shift; taxon < n; taxon += group)
+        tips[(taxon * ppr + c) * 4 + r] = src[(size_t)taxon * a.P];
+    }
+  }
+  __syncthreads();
+
+  // What a visit needs from memory is requested kAhead visits before it is used (the
+  // schedule sits in LDS, so future visits' children are known): the two matrix
+  // registers, the two tip words, and the entry itself.  Child ids stay vector
+  // registers (multiplicands of per-lane addresses); the `slots` word, which also
+  // carries the two is-a-tip flags, is the only scalar.
+  constexpr int kAhead = 4;
+  struct Ahead {
+    double A0, A1;
+    uint32_t w0, w1;
+    int slots;
+  };
+  const unsigned lane8 = 8u * lane, col4 = 4u * col;
+  auto request = [&](int i) {
+    const SchedEntry sv = sched_l[i < n - 1 ? i : n - 2];
+    int c0 = sv.child0, c1 = sv.child1;
+    asm volatile("" : "+v"(c0), "+v"(c1));  // stay vector operands (see gradient_mfma_kernel)
+    Ahead h;
+    h.A0 = *reinterpret_cast<const double*>(mats_e + (__umul24((unsigned)c0, node_bytes) + a_off));
+    h.A1 = *reinterpret_cast<const double*>(mats_e + (__umul24((unsigned)c1, node_bytes) + a_off));
+    h.w0 = *reinterpret_cast<const uint32_t*>(tips + (__umul24((unsigned)c0, (unsigned)(ppr * 4)) + col4));
+    h.w1 = *reinterpret_cast<const uint32_t*>(tips + (__umul24((unsigned)c1, (unsigned)(ppr * 4)) + col4));
+    h.slots = sv.slots;
+    return h;
+  };
+  auto slot_ptr = [&](int slot) {
+    return reinterpret_cast<double*>(reinterpret_cast<char*>(plv) +
+                                     ((unsigned)slot * (unsigned)(R * kTile * 8) + lane8));
+  };
+  double L[R];
+  int esum[R];  // RESCALE: power-of-two exponents removed so far in this walk, per pattern
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    L[r] = 0.0;
+    esum[r] = 0;
+  }
+  auto visit = [&](int i, Ahead& h) {
+    const int slots = __builtin_amdgcn_readfirstlane(h.slots);
+    double B0[R], B1[R];
+    if (slots & (1 << 24)) {
+#pragma unroll
+      for (int r = 0; r < R; r++) B0[r] = (double)__builtin_amdgcn_ubfe(h.w0, (uint32_t)(8 * r + hi), 1u);
+    } else {
+      const double* src = slot_ptr((slots >> 8) & 0xff);
+#pragma unroll
+      for (int r = 0; r < R; r++) B0[r] = src[r * kTile];
+    }
+    if (slots & (1 << 25)) {
+#pragma unroll
+      for (int r = 0; r < R; r++) B1[r] = (double)__builtin_amdgcn_ubfe(h.w1, (uint32_t)(8 * r + hi), 1u);
+    } else {
+      const double* src = slot_ptr((slots >> 16) & 0xff);
+#pragma unroll
+      for (int r = 0; r < R; r++) B1[r] = src[r * kTile];
+    }
+    const double A0 = h.A0, A1 = h.A1;
+    h = request(i + kAhead);  // refill this ring slot
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const double D0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, B0[r], 0.0, 0, 0, 0);
+      const double D1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, B1[r], 0.0, 0, 0, 0);
+      L[r] = D0 * D1;
+      if (RESCALE) {
+        // exact per-pattern power-of-two rescaling (largest entry over states, categories)
+        double mx = L[r];
+        mx = fmax(mx, __shfl_xor(mx, 16, 64));
+        mx = fmax(mx, __shfl_xor(mx, 32, 64));
+        if (Kp >= 2) mx = fmax(mx, __shfl_xor(mx, 4, 64));
+        if (Kp >= 4) mx = fmax(mx, __shfl_xor(mx, 8, 64));
+        const int ex = mx > 0.0 ? ilogb(mx) : 0;
+        L[r] = ldexp(L[r], -ex);
+        esum[r] += ex;
+      }
+    }
+    double* dst = slot_ptr(slots & 0xff);
+#pragma unroll
+    for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
+  };
+  double site[R];
+  int site_exp[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    site[r] = 0.0;
+    site_exp[r] = 0;
+  }
+  for (int g = 0; g < groups; g++) {
+    const int cat_g = 4 * g + cat;
+    const int catc = cat_g < K ? cat_g : K - 1;  // padded category (weight 0) reads a valid matrix
+    a_off = 8u * (catc * 16 + lo * 4 + hi);
+    wgt = (cat_g < K ? model->cat_weight[cat_g] : 0.0) * model->pi[hi];
+    Ahead ring[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) ring[j] = request(j);
+#pragma unroll
+    for (int r = 0; r < R; r++) esum[r] = 0;
+    for (int i = 0; i < n - 1; i += kAhead) {
+#pragma unroll
+      for (int j = 0; j < kAhead; j++)
+        if (i + j < n - 1) visit(i + j, ring[j]);
+    }
+    // root: this group's share of the site likelihood = sum over its categories (blocks)
+    // and the states (hi) of cw * pi * L; every lane of a pattern ends up with the sum
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      double v = wgt * L[r];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (Kp >= 2) v += __shfl_xor(v, 4, 64);
+      if (Kp >= 4) v += __shfl_xor(v, 8, 64);
+      if (!RESCALE) {
+        site[r] += v;
+      } else if (g == 0) {
+        site[r] = v;
+        site_exp[r] = esum[r];
+      } else if (esum[r] > site_exp[r]) {
+        site[r] = ldexp(site[r], site_exp[r] - esum[r]) + v;
+        site_exp[r] = esum[r];
+      } else {
+        site[r] += ldexp(v, esum[r] - site_exp[r]);
+      }
+    }
+  }
+  double ll = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const bool owner = hi == 0 && cat == 0 && pat[r] < a.P;  // one lane per pattern
+    if (owner) {
+      if (a.site_lik) {
+        // per-pattern site likelihood for a following gradient pass (rescaled: the
+        // mantissa here, the power of two in site_exp)
+        const size_t at = ((size_t)a.grad_offset + te.eval) * a.tiles * kTile + pat[r];
+        a.site_lik[at] = site[r];
+        if (RESCALE) a.site_exp[at] = site_exp[r];
+      }
+      ll += pw[r] * (RESCALE ? log(site[r]) + site_exp[r] * 0.69314718055994530942 : log(site[r]));
+    }
+  }
+  ll = wave_sum(ll);
+  if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------
+// Launch wrappers
+// ------------------------------------------------------------------------
+// which log-likelihood kernel runs by default when both can (measured)
+constexpr bool kLoglikMfmaDefault = true;
+static size_t loglik_mfma_lds_bytes(int n, int K, int max_slots) {
+  const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
+  const size_t tip_bytes = (((size_t)n * 4 * (16 / kp) + 7) / 8) * 8;
+  const size_t bytes = tip_bytes + sizeof(SchedEntry) * (size_t)(n - 1) +
+                       sizeof(double) * (size_t)max_slots * kLlR * kTile;
+  const size_t reach = (size_t)(2 * n - 1) * 4 * (16 / kp);  // mask fetches of internal ids
+  return bytes > reach ? bytes : reach;
+}
+int loglik_mfma_tiles(int P, int K) {
+  const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
+  const int per_wave = kLlR * (16 / kp);
+  return (P + per_wave - 1) / per_wave;
+}
+bool loglik_mfma_supported(const LikArgs& a, bool rescale) {
+  // The matrix-core log-likelihood kernel needs tips in state-mask form (K > 4: the
+  // categories are walked four at a time).  MI_PHYLO_LOGLIK_PATH=valu|mfma forces one of the two kernels.
+  static const int forced = [] {
+    const char* env = getenv("MI_PHYLO_LOGLIK_PATH");
+    if (!env) return 0;
+    return std::string(env) == "mfma" ? 2 : (std::string(env) == "valu" ? 1 : 0);
+  }();
+  (void)rescale;
+  const bool possible = a.K <= kMaxCategories && a.tip_masks != nullptr;
+  if (forced == 1) return false;
+  if (forced == 2) return possible;
+  return possible && kLoglikMfmaDefault;
+}
+static bool use_loglik_mfma(const LikArgs& a, bool rescale, int max_slots) {
+  return loglik_mfma_supported(a, rescale) &&
+         loglik_mfma_lds_bytes(a.n, a.K, max_slots) <= 160 * 1024;
+}
+static void launch_loglik_mfma(const LikArgs& a_in, int count, bool rescale, int max_slots,
+                               hipStream_t s) {
+  LikArgs a = a_in;
+  a.lds_slots = max_slots;
+  a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
+  const dim3 grid(loglik_mfma_tiles(a.P, a.K), count), block(kTile);
+  const size_t lds = loglik_mfma_lds_bytes(a.n, a.K, max_slots);
+  if (rescale) {
+    allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLlR, true>), lds);
+    hipLaunchKernelGGL((loglik_mfma_kernel<kLlR, true>), grid, block, lds, s, a);
+  } else {
+    allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLlR, false>), lds);
+    hipLaunchKernelGGL((loglik_mfma_kernel<kLlR, false>), grid, block, lds, s, a);
+  }
+}
+void launch_loglik(const LikArgs& a_in, int count, bool rescale, int max_slots, hipStream_t s) {
+  if (count <= 0) return;
+  if (use_loglik_mfma(a_in, rescale, max_slots)) {
+    launch_loglik_mfma(a_in, count, rescale, max_slots, s);
+    return;
+  }
+  LikArgs a = a_in;
+  a.lds_slots = max_slots;
+  const dim3 grid(a.tiles, count), block(kTile);
+  const size_t lds = (size_t)max_slots * 4 * kTile * sizeof(double) + (size_t)a.n * kTile;
+  const bool tp = a.tip_partials != nullptr;
+  if (rescale) {
+    if (tp) hipLaunchKernelGGL((loglik_onchip_kernel<true, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((loglik_onchip_kernel<true, false>), grid, block, lds, s, a);
+  } else {
+    if (tp) hipLaunchKernelGGL((loglik_onchip_kernel<false, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((loglik_onchip_kernel<false, false>), grid, block, lds, s, a);
+  }
+}
+const char* loglik_kernel_name(const LikArgs& a, bool rescale, int max_slots) {
+  return use_loglik_mfma(a, rescale, max_slots) ? "loglik_mfma_kernel" : "loglik_onchip_kernel";
+}
+
+}  // namespace miphylo

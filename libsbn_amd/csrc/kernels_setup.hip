@@ -1,0 +1,853 @@
+// Per-call set-up kernels: tree schedules, model eigensystems, transition matrices.
+// (gfx950 / CDNA4, wave64; see DESIGN.md for the mapping and what bounds each kernel.)
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <string>
+
+#include "mi_phylo_device_utils.h"
+#include "mi_phylo_kernels.h"
+
+namespace miphylo {
+
+namespace {
+using namespace dev;
+
+// ------------------------------------------------------------------------
+// Tree setup: parent-id vector -> evaluation schedule (one thread per tree).
+// Restates node.cpp:32-59 (children ordered by max leaf id),
+// unrooted_tree.cpp:27-37 (Detrifurcate), tree.cpp:72-78 (SlideRootPosition, a
+// no-op on a detrifurcated tree), fat_beagle.cpp:96-101,507-511 (x rates).
+// The schedule lists internal nodes in a post-order chosen by Sethi-Ullman
+// labels so that the on-chip kernel needs at most floor(log2 n)+1 live
+// partial-likelihood vectors; any post-order gives bitwise the same vectors.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
+  // One wave per tree.  The walk itself is sequential (lane 0); its working set
+  // lives in LDS (13 N ints) unless the tree is too large, and the bulk copies
+  // (branch lengths, schedule) are done by all 64 lanes.
+  extern __shared__ int32_t ts_lds[];
+  const int t = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int n = a.n, N = 2 * n - 1;
+  const int nodes_in = a.rooted ? N : N - 1;
+  const int32_t* par_in = a.parent_ids + (size_t)t * (nodes_in - 1);
+  int32_t* maxleaf = a.use_lds ? ts_lds : a.scratch + (size_t)t * 13 * N;
+  int32_t* cnt = maxleaf + N;
+  int32_t* kids = cnt + N;  // 3 per node
+  int32_t* c0 = kids + 3 * N;
+  int32_t* c1 = c0 + N;
+  int32_t* label = c1 + N;
+  int32_t* slot = label + N;
+  int32_t* stack = slot + N;  // 2N
+  int32_t* par = stack + 2 * N;  // the parent ids, fetched by the whole wave at once
+  __shared__ int ok_flag;
+  SchedEntry* sched = a.sched + (size_t)t * (n - 1);
+  double* ble = a.bl_eff + (size_t)t * N;
+
+  for (int v = lane; v < N; v += 64) {
+    maxleaf[v] = v < n ? v : -1;
+    cnt[v] = 0;
+    label[v] = 0;
+    slot[v] = 0;
+    c0[v] = c1[v] = 0;
+    if (v < nodes_in - 1) par[v] = par_in[v];
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int status = kOk;
+    for (int v = 0; v < nodes_in - 1; v++) {
+      const int p = par[v];
+      if (p <= v || p >= nodes_in || p < n) {
+        status = kBadParentIds;
+        break;
+      }
+      if (maxleaf[v] > maxleaf[p]) maxleaf[p] = maxleaf[v];
+    }
+    for (int v = 0; v < nodes_in - 1 && status == kOk; v++) {
+      const int p = par[v];
+      int k = cnt[p];
+      if (k >= 3) {
+        status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
+        break;
+      }
+      while (k > 0 && maxleaf[kids[3 * p + k - 1]] > maxleaf[v]) {
+        kids[3 * p + k] = kids[3 * p + k - 1];
+        k--;
+      }
+      kids[3 * p + k] = v;
+      cnt[p]++;
+    }
+    const int root_in = nodes_in - 1;
+    for (int v = n; v < nodes_in && status == kOk; v++) {
+      const int want = (!a.rooted && v == root_in) ? 3 : 2;
+      if (cnt[v] != want) status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
+    }
+    if (status == kOk) {
+      for (int v = n; v < nodes_in; v++) {
+        c0[v] = kids[3 * v];
+        c1[v] = kids[3 * v + 1];
+      }
+      if (!a.rooted) {
+        // (k0,k1,k2) at root r  ->  r = (k1,k2), r+1 = (k0, r)
+        const int r = root_in;
+        c0[r] = kids[3 * r + 1];
+        c1[r] = kids[3 * r + 2];
+        c0[r + 1] = kids[3 * r];
+        c1[r + 1] = r;
+      }
+      // Sethi-Ullman labels (tips cost nothing: they are read in compact form).
+      for (int v = n; v < N; v++) {
+        const int l0 = label[c0[v]], l1 = label[c1[v]];
+        label[v] = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
+      }
+      // Post-order DFS, heavier child first; slots from a free bitmask.
+      uint32_t free_mask = 0xffffffffu;
+      int top = 0, out = 0;
+      stack[top++] = (N - 1) << 1;
+      int used_max = 0;
+      while (top) {
+        const int item = stack[--top];
+        const int v = item >> 1;
+        if (item & 1) {
+          const int a0 = c0[v], a1 = c1[v];
+          if (a0 >= n) free_mask |= 1u << slot[a0];
+          if (a1 >= n) free_mask |= 1u << slot[a1];
+          const int sl = __ffs(free_mask) - 1;
+          free_mask &= ~(1u << sl);
+          slot[v] = sl;
+          if (sl + 1 > used_max) used_max = sl + 1;
+          sched[out++] = {v, a0, a1, sl | (slot[a0] << 8) | (slot[a1] << 16) |
+                                        ((a0 < n ? 1 : 0) << 24) | ((a1 < n ? 1 : 0) << 25)};
+        } else {
+          stack[top++] = (v << 1) | 1;
+          const int a0 = c0[v], a1 = c1[v];
+          const bool first0 = label[a0] >= label[a1];
+          const int lo = first0 ? a1 : a0, hi = first0 ? a0 : a1;
+          if (lo >= n) stack[top++] = lo << 1;
+          if (hi >= n) stack[top++] = hi << 1;  // popped first
+        }
+      }
+      if (used_max > a.max_slots) status = kTooManySlots;
+      // ---- schedule of the on-chip gradient kernel ----
+      // A non-root internal node is UNSTORED (2) when all its internal children are
+      // stored, else STORED (1): every stored node then has an unstored child, so at
+      // most (n-2)/2 nodes need an LDS slot; an unstored node's vector is
+      // recomputed from its (stored or tip) children where it is needed.
+      if (a.macros) {
+        int32_t* cls = cnt;
+        int32_t* sslot = maxleaf;
+        int stored = 0;
+        for (int v = n; v < N - 1; v++) {
+          const int a0 = c0[v], a1 = c1[v];
+          const bool unstored = (a0 < n || cls[a0] == 1) && (a1 < n || cls[a1] == 1);
+          cls[v] = unstored ? 2 : 1;
+          sslot[v] = unstored ? 0 : stored++;
+        }
+        cls[N - 1] = 1;
+        sslot[N - 1] = -1;
+        MacroEntry* mac = a.macros + (size_t)t * max_macros(n);
+        int m = 0;
+        for (int v = n; v < N; v++) {
+          if (cls[v] != 1) continue;
+          MacroEntry me;
+          int kind[2];
+          me.node = v;
+          me.pad = 0;
+          me.qslot = sslot[v];
+          for (int j = 0; j < 2; j++) {
+            const int ch = j ? c1[v] : c0[v];
+            me.child[j] = ch;
+            kind[j] = ch < n ? 0 : cls[ch];
+            me.cslot[j] = (ch >= n && cls[ch] == 1) ? sslot[ch] : 0;
+            const bool expand = ch >= n && cls[ch] == 2;
+            const int ga = expand ? c0[ch] : 0, gb = expand ? c1[ch] : 0;
+            me.grand[2 * j] = ga;
+            me.grand[2 * j + 1] = gb;
+            me.gslot[2 * j] = ga >= n ? sslot[ga] : 0;
+            me.gslot[2 * j + 1] = gb >= n ? sslot[gb] : 0;
+          }
+          me.shape = macro_shape(kind[0], kind[1], v == N - 1, me.child, me.grand, n);
+          mac[m++] = me;
+        }
+        a.macro_count[t] = m;
+        if (stored > max_stored(n)) status = kTooManySlots;
+      }
+    }
+    if (status != kOk) set_status(a.status, status, t);
+    ok_flag = status == kOk || status == kTooManySlots;
+  }
+  __syncthreads();
+  if (!ok_flag) {
+    if (lane == 0 && a.macro_count) a.macro_count[t] = 0;
+    for (int i = lane; i < n - 1; i += 64) sched[i] = {n + i, 0, 1, 0};
+    for (int v = lane; v < N; v += 64) ble[v] = 0.0;
+    return;
+  }
+  if (!a.rooted) {
+    const double* bl = a.bl + (size_t)t * (N - 1);
+    for (int v = lane; v < N; v += 64) ble[v] = v < N - 2 ? bl[v] : 0.0;
+  } else {
+    const double* bl = a.bl + (size_t)t * N;
+    const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
+    for (int v = lane; v < N; v += 64)
+      ble[v] = (rates && v < N - 1) ? bl[v] * rates[v] : bl[v];
+  }
+}
+
+// ------------------------------------------------------------------------
+// Tree setup for N <= 64 nodes: the same walk with every per-node array held in ONE
+// vector register (lane = node id) and indexed with v_readlane / v_writelane.  The walk
+// is sequential and its cost is the latency of each dependent array access: a
+// cross-lane read is an order of magnitude quicker than an LDS round trip.  All
+// values are wave-uniform, so control flow is scalar.
+// ------------------------------------------------------------------------
+#define RDL(arr, i) __builtin_amdgcn_readlane((arr), (i))
+#define WRL(arr, i, val) (arr) = (lane == (i)) ? (val) : (arr)
+// A per-node array of up to NB * 64 entries held in NB vector registers: entry i lives in
+// lane i % 64 of register i / 64.  `rd` reads an entry with a wave-uniform index (two or
+// four v_readlane and scalar selects, no branch), `own(nb)` is the node id this lane holds
+// in register nb.
+template <int NB>
+struct NodeArray {
+  int r[NB];
+  __device__ __forceinline__ void fill(int v) {
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) r[nb] = v;
+  }
+  __device__ __forceinline__ int rd(int i) const {
+    int out = __builtin_amdgcn_readlane(r[0], i & 63);
+#pragma unroll
+    for (int nb = 1; nb < NB; nb++) {
+      const int x = __builtin_amdgcn_readlane(r[nb], i & 63);
+      out = (i >> 6) == nb ? x : out;
+    }
+    return out;
+  }
+  // lane-varying index (gather): every lane reads entry idx
+  __device__ __forceinline__ int gather(int idx) const {
+    int out = __shfl(r[0], idx & 63, 64);
+#pragma unroll
+    for (int nb = 1; nb < NB; nb++) {
+      const int x = __shfl(r[nb], idx & 63, 64);
+      out = (idx >> 6) == nb ? x : out;
+    }
+    return out;
+  }
+};
+
+template <int NB>
+__global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
+  // Branch-free by construction: the tree walks are dependent chains, and on this machine
+  // a taken scalar branch costs more than the handful of instructions it would skip, so
+  // every loop body is straight-line code (lane selects / scalar selects) and whatever can
+  // be done by all lanes at once (child lists, sorting, the macro entries) is.
+  using Arr = NodeArray<NB>;
+  const int t = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int n = a.n, N = 2 * n - 1;
+  const int nodes_in = a.rooted ? N : N - 1;
+  const int root_in = nodes_in - 1;
+  const int32_t* par_in = a.parent_ids + (size_t)t * (nodes_in - 1);
+  SchedEntry* sched = a.sched + (size_t)t * (n - 1);
+  double* ble = a.bl_eff + (size_t)t * N;
+  auto own = [&](int nb) { return lane + 64 * nb; };
+
+  Arr par, maxleaf;
+  int status = kOk;
+  bool bad_parent = false;
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) {
+    const int v = own(nb);
+    par.r[nb] = v < nodes_in - 1 ? par_in[v] : -1;
+    maxleaf.r[nb] = v < n ? v : -1;
+    bad_parent |= v < nodes_in - 1 && (par.r[nb] <= v || par.r[nb] >= nodes_in || par.r[nb] < n);
+  }
+  if (__any(bad_parent)) status = kBadParentIds;
+
+  // max leaf id below every node, bottom-up (ids are a post-order: children first)
+  if (status == kOk)
+    for (int v = 0; v < nodes_in - 1; v++) {
+      const int p = par.rd(v), mv = maxleaf.rd(v);
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++)
+        maxleaf.r[nb] = (own(nb) == p && mv > maxleaf.r[nb]) ? mv : maxleaf.r[nb];
+    }
+  // every lane collects the children (at most three) of the nodes it holds, ascending max
+  // leaf id, by looking at each node once
+  Arr cnt, k0, k1, k2, m0, m1;
+  cnt.fill(0); k0.fill(0); k1.fill(0); k2.fill(0); m0.fill(0); m1.fill(0);
+  if (status == kOk)
+    for (int v = 0; v < nodes_in - 1; v++) {
+      const int p = par.rd(v), mv = maxleaf.rd(v);
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const bool mine = own(nb) == p;
+        const int c = cnt.r[nb];
+        // sorted insert of (v, mv) into (k0 | m0), (k1 | m1), k2; equal keys cannot occur
+        // (disjoint leaf sets)
+        const bool lt0 = c >= 1 && m0.r[nb] > mv, lt1 = c >= 2 && m1.r[nb] > mv;
+        const int n0 = c == 0 || lt0 ? v : k0.r[nb];
+        const int n1 = c == 0 ? k1.r[nb] : (lt0 ? k0.r[nb] : (c == 1 || lt1 ? v : k1.r[nb]));
+        const int n2 = c < 2 ? k2.r[nb] : (lt1 ? k1.r[nb] : v);
+        const int nm0 = c == 0 || lt0 ? mv : m0.r[nb];
+        const int nm1 = c == 0 ? m1.r[nb] : (lt0 ? m0.r[nb] : (c == 1 || lt1 ? mv : m1.r[nb]));
+        k0.r[nb] = mine ? n0 : k0.r[nb];
+        k1.r[nb] = mine ? n1 : k1.r[nb];
+        k2.r[nb] = (mine && c <= 2) ? n2 : k2.r[nb];
+        m0.r[nb] = mine ? nm0 : m0.r[nb];
+        m1.r[nb] = mine ? nm1 : m1.r[nb];
+        cnt.r[nb] += mine ? 1 : 0;
+      }
+    }
+  if (status == kOk) {
+    bool wrong = false;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const int v = own(nb);
+      const int want = (!a.rooted && v == root_in) ? 3 : 2;
+      wrong |= v >= n && v < nodes_in && cnt.r[nb] != want;
+    }
+    if (__any(wrong)) status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
+  }
+  Arr c0, c1;
+  c0.fill(0);
+  c1.fill(0);
+  // schedule, entry i in lane i % 64 of register i / 64
+  Arr s_node, s_c0, s_c1, s_sl;
+  s_node.fill(0); s_c0.fill(0); s_c1.fill(0); s_sl.fill(0);
+  int macro_total = 0, stored_total = 0;
+  MacroEntry me[NB];
+  bool is_macro[NB];
+  int macro_rank[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) {
+    me[nb] = MacroEntry{};
+    is_macro[nb] = false;
+    macro_rank[nb] = 0;
+  }
+  if (status == kOk) {
+    const int kr0 = a.rooted ? 0 : k0.rd(root_in);
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const int v = own(nb);
+      if (v >= n && v < nodes_in) {
+        c0.r[nb] = k0.r[nb];
+        c1.r[nb] = k1.r[nb];
+      }
+      if (!a.rooted) {
+        // (k0,k1,k2) at root r  ->  r = (k1,k2), r+1 = (k0, r)
+        if (v == root_in) {
+          c0.r[nb] = k1.r[nb];
+          c1.r[nb] = k2.r[nb];
+        }
+        if (v == root_in + 1) {
+          c0.r[nb] = kr0;
+          c1.r[nb] = root_in;
+        }
+      }
+    }
+    if (!a.need_slots) {
+      // only the matrix-core gradient kernel and finalize will read this tree: the
+      // node-id order (already a post-order) with no slot assignment is enough
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const int node = n + own(nb);
+        s_node.r[nb] = node;
+        s_c0.r[nb] = c0.gather(node < N ? node : 0);
+        s_c1.r[nb] = c1.gather(node < N ? node : 0);
+      }
+    } else {
+      // Sethi-Ullman labels and internal-subtree sizes, bottom-up (tips cost nothing)
+      Arr label, size;
+      label.fill(0);
+      size.fill(0);
+      for (int v = n; v < N; v++) {
+        const int a0 = c0.rd(v), a1 = c1.rd(v);
+        const int l0 = label.rd(a0), l1 = label.rd(a1);
+        const int sz = 1 + size.rd(a0) + size.rd(a1);
+        const int lb = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+          label.r[nb] = own(nb) == v ? lb : label.r[nb];
+          size.r[nb] = own(nb) == v ? sz : size.r[nb];
+        }
+      }
+      // position in the post-order that visits the heavier child first: top-down, a
+      // node's subtree occupies [start, start + size), the node itself comes last
+      Arr first, second, size_first, start;
+      start.fill(0);
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const int lab0 = label.gather(c0.r[nb]), lab1 = label.gather(c1.r[nb]);
+        const bool first0 = lab0 >= lab1;
+        first.r[nb] = first0 ? c0.r[nb] : c1.r[nb];
+        second.r[nb] = first0 ? c1.r[nb] : c0.r[nb];
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) size_first.r[nb] = size.gather(first.r[nb]);
+      // (the same loop fills node_at[position] = node)
+      Arr node_at;
+      node_at.fill(0);
+      for (int v = N - 1; v >= n; v--) {
+        const int st = start.rd(v), f = first.rd(v), sc = second.rd(v), sf = size_first.rd(v);
+        const int pos = st + size.rd(v) - 1;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+          start.r[nb] = own(nb) == f ? st : (own(nb) == sc ? st + sf : start.r[nb]);
+          node_at.r[nb] = own(nb) == pos ? v : node_at.r[nb];
+        }
+      }
+      // LDS slots in schedule order from a free bitmask
+      Arr slot;
+      slot.fill(0);
+      uint32_t free_mask = 0xffffffffu;
+      int used_max = 0;
+      for (int out = 0; out < n - 1; out++) {
+        const int v = node_at.rd(out);
+        const int a0 = c0.rd(v), a1 = c1.rd(v);
+        const int sa0 = slot.rd(a0), sa1 = slot.rd(a1);
+        free_mask |= (a0 >= n ? 1u << sa0 : 0u) | (a1 >= n ? 1u << sa1 : 0u);
+        const int sl = __ffs(free_mask) - 1;
+        free_mask &= ~(1u << sl);
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) slot.r[nb] = own(nb) == v ? sl : slot.r[nb];
+        used_max = sl + 1 > used_max ? sl + 1 : used_max;
+      }
+      if (used_max > a.max_slots) status = kTooManySlots;
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const int node = node_at.r[nb];
+        const int ch0 = c0.gather(node), ch1 = c1.gather(node);
+        s_node.r[nb] = node;
+        s_c0.r[nb] = ch0;
+        s_c1.r[nb] = ch1;
+        s_sl.r[nb] = slot.gather(node) | (slot.gather(ch0) << 8) | (slot.gather(ch1) << 16) |
+                     ((ch0 < n ? 1 : 0) << 24) | ((ch1 < n ? 1 : 0) << 25);
+      }
+    }
+    // ---- schedule of the on-chip gradient kernel (see tree_setup_kernel) ----
+    if (a.macros) {
+      // stored (1) / unstored (2) classes, bottom-up
+      Arr cls;
+      cls.fill(0);
+      for (int v = n; v < N - 1; v++) {
+        const int a0 = c0.rd(v), a1 = c1.rd(v);
+        const int k0c = cls.rd(a0), k1c = cls.rd(a1);
+        const bool unstored = (a0 < n || k0c == 1) && (a1 < n || k1c == 1);
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) cls.r[nb] = own(nb) == v ? (unstored ? 2 : 1) : cls.r[nb];
+      }
+      Arr sslot;
+      int stored_before = 0, macros_before = 0;
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const int v = own(nb);
+        cls.r[nb] = v == N - 1 ? 1 : cls.r[nb];
+        const bool internal = v >= n && v < N;
+        const bool stored = internal && cls.r[nb] == 1 && v != N - 1;
+        const uint64_t stored_mask = __ballot(stored);
+        const uint64_t macro_mask = __ballot(internal && cls.r[nb] == 1);
+        const uint64_t below = (1ull << lane) - 1;
+        // slots and macro indices in node-id order
+        sslot.r[nb] = v == N - 1 ? -1 : stored_before + __popcll(stored_mask & below);
+        is_macro[nb] = internal && cls.r[nb] == 1;
+        macro_rank[nb] = macros_before + __popcll(macro_mask & below);
+        stored_before += __popcll(stored_mask);
+        macros_before += __popcll(macro_mask);
+      }
+      stored_total = stored_before;
+      macro_total = macros_before;
+      // every lane that owns a macro assembles it from its children's lanes (cross-lane
+      // reads stay outside lane-dependent conditions: an inactive source lane reads as 0)
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        int kind[2];
+        me[nb].node = own(nb);
+        me[nb].pad = 0;
+        me[nb].qslot = sslot.r[nb];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int ch = j ? c1.r[nb] : c0.r[nb];
+          const int cls_ch = cls.gather(ch), chs = sslot.gather(ch);
+          const int ga_ = c0.gather(ch), gb_ = c1.gather(ch);
+          const int cc = ch >= n ? cls_ch : 0;
+          me[nb].child[j] = ch;
+          kind[j] = cc;
+          me[nb].cslot[j] = cc == 1 ? chs : 0;
+          const bool expand = cc == 2;
+          const int ga = expand ? ga_ : 0, gb = expand ? gb_ : 0;
+          const int gas = sslot.gather(ga), gbs = sslot.gather(gb);
+          me[nb].grand[2 * j] = ga;
+          me[nb].grand[2 * j + 1] = gb;
+          me[nb].gslot[2 * j] = ga >= n ? gas : 0;
+          me[nb].gslot[2 * j + 1] = gb >= n ? gbs : 0;
+        }
+        me[nb].shape =
+            macro_shape(kind[0], kind[1], own(nb) == N - 1, me[nb].child, me[nb].grand, n);
+      }
+      if (stored_total > max_stored(n)) status = kTooManySlots;
+    }
+  }
+  if (status != kOk && lane == 0) set_status(a.status, status, t);
+  const bool ok = status == kOk || status == kTooManySlots;
+  if (!ok) {
+    if (lane == 0 && a.macro_count) a.macro_count[t] = 0;
+    for (int i = lane; i < n - 1; i += 64) sched[i] = {n + i, 0, 1, 0};
+    for (int v = lane; v < N; v += 64) ble[v] = 0.0;
+    return;
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++)
+    if (own(nb) < n - 1) sched[own(nb)] = {s_node.r[nb], s_c0.r[nb], s_c1.r[nb], s_sl.r[nb]};
+  if (a.macros) {
+    MacroEntry* mac = a.macros + (size_t)t * max_macros(n);
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+      if (is_macro[nb]) mac[macro_rank[nb]] = me[nb];
+    if (lane == 0) a.macro_count[t] = macro_total;
+  }
+  if (!a.rooted) {
+    const double* bl = a.bl + (size_t)t * (N - 1);
+    for (int v = lane; v < N; v += 64) ble[v] = v < N - 2 ? bl[v] : 0.0;
+  } else {
+    const double* bl = a.bl + (size_t)t * N;
+    const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
+    for (int v = lane; v < N; v += 64) ble[v] = (rates && v < N - 1) ? bl[v] * rates[v] : bl[v];
+  }
+}
+#undef RDL
+#undef WRL
+
+// ------------------------------------------------------------------------
+// Model setup (one thread per model instance).
+// ------------------------------------------------------------------------
+__device__ void jacobi4(const double* A_in, double* evals, double* U) {
+  double A[16];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) A[i * 4 + j] = i >= j ? A_in[i * 4 + j] : A_in[j * 4 + i];
+  for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        const double x = A[i * 4 + j] * A[i * 4 + j];
+        if (i != j) off += x; else diag += x;
+      }
+    if (off <= 1e-40 * diag || off == 0.) break;
+    for (int p = 0; p < 3; p++)
+      for (int q = p + 1; q < 4; q++) {
+        const double apq = A[p * 4 + q];
+        if (apq == 0.) continue;
+        const double theta = (A[q * 4 + q] - A[p * 4 + p]) / (2. * apq);
+        const double tt = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+        const double c = 1. / sqrt(tt * tt + 1.), sn = tt * c;
+        for (int k = 0; k < 4; k++) {
+          const double akp = A[k * 4 + p], akq = A[k * 4 + q];
+          A[k * 4 + p] = c * akp - sn * akq;
+          A[k * 4 + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < 4; k++) {
+          const double apk = A[p * 4 + k], aqk = A[q * 4 + k];
+          A[p * 4 + k] = c * apk - sn * aqk;
+          A[q * 4 + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < 4; k++) {
+          const double ukp = U[k * 4 + p], ukq = U[k * 4 + q];
+          U[k * 4 + p] = c * ukp - sn * ukq;
+          U[k * 4 + q] = sn * ukp + c * ukq;
+        }
+      }
+  }
+  for (int i = 0; i < 4; i++) evals[i] = A[i * 4 + i];
+  for (int i = 0; i < 3; i++) {
+    int m = i;
+    for (int j = i + 1; j < 4; j++)
+      if (evals[j] < evals[m]) m = j;
+    if (m != i) {
+      const double tmp = evals[i]; evals[i] = evals[m]; evals[m] = tmp;
+      for (int k = 0; k < 4; k++) {
+        const double u = U[k * 4 + i]; U[k * 4 + i] = U[k * 4 + m]; U[k * 4 + m] = u;
+      }
+    }
+  }
+}
+
+// stick_breaking_transform.cpp:20-43
+__device__ void stick_breaking(int K, const double* y, double* x) {
+  double stick = 1.0;
+  for (int k = 0; k < K - 1; k++) {
+    const double z = 1.0 / (1 + exp(-(y[k] - log((double)(K - k - 1)))));
+    x[k] = stick * z;
+    stick -= x[k];
+  }
+  x[K - 1] = stick;
+}
+__device__ void stick_breaking_inverse(int K, const double* x, double* y) {
+  double sum = 0;
+  for (int k = 0; k < K - 1; k++) {
+    const double z = x[k] / (1.0 - sum);
+    y[k] = log(z / (1.0 - z)) + log((double)(K - k - 1));
+    sum += x[k];
+  }
+}
+
+__global__ void model_setup_kernel(ModelSetupArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.T * a.models_per_tree) return;
+  const int t = idx / a.models_per_tree, j = idx % a.models_per_tree;
+  const double* row = a.params + (size_t)t * a.param_count;
+  DevModel& m = a.models[idx];
+  if (a.subst == 0) {
+    // substitution_model.hpp:59-74 (JC69 eigensystem as hard-coded there)
+    const double V[16] = {1.0, 2.0, 0.0, 0.5, 1.0, -2.0, 0.5, 0.0,
+                          1.0, 2.0, 0.0, -0.5, 1.0, -2.0, -0.5, 0.0};
+    const double Vi[16] = {0.25, 0.25, 0.25, 0.25, 0.125, -0.125, 0.125, -0.125,
+                           0.0,  1.0,  0.0,  -1.0, 1.0,   0.0,    -1.0,  0.0};
+    for (int i = 0; i < 4; i++) {
+      m.pi[i] = 0.25;
+      m.lambda[i] = i == 0 ? 0.0 : -1.3333333333333333;
+      for (int k = 0; k < 4; k++) m.Q[i * 4 + k] = i == k ? -1.0 : 1.0 / 3.0;
+    }
+    for (int i = 0; i < 16; i++) {
+      m.V[i] = V[i];
+      m.Vinv[i] = Vi[i];
+    }
+  } else {
+    // substitution_model.cpp:17-80, with the finite-difference perturbation of
+    // fat_beagle.cpp:400-438 applied for j > 0: coordinate c of the
+    // stick-breaking image of (frequencies | rates), sign +/-.
+    double rates[6], freqs[4];
+    for (int i = 0; i < 6; i++) rates[i] = row[a.rates_off + i];
+    for (int i = 0; i < 4; i++) freqs[i] = row[a.freqs_off + i];
+    double fsum = 0, rsum = 0;
+    for (int i = 0; i < 4; i++) fsum += freqs[i];
+    for (int i = 0; i < 6; i++) rsum += rates[i];
+    if (j == 0) {
+      if (fabs(fsum - 1.) >= 0.001) set_status(a.status, kGtrFrequencies, t);
+      if (fabs(rsum - 1.) >= 0.001) set_status(a.status, kGtrRates, t);
+    }
+    if (j > 0) {
+      const int coord = (j - 1) >> 1;
+      const double delta = ((j - 1) & 1) ? -1.e-6 : 1.e-6;
+      double y[5];
+      if (coord < 3) {
+        stick_breaking_inverse(4, freqs, y);
+        y[coord] += delta;
+        stick_breaking(4, y, freqs);
+      } else {
+        stick_breaking_inverse(6, rates, y);
+        y[coord - 3] += delta;
+        stick_breaking(6, y, rates);
+      }
+    }
+    double Q[16];
+    int ri = 0;
+    for (int i = 0; i < 4; i++)
+      for (int k = i + 1; k < 4; k++) {
+        const double r = rates[ri++];
+        Q[i * 4 + k] = r * freqs[k];
+        Q[k * 4 + i] = r * freqs[i];
+      }
+    double total = 0;
+    for (int i = 0; i < 4; i++) {
+      double row_sum = 0;
+      for (int k = 0; k < 4; k++)
+        if (i != k) row_sum += Q[i * 4 + k];
+      Q[i * 4 + i] = -row_sum;
+      total += row_sum * freqs[i];
+    }
+    for (int i = 0; i < 16; i++) Q[i] /= total;
+    double sq[4], S[16], U[16], ev[4];
+    for (int i = 0; i < 4; i++) sq[i] = sqrt(freqs[i]);
+    for (int i = 0; i < 4; i++)
+      for (int k = 0; k < 4; k++) S[i * 4 + k] = sq[i] * Q[i * 4 + k] * (1.0 / sq[k]);
+    jacobi4(S, ev, U);
+    for (int i = 0; i < 4; i++) {
+      m.pi[i] = freqs[i];
+      m.lambda[i] = ev[i];
+      for (int k = 0; k < 4; k++) {
+        m.Q[i * 4 + k] = Q[i * 4 + k];
+        m.V[i * 4 + k] = (1.0 / sq[i]) * U[i * 4 + k];
+        m.Vinv[i * 4 + k] = U[k * 4 + i] * sq[k];
+      }
+    }
+  }
+  if (a.site == 0) {
+    m.cat_rate[0] = 1.0;
+    m.cat_weight[0] = 1.0;
+    m.cat_drate[0] = 0.0;
+  } else {
+    // site_model.cpp:37-62
+    const int K = a.K;
+    const double shape = row[a.shape_off];
+    double mean_rate = 0, mean_deriv = 0;
+    for (int i = 0; i < K; i++) {
+      const double quantile = (2.0 * i + 1.0) / (2.0 * K);
+      const double r = pow(-log(1.0 - quantile), 1.0 / shape);
+      m.cat_rate[i] = r;
+      mean_rate += r;
+      const double du = -r * log(-log(1.0 - quantile)) / (shape * shape);
+      m.cat_drate[i] = du;
+      mean_deriv += du;
+    }
+    mean_rate /= K;
+    mean_deriv /= K;
+    for (int i = 0; i < K; i++) {
+      m.cat_drate[i] =
+          (m.cat_drate[i] * mean_rate - m.cat_rate[i] * mean_deriv) / (mean_rate * mean_rate);
+      m.cat_rate[i] /= mean_rate;
+      m.cat_weight[i] = 1.0 / K;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
+// Transition matrices (beagleUpdateTransitionMatrices, fat_beagle.cpp:304-314):
+// one thread per (evaluation, edge, category).
+// BEAGLE evaluates P = V diag(exp(l r t)) V^-1.  We evaluate the algebraically
+// identical P = I + V diag(expm1(l r t)) V^-1: for small r t the BEAGLE form
+// obtains the O(r t) off-diagonal entries as a difference of O(1) terms and
+// loses ~1e-16/(r t) relative accuracy there (5e-14 relative in logL on the
+// reference's fluA test, which its 2e-6 finite-difference divisor turns into 1e-3
+// of gradient noise); the expm1 form agrees with an 80-bit evaluation to 1e-15.
+// See DESIGN.md "Accuracy".
+// ------------------------------------------------------------------------
+constexpr int kTransitionBlock = 256;
+__global__ __launch_bounds__(kTransitionBlock) void transition_kernel(TransitionArgs a) {
+  // one thread per matrix; the 128-byte results are staged through LDS (row stride 17:
+  // conflict-free) so that the block writes its 32 KB of output as whole cache lines
+  __shared__ double stage[kTransitionBlock * 17];
+  const long first = (long)blockIdx.x * kTransitionBlock;
+  const long idx = first + threadIdx.x;
+  const long total = (long)a.E * (a.N - 1) * a.K;
+  double Pm[16];
+  bool tip_edge = false;
+  int mi_keep = 0;
+  if (idx < total) {
+    const int k = idx % a.K;
+    const int edge = (idx / a.K) % (a.N - 1);
+    const int e = idx / ((long)a.K * (a.N - 1));
+    int t, mi;
+    a.map.decode(e, t, mi);
+    const DevModel& m = a.models[mi];
+    const double bl = a.bl_eff[(size_t)t * a.N + edge];
+    const double rt = m.cat_rate[k] * bl;
+    double ex[4], W[16];
+    for (int x = 0; x < 4; x++) ex[x] = expm1(m.lambda[x] * rt);
+    for (int x = 0; x < 4; x++)
+      for (int j = 0; j < 4; j++) W[x * 4 + j] = ex[x] * m.Vinv[x * 4 + j];
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        double sum = i == j ? 1.0 : 0.0;
+        for (int x = 0; x < 4; x++) sum += m.V[i * 4 + x] * W[x * 4 + j];
+        Pm[i * 4 + j] = sum > 0 ? sum : 0;  // BEAGLE clamps negative probabilities to 0
+        stage[threadIdx.x * 17 + i * 4 + j] = Pm[i * 4 + j];
+      }
+    tip_edge = edge < a.n;
+    mi_keep = mi;
+  }
+  __syncthreads();
+  const long left = total - first;
+  const int count = (int)(left < kTransitionBlock ? left : kTransitionBlock) * 16;
+  double* out = a.mats + first * 16;
+  for (int x = threadIdx.x; x < count; x += kTransitionBlock) out[x] = stage[(x >> 4) * 17 + (x & 15)];
+  if (a.tip_tables != nullptr) {
+    // Tip edges: what a compact tip state st contributes to the forward sweep is a
+    // COLUMN of P; a gap contributes 1 (rows of P sum to 1).  Tabulated per state so
+    // that the VALU log-likelihood kernel fetches it with one 32-byte gather instead of
+    // spending FP64 issue slots on one-hot vectors: table[st][i] = P[i][st], st = 0..4.
+    // Written by the whole block from the staged matrices (contiguous destinations).
+    for (int x = threadIdx.x; x < (count >> 4) * 20; x += kTransitionBlock) {
+      const int m = x / 20, j = x - m * 20;
+      const long id = first + m;
+      const int k = id % a.K;
+      const int edge = (id / a.K) % (a.N - 1);
+      const int e = id / ((long)a.K * (a.N - 1));
+      if (edge < a.n)
+        a.tip_tables[(((size_t)e * a.n + edge) * a.K + k) * 20 + j] =
+            j < 16 ? stage[m * 17 + (j & 3) * 4 + (j >> 2)] : 1.0;
+    }
+  }
+  if (a.tr_mats != nullptr) {
+    // Matrix of the matrix-core kernel's pre-order step, per edge: P again for an
+    // internal edge (the kernel reads it transposed), and for a tip edge -- whose
+    // derivative is (q_parent o sibling) . (P Q) e_state, one product instead of two --
+    // (P Q) stored transposed so that the same transposed read yields it in forward layout.
+    __syncthreads();
+    if (tip_edge) {
+      const DevModel& m = a.models[mi_keep];
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+          double pq = 0;
+          for (int x = 0; x < 4; x++) pq += Pm[i * 4 + x] * m.Q[x * 4 + j];
+          stage[threadIdx.x * 17 + j * 4 + i] = pq;
+        }
+    }
+    __syncthreads();
+    double* out2 = a.tr_mats + first * 16;
+    for (int x = threadIdx.x; x < count; x += kTransitionBlock)
+      out2[x] = stage[(x >> 4) * 17 + (x & 15)];
+  }
+  if (a.phi != nullptr) {
+    // Analytic substitution gradient: d exp(Q tau) = V ((V^-1 dQ V) o Phi) V^-1 with the
+    // divided differences Phi_ij = (e^{l_i tau} - e^{l_j tau}) / (l_i - l_j), Phi_ii =
+    // tau e^{l_i tau}, tau = r_k t.  Evaluated as tau e^{l_j tau} expm1(x)/x, x = (l_i -
+    // l_j) tau, which is stable for close and for equal eigenvalues.
+    __syncthreads();
+    if (idx < total) {
+      const int k = idx % a.K;
+      const int edge = (idx / a.K) % (a.N - 1);
+      const int e = idx / ((long)a.K * (a.N - 1));
+      int t, mi;
+      a.map.decode(e, t, mi);
+      const DevModel& m = a.models[mi];
+      const double tau = m.cat_rate[k] * a.bl_eff[(size_t)t * a.N + edge];
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+          const double x = (m.lambda[i] - m.lambda[j]) * tau;
+          const double r = fabs(x) < 1e-5 ? 1.0 + 0.5 * x + x * x * (1.0 / 6.0) : expm1(x) / x;
+          stage[threadIdx.x * 17 + i * 4 + j] = tau * exp(m.lambda[j] * tau) * r;
+        }
+    }
+    __syncthreads();
+    double* out3 = a.phi + first * 16;
+    for (int x = threadIdx.x; x < count; x += kTransitionBlock)
+      out3[x] = stage[(x >> 4) * 17 + (x & 15)];
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------
+// Launch wrappers
+// ------------------------------------------------------------------------
+void launch_tree_setup(const TreeSetupArgs& a_in, hipStream_t s) {
+  TreeSetupArgs a = a_in;
+  const size_t lds = sizeof(int32_t) * 13 * (size_t)(2 * a.n - 1);
+  a.use_lds = lds <= 48 * 1024;
+  // MI_PHYLO_TREE_SETUP=lds forces the general kernel (testing)
+  static const bool force_lds = [] {
+    const char* env = getenv("MI_PHYLO_TREE_SETUP");
+    return env && std::string(env) == "lds";
+  }();
+  const int N = 2 * a.n - 1;
+  if (a.n >= 3 && N <= 256 && !force_lds) {
+    if (N <= 64) hipLaunchKernelGGL(tree_setup_small_kernel<1>, dim3(a.T), dim3(64), 0, s, a);
+    else if (N <= 128) hipLaunchKernelGGL(tree_setup_small_kernel<2>, dim3(a.T), dim3(64), 0, s, a);
+    else if (N <= 192) hipLaunchKernelGGL(tree_setup_small_kernel<3>, dim3(a.T), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(tree_setup_small_kernel<4>, dim3(a.T), dim3(64), 0, s, a);
+    return;
+  }
+  hipLaunchKernelGGL(tree_setup_kernel, dim3(a.T), dim3(64), a.use_lds ? lds : 0, s, a);
+}
+void launch_model_setup(const ModelSetupArgs& a, hipStream_t s) {
+  const int total = a.T * a.models_per_tree;
+  hipLaunchKernelGGL(model_setup_kernel, dim3((total + 63) / 64), dim3(64), 0, s, a);
+}
+void launch_transition(const TransitionArgs& a, hipStream_t s) {
+  const long total = (long)a.E * (a.N - 1) * a.K;
+  hipLaunchKernelGGL(transition_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                     a);
+}
+}  // namespace miphylo

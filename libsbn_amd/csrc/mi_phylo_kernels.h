@@ -1,5 +1,5 @@
 // Launch interface between the host engine (mi_phylo_engine.cpp) and the HIP
-// kernels (mi_phylo_kernels.hip).  Plain structs of device pointers.
+// kernels (kernels_*.hip).  Plain structs of device pointers.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -769,7 +769,12 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
             j < 16 ? stage[m * 17 + (j & 3) * 4 + (j >> 2)] : 1.0;
     }
   }
-  if (a.tr_mats != nullptr) {
+  // blocks whose matrices all belong to log-likelihood-only evaluations (the finite-difference
+  // passes of a GTR gradient call) have no pre-order step to prepare
+  const long per_eval = (long)a.K * (a.N - 1);
+  const bool tr_needed = first / per_eval < a.tr_skip_begin ||
+                         (first + (count >> 4) - 1) / per_eval >= a.tr_skip_end;
+  if (a.tr_mats != nullptr && tr_needed) {
     // Matrix of the matrix-core kernel's pre-order step, per edge: P again for an
     // internal edge (the kernel reads it transposed), and for a tip edge -- whose
     // derivative is (q_parent o sibling) . (P Q) e_state, one product instead of two --

@@ -333,6 +333,9 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   tr.tr_mats = mfma ? e->tr_mats.as<double>() : nullptr;
   tr.phi = analytic ? e->phi.as<double>() : nullptr;
   tr.n = n;
+  // evaluations [T, 17 T) of a finite-difference GTR call never run the gradient kernel
+  tr.tr_skip_begin = c.E > T ? T : c.E;
+  tr.tr_skip_end = c.E > T ? std::min(17 * T, c.E) : c.E;
   launch_transition(tr, s);
 
   LikArgs la{};

@@ -66,6 +66,7 @@ struct TransitionArgs {
   double* tr_mats;       // [E][N-1][K][4][4]: matrix of the matrix-core pre-order step (P, or (P Q)^T for tips); may be nullptr
   double* phi;           // [E][N-1][K][4][4]: divided differences of exp(lambda r t) (analytic substitution gradient); may be nullptr
   int n;
+  int tr_skip_begin, tr_skip_end;  // evaluations [begin, end) are log-likelihood only: no tr_mats for them
 };
 
 struct LikArgs {

@@ -687,6 +687,10 @@ int gradient_mfma_width(int n, bool subst) {
   return max_macros(n) * kMacroPositions * 2 + (subst ? kSubstExtra : 0);
 }
 int gradient_mfma_groups(int K) { return K <= 4 ? 1 : (K + 3) / 4; }
+int gradient_mfma_tiles(int P, int K) {
+  const int per_wave = kLlR * (16 / (K == 1 ? 1 : (K == 2 ? 2 : 4)));
+  return (P + per_wave - 1) / per_wave;
+}
 bool gradient_mfma_fits(int n, int K, bool rescale) {
   return n >= 3 && K <= kMaxCategories &&
          gradient_mfma_lds_bytes(n, K, rescale, true) <= 160 * 1024;
@@ -704,7 +708,7 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool sub
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
   a.cat_groups = gradient_mfma_groups(a.K);
   const size_t lds = gradient_mfma_lds_bytes(a.n, a.K, rescale, subst);
-  const dim3 grid(loglik_mfma_tiles(a.P, a.K) * a.cat_groups, count);
+  const dim3 grid(gradient_mfma_tiles(a.P, a.K) * a.cat_groups, count);
   if (rescale || subst) {
     if (rescale && subst) launch_gradient_mfma_variant<true, true>(a, grid, lds, s);
     else if (rescale) launch_gradient_mfma_variant<true, false>(a, grid, lds, s);

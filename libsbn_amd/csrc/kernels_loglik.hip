@@ -4,6 +4,7 @@
 
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 #include "mi_phylo_device_utils.h"
 #include "mi_phylo_kernels.h"
@@ -174,7 +175,9 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
 // ------------------------------------------------------------------------
 template <int R, bool RESCALE>
 __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
-  static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
+  static_assert(R <= 8, "tip masks of one column group are packed in one 32- or 64-bit word");
+  using TipWord = std::conditional_t<(R > 4), uint64_t, uint32_t>;
+  constexpr unsigned TB = sizeof(TipWord);  // bytes of tip masks per (taxon, column)
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
@@ -207,20 +210,23 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   // that the ignored mask fetch of an internal node id needs no clamping) | schedule |
   // vectors [slot][r][lane]
   uint8_t* tips = reinterpret_cast<uint8_t*>(lds);
-  SchedEntry* sched_l = reinterpret_cast<SchedEntry*>(lds + ((n * ppr * 4 + 7) >> 3));
+  SchedEntry* sched_l = reinterpret_cast<SchedEntry*>(lds + ((n * ppr * TB + 7) >> 3));
   double* plv = reinterpret_cast<double*>(sched_l + (n - 1));
   for (int i = lane; i < n - 1; i += kTile) sched_l[i] = sched[i];
   {
     const int tp_shift = TP <= 16 ? 4 : (TP <= 32 ? 5 : 6);
-    const int q = lane & ((1 << tp_shift) - 1), group = 64 >> tp_shift;
+    const int group = 64 >> tp_shift;
     const int ppr_shift = Kp == 4 ? 2 : (Kp == 2 ? 3 : 4);
-    const int r = q >> ppr_shift, c = q & (ppr - 1);
-    if (q < TP) {
-      const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
-      const uint8_t* src = a.tip_masks + pp;
+    for (int qb = 0; qb < TP; qb += kTile) {  // one trip unless the tile is wider than the wave
+      const int q = qb + (lane & ((1 << tp_shift) - 1));
+      const int r = q >> ppr_shift, c = q & (ppr - 1);
+      if (q < TP) {
+        const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
+        const uint8_t* src = a.tip_masks + pp;
 #pragma unroll 4
-      for (int taxon = lane >> tp_shift; taxon < n; taxon += group)
-        tips[(taxon * ppr + c) * 4 + r] = src[(size_t)taxon * a.P];
+        for (int taxon = lane >> tp_shift; taxon < n; taxon += group)
+          tips[(taxon * ppr + c) * TB + r] = src[(size_t)taxon * a.P];
+      }
     }
   }
   __syncthreads();
@@ -233,10 +239,10 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   constexpr int kAhead = 4;
   struct Ahead {
     double A0, A1;
-    uint32_t w0, w1;
+    TipWord w0, w1;
     int slots;
   };
-  const unsigned lane8 = 8u * lane, col4 = 4u * col;
+  const unsigned lane8 = 8u * lane, col4 = TB * col;
   auto request = [&](int i) {
     const SchedEntry sv = sched_l[i < n - 1 ? i : n - 2];
     int c0 = sv.child0, c1 = sv.child1;
@@ -244,8 +250,8 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
     Ahead h;
     h.A0 = *reinterpret_cast<const double*>(mats_e + (__umul24((unsigned)c0, node_bytes) + a_off));
     h.A1 = *reinterpret_cast<const double*>(mats_e + (__umul24((unsigned)c1, node_bytes) + a_off));
-    h.w0 = *reinterpret_cast<const uint32_t*>(tips + (__umul24((unsigned)c0, (unsigned)(ppr * 4)) + col4));
-    h.w1 = *reinterpret_cast<const uint32_t*>(tips + (__umul24((unsigned)c1, (unsigned)(ppr * 4)) + col4));
+    h.w0 = *reinterpret_cast<const TipWord*>(tips + (__umul24((unsigned)c0, (unsigned)ppr * TB) + col4));
+    h.w1 = *reinterpret_cast<const TipWord*>(tips + (__umul24((unsigned)c1, (unsigned)ppr * TB) + col4));
     h.slots = sv.slots;
     return h;
   };
@@ -260,12 +266,16 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
     L[r] = 0.0;
     esum[r] = 0;
   }
+  auto tip_bit = [&](TipWord w, int r) {  // 0.0 / 1.0: is this lane's state compatible with the tip
+    const uint32_t half = r < 4 ? (uint32_t)w : (uint32_t)((uint64_t)w >> 32);
+    return (double)__builtin_amdgcn_ubfe(half, (uint32_t)(8 * (r & 3) + hi), 1u);
+  };
   auto visit = [&](int i, Ahead& h) {
     const int slots = __builtin_amdgcn_readfirstlane(h.slots);
     double B0[R], B1[R];
     if (slots & (1 << 24)) {
 #pragma unroll
-      for (int r = 0; r < R; r++) B0[r] = (double)__builtin_amdgcn_ubfe(h.w0, (uint32_t)(8 * r + hi), 1u);
+      for (int r = 0; r < R; r++) B0[r] = tip_bit(h.w0, r);
     } else {
       const double* src = slot_ptr((slots >> 8) & 0xff);
 #pragma unroll
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
     }
     if (slots & (1 << 25)) {
 #pragma unroll
-      for (int r = 0; r < R; r++) B1[r] = (double)__builtin_amdgcn_ubfe(h.w1, (uint32_t)(8 * r + hi), 1u);
+      for (int r = 0; r < R; r++) B1[r] = tip_bit(h.w1, r);
     } else {
       const double* src = slot_ptr((slots >> 16) & 0xff);
 #pragma unroll
@@ -372,17 +382,19 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
 // ------------------------------------------------------------------------
 // which log-likelihood kernel runs by default when both can (measured)
 constexpr bool kLoglikMfmaDefault = true;
+constexpr int kLogR = 4;  // registers (16 columns each) per node in loglik_mfma_kernel: 3 -> 4 is 8 % faster, 6 (64-bit tip words) 12 % slower
 static size_t loglik_mfma_lds_bytes(int n, int K, int max_slots) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
-  const size_t tip_bytes = (((size_t)n * 4 * (16 / kp) + 7) / 8) * 8;
+  const size_t tb = kLogR > 4 ? 8 : 4;  // bytes of tip masks per (taxon, column)
+  const size_t tip_bytes = (((size_t)n * tb * (16 / kp) + 7) / 8) * 8;
   const size_t bytes = tip_bytes + sizeof(SchedEntry) * (size_t)(n - 1) +
-                       sizeof(double) * (size_t)max_slots * kLlR * kTile;
-  const size_t reach = (size_t)(2 * n - 1) * 4 * (16 / kp);  // mask fetches of internal ids
+                       sizeof(double) * (size_t)max_slots * kLogR * kTile;
+  const size_t reach = (size_t)(2 * n - 1) * tb * (16 / kp);  // mask fetches of internal ids
   return bytes > reach ? bytes : reach;
 }
 int loglik_mfma_tiles(int P, int K) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
-  const int per_wave = kLlR * (16 / kp);
+  const int per_wave = kLogR * (16 / kp);
   return (P + per_wave - 1) / per_wave;
 }
 bool loglik_mfma_supported(const LikArgs& a, bool rescale) {
@@ -411,11 +423,11 @@ static void launch_loglik_mfma(const LikArgs& a_in, int count, bool rescale, int
   const dim3 grid(loglik_mfma_tiles(a.P, a.K), count), block(kTile);
   const size_t lds = loglik_mfma_lds_bytes(a.n, a.K, max_slots);
   if (rescale) {
-    allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLlR, true>), lds);
-    hipLaunchKernelGGL((loglik_mfma_kernel<kLlR, true>), grid, block, lds, s, a);
+    allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLogR, true>), lds);
+    hipLaunchKernelGGL((loglik_mfma_kernel<kLogR, true>), grid, block, lds, s, a);
   } else {
-    allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLlR, false>), lds);
-    hipLaunchKernelGGL((loglik_mfma_kernel<kLlR, false>), grid, block, lds, s, a);
+    allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLogR, false>), lds);
+    hipLaunchKernelGGL((loglik_mfma_kernel<kLogR, false>), grid, block, lds, s, a);
   }
 }
 void launch_loglik(const LikArgs& a_in, int count, bool rescale, int max_slots, hipStream_t s) {

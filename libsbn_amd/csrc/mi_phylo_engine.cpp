@@ -265,7 +265,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
                     gradient_mfma_fits(e->n, e->K, d.rescaling) && reduce_tiles_fits(e->N);
   const bool onchip = mfma;  // the only on-chip gradient kernel; everything else streams PLVs
   const int groups = mfma ? gradient_mfma_groups(e->K) : 1;
-  const int g_tiles = mfma ? loglik_mfma_tiles(e->P, e->K) * groups : e->tiles;
+  const int g_tiles = mfma ? gradient_mfma_tiles(e->P, e->K) * groups : e->tiles;
   const bool analytic = e->analytic_subst && mfma && e->spec.subst_model == MI_SUBST_GTR;
   if (reserve(e, d.T, d.gradient, !onchip, analytic)) return 1;
   const CallShape c = call_shape(e, d.T, d.gradient, analytic);
@@ -593,7 +593,7 @@ int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
   e->P = spec->pattern_count;
   e->K = spec->category_count;
   e->tiles = (e->P + kTile - 1) / kTile;
-  e->ll_stride = std::max(e->tiles, loglik_mfma_tiles(e->P, e->K));
+  e->ll_stride = std::max({e->tiles, loglik_mfma_tiles(e->P, e->K), gradient_mfma_tiles(e->P, e->K)});
   int lg = 0;
   while ((2 << lg) <= e->n) lg++;
   e->max_slots = lg + 1;

@@ -131,6 +131,7 @@ void launch_transition(const TransitionArgs& a, hipStream_t s);
 // On-chip (LDS-resident) log-likelihood: evaluations [eval_offset, eval_offset+count)
 void launch_loglik(const LikArgs& a, int count, bool rescale, int max_slots, hipStream_t s);
 int loglik_mfma_tiles(int P, int K);
+int gradient_mfma_tiles(int P, int K);
 // Gradient, partial-likelihood vectors streamed through HBM (any tree size, rescaling)
 void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t s);
 // Gradient with all partial-likelihood vectors resident in LDS (no rescaling;

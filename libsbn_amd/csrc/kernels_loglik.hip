@@ -174,7 +174,10 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
 // for the element-wise products.
 // ------------------------------------------------------------------------
 template <int R, bool RESCALE>
-__global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
+// (kTile, 2): with at most 256 registers per lane the compiler keeps the products in
+// ordinary vector registers; without the bound it places them in accumulation registers
+// and spends two v_accvgpr_read per product to get them back
+__global__ __launch_bounds__(kTile, 2) void loglik_mfma_kernel(LikArgs a) {
   static_assert(R <= 8, "tip masks of one column group are packed in one 32- or 64-bit word");
   using TipWord = std::conditional_t<(R > 4), uint64_t, uint32_t>;
   constexpr unsigned TB = sizeof(TipWord);  // bytes of tip masks per (taxon, column)
@@ -212,7 +215,29 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   uint8_t* tips = reinterpret_cast<uint8_t*>(lds);
   SchedEntry* sched_l = reinterpret_cast<SchedEntry*>(lds + ((n * ppr * TB + 7) >> 3));
   double* plv = reinterpret_cast<double*>(sched_l + (n - 1));
-  for (int i = lane; i < n - 1; i += kTile) sched_l[i] = sched[i];
+  // In a post-order the visit just before a node's is that of one of its children
+  // (unless both are tips): that child -- made child 1 here, the element-wise product
+  // commutes -- is taken from the registers the previous visit left it in, and a visit
+  // whose successor consumes it that way does not store its vector at all.
+  constexpr int kFromPrev = 1 << 26, kStore = 1 << 27;
+  for (int i = lane; i < n - 1; i += kTile) {
+    SchedEntry v = sched[i];
+    const int prev = i > 0 ? sched[i - 1].node : -1;
+    if (v.child0 == prev && v.child1 != prev) {
+      const int c = v.child0;
+      v.child0 = v.child1;
+      v.child1 = c;
+      const int sl = v.slots;
+      v.slots = (sl & 0xff) | ((sl >> 8) & 0xff00) | ((sl & 0xff00) << 8) |
+                ((sl >> 1) & (1 << 24)) | ((sl & (1 << 24)) << 1);
+    }
+    if (v.child1 == prev) v.slots |= kFromPrev;
+    // (the root's vector is read from L after the walk)
+    const bool consumed =
+        i == n - 2 || sched[i + 1].child0 == v.node || sched[i + 1].child1 == v.node;
+    if (!consumed) v.slots |= kStore;
+    sched_l[i] = v;
+  }
   {
     const int tp_shift = TP <= 16 ? 4 : (TP <= 32 ? 5 : 6);
     const int group = 64 >> tp_shift;
@@ -272,7 +297,7 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
   };
   auto visit = [&](int i, Ahead& h) {
     const int slots = __builtin_amdgcn_readfirstlane(h.slots);
-    double B0[R], B1[R];
+    double B0[R];
     if (slots & (1 << 24)) {
 #pragma unroll
       for (int r = 0; r < R; r++) B0[r] = tip_bit(h.w0, r);
@@ -281,20 +306,23 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
 #pragma unroll
       for (int r = 0; r < R; r++) B0[r] = src[r * kTile];
     }
-    if (slots & (1 << 25)) {
+    // child 1: normally the previous visit's result, still in L
+    if (!(slots & kFromPrev)) {
+      if (slots & (1 << 25)) {
 #pragma unroll
-      for (int r = 0; r < R; r++) B1[r] = tip_bit(h.w1, r);
-    } else {
-      const double* src = slot_ptr((slots >> 16) & 0xff);
+        for (int r = 0; r < R; r++) L[r] = tip_bit(h.w1, r);
+      } else {
+        const double* src = slot_ptr((slots >> 16) & 0xff);
 #pragma unroll
-      for (int r = 0; r < R; r++) B1[r] = src[r * kTile];
+        for (int r = 0; r < R; r++) L[r] = src[r * kTile];
+      }
     }
     const double A0 = h.A0, A1 = h.A1;
     h = request(i + kAhead);  // refill this ring slot
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const double D0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, B0[r], 0.0, 0, 0, 0);
-      const double D1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, B1[r], 0.0, 0, 0, 0);
+      const double D1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, L[r], 0.0, 0, 0, 0);
       L[r] = D0 * D1;
       if (RESCALE) {
         // exact per-pattern power-of-two rescaling (largest entry over states, categories)
@@ -308,9 +336,11 @@ __global__ __launch_bounds__(kTile) void loglik_mfma_kernel(LikArgs a) {
         esum[r] += ex;
       }
     }
-    double* dst = slot_ptr(slots & 0xff);
+    if (slots & kStore) {
+      double* dst = slot_ptr(slots & 0xff);
 #pragma unroll
-    for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
+      for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
+    }
   };
   double site[R];
   int site_exp[R];

@@ -386,19 +386,30 @@ __global__ __launch_bounds__(kTile, 2) void loglik_mfma_kernel(LikArgs a) {
       }
     }
   }
+  // every lane of a pattern holds its site likelihood: the lane with state index hi
+  // takes register r = hi (+4, ...), so a wave evaluates each logarithm once
   double ll = 0.0;
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    const bool owner = hi == 0 && cat == 0 && pat[r] < a.P;  // one lane per pattern
+  for (int r0 = 0; r0 < R; r0 += 4) {
+    double sv = site[r0], wv = pw[r0];
+    int pv = pat[r0], ev = site_exp[r0];
+#pragma unroll
+    for (int j = 1; j < 4 && r0 + j < R; j++) {
+      sv = hi == j ? site[r0 + j] : sv;
+      wv = hi == j ? pw[r0 + j] : wv;
+      pv = hi == j ? pat[r0 + j] : pv;
+      ev = hi == j ? site_exp[r0 + j] : ev;
+    }
+    const bool owner = r0 + hi < R && cat == 0 && pv < a.P;  // one lane per pattern
     if (owner) {
       if (a.site_lik) {
         // per-pattern site likelihood for a following gradient pass (rescaled: the
         // mantissa here, the power of two in site_exp)
-        const size_t at = ((size_t)a.grad_offset + te.eval) * a.tiles * kTile + pat[r];
-        a.site_lik[at] = site[r];
-        if (RESCALE) a.site_exp[at] = site_exp[r];
+        const size_t at = ((size_t)a.grad_offset + te.eval) * a.tiles * kTile + pv;
+        a.site_lik[at] = sv;
+        if (RESCALE) a.site_exp[at] = ev;
       }
-      ll += pw[r] * (RESCALE ? log(site[r]) + site_exp[r] * 0.69314718055994530942 : log(site[r]));
+      ll += wv * (RESCALE ? log(sv) + ev * 0.69314718055994530942 : log(sv));
     }
   }
   ll = wave_sum(ll);

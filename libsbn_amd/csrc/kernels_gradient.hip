@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       store_slot(sl.q, Lv);
     } else {
       // root: site likelihood per pattern, log-likelihood partial, derivative weights
-      double ll = 0.0;
+      double sitev[R];
 #pragma unroll
       for (int r = 0; r < R; r++) {
         double v;
@@ -463,10 +463,27 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
           if (Kp >= 2) v += __shfl_xor(v, 4, 64);
           if (Kp >= 4) v += __shfl_xor(v, 8, 64);
         }
-        qroot[r] = pi_l * cw_l * (pw[r] / v);  // pw = 0 for padding patterns
-        if (hi == 0 && (b % Kp) == 0 && pat[r] < a.P)
-          ll += pw[r] * (RESCALE ? log(v) + esum[r] * 0.69314718055994530942 : log(v));
+        sitev[r] = v;
       }
+      // every lane of a pattern holds its site likelihood: the lane with state index hi
+      // does the division and the logarithm of register r = hi only, and the quotients
+      // go back to the pattern's other lanes with one cross-lane read per register
+      static_assert(R <= 4, "one register per state index");
+      double sv = sitev[0], wv = pw[0];
+      int pv = pat[0], ev = esum[0];
+#pragma unroll
+      for (int j = 1; j < R; j++) {
+        sv = hi == j ? sitev[j] : sv;
+        wv = hi == j ? pw[j] : wv;
+        pv = hi == j ? pat[j] : pv;
+        ev = hi == j ? esum[j] : ev;
+      }
+      const double quot = wv / sv;  // pw = 0 for padding patterns
+#pragma unroll
+      for (int r = 0; r < R; r++) qroot[r] = pi_l * cw_l * __shfl(quot, (r << 4) | (lane & 15), 64);
+      double ll = 0.0;
+      if (hi < R && (b % Kp) == 0 && pv < a.P)
+        ll = wv * (RESCALE ? log(sv) + ev * 0.69314718055994530942 : log(sv));
       ll = wave_sum(ll);
       if (lane == 0 && groups == 1) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
       if (SUBST) {

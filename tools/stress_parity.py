@@ -52,6 +52,11 @@ for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
             okk = np.max(np.abs(a - f_) / np.maximum(np.abs(f_), 1.0)) <= 1e-4
             if not okk: print("  subst", a, f_)
             ok &= okk
+    # the log-likelihood-only call (its own kernel and traversal order)
+    ll = np.asarray(eng.log_likelihoods(pids, bls, pr, resc))
+    okl = np.all(np.abs(ll - og["log_likelihood"]) <= RTOL * np.abs(og["log_likelihood"]) + 1e-13)
+    if not okl: print("  logL call", ll, og["log_likelihood"])
+    ok &= bool(okl)
     total += 1
     if not ok:
         bad += 1

@@ -235,7 +235,12 @@ __global__ __launch_bounds__(kTile, 2) void loglik_mfma_kernel(LikArgs a) {
     // (the root's vector is read from L after the walk)
     const bool consumed =
         i == n - 2 || sched[i + 1].child0 == v.node || sched[i + 1].child1 == v.node;
-    if (!consumed) v.slots |= kStore;
+    if (!consumed) {
+      v.slots |= kStore;
+      // stored vectors use the low slot numbers only (loglik_mfma_slots); anything else
+      // is an internal error that must not pass silently
+      if ((v.slots & 0xff) >= a.lds_slots) set_status(a.status, kTooManySlots, t);
+    }
     sched_l[i] = v;
   }
   {
@@ -424,12 +429,19 @@ __global__ __launch_bounds__(kTile, 2) void loglik_mfma_kernel(LikArgs a) {
 // which log-likelihood kernel runs by default when both can (measured)
 constexpr bool kLoglikMfmaDefault = true;
 constexpr int kLogR = 4;  // registers (16 columns each) per node in loglik_mfma_kernel: 3 -> 4 is 8 % faster, 6 (64-bit tip words) 12 % slower
+// LDS vector slots of the matrix-core kernel.  The schedule numbers its slots for a walk
+// that stores every node (max_slots = floor(log2 n) + 1 bounds them); with the chain child
+// forwarded in registers the vectors that are really stored -- the first-visited child of a
+// node with two internal children -- only ever carry the numbers below max_slots - 2 (a
+// stored vector coexists with at least the two nodes of the sibling subtree that end that
+// subtree's walk); the kernel checks it.
+static int loglik_mfma_slots(int max_slots) { return max_slots > 3 ? max_slots - 2 : 1; }
 static size_t loglik_mfma_lds_bytes(int n, int K, int max_slots) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
   const size_t tb = kLogR > 4 ? 8 : 4;  // bytes of tip masks per (taxon, column)
   const size_t tip_bytes = (((size_t)n * tb * (16 / kp) + 7) / 8) * 8;
   const size_t bytes = tip_bytes + sizeof(SchedEntry) * (size_t)(n - 1) +
-                       sizeof(double) * (size_t)max_slots * kLogR * kTile;
+                       sizeof(double) * (size_t)loglik_mfma_slots(max_slots) * kLogR * kTile;
   const size_t reach = (size_t)(2 * n - 1) * tb * (16 / kp);  // mask fetches of internal ids
   return bytes > reach ? bytes : reach;
 }
@@ -459,7 +471,7 @@ static bool use_loglik_mfma(const LikArgs& a, bool rescale, int max_slots) {
 static void launch_loglik_mfma(const LikArgs& a_in, int count, bool rescale, int max_slots,
                                hipStream_t s) {
   LikArgs a = a_in;
-  a.lds_slots = max_slots;
+  a.lds_slots = loglik_mfma_slots(max_slots);
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
   const dim3 grid(loglik_mfma_tiles(a.P, a.K), count), block(kTile);
   const size_t lds = loglik_mfma_lds_bytes(a.n, a.K, max_slots);

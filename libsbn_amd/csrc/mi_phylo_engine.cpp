@@ -364,6 +364,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.g_part = e->g_part.as<double>();
 
   la.site_lik = nullptr;
+  la.status = e->status.as<int32_t>();
   // one launch covers at most kMaxEvals evaluations (grid y dimension: 65535; a multiple
   // of 8 keeps whole evaluations per XCD)
   constexpr int kMaxEvals = 32768;

@@ -96,6 +96,7 @@ struct LikArgs {
   double* g_part;              // [Eg][tiles][2][N]
   double* site_lik;            // [Eg][tiles*64] per-pattern site likelihood (K > 4 gradient: from the logL pass)
   int32_t* site_exp;           // [Eg][tiles*64] its power of two when rescaling
+  int32_t* status;             // [2]: code, tree (schedule does not fit the kernel's LDS slots)
 };
 
 struct FinalizeArgs {

@@ -173,11 +173,11 @@ __global__ __launch_bounds__(kTile) void loglik_onchip_kernel(LikArgs a) {
 // per SIMD (28 MAC/clk/SIMD, 1.8x the FP64 VALU peak), and the VALU stays free
 // for the element-wise products.
 // ------------------------------------------------------------------------
-template <int R, bool RESCALE>
-// (kTile, 2): with at most 256 registers per lane the compiler keeps the products in
+template <int R, bool RESCALE, bool MULTI>
+// (kTile, 5): LDS allows ~20 waves per CU for typical trees; and with at most 256 registers per lane the compiler keeps the products in
 // ordinary vector registers; without the bound it places them in accumulation registers
 // and spends two v_accvgpr_read per product to get them back
-__global__ __launch_bounds__(kTile, 2) void loglik_mfma_kernel(LikArgs a) {
+__global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
   static_assert(R <= 8, "tip masks of one column group are packed in one 32- or 64-bit word");
   using TipWord = std::conditional_t<(R > 4), uint64_t, uint32_t>;
   constexpr unsigned TB = sizeof(TipWord);  // bytes of tip masks per (taxon, column)
@@ -194,7 +194,8 @@ __global__ __launch_bounds__(kTile, 2) void loglik_mfma_kernel(LikArgs a) {
   const int cat = b % Kp, pgrp = b / Kp, ppr = 16 / Kp;  // ppr = patterns per register
   // K > 4: the categories are walked four at a time (`groups` complete walks that only
   // meet in the per-pattern site likelihood); the per-group lane constants follow
-  const int groups = Kp == 4 ? (K + 3) / 4 : 1;
+  // (MULTI: a compile-time 1 keeps the site-likelihood accumulators out of the walk's registers)
+  const int groups = MULTI ? (K + 3) / 4 : 1;
   const char* __restrict__ mats_e =
       reinterpret_cast<const char*>(a.mats + (size_t)e * (a.N - 1) * K * 16);
   unsigned a_off = 0;  // per-lane element of a child's matrix block: A_b[i = lo][k = hi] (bytes)
@@ -202,12 +203,14 @@ __global__ __launch_bounds__(kTile, 2) void loglik_mfma_kernel(LikArgs a) {
   const unsigned node_bytes = (unsigned)K * 128u;
   const int TP = ppr * R, tile_start = te.tile * TP;
   const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
-  int pat[R];
-  double pw[R];
+  // the epilogue's lane (hi, column) owns register r = hi (+4, ...): its pattern and weight
+  constexpr int kOwned = (R + 3) / 4;
+  int own_pat[kOwned];
+  double own_w[kOwned];
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    pat[r] = tile_start + r * ppr + col;
-    pw[r] = a.weights[pat[r] < a.P ? pat[r] : a.P - 1];
+  for (int q = 0; q < kOwned; q++) {
+    own_pat[q] = tile_start + (4 * q + hi) * ppr + col;
+    own_w[q] = a.weights[own_pat[q] < a.P ? own_pat[q] : a.P - 1];
   }
   // LDS: tip state masks [taxon][column][r] (bit s: compatible with state s; first, so
   // that the ignored mask fetch of an internal node id needs no clamping) | schedule |
@@ -396,13 +399,13 @@ __global__ __launch_bounds__(kTile, 2) void loglik_mfma_kernel(LikArgs a) {
   double ll = 0.0;
 #pragma unroll
   for (int r0 = 0; r0 < R; r0 += 4) {
-    double sv = site[r0], wv = pw[r0];
-    int pv = pat[r0], ev = site_exp[r0];
+    double sv = site[r0];
+    const double wv = own_w[r0 / 4];
+    const int pv = own_pat[r0 / 4];
+    int ev = site_exp[r0];
 #pragma unroll
     for (int j = 1; j < 4 && r0 + j < R; j++) {
       sv = hi == j ? site[r0 + j] : sv;
-      wv = hi == j ? pw[r0 + j] : wv;
-      pv = hi == j ? pat[r0 + j] : pv;
       ev = hi == j ? site_exp[r0 + j] : ev;
     }
     const bool owner = r0 + hi < R && cat == 0 && pv < a.P;  // one lane per pattern
@@ -475,12 +478,17 @@ static void launch_loglik_mfma(const LikArgs& a_in, int count, bool rescale, int
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
   const dim3 grid(loglik_mfma_tiles(a.P, a.K), count), block(kTile);
   const size_t lds = loglik_mfma_lds_bytes(a.n, a.K, max_slots);
+  auto go = [&](auto kernel) {
+    allow_large_lds(reinterpret_cast<const void*>(kernel), lds);
+    hipLaunchKernelGGL(kernel, grid, block, lds, s, a);
+  };
+  const bool multi = a.K > 4;
   if (rescale) {
-    allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLogR, true>), lds);
-    hipLaunchKernelGGL((loglik_mfma_kernel<kLogR, true>), grid, block, lds, s, a);
+    if (multi) go(loglik_mfma_kernel<kLogR, true, true>);
+    else go(loglik_mfma_kernel<kLogR, true, false>);
   } else {
-    allow_large_lds(reinterpret_cast<const void*>(loglik_mfma_kernel<kLogR, false>), lds);
-    hipLaunchKernelGGL((loglik_mfma_kernel<kLogR, false>), grid, block, lds, s, a);
+    if (multi) go(loglik_mfma_kernel<kLogR, false, true>);
+    else go(loglik_mfma_kernel<kLogR, false, false>);
   }
 }
 void launch_loglik(const LikArgs& a_in, int count, bool rescale, int max_slots, hipStream_t s) {

@@ -318,6 +318,32 @@ def test_large_trees_and_category_counts(n, K):
                 1e-9 * max(1.0, abs(og["site_model"][t]))
 
 
+@pytest.mark.parametrize("n", [4, 8, 16, 31, 32, 64, 128])
+def test_balanced_trees(n):
+    """Perfectly balanced trees need the most simultaneously live vectors: the worst case
+    for the log-likelihood kernel's LDS slots (it keeps slots only for vectors that are
+    really stored and reports an internal error if a schedule needs more) and for the
+    gradient kernel's half storage."""
+    rng = np.random.default_rng(900 + n)
+    P, T = 70, 3
+    tips, w = TU.random_alignment(n, P, rng)
+    pids, bls = TU.random_trees(n, T, rng, mean_bl=0.05)
+    pids[0] = TU.balanced_topology(n)
+    pids[1] = TU.ladder_topology(n)
+    eng = _engine("JC69", "weibull+4", "strict", tips, w)
+    spec = O.make_spec(n, P, "JC69", "weibull+4", "strict")
+    pr = _params(spec, T, **{"Weibull shape": rng.uniform(0.4, 1.5, size=(T, 1))})
+    for resc in (False, True):
+        ll = eng.log_likelihoods(pids, bls, pr, resc)
+        oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, resc, 3)
+        assert np.all(np.abs(ll - oll) <= RTOL * np.abs(oll))
+        g = eng.gradients(pids, bls, pr, resc)
+        og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 3)
+        for t in range(T):
+            assert abs(g[t].log_likelihood - oll[t]) <= RTOL * abs(oll[t])
+            assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t])
+
+
 def test_rescaling_rescues_underflow():
     """600 taxa x short alignment: unscaled site likelihoods underflow FP64 (logL = -inf
     or NaN without rescaling); with rescaling the engine matches the oracle."""

@@ -51,6 +51,22 @@ def ladder_topology(n, rooted=False):
     return _polish((t, n - 2, n - 1), n)
 
 
+def balanced_topology(n, rooted=False):
+    """Most balanced tree on n leaves (pairs joined level by level): the worst case for
+    the number of simultaneously live partial-likelihood vectors of a post-order walk."""
+    parts = list(range(n))
+    target = 1 if rooted else 3
+    while len(parts) > target:
+        nxt = [(parts[i], parts[i + 1]) for i in range(0, len(parts) - 1, 2)]
+        if len(parts) % 2:
+            nxt.append(parts[-1])
+        if len(nxt) < target:  # unrooted: stop at the trifurcation
+            nxt = [parts[0], parts[1]] + ([tuple(parts[2:])] if len(parts) > 3 else parts[2:])
+        parts = nxt
+    tree = tuple(parts) if not rooted else parts[0]
+    return _polish(tree, n)
+
+
 def random_trees(n, T, rng, rooted=False, mean_bl=0.1):
     nodes = 2 * n - 1 if rooted else 2 * n - 2
     pids = np.stack([random_topology(n, rng, rooted) for _ in range(T)])

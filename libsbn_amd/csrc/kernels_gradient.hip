@@ -2,6 +2,7 @@
 // (gfx950 / CDNA4, wave64; see DESIGN.md for the mapping and what bounds each kernel.)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 
@@ -184,7 +185,13 @@ __device__ __forceinline__ double row_shr_add(double v) {
 //     is made scalar for the control flow
 // LDS per wave: max_stored(n) * R * 512 B of vectors (+ edge sums, tip state masks).
 // ------------------------------------------------------------------------
-template <int R, int DBG = 0, bool RESCALE = false, bool SUBST = false>
+// ARENA (trees whose stored vectors would crowd the LDS): the post-order vectors of the
+// stored nodes go to a per-wave arena in HBM as they are produced and are read back from
+// there by the pre-order walk; LDS then only holds the vectors that are live at one time
+// -- post-order vectors until their consumer's macro, pre-order vectors from the parent's
+// macro to their own: the same intervals walked backwards, so one interval colouring
+// (macro_slots_kernel, packed into the upper halves of the slot fields) serves both walks.
+template <int R, int DBG = 0, bool RESCALE = false, bool SUBST = false, bool ARENA = false>
 __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
   extern __shared__ double glds[];
@@ -214,6 +221,12 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       SUBST ? reinterpret_cast<const char*>(a.phi + (size_t)e * (N - 1) * K * 16) : nullptr;
   const MacroEntry* __restrict__ macros = a.macros + (size_t)t * max_macros(n);
   const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
+  if (ARENA) {
+    // this launch takes the trees whose live vectors fit its LDS slots (and not the
+    // previous, tighter launch's)
+    const int need = __builtin_amdgcn_readfirstlane(a.slot_need[t]);
+    if (need <= a.lds_lo || need > a.lds_slots) return;
+  }
   // byte offsets inside one node's K matrices
   const unsigned f_off = 8u * (catc * 16 + lo * 4 + hi);  // forward:    A[i=lo][k=hi] = P[lo][hi]
   const unsigned t_off = 8u * (catc * 16 + hi * 4 + lo);  // transposed: A[i=lo][k=hi] = P[hi][lo]
@@ -242,7 +255,16 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   double* gacc = glds + ((n * ppr * 4 + 7) >> 3);
   double* plv = gacc + gwidth;
   // RESCALE: per (slot, pattern) power-of-two exponent taken out of a stored vector
-  int32_t* exps = reinterpret_cast<int32_t*>(plv + (size_t)max_stored(n) * R * kTile);
+  int32_t* exps = reinterpret_cast<int32_t*>(
+      plv + (size_t)(ARENA ? a.lds_slots : max_stored(n)) * R * kTile);
+  // ARENA: this wave's [stored node][r][lane] block of post-order vectors in HBM
+  char* const arena =
+      ARENA ? reinterpret_cast<char*>(a.plv + ((size_t)te.eval * gridDim.x + te.tile) *
+                                                   max_stored(n) * R * kTile)
+            : nullptr;
+  // slot fields: ARENA packs (LDS slot << 16 | id of the stored node); else the id is the slot
+  auto lslot = [&](int f) { return ARENA ? (int)((unsigned)f >> 16) : f; };
+  auto uid = [&](int f) { return ARENA ? (f & 0xffff) : f; };
   {
     // tip staging without divisions: the 64 lanes are (taxon group, pattern column) with
     // the column count rounded up to a power of two (TP = 4R, 8R or 16R, R <= 4)
@@ -298,6 +320,29 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
 #pragma unroll
     for (int r = 0; r < R; r++) c[r * kTile] = x.v[r];
   };
+  auto arena_ptr = [&](int id) {
+    asm volatile("" : "+v"(id));
+    return reinterpret_cast<double*>(arena + (__umul24((unsigned)id, (unsigned)(R * kTile * 8)) + lane8));
+  };
+  auto store_arena = [&](int id, const V& x) {
+    double* c = arena_ptr(id);
+#pragma unroll
+    for (int r = 0; r < R; r++) c[r * kTile] = x.v[r];
+  };
+  // ARENA, pre-order walk: the post-order vectors of a macro's stored inputs sit in the
+  // arena at consecutive indices from the macro's base (upper half of its shape word, a
+  // scalar), in position order -- so they can be requested a whole macro ahead, before
+  // the macro's slot fields are even loaded.
+  struct PreL {
+    V x0, y0, x1, y1;
+  };
+  auto arena_at = [&](int k) {  // k is wave-uniform (scalar)
+    V x;
+    const double* c = reinterpret_cast<const double*>(arena + (size_t)k * (R * kTile * 8) + lane8);
+#pragma unroll
+    for (int r = 0; r < R; r++) x.v[r] = c[r * kTile];
+    return x;
+  };
   auto mm = [&](double A, const V& x) {  // block-wise matrix product, R instructions
     V y;
 #pragma unroll
@@ -318,6 +363,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   };
   struct Slots {  // second half: needed during the macro
     int q, cs0, cs1, gs0, gs1, gs2, gs3;
+    int dst;  // ARENA: where this node's post-order vector goes in the arena
   };
   auto load_ids = [&](int m) {
     const int4* p = reinterpret_cast<const int4*>(macros + m);
@@ -327,7 +373,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   auto load_slots = [&](int m) {
     const int4* p = reinterpret_cast<const int4*>(macros + m) + 2;
     const int4 x = p[0], y = p[1];
-    return Slots{x.x, x.y, x.z, x.w, y.x, y.y, y.z};
+    return Slots{x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
   };
   // shape word, scalar: bits 0-1 kind0, 2-3 kind1, 4 root, 8.. tip flags
   auto kind0 = [](int s) { return s & 3; };
@@ -384,33 +430,52 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   struct Ops {
     V q, x0, y0, x1, y1;  // q: pre-order vector; child 0: x0 (,y0 when unstored); child 1
   };
-  auto load_ops = [&](int sh, const Slots& sl, const MacroMats& cm, bool pre) {
+  auto is_tip_early = [](int s, int j) { return ((s >> (8 + j)) & 1) != 0; };
+  auto prefetch_L = [&](int sh) {
+    PreL p;
+    int k = (int)((unsigned)sh >> 16);
+    if ((sh & 3) == 2) {
+      if (!is_tip_early(sh, 2)) p.x0 = arena_at(k++);
+      if (!is_tip_early(sh, 3)) p.y0 = arena_at(k++);
+    } else if ((sh & 3) == 1) {
+      p.x0 = arena_at(k++);
+    }
+    if (((sh >> 2) & 3) == 2) {
+      if (!is_tip_early(sh, 4)) p.x1 = arena_at(k++);
+      if (!is_tip_early(sh, 5)) p.y1 = arena_at(k++);
+    } else if (((sh >> 2) & 3) == 1) {
+      p.x1 = arena_at(k++);
+    }
+    return p;
+  };
+  auto load_ops = [&](int sh, const Slots& sl, const MacroMats& cm, bool pre, const PreL& pl) {
     Ops o;
+    const bool from_arena = ARENA && pre;
     if (pre) {
       if (is_root(sh)) {
 #pragma unroll
         for (int r = 0; r < R; r++) o.q.v[r] = qroot[r];
       } else {
-        o.q = load_slot(sl.q);
+        o.q = load_slot(lslot(sl.q));
         if (RESCALE) {
 #pragma unroll
           for (int r = 0; r < R; r++)
-            o.q.v[r] = ldexp(o.q.v[r], -exps[__umul24((unsigned)sl.q, (unsigned)TP) +
+            o.q.v[r] = ldexp(o.q.v[r], -exps[__umul24((unsigned)uid(sl.q), (unsigned)TP) +
                                               (unsigned)(r * ppr + col)]);
         }
       }
     }
     if (kind0(sh) == 2) {
-      o.x0 = is_tip(sh, 2) ? tip_vector(cm.tw[2]) : load_slot(sl.gs0);
-      o.y0 = is_tip(sh, 3) ? tip_vector(cm.tw[3]) : load_slot(sl.gs1);
+      o.x0 = is_tip(sh, 2) ? tip_vector(cm.tw[2]) : (from_arena ? pl.x0 : load_slot(lslot(sl.gs0)));
+      o.y0 = is_tip(sh, 3) ? tip_vector(cm.tw[3]) : (from_arena ? pl.y0 : load_slot(lslot(sl.gs1)));
     } else {
-      o.x0 = is_tip(sh, 0) ? tip_vector(cm.tw[0]) : load_slot(sl.cs0);
+      o.x0 = is_tip(sh, 0) ? tip_vector(cm.tw[0]) : (from_arena ? pl.x0 : load_slot(lslot(sl.cs0)));
     }
     if (kind1(sh) == 2) {
-      o.x1 = is_tip(sh, 4) ? tip_vector(cm.tw[4]) : load_slot(sl.gs2);
-      o.y1 = is_tip(sh, 5) ? tip_vector(cm.tw[5]) : load_slot(sl.gs3);
+      o.x1 = is_tip(sh, 4) ? tip_vector(cm.tw[4]) : (from_arena ? pl.x1 : load_slot(lslot(sl.gs2)));
+      o.y1 = is_tip(sh, 5) ? tip_vector(cm.tw[5]) : (from_arena ? pl.y1 : load_slot(lslot(sl.gs3)));
     } else {
-      o.x1 = is_tip(sh, 1) ? tip_vector(cm.tw[1]) : load_slot(sl.cs1);
+      o.x1 = is_tip(sh, 1) ? tip_vector(cm.tw[1]) : (from_arena ? pl.x1 : load_slot(lslot(sl.cs1)));
     }
     return o;
   };
@@ -441,10 +506,11 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
           const int ex = mx > 0.0 ? ilogb(mx) : 0;
           Lv.v[r] = ldexp(Lv.v[r], -ex);
           esum[r] += ex;
-          exps[__umul24((unsigned)sl.q, (unsigned)TP) + (unsigned)(r * ppr + col)] = ex;
+          exps[__umul24((unsigned)uid(sl.q), (unsigned)TP) + (unsigned)(r * ppr + col)] = ex;
         }
       }
-      store_slot(sl.q, Lv);
+      store_slot(lslot(sl.q), Lv);
+      if (ARENA) store_arena(sl.dst, Lv);
     } else {
       // root: site likelihood per pattern, log-likelihood partial, derivative weights
       double sitev[R];
@@ -512,14 +578,14 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     MacroMats ma = fetch_mats(ia, false), mb;
     ib = load_ids(M > 1 ? 1 : 0);
     for (int m = 0; m < M; m += 2) {
-      const Ops oa = load_ops(sha, sa, ma, false);
+      const Ops oa = load_ops(sha, sa, ma, false, PreL{});
       shb = __builtin_amdgcn_readfirstlane(ib.shape);
       mb = fetch_mats(ib, false);
       ia = load_ids(m + 2 < M ? m + 2 : M - 1);
       sb = load_slots(m + 1 < M ? m + 1 : M - 1);
       post_step(sha, sa, ma, oa);
       if (m + 1 < M) {
-        const Ops ob = load_ops(shb, sb, mb, false);
+        const Ops ob = load_ops(shb, sb, mb, false, PreL{});
         sha = __builtin_amdgcn_readfirstlane(ia.shape);
         ma = fetch_mats(ia, false);
         ib = load_ids(m + 3 < M ? m + 3 : M - 1);
@@ -613,7 +679,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       if (SUBST) subst_stats(qs, Lc, phi);
       if (tip) return mul(qs, mm(trm, Lc));
       qc = mm(trm, qs);
-      if (keep) store_slot(slot, qc);
+      if (keep) store_slot(lslot(slot), qc);
       return mul(qc, mm(AQ, Lc));
     };
     V q0, q1;
@@ -647,17 +713,21 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     int sha = __builtin_amdgcn_readfirstlane(ia.shape), shb = 0;
     MacroMats ma = fetch_mats(ia, true), mb;
     ib = load_ids(M > 1 ? M - 2 : 0);
+    PreL la, lb;  // ARENA: stored inputs of the macro after the current one, in flight
+    if (ARENA) la = prefetch_L(sha);
     for (int m = M - 1; m >= 0; m -= 2) {
-      const Ops oa = load_ops(sha, sa, ma, true);
+      const Ops oa = load_ops(sha, sa, ma, true, la);
       shb = __builtin_amdgcn_readfirstlane(ib.shape);
       mb = fetch_mats(ib, true);
+      if (ARENA) lb = prefetch_L(shb);
       ia = load_ids(m >= 2 ? m - 2 : 0);
       sb = load_slots(m >= 1 ? m - 1 : 0);
       pre_step(sha, sa, ma, oa, m);
       if (m >= 1) {
-        const Ops ob = load_ops(shb, sb, mb, true);
+        const Ops ob = load_ops(shb, sb, mb, true, lb);
         sha = __builtin_amdgcn_readfirstlane(ia.shape);
         ma = fetch_mats(ia, true);
+        if (ARENA) la = prefetch_L(sha);
         ib = load_ids(m >= 3 ? m - 3 : 0);
         sa = load_slots(m >= 2 ? m - 2 : 0);
         pre_step(shb, sb, mb, ob, m - 1);
@@ -691,14 +761,18 @@ void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t 
     else hipLaunchKernelGGL((gradient_hbm_kernel<false, false>), grid, block, 0, s, a);
   }
 }
-size_t gradient_mfma_lds_bytes(int n, int K, bool rescale, bool subst) {
+// LDS bytes of a wave that keeps `slots` vectors (tip masks, edge sums, vectors, exponents)
+static size_t gradient_mfma_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
   const size_t tip_bytes = (((size_t)n * 4 * (16 / kp) + 7) / 8) * 8;
-  size_t bytes = tip_bytes + sizeof(double) * ((size_t)max_stored(n) * kLlR * kTile +
+  size_t bytes = tip_bytes + sizeof(double) * ((size_t)slots * kLlR * kTile +
                                                gradient_mfma_width(n, subst));
   if (rescale) bytes += sizeof(int32_t) * (size_t)max_stored(n) * kLlR * (16 / kp);
   const size_t reach = (size_t)(2 * n - 1) * 4 * (16 / kp);  // mask fetches of internal ids
   return bytes > reach ? bytes : reach;
+}
+size_t gradient_mfma_lds_bytes(int n, int K, bool rescale, bool subst) {
+  return gradient_mfma_lds_bytes_for(n, K, rescale, subst, max_stored(n));
 }
 int gradient_mfma_width(int n, bool subst) {
   return max_macros(n) * kMacroPositions * 2 + (subst ? kSubstExtra : 0);
@@ -708,15 +782,192 @@ int gradient_mfma_tiles(int P, int K) {
   const int per_wave = kLlR * (16 / (K == 1 ? 1 : (K == 2 ? 2 : 4)));
   return (P + per_wave - 1) / per_wave;
 }
-bool gradient_mfma_fits(int n, int K, bool rescale) {
-  return n >= 3 && K <= kMaxCategories &&
-         gradient_mfma_lds_bytes(n, K, rescale, true) <= 160 * 1024;
+// ---- arena variant: LDS slots of the two launches ----
+// Live vectors of the macro walk: each is either live in the node-level Sethi-Ullman walk
+// (at most floor(log2 n) at a time) or one of the two children of an unstored node that
+// is, so 2 floor(log2 n) always suffice (second launch); floor(log2 n) + 2 is what trees
+// need in practice (first launch: random, ladder and balanced trees up to 200 taxa never
+// exceeded floor(log2 n) + 1 in simulation).
+static int floor_log2(int n) {
+  int lg = 0;
+  while ((2 << lg) <= n) lg++;
+  return lg;
 }
-template <bool RESCALE, bool SUBST>
+int gradient_arena_slots_sure(int n) { return std::max(1, std::min(max_stored(n), 2 * floor_log2(n))); }
+int gradient_arena_slots_usual(int n) { return std::min(gradient_arena_slots_sure(n), floor_log2(n) + 2); }
+size_t gradient_arena_bytes_per_eval(int n, int P, int K) {
+  return (size_t)gradient_mfma_tiles(P, K) * gradient_mfma_groups(K) * max_stored(n) * kLlR * kTile *
+         sizeof(double);
+}
+// The arena variant runs when keeping every stored vector in LDS would leave 6 or fewer
+// waves per CU (the registers allow 8), or would not fit at all: measured cross-over with
+// 934 patterns at 31-32 taxa (29 taxa: 1.34 ms per 1000 trees in LDS / 1.47 arena; 32: 1.60 /
+// 1.56; 42: 2.79 / 2.03).  MI_PHYLO_GRADIENT_STORE=lds|arena forces one of the two.
+bool gradient_mfma_use_arena(int n, int K, bool rescale, bool subst) {
+  static const int forced = [] {
+    const char* env = getenv("MI_PHYLO_GRADIENT_STORE");
+    if (!env) return 0;
+    return std::string(env) == "arena" ? 2 : (std::string(env) == "lds" ? 1 : 0);
+  }();
+  const size_t lds_all = gradient_mfma_lds_bytes(n, K, rescale, subst);
+  const bool lds_fits = lds_all <= 160 * 1024;
+  if (forced == 1 && lds_fits) return false;
+  if (forced == 2) return true;
+  return !lds_fits || (160 * 1024) / lds_all < 7;
+}
+bool gradient_mfma_fits(int n, int K, bool rescale) {
+  if (n < 3 || K > kMaxCategories) return false;
+  if (gradient_mfma_lds_bytes(n, K, rescale, true) <= 160 * 1024) return true;
+  return gradient_mfma_lds_bytes_for(n, K, rescale, true, gradient_arena_slots_sure(n)) <= 160 * 1024;
+}
+
+// One thread per tree: the macro schedule re-ordered and given reusable LDS slots.
+// tree_setup lists the macros by node id -- a post-order, but one that can keep many
+// vectors alive.  Here the macro tree (a macro's inputs are the stored nodes among its
+// children / grandchildren, up to four) is walked Sethi-Ullman style, the input needing
+// the most slots first, and the stored vectors' LDS slots are an interval colouring in
+// that order (free the inputs' slots, take the lowest free one for the node), packed
+// into the upper halves of the slot fields.  need[t] = slots the tree uses.
+struct MacroInputs {
+  int count;
+  int field[4];  // which slot field: 0,1 = cslot[j]; 2..5 = gslot[g]
+};
+__device__ inline MacroInputs macro_inputs(const MacroEntry& e) {  // which inputs are stored nodes
+  MacroInputs in{0, {0, 0, 0, 0}};
+  for (int j = 0; j < 2; j++) {
+    const int kind = (e.shape >> (2 * j)) & 3;
+    if (kind == 1) in.field[in.count++] = j;
+    if (kind == 2)
+      for (int g = 2 * j; g < 2 * j + 2; g++)
+        if (!((e.shape >> (10 + g)) & 1)) in.field[in.count++] = 2 + g;
+  }
+  return in;
+}
+__device__ inline int32_t& macro_field(MacroEntry& e, int f) { return f < 2 ? e.cslot[f] : e.gslot[f - 2]; }
+// (a wave per tree: the entries are staged in LDS by all lanes, lane 0 does the walk)
+__global__ __launch_bounds__(kTile) void macro_slots_kernel(const MacroEntry* macros_in,
+                                                            MacroEntry* macros_out,
+                                                            const int32_t* macro_count, int n, int T,
+                                                            int32_t* need, int sure, int32_t* status) {
+  extern __shared__ int32_t slot_scratch[];
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int Mmax = max_macros(n), S = max_stored(n);
+  MacroEntry* ent = reinterpret_cast<MacroEntry*>(slot_scratch);
+  int32_t* mac_of = slot_scratch + (size_t)Mmax * (sizeof(MacroEntry) / 4);  // stored id -> macro, later -> LDS slot
+  int32_t* label = mac_of + S;
+  int32_t* order = label + Mmax;
+  int32_t* stack = order + Mmax;
+  const int M = macro_count[t];
+  if (M <= 0) {
+    if (lane == 0) need[t] = 0;
+    return;
+  }
+  {
+    const int32_t* src = reinterpret_cast<const int32_t*>(macros_in + (size_t)t * Mmax);
+    for (int i = lane; i < M * 16; i += kTile) slot_scratch[i] = src[i];
+  }
+  __syncthreads();
+  if (lane == 0) {
+    // inputs of a macro as macro indices, sorted by label, largest first
+    auto sorted_inputs = [&](MacroEntry& e, int* idx) {
+      const MacroInputs mi = macro_inputs(e);
+      for (int i = 0; i < mi.count; i++) idx[i] = mac_of[macro_field(e, mi.field[i])];
+      for (int i = 1; i < mi.count; i++)
+        for (int k = i; k > 0 && label[idx[k]] > label[idx[k - 1]]; k--) {
+          const int x = idx[k];
+          idx[k] = idx[k - 1];
+          idx[k - 1] = x;
+        }
+      return mi.count;
+    };
+    // 1. labels, bottom-up (the given order is a post-order)
+    for (int m = 0; m < M; m++) {
+      int idx[4];
+      const int k = sorted_inputs(ent[m], idx);
+      const bool root = (ent[m].shape & 16) != 0;
+      int l = root ? k : (k > 1 ? k : 1);
+      for (int i = 0; i < k; i++) l = l > label[idx[i]] + i ? l : label[idx[i]] + i;
+      label[m] = l;
+      if (!root) mac_of[ent[m].qslot] = m;
+    }
+    // 2. post-order from the root (the last macro), largest label first
+    int top = 0, emitted = 0;
+    stack[top++] = (M - 1) << 1;
+    while (top) {
+      const int item = stack[--top];
+      const int m = item >> 1;
+      if (item & 1) {
+        order[emitted++] = m;
+        continue;
+      }
+      stack[top++] = item | 1;
+      int idx[4];
+      const int k = sorted_inputs(ent[m], idx);
+      for (int i = k - 1; i >= 0; i--) stack[top++] = idx[i] << 1;  // idx[0] is popped first
+    }
+    // 2b. arena indices: a macro's stored inputs are numbered consecutively in position
+    // order from the macro's base (upper half of its shape word); each input is told where
+    // its vector goes (pad field)
+    int next_index = 0;
+    for (int o = 0; o < M; o++) {
+      MacroEntry& e = ent[order[o]];
+      const MacroInputs mi = macro_inputs(e);
+      e.shape |= next_index << 16;
+      for (int i = 0; i < mi.count; i++) ent[mac_of[macro_field(e, mi.field[i])]].pad = next_index++;
+    }
+    // 3. slots in that order (packed in place); mac_of becomes stored id -> LDS slot
+    uint64_t free_mask = ~0ull;
+    int used = 0;
+    for (int o = 0; o < M; o++) {
+      MacroEntry& e = ent[order[o]];
+      const MacroInputs mi = macro_inputs(e);
+      for (int i = 0; i < mi.count; i++) {
+        int32_t& f = macro_field(e, mi.field[i]);
+        const int s = mac_of[f];
+        free_mask |= 1ull << s;
+        f |= s << 16;
+      }
+      if (!(e.shape & 16)) {
+        const int s = __ffsll((unsigned long long)free_mask) - 1;
+        free_mask &= ~(1ull << s);
+        mac_of[e.qslot] = s;
+        e.qslot |= s << 16;
+        if (s + 1 > used) used = s + 1;
+      }
+    }
+    need[t] = used;
+    if (used > sure || emitted != M) set_status(status, kTooManySlots, t);
+  }
+  __syncthreads();
+  {
+    int32_t* dst = reinterpret_cast<int32_t*>(macros_out + (size_t)t * Mmax);
+    for (int i = lane; i < M * 16; i += kTile) dst[i] = slot_scratch[order[i >> 4] * 16 + (i & 15)];
+  }
+}
+void launch_macro_slots(const MacroEntry* macros_in, MacroEntry* macros_out,
+                        const int32_t* macro_count, int n, int T, int32_t* need, int32_t* status,
+                        hipStream_t s) {
+  const size_t lds = sizeof(MacroEntry) * (size_t)max_macros(n) +
+                     sizeof(int32_t) * ((size_t)max_stored(n) + 3 * (size_t)max_macros(n));
+  allow_large_lds(reinterpret_cast<const void*>(macro_slots_kernel), lds);
+  hipLaunchKernelGGL(macro_slots_kernel, dim3(T), dim3(kTile), lds, s, macros_in, macros_out,
+                     macro_count, n, T, need, gradient_arena_slots_sure(n), status);
+}
+
+template <bool RESCALE, bool SUBST, bool ARENA>
 static void launch_gradient_mfma_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  allow_large_lds(reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR, 0, RESCALE, SUBST>),
-                  lds);
-  hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 0, RESCALE, SUBST>), grid, dim3(kTile), lds, s, a);
+  allow_large_lds(
+      reinterpret_cast<const void*>(gradient_mfma_kernel<kLlR, 0, RESCALE, SUBST, ARENA>), lds);
+  hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 0, RESCALE, SUBST, ARENA>), grid, dim3(kTile), lds, s,
+                     a);
+}
+template <bool ARENA>
+static void launch_gradient_mfma_store(const LikArgs& a, dim3 grid, size_t lds, bool rescale,
+                                       bool subst, hipStream_t s) {
+  if (rescale && subst) launch_gradient_mfma_variant<true, true, ARENA>(a, grid, lds, s);
+  else if (rescale) launch_gradient_mfma_variant<true, false, ARENA>(a, grid, lds, s);
+  else if (subst) launch_gradient_mfma_variant<false, true, ARENA>(a, grid, lds, s);
+  else launch_gradient_mfma_variant<false, false, ARENA>(a, grid, lds, s);
 }
 void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool subst,
                           hipStream_t s) {
@@ -724,12 +975,26 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool sub
   LikArgs a = a_in;
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
   a.cat_groups = gradient_mfma_groups(a.K);
-  const size_t lds = gradient_mfma_lds_bytes(a.n, a.K, rescale, subst);
   const dim3 grid(gradient_mfma_tiles(a.P, a.K) * a.cat_groups, count);
+  if (gradient_mfma_use_arena(a.n, a.K, rescale, subst)) {
+    // two launches over the same grid: the trees that fit the usual number of LDS slots,
+    // then (more LDS per wave) the rest; a wave of the other launch's tree exits at once
+    const int usual = gradient_arena_slots_usual(a.n), sure = gradient_arena_slots_sure(a.n);
+    a.lds_lo = -1;
+    a.lds_slots = usual;
+    launch_gradient_mfma_store<true>(
+        a, grid, gradient_mfma_lds_bytes_for(a.n, a.K, rescale, subst, usual), rescale, subst, s);
+    if (sure > usual) {
+      a.lds_lo = usual;
+      a.lds_slots = sure;
+      launch_gradient_mfma_store<true>(
+          a, grid, gradient_mfma_lds_bytes_for(a.n, a.K, rescale, subst, sure), rescale, subst, s);
+    }
+    return;
+  }
+  const size_t lds = gradient_mfma_lds_bytes(a.n, a.K, rescale, subst);
   if (rescale || subst) {
-    if (rescale && subst) launch_gradient_mfma_variant<true, true>(a, grid, lds, s);
-    else if (rescale) launch_gradient_mfma_variant<true, false>(a, grid, lds, s);
-    else launch_gradient_mfma_variant<false, true>(a, grid, lds, s);
+    launch_gradient_mfma_store<false>(a, grid, lds, rescale, subst, s);
     return;
   }
   // ablation builds: 1 no matrix products, 2 no cross-lane reductions,
@@ -745,7 +1010,7 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool sub
     case 128: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 128>), grid, dim3(kTile), lds, s, a); return;
     default: break;
   }
-  launch_gradient_mfma_variant<false, false>(a, grid, lds, s);
+  launch_gradient_mfma_store<false>(a, grid, lds, false, false, s);
 }
 const char* gradient_kernel_name() { return "gradient_hbm_kernel"; }
 const char* gradient_mfma_kernel_name() { return "gradient_mfma_kernel"; }

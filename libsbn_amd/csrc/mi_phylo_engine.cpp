@@ -147,7 +147,7 @@ struct mi_engine {
   Buffer tip_states, tip_partials, tip_masks, weights;
   bool have_tip_masks = false;  // every tip vector is 0/1: the matrix-core kernel can run
   // per-call workspace
-  Buffer tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
+  Buffer arena_macros, slot_need, tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
       ll_sum, g_sum, status;
   PinnedArena pinned;
   bool allow_onchip_gradient = true;
@@ -225,6 +225,15 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
     const size_t per = plv_bytes_per_eval(e);
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / per));
     if (need_hbm_path && e->plv.ensure(per * chunk)) return 1;
+    // the arena variant of the matrix-core kernel keeps its stored vectors in the same buffer
+    if (!need_hbm_path && (gradient_mfma_use_arena(n, e->K, false, true) ||
+                           gradient_mfma_use_arena(n, e->K, true, true))) {
+      const size_t aper = gradient_arena_bytes_per_eval(n, e->P, e->K);
+      const size_t achunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / aper));
+      if (e->plv.ensure(aper * achunk)) return 1;
+      if (e->arena_macros.ensure(sizeof(MacroEntry) * (size_t)T * max_macros(n))) return 1;
+      if (e->slot_need.ensure(sizeof(int32_t) * (size_t)T)) return 1;
+    }
     const size_t g_width = std::max<size_t>(2 * (size_t)N, (size_t)gradient_mfma_width(n, true));
     if (e->g_part.ensure(sizeof(double) * (size_t)c.Eg * e->ll_stride * gradient_mfma_groups(e->K) *
                          g_width))
@@ -293,6 +302,11 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // the Sethi-Ullman schedule with LDS slots is what the log-likelihood kernels walk
   ts.need_slots = !(d.gradient && mfma && groups == 1 && (!c.gtr || analytic));
   launch_tree_setup(ts, s);
+  const bool arena = mfma && gradient_mfma_use_arena(n, e->K, d.rescaling, analytic);
+  if (arena)
+    launch_macro_slots(e->macros.as<MacroEntry>(), e->arena_macros.as<MacroEntry>(),
+                       e->macro_count.as<int32_t>(), n, T, e->slot_need.as<int32_t>(),
+                       e->status.as<int32_t>(), s);
 
   ModelSetupArgs ms{};
   ms.T = T;
@@ -349,7 +363,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.map = map;
   la.models = e->models.as<DevModel>();
   la.sched = e->sched.as<SchedEntry>();
-  la.macros = e->macros.as<MacroEntry>();
+  la.macros = arena ? e->arena_macros.as<MacroEntry>() : e->macros.as<MacroEntry>();
   la.macro_count = e->macro_count.as<int32_t>();
   la.mats = e->mats.as<double>();
   la.tip_tables = e->tip_tables.as<double>();
@@ -365,6 +379,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
 
   la.site_lik = nullptr;
   la.status = e->status.as<int32_t>();
+  la.slot_need = e->slot_need.as<int32_t>();
   // one launch covers at most kMaxEvals evaluations (grid y dimension: 65535; a multiple
   // of 8 keeps whole evaluations per XCD)
   constexpr int kMaxEvals = 32768;
@@ -377,8 +392,14 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   };
   auto grad_range = [&](int eval_begin, int grad_begin, int count) {
     if (mfma) {
-      for (int done = 0; done < count; done += kMaxEvals) {
-        const int part = std::min(kMaxEvals, count - done);
+      // (arena variant: a launch covers what its HBM arena holds)
+      const int max_part =
+          arena ? (int)std::max<size_t>(
+                      1, std::min<size_t>(kMaxEvals, e->plv.bytes / gradient_arena_bytes_per_eval(
+                                                                        n, e->P, e->K)))
+                : kMaxEvals;
+      for (int done = 0; done < count; done += max_part) {
+        const int part = std::min(max_part, count - done);
         LikArgs g = la;
         g.eval_offset = eval_begin + done;
         g.grad_offset = grad_begin + done;
@@ -449,7 +470,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     ra.x_sum = e->x_sum.as<double>();
     ra.n = n;
     ra.T = T;
-    ra.macros = e->macros.as<MacroEntry>();
+    ra.macros = arena ? e->arena_macros.as<MacroEntry>() : e->macros.as<MacroEntry>();
     ra.macro_count = e->macro_count.as<int32_t>();
     launch_reduce_tiles(ra, s);
     fa.ll_tiles = 1;
@@ -699,6 +720,7 @@ void mi_engine_destroy(mi_engine* e) {
   }
   for (Buffer* b :
        {&e->tip_states, &e->tip_partials, &e->tip_masks, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
+        &e->arena_macros, &e->slot_need,
         &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,
         &e->ll_sum, &e->g_sum, &e->status,

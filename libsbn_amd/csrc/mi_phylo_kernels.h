@@ -97,6 +97,8 @@ struct LikArgs {
   double* site_lik;            // [Eg][tiles*64] per-pattern site likelihood (K > 4 gradient: from the logL pass)
   int32_t* site_exp;           // [Eg][tiles*64] its power of two when rescaling
   int32_t* status;             // [2]: code, tree (schedule does not fit the kernel's LDS slots)
+  const int32_t* slot_need;    // [T] arena gradient kernel: LDS slots each tree's schedule uses
+  int lds_lo;                  // arena gradient kernel: this launch takes trees with lds_lo < need <= lds_slots
 };
 
 struct FinalizeArgs {
@@ -145,6 +147,13 @@ int gradient_mfma_groups(int K);  // waves per pattern tile (category groups of 
 // subst: analytic substitution gradient statistics appended (kSubstExtra doubles)
 int gradient_mfma_width(int n, bool subst = false);  // doubles per (gradient evaluation, tile) of its partial sums
 void launch_gradient_mfma(const LikArgs& a, int count, bool rescale, bool subst, hipStream_t s);
+// arena variant of the matrix-core gradient kernel (stored post-order vectors in HBM, LDS
+// slots reused): when it runs, its slot assignment pass, and its HBM need per evaluation
+bool gradient_mfma_use_arena(int n, int K, bool rescale, bool subst);
+void launch_macro_slots(const MacroEntry* macros_in, MacroEntry* macros_out,
+                        const int32_t* macro_count, int n, int T, int32_t* need, int32_t* status,
+                        hipStream_t s);
+size_t gradient_arena_bytes_per_eval(int n, int P, int K);
 // Sum of the per-tile partials: ll_sum[e] = sum_i ll_part[e][i] for e < E,
 // g_sum[gi][2N] = sum_i g_part[gi][i][2N] for gi < Eg (fixed order: deterministic).
 struct ReduceArgs {

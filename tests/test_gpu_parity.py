@@ -492,6 +492,53 @@ print('path-ok')
     assert "path-ok" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("store", ["lds", "arena"])
+def test_both_gradient_stores_match_oracle(store):
+    """The matrix-core gradient kernel keeps the stored post-order vectors either all in LDS
+    (small trees) or in an HBM arena with a few reusable LDS slots (MI_PHYLO_GRADIENT_STORE
+    forces one; chosen once per process, hence the subprocess): same parity bar, on DS1
+    (27 taxa) and on 40- and 70-taxon random / ladder / balanced trees, with and without
+    rescaling, constant rate and four categories, FD and analytic GTR gradients."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, os, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import oracle_lib as O, libsbn_amd as L, tree_utils as TU
+import test_gpu_parity as TG
+st = O.load_struct('ds1_sub10'); tips, w, pids, bls = O.struct_arrays(st)
+cases = [(tips, w, pids, bls)]
+rng = np.random.default_rng(77)
+for n in (40, 70):
+    t2, w2 = TU.random_alignment(n, 90, rng)
+    p2, b2 = TU.random_trees(n, 4, rng, mean_bl=0.05)
+    p2[0] = TU.balanced_topology(n); p2[1] = TU.ladder_topology(n)
+    cases.append((t2, w2, p2, b2))
+for tips, w, pids, bls in cases:
+    n, P = tips.shape; T = len(pids)
+    for subst, site in (('JC69', 'constant'), ('JC69', 'weibull+4'), ('GTR', 'weibull+4')):
+        eng = L.Engine(L.PhyloModelSpecification(subst, site, 'strict'), tips, w)
+        spec = O.make_spec(n, P, subst, site, 'strict')
+        blocks = {}
+        if subst == 'GTR':
+            r, f = TU.random_gtr_params(T, rng); blocks['GTR rates'] = r; blocks['frequencies'] = f
+        if site != 'constant': blocks['Weibull shape'] = rng.uniform(0.4, 1.5, size=(T, 1))
+        pr = TG._params(spec, T, **blocks)
+        for resc in (False, True):
+            g = eng.gradients(pids, bls, pr, resc)
+            assert eng.last_call_info()[0] == 'gradient_mfma_kernel', eng.last_call_info()
+            og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 4)
+            for t in range(T):
+                assert abs(g[t].log_likelihood - og['log_likelihood'][t]) <= 1e-10 * abs(og['log_likelihood'][t])
+                assert TG._close(g[t].gradient['branch_lengths'], og['branch_lengths'][t]), (n, subst, site, resc, t)
+print('store-ok')
+"""
+    env = dict(os.environ, MI_PHYLO_GRADIENT_STORE=store)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "store-ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_random_rooted_vs_oracle():
     rng = np.random.default_rng(7)
     n, P, T = 12, 77, 4

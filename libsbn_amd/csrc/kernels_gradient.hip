@@ -190,7 +190,7 @@ __device__ __forceinline__ double row_shr_add(double v) {
 // there by the pre-order walk; LDS then only holds the vectors that are live at one time
 // -- post-order vectors until their consumer's macro, pre-order vectors from the parent's
 // macro to their own: the same intervals walked backwards, so one interval colouring
-// (macro_slots_kernel, packed into the upper halves of the slot fields) serves both walks.
+// (macro_slots_kernel) serves both walks.
 template <int R, int DBG = 0, bool RESCALE = false, bool SUBST = false, bool ARENA = false>
 __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
@@ -262,9 +262,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       ARENA ? reinterpret_cast<char*>(a.plv + ((size_t)te.eval * gridDim.x + te.tile) *
                                                    max_stored(n) * R * kTile)
             : nullptr;
-  // slot fields: ARENA packs (LDS slot << 16 | id of the stored node); else the id is the slot
-  auto lslot = [&](int f) { return ARENA ? (int)((unsigned)f >> 16) : f; };
-  auto uid = [&](int f) { return ARENA ? (f & 0xffff) : f; };
+  // (ARENA: the slot fields of the re-ordered schedule are the reusable LDS slots, and a
+  // stored node is identified by its arena index `dst`)
   {
     // tip staging without divisions: the 64 lanes are (taxon group, pattern column) with
     // the column count rounded up to a power of two (TP = 4R, 8R or 16R, R <= 4)
@@ -338,7 +337,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   };
   auto arena_at = [&](int k) {  // k is wave-uniform (scalar)
     V x;
-    const double* c = reinterpret_cast<const double*>(arena + (size_t)k * (R * kTile * 8) + lane8);
+    const double* c =
+        reinterpret_cast<const double*>(arena + ((unsigned)k * (unsigned)(R * kTile * 8) + lane8));
 #pragma unroll
     for (int r = 0; r < R; r++) x.v[r] = c[r * kTile];
     return x;
@@ -456,26 +456,26 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
 #pragma unroll
         for (int r = 0; r < R; r++) o.q.v[r] = qroot[r];
       } else {
-        o.q = load_slot(lslot(sl.q));
+        o.q = load_slot(sl.q);
         if (RESCALE) {
 #pragma unroll
           for (int r = 0; r < R; r++)
-            o.q.v[r] = ldexp(o.q.v[r], -exps[__umul24((unsigned)uid(sl.q), (unsigned)TP) +
+            o.q.v[r] = ldexp(o.q.v[r], -exps[__umul24((unsigned)(ARENA ? sl.dst : sl.q), (unsigned)TP) +
                                               (unsigned)(r * ppr + col)]);
         }
       }
     }
     if (kind0(sh) == 2) {
-      o.x0 = is_tip(sh, 2) ? tip_vector(cm.tw[2]) : (from_arena ? pl.x0 : load_slot(lslot(sl.gs0)));
-      o.y0 = is_tip(sh, 3) ? tip_vector(cm.tw[3]) : (from_arena ? pl.y0 : load_slot(lslot(sl.gs1)));
+      o.x0 = is_tip(sh, 2) ? tip_vector(cm.tw[2]) : (from_arena ? pl.x0 : load_slot(sl.gs0));
+      o.y0 = is_tip(sh, 3) ? tip_vector(cm.tw[3]) : (from_arena ? pl.y0 : load_slot(sl.gs1));
     } else {
-      o.x0 = is_tip(sh, 0) ? tip_vector(cm.tw[0]) : (from_arena ? pl.x0 : load_slot(lslot(sl.cs0)));
+      o.x0 = is_tip(sh, 0) ? tip_vector(cm.tw[0]) : (from_arena ? pl.x0 : load_slot(sl.cs0));
     }
     if (kind1(sh) == 2) {
-      o.x1 = is_tip(sh, 4) ? tip_vector(cm.tw[4]) : (from_arena ? pl.x1 : load_slot(lslot(sl.gs2)));
-      o.y1 = is_tip(sh, 5) ? tip_vector(cm.tw[5]) : (from_arena ? pl.y1 : load_slot(lslot(sl.gs3)));
+      o.x1 = is_tip(sh, 4) ? tip_vector(cm.tw[4]) : (from_arena ? pl.x1 : load_slot(sl.gs2));
+      o.y1 = is_tip(sh, 5) ? tip_vector(cm.tw[5]) : (from_arena ? pl.y1 : load_slot(sl.gs3));
     } else {
-      o.x1 = is_tip(sh, 1) ? tip_vector(cm.tw[1]) : (from_arena ? pl.x1 : load_slot(lslot(sl.cs1)));
+      o.x1 = is_tip(sh, 1) ? tip_vector(cm.tw[1]) : (from_arena ? pl.x1 : load_slot(sl.cs1));
     }
     return o;
   };
@@ -506,10 +506,10 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
           const int ex = mx > 0.0 ? ilogb(mx) : 0;
           Lv.v[r] = ldexp(Lv.v[r], -ex);
           esum[r] += ex;
-          exps[__umul24((unsigned)uid(sl.q), (unsigned)TP) + (unsigned)(r * ppr + col)] = ex;
+          exps[__umul24((unsigned)(ARENA ? sl.dst : sl.q), (unsigned)TP) + (unsigned)(r * ppr + col)] = ex;
         }
       }
-      store_slot(lslot(sl.q), Lv);
+      store_slot(sl.q, Lv);
       if (ARENA) store_arena(sl.dst, Lv);
     } else {
       // root: site likelihood per pattern, log-likelihood partial, derivative weights
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       if (SUBST) subst_stats(qs, Lc, phi);
       if (tip) return mul(qs, mm(trm, Lc));
       qc = mm(trm, qs);
-      if (keep) store_slot(lslot(slot), qc);
+      if (keep) store_slot(slot, qc);
       return mul(qc, mm(AQ, Lc));
     };
     V q0, q1;
@@ -826,8 +826,9 @@ bool gradient_mfma_fits(int n, int K, bool rescale) {
 // vectors alive.  Here the macro tree (a macro's inputs are the stored nodes among its
 // children / grandchildren, up to four) is walked Sethi-Ullman style, the input needing
 // the most slots first, and the stored vectors' LDS slots are an interval colouring in
-// that order (free the inputs' slots, take the lowest free one for the node), packed
-// into the upper halves of the slot fields.  need[t] = slots the tree uses.
+// that order (free the inputs' slots, take the lowest free one for the node) and replace
+// the node-unique numbers in the slot fields; the arena index of a stored node's vector
+// goes to its `pad` field.  need[t] = slots the tree uses.
 struct MacroInputs {
   int count;
   int field[4];  // which slot field: 0,1 = cslot[j]; 2..5 = gslot[g]
@@ -925,13 +926,13 @@ __global__ __launch_bounds__(kTile) void macro_slots_kernel(const MacroEntry* ma
         int32_t& f = macro_field(e, mi.field[i]);
         const int s = mac_of[f];
         free_mask |= 1ull << s;
-        f |= s << 16;
+        f = s;
       }
       if (!(e.shape & 16)) {
         const int s = __ffsll((unsigned long long)free_mask) - 1;
         free_mask &= ~(1ull << s);
         mac_of[e.qslot] = s;
-        e.qslot |= s << 16;
+        e.qslot = s;
         if (s + 1 > used) used = s + 1;
       }
     }

@@ -53,7 +53,7 @@ struct MacroEntry {
   int32_t qslot;     // its LDS slot, -1 for the root (q = frequencies)
   int32_t cslot[2];  // slot of a stored child (else 0)
   int32_t gslot[4];  // slots of the grandchildren (0 for tips)
-  int32_t pad;
+  int32_t pad;       // arena variant (macro_slots_kernel): index of the node's post-order vector in the arena
 };
 constexpr int kMacroPositions = 6;  // edges a macro can own: child0, child1, grand0..3
 

@@ -116,6 +116,31 @@ def all_reduce_step_terms(log_likelihoods, branch_gradients, branch_index, param
     return packed[0], packed[1:]
 
 
+def pattern_shard(pattern_count, rank, world_size):
+    """Contiguous block [lo, hi) of site patterns of rank `rank` (second way:
+    few trees x very long alignments).  Every rank builds its Engine from
+    tips[:, lo:hi] / weights[lo:hi], evaluates ALL trees with the same parameters, and the
+    per-tree results are summed over ranks (all_reduce_pattern_shards)."""
+    return tree_shard(pattern_count, rank, world_size)
+
+
+def all_reduce_pattern_shards(packed, group=None):
+    """Sum of the per-tree results of pattern shards: ONE all-reduce.
+
+    The log-likelihood and every gradient block of the unrooted path are sums over site
+    patterns (rescaling is per pattern, the finite-difference substitution gradient is
+    linear in log-likelihoods), so `packed` = pack_results(logL, [gradient blocks...]) of
+    this rank's pattern block summed over ranks is the result for the whole alignment.
+    (Rooted trees: the log-det-Jacobian of LogLikelihood(RootedTree) is a per-tree
+    constant, not a pattern sum -- shard the unrooted quantities and add it once.)
+    In place; returns `packed`.
+    """
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    return packed
+
+
 class ShardedBatch:
     """Splits the inputs of one Engine call by tree and reassembles the outputs.
 

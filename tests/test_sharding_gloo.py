@@ -107,6 +107,64 @@ def test_two_rank_tree_sharding_matches_unsharded(T, tmp_path):
     assert np.allclose(red[1:], want, rtol=1e-12, atol=1e-12)
 
 
+def _pattern_worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libsbn_amd import sharding as S
+    st = O.load_struct("ds1_sub10")
+    tips, w, pids, bls = O.struct_arrays(st)
+    T = 3
+    lo, hi = S.pattern_shard(tips.shape[1], rank, world)
+    spec = O.make_spec(27, hi - lo, "GTR", "weibull+4")
+    pr = _gtr_params(T)
+    g = O.unrooted_gradients(spec, np.ascontiguousarray(tips[:, lo:hi]),
+                             np.ascontiguousarray(w[lo:hi]), pids[:T], bls[:T], pr, True)
+    packed = S.pack_results(torch.from_numpy(g["log_likelihood"]),
+                            [torch.from_numpy(g["site_model"]),
+                             torch.from_numpy(g["substitution_model"]),
+                             torch.from_numpy(g["branch_lengths"])])
+    total = S.all_reduce_pattern_shards(packed)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "summed.npy"), total.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _gtr_params(T):
+    spec = O.make_spec(27, 934, "GTR", "weibull+4")
+    lay = O.param_layout(spec)
+    pr = np.zeros((T, O.param_count(spec)))
+    pr[:, lay["GTR rates"]:lay["GTR rates"] + 6] = [0.05, 0.1, 0.15, 0.2, 0.25, 0.25]
+    pr[:, lay["frequencies"]:lay["frequencies"] + 4] = [0.1, 0.2, 0.3, 0.4]
+    pr[:, lay["Weibull shape"]] = 0.7
+    return pr
+
+
+def test_two_rank_pattern_sharding_sums_to_unsharded(tmp_path):
+    """SURVEY 8e, second way: ranks own contiguous blocks of site patterns, evaluate all
+    trees, one all-reduce(sum).  Log-likelihood, branch, site-model and (finite-difference)
+    substitution-model gradients of the whole alignment are recovered (rescaling on)."""
+    port = _free_port()
+    mp.spawn(_pattern_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "summed.npy")
+    st = O.load_struct("ds1_sub10")
+    tips, w, pids, bls = O.struct_arrays(st)
+    T = 3
+    spec = O.make_spec(27, 934, "GTR", "weibull+4")
+    g = O.unrooted_gradients(spec, tips, w, pids[:T], bls[:T], _gtr_params(T), True)
+    want = np.concatenate([g["log_likelihood"][:, None], g["site_model"].reshape(T, -1),
+                           g["substitution_model"].reshape(T, -1), g["branch_lengths"]], axis=1)
+    assert got.shape == want.shape
+    # sums are taken in a different order; the substitution block is a finite difference
+    # of log-likelihoods (1e-6 steps), so its rounding noise is ~1e-16 * |logL| / 1e-6
+    assert np.allclose(got[:, :2], want[:, :2], rtol=1e-11, atol=1e-9)
+    assert np.allclose(got[:, 10:], want[:, 10:], rtol=1e-11, atol=1e-9)
+    assert np.allclose(got[:, 2:10], want[:, 2:10], rtol=1e-5, atol=1e-4)
+
+
 def test_shard_arithmetic():
     from libsbn_amd import sharding as S
     for T in (1, 7, 8, 1000, 1001):

@@ -480,6 +480,18 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
     return o;
   };
 
+  V pend_L;  // ARENA: the last stored vector, on its way to the arena
+  int pend_dst = 0;
+  bool pend = false;
+  auto flush_arena = [&]() {
+    // after the fetches: loads issued behind a store cannot be consumed before the store
+    // has completed (one in-order counter), so the store goes where the loads behind it
+    // are not needed for a whole macro
+    if (ARENA && pend) {
+      store_arena(pend_dst, pend_L);
+      pend = false;
+    }
+  };
   // ================= post-order over the stored nodes (+ root: site likelihood) ====
   auto post_step = [&](int sh, const Slots& sl, const MacroMats& cm, const Ops& o) {
     V L0, L1;
@@ -510,7 +522,11 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
         }
       }
       store_slot(sl.q, Lv);
-      if (ARENA) store_arena(sl.dst, Lv);
+      if (ARENA) {  // stored to the arena after the next macro's fetches have been issued
+        pend_L = Lv;
+        pend_dst = sl.dst;
+        pend = true;
+      }
     } else {
       // root: site likelihood per pattern, log-likelihood partial, derivative weights
       double sitev[R];
@@ -583,6 +599,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       mb = fetch_mats(ib, false);
       ia = load_ids(m + 2 < M ? m + 2 : M - 1);
       sb = load_slots(m + 1 < M ? m + 1 : M - 1);
+      flush_arena();
       post_step(sha, sa, ma, oa);
       if (m + 1 < M) {
         const Ops ob = load_ops(shb, sb, mb, false, PreL{});
@@ -590,9 +607,11 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
         ma = fetch_mats(ia, false);
         ib = load_ids(m + 3 < M ? m + 3 : M - 1);
         sa = load_slots(m + 2 < M ? m + 2 : M - 1);
+        flush_arena();
         post_step(shb, sb, mb, ob);
       }
     }
+    flush_arena();
   }
   if (DBG & 128) return;
   // ================= pre-order + edge derivatives =================

@@ -102,7 +102,14 @@ def cpu_baseline(tips, w, pids, bls, params, mode, budget_s=12.0):
     t0 = time.perf_counter()
     fn(spec, tips, w, a, b, c, False, cores)
     dt = time.perf_counter() - t0
+    # also on one core (about 2 s)
+    S1 = max(1, int(rate / cores * 2.0))
+    a1, b1, c1 = take(S1)
+    t0 = time.perf_counter()
+    fn(spec, tips, w, a1, b1, c1, False, 1)
+    one_core = S1 / (time.perf_counter() - t0)
     return {"value": S2 / dt, "unit": "trees/s", "cores": cores, "kind": "port",
+            "value_on_one_core": one_core,
             "sample": f"{S2} trees (the same batch, cycled), {mode} semantics, "
                       f"{cores} OpenMP threads = usable cores (affinity mask capped by the "
                       f"cgroup CPU quota; host has {os.cpu_count()} logical CPUs), one tree "

@@ -294,7 +294,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ts.rates = (d.rooted && (d.gradient || d.with_jacobian)) ? d.rates : nullptr;
   ts.scratch = e->tree_scratch.as<int32_t>();
   ts.sched = e->sched.as<SchedEntry>();
-  ts.macros = e->macros.as<MacroEntry>();
+  // (the gradient schedule is only built for gradient calls that walk it)
+  ts.macros = (d.gradient && mfma) ? e->macros.as<MacroEntry>() : nullptr;
   ts.macro_count = e->macro_count.as<int32_t>();
   ts.bl_eff = e->bl_eff.as<double>();
   ts.status = e->status.as<int32_t>();

@@ -333,13 +333,13 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
       const double D1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, L[r], 0.0, 0, 0, 0);
       L[r] = D0 * D1;
       if (RESCALE) {
-        // exact per-pattern power-of-two rescaling (largest entry over states, categories)
-        double mx = L[r];
-        mx = fmax(mx, __shfl_xor(mx, 16, 64));
-        mx = fmax(mx, __shfl_xor(mx, 32, 64));
-        if (Kp >= 2) mx = fmax(mx, __shfl_xor(mx, 4, 64));
-        if (Kp >= 4) mx = fmax(mx, __shfl_xor(mx, 8, 64));
-        const int ex = mx > 0.0 ? ilogb(mx) : 0;
+        // exact power-of-two rescaling per (pattern, category): the scale is the exponent
+        // of the SUM over the four states, which one product with a ones matrix leaves in
+        // all four lanes of the column -- no cross-lane traffic, and the matrix pipe has
+        // the slack (any power of two works: the mantissas are unchanged; 0 -> exponent 0).
+        // The categories' exponents meet at the root.
+        const double colsum = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, L[r], 0.0, 0, 0, 0);
+        const int ex = __builtin_amdgcn_frexp_exp(colsum);
         L[r] = ldexp(L[r], -ex);
         esum[r] += ex;
       }
@@ -377,6 +377,12 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
       double v = wgt * L[r];
+      int ev = esum[r];  // RESCALE: common exponent of this pattern's categories
+      if (RESCALE) {
+        if (Kp >= 2) ev = max(ev, __shfl_xor(ev, 4, 64));
+        if (Kp >= 4) ev = max(ev, __shfl_xor(ev, 8, 64));
+        v = ldexp(v, esum[r] - ev);
+      }
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
       if (Kp >= 2) v += __shfl_xor(v, 4, 64);
@@ -385,12 +391,12 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
         site[r] += v;
       } else if (g == 0) {
         site[r] = v;
-        site_exp[r] = esum[r];
-      } else if (esum[r] > site_exp[r]) {
-        site[r] = ldexp(site[r], site_exp[r] - esum[r]) + v;
-        site_exp[r] = esum[r];
+        site_exp[r] = ev;
+      } else if (ev > site_exp[r]) {
+        site[r] = ldexp(site[r], site_exp[r] - ev) + v;
+        site_exp[r] = ev;
       } else {
-        site[r] += ldexp(v, esum[r] - site_exp[r]);
+        site[r] += ldexp(v, ev - site_exp[r]);
       }
     }
   }

@@ -255,7 +255,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   double* gacc = glds + ((n * ppr * 4 + 7) >> 3);
   double* plv = gacc + gwidth;
   // RESCALE: per (slot, pattern) power-of-two exponent taken out of a stored vector
-  int32_t* exps = reinterpret_cast<int32_t*>(
+  // (16 bits hold any FP64 exponent; 32-bit entries pushed DS1's footprint over the
+  // 20 KB that 8 waves per CU leave)
+  int16_t* exps = reinterpret_cast<int16_t*>(
       plv + (size_t)(ARENA ? a.lds_slots : max_stored(n)) * R * kTile);
   // ARENA: this wave's [stored node][r][lane] block of post-order vectors in HBM
   char* const arena =
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
         if (RESCALE) {
 #pragma unroll
           for (int r = 0; r < R; r++)
-            o.q.v[r] = ldexp(o.q.v[r], -exps[__umul24((unsigned)(ARENA ? sl.dst : sl.q), (unsigned)TP) +
+            o.q.v[r] = ldexp(o.q.v[r], -(int)exps[__umul24((unsigned)(ARENA ? sl.dst : sl.q), (unsigned)TP) +
                                               (unsigned)(r * ppr + col)]);
         }
       }
@@ -510,15 +512,16 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
         // only place an exponent re-enters is where a stored node's q is read back.
 #pragma unroll
         for (int r = 0; r < R; r++) {
-          double mx = Lv.v[r];
-          mx = fmax(mx, __shfl_xor(mx, 16, 64));
-          mx = fmax(mx, __shfl_xor(mx, 32, 64));
-          if (Kp >= 2) mx = fmax(mx, __shfl_xor(mx, 4, 64));
-          if (Kp >= 4) mx = fmax(mx, __shfl_xor(mx, 8, 64));
-          const int ex = mx > 0.0 ? ilogb(mx) : 0;
+          // (the exponent of each category's sum over the states comes from one product
+          // with a ones matrix; the largest over the categories is the pattern's scale)
+          const double colsum = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, Lv.v[r], 0.0, 0, 0, 0);
+          int ex = colsum > 0.0 ? __builtin_amdgcn_frexp_exp(colsum) : -4096;
+          if (Kp >= 2) ex = max(ex, __shfl_xor(ex, 4, 64));
+          if (Kp >= 4) ex = max(ex, __shfl_xor(ex, 8, 64));
+          ex = ex == -4096 ? 0 : ex;
           Lv.v[r] = ldexp(Lv.v[r], -ex);
           esum[r] += ex;
-          exps[__umul24((unsigned)(ARENA ? sl.dst : sl.q), (unsigned)TP) + (unsigned)(r * ppr + col)] = ex;
+          exps[__umul24((unsigned)(ARENA ? sl.dst : sl.q), (unsigned)TP) + (unsigned)(r * ppr + col)] = (int16_t)ex;
         }
       }
       store_slot(sl.q, Lv);
@@ -786,7 +789,7 @@ static size_t gradient_mfma_lds_bytes_for(int n, int K, bool rescale, bool subst
   const size_t tip_bytes = (((size_t)n * 4 * (16 / kp) + 7) / 8) * 8;
   size_t bytes = tip_bytes + sizeof(double) * ((size_t)slots * kLlR * kTile +
                                                gradient_mfma_width(n, subst));
-  if (rescale) bytes += sizeof(int32_t) * (size_t)max_stored(n) * kLlR * (16 / kp);
+  if (rescale) bytes += ((sizeof(int16_t) * (size_t)max_stored(n) * kLlR * (16 / kp) + 7) / 8) * 8;
   const size_t reach = (size_t)(2 * n - 1) * 4 * (16 / kp);  // mask fetches of internal ids
   return bytes > reach ? bytes : reach;
 }

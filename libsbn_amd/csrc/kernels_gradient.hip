@@ -660,8 +660,11 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   // (subst_gradient_kernel finishes: dlogL/dQ = V^-T H V^T, chain rule to the
   // parameters).  G is a matrix product over patterns, i.e. matrix-core work: operands
   // are the 4x4-block transposes of u and L_c (lane (hi, lo) <-> (lo, hi)).
-  const int tr_lane = 16 * lo + 4 * b + hi;
-  auto blockT = [&](double x) { return __shfl(x, tr_lane, 64); };
+  // block transpose (lane (hi, lo) <-> (lo, hi)) on the matrix cores: a register used as
+  // the A operand is read transposed, so A = x against the identity returns x^T in the
+  // ordinary layout -- one product instead of two ds_bpermute and their wait
+  const double ident = hi == lo ? 1.0 : 0.0;
+  auto blockT = [&](double x) { return __builtin_amdgcn_mfma_f64_4x4x4f64(x, ident, 0.0, 0, 0, 0); };
   const double AVt = SUBST ? model->V[hi * 4 + lo] : 0.0;     // A operand V^T: A[i][k] = V[k][i]
   const double AVi = SUBST ? model->Vinv[lo * 4 + hi] : 0.0;  // A operand V^-1
   double Ht = 0.0;  // (hi = i, lo = j) holds H^T[i][j] of this block's category

@@ -253,7 +253,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   uint8_t* tips = reinterpret_cast<uint8_t*>(glds);
   const int gwidth = max_macros(n) * kMacroPositions * 2 + (SUBST ? kSubstExtra : 0);
   double* gacc = glds + ((n * ppr * 4 + 7) >> 3);
-  double* plv = gacc + gwidth;
+  // (in LDS the substitution extras are only the four root sums; H goes out from registers)
+  const int lds_width = max_macros(n) * kMacroPositions * 2 + (SUBST ? 4 : 0);
+  double* plv = gacc + lds_width;
   // RESCALE: per (slot, pattern) power-of-two exponent taken out of a stored vector
   // (16 bits hold any FP64 exponent; 32-bit entries pushed DS1's footprint over the
   // 20 KB that 8 waves per CU leave)
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
         z = row_shr_add<4>(z);
         z = row_shr_add<2>(z);
         z = row_shr_add<1>(z);
-        if ((lane & 15) == 15) gacc[gwidth - 4 + hi] = z;
+        if ((lane & 15) == 15) gacc[lds_width - 4 + hi] = z;
       }
     }
   };
@@ -765,7 +767,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
   for (int i = lane; i < M * kMacroPositions * 2; i += kTile) gout[i] = gacc[i];
   if (SUBST) {
     gout[gwidth - kSubstExtra + lane] = Ht;
-    if (lane < 4) gout[gwidth - 4 + lane] = gacc[gwidth - 4 + lane];
+    if (lane < 4) gout[gwidth - 4 + lane] = gacc[lds_width - 4 + lane];
   }
 }
 
@@ -791,7 +793,7 @@ static size_t gradient_mfma_lds_bytes_for(int n, int K, bool rescale, bool subst
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
   const size_t tip_bytes = (((size_t)n * 4 * (16 / kp) + 7) / 8) * 8;
   size_t bytes = tip_bytes + sizeof(double) * ((size_t)slots * kLlR * kTile +
-                                               gradient_mfma_width(n, subst));
+                                               max_macros(n) * kMacroPositions * 2 + (subst ? 4 : 0));
   if (rescale) bytes += ((sizeof(int16_t) * (size_t)max_stored(n) * kLlR * (16 / kp) + 7) / 8) * 8;
   const size_t reach = (size_t)(2 * n - 1) * 4 * (16 / kp);  // mask fetches of internal ids
   return bytes > reach ? bytes : reach;

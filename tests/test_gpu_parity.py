@@ -573,6 +573,31 @@ def test_pattern_blocks_sum_to_the_whole_alignment():
         assert np.allclose(gs, [x.gradient["site_model"][0] for x in ref], rtol=1e-10, atol=1e-9)
 
 
+def test_arena_gradient_in_several_launches(monkeypatch):
+    """Trees of 45 and 300 taxa take the arena variant of the gradient kernel; with a tiny
+    arena budget (MI_PHYLO_PLV_BYTES, read when the engine is created) a call is split into
+    many launches.  16 categories add the per-group log-likelihood pass."""
+    monkeypatch.setenv("MI_PHYLO_PLV_BYTES", "3000000")
+    rng = np.random.default_rng(99)
+    for (n, P, K, T) in ((45, 130, 4, 37), (45, 130, 16, 5), (300, 30, 4, 2)):
+        tips, w = TU.random_alignment(n, P, rng)
+        pids, bls = TU.random_trees(n, T, rng, mean_bl=0.05)
+        pids[0] = TU.balanced_topology(n)
+        pids[1] = TU.ladder_topology(n)
+        site = f"weibull+{K}"
+        eng = _engine("JC69", site, "strict", tips, w)
+        spec = O.make_spec(n, P, "JC69", site, "strict")
+        pr = _params(spec, T, **{"Weibull shape": rng.uniform(0.4, 1.5, size=(T, 1))})
+        for resc in (False, True):
+            g = eng.gradients(pids, bls, pr, resc)
+            assert eng.last_call_info()[0] == "gradient_mfma_kernel"
+            og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 4)
+            for t in range(T):
+                assert abs(g[t].log_likelihood - og["log_likelihood"][t]) <= \
+                    RTOL * abs(og["log_likelihood"][t])
+                assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t])
+
+
 def test_random_rooted_vs_oracle():
     rng = np.random.default_rng(7)
     n, P, T = 12, 77, 4

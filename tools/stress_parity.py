@@ -8,10 +8,10 @@ import numpy as np
 import oracle_lib as O, libsbn_amd as L, tree_utils as TU
 import test_gpu_parity as TG
 RTOL = 1e-10
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(os.environ.get('STRESS_SEED', '2024')))
 bad = 0; total = 0
 for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
-    n = int(rng.choice([3, 4, 5, 6, 7, 9, 12, 17, 26, 31, 32, 33, 45, 64, 80]))
+    n = int(rng.choice([3, 4, 5, 6, 7, 9, 12, 17, 26, 27, 28, 29, 30, 31, 32, 33, 45, 64, 80, 100, 130, 257]))
     P = int(rng.choice([1, 2, 3, 11, 12, 13, 16, 47, 48, 49, 64, 100, 257]))
     K = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 11, 16]))
     subst = str(rng.choice(["JC69", "GTR"]))
@@ -34,11 +34,19 @@ for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
     og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 4)
     O.set_transition_mode(0)
     ok = True
+    if not np.all(np.isfinite(og["log_likelihood"])):
+        # unscaled evaluation underflowed in the oracle too (large trees): nothing to
+        # compare beyond "the engine does not pretend to have a number"
+        total += 1
+        if np.all(np.isfinite([x.log_likelihood for x in g])):
+            bad += 1
+            print("MISMATCH (finite where the oracle underflows)", dict(n=n, P=P, K=K, resc=resc))
+        continue
     for t in range(T):
         okl = abs(g[t].log_likelihood - og["log_likelihood"][t]) <= RTOL * abs(og["log_likelihood"][t]) + 1e-13
         if not okl: print("  ll", g[t].log_likelihood, og["log_likelihood"][t])
         # (a gradient that is zero up to rounding -- all-gap columns -- has no relative scale)
-        scale = max(np.max(np.abs(og["branch_lengths"][t])), 1e-6)
+        scale = max(np.max(np.abs(og["branch_lengths"][t])), 1e-4)  # (cancellation noise of O(1) terms is ~1e-15)
         okb = np.max(np.abs(g[t].gradient["branch_lengths"] - og["branch_lengths"][t])) <= 1e-9 * scale
         if not okb: print("  bl", g[t].gradient["branch_lengths"], og["branch_lengths"][t])
         ok &= okl and okb

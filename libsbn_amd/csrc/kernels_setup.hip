@@ -22,7 +22,16 @@ using namespace dev;
 // labels so that the on-chip kernel needs at most floor(log2 n)+1 live
 // partial-likelihood vectors; any post-order gives bitwise the same vectors.
 // ------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a) {
+// The model instances are independent of the trees: their set-up (one thread per model
+// instance, defined below) rides in the same launch as extra workgroups behind the T
+// tree workgroups -- one dispatch less per call, and the two run side by side.
+__device__ void model_setup_thread(const ModelSetupArgs& a, int idx);
+
+__global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a, ModelSetupArgs ms) {
+  if ((int)blockIdx.x >= a.T) {
+    model_setup_thread(ms, ((int)blockIdx.x - a.T) * 64 + (int)threadIdx.x);
+    return;
+  }
   // One wave per tree.  The walk itself is sequential (lane 0); its working set
   // lives in LDS (13 N ints) unless the tree is too large, and the bulk copies
   // (branch lengths, schedule) are done by all 64 lanes.
@@ -237,7 +246,11 @@ struct NodeArray {
 };
 
 template <int NB>
-__global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a) {
+__global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a, ModelSetupArgs ms) {
+  if ((int)blockIdx.x >= a.T) {
+    model_setup_thread(ms, ((int)blockIdx.x - a.T) * 64 + (int)threadIdx.x);
+    return;
+  }
   // Branch-free by construction: the tree walks are dependent chains, and on this machine
   // a taken scalar branch costs more than the handful of instructions it would skip, so
   // every loop body is straight-line code (lane selects / scalar selects) and whatever can
@@ -592,8 +605,7 @@ __device__ void stick_breaking_inverse(int K, const double* x, double* y) {
   }
 }
 
-__global__ void model_setup_kernel(ModelSetupArgs a) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ void model_setup_thread(const ModelSetupArgs& a, int idx) {
   if (idx >= a.T * a.models_per_tree) return;
   const int t = idx / a.models_per_tree, j = idx % a.models_per_tree;
   const double* row = a.params + (size_t)t * a.param_count;
@@ -827,7 +839,7 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
 // ------------------------------------------------------------------------
 // Launch wrappers
 // ------------------------------------------------------------------------
-void launch_tree_setup(const TreeSetupArgs& a_in, hipStream_t s) {
+void launch_setup(const TreeSetupArgs& a_in, const ModelSetupArgs& ms, hipStream_t s) {
   TreeSetupArgs a = a_in;
   const size_t lds = sizeof(int32_t) * 13 * (size_t)(2 * a.n - 1);
   a.use_lds = lds <= 48 * 1024;
@@ -837,18 +849,20 @@ void launch_tree_setup(const TreeSetupArgs& a_in, hipStream_t s) {
     return env && std::string(env) == "lds";
   }();
   const int N = 2 * a.n - 1;
+  // T workgroups of trees, then the model instances, 64 per workgroup
+  const dim3 grid(a.T + (ms.T * ms.models_per_tree + 63) / 64), block(64);
   if (a.n >= 3 && N <= 256 && !force_lds) {
-    if (N <= 64) hipLaunchKernelGGL(tree_setup_small_kernel<1>, dim3(a.T), dim3(64), 0, s, a);
-    else if (N <= 128) hipLaunchKernelGGL(tree_setup_small_kernel<2>, dim3(a.T), dim3(64), 0, s, a);
-    else if (N <= 192) hipLaunchKernelGGL(tree_setup_small_kernel<3>, dim3(a.T), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(tree_setup_small_kernel<4>, dim3(a.T), dim3(64), 0, s, a);
+    if (N <= 64) hipLaunchKernelGGL(tree_setup_small_kernel<1>, grid, block, 0, s, a, ms);
+    else if (N <= 128) hipLaunchKernelGGL(tree_setup_small_kernel<2>, grid, block, 0, s, a, ms);
+    else if (N <= 192) hipLaunchKernelGGL(tree_setup_small_kernel<3>, grid, block, 0, s, a, ms);
+    else hipLaunchKernelGGL(tree_setup_small_kernel<4>, grid, block, 0, s, a, ms);
     return;
   }
-  hipLaunchKernelGGL(tree_setup_kernel, dim3(a.T), dim3(64), a.use_lds ? lds : 0, s, a);
+  hipLaunchKernelGGL(tree_setup_kernel, grid, block, a.use_lds ? lds : 0, s, a, ms);
 }
-void launch_model_setup(const ModelSetupArgs& a, hipStream_t s) {
-  const int total = a.T * a.models_per_tree;
-  hipLaunchKernelGGL(model_setup_kernel, dim3((total + 63) / 64), dim3(64), 0, s, a);
+void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s) {  // trees only
+  ModelSetupArgs none{};
+  launch_setup(a, none, s);
 }
 void launch_transition(const TransitionArgs& a, hipStream_t s) {
   const long total = (long)a.E * (a.N - 1) * a.K;

@@ -302,13 +302,6 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ts.max_slots = e->max_slots;
   // the Sethi-Ullman schedule with LDS slots is what the log-likelihood kernels walk
   ts.need_slots = !(d.gradient && mfma && groups == 1 && (!c.gtr || analytic));
-  launch_tree_setup(ts, s);
-  const bool arena = mfma && gradient_mfma_use_arena(n, e->K, d.rescaling, analytic);
-  if (arena)
-    launch_macro_slots(e->macros.as<MacroEntry>(), e->arena_macros.as<MacroEntry>(),
-                       e->macro_count.as<int32_t>(), n, T, e->slot_need.as<int32_t>(),
-                       e->status.as<int32_t>(), s);
-
   ModelSetupArgs ms{};
   ms.T = T;
   ms.models_per_tree = c.models_per_tree;
@@ -322,7 +315,12 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ms.params = d.params;
   ms.models = e->models.as<DevModel>();
   ms.status = e->status.as<int32_t>();
-  launch_model_setup(ms, s);
+  launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
+  const bool arena = mfma && gradient_mfma_use_arena(n, e->K, d.rescaling, analytic);
+  if (arena)
+    launch_macro_slots(e->macros.as<MacroEntry>(), e->arena_macros.as<MacroEntry>(),
+                       e->macro_count.as<int32_t>(), n, T, e->slot_need.as<int32_t>(),
+                       e->status.as<int32_t>(), s);
 
   const EvalMap map{T, c.models_per_tree};
   TransitionArgs tr{};

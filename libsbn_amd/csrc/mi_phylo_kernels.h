@@ -128,8 +128,9 @@ struct FinalizeArgs {
   int use_lds;  // set by the launcher
 };
 
-void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s);
-void launch_model_setup(const ModelSetupArgs& a, hipStream_t s);
+// tree schedules (one wave per tree) and model instances (one thread each) in one launch
+void launch_setup(const TreeSetupArgs& a, const ModelSetupArgs& ms, hipStream_t s);
+void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s);  // trees only
 void launch_transition(const TransitionArgs& a, hipStream_t s);
 // On-chip (LDS-resident) log-likelihood: evaluations [eval_offset, eval_offset+count)
 void launch_loglik(const LikArgs& a, int count, bool rescale, int max_slots, hipStream_t s);

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
   const int N2 = 2 * a.N;
   const int W = a.g_width ? a.g_width : N2;  // doubles per (evaluation, tile)
   double llp = 0;
-  for (int i = threadIdx.x; i < a.ll_tiles; i += 256) llp += a.ll_part[(size_t)b * a.ll_tiles + i];
+  for (int i = threadIdx.x; i < a.ll_used.of(b); i += 256) llp += a.ll_part[(size_t)b * a.ll_tiles + i];
   llp = wave_sum(llp);
   if (lane == 0) llw[wv] = llp;
   const int t = b < a.T ? b : b - a.T;  // gradient evaluations: [0,T) main, [T,2T) site pass
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
   __syncthreads();
   __shared__ double sh_ll, sh_jac;
   if (lane == 0) {
-    sh_ll = sum_tiles(a.ll_part + (size_t)t * a.ll_tiles, a.ll_tiles);
+    sh_ll = sum_tiles(a.ll_part + (size_t)t * a.ll_tiles, a.ll_used.of(t));
     double jac = 0.0;
     if (a.rooted && (a.with_jacobian || (a.gradient && a.gtr))) {
       // fat_beagle.cpp:82-94; iteration order of TripleIdPreorderBifurcating
@@ -308,8 +308,8 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
     // fat_beagle.cpp:431,455-464: rates (5) then frequencies (3)
     const int coord = lane < 5 ? 3 + lane : lane - 5;
     const size_t ep = (size_t)T + (size_t)t * 16 + 2 * coord;
-    double lp = sum_tiles(a.ll_part + ep * a.ll_tiles, a.ll_tiles);
-    double lm = sum_tiles(a.ll_part + (ep + 1) * a.ll_tiles, a.ll_tiles);
+    double lp = sum_tiles(a.ll_part + ep * a.ll_tiles, a.ll_used.of((long)ep));
+    double lm = sum_tiles(a.ll_part + (ep + 1) * a.ll_tiles, a.ll_used.of((long)ep + 1));
     if (a.rooted) {
       lp += jac;
       lm += jac;

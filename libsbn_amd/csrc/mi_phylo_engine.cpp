@@ -270,8 +270,18 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   if (e->param_count > 0 && !d.params) return fail("null parameter matrix");
   // on-chip gradient kernels: the matrix-core one (K <= 4; rescaling supported) or the
   // VALU one (no rescaling); everything else takes the HBM-streamed kernel
+  // which log-likelihood kernel runs (also decides who fills the tip tables, below)
+  LikArgs probe{};
+  probe.n = e->n;
+  probe.K = e->K;
+  probe.tip_masks = e->have_tip_masks ? e->tip_masks.as<uint8_t>() : nullptr;
+  const bool loglik_is_valu =
+      std::string(loglik_kernel_name(probe, d.rescaling, e->max_slots)) == "loglik_onchip_kernel";
+  // (K > 4: the matrix-core gradient kernel takes the site likelihoods from a pass of the
+  // matrix-core log-likelihood kernel; if that one cannot run, neither can it)
   const bool mfma = d.gradient && e->allow_onchip_gradient && e->have_tip_masks &&
-                    gradient_mfma_fits(e->n, e->K, d.rescaling) && reduce_tiles_fits(e->N);
+                    gradient_mfma_fits(e->n, e->K, d.rescaling) && reduce_tiles_fits(e->N) &&
+                    (gradient_mfma_groups(e->K) == 1 || !loglik_is_valu);
   const bool onchip = mfma;  // the only on-chip gradient kernel; everything else streams PLVs
   const int groups = mfma ? gradient_mfma_groups(e->K) : 1;
   const int g_tiles = mfma ? gradient_mfma_tiles(e->P, e->K) * groups : e->tiles;
@@ -280,8 +290,6 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const CallShape c = call_shape(e, d.T, d.gradient, analytic);
   const int n = e->n, N = e->N, T = d.T;
   HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, s));
-  // kernels write different numbers of logL partial sums per evaluation; unused ones stay 0
-  HIP_TRY(hipMemsetAsync(e->ll_part.ptr, 0, sizeof(double) * (size_t)c.E * e->ll_stride, s));
 
   TreeSetupArgs ts{};
   ts.n = n;
@@ -333,14 +341,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   tr.mats = e->mats.as<double>();
   // the per-state tip tables feed the VALU walk kernels only
   // (only the VALU log-likelihood kernel reads them)
-  LikArgs probe{};
-  probe.n = n;
-  probe.K = e->K;
-  probe.tip_masks = e->have_tip_masks ? e->tip_masks.as<uint8_t>() : nullptr;
   const bool loglik_runs =
       !d.gradient || (c.gtr && !analytic) || (mfma && groups > 1);
-  const bool loglik_is_valu =
-      std::string(loglik_kernel_name(probe, d.rescaling, e->max_slots)) == "loglik_onchip_kernel";
   const bool need_tip_tables = loglik_runs && loglik_is_valu;
   tr.tip_tables = need_tip_tables ? e->tip_tables.as<double>() : nullptr;
   tr.tr_mats = mfma ? e->tr_mats.as<double>() : nullptr;
@@ -452,6 +454,19 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   fa.g_tiles = g_tiles;
   fa.ll_part = e->ll_part.as<double>();
   fa.g_part = e->g_part.as<double>();
+  // logL partial sums each evaluation's walk kernel wrote (no memset of ll_part: the
+  // consumers sum exactly these): the log-likelihood kernel in use tiles the patterns its
+  // way, the gradient kernels theirs; K > 4 takes the gradient evaluations' logL from the
+  // log-likelihood pass
+  const int ll_kernel_count = loglik_is_valu ? e->tiles : loglik_mfma_tiles(e->P, e->K);
+  const int grad_kernel_count =
+      mfma ? (groups > 1 ? ll_kernel_count : gradient_mfma_tiles(e->P, e->K)) : e->tiles;
+  LlCounts ll_used{d.gradient ? grad_kernel_count : ll_kernel_count, ll_kernel_count, 0, 0};
+  if (d.gradient && c.gtr && !analytic) {
+    ll_used.mid_lo = T;
+    ll_used.mid_hi = 17 * T;
+  }
+  fa.ll_used = ll_used;
   if (reduce_tiles_fits(N)) {
     // sum the per-tile partials with one workgroup per evaluation first
     ReduceArgs ra{};
@@ -459,6 +474,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     ra.E = c.E;
     ra.Eg = c.Eg;
     ra.ll_tiles = e->ll_stride;
+    ra.ll_used = ll_used;
     ra.g_tiles = g_tiles;
     ra.ll_part = e->ll_part.as<double>();
     ra.g_part = e->g_part.as<double>();
@@ -473,6 +489,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     ra.macro_count = e->macro_count.as<int32_t>();
     launch_reduce_tiles(ra, s);
     fa.ll_tiles = 1;
+    fa.ll_used = LlCounts{1, 1, 0, 0};
     fa.g_tiles = 1;
     fa.ll_part = ra.ll_sum;
     fa.g_part = ra.g_sum;

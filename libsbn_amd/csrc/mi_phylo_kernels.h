@@ -101,9 +101,18 @@ struct LikArgs {
   int lds_lo;                  // arena gradient kernel: this launch takes trees with lds_lo < need <= lds_slots
 };
 
+// How many logL partial sums each evaluation's walk kernel wrote (the kernels tile the
+// patterns differently): `mid` for evaluations [mid_lo, mid_hi) -- the finite-difference
+// passes of a GTR gradient call --, `ends` for the others.  Consumers sum exactly those.
+struct LlCounts {
+  int ends, mid, mid_lo, mid_hi;
+  __host__ __device__ int of(long e) const { return (e >= mid_lo && e < mid_hi) ? mid : ends; }
+};
+
 struct FinalizeArgs {
   int n, N, T, K, tiles;
-  int ll_tiles;  // logL partial sums per evaluation
+  int ll_tiles;  // stride of ll_part per evaluation
+  LlCounts ll_used;
   int g_tiles;   // gradient partial sums per gradient evaluation
   int gradient, rooted, with_jacobian;
   int gtr, site_fused, site_separate;
@@ -159,6 +168,7 @@ size_t gradient_arena_bytes_per_eval(int n, int P, int K);
 // g_sum[gi][2N] = sum_i g_part[gi][i][2N] for gi < Eg (fixed order: deterministic).
 struct ReduceArgs {
   int N, E, Eg, ll_tiles, g_tiles;
+  LlCounts ll_used;
   const double* ll_part;
   const double* g_part;
   double* ll_sum;

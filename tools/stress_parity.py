@@ -57,7 +57,10 @@ for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
             ok &= okk
         if subst == "GTR":
             a = g[t].gradient["substitution_model"]; f_ = og["substitution_model"][t]
-            okk = np.max(np.abs(a - f_) / np.maximum(np.abs(f_), 1.0)) <= 1e-4
+            # (finite differences of logL with a 1e-6 step: rounding noise ~ 1e-16 |logL| / 2e-6
+            # per ulp of difference in the summation order)
+            okk = np.max(np.abs(a - f_) / np.maximum(np.abs(f_), 1.0)) <= \
+                max(1e-4, 2e-9 * abs(og["log_likelihood"][t]))
             if not okk: print("  subst", a, f_)
             ok &= okk
     # the log-likelihood-only call (its own kernel and traversal order)

@@ -484,6 +484,17 @@ for site, K in (('constant', 1), ('weibull+2', 2), ('weibull+3', 3), ('weibull+4
         oll = O.unrooted_log_likelihoods(spec, tips, w, pids, bls, pr, False, 4)
         assert np.all(np.abs(ll - oll) <= 1e-10 * np.abs(oll)), (site, subst)
         assert eng.last_call_info()[0] == sys.argv[1], eng.last_call_info()
+# more than four categories: the matrix-core gradient kernel depends on a pass of the
+# matrix-core log-likelihood kernel; either way the gradients must match
+eng = L.Engine(L.PhyloModelSpecification('JC69', 'weibull+6', 'strict'), tips, w)
+spec = O.make_spec(27, 934, 'JC69', 'weibull+6', 'strict')
+pr = np.zeros((10, O.param_count(spec))); pr[:, O.param_layout(spec)['Weibull shape']] = 0.7
+g = eng.gradients(pids, bls, pr)
+og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, False, 4)
+for t in range(10):
+    assert abs(g[t].log_likelihood - og['log_likelihood'][t]) <= 1e-10 * abs(og['log_likelihood'][t])
+    d = np.abs(g[t].gradient['branch_lengths'] - og['branch_lengths'][t])
+    assert np.all(d <= 1e-9 * np.maximum(1.0, np.abs(og['branch_lengths'][t]))), t
 print('path-ok')
 """
     env = dict(os.environ, MI_PHYLO_LOGLIK_PATH=path)

@@ -21,8 +21,10 @@ for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
     tips, w = TU.random_alignment(n, P, rng, gap_fraction=float(rng.choice([0.0, 0.05, 0.5])))
     pids, bls = TU.random_trees(n, T, rng, mean_bl=float(rng.choice([0.001, 0.1, 1.0])))
     if rng.integers(0, 3) == 0: pids[0] = TU.ladder_topology(n)
-    eng = L.Engine(L.PhyloModelSpecification(subst, site, "none"), tips, w, device=0)
-    spec = O.make_spec(n, P, subst, site, "none")
+    as_partials = rng.integers(0, 5) == 0  # tips handed over as 0/1 partial vectors
+    eng = L.Engine(L.PhyloModelSpecification(subst, site, "none"), tips, w, device=0,
+                   use_tip_states=not as_partials)
+    spec = O.make_spec(n, P, subst, site, "none", use_tip_states=0 if as_partials else 1)
     blocks = {}
     if subst == "GTR":
         r, f = TU.random_gtr_params(T, rng); blocks["GTR rates"] = r; blocks["frequencies"] = f

@@ -158,38 +158,43 @@ def main():
     d_pid = torch.from_numpy(pids).to(dev)
     d_bl = torch.from_numpy(bls).to(dev)
     d_par = torch.from_numpy(params).to(dev)
-    # packed per-tree result: [logL | site gradient | branch gradient (N)]
-    d_ll = torch.zeros(T, dtype=torch.float64, device=dev)
-    d_site = torch.zeros(T, dtype=torch.float64, device=dev)
-    d_g = torch.zeros((T, N), dtype=torch.float64, device=dev)
-    gathered = [None]
-    pending = [None]  # all-gather in flight
+    # per-tree results [logL | site gradient | branch gradient (N)]: ONE buffer per rank that
+    # the engine writes into directly (no packing copy before the collective); two sets, so
+    # that the all-gather of step k overlaps the kernels of step k + 1
+    sets = [sharding.ResultBlocks(T, N, extra=1, device=dev) for _ in range(2)]
+    outs = [torch.empty((world, sets[0].buffer.numel()), dtype=torch.float64, device=dev)
+            for _ in range(2)] if distributed else [None, None]
+    state = {"k": 0, "pending": None, "gathered": None}
     grad = args.mode == "gradient"
     eng.reserve(T, grad)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
+        i = state["k"] & 1
+        state["k"] += 1
+        blk = sets[i]
         if grad:
             eng.gradients_device(stream, T, d_pid.data_ptr(), d_bl.data_ptr(), d_par.data_ptr(),
-                                 d_ll.data_ptr(), d_g.data_ptr(), d_site.data_ptr(), None)
+                                 blk.log_likelihoods.data_ptr(), blk.branch_gradients.data_ptr(),
+                                 blk.extras[0].data_ptr(), None)
         else:
             eng.log_likelihoods_device(stream, T, d_pid.data_ptr(), d_bl.data_ptr(),
-                                       d_par.data_ptr(), d_ll.data_ptr())
+                                       d_par.data_ptr(), blk.log_likelihoods.data_ptr())
         if distributed:
-            # the one collective of the call: every rank's per-tree results, tree order.
-            # It is enqueued asynchronously (RCCL's stream) from a private copy of the
-            # results, so it overlaps the next step's kernels; its result is collected
-            # one step later (and, for the last step, before the timed region ends).
-            packed = sharding.pack_results(d_ll, [d_site, d_g])
-            handle = sharding.all_gather_trees(packed, world * T, async_op=True)
-            if pending[0] is not None:
-                gathered[0] = pending[0].result()
-            pending[0] = handle
+            # the one collective of the call: every rank's per-tree results, tree order,
+            # enqueued asynchronously (RCCL's stream) so that it overlaps the next step's
+            # kernels, which write the other buffer set; it is waited for one step later
+            # (and, for the last step, before the timed region ends).
+            out, work = sharding.all_gather_result_blocks(blk, out=outs[i], async_op=True)
+            drain()
+            state["pending"] = (work, out)
 
     def drain():
-        if pending[0] is not None:
-            gathered[0] = pending[0].result()
-            pending[0] = None
+        if state["pending"] is not None:
+            work, out = state["pending"]
+            work.wait()
+            state["gathered"] = out
+            state["pending"] = None
 
     for _ in range(args.warmup):
         step()
@@ -217,13 +222,17 @@ def main():
         elapsed = float(tmax.item())
 
     # sanity: results are finite and the gathered copy matches
+    last = sets[(state["k"] - 1) & 1]
+    d_ll, d_g = last.log_likelihoods, last.branch_gradients
     assert bool(torch.isfinite(d_ll).all()), "non-finite log-likelihoods"
     if grad:
         assert bool(torch.isfinite(d_g).all()), "non-finite gradients"
     if distributed:
-        assert gathered[0].shape == (world * T, 2 + N)
-        lo = rank * T
-        assert bool(torch.equal(gathered[0][lo:lo + T, 0], d_ll)), "gathered slice mismatch"
+        ll_all, _, g_all = sharding.gathered_views(state["gathered"], last)
+        assert ll_all.shape == (world, T) and g_all.shape == (world, T, N)
+        assert bool(torch.equal(ll_all[rank], d_ll)), "gathered slice mismatch"
+        if grad:
+            assert bool(torch.equal(g_all[rank], d_g)), "gathered gradient slice mismatch"
 
     out = None
     if rank == 0:

@@ -78,6 +78,50 @@ def all_gather_trees(local, tree_count, group=None, async_op=False):
     return handle if async_op else handle.result()
 
 
+class ResultBlocks:
+    """The per-tree results of one rank as ONE buffer the engine writes into directly:
+    [logL (T) | `extra` scalar columns (T each) | branch gradient (T x N)], each block
+    contiguous (what the C ABI's output pointers want) -- so the collective needs no packing
+    copy.  `log_likelihoods`, `extras[i]`, `branch_gradients` are views of `buffer`."""
+
+    def __init__(self, tree_count, node_count, extra=0, device=None, dtype=None):
+        import torch
+        dtype = dtype or torch.float64
+        T, N = tree_count, node_count
+        self.tree_count, self.node_count, self.extra = T, N, extra
+        self.buffer = torch.zeros(T * (1 + extra + N), dtype=dtype, device=device)
+        self.log_likelihoods = self.buffer[:T]
+        self.extras = [self.buffer[(1 + i) * T:(2 + i) * T] for i in range(extra)]
+        self.branch_gradients = self.buffer[(1 + extra) * T:].view(T, N)
+
+
+def all_gather_result_blocks(blocks, out=None, group=None, async_op=False):
+    """All-gather the ResultBlocks buffers of all ranks (equal tree counts per rank) into
+    `out` [world, T (1 + extra + N)] -- one collective, no packing.  Returns (out, work);
+    `work` is None unless async_op.  gathered_views(out, blocks) gives tree-order views."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if out is None:
+        out = torch.empty((world, blocks.buffer.numel()), dtype=blocks.buffer.dtype,
+                          device=blocks.buffer.device)
+    # (the flat view is the concatenated form every backend accepts)
+    work = dist.all_gather_into_tensor(out.view(-1), blocks.buffer, group=group,
+                                       async_op=async_op)
+    return out, (work if async_op else None)
+
+
+def gathered_views(out, blocks):
+    """Tree-order results from all_gather_result_blocks' output: per rank r the trees
+    [r T, (r + 1) T).  Returns (logL [world, T], extras [world, T] each, branch gradients
+    [world, T, N]) as views of `out` (rank-major = tree order; reshape(-1, ...) to flatten)."""
+    T, N, X = blocks.tree_count, blocks.node_count, blocks.extra
+    ll = out[:, :T]
+    extras = [out[:, (1 + i) * T:(2 + i) * T] for i in range(X)]
+    g = out[:, (1 + X) * T:].view(out.shape[0], T, N)
+    return ll, extras, g
+
+
 def all_reduce_step_terms(log_likelihoods, branch_gradients, branch_index, parameter_count,
                           tree_weights=None, group=None):
     """The caller-side reductions of one variational-inference step folded into ONE

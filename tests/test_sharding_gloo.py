@@ -64,6 +64,21 @@ def _worker(rank, world, port, T, out_dir):
     # the asynchronous form (what bench.py overlaps with the next step) gives the same rows
     handle = S.all_gather_trees(compute(batch.lo, batch.hi), T, async_op=True)
     assert torch.equal(handle.result(), gathered)
+    # the zero-copy form bench.py uses: the "engine" writes straight into one buffer per rank
+    # (equal shards only)
+    if T % world == 0:
+        Tl = T // world
+        blocks = S.ResultBlocks(Tl, 53, extra=1)
+        mine = compute(batch.lo, batch.hi)
+        blocks.log_likelihoods.copy_(mine[:, 0])
+        blocks.extras[0].copy_(mine[:, 1])
+        blocks.branch_gradients.copy_(mine[:, 2:])
+        out, work = S.all_gather_result_blocks(blocks, async_op=True)
+        work.wait()
+        ll_all, extras_all, g_all = S.gathered_views(out, blocks)
+        assert torch.equal(ll_all.reshape(-1), gathered[:, 0])
+        assert torch.equal(extras_all[0].reshape(-1), gathered[:, 1])
+        assert torch.equal(g_all.reshape(T, 53), gathered[:, 2:])
     # the fused step reduction: sum of log-likelihoods + scatter-add of branch gradients by
     # (here: synthetic) split index, one all-reduce
     local = compute(batch.lo, batch.hi)

@@ -26,11 +26,17 @@ class PhyloModelSpecification:
     clock: str = "strict"
 
 
-@dataclass
 class PhyloGradient:
-    """src/tree_gradient.hpp:10-19."""
-    log_likelihood: float
-    gradient: dict
+    """src/tree_gradient.hpp:10-19.  (A plain __slots__ class: a call returns one object
+    per tree, and dataclass construction was most of the Python-side time of a call.)"""
+    __slots__ = ("log_likelihood", "gradient")
+
+    def __init__(self, log_likelihood, gradient):
+        self.log_likelihood = log_likelihood
+        self.gradient = gradient
+
+    def __repr__(self):
+        return f"PhyloGradient(log_likelihood={self.log_likelihood!r}, gradient={self.gradient!r})"
 
 
 def _parse_site(site):
@@ -166,7 +172,14 @@ class Engine:
             blocks = dict(blocks, substitution_model=subst)
         names = list(blocks)
         rows = [list(blocks[k]) for k in names]  # lists of row views
-        return [PhyloGradient(l, dict(zip(names, r))) for l, *r in zip(ll.tolist(), *rows)]
+        lls = ll.tolist()
+        if len(names) == 1:
+            (a,), (ra,) = names, rows
+            return [PhyloGradient(l, {a: x}) for l, x in zip(lls, ra)]
+        if len(names) == 2:
+            (a, b), (ra, rb) = names, rows
+            return [PhyloGradient(l, {a: x, b: y}) for l, x, y in zip(lls, ra, rb)]
+        return [PhyloGradient(l, dict(zip(names, r))) for l, *r in zip(lls, *rows)]
 
     def rooted_log_likelihoods(self, parent_ids, branch_lengths, params=None, rates=None,
                                node_heights=None, node_bounds=None, rescaling=False,

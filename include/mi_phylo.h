@@ -105,7 +105,11 @@ int32_t mi_engine_log_likelihoods_unrooted(mi_engine* engine, int32_t tree_count
 /* Engine::Gradients(const UnrootedTreeCollection&, ...): PhyloGradient per tree.
  * out_branch_gradient[T][2n-1] = gradient_["branch_lengths"] (last two entries 0);
  * out_site_gradient[T] = gradient_["site_model"] (K > 1, else untouched; may be NULL);
- * out_subst_gradient[T][8] = gradient_["substitution_model"] (GTR; may be NULL). */
+ * out_subst_gradient[T][8] = gradient_["substitution_model"] (GTR; may be NULL).
+ * A NULL output also skips the work only it needs: without out_subst_gradient the 16
+ * finite-difference log-likelihood passes of a GTR call (fat_beagle.cpp:400-465), without
+ * out_site_gradient the separate site-model pass (fat_beagle.cpp:488-496); the outputs that
+ * are delivered are bit-identical to those of the full call. */
 int32_t mi_engine_gradients_unrooted(mi_engine* engine, int32_t tree_count,
                                      const int32_t* parent_ids, const double* branch_lengths,
                                      const double* params, int32_t rescaling,

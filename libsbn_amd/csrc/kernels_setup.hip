@@ -733,6 +733,12 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
   const long first = (long)blockIdx.x * kTransitionBlock;
   const long idx = first + threadIdx.x;
   const long total = (long)a.E * (a.N - 1) * a.K;
+  {
+    // whole workgroups inside a range of evaluations that nobody walks have nothing to do
+    const long per = (long)a.K * (a.N - 1);
+    const long last = (first + kTransitionBlock - 1 < total ? first + kTransitionBlock - 1 : total - 1);
+    if (first / per >= a.ev_skip_begin && last / per < a.ev_skip_end) return;
+  }
   double Pm[16];
   bool tip_edge = false;
   int mi_keep = 0;

@@ -341,8 +341,14 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   tr.mats = e->mats.as<double>();
   // the per-state tip tables feed the VALU walk kernels only
   // (only the VALU log-likelihood kernel reads them)
-  const bool loglik_runs =
-      !d.gradient || (c.gtr && !analytic) || (mfma && groups > 1);
+  // The C ABI's outputs are optional, and work nobody reads is not done: without a
+  // substitution-gradient output the 16 finite-difference log-likelihood passes of a GTR
+  // call are skipped, without a site-gradient output the extra gradient pass under the
+  // perturbed model (section 8 of DESIGN.md) too.  The evaluations keep their numbers; what
+  // is delivered is bit-identical to the full call.
+  const bool fd_pass = d.gradient && c.gtr && !analytic && d.out_subst != nullptr;
+  const bool site_pass = c.site_separate && d.out_site != nullptr;
+  const bool loglik_runs = !d.gradient || fd_pass || (mfma && groups > 1);
   const bool need_tip_tables = loglik_runs && loglik_is_valu;
   tr.tip_tables = need_tip_tables ? e->tip_tables.as<double>() : nullptr;
   tr.tr_mats = mfma ? e->tr_mats.as<double>() : nullptr;
@@ -351,6 +357,12 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // evaluations [T, 17 T) of a finite-difference GTR call never run the gradient kernel
   tr.tr_skip_begin = c.E > T ? T : c.E;
   tr.tr_skip_end = c.E > T ? std::min(17 * T, c.E) : c.E;
+  // evaluations nobody walks need no matrices at all
+  tr.ev_skip_begin = tr.ev_skip_end = 0;
+  if (d.gradient && c.gtr && !analytic && !fd_pass) {
+    tr.ev_skip_begin = T;
+    tr.ev_skip_end = site_pass ? 17 * T : c.E;
+  }
   launch_transition(tr, s);
 
   LikArgs la{};
@@ -434,10 +446,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   } else {
     grad_range(0, 0, T);
     if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used + 1], s));
-    if (c.gtr && !analytic) {
-      loglik_range(T, 16 * T);
-    }
-    if (c.site_separate) grad_range(17 * T, T, T);
+    if (fd_pass) loglik_range(T, 16 * T);
+    if (site_pass) grad_range(17 * T, T, T);
     e->dominant = mfma ? gradient_mfma_kernel_name() : gradient_kernel_name();
   }
   if (prof) e->prof_used++;

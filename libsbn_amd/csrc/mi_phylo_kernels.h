@@ -67,6 +67,7 @@ struct TransitionArgs {
   double* phi;           // [E][N-1][K][4][4]: divided differences of exp(lambda r t) (analytic substitution gradient); may be nullptr
   int n;
   int tr_skip_begin, tr_skip_end;  // evaluations [begin, end) are log-likelihood only: no tr_mats for them
+  int ev_skip_begin, ev_skip_end;  // evaluations [begin, end) are not walked at all: no matrices
 };
 
 struct LikArgs {

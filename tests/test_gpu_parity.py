@@ -609,6 +609,50 @@ def test_arena_gradient_in_several_launches(monkeypatch):
                 assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t])
 
 
+def test_optional_outputs_skip_work_but_not_results():
+    """The device entry points take NULL for the site- and substitution-gradient outputs.
+    A GTR+weibull call without them skips the 16 finite-difference passes / the extra
+    gradient pass, and what it does deliver is bit-identical to the full call."""
+    import torch
+    st = O.load_struct("ds1_sub10")
+    tips, w, pids, bls = O.struct_arrays(st)
+    T, N = len(pids), 53
+    eng = _engine("GTR", "weibull+4", "strict", tips, w)
+    spec = O.make_spec(27, 934, "GTR", "weibull+4", "strict")
+    rng = np.random.default_rng(3)
+    r, f = TU.random_gtr_params(T, rng)
+    pr = _params(spec, T, **{"GTR rates": r, "frequencies": f,
+                              "Weibull shape": np.full((T, 1), 0.8)})
+    dev = torch.device("cuda", 0)
+    d_pid = torch.from_numpy(pids).to(dev)
+    d_bl = torch.from_numpy(bls).to(dev)
+    d_pr = torch.from_numpy(pr).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(with_site, with_subst):
+        ll = torch.zeros(T, dtype=torch.float64, device=dev)
+        g = torch.zeros((T, N), dtype=torch.float64, device=dev)
+        site = torch.zeros(T, dtype=torch.float64, device=dev)
+        sub = torch.zeros((T, 8), dtype=torch.float64, device=dev)
+        eng.gradients_device(stream, T, d_pid.data_ptr(), d_bl.data_ptr(), d_pr.data_ptr(),
+                             ll.data_ptr(), g.data_ptr(), site.data_ptr() if with_site else None,
+                             sub.data_ptr() if with_subst else None)
+        eng.check_status(stream)
+        torch.cuda.synchronize()
+        return ll.cpu().numpy(), g.cpu().numpy(), site.cpu().numpy(), sub.cpu().numpy(), \
+            eng.last_call_info()
+
+    full = call(True, True)
+    og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, False, 4)
+    assert np.all(np.abs(full[0] - og["log_likelihood"]) <= RTOL * np.abs(og["log_likelihood"]))
+    no_subst = call(True, False)
+    branch_only = call(False, False)
+    for part in (no_subst, branch_only):
+        assert np.array_equal(part[0], full[0]) and np.array_equal(part[1], full[1])
+    assert np.array_equal(no_subst[2], full[2])  # site gradient: same (perturbed-model) pass
+    assert np.all(branch_only[2] == 0) and np.all(no_subst[3] == 0)  # untouched outputs
+
+
 def test_random_rooted_vs_oracle():
     rng = np.random.default_rng(7)
     n, P, T = 12, 77, 4

@@ -972,7 +972,8 @@ int32_t mi_engine_gradients_unrooted(mi_engine* e, int32_t T, const int32_t* par
   if (mi_engine_gradients_unrooted_device(
           e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
           e->in_params.as<double>(), rescaling, e->out_ll.as<double>(), e->out_a.as<double>(),
-          e->out_site.as<double>(), e->out_subst.as<double>()))
+          out_site ? e->out_site.as<double>() : nullptr,
+          out_subst ? e->out_subst.as<double>() : nullptr))  // NULL outputs skip their work
     return 1;
   if (download(e, out_ll, e->out_ll, T)) return 1;
   if (download(e, out_branch, e->out_a, (size_t)T * N)) return 1;
@@ -1039,7 +1040,8 @@ int32_t mi_engine_gradients_rooted(mi_engine* e, int32_t T, const int32_t* paren
           e->in_rate_counts.as<int32_t>(), e->in_heights.as<double>(),
           e->in_bounds.as<double>(), e->in_ratios.as<double>(), rescaling,
           e->out_ll.as<double>(), e->out_a.as<double>(), e->out_b.as<double>(),
-          e->out_site.as<double>(), e->out_subst.as<double>()))
+          out_site ? e->out_site.as<double>() : nullptr,
+          out_subst ? e->out_subst.as<double>() : nullptr))  // NULL outputs skip their work
     return 1;
   if (download(e, out_ll, e->out_ll, T)) return 1;
   if (download(e, out_ratios, e->out_a, (size_t)T * (n - 1))) return 1;

@@ -149,15 +149,24 @@ class Engine:
             self._h, T, _ptr(pid), _ptr(bl), _ptr(pr), int(rescaling), _ptr(out)))
         return out
 
-    def gradients(self, parent_ids, branch_lengths, params=None, rescaling=False):
-        """Engine::Gradients(const UnrootedTreeCollection&, ...) -> [PhyloGradient]."""
+    def gradients(self, parent_ids, branch_lengths, params=None, rescaling=False,
+                  gradient_blocks=None):
+        """Engine::Gradients(const UnrootedTreeCollection&, ...) -> [PhyloGradient].
+
+        gradient_blocks (an extension): None = every block the reference returns; or a
+        collection of block names the caller will read ("branch_lengths" always comes) --
+        a caller that only uses the branch-length gradient of a GTR model (vip does) saves
+        the 16 finite-difference passes behind "substitution_model" and the extra pass
+        behind "site_model"; what is returned is bit-identical to the full call."""
         n, N = self.taxon_count, self.node_count
         pid = _np(parent_ids, np.int32).reshape(-1, 2 * n - 3)
         T = pid.shape[0]
         bl = _np(branch_lengths, np.float64).reshape(T, 2 * n - 2)
         pr = self._params(params, T)
         ll, g = np.empty(T), np.empty((T, N))
-        site, subst = np.empty(T), np.empty((T, 8))
+        want = None if gradient_blocks is None else set(gradient_blocks)
+        site = np.empty(T) if want is None or "site_model" in want else None
+        subst = np.empty((T, 8)) if want is None or "substitution_model" in want else None
         self._check(self._lib.mi_engine_gradients_unrooted(
             self._h, T, _ptr(pid), _ptr(bl), _ptr(pr), int(rescaling), _ptr(ll), _ptr(g),
             _ptr(site), _ptr(subst)))
@@ -166,9 +175,9 @@ class Engine:
     def _phylo_gradients(self, ll, blocks, site, subst):
         """Per-tree PhyloGradient objects over row views of the freshly allocated result
         arrays of one call (no per-tree copies: 1000 trees cost ~0.3 ms instead of ~1.1)."""
-        if self.category_count > 1:
+        if self.category_count > 1 and site is not None:
             blocks = dict(blocks, site_model=site.reshape(-1, 1))
-        if self.is_gtr:
+        if self.is_gtr and subst is not None:
             blocks = dict(blocks, substitution_model=subst)
         names = list(blocks)
         rows = [list(blocks[k]) for k in names]  # lists of row views

@@ -651,6 +651,14 @@ def test_optional_outputs_skip_work_but_not_results():
         assert np.array_equal(part[0], full[0]) and np.array_equal(part[1], full[1])
     assert np.array_equal(no_subst[2], full[2])  # site gradient: same (perturbed-model) pass
     assert np.all(branch_only[2] == 0) and np.all(no_subst[3] == 0)  # untouched outputs
+    # the Python mirror's form of the same thing
+    allg = eng.gradients(pids, bls, pr)
+    some = eng.gradients(pids, bls, pr, gradient_blocks=("branch_lengths",))
+    assert sorted(allg[0].gradient) == ["branch_lengths", "site_model", "substitution_model"]
+    assert sorted(some[0].gradient) == ["branch_lengths"]
+    for a_, b_ in zip(allg, some):
+        assert a_.log_likelihood == b_.log_likelihood
+        assert np.array_equal(a_.gradient["branch_lengths"], b_.gradient["branch_lengths"])
 
 
 def test_random_rooted_vs_oracle():

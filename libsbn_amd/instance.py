@@ -113,9 +113,12 @@ class unrooted_instance(_Instance):
         pid, bl = self._trees()
         return self.get_engine().log_likelihoods(pid, bl, self._params, self._rescaling)
 
-    def phylo_gradients(self):
+    def phylo_gradients(self, gradient_blocks=None):
+        """pylibsbn's phylo_gradients(); gradient_blocks (an extension, see
+        Engine.gradients) names the blocks the caller will read."""
         pid, bl = self._trees()
-        return self.get_engine().gradients(pid, bl, self._params, self._rescaling)
+        return self.get_engine().gradients(pid, bl, self._params, self._rescaling,
+                                           gradient_blocks=gradient_blocks)
 
 
 class rooted_instance(_Instance):

@@ -661,6 +661,46 @@ def test_optional_outputs_skip_work_but_not_results():
         assert np.array_equal(a_.gradient["branch_lengths"], b_.gradient["branch_lengths"])
 
 
+def test_extreme_branch_lengths():
+    """Branches of length 0 (P = I), 1e-12, 1e-9 and 25-40 substitutions per site (P at
+    stationarity), internal and pendant, with and without rescaling: both call kinds keep
+    the parity bar (the expm1 form of the transition matrices matters for the tiny ones)."""
+    rng = np.random.default_rng(5)
+    for n, P, K, subst in ((12, 60, 4, "JC69"), (27, 100, 4, "GTR"), (40, 64, 1, "GTR"),
+                           (27, 50, 8, "JC69")):
+        T = 5
+        tips, w = TU.random_alignment(n, P, rng)
+        pids, bls = TU.random_trees(n, T, rng, mean_bl=0.1)
+        for t in range(T):
+            idx = rng.choice(np.arange(n, bls.shape[1] - 1), size=3, replace=False)
+            bls[t, idx[0]], bls[t, idx[1]], bls[t, idx[2]] = 0.0, 1e-12, 40.0
+            bls[t, rng.integers(0, n)] = 1e-9
+            bls[t, rng.integers(0, n)] = 25.0
+        site = "constant" if K == 1 else f"weibull+{K}"
+        eng = _engine(subst, site, "strict", tips, w)
+        spec = O.make_spec(n, P, subst, site, "strict")
+        blocks = {}
+        if subst == "GTR":
+            r, f = TU.random_gtr_params(T, rng)
+            blocks = {"GTR rates": r, "frequencies": f}
+        if K > 1:
+            blocks["Weibull shape"] = rng.uniform(0.3, 2.0, size=(T, 1))
+        pr = _params(spec, T, **blocks)
+        for resc in (False, True):
+            g = eng.gradients(pids, bls, pr, resc)
+            ll = eng.log_likelihoods(pids, bls, pr, resc)
+            O.set_transition_mode(1)
+            og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 4)
+            O.set_transition_mode(0)
+            for t in range(T):
+                ref = og["log_likelihood"][t]
+                assert abs(g[t].log_likelihood - ref) <= RTOL * abs(ref)
+                assert abs(ll[t] - ref) <= RTOL * abs(ref)
+                want = og["branch_lengths"][t]
+                scale = np.maximum(np.abs(want), 1e-3 * np.max(np.abs(want)))
+                assert np.all(np.abs(g[t].gradient["branch_lengths"] - want) <= 1e-9 * scale + 1e-12)
+
+
 def test_random_rooted_vs_oracle():
     rng = np.random.default_rng(7)
     n, P, T = 12, 77, 4

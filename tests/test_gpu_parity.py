@@ -701,6 +701,41 @@ def test_extreme_branch_lengths():
                 assert np.all(np.abs(g[t].gradient["branch_lengths"] - want) <= 1e-9 * scale + 1e-12)
 
 
+def test_extreme_model_parameters():
+    """Weibull shapes from 0.05 (one category carries all the rate) to 60 (all rates ~1),
+    GTR rates / frequencies down to 1e-5, an all-gap and a constant column."""
+    rng = np.random.default_rng(8)
+    n, P, T = 20, 80, 6
+    tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.1)
+    tips[:, 0] = 4
+    tips[:, 1] = 2
+    pids, bls = TU.random_trees(n, T, rng, mean_bl=0.08)
+    for K, shapes in ((4, [0.05, 0.1, 0.5, 5.0, 20.0, 60.0]), (8, [0.05, 0.2, 1.0, 3.0, 15.0, 40.0])):
+        site = f"weibull+{K}"
+        for subst in ("JC69", "GTR"):
+            eng = _engine(subst, site, "strict", tips, w)
+            spec = O.make_spec(n, P, subst, site, "strict")
+            blocks = {"Weibull shape": np.array(shapes).reshape(T, 1)}
+            if subst == "GTR":
+                r = np.array([[1e-4, 0.3, 0.2, 0.1, 0.3999, 1e-5]] * T)
+                r /= r.sum(1, keepdims=True)
+                f = np.array([[1e-5, 0.4, 0.3, 0.3 - 1e-5]] * T)
+                blocks.update({"GTR rates": r, "frequencies": f})
+            pr = _params(spec, T, **blocks)
+            for resc in (False, True):
+                g = eng.gradients(pids, bls, pr, resc,
+                                  gradient_blocks=("branch_lengths", "site_model"))
+                O.set_transition_mode(1)
+                og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 4)
+                O.set_transition_mode(0)
+                for t in range(T):
+                    ref = og["log_likelihood"][t]
+                    assert abs(g[t].log_likelihood - ref) <= RTOL * abs(ref)
+                    want = og["branch_lengths"][t]
+                    scale = np.maximum(np.abs(want), 1e-3 * np.max(np.abs(want)))
+                    assert np.all(np.abs(g[t].gradient["branch_lengths"] - want) <= 1e-8 * scale)
+
+
 def test_random_rooted_vs_oracle():
     rng = np.random.default_rng(7)
     n, P, T = 12, 77, 4

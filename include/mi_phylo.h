@@ -56,14 +56,15 @@ extern "C" {
 
 typedef struct mi_engine mi_engine;
 
-enum { MI_SUBST_JC69 = 0, MI_SUBST_GTR = 1 };       /* src/substitution_model.cpp:6-15 */
+enum { MI_SUBST_JC69 = 0, MI_SUBST_GTR = 1,         /* src/substitution_model.cpp:6-15 */
+       MI_SUBST_REVERSIBLE = 2 };                     /* 20 states: empirical model given as data */
 enum { MI_SITE_CONSTANT = 0, MI_SITE_WEIBULL = 1 }; /* src/site_model.cpp:10-25 */
 enum { MI_CLOCK_NONE = 0, MI_CLOCK_STRICT = 1 };    /* src/clock_model.cpp:6-15 */
 
 typedef struct {
   int32_t taxon_count;    /* n >= 3 */
   int32_t pattern_count;  /* P >= 1 */
-  int32_t state_count;    /* s: 4 */
+  int32_t state_count;    /* s: 4 (DNA, everything the reference has) or 20 (amino acids) */
   int32_t category_count; /* K: 1 for constant, K of "weibull+K" */
   int32_t subst_model;    /* MI_SUBST_* */
   int32_t site_model;     /* MI_SITE_* */
@@ -84,6 +85,21 @@ const char* mi_last_error(void);
 int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
                          const double* tip_partials, const double* pattern_weights,
                          mi_engine** out_engine);
+/* 20-state engines (state_count == 20, subst_model == MI_SUBST_REVERSIBLE; not in the
+ * reference, whose factory src/substitution_model.cpp:6-15 knows JC69 and GTR only -- this is
+ * the entry a third branch `"WAG"` of that factory would call).  The model is DATA with no
+ * free parameters: 190 exchangeabilities (upper triangle, row by row, like the reference's
+ * GTR rates, substitution_model.cpp:39-55) and 20 frequencies, amino-acid order
+ * ARNDCQEGHILKMFPSTWYV; Q is built and normalised by the reference's GTR recipe and
+ * eigendecomposed on the device once.  NULL tables = the built-in WAG table
+ * (mi_engine_create does the same for such a spec).  tip_states: 0..19, >= 20 = gap /
+ * ambiguous.  Parameter rows then hold only the site and clock blocks, as for JC69. */
+int32_t mi_engine_create_reversible(const mi_engine_spec* spec, const double* exchangeabilities,
+                                    const double* frequencies, const int32_t* tip_states,
+                                    const double* tip_partials, const double* pattern_weights,
+                                    mi_engine** out_engine);
+/* the built-in WAG table in that form: exchangeabilities[190], frequencies[20] (sum 1) */
+int32_t mi_wag_model(double* exchangeabilities, double* frequencies);
 void mi_engine_destroy(mi_engine* engine);
 
 /* Engine::GetPhyloModelBlockSpecification: blocks in std::map (ASCII) order. */

@@ -25,6 +25,9 @@ SYMBOLS = {
     "mi_abi_version": (C.c_int32, []),
     "mi_last_error": (C.c_char_p, []),
     "mi_engine_create": (C.c_int32, [C.POINTER(EngineSpec), _V, _V, _V, C.POINTER(_V)]),
+    "mi_engine_create_reversible":
+        (C.c_int32, [C.POINTER(EngineSpec), _V, _V, _V, _V, _V, C.POINTER(_V)]),
+    "mi_wag_model": (C.c_int32, [F64P, F64P]),
     "mi_engine_destroy": (None, [_V]),
     "mi_engine_param_count": (C.c_int32, [_V]),
     "mi_engine_block_count": (C.c_int32, [_V]),

@@ -1,0 +1,688 @@
+// 20-state (amino-acid) path: Felsenstein pruning, the pre-order sweep and the edge
+// derivatives for alignments whose partial-likelihood vectors (PLVs) do not fit on chip
+// (BASELINE.json configs[4]: 512 taxa x 50 000 patterns x 4 categories, 32 MB per PLV).
+//
+// Restates, for s = 20, what the reference asks BEAGLE to do in
+//   FatBeagle::LogLikelihoodInternals   src/fat_beagle.cpp:50-70
+//   FatBeagle::BranchGradientInternals  src/fat_beagle.cpp:119-175
+// (update transition matrices, post-order partials with rescaling, root log-likelihood,
+// pre-order partials, edge derivatives).  The reference itself is DNA-only
+// (src/substitution_model.cpp:6-15); parity is against the s-generic CPU oracle.
+//
+// Mapping (gfx950, wave64).  One wave = one (evaluation, rate category, block of
+// kAa{Post,Pre}Tiles x 16 site patterns); it walks the whole tree for its block and never
+// talks to another wave.  A 16-pattern tile of one category is five registers:
+//     reg t, lane l  =  L[state 4t + (l >> 4)][pattern l & 15]
+// which is at once
+//   * the B operand of k-step t of  v_mfma_f64_16x16x4_f64  (B[k][j] at lane 16k + j) and of
+//     v_mfma_f64_4x4x4_4b_f64 (B_b[k][j'] at lane 16k + 4b + j'),
+//   * the C/D layout of both (16x16x4: row (l>>4) + 4r, col l&15; 4x4x4: row l>>4), so the
+//     result of P x L -- rows 0..15 from five 16x16x4 steps, rows 16..19 from five 4x4x4
+//     steps: 20 = 16 + 4, no padding -- is again a tile, with no cross-lane movement,
+//   * 512 contiguous bytes in HBM: the arena layout is
+//     [evaluation][node][category][tile][state][16 patterns] (pattern-major inside a tile),
+//     so every load/store instruction of a wave moves one contiguous 512-byte line group.
+// Measured (tools/fp64_peak_probe.hip, profiles/r02_fp64_peak_probe.txt): this 16+4 mix
+// sustains 69-71 TFLOP/s device-wide at >= 2 waves per SIMD, the same as 4x4x4 alone, with
+// 2.5x fewer instructions; 16x16x4 alone (rows padded to 32) reaches 34-49.
+// Transition matrices are pre-packed by aa_transition_kernel as A operands (10 registers
+// per matrix), tips are compact states: a tip child's product is a gather of a COLUMN of P.
+// Rescaling is by exact powers of two per (pattern, category) column at every internal
+// node (the column sum's exponent, obtained in all four lanes of the column by one more
+// 4x4x4 product with a ones matrix).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "mi_phylo_device_utils.h"
+#include "mi_phylo_kernels.h"
+
+namespace miphylo {
+
+namespace {
+using namespace dev;
+
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------
+// Model set-up: Q from (exchangeabilities, frequencies) by the reference's GTR recipe
+// (substitution_model.cpp:39-80) and its symmetric eigendecomposition (cyclic Jacobi,
+// one wave; once per engine).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void aa_model_setup_kernel(const double* exch,
+                                                             const double* freqs, AaModel* m,
+                                                             int32_t* status) {
+  __shared__ double A[kAa * kAa], U[kAa * kAa], Q[kAa * kAa], pi[kAa], sq[kAa], ev[kAa];
+  __shared__ double rot[2];
+  __shared__ int done;
+  const int lane = threadIdx.x;
+  if (lane < kAa) {
+    pi[lane] = freqs[lane];
+    sq[lane] = sqrt(freqs[lane]);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double fsum = 0;
+    for (int i = 0; i < kAa; i++) fsum += pi[i];
+    if (fabs(fsum - 1.) >= 0.001) set_status(status, kGtrFrequencies, 0);
+    int ri = 0;
+    for (int i = 0; i < kAa; i++)
+      for (int j = i + 1; j < kAa; j++) {
+        const double r = exch[ri++];
+        Q[i * kAa + j] = r * pi[j];
+        Q[j * kAa + i] = r * pi[i];
+      }
+    double total = 0;
+    for (int i = 0; i < kAa; i++) {
+      double row = 0;
+      for (int j = 0; j < kAa; j++)
+        if (i != j) row += Q[i * kAa + j];
+      Q[i * kAa + i] = -row;
+      total += row * pi[i];
+    }
+    for (int i = 0; i < kAa * kAa; i++) Q[i] /= total;
+  }
+  __syncthreads();
+  for (int idx = lane; idx < kAa * kAa; idx += 64) {
+    const int i = idx / kAa, j = idx % kAa;
+    // S = Pi^1/2 Q Pi^-1/2; the lower triangle is authoritative
+    const int a = i >= j ? i : j, b = i >= j ? j : i;
+    A[idx] = sq[a] * Q[a * kAa + b] * (1.0 / sq[b]);
+    U[idx] = i == j ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int sweep = 0; sweep < 100; sweep++) {
+    if (lane == 0) {
+      double off = 0, diag = 0;
+      for (int i = 0; i < kAa; i++)
+        for (int j = 0; j < kAa; j++) {
+          const double x = A[i * kAa + j];
+          if (i != j) off += x * x;
+          else diag += x * x;
+        }
+      done = (off <= 1e-45 * diag || off == 0.) ? 1 : 0;
+    }
+    __syncthreads();
+    if (done) break;
+    for (int p = 0; p < kAa - 1; p++)
+      for (int q = p + 1; q < kAa; q++) {
+        if (lane == 0) {
+          const double apq = A[p * kAa + q];
+          double c = 1.0, sn = 0.0;
+          if (apq != 0.) {
+            const double theta = (A[q * kAa + q] - A[p * kAa + p]) / (2. * apq);
+            const double t = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+            c = 1. / sqrt(t * t + 1.);
+            sn = t * c;
+          }
+          rot[0] = c;
+          rot[1] = sn;
+        }
+        __syncthreads();
+        const double c = rot[0], sn = rot[1];
+        if (lane < kAa) {
+          const int k = lane;
+          const double akp = A[k * kAa + p], akq = A[k * kAa + q];
+          A[k * kAa + p] = c * akp - sn * akq;
+          A[k * kAa + q] = sn * akp + c * akq;
+        }
+        __syncthreads();
+        if (lane < kAa) {
+          const int k = lane;
+          const double apk = A[p * kAa + k], aqk = A[q * kAa + k];
+          A[p * kAa + k] = c * apk - sn * aqk;
+          A[q * kAa + k] = sn * apk + c * aqk;
+          const double ukp = U[k * kAa + p], ukq = U[k * kAa + q];
+          U[k * kAa + p] = c * ukp - sn * ukq;
+          U[k * kAa + q] = sn * ukp + c * ukq;
+        }
+        __syncthreads();
+      }
+  }
+  if (lane == 0) {
+    for (int i = 0; i < kAa; i++) ev[i] = A[i * kAa + i];
+    for (int i = 0; i < kAa - 1; i++) {  // ascending, permuting the columns of U
+      int mi = i;
+      for (int j = i + 1; j < kAa; j++)
+        if (ev[j] < ev[mi]) mi = j;
+      if (mi != i) {
+        const double t = ev[i]; ev[i] = ev[mi]; ev[mi] = t;
+        for (int k = 0; k < kAa; k++) {
+          const double u = U[k * kAa + i]; U[k * kAa + i] = U[k * kAa + mi]; U[k * kAa + mi] = u;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (lane < kAa) {
+    m->pi[lane] = pi[lane];
+    m->lambda[lane] = ev[lane];
+  }
+  for (int idx = lane; idx < kAa * kAa; idx += 64) {
+    const int i = idx / kAa, j = idx % kAa;
+    m->Q[idx] = Q[idx];
+    m->V[idx] = (1.0 / sq[i]) * U[idx];
+    m->Vinv[idx] = U[j * kAa + i] * sq[j];
+  }
+}
+
+// ------------------------------------------------------------------------
+// Transition matrices (beagleUpdateTransitionMatrices, fat_beagle.cpp:304-314), one
+// workgroup per (edge, category, evaluation): P = I + V expm1(L r t) V^-1 (the stable form
+// of V exp(L r t) V^-1, see kernels_setup.hip), negative entries clamped to 0 as BEAGLE
+// does; for a gradient call also P^T and P Q.  Internal edges are written as matrix-core
+// A operands:
+//   registers 0..4 (16x16x4, k-step t):  lane l holds M[l & 15][4t + (l >> 4)]
+//   registers 5..9 (4x4x4,   k-step t):  lane l holds M[16 + (l & 3)][4t + (l >> 4)]
+// tip edges as per-state columns (state 20 = gap: P 1 = 1, (P Q) 1 = 0).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aa_transition_kernel(AaTransitionArgs a) {
+  __shared__ double ex[kAa], Pm[kAa * kAa], PQm[kAa * kAa];
+  const int edge = blockIdx.x, k = blockIdx.y, el = blockIdx.z;
+  const int tree = a.eval_offset + el;
+  const int tid = threadIdx.x;
+  const AaModel& m = *a.model;
+  const double rt = a.models[tree].cat_rate[k] * a.bl_eff[(size_t)tree * a.N + edge];
+  if (tid < kAa) ex[tid] = expm1(m.lambda[tid] * rt);
+  __syncthreads();
+  for (int idx = tid; idx < kAa * kAa; idx += 256) {
+    const int i = idx / kAa, j = idx % kAa;
+    double sum = i == j ? 1.0 : 0.0;
+    for (int x = 0; x < kAa; x++) sum += m.V[i * kAa + x] * ex[x] * m.Vinv[x * kAa + j];
+    Pm[idx] = sum > 0 ? sum : 0;
+  }
+  __syncthreads();
+  if (a.gradient) {
+    for (int idx = tid; idx < kAa * kAa; idx += 256) {
+      const int i = idx / kAa, j = idx % kAa;
+      double sum = 0;
+      for (int x = 0; x < kAa; x++) sum += Pm[i * kAa + x] * m.Q[x * kAa + j];
+      PQm[idx] = sum;
+    }
+    __syncthreads();
+  }
+  if (edge < a.n) {
+    const size_t base = (((size_t)el * a.n + edge) * a.K + k) * kAaTipTable;
+    for (int idx = tid; idx < kAaTipTable; idx += 256) {
+      const int x = idx / kAa, i = idx % kAa;
+      a.tipP[base + idx] = x < kAa ? Pm[i * kAa + x] : 1.0;
+      if (a.gradient) a.tipPQ[base + idx] = x < kAa ? PQm[i * kAa + x] : 0.0;
+    }
+  } else {
+    const size_t base = (((size_t)el * (a.n - 1) + (edge - a.n)) * a.K + k) * kAaPack;
+    for (int idx = tid; idx < kAaPack; idx += 256) {
+      const int r = idx >> 6, l = idx & 63, g = l >> 4;
+      const int t = r < 5 ? r : r - 5;
+      const int row = r < 5 ? (l & 15) : 16 + (l & 3), col = 4 * t + g;
+      a.matP[base + idx] = Pm[row * kAa + col];
+      if (a.gradient) {
+        a.matPT[base + idx] = Pm[col * kAa + row];
+        a.matPQ[base + idx] = PQm[row * kAa + col];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
+// Walk helpers
+// ------------------------------------------------------------------------
+__device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// S = M x L for M tiles of 16 patterns: per tile five 16x16x4 steps (rows 0..15) and five
+// 4x4x4 steps (rows 16..19)
+template <int M>
+__device__ __forceinline__ void mat_apply(const double* __restrict__ pack, int lane,
+                                          const double (&L)[M][5], double (&S)[M][5]) {
+  double A16[5], A4[5];
+#pragma unroll
+  for (int t = 0; t < 5; t++) {
+    A16[t] = pack[t * 64 + lane];
+    A4[t] = pack[(5 + t) * 64 + lane];
+  }
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    double4v c = {0, 0, 0, 0};
+    double d = 0;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(A16[t], L[u][t], c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f64_4x4x4f64(A4[t], L[u][t], d, 0, 0, 0);
+    }
+    S[u][0] = c.x; S[u][1] = c.y; S[u][2] = c.z; S[u][3] = c.w;
+    S[u][4] = d;
+  }
+}
+
+// product of a tip child: column `state` of the matrix (tables [21][20])
+template <int M>
+__device__ __forceinline__ void tip_apply(const double* __restrict__ table,
+                                          const int8_t* __restrict__ tips, int P, int p0, int lane,
+                                          double (&S)[M][5]) {
+  const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    const int p = p0 + u * 16 + j;
+    const int x = p < P ? tips[p] : kAa;
+    const double* col = table + x * kAa + g;
+#pragma unroll
+    for (int t = 0; t < 5; t++) S[u][t] = col[4 * t];
+  }
+}
+
+template <int M>
+__device__ __forceinline__ void load_tiles(const double* __restrict__ src, int lane,
+                                           double (&L)[M][5]) {
+#pragma unroll
+  for (int u = 0; u < M; u++)
+#pragma unroll
+    for (int t = 0; t < 5; t++) L[u][t] = src[u * kAaTileDoubles + t * 64 + lane];
+}
+template <int M>
+__device__ __forceinline__ void store_tiles(double* __restrict__ dst, int lane,
+                                            const double (&L)[M][5]) {
+#pragma unroll
+  for (int u = 0; u < M; u++)
+#pragma unroll
+    for (int t = 0; t < 5; t++) dst[u * kAaTileDoubles + t * 64 + lane] = L[u][t];
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs by linear id.  The walk kernels give each
+// XCD a CONTIGUOUS range of the (evaluation x category)-major work list, so that an XCD's
+// L2 holds the transition matrices of one or two (evaluation, category) units instead of all.
+struct AaUnit {
+  int ec, blk;
+  bool valid;
+};
+__device__ __forceinline__ AaUnit aa_unit(int blocks, int units) {
+  const long W = (long)blocks * units;
+  const long per = (W + 7) / 8;
+  const long id = blockIdx.x;
+  const long w = (id & 7) * per + (id >> 3);
+  AaUnit r;
+  r.valid = (id >> 3) < per && w < W;
+  r.ec = (int)(w / blocks);
+  r.blk = (int)(w - (long)r.ec * blocks);
+  return r;
+}
+
+// ------------------------------------------------------------------------
+// Post-order (beagleUpdatePartials with rescaling + beagleCalculateRootLogLikelihoods'
+// per-pattern part; fat_beagle.cpp:60-68,139-141).  The schedule is tree_setup's
+// Sethi-Ullman post-order: the node visited just before a node is one of its children
+// (unless both are tips), and that child's vector is taken from the registers the previous
+// visit left it in.  GRAD: every internal vector is also kept in the arena, by node, for the
+// pre-order kernel; otherwise only vectors that are not consumed from registers are
+// written, into the schedule's slot (<= floor(log2 n) + 1 per evaluation).
+// ------------------------------------------------------------------------
+template <int M, bool GRAD>
+__global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
+  const int blocks = a.tiles / M;
+  const AaUnit un = aa_unit(blocks, a.evals * a.K);
+  if (!un.valid) return;
+  const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
+  const int el = un.ec / a.K, cat = un.ec - el * a.K, blk = un.blk;
+  const int tree = a.eval_offset + el;
+  const int n = a.n, K = a.K, P = a.P;
+  const int p0 = blk * M * 16;
+  const size_t tiles = a.tiles;
+  const int nodes = GRAD ? n - 1 : a.slots;
+  const SchedEntry* sched = a.sched + (size_t)tree * (n - 1);
+  double* arena = a.arena + (((size_t)el * nodes * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles;
+  const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;  // per node / slot
+  int32_t* exp_cum = a.exp_cum + ((size_t)el * nodes * K + cat) * tiles * 16 + p0;
+  int32_t* exp_loc = GRAD ? a.exp_loc + ((size_t)el * (n - 1) * K + cat) * tiles * 16 + p0 : nullptr;
+  const size_t exp_stride = (size_t)K * tiles * 16;
+  const double* matP = a.matP + ((size_t)el * (n - 1) * K + cat) * kAaPack;
+  const double* tipP = a.tipP + ((size_t)el * n * K + cat) * kAaTipTable;
+
+  double R[M][5];
+  int E[M];
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    E[u] = 0;
+#pragma unroll
+    for (int t = 0; t < 5; t++) R[u][t] = 0;
+  }
+  int prev = -1;
+  for (int i = 0; i < n - 1; i++) {
+    const SchedEntry se = sched[i];
+    const int v = sgpr(se.node), slots = sgpr(se.slots);
+    const int next_c0 = i + 1 < n - 1 ? sgpr(sched[i + 1].child0) : -1;
+    const int next_c1 = i + 1 < n - 1 ? sgpr(sched[i + 1].child1) : -1;
+    double S[2][M][5];
+    int Ec[2][M];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int ch = sgpr(c ? se.child1 : se.child0);
+      if (ch < n) {
+        tip_apply<M>(tipP + (size_t)ch * K * kAaTipTable, a.tip_states + (size_t)ch * P, P, p0,
+                     lane, S[c]);
+#pragma unroll
+        for (int u = 0; u < M; u++) Ec[c][u] = 0;
+      } else {
+        double L[M][5];
+        if (ch == prev) {
+#pragma unroll
+          for (int u = 0; u < M; u++) {
+            Ec[c][u] = E[u];
+#pragma unroll
+            for (int t = 0; t < 5; t++) L[u][t] = R[u][t];
+          }
+        } else {
+          const int idx = GRAD ? ch - n : ((slots >> (8 + 8 * c)) & 0xff);
+          load_tiles<M>(arena + idx * arena_stride, lane, L);
+#pragma unroll
+          for (int u = 0; u < M; u++) Ec[c][u] = exp_cum[idx * exp_stride + u * 16 + j];
+        }
+        mat_apply<M>(matP + (size_t)(ch - n) * K * kAaPack, lane, L, S[c]);
+      }
+    }
+    int eloc[M];
+#pragma unroll
+    for (int u = 0; u < M; u++) {
+      double cs = 0;
+#pragma unroll
+      for (int t = 0; t < 5; t++) {
+        R[u][t] = S[0][u][t] * S[1][u][t];
+        cs = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, R[u][t], cs, 0, 0, 0);
+      }
+      // exact power-of-two rescaling by the exponent of the column sum (all four lanes of
+      // a column hold the same sum)
+      const int e = cs > 0.0 ? ilogb(cs) : 0;
+#pragma unroll
+      for (int t = 0; t < 5; t++) R[u][t] = ldexp(R[u][t], -e);
+      eloc[u] = e;
+      E[u] = Ec[0][u] + Ec[1][u] + e;
+    }
+    const bool is_root = i == n - 2;
+    const bool chained = v == next_c0 || v == next_c1;
+    if (GRAD) {
+      if (g == 0) {
+#pragma unroll
+        for (int u = 0; u < M; u++) exp_loc[(size_t)(v - n) * exp_stride + u * 16 + j] = eloc[u];
+      }
+      if (!is_root) {
+        store_tiles<M>(arena + (size_t)(v - n) * arena_stride, lane, R);
+        if (!chained && g == 0) {
+#pragma unroll
+          for (int u = 0; u < M; u++) exp_cum[(size_t)(v - n) * exp_stride + u * 16 + j] = E[u];
+        }
+      }
+    } else if (!is_root && !chained) {
+      const int dst = slots & 0xff;
+      store_tiles<M>(arena + dst * arena_stride, lane, R);
+      if (g == 0) {
+#pragma unroll
+        for (int u = 0; u < M; u++) exp_cum[dst * exp_stride + u * 16 + j] = E[u];
+      }
+    }
+    prev = v;
+  }
+  // root: sum_i pi_i L_root[i] per pattern (scaled) and its exponent
+  double pi[5];
+#pragma unroll
+  for (int t = 0; t < 5; t++) pi[t] = a.model->pi[4 * t + g];
+  const size_t rbase = ((size_t)el * K + cat) * tiles * 16 + p0;
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    double s = 0;
+#pragma unroll
+    for (int t = 0; t < 5; t++) s += pi[t] * R[u][t];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (g == 0) {
+      a.root_val[rbase + u * 16 + j] = s;
+      a.root_exp[rbase + u * 16 + j] = E[u];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
+// Root: the categories meet (site likelihood), log-likelihood partial sums, and the weight
+// the root's pre-order vector carries: w_p cw_k 2^(E_k - Emax) / site_p  (the pre-order
+// recursion is linear, so every edge derivative is then a plain sum over patterns).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aa_root_kernel(AaWalkArgs a) {
+  __shared__ double red[256];
+  const int el = blockIdx.y, tree = a.eval_offset + el;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const size_t tp = (size_t)a.tiles * 16;
+  const DevModel& m = a.models[tree];
+  double ll = 0;
+  if (p < (int)tp) {
+    const size_t base = (size_t)el * a.K * tp + p;
+    if (p < a.P) {
+      int emax = INT_MIN;
+      for (int k = 0; k < a.K; k++) emax = max(emax, a.root_exp[base + k * tp]);
+      double site = 0;
+      for (int k = 0; k < a.K; k++)
+        site += m.cat_weight[k] * ldexp(a.root_val[base + k * tp], a.root_exp[base + k * tp] - emax);
+      const double w = a.weights[p];
+      ll = w * (log(site) + emax * 0.6931471805599453094);
+      if (a.root_scale)
+        for (int k = 0; k < a.K; k++)
+          a.root_scale[base + k * tp] =
+              w * m.cat_weight[k] * ldexp(1.0, a.root_exp[base + k * tp] - emax) / site;
+    } else if (a.root_scale) {
+      for (int k = 0; k < a.K; k++) a.root_scale[base + k * tp] = 0.0;
+    }
+  }
+  red[threadIdx.x] = ll;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.ll_part[(size_t)tree * a.ll_stride + blockIdx.x] = red[0];
+}
+
+// ------------------------------------------------------------------------
+// Pre-order + edge derivatives (beagleUpdatePrePartials, beagleCalculateEdgeDerivatives;
+// fat_beagle.cpp:144-166), walking the same schedule backwards: a parent before its
+// children, and the node visited next is one of the current node's children, whose
+// pre-order vector stays in registers.  With L_s = L 2^-E (E: powers of two removed in the
+// subtree) and q_s = q 2^E, q_s o L_s is scale free and
+//     q_child_s = P_child^T (q_s o P_sib L_sib_s) 2^-e_node
+// (e_node: the power removed AT the node), so only e_node is needed here.  The derivative of
+// edge x (child of v, sibling y) is  sum (q_v o P_y L_y) . (P_x Q) L_x : for a tip x both
+// products are table look-ups.  A child's pre-order vector overwrites its post-order
+// vector in the arena (dead once the parent has been visited).
+// ------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
+  const int blocks = a.tiles / M;
+  const AaUnit un = aa_unit(blocks, a.evals * a.K);
+  if (!un.valid) return;
+  const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
+  const int el = un.ec / a.K, cat = un.ec - el * a.K, blk = un.blk;
+  const int tree = a.eval_offset + el;
+  const int n = a.n, N = a.N, K = a.K, P = a.P;
+  const int p0 = blk * M * 16;
+  const size_t tiles = a.tiles;
+  const SchedEntry* sched = a.sched + (size_t)tree * (n - 1);
+  double* arena = a.arena + (((size_t)el * (n - 1) * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles;
+  const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;
+  const int32_t* exp_loc = a.exp_loc + ((size_t)el * (n - 1) * K + cat) * tiles * 16 + p0;
+  const size_t exp_stride = (size_t)K * tiles * 16;
+  const size_t mbase = ((size_t)el * (n - 1) * K + cat) * kAaPack;
+  const double* matP = a.matP + mbase;
+  const double* matPT = a.matPT + mbase;
+  const double* matPQ = a.matPQ + mbase;
+  const double* tipP = a.tipP + ((size_t)el * n * K + cat) * kAaTipTable;
+  const double* tipPQ = a.tipPQ + ((size_t)el * n * K + cat) * kAaTipTable;
+  double* gp = a.g_part + (((size_t)el * K + cat) * blocks + blk) * N;
+
+  double Qk[M][5];
+#pragma unroll
+  for (int u = 0; u < M; u++)
+#pragma unroll
+    for (int t = 0; t < 5; t++) Qk[u][t] = 0;
+  int kept = -1;
+  for (int i = n - 2; i >= 0; i--) {
+    const SchedEntry se = sched[i];
+    const int v = sgpr(se.node);
+    const int next = i > 0 ? sgpr(sched[i - 1].node) : -1;
+    double q[M][5];
+    if (i == n - 2) {
+      const size_t rbase = ((size_t)el * K + cat) * tiles * 16 + p0;
+#pragma unroll
+      for (int u = 0; u < M; u++) {
+        const double rs = a.root_scale[rbase + u * 16 + j];
+#pragma unroll
+        for (int t = 0; t < 5; t++) q[u][t] = a.model->pi[4 * t + g] * rs;
+      }
+    } else if (kept == v) {
+#pragma unroll
+      for (int u = 0; u < M; u++)
+#pragma unroll
+        for (int t = 0; t < 5; t++) q[u][t] = Qk[u][t];
+    } else {
+      load_tiles<M>(arena + (size_t)(v - n) * arena_stride, lane, q);
+    }
+    int ev[M];
+#pragma unroll
+    for (int u = 0; u < M; u++) ev[u] = exp_loc[(size_t)(v - n) * exp_stride + u * 16 + j];
+    double S[2][M][5], D[2][M][5];
+    int ch[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      ch[c] = sgpr(c ? se.child1 : se.child0);
+      if (ch[c] < n) {
+        const int8_t* tips = a.tip_states + (size_t)ch[c] * P;
+        tip_apply<M>(tipP + (size_t)ch[c] * K * kAaTipTable, tips, P, p0, lane, S[c]);
+        tip_apply<M>(tipPQ + (size_t)ch[c] * K * kAaTipTable, tips, P, p0, lane, D[c]);
+      } else {
+        double L[M][5];
+        load_tiles<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, L);
+        mat_apply<M>(matP + (size_t)(ch[c] - n) * K * kAaPack, lane, L, S[c]);
+        mat_apply<M>(matPQ + (size_t)(ch[c] - n) * K * kAaPack, lane, L, D[c]);
+      }
+    }
+    // u_c = q o S[sibling] 2^-e (kept in S[sibling]); X_c = sum u_c . D[c]
+    double X0 = 0, X1 = 0;
+#pragma unroll
+    for (int u = 0; u < M; u++)
+#pragma unroll
+      for (int t = 0; t < 5; t++) {
+        const double qq = ldexp(q[u][t], -ev[u]);
+        const double u0 = qq * S[1][u][t], u1 = qq * S[0][u][t];
+        X0 += u0 * D[0][u][t];
+        X1 += u1 * D[1][u][t];
+        S[1][u][t] = u0;
+        S[0][u][t] = u1;
+      }
+    X0 = wave_sum(X0);
+    X1 = wave_sum(X1);
+    if (lane == 0) {
+      gp[ch[0]] = X0;
+      gp[ch[1]] = X1;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      if (ch[c] < n) continue;
+      double qc[M][5];
+      mat_apply<M>(matPT + (size_t)(ch[c] - n) * K * kAaPack, lane, S[1 - c], qc);
+      if (ch[c] == next) {
+#pragma unroll
+        for (int u = 0; u < M; u++)
+#pragma unroll
+          for (int t = 0; t < 5; t++) Qk[u][t] = qc[u][t];
+        kept = ch[c];
+      } else {
+        store_tiles<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, qc);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
+// Reduction: log-likelihood per evaluation; branch gradient sum_k r_k X_k and site-model
+// numerator sum_k (d r_k / d shape) X_k per edge, blocks summed in order (deterministic).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aa_reduce_kernel(AaWalkArgs a, int ll_blocks) {
+  const int el = blockIdx.y, tree = a.eval_offset + el;
+  const int N = a.N;
+  if (blockIdx.x == 0) {
+    __shared__ double red[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < ll_blocks; i += 256) s += a.ll_part[(size_t)tree * a.ll_stride + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) a.ll_sum[tree] = red[0];
+    if (!a.gradient) return;
+  }
+  if (!a.gradient) return;
+  const int edge = blockIdx.x * 256 + threadIdx.x;
+  if (edge >= N) return;
+  const DevModel& m = a.models[tree];
+  const int blocks = a.tiles / kAaPreTiles;
+  double br = 0, si = 0;
+  if (edge < N - 1) {
+    for (int k = 0; k < a.K; k++) {
+      const double* gp = a.g_part + ((size_t)el * a.K + k) * blocks * N + edge;
+      double x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+      int b = 0;
+      for (; b + 4 <= blocks; b += 4) {
+        x0 += gp[(size_t)b * N];
+        x1 += gp[(size_t)(b + 1) * N];
+        x2 += gp[(size_t)(b + 2) * N];
+        x3 += gp[(size_t)(b + 3) * N];
+      }
+      for (; b < blocks; b++) x0 += gp[(size_t)b * N];
+      const double xs = (x0 + x1) + (x2 + x3);
+      br += m.cat_rate[k] * xs;
+      si += m.cat_drate[k] * xs;
+    }
+  }
+  a.g_sum[((size_t)tree * 2 + 0) * N + edge] = br;
+  a.g_sum[((size_t)tree * 2 + 1) * N + edge] = si;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------
+// Launch wrappers
+// ------------------------------------------------------------------------
+void launch_aa_model_setup(const double* exch, const double* freqs, AaModel* model,
+                           int32_t* status, hipStream_t s) {
+  hipLaunchKernelGGL(aa_model_setup_kernel, dim3(1), dim3(64), 0, s, exch, freqs, model, status);
+}
+void launch_aa_transition(const AaTransitionArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(aa_transition_kernel, dim3(a.N - 1, a.K, a.evals), dim3(256), 0, s, a);
+}
+int aa_tiles(int P) {
+  const int per = std::max(kAaPostTiles, kAaPreTiles);
+  const int tiles = (P + kAaTile - 1) / kAaTile;
+  return (tiles + per - 1) / per * per;
+}
+int aa_ll_blocks(int P) { return (aa_tiles(P) * kAaTile + 255) / 256; }
+static unsigned aa_grid(int blocks, int units) {
+  const long W = (long)blocks * units;
+  return (unsigned)(8 * ((W + 7) / 8));
+}
+void launch_aa_post(const AaWalkArgs& a, hipStream_t s) {
+  const dim3 grid(aa_grid(a.tiles / kAaPostTiles, a.evals * a.K));
+  if (a.gradient)
+    hipLaunchKernelGGL((aa_post_kernel<kAaPostTiles, true>), grid, dim3(64), 0, s, a);
+  else
+    hipLaunchKernelGGL((aa_post_kernel<kAaPostTiles, false>), grid, dim3(64), 0, s, a);
+}
+void launch_aa_root(const AaWalkArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(aa_root_kernel, dim3(aa_ll_blocks(a.P), a.evals), dim3(256), 0, s, a);
+}
+void launch_aa_pre(const AaWalkArgs& a, hipStream_t s) {
+  const dim3 grid(aa_grid(a.tiles / kAaPreTiles, a.evals * a.K));
+  hipLaunchKernelGGL((aa_pre_kernel<kAaPreTiles>), grid, dim3(64), 0, s, a);
+}
+void launch_aa_reduce(const AaWalkArgs& a, hipStream_t s) {
+  const int gx = a.gradient ? (a.N + 255) / 256 : 1;
+  hipLaunchKernelGGL(aa_reduce_kernel, dim3(gx, a.evals), dim3(256), 0, s, a, aa_ll_blocks(a.P));
+}
+const char* aa_post_kernel_name() { return "aa_post_kernel"; }
+const char* aa_pre_kernel_name() { return "aa_pre_kernel"; }
+
+}  // namespace miphylo

@@ -371,9 +371,12 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
     __syncthreads();
     if (lane == 0) {
       for (int i = 0; i < n - 2; i++) {
-        const int a0 = c0[i] >= n ? c0[i] - n : 0, a1 = c1[i] >= n ? c1[i] - n : 0;
-        outA[i] = Pv[i] * hg[i] + E0[i] * outA[a0] + E1[i] * outA[a1];
-        outB[i] = Pv[i] * aux[i] + E0[i] * outB[a0] + E1[i] * outB[a1];
+        // a leaf child contributes nothing -- and must not be READ either: LDS is not
+        // cleared between workgroups, and 0 * (NaN residue) would poison every ancestor
+        const bool i0 = c0[i] >= n, i1 = c1[i] >= n;
+        const int a0 = i0 ? c0[i] - n : 0, a1 = i1 ? c1[i] - n : 0;
+        outA[i] = Pv[i] * hg[i] + (i0 ? E0[i] * outA[a0] : 0.0) + (i1 ? E1[i] * outA[a1] : 0.0);
+        outB[i] = Pv[i] * aux[i] + (i0 ? E0[i] * outB[a0] : 0.0) + (i1 ? E1[i] * outB[a1] : 0.0);
       }
       mult[root - n] = 1.0;  // :102-130
       for (int v = root; v >= n; v--) {

@@ -31,139 +31,7 @@ int fail(const std::string& msg) {
 }
 }  // namespace miphylo
 
-namespace {
-using miphylo::fail;
-
-#define HIP_TRY(expr)                                                              \
-  do {                                                                             \
-    hipError_t err__ = (expr);                                                     \
-    if (err__ != hipSuccess)                                                       \
-      return fail(std::string("HIP error: ") + hipGetErrorString(err__) + " at " + \
-                  __FILE__ + ":" + std::to_string(__LINE__));                      \
-  } while (0)
-
-// A device buffer that only ever grows.
-struct Buffer {
-  void* ptr = nullptr;
-  size_t bytes = 0;
-  int ensure(size_t need) {
-    if (need <= bytes) return 0;
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr;
-    bytes = 0;
-    HIP_TRY(hipMalloc(&ptr, need));
-    bytes = need;
-    return 0;
-  }
-  void release() {
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr;
-    bytes = 0;
-  }
-  template <typename T>
-  T* as() const { return static_cast<T*>(ptr); }
-};
-
-// Pinned host staging for the host-pointer entry points: inputs are copied into it and
-// DMA'd from there, outputs are DMA'd into it and copied out after the call's one
-// synchronisation.  (hipMemcpyAsync on pageable memory is staged by the runtime, copy by
-// copy and mostly synchronously: ~0.5 ms per call for 1000 DS1 trees, against ~0.1 ms.)
-struct PinnedArena {
-  char* ptr = nullptr;
-  size_t bytes = 0, used = 0;
-  struct Pending {
-    void* host;
-    const void* staged;
-    size_t bytes;
-  };
-  std::vector<Pending> pending;
-  // returns nullptr on failure; may synchronise `s` when it has to grow
-  void* alloc(size_t need, hipStream_t s) {
-    need = (need + 255) & ~(size_t)255;
-    if (used + need > bytes) {
-      // copies already issued from / into the old block must finish before it goes away;
-      // pending outputs are delivered first
-      if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
-      flush();
-      if (ptr) (void)hipHostFree(ptr);
-      ptr = nullptr;
-      bytes = 0;
-      const size_t want = std::max<size_t>(2 * (used + need), 1 << 20);
-      if (hipHostMalloc(reinterpret_cast<void**>(&ptr), want, hipHostMallocDefault) != hipSuccess)
-        return nullptr;
-      bytes = want;
-      used = 0;
-    }
-    void* p = ptr + used;
-    used += need;
-    return p;
-  }
-  void flush() {  // after a synchronisation: hand the staged outputs to the caller
-    for (const Pending& q : pending) memcpy(q.host, q.staged, q.bytes);
-    pending.clear();
-  }
-  void reset() {
-    pending.clear();
-    used = 0;
-  }
-  void release() {
-    if (ptr) (void)hipHostFree(ptr);
-    ptr = nullptr;
-    bytes = used = 0;
-    pending.clear();
-  }
-};
-
-struct Block {
-  std::string name;
-  int start, length;
-};
-
-const char* status_message(int code) {
-  switch (code) {
-    case kBadParentIds: return "parent id vector is not in the reference's post-order id form";
-    case kNotBifurcating: return "expected a bifurcating tree (node.cpp:198,240)";
-    case kNotTrifurcatingRoot:
-      return "UnrootedTree::Detrifurcate given a non-trifurcating tree.";
-    case kGtrFrequencies: return "GTR frequencies do not sum to 1 +/- 0.001!";
-    case kGtrRates: return "GTR rates do not sum to 1 +/- 0.001!";
-    case kBadRateCount:
-      return "The number of rates should be equal to 1 (i.e. strict clock) or equal to the "
-             "number of branches.";
-    case kTooManySlots: return "internal error: evaluation schedule needs too many LDS slots";
-    default: return "unknown device status";
-  }
-}
-
-}  // namespace
-
-struct mi_engine {
-  mi_engine_spec spec;
-  int n, N, P, K, tiles, max_slots, ll_stride;
-  int param_count, rates_off, freqs_off, shape_off, clock_off;
-  std::vector<Block> blocks;
-  hipStream_t stream = nullptr;
-  // static device data
-  Buffer tip_states, tip_partials, tip_masks, weights;
-  bool have_tip_masks = false;  // every tip vector is 0/1: the matrix-core kernel can run
-  // per-call workspace
-  Buffer arena_macros, slot_need, tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
-      ll_sum, g_sum, status;
-  PinnedArena pinned;
-  bool allow_onchip_gradient = true;
-  bool analytic_subst = false;       // MI_PHYLO_SUBST_GRADIENT=analytic (opt-in)
-  int gradient_path = 0;  // 0 auto, 2 hbm, 3 mfma (MI_PHYLO_GRADIENT_PATH)
-  // staging for the host-pointer entry points
-  Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
-      in_ratios, out_ll, out_a, out_b, out_site, out_subst;
-  size_t plv_budget = (size_t)8 << 30;
-  // kernel timing (bench.py)
-  std::vector<hipEvent_t> prof_events;  // pairs
-  int prof_capacity = 0, prof_used = 0;
-  // last-call info
-  const char* dominant = "";
-  int64_t last_evals = 0, last_grad_evals = 0;
-};
+#include "mi_phylo_engine.h"
 
 namespace {
 
@@ -244,27 +112,11 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
   return 0;
 }
 
-struct DeviceCall {
-  bool gradient = false, rooted = false, with_jacobian = false, rescaling = false;
-  int T = 0;
-  const int32_t* parent_ids = nullptr;
-  const double* bl = nullptr;
-  const double* params = nullptr;
-  const double* rates = nullptr;
-  const int32_t* rate_counts = nullptr;
-  const double* heights = nullptr;
-  const double* bounds = nullptr;
-  const double* ratios = nullptr;
-  double* out_ll = nullptr;
-  double* out_branch = nullptr;
-  double* out_ratios = nullptr;
-  double* out_clock = nullptr;
-  double* out_site = nullptr;
-  double* out_subst = nullptr;
-};
-
 // Enqueue one engine call; every pointer in `d` is a device pointer.
 int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
+  // (a caller driving several GPUs from one thread may have another device current)
+  HIP_TRY(hipSetDevice(e->spec.device));
+  if (e->s == kAa) return aa_run_device(e, s, d);
   if (d.T <= 0) return fail("tree_count must be positive");
   if (!d.parent_ids || !d.bl || !d.out_ll) return fail("null tree / output pointer");
   if (e->param_count > 0 && !d.params) return fail("null parameter matrix");
@@ -544,6 +396,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
 }
 
 int check_status(mi_engine* e, hipStream_t s) {
+  HIP_TRY(hipSetDevice(e->spec.device));
   int32_t st[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(st, e->status.ptr, sizeof st, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -604,18 +457,47 @@ extern "C" {
 int32_t mi_abi_version(void) { return MI_PHYLO_ABI_VERSION; }
 const char* mi_last_error(void) { return g_error.c_str(); }
 
+static int32_t create_engine(const mi_engine_spec* spec, const double* exchangeabilities,
+                             const double* frequencies, const int32_t* tip_states,
+                             const double* tip_partials, const double* pattern_weights,
+                             mi_engine** out_engine);
+
 int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
                          const double* tip_partials, const double* pattern_weights,
                          mi_engine** out_engine) {
+  return create_engine(spec, nullptr, nullptr, tip_states, tip_partials, pattern_weights,
+                       out_engine);
+}
+
+int32_t mi_engine_create_reversible(const mi_engine_spec* spec, const double* exchangeabilities,
+                                    const double* frequencies, const int32_t* tip_states,
+                                    const double* tip_partials, const double* pattern_weights,
+                                    mi_engine** out_engine) {
+  if (spec && spec->subst_model != MI_SUBST_REVERSIBLE)
+    return fail("mi_engine_create_reversible needs subst_model == MI_SUBST_REVERSIBLE");
+  if ((exchangeabilities == nullptr) != (frequencies == nullptr))
+    return fail("pass both exchangeabilities and frequencies, or neither (built-in WAG)");
+  return create_engine(spec, exchangeabilities, frequencies, tip_states, tip_partials,
+                       pattern_weights, out_engine);
+}
+
+static int32_t create_engine(const mi_engine_spec* spec, const double* exchangeabilities,
+                             const double* frequencies, const int32_t* tip_states,
+                             const double* tip_partials, const double* pattern_weights,
+                             mi_engine** out_engine) {
   if (!spec || !out_engine) return fail("null spec / out_engine");
   *out_engine = nullptr;
   if (spec->taxon_count < 3) return fail("need at least 3 taxa");
   if (spec->pattern_count < 1) return fail("need at least one site pattern");
-  if (spec->state_count != kStates)
-    return fail("only 4-state (DNA) models are implemented, as in the reference "
-                "(substitution_model.cpp:6-15)");
-  if (spec->subst_model != MI_SUBST_JC69 && spec->subst_model != MI_SUBST_GTR)
+  if (spec->state_count != kStates && spec->state_count != kAa)
+    return fail("state_count must be 4 (DNA, as in the reference: substitution_model.cpp:6-15) "
+                "or 20 (amino acids)");
+  const int states = spec->state_count;
+  if (states == kStates && spec->subst_model != MI_SUBST_JC69 && spec->subst_model != MI_SUBST_GTR)
     return fail("Substitution model not known");
+  if (states == kAa && spec->subst_model != MI_SUBST_REVERSIBLE)
+    return fail("a 20-state engine takes subst_model MI_SUBST_REVERSIBLE (an empirical model "
+                "given as data; WAG when none is passed)");
   if (spec->site_model != MI_SITE_CONSTANT && spec->site_model != MI_SITE_WEIBULL)
     return fail("Site model not known");
   if (spec->clock_model != MI_CLOCK_NONE && spec->clock_model != MI_CLOCK_STRICT)
@@ -640,8 +522,16 @@ int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
   e->N = 2 * e->n - 1;
   e->P = spec->pattern_count;
   e->K = spec->category_count;
-  e->tiles = (e->P + kTile - 1) / kTile;
-  e->ll_stride = std::max({e->tiles, loglik_mfma_tiles(e->P, e->K), gradient_mfma_tiles(e->P, e->K)});
+  e->s = states;
+  if (states == kAa) {
+    e->tiles = aa_tiles(e->P);
+    e->ll_stride = aa_ll_blocks(e->P);
+    e->plv_budget = (size_t)48 << 30;  // 32 MB per vector at 50 000 patterns x 4 categories
+  } else {
+    e->tiles = (e->P + kTile - 1) / kTile;
+    e->ll_stride =
+        std::max({e->tiles, loglik_mfma_tiles(e->P, e->K), gradient_mfma_tiles(e->P, e->K)});
+  }
   int lg = 0;
   while ((2 << lg) <= e->n) lg++;
   e->max_slots = lg + 1;
@@ -692,12 +582,34 @@ int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     return cleanup_fail(fail("hipStreamCreate failed"));
   const size_t np = (size_t)e->n * e->P;
-  std::vector<int8_t> st8(np, 4);
+  std::vector<int8_t> st8(np, (int8_t)states);
   if (tip_states)
     for (size_t i = 0; i < np; i++) {
       const int32_t v = tip_states[i];
-      st8[i] = (v >= 0 && v < kStates) ? (int8_t)v : (int8_t)kStates;
+      st8[i] = (v >= 0 && v < states) ? (int8_t)v : (int8_t)states;
     }
+  if (states == kAa) {
+    // the 20-state kernels read compact states only; tip partials are accepted in the form
+    // SitePattern::GetPartials produces (one-hot, or all ones for a gap: site_pattern.cpp:117-131)
+    if (!spec->use_tip_states && tip_partials) {
+      for (size_t i = 0; i < np; i++) {
+        int ones = 0, last = 0;
+        for (int x = 0; x < states; x++) {
+          const double v = tip_partials[i * states + x];
+          if (v == 1.0) { ones++; last = x; }
+          else if (v != 0.0) ones = -states - 1;
+        }
+        if (ones == 1) st8[i] = (int8_t)last;
+        else if (ones == states) st8[i] = (int8_t)states;
+        else {
+          mi_engine_destroy(e);
+          return fail("20-state engine: tip partials must be one-hot or all ones");
+        }
+      }
+    }
+    if (upload(e->tip_states, st8.data(), np, e->stream)) return cleanup_fail(1);
+    if (aa_engine_init(e, exchangeabilities, frequencies)) return cleanup_fail(1);
+  } else {
   if (upload(e->tip_states, st8.data(), np, e->stream)) return cleanup_fail(1);
   if (!spec->use_tip_states) {
     std::vector<double> tp(np * kStates);
@@ -732,6 +644,7 @@ int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
     }
     if (e->have_tip_masks && upload(e->tip_masks, masks.data(), np, e->stream)) return cleanup_fail(1);
   }
+  }
   if (upload(e->weights, pattern_weights, (size_t)e->P, e->stream)) return cleanup_fail(1);
   if (hipStreamSynchronize(e->stream) != hipSuccess)
     return cleanup_fail(fail("upload of tips failed"));
@@ -749,7 +662,9 @@ void mi_engine_destroy(mi_engine* e) {
         &e->arena_macros, &e->slot_need,
         &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,
-        &e->ll_sum, &e->g_sum, &e->status,
+        &e->ll_sum, &e->g_sum, &e->status, &e->aa_model, &e->aa_matP, &e->aa_matPT, &e->aa_matPQ,
+        &e->aa_tipP, &e->aa_tipPQ, &e->aa_exp_cum, &e->aa_exp_loc, &e->aa_root_val,
+        &e->aa_root_exp, &e->aa_root_scale,
         &e->in_parent, &e->in_bl, &e->in_params, &e->in_rates, &e->in_rate_counts,
         &e->in_heights, &e->in_bounds, &e->in_ratios, &e->out_ll, &e->out_a, &e->out_b,
         &e->out_site, &e->out_subst})
@@ -775,6 +690,7 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
   if (!e) return fail("null engine");
   if (tree_count <= 0) return fail("tree_count must be positive");
   HIP_TRY(hipSetDevice(e->spec.device));
+  if (e->s == kAa) return aa_reserve(e, tree_count, for_gradients != 0);
   // the HBM arena is only reserved when a later call may need it (rescaling with the VALU
   // kernel or real-valued tip partials still can: reserve() grows on demand then)
   const bool onchip = e->allow_onchip_gradient && e->have_tip_masks &&

@@ -1,0 +1,179 @@
+// Private to libmi_phylo.so: the engine object behind include/mi_phylo.h and the helpers
+// its translation units share (mi_phylo_engine.cpp: 4-state call sequence and the C ABI;
+// mi_phylo_engine_aa.cpp: 20-state call sequence).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_phylo.h"
+#include "mi_phylo_kernels.h"
+
+namespace miphylo {
+int fail(const std::string& msg);  // sets mi_last_error()
+}
+using miphylo::fail;
+using namespace miphylo;
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t err__ = (expr);                                                     \
+    if (err__ != hipSuccess)                                                       \
+      return fail(std::string("HIP error: ") + hipGetErrorString(err__) + " at " + \
+                  __FILE__ + ":" + std::to_string(__LINE__));                      \
+  } while (0)
+
+// A device buffer that only ever grows.
+struct Buffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return 0;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    HIP_TRY(hipMalloc(&ptr, need));
+    bytes = need;
+    return 0;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T* as() const { return static_cast<T*>(ptr); }
+};
+
+// Pinned host staging for the host-pointer entry points: inputs are copied into it and
+// DMA'd from there, outputs are DMA'd into it and copied out after the call's one
+// synchronisation.  (hipMemcpyAsync on pageable memory is staged by the runtime, copy by
+// copy and mostly synchronously: ~0.5 ms per call for 1000 DS1 trees, against ~0.1 ms.)
+struct PinnedArena {
+  char* ptr = nullptr;
+  size_t bytes = 0, used = 0;
+  struct Pending {
+    void* host;
+    const void* staged;
+    size_t bytes;
+  };
+  std::vector<Pending> pending;
+  // returns nullptr on failure; may synchronise `s` when it has to grow
+  void* alloc(size_t need, hipStream_t s) {
+    need = (need + 255) & ~(size_t)255;
+    if (used + need > bytes) {
+      // copies already issued from / into the old block must finish before it goes away;
+      // pending outputs are delivered first
+      if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+      flush();
+      if (ptr) (void)hipHostFree(ptr);
+      ptr = nullptr;
+      bytes = 0;
+      const size_t want = std::max<size_t>(2 * (used + need), 1 << 20);
+      if (hipHostMalloc(reinterpret_cast<void**>(&ptr), want, hipHostMallocDefault) != hipSuccess)
+        return nullptr;
+      bytes = want;
+      used = 0;
+    }
+    void* p = ptr + used;
+    used += need;
+    return p;
+  }
+  void flush() {  // after a synchronisation: hand the staged outputs to the caller
+    for (const Pending& q : pending) memcpy(q.host, q.staged, q.bytes);
+    pending.clear();
+  }
+  void reset() {
+    pending.clear();
+    used = 0;
+  }
+  void release() {
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = used = 0;
+    pending.clear();
+  }
+};
+
+struct Block {
+  std::string name;
+  int start, length;
+};
+
+inline const char* status_message(int code) {
+  switch (code) {
+    case kBadParentIds: return "parent id vector is not in the reference's post-order id form";
+    case kNotBifurcating: return "expected a bifurcating tree (node.cpp:198,240)";
+    case kNotTrifurcatingRoot:
+      return "UnrootedTree::Detrifurcate given a non-trifurcating tree.";
+    case kGtrFrequencies: return "GTR frequencies do not sum to 1 +/- 0.001!";
+    case kGtrRates: return "GTR rates do not sum to 1 +/- 0.001!";
+    case kBadRateCount:
+      return "The number of rates should be equal to 1 (i.e. strict clock) or equal to the "
+             "number of branches.";
+    case kTooManySlots: return "internal error: evaluation schedule needs too many LDS slots";
+    default: return "unknown device status";
+  }
+}
+
+struct mi_engine {
+  mi_engine_spec spec;
+  int n, N, P, K, tiles, max_slots, ll_stride;
+  int s = 4;  // states: 4 (kernels_{loglik,gradient}.hip) or 20 (kernels_aa.hip)
+  int param_count, rates_off, freqs_off, shape_off, clock_off;
+  std::vector<Block> blocks;
+  hipStream_t stream = nullptr;
+  // static device data
+  Buffer tip_states, tip_partials, tip_masks, weights;
+  bool have_tip_masks = false;  // every tip vector is 0/1: the matrix-core kernel can run
+  // per-call workspace
+  Buffer arena_macros, slot_need, tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
+      ll_sum, g_sum, status;
+  // 20-state path: the engine's eigensystem and the streamed workspace (the arena is `plv`)
+  Buffer aa_model, aa_matP, aa_matPT, aa_matPQ, aa_tipP, aa_tipPQ, aa_exp_cum, aa_exp_loc,
+      aa_root_val, aa_root_exp, aa_root_scale;
+  bool aa_reserved_gradient = false;
+  PinnedArena pinned;
+  bool allow_onchip_gradient = true;
+  bool analytic_subst = false;       // MI_PHYLO_SUBST_GRADIENT=analytic (opt-in)
+  int gradient_path = 0;  // 0 auto, 2 hbm, 3 mfma (MI_PHYLO_GRADIENT_PATH)
+  // staging for the host-pointer entry points
+  Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
+      in_ratios, out_ll, out_a, out_b, out_site, out_subst;
+  size_t plv_budget = (size_t)8 << 30;
+  // kernel timing (bench.py)
+  std::vector<hipEvent_t> prof_events;  // pairs
+  int prof_capacity = 0, prof_used = 0;
+  // last-call info
+  const char* dominant = "";
+  int64_t last_evals = 0, last_grad_evals = 0;
+};
+
+
+// One engine call with every pointer a device pointer (what the *_device entry points build).
+struct DeviceCall {
+  bool gradient = false, rooted = false, with_jacobian = false, rescaling = false;
+  int T = 0;
+  const int32_t* parent_ids = nullptr;
+  const double* bl = nullptr;
+  const double* params = nullptr;
+  const double* rates = nullptr;
+  const int32_t* rate_counts = nullptr;
+  const double* heights = nullptr;
+  const double* bounds = nullptr;
+  const double* ratios = nullptr;
+  double* out_ll = nullptr;
+  double* out_branch = nullptr;
+  double* out_ratios = nullptr;
+  double* out_clock = nullptr;
+  double* out_site = nullptr;
+  double* out_subst = nullptr;
+};
+
+// mi_phylo_engine_aa.cpp
+int aa_engine_init(mi_engine* e, const double* exchangeabilities, const double* frequencies);
+int aa_reserve(mi_engine* e, int T, bool gradient);
+int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d);

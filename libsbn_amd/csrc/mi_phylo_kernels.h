@@ -201,6 +201,83 @@ bool reduce_tiles_fits(int N);
 void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s);
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);
 
+// ------------------------------------------------------------------------
+// 20-state path (kernels_aa.hip): partial-likelihood vectors streamed through HBM in
+// 16-pattern matrix-core tiles, one wave per (evaluation, category, pattern block).
+// ------------------------------------------------------------------------
+constexpr int kAa = 20;              // states
+constexpr int kAaTile = 16;          // site patterns per matrix-core tile
+constexpr int kAaTileDoubles = 320;  // one tile of one category: 5 registers x 64 lanes
+constexpr int kAaPack = 640;         // one 20x20 matrix as matrix-core A operands: 10 registers x 64 lanes
+constexpr int kAaTipTable = 21 * 20; // per tip edge and category: column of the matrix per state, 20 = gap
+constexpr int kAaPostTiles = 2;      // tiles a wave of the post-order kernel takes
+constexpr int kAaPreTiles = 2;       // ... of the pre-order kernel
+
+// The substitution model of a 20-state engine: one eigensystem per engine (an empirical
+// model has no free parameters); the per-tree part is the site model in DevModel.
+struct AaModel {
+  double pi[kAa];
+  double lambda[kAa];
+  double Q[kAa * kAa];     // row-major, normalised to one expected substitution per unit time
+  double V[kAa * kAa];     // eigenvectors
+  double Vinv[kAa * kAa];  // inverse eigenvectors
+};
+
+struct AaTransitionArgs {
+  int n, N, K;
+  int eval_offset, evals;   // this chunk of evaluations (evaluation == tree)
+  int gradient;             // also the pre-order matrices
+  const AaModel* model;
+  const DevModel* models;   // [T]: category rates
+  const double* bl_eff;     // [T][N]
+  double* matP;             // [evals][n-1][K][kAaPack]  P of internal edges
+  double* matPT;            // same: P^T (pre-order propagation)
+  double* matPQ;            // same: P Q (edge derivative)
+  double* tipP;             // [evals][n][K][21][20]: tipP[x][i] = P[i][x], x = 20: 1
+  double* tipPQ;            // same for P Q (x = 20: 0)
+};
+
+struct AaWalkArgs {
+  int n, N, P, K;
+  int tiles;               // 16-pattern tiles, rounded up to a multiple of what one wave takes
+  int eval_offset, evals;  // this chunk
+  int gradient;            // post-order: every internal vector is kept, indexed by node
+  int slots;               // log-likelihood only: vectors are kept by schedule slot
+  int ll_stride;           // stride of ll_part per evaluation
+  const SchedEntry* sched; // [T][n-1]
+  const AaModel* model;
+  const DevModel* models;  // [T]
+  const double* matP;
+  const double* matPT;
+  const double* matPQ;
+  const double* tipP;
+  const double* tipPQ;
+  const int8_t* tip_states;  // [n][P], 20 = gap
+  const double* weights;     // [P]
+  double* arena;       // [evals][n-1 | slots][K][tiles][kAaTileDoubles]
+  int32_t* exp_cum;    // [evals][n-1 | slots][K][tiles*16]: power of two removed below and at the node
+  int32_t* exp_loc;    // [evals][n-1][K][tiles*16]: power of two removed at the node (gradient)
+  double* root_val;    // [evals][K][tiles*16]: sum_i pi_i L_root[i] (scaled)
+  int32_t* root_exp;   // [evals][K][tiles*16]
+  double* root_scale;  // [evals][K][tiles*16]: w_p cw_k 2^(E_k - Emax) / site_p, the root's pre-order weight
+  double* ll_part;     // [T][ll_stride]
+  double* g_part;      // [evals][K][blocks][N]: per-edge sums of one wave
+  double* ll_sum;      // [T]
+  double* g_sum;       // [T][2][N]
+};
+
+void launch_aa_model_setup(const double* exchangeabilities, const double* freqs, AaModel* model,
+                           int32_t* status, hipStream_t s);
+void launch_aa_transition(const AaTransitionArgs& a, hipStream_t s);
+int aa_tiles(int P);                 // padded tile count
+int aa_ll_blocks(int P);             // partial log-likelihood sums per evaluation
+void launch_aa_post(const AaWalkArgs& a, hipStream_t s);
+void launch_aa_root(const AaWalkArgs& a, hipStream_t s);
+void launch_aa_pre(const AaWalkArgs& a, hipStream_t s);
+void launch_aa_reduce(const AaWalkArgs& a, hipStream_t s);
+const char* aa_post_kernel_name();
+const char* aa_pre_kernel_name();
+
 const char* loglik_kernel_name(const LikArgs& a, bool rescale, int max_slots);
 const char* gradient_kernel_name();
 const char* gradient_mfma_kernel_name();

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _capi
 
-SUBST = {"JC69": 0, "GTR": 1}
+SUBST = {"JC69": 0, "GTR": 1, "WAG": 2, "reversible": 2}
 CLOCK = {"none": 0, "strict": 1}
 
 
@@ -24,6 +24,16 @@ class PhyloModelSpecification:
     substitution: str = "JC69"
     site: str = "constant"
     clock: str = "strict"
+
+
+def wag_model():
+    """The built-in WAG table as (exchangeabilities[190], frequencies[20]) -- upper triangle
+    row by row, amino-acid order ARNDCQEGHILKMFPSTWYV (mi_wag_model)."""
+    ex, fr = np.zeros(190), np.zeros(20)
+    rc = _capi.load().mi_wag_model(ex.ctypes.data_as(_capi.F64P), fr.ctypes.data_as(_capi.F64P))
+    if rc != 0:
+        raise RuntimeError(_capi.last_error())
+    return ex, fr
 
 
 class PhyloGradient:
@@ -61,10 +71,12 @@ class Engine:
     """One MI355X engine: tips + pattern weights resident in HBM."""
 
     def __init__(self, model_specification, patterns, weights, use_tip_states=True,
-                 device=-1, thread_count=1, tip_partials=None):
+                 device=-1, thread_count=1, tip_partials=None, reversible_model=None):
         """patterns: [taxon][pattern] compact states (SitePattern::GetPatterns), or None when
-        tip_partials ([taxon][pattern][4], SitePattern::GetPartials) is given with
-        use_tip_states=False."""
+        tip_partials ([taxon][pattern][s], SitePattern::GetPartials) is given with
+        use_tip_states=False.  Substitution "WAG" / "reversible" makes a 20-state engine
+        (s = 20); reversible_model = (exchangeabilities[190], frequencies[20]) replaces the
+        built-in WAG table."""
         if thread_count == 0:  # src/engine.cpp:14-16
             raise RuntimeError("Thread count needs to be strictly positive.")
         self._lib = _capi.load()
@@ -75,12 +87,14 @@ class Engine:
         if model_specification.clock not in CLOCK:
             raise RuntimeError("Clock model not known: " + model_specification.clock)
         site_kind, K = _parse_site(model_specification.site)
+        states = 20 if SUBST[model_specification.substitution] == 2 else 4
+        self.state_count = states
         weights = _np(weights, np.float64)
         if tip_partials is not None:
             tip_partials = _np(tip_partials, np.float64)
             n, P = tip_partials.shape[:2]
-            if tip_partials.shape != (n, P, 4):
-                raise RuntimeError("tip partials must be [taxon][pattern][4]")
+            if tip_partials.shape != (n, P, states):
+                raise RuntimeError(f"tip partials must be [taxon][pattern][{states}]")
         if patterns is not None:
             patterns = _np(patterns, np.int32)
             n, P = patterns.shape
@@ -88,12 +102,23 @@ class Engine:
             raise RuntimeError("pattern weights must have one entry per site pattern")
         self.taxon_count, self.pattern_count, self.category_count = n, P, K
         self.node_count = 2 * n - 1
-        self.spec = _capi.EngineSpec(n, P, 4, K, SUBST[model_specification.substitution],
+        self.spec = _capi.EngineSpec(n, P, states, K, SUBST[model_specification.substitution],
                                      site_kind, CLOCK[model_specification.clock],
                                      1 if use_tip_states else 0, device, 0)
         h = C.c_void_p()
-        rc = self._lib.mi_engine_create(C.byref(self.spec), _ptr(patterns), _ptr(tip_partials),
-                                        _ptr(weights), C.byref(h))
+        if states == 20:
+            ex = fr = None
+            if reversible_model is not None:
+                ex, fr = (_np(x, np.float64) for x in reversible_model)
+                if ex.shape != (190,) or fr.shape != (20,):
+                    raise RuntimeError("reversible_model must be (exchangeabilities[190], "
+                                       "frequencies[20])")
+            rc = self._lib.mi_engine_create_reversible(
+                C.byref(self.spec), _ptr(ex), _ptr(fr), _ptr(patterns), _ptr(tip_partials),
+                _ptr(weights), C.byref(h))
+        else:
+            rc = self._lib.mi_engine_create(C.byref(self.spec), _ptr(patterns),
+                                            _ptr(tip_partials), _ptr(weights), C.byref(h))
         self._check(rc)
         self._h = h
         self.param_count = self._lib.mi_engine_param_count(h)

@@ -50,6 +50,29 @@ typedef double real;
 static int g_transition_mode = 0;
 void orc_set_transition_mode(int mode) { g_transition_mode = mode; }
 
+/* 1: run the sweeps through the s-generic loops also when s == 4 (the default
+ * lets the compiler unroll a constant-s copy of the SAME code for s == 4).  Used by
+ * tests/test_oracle_kats.py to show that the code path the 20-state parity tests rely
+ * on reproduces every known-answer value of the reference at s == 4. */
+static int g_generic_states = 0;
+void orc_set_generic_states(int on) { g_generic_states = on; }
+
+/* ORC_SUBST_REVERSIBLE: a general time-reversible model given as DATA (s(s-1)/2
+ * exchangeabilities in upper-triangle row order + s frequencies), with no free
+ * parameters -- what an empirical amino-acid model (WAG, LG, ...) is.  Not in the
+ * reference (substitution_model.cpp:6-15 knows JC69 and GTR only); it is built by the
+ * reference's own GTR recipe (substitution_model.cpp:39-80) from the table. */
+static double g_rev_rates[ORC_MAX_STATES * (ORC_MAX_STATES - 1) / 2];
+static double g_rev_freqs[ORC_MAX_STATES];
+static int g_rev_states = 0;
+int orc_set_reversible_model(int s, const double* exchangeabilities, const double* freqs) {
+  if (s < 2 || s > ORC_MAX_STATES) return 1;
+  for (int i = 0; i < s * (s - 1) / 2; i++) g_rev_rates[i] = exchangeabilities[i];
+  for (int i = 0; i < s; i++) g_rev_freqs[i] = freqs[i];
+  g_rev_states = s;
+  return 0;
+}
+
 static _Thread_local char g_err[512];
 const char* orc_last_error(void) { return g_err; }
 static int fail(const char* msg) {
@@ -560,6 +583,12 @@ static int model_set(const orc_spec_t* spec, const real* params, model_t* m) {
     if (R_FABS(fsum - 1.) >= 0.001) return fail("GTR frequencies do not sum to 1 +/- 0.001!");
     if (R_FABS(rsum - 1.) >= 0.001) return fail("GTR rates do not sum to 1 +/- 0.001!");
     gtr_update(m);
+  } else if (spec->subst_model == ORC_SUBST_REVERSIBLE) {
+    if (g_rev_states != s) return fail("orc_set_reversible_model was not called for this state count");
+    m->n_gtr_rates = s * (s - 1) / 2;
+    for (int i = 0; i < m->n_gtr_rates; i++) m->gtr_rates[i] = g_rev_rates[i];
+    for (int i = 0; i < s; i++) m->pi[i] = g_rev_freqs[i];
+    gtr_update(m);
   } else {
     return fail("Substitution model not known");
   }
@@ -739,7 +768,7 @@ static inline __attribute__((always_inline)) void post_order_impl(
 }
 static void post_order(core_ws_t* w, const int32_t* child0, const int32_t* child1,
                        int rescaling) {
-  if (w->s == 4) post_order_impl(w, child0, child1, rescaling, 4); /* unrolled by the compiler */
+  if (w->s == 4 && !g_generic_states) post_order_impl(w, child0, child1, rescaling, 4); /* unrolled by the compiler */
   else post_order_impl(w, child0, child1, rescaling, w->s);
 }
 
@@ -840,7 +869,7 @@ static inline __attribute__((always_inline)) void pre_order_impl(
   }
 }
 static void pre_order(core_ws_t* w, const model_t* m, const int32_t* tr, int rescaling) {
-  if (w->s == 4) pre_order_impl(w, m, tr, rescaling, 4);
+  if (w->s == 4 && !g_generic_states) pre_order_impl(w, m, tr, rescaling, 4);
   else pre_order_impl(w, m, tr, rescaling, w->s);
 }
 
@@ -876,7 +905,7 @@ static inline __attribute__((always_inline)) void edge_derivatives_impl(
 }
 static void edge_derivatives(const core_ws_t* w, const model_t* m, const double* weights,
                              const real* dscale, real* grad) {
-  if (w->s == 4) edge_derivatives_impl(w, m, weights, dscale, grad, 4);
+  if (w->s == 4 && !g_generic_states) edge_derivatives_impl(w, m, weights, dscale, grad, 4);
   else edge_derivatives_impl(w, m, weights, dscale, grad, w->s);
 }
 
@@ -1096,7 +1125,7 @@ int orc_unrooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
       b[fixed] = 0.0;
       out_logl[t] = (double)core_branch_gradient_ws(&ws, &model, pattern_weights, c0, c1, b,
                                                     model.cat_rates, rescaling, g);
-      if (model.n_gtr_rates > 0 && out_subst) {
+      if (spec->subst_model == ORC_SUBST_GTR && out_subst) {
         /* f = StaticUnrootedLogLikelihood(in_tree): Detrifurcate without the slide */
         real* b0 = (real*)malloc(sizeof(real) * N);
         int32_t* d0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (n - 1));
@@ -1324,7 +1353,7 @@ int orc_rooted_gradients(const orc_spec_t* spec, const int32_t* tip_states,
       for (int i = 0; i < N - 1; i++) b[i] *= r[i];
       out_logl[t] = (double)core_branch_gradient_ws(&ws, &model, pattern_weights, c0, c1, b,
                                                     model.cat_rates, rescaling, bg);
-      if (model.n_gtr_rates > 0 && out_subst) {
+      if (spec->subst_model == ORC_SUBST_GTR && out_subst) {
         ll_ctx_t ctx = {spec, tip_states, pattern_weights, c0, c1, b, rescaling,
                         log_det_jacobian(n, c0, c1, h, bd), &ws};
         rc = subst_gradient_fd(spec, pr, &model, ll_of_model, &ctx, out_subst + (size_t)t * 8);

@@ -32,7 +32,7 @@ extern "C" {
 #define ORC_MAX_STATES 20
 #define ORC_MAX_CATEGORIES 16
 
-enum { ORC_SUBST_JC69 = 0, ORC_SUBST_GTR = 1 };
+enum { ORC_SUBST_JC69 = 0, ORC_SUBST_GTR = 1, ORC_SUBST_REVERSIBLE = 2 };
 enum { ORC_SITE_CONSTANT = 0, ORC_SITE_WEIBULL = 1 };
 enum { ORC_CLOCK_NONE = 0, ORC_CLOCK_STRICT = 1 };
 
@@ -64,6 +64,11 @@ typedef struct {
 const char* orc_last_error(void);
 /* 0 (default): BEAGLE's P = V exp(L t) V^-1;  1: I + V expm1(L t) V^-1 (see .c) */
 void orc_set_transition_mode(int mode);
+/* 1: s == 4 also runs through the s-generic loops (see .c) */
+void orc_set_generic_states(int on);
+/* table of the ORC_SUBST_REVERSIBLE model: s(s-1)/2 exchangeabilities (upper triangle,
+ * row by row) and s frequencies; no free parameters.  Process-wide. */
+int orc_set_reversible_model(int s, const double* exchangeabilities, const double* freqs);
 
 /* ---- integer half ------------------------------------------------------- */
 

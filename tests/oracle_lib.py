@@ -14,7 +14,7 @@ ORACLE_DIR = os.path.join(REPO, "oracle")
 GOLDEN = os.path.join(REPO, "tests", "golden")
 DATA = os.path.join(GOLDEN, "data")
 
-SUBST = {"JC69": 0, "GTR": 1}
+SUBST = {"JC69": 0, "GTR": 1, "reversible": 2, "WAG": 2}
 SITE = {"constant": 0, "weibull": 1}
 CLOCK = {"none": 0, "strict": 1}
 
@@ -52,6 +52,25 @@ def select(variant):
 def set_transition_mode(mode):
     """0: BEAGLE's exp form (default); 1: expm1 form. Applies to the selected variant."""
     lib().orc_set_transition_mode(int(mode))
+
+
+def set_generic_states(on):
+    """1: s == 4 also runs through the oracle's s-generic loops (the code the 20-state
+    parity tests rely on)."""
+    lib().orc_set_generic_states(int(on))
+
+
+def set_reversible_model(exchangeabilities, freqs):
+    """Table of the 'reversible' substitution model (process-wide, per oracle variant)."""
+    ex, fr = f64(exchangeabilities), f64(freqs)
+    s = len(fr)
+    assert len(ex) == s * (s - 1) // 2
+    for variant in ("f64", "ld"):
+        keep = _variant
+        select(variant)
+        rc = lib().orc_set_reversible_model(s, _p(ex, C.c_double), _p(fr, C.c_double))
+        select(keep)
+        assert rc == 0
 
 
 def lib():

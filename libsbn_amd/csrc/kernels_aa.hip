@@ -228,42 +228,48 @@ __global__ __launch_bounds__(256) void aa_transition_kernel(AaTransitionArgs a) 
 // ------------------------------------------------------------------------
 __device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-// S = M x L for M tiles of 16 patterns: per tile five 16x16x4 steps (rows 0..15) and five
-// 4x4x4 steps (rows 16..19)
+// S = Mat x L for M tiles of 16 patterns, the matrix given as its ten A-operand registers:
+// per tile five 16x16x4 steps (rows 0..15) and five 4x4x4 steps (rows 16..19)
 template <int M>
-__device__ __forceinline__ void mat_apply(const double* __restrict__ pack, int lane,
-                                          const double (&L)[M][5], double (&S)[M][5]) {
-  double A16[5], A4[5];
-#pragma unroll
-  for (int t = 0; t < 5; t++) {
-    A16[t] = pack[t * 64 + lane];
-    A4[t] = pack[(5 + t) * 64 + lane];
-  }
+__device__ __forceinline__ void mat_apply(const double (&A)[10], const double (&L)[M][5],
+                                          double (&S)[M][5]) {
 #pragma unroll
   for (int u = 0; u < M; u++) {
     double4v c = {0, 0, 0, 0};
     double d = 0;
 #pragma unroll
     for (int t = 0; t < 5; t++) {
-      c = __builtin_amdgcn_mfma_f64_16x16x4f64(A16[t], L[u][t], c, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f64_4x4x4f64(A4[t], L[u][t], d, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t], L[u][t], c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f64_4x4x4f64(A[5 + t], L[u][t], d, 0, 0, 0);
     }
     S[u][0] = c.x; S[u][1] = c.y; S[u][2] = c.z; S[u][3] = c.w;
     S[u][4] = d;
   }
 }
 
-// product of a tip child: column `state` of the matrix (tables [21][20])
+__device__ __forceinline__ void load_pack(const double* __restrict__ pack, int lane,
+                                          double (&A)[10]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) A[r] = pack[r * 64 + lane];
+}
+
+// compact states of a tip for this lane's pattern column of each tile (20 = gap / padding)
 template <int M>
-__device__ __forceinline__ void tip_apply(const double* __restrict__ table,
-                                          const int8_t* __restrict__ tips, int P, int p0, int lane,
-                                          double (&S)[M][5]) {
-  const int g = lane >> 4, j = lane & 15;
+__device__ __forceinline__ void load_tip_states(const int8_t* __restrict__ tips, int P, int p0,
+                                                int lane, int (&x)[M]) {
 #pragma unroll
   for (int u = 0; u < M; u++) {
-    const int p = p0 + u * 16 + j;
-    const int x = p < P ? tips[p] : kAa;
-    const double* col = table + x * kAa + g;
+    const int p = p0 + u * 16 + (lane & 15);
+    x[u] = p < P ? tips[p] : kAa;
+  }
+}
+// product of a tip child: column `state` of the matrix (tables [21][20])
+template <int M>
+__device__ __forceinline__ void tip_gather(const double* __restrict__ table, const int (&x)[M],
+                                           int lane, double (&S)[M][5]) {
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    const double* col = table + x[u] * kAa + (lane >> 4);
 #pragma unroll
     for (int t = 0; t < 5; t++) S[u][t] = col[4 * t];
   }
@@ -305,6 +311,31 @@ __device__ __forceinline__ AaUnit aa_unit(int blocks, int units) {
   return r;
 }
 
+// The schedule of a tree in LDS, a window of kSchedWindow entries at a time (a wave looks
+// two visits ahead); one wave per workgroup, so the window is private to the wave.
+constexpr int kSchedWindow = 256;
+struct SchedWindow {
+  const SchedEntry* sched;  // the tree's n-1 entries in HBM
+  SchedEntry* lds;
+  int count, base, lane;
+  // forward walk: entries [base, base + window)
+  __device__ __forceinline__ void fill_from(int first) {
+    base = first;
+    __syncthreads();
+    for (int i = lane; i < kSchedWindow && base + i < count; i += 64) lds[i] = sched[base + i];
+    __syncthreads();
+  }
+  // backward walk: entries (last - window, last]
+  __device__ __forceinline__ void fill_upto(int last) {
+    base = last - kSchedWindow + 1;
+    if (base < 0) base = 0;
+    __syncthreads();
+    for (int i = lane; i < kSchedWindow && base + i < count; i += 64) lds[i] = sched[base + i];
+    __syncthreads();
+  }
+  __device__ __forceinline__ SchedEntry at(int i) const { return lds[i - base]; }
+};
+
 // ------------------------------------------------------------------------
 // Post-order (beagleUpdatePartials with rescaling + beagleCalculateRootLogLikelihoods'
 // per-pattern part; fat_beagle.cpp:60-68,139-141).  The schedule is tree_setup's
@@ -313,9 +344,18 @@ __device__ __forceinline__ AaUnit aa_unit(int blocks, int units) {
 // visit left it in.  GRAD: every internal vector is also kept in the arena, by node, for the
 // pre-order kernel; otherwise only vectors that are not consumed from registers are
 // written, into the schedule's slot (<= floor(log2 n) + 1 per evaluation).
+//
+// Latency: a visit is ~0.3 us of matrix-core work behind ~1.5 us of memory latency, hidden by
+// occupancy (4-5 waves per SIMD), so the kernel is written for few registers and for ONE
+// memory round trip per visit: the schedule sits in LDS, and the tip states that address
+// the table columns of visit i+1 are requested during visit i.  (A register double buffer
+// of the operands of visit i+1 was tried: hipcc turns the counted waits of such a pipeline
+// into vmcnt(0) wherever loads sit in divergent-count branches, and the lost occupancy
+// cost more than the prefetch gained: 4.5 -> 5.0 ms.)
 // ------------------------------------------------------------------------
 template <int M, bool GRAD>
 __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
+  __shared__ SchedEntry sched_lds[kSchedWindow];
   const int blocks = a.tiles / M;
   const AaUnit un = aa_unit(blocks, a.evals * a.K);
   if (!un.valid) return;
@@ -326,7 +366,6 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
   const int p0 = blk * M * 16;
   const size_t tiles = a.tiles;
   const int nodes = GRAD ? n - 1 : a.slots;
-  const SchedEntry* sched = a.sched + (size_t)tree * (n - 1);
   double* arena = a.arena + (((size_t)el * nodes * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles;
   const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;  // per node / slot
   int32_t* exp_cum = a.exp_cum + ((size_t)el * nodes * K + cat) * tiles * 16 + p0;
@@ -334,6 +373,25 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
   const size_t exp_stride = (size_t)K * tiles * 16;
   const double* matP = a.matP + ((size_t)el * (n - 1) * K + cat) * kAaPack;
   const double* tipP = a.tipP + ((size_t)el * n * K + cat) * kAaTipTable;
+  const int count = n - 1;
+  SchedWindow win{a.sched + (size_t)tree * count, sched_lds, count, 0, lane};
+  win.fill_from(0);
+
+  // stage 0 of visit k: tip states of its tip children
+  auto stage0 = [&](int k, int (&x)[2][M]) {
+    const SchedEntry se = win.at(k);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int ch = sgpr(c ? se.child1 : se.child0);
+      if (ch < n) load_tip_states<M>(a.tip_states + (size_t)ch * P, P, p0, lane, x[c]);
+    }
+  };
+  int xc[2][M], xn[2][M];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int u = 0; u < M; u++) xc[c][u] = xn[c][u] = kAa;
+  stage0(0, xc);
 
   double R[M][5];
   int E[M];
@@ -344,23 +402,29 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
     for (int t = 0; t < 5; t++) R[u][t] = 0;
   }
   int prev = -1;
-  for (int i = 0; i < n - 1; i++) {
-    const SchedEntry se = sched[i];
+  for (int i = 0; i < count; i++) {
+    if (i + 1 >= win.base + kSchedWindow && i + 1 < count) win.fill_from(i);
+    const SchedEntry se = win.at(i);
     const int v = sgpr(se.node), slots = sgpr(se.slots);
-    const int next_c0 = i + 1 < n - 1 ? sgpr(sched[i + 1].child0) : -1;
-    const int next_c1 = i + 1 < n - 1 ? sgpr(sched[i + 1].child1) : -1;
+    int next_c0 = -1, next_c1 = -1;
+    if (i + 1 < count) {
+      const SchedEntry s1 = win.at(i + 1);
+      next_c0 = sgpr(s1.child0);
+      next_c1 = sgpr(s1.child1);
+      stage0(i + 1, xn);
+    }
     double S[2][M][5];
     int Ec[2][M];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       const int ch = sgpr(c ? se.child1 : se.child0);
       if (ch < n) {
-        tip_apply<M>(tipP + (size_t)ch * K * kAaTipTable, a.tip_states + (size_t)ch * P, P, p0,
-                     lane, S[c]);
+        tip_gather<M>(tipP + (size_t)ch * K * kAaTipTable, xc[c], lane, S[c]);
 #pragma unroll
         for (int u = 0; u < M; u++) Ec[c][u] = 0;
       } else {
-        double L[M][5];
+        double A[10], L[M][5];
+        load_pack(matP + (size_t)(ch - n) * K * kAaPack, lane, A);
         if (ch == prev) {
 #pragma unroll
           for (int u = 0; u < M; u++) {
@@ -374,7 +438,7 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
 #pragma unroll
           for (int u = 0; u < M; u++) Ec[c][u] = exp_cum[idx * exp_stride + u * 16 + j];
         }
-        mat_apply<M>(matP + (size_t)(ch - n) * K * kAaPack, lane, L, S[c]);
+        mat_apply<M>(A, L, S[c]);
       }
     }
     int eloc[M];
@@ -394,7 +458,7 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
       eloc[u] = e;
       E[u] = Ec[0][u] + Ec[1][u] + e;
     }
-    const bool is_root = i == n - 2;
+    const bool is_root = i == count - 1;
     const bool chained = v == next_c0 || v == next_c1;
     if (GRAD) {
       if (g == 0) {
@@ -417,6 +481,10 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
       }
     }
     prev = v;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int u = 0; u < M; u++) xc[c][u] = xn[c][u];
   }
   // root: sum_i pi_i L_root[i] per pattern (scaled) and its exponent
   double pi[5];
@@ -487,9 +555,14 @@ __global__ __launch_bounds__(256) void aa_root_kernel(AaWalkArgs a) {
 // edge x (child of v, sibling y) is  sum (q_v o P_y L_y) . (P_x Q) L_x : for a tip x both
 // products are table look-ups.  A child's pre-order vector overwrites its post-order
 // vector in the arena (dead once the parent has been visited).
+//
+// As in the post-order kernel: the schedule in LDS, tip states one visit ahead, everything a
+// visit reads from the arena requested at its top, few registers (the derivative products
+// are consumed tile by tile) for occupancy.
 // ------------------------------------------------------------------------
 template <int M>
 __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
+  __shared__ SchedEntry sched_lds[kSchedWindow];
   const int blocks = a.tiles / M;
   const AaUnit un = aa_unit(blocks, a.evals * a.K);
   if (!un.valid) return;
@@ -499,7 +572,6 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
   const int n = a.n, N = a.N, K = a.K, P = a.P;
   const int p0 = blk * M * 16;
   const size_t tiles = a.tiles;
-  const SchedEntry* sched = a.sched + (size_t)tree * (n - 1);
   double* arena = a.arena + (((size_t)el * (n - 1) * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles;
   const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;
   const int32_t* exp_loc = a.exp_loc + ((size_t)el * (n - 1) * K + cat) * tiles * 16 + p0;
@@ -511,19 +583,43 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
   const double* tipP = a.tipP + ((size_t)el * n * K + cat) * kAaTipTable;
   const double* tipPQ = a.tipPQ + ((size_t)el * n * K + cat) * kAaTipTable;
   double* gp = a.g_part + (((size_t)el * K + cat) * blocks + blk) * N;
+  const int count = n - 1;
+  SchedWindow win{a.sched + (size_t)tree * count, sched_lds, count, 0, lane};
+  win.fill_upto(count - 1);
 
-  double Qk[M][5];
+  auto stage0 = [&](int k, int (&x)[2][M]) {
+    const SchedEntry se = win.at(k);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int ch = sgpr(c ? se.child1 : se.child0);
+      if (ch < n) load_tip_states<M>(a.tip_states + (size_t)ch * P, P, p0, lane, x[c]);
+    }
+  };
+  int xc[2][M], xn[2][M];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int u = 0; u < M; u++) xc[c][u] = xn[c][u] = kAa;
+  stage0(count - 1, xc);
+
+  // the node's pre-order vector: computed by the parent's visit and kept here when this
+  // visit follows it immediately, else read back from the arena
+  double q[M][5];
 #pragma unroll
   for (int u = 0; u < M; u++)
 #pragma unroll
-    for (int t = 0; t < 5; t++) Qk[u][t] = 0;
+    for (int t = 0; t < 5; t++) q[u][t] = 0;
   int kept = -1;
-  for (int i = n - 2; i >= 0; i--) {
-    const SchedEntry se = sched[i];
+  for (int i = count - 1; i >= 0; i--) {
+    if (i - 1 < win.base && win.base > 0) win.fill_upto(i);
+    const SchedEntry se = win.at(i);
     const int v = sgpr(se.node);
-    const int next = i > 0 ? sgpr(sched[i - 1].node) : -1;
-    double q[M][5];
-    if (i == n - 2) {
+    const int next = i > 0 ? sgpr(win.at(i - 1).node) : -1;
+    int ch[2];
+    ch[0] = sgpr(se.child0);
+    ch[1] = sgpr(se.child1);
+    if (i > 0) stage0(i - 1, xn);
+    if (i == count - 1) {
       const size_t rbase = ((size_t)el * K + cat) * tiles * 16 + p0;
 #pragma unroll
       for (int u = 0; u < M; u++) {
@@ -531,67 +627,95 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
 #pragma unroll
         for (int t = 0; t < 5; t++) q[u][t] = a.model->pi[4 * t + g] * rs;
       }
-    } else if (kept == v) {
-#pragma unroll
-      for (int u = 0; u < M; u++)
-#pragma unroll
-        for (int t = 0; t < 5; t++) q[u][t] = Qk[u][t];
-    } else {
+    } else if (kept != v) {
       load_tiles<M>(arena + (size_t)(v - n) * arena_stride, lane, q);
     }
-    int ev[M];
+    // the children's post-order vectors (internal children), requested together
+    double L[2][M][5];
 #pragma unroll
-    for (int u = 0; u < M; u++) ev[u] = exp_loc[(size_t)(v - n) * exp_stride + u * 16 + j];
-    double S[2][M][5], D[2][M][5];
-    int ch[2];
+    for (int c = 0; c < 2; c++)
+      if (ch[c] >= n) load_tiles<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, L[c]);
+#pragma unroll
+    for (int u = 0; u < M; u++) {
+      const int ev = exp_loc[(size_t)(v - n) * exp_stride + u * 16 + j];
+#pragma unroll
+      for (int t = 0; t < 5; t++) q[u][t] = ldexp(q[u][t], -ev);
+    }
+    // S[c] = P_c L_c (tip: column of P)
+    double S[2][M][5];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-      ch[c] = sgpr(c ? se.child1 : se.child0);
       if (ch[c] < n) {
-        const int8_t* tips = a.tip_states + (size_t)ch[c] * P;
-        tip_apply<M>(tipP + (size_t)ch[c] * K * kAaTipTable, tips, P, p0, lane, S[c]);
-        tip_apply<M>(tipPQ + (size_t)ch[c] * K * kAaTipTable, tips, P, p0, lane, D[c]);
+        tip_gather<M>(tipP + (size_t)ch[c] * K * kAaTipTable, xc[c], lane, S[c]);
       } else {
-        double L[M][5];
-        load_tiles<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, L);
-        mat_apply<M>(matP + (size_t)(ch[c] - n) * K * kAaPack, lane, L, S[c]);
-        mat_apply<M>(matPQ + (size_t)(ch[c] - n) * K * kAaPack, lane, L, D[c]);
+        double A[10];
+        load_pack(matP + (size_t)(ch[c] - n) * K * kAaPack, lane, A);
+        mat_apply<M>(A, L[c], S[c]);
       }
     }
-    // u_c = q o S[sibling] 2^-e (kept in S[sibling]); X_c = sum u_c . D[c]
-    double X0 = 0, X1 = 0;
+    // u_c = q o S[sibling] (q carries 2^-e), kept in S[sibling]
 #pragma unroll
     for (int u = 0; u < M; u++)
 #pragma unroll
       for (int t = 0; t < 5; t++) {
-        const double qq = ldexp(q[u][t], -ev[u]);
-        const double u0 = qq * S[1][u][t], u1 = qq * S[0][u][t];
-        X0 += u0 * D[0][u][t];
-        X1 += u1 * D[1][u][t];
+        const double u0 = q[u][t] * S[1][u][t], u1 = q[u][t] * S[0][u][t];
         S[1][u][t] = u0;
         S[0][u][t] = u1;
       }
-    X0 = wave_sum(X0);
-    X1 = wave_sum(X1);
-    if (lane == 0) {
-      gp[ch[0]] = X0;
-      gp[ch[1]] = X1;
-    }
+    // X_c = sum u_c . (P_c Q) L_c, the derivative products consumed tile by tile
+    double X[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-      if (ch[c] < n) continue;
-      double qc[M][5];
-      mat_apply<M>(matPT + (size_t)(ch[c] - n) * K * kAaPack, lane, S[1 - c], qc);
-      if (ch[c] == next) {
+      double x = 0;
+      if (ch[c] < n) {
+        double D[M][5];
+        tip_gather<M>(tipPQ + (size_t)ch[c] * K * kAaTipTable, xc[c], lane, D);
 #pragma unroll
         for (int u = 0; u < M; u++)
 #pragma unroll
-          for (int t = 0; t < 5; t++) Qk[u][t] = qc[u][t];
-        kept = ch[c];
+          for (int t = 0; t < 5; t++) x += S[1 - c][u][t] * D[u][t];
       } else {
-        store_tiles<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, qc);
+        double A[10];
+        load_pack(matPQ + (size_t)(ch[c] - n) * K * kAaPack, lane, A);
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+          double L1[1][5], D1[1][5];
+#pragma unroll
+          for (int t = 0; t < 5; t++) L1[0][t] = L[c][u][t];
+          mat_apply<1>(A, L1, D1);
+#pragma unroll
+          for (int t = 0; t < 5; t++) x += S[1 - c][u][t] * D1[0][t];
+        }
       }
+      X[c] = wave_sum(x);
     }
+    if (lane == 0) {
+      gp[ch[0]] = X[0];
+      gp[ch[1]] = X[1];
+    }
+    // q_c = P_c^T u_c for internal children: into the arena, or kept for the next visit
+    int keep_next = -1;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      if (ch[c] < n || ch[c] == next) continue;
+      double A[10], qc[M][5];
+      load_pack(matPT + (size_t)(ch[c] - n) * K * kAaPack, lane, A);
+      mat_apply<M>(A, S[1 - c], qc);
+      store_tiles<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, qc);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      if (ch[c] < n || ch[c] != next) continue;
+      double A[10];
+      load_pack(matPT + (size_t)(ch[c] - n) * K * kAaPack, lane, A);
+      mat_apply<M>(A, S[1 - c], q);
+      keep_next = ch[c];
+    }
+    kept = keep_next;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int u = 0; u < M; u++) xc[c][u] = xn[c][u];
   }
 }
 
@@ -600,46 +724,53 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
 // numerator sum_k (d r_k / d shape) X_k per edge, blocks summed in order (deterministic).
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void aa_reduce_kernel(AaWalkArgs a, int ll_blocks) {
+  // grid (1 + ceil(N / 64), evaluations): workgroup 0 sums the log-likelihood partials, the
+  // others take 64 edges each, four waves splitting the pattern blocks (fixed order)
+  __shared__ double red[256], red2[256];
   const int el = blockIdx.y, tree = a.eval_offset + el;
-  const int N = a.N;
+  const int N = a.N, tid = threadIdx.x;
   if (blockIdx.x == 0) {
-    __shared__ double red[256];
     double s = 0;
-    for (int i = threadIdx.x; i < ll_blocks; i += 256) s += a.ll_part[(size_t)tree * a.ll_stride + i];
-    red[threadIdx.x] = s;
+    for (int i = tid; i < ll_blocks; i += 256) s += a.ll_part[(size_t)tree * a.ll_stride + i];
+    red[tid] = s;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      if (tid < off) red[tid] += red[tid + off];
       __syncthreads();
     }
-    if (threadIdx.x == 0) a.ll_sum[tree] = red[0];
-    if (!a.gradient) return;
+    if (tid == 0) a.ll_sum[tree] = red[0];
+    return;
   }
-  if (!a.gradient) return;
-  const int edge = blockIdx.x * 256 + threadIdx.x;
-  if (edge >= N) return;
+  const int edge = (blockIdx.x - 1) * 64 + (tid & 63), part = tid >> 6;
   const DevModel& m = a.models[tree];
   const int blocks = a.tiles / kAaPreTiles;
+  const int b0 = (int)((long)blocks * part / 4), b1 = (int)((long)blocks * (part + 1) / 4);
   double br = 0, si = 0;
   if (edge < N - 1) {
     for (int k = 0; k < a.K; k++) {
       const double* gp = a.g_part + ((size_t)el * a.K + k) * blocks * N + edge;
       double x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-      int b = 0;
-      for (; b + 4 <= blocks; b += 4) {
+      int b = b0;
+      for (; b + 4 <= b1; b += 4) {
         x0 += gp[(size_t)b * N];
         x1 += gp[(size_t)(b + 1) * N];
         x2 += gp[(size_t)(b + 2) * N];
         x3 += gp[(size_t)(b + 3) * N];
       }
-      for (; b < blocks; b++) x0 += gp[(size_t)b * N];
+      for (; b < b1; b++) x0 += gp[(size_t)b * N];
       const double xs = (x0 + x1) + (x2 + x3);
       br += m.cat_rate[k] * xs;
       si += m.cat_drate[k] * xs;
     }
   }
-  a.g_sum[((size_t)tree * 2 + 0) * N + edge] = br;
-  a.g_sum[((size_t)tree * 2 + 1) * N + edge] = si;
+  red[tid] = br;
+  red2[tid] = si;
+  __syncthreads();
+  if (part == 0 && edge < N) {
+    const int l = tid & 63;
+    a.g_sum[((size_t)tree * 2 + 0) * N + edge] = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
+    a.g_sum[((size_t)tree * 2 + 1) * N + edge] = (red2[l] + red2[64 + l]) + (red2[128 + l] + red2[192 + l]);
+  }
 }
 
 }  // namespace
@@ -679,7 +810,7 @@ void launch_aa_pre(const AaWalkArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((aa_pre_kernel<kAaPreTiles>), grid, dim3(64), 0, s, a);
 }
 void launch_aa_reduce(const AaWalkArgs& a, hipStream_t s) {
-  const int gx = a.gradient ? (a.N + 255) / 256 : 1;
+  const int gx = a.gradient ? 1 + (a.N + 63) / 64 : 1;
   hipLaunchKernelGGL(aa_reduce_kernel, dim3(gx, a.evals), dim3(256), 0, s, a, aa_ll_blocks(a.P));
 }
 const char* aa_post_kernel_name() { return "aa_post_kernel"; }

@@ -848,7 +848,7 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
 void launch_setup(const TreeSetupArgs& a_in, const ModelSetupArgs& ms, hipStream_t s) {
   TreeSetupArgs a = a_in;
   const size_t lds = sizeof(int32_t) * 13 * (size_t)(2 * a.n - 1);
-  a.use_lds = lds <= 48 * 1024;
+  a.use_lds = lds <= 64 * 1024;  // (N <= 1260: the 512-taxon trees of the 20-state bench)
   // MI_PHYLO_TREE_SETUP=lds forces the general kernel (testing)
   static const bool force_lds = [] {
     const char* env = getenv("MI_PHYLO_TREE_SETUP");

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define MI_PHYLO_ABI_VERSION 1
+#define MI_PHYLO_ABI_VERSION 2
 
 typedef struct mi_engine mi_engine;
 
@@ -76,6 +76,8 @@ typedef struct {
 
 int32_t mi_abi_version(void);
 const char* mi_last_error(void);
+/* visible HIP devices (0 without a GPU); what thread_count is capped by in the adapter */
+int32_t mi_device_count(void);
 
 /* Engine::Engine + FatBeagle::SetTipStates/SetTipPartials/SetPatternWeights.
  * tip_states[n*P]: 0..s-1, >= s means gap (src/site_pattern.cpp:16-46).
@@ -98,6 +100,30 @@ int32_t mi_engine_create_reversible(const mi_engine_spec* spec, const double* ex
                                     const double* frequencies, const int32_t* tip_states,
                                     const double* tip_partials, const double* pattern_weights,
                                     mi_engine** out_engine);
+/* One handle driving several devices -- what Engine's thread_count FatBeagles are
+ * (src/engine.cpp:14-27; FatBeagleParallelize, src/fat_beagle.hpp:119-149): `shard_count`
+ * engines, shard i on HIP device devices[i] (NULL: round-robin over the visible devices; an
+ * ordinal may repeat, which puts several logical shards on one device), tips and weights
+ * resident on each.  shard_mode MI_SHARD_TREES: the host-pointer calls deal the trees to
+ * the shards in contiguous blocks (mi_shard_range), all devices work side by side, results
+ * come back in tree order -- bit-identical to a single engine's.  MI_SHARD_PATTERNS (few
+ * trees, very long alignments): shard i holds the site patterns mi_shard_range(P, count, i),
+ * evaluates every tree on them, and the per-tree results of the unrooted calls (sums over
+ * patterns, all of them) are added in shard order.  spec->device is ignored.
+ * exchangeabilities / frequencies: as mi_engine_create_reversible (NULL for 4-state models).
+ * The *_device entry points need a single-device engine (one engine per device, e.g. one
+ * process per GPU under torch.distributed: INTEGRATION.md). */
+enum { MI_SHARD_TREES = 0, MI_SHARD_PATTERNS = 1 };
+int32_t mi_engine_create_sharded(const mi_engine_spec* spec, int32_t shard_count,
+                                 const int32_t* devices, int32_t shard_mode,
+                                 const double* exchangeabilities, const double* frequencies,
+                                 const int32_t* tip_states, const double* tip_partials,
+                                 const double* pattern_weights, mi_engine** out_engine);
+int32_t mi_engine_shard_count(const mi_engine* engine);
+/* Contiguous block of shard `shard` of `shard_count` over `total` units: block sizes differ
+ * by at most one, the larger blocks first. */
+int32_t mi_shard_range(int32_t total, int32_t shard_count, int32_t shard, int32_t* begin,
+                       int32_t* count);
 /* the built-in WAG table in that form: exchangeabilities[190], frequencies[20] (sum 1) */
 int32_t mi_wag_model(double* exchangeabilities, double* frequencies);
 void mi_engine_destroy(mi_engine* engine);
@@ -131,6 +157,26 @@ int32_t mi_engine_gradients_unrooted(mi_engine* engine, int32_t tree_count,
                                      const double* params, int32_t rescaling,
                                      double* out_log_likelihoods, double* out_branch_gradient,
                                      double* out_site_gradient, double* out_subst_gradient);
+
+/* Engine::Gradients(const UnrootedTreeCollection&, ...) followed, on the device, by the
+ * reductions a variational-inference step applies to its result (vip/burrito.py:143-166,
+ * vip/branch_model.py:104-133, src/unrooted_sbn_instance.cpp:176-198):
+ *   out_sums[0] = sum_t w_t logL_t          out_sums[1] = sum_t w_t gradient_["site_model"]_t
+ *   out_index_gradient[k] = sum over (t, v) with branch_index[t][v] == k of
+ *                           w_t gradient_["branch_lengths"]_t[v]        (k < index_count)
+ * branch_index[T][2n-1]: the parameter (split) index of every node's branch, negative = not a
+ * parameter (the root and the fixed node always carry a zero gradient); tree_weights[T] or
+ * NULL (w_t = 1).  Sums run in (t, v) order: deterministic.  out_log_likelihoods[T] may be
+ * NULL.  A multi-GPU step then needs ONE all-reduce of 2 + index_count doubles.  The
+ * substitution-model block (16 finite-difference passes for GTR) is not computed. */
+int32_t mi_engine_gradients_unrooted_reduced(mi_engine* engine, int32_t tree_count,
+                                             const int32_t* parent_ids,
+                                             const double* branch_lengths, const double* params,
+                                             int32_t rescaling, const int32_t* branch_index,
+                                             const double* tree_weights, int32_t index_count,
+                                             double* out_sums /* [2] */,
+                                             double* out_index_gradient /* [index_count] */,
+                                             double* out_log_likelihoods /* [T] or NULL */);
 
 /* Engine::LogLikelihoods(const RootedTreeCollection&) when with_jacobian != 0
  * (branch lengths x rates, + log-det-Jacobian, fat_beagle.cpp:82-104), or
@@ -200,6 +246,12 @@ int32_t mi_engine_gradients_rooted_device(mi_engine* engine, void* stream, int32
                                           double* out_ratios_root_height,
                                           double* out_clock_gradient, double* out_site_gradient,
                                           double* out_subst_gradient);
+
+int32_t mi_engine_gradients_unrooted_reduced_device(
+    mi_engine* engine, void* stream, int32_t tree_count, const int32_t* parent_ids,
+    const double* branch_lengths, const double* params, int32_t rescaling,
+    const int32_t* branch_index, const double* tree_weights, int32_t index_count,
+    double* out_sums, double* out_index_gradient, double* out_log_likelihoods);
 
 /* Make sure the workspace for `tree_count` trees exists (so that a following
  * *_device call allocates nothing and can be captured in a hipGraph). */

@@ -24,6 +24,16 @@ _V = C.c_void_p
 SYMBOLS = {
     "mi_abi_version": (C.c_int32, []),
     "mi_last_error": (C.c_char_p, []),
+    "mi_device_count": (C.c_int32, []),
+    "mi_engine_create_sharded":
+        (C.c_int32, [C.POINTER(EngineSpec), C.c_int32, I32P, C.c_int32, _V, _V, _V, _V, _V,
+                     C.POINTER(_V)]),
+    "mi_engine_shard_count": (C.c_int32, [_V]),
+    "mi_shard_range": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, I32P, I32P]),
+    "mi_engine_gradients_unrooted_reduced":
+        (C.c_int32, [_V, C.c_int32, _V, _V, _V, C.c_int32, _V, _V, C.c_int32, _V, _V, _V]),
+    "mi_engine_gradients_unrooted_reduced_device":
+        (C.c_int32, [_V, _V, C.c_int32, _V, _V, _V, C.c_int32, _V, _V, C.c_int32, _V, _V, _V]),
     "mi_engine_create": (C.c_int32, [C.POINTER(EngineSpec), _V, _V, _V, C.POINTER(_V)]),
     "mi_engine_create_reversible":
         (C.c_int32, [C.POINTER(EngineSpec), _V, _V, _V, _V, _V, C.POINTER(_V)]),

@@ -10,6 +10,7 @@
 //   EigenMatrixXdRef (row-major)            mihost::ParamMatrix
 // Errors are std::runtime_error, like Failwith (src/sugar.hpp:67-78).
 #pragma once
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -24,9 +25,15 @@ struct PhyloModelSpecification {
 };
 
 struct EngineSpecification {
+  // The reference makes thread_count_ FatBeagle instances and deals the trees of a call to
+  // them (engine.cpp:23-27, fat_beagle.hpp:119-149).  Here the executors are GPUs: the trees
+  // of a call are dealt, in contiguous blocks, to min(thread_count_, visible devices) devices
+  // driven by ONE handle (mi_engine_create_sharded); on a one-GPU machine any thread count
+  // gives one engine.  device_shards_ overrides that (testing: several logical shards).
   size_t thread_count_;
   std::vector<int> beagle_flag_vector_;  // accepted and ignored
   bool use_tip_states_;
+  std::vector<int32_t> device_shards_ = {};
 };
 
 using GradientMap = std::map<std::string, std::vector<double>>;
@@ -64,7 +71,10 @@ class Engine {
     spec.state_count = 4;
     if (specification.substitution_ == "JC69") spec.subst_model = MI_SUBST_JC69;
     else if (specification.substitution_ == "GTR") spec.subst_model = MI_SUBST_GTR;
-    else Failwith("Substitution model not known: " + specification.substitution_);
+    else if (specification.substitution_ == "WAG") {  // 20 states, built-in table
+      spec.subst_model = MI_SUBST_REVERSIBLE;
+      spec.state_count = 20;
+    } else Failwith("Substitution model not known: " + specification.substitution_);
     if (specification.site_ == "constant") {
       spec.site_model = MI_SITE_CONSTANT;
       spec.category_count = 1;
@@ -84,8 +94,16 @@ class Engine {
     category_count_ = spec.category_count;
     is_gtr_ = spec.subst_model == MI_SUBST_GTR;
     const auto tips = site_pattern_.FlatPatterns();
-    Check(mi_engine_create(&spec, tips.data(), nullptr, site_pattern_.GetWeights().data(),
-                           &handle_));
+    std::vector<int32_t> shards = engine_specification.device_shards_;
+    if (shards.empty()) {
+      const size_t devices = static_cast<size_t>(std::max(1, mi_device_count()));
+      for (size_t i = 0; i < std::min(engine_specification.thread_count_, devices); i++)
+        shards.push_back(static_cast<int32_t>(i));
+    }
+    taxon_count_ = static_cast<size_t>(spec.taxon_count);
+    Check(mi_engine_create_sharded(&spec, static_cast<int32_t>(shards.size()), shards.data(),
+                                   MI_SHARD_TREES, nullptr, nullptr, tips.data(), nullptr,
+                                   site_pattern_.GetWeights().data(), &handle_));
     for (int i = 0; i < mi_engine_block_count(handle_); i++) {
       const char* name;
       int32_t start, length;
@@ -106,8 +124,9 @@ class Engine {
                                      const ParamMatrix& params, const bool rescaling) const {
     std::vector<int32_t> parents;
     std::vector<double> bl;
-    Flatten(trees, params, &parents, &bl);
+    Flatten(trees, params, false, &parents, &bl);
     std::vector<double> out(trees.size());
+    if (trees.empty()) return out;  // FatBeagleParallelize returns an empty vector
     Check(mi_engine_log_likelihoods_unrooted(handle_, static_cast<int32_t>(trees.size()),
                                              parents.data(), bl.data(), params.data.data(),
                                              rescaling, out.data()));
@@ -130,7 +149,8 @@ class Engine {
     const size_t T = trees.size(), N = 2 * site_pattern_.SequenceCount() - 1;
     std::vector<int32_t> parents;
     std::vector<double> bl;
-    Flatten(trees, params, &parents, &bl);
+    Flatten(trees, params, false, &parents, &bl);
+    if (trees.empty()) return {};
     std::vector<double> ll(T), g(T * N), site(T), subst(T * 8);
     Check(mi_engine_gradients_unrooted(handle_, static_cast<int32_t>(T), parents.data(),
                                        bl.data(), params.data.data(), rescaling, ll.data(),
@@ -149,7 +169,8 @@ class Engine {
     const size_t T = trees.size(), n = site_pattern_.SequenceCount(), N = 2 * n - 1;
     std::vector<int32_t> parents, rate_counts;
     std::vector<double> bl, rates, heights, bounds, ratios;
-    Flatten(trees, params, &parents, &bl);
+    Flatten(trees, params, true, &parents, &bl);
+    if (trees.empty()) return {};
     for (const auto& tree : trees) {
       if (!tree.TimeTreeHasBeenInitialized())  // rooted_tree.hpp:50-53
         Failwith("Attempted access of a time tree member that requires the time tree to be "
@@ -186,17 +207,26 @@ class Engine {
   BlockSpecificationMap block_specification_;
   int category_count_ = 1;
   bool is_gtr_ = false;
+  size_t taxon_count_ = 0;
 
   static void Check(int rc) {
     if (rc != 0) Failwith(mi_last_error());
   }
 
   template <class TColl>
-  void Flatten(const TColl& trees, const ParamMatrix& params, std::vector<int32_t>* parents,
-               std::vector<double>* bl) const {
+  void Flatten(const TColl& trees, const ParamMatrix& params, bool rooted,
+               std::vector<int32_t>* parents, std::vector<double>* bl) const {
     if (trees.size() != params.rows)  // fat_beagle.hpp:138
       Failwith("We param_matrix needs as many rows as we have trees.");
     if (params.cols != ParameterCount()) Failwith("Parameters are the wrong dimension!");
+    // every tree must be on the alignment's taxa: the C ABI reads fixed-size rows
+    const size_t n = taxon_count_;
+    const size_t want_parents = rooted ? 2 * n - 2 : 2 * n - 3, want_bl = want_parents + 1;
+    for (const auto& tree : trees)
+      if (tree.parent_ids.size() != want_parents || tree.branch_lengths.size() != want_bl)
+        Failwith("Tree does not have the taxon count of the site pattern (expected " +
+                 std::to_string(want_parents) + " parent ids and " + std::to_string(want_bl) +
+                 " branch lengths).");
     for (const auto& tree : trees) {
       parents->insert(parents->end(), tree.parent_ids.begin(), tree.parent_ids.end());
       bl->insert(bl->end(), tree.branch_lengths.begin(), tree.branch_lengths.end());
@@ -208,7 +238,8 @@ class Engine {
                                            bool with_jacobian) const {
     std::vector<int32_t> parents;
     std::vector<double> bl, rates, heights, bounds;
-    Flatten(trees, params, &parents, &bl);
+    Flatten(trees, params, true, &parents, &bl);
+    if (trees.empty()) return {};
     if (with_jacobian)
       for (const auto& tree : trees) {
         if (!tree.TimeTreeHasBeenInitialized())

@@ -420,11 +420,63 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------
+// Caller-side reductions of one variational-inference step, on the device
+// (vip/burrito.py:143-166: sum of the per-tree log-likelihoods; vip/branch_model.py:125-132:
+// per-tree branch gradients scatter-added by split index).  No float atomics: the thread that
+// owns index k scans the (tree, node) pairs in order -- staged through LDS a chunk at a time
+// -- and adds the ones that carry k, so every sum has a fixed order.
+// ------------------------------------------------------------------------
+constexpr int kViChunk = 2048;
+__global__ __launch_bounds__(256) void vi_reduce_kernel(ViReduceArgs a) {
+  __shared__ int32_t idx[kViChunk];
+  __shared__ double val[kViChunk];
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  if (blockIdx.x == gridDim.x - 1) {  // the last workgroup: the two scalar sums
+    for (int which = 0; which < 2; which++) {
+      const double* x = which ? a.site : a.ll;
+      double s = 0;
+      if (x)
+        for (int t = tid; t < a.T; t += 256) s += (a.tree_weights ? a.tree_weights[t] : 1.0) * x[t];
+      red[tid] = s;
+      __syncthreads();
+      for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+      }
+      if (tid == 0) a.out_sums[which] = red[0];
+      __syncthreads();
+    }
+    return;
+  }
+  const int k = blockIdx.x * 256 + tid;
+  const long total = (long)a.T * a.N;
+  double sum = 0;
+  for (long base = 0; base < total; base += kViChunk) {
+    const int count = (int)(total - base < kViChunk ? total - base : kViChunk);
+    for (int i = tid; i < count; i += 256) {
+      const long e = base + i;
+      idx[i] = a.branch_index[e];
+      val[i] = a.branch[e] * (a.tree_weights ? a.tree_weights[e / a.N] : 1.0);
+    }
+    __syncthreads();
+    if (k < a.index_count)
+      for (int i = 0; i < count; i++)
+        if (idx[i] == k) sum += val[i];
+    __syncthreads();
+  }
+  if (k < a.index_count) a.out_index_gradient[k] = sum;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------
 // Launch wrappers
 // ------------------------------------------------------------------------
+void launch_vi_reduce(const ViReduceArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(vi_reduce_kernel, dim3((a.index_count + 255) / 256 + 1), dim3(256), 0, s, a);
+}
 void launch_subst_gradient(const SubstGradArgs& a, hipStream_t s) {
   if (a.T <= 0) return;
   hipLaunchKernelGGL(subst_gradient_kernel, dim3((a.T + 63) / 64), dim3(64), 0, s, a);

@@ -452,10 +452,21 @@ hipStream_t pick_stream(mi_engine* e, void* stream) {
 
 }  // namespace
 
+namespace {
+const char kShardedDeviceCall[] =
+    "device-pointer entry points need a single-device engine: one engine per device (one "
+    "process per GPU), or the host-pointer entry points";
+}
+
 extern "C" {
 
 int32_t mi_abi_version(void) { return MI_PHYLO_ABI_VERSION; }
 const char* mi_last_error(void) { return g_error.c_str(); }
+int32_t mi_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
 
 static int32_t create_engine(const mi_engine_spec* spec, const double* exchangeabilities,
                              const double* frequencies, const int32_t* tip_states,
@@ -654,6 +665,9 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
 
 void mi_engine_destroy(mi_engine* e) {
   if (!e) return;
+  for (mi_engine* shard : e->shards) mi_engine_destroy(shard);
+  e->shards.clear();
+  if (e->stream || e->tip_states.ptr) (void)hipSetDevice(e->spec.device);
   if (e->stream) {
     (void)hipStreamSynchronize(e->stream);
   }
@@ -664,7 +678,8 @@ void mi_engine_destroy(mi_engine* e) {
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,
         &e->ll_sum, &e->g_sum, &e->status, &e->aa_model, &e->aa_matP, &e->aa_matPT, &e->aa_matPQ,
         &e->aa_tipP, &e->aa_tipPQ, &e->aa_exp_cum, &e->aa_exp_loc, &e->aa_root_val,
-        &e->aa_root_exp, &e->aa_root_scale,
+        &e->aa_root_exp, &e->aa_root_scale, &e->in_index, &e->in_weights, &e->out_reduced,
+        &e->red_ll, &e->red_g, &e->red_site,
         &e->in_parent, &e->in_bl, &e->in_params, &e->in_rates, &e->in_rate_counts,
         &e->in_heights, &e->in_bounds, &e->in_ratios, &e->out_ll, &e->out_a, &e->out_b,
         &e->out_site, &e->out_subst})
@@ -689,6 +704,15 @@ int32_t mi_engine_block(const mi_engine* e, int32_t index, const char** name, in
 int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradients) {
   if (!e) return fail("null engine");
   if (tree_count <= 0) return fail("tree_count must be positive");
+  if (!e->shards.empty()) {
+    const int D = (int)e->shards.size();
+    for (int i = 0; i < D; i++) {
+      int32_t b = 0, c = tree_count;
+      if (e->shard_mode == MI_SHARD_TREES) mi_shard_range(tree_count, D, i, &b, &c);
+      if (c > 0 && mi_engine_reserve(e->shards[i], c, for_gradients)) return 1;
+    }
+    return 0;
+  }
   HIP_TRY(hipSetDevice(e->spec.device));
   if (e->s == kAa) return aa_reserve(e, tree_count, for_gradients != 0);
   // the HBM arena is only reserved when a later call may need it (rescaling with the VALU
@@ -700,11 +724,17 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
 
 int32_t mi_engine_check_status(mi_engine* e, void* stream) {
   if (!e) return fail("null engine");
+  if (!e->shards.empty()) {
+    for (mi_engine* shard : e->shards)
+      if (check_status(shard, shard->stream)) return 1;
+    return 0;
+  }
   return check_status(e, pick_stream(e, stream));
 }
 
 int32_t mi_engine_profile_begin(mi_engine* e, int32_t max_calls) {
   if (!e) return fail("null engine");
+  if (!e->shards.empty()) return mi_engine_profile_begin(e->shards[0], max_calls);
   if (max_calls < 0) return fail("max_calls must be >= 0");
   HIP_TRY(hipSetDevice(e->spec.device));
   while ((int)e->prof_events.size() < 2 * max_calls) {
@@ -720,6 +750,8 @@ int32_t mi_engine_profile_begin(mi_engine* e, int32_t max_calls) {
 int32_t mi_engine_profile_collect(mi_engine* e, double* out_ms, int32_t capacity,
                                   int32_t* out_count) {
   if (!e) return fail("null engine");
+  if (!e->shards.empty())
+    return mi_engine_profile_collect(e->shards[0], out_ms, capacity, out_count);
   const int count = std::min(e->prof_used, capacity);
   for (int i = 0; i < count; i++) {
     HIP_TRY(hipEventSynchronize(e->prof_events[2 * i + 1]));
@@ -736,6 +768,9 @@ int32_t mi_engine_profile_collect(mi_engine* e, double* out_ms, int32_t capacity
 int32_t mi_engine_last_call_info(const mi_engine* e, const char** dominant_kernel,
                                  int64_t* evaluations, int64_t* gradient_evaluations) {
   if (!e) return fail("null engine");
+  if (!e->shards.empty())
+    return mi_engine_last_call_info(e->shards[0], dominant_kernel, evaluations,
+                                    gradient_evaluations);
   if (dominant_kernel) *dominant_kernel = e->dominant;
   if (evaluations) *evaluations = e->last_evals;
   if (gradient_evaluations) *gradient_evaluations = e->last_grad_evals;
@@ -749,6 +784,7 @@ int32_t mi_engine_log_likelihoods_unrooted_device(mi_engine* e, void* stream, in
                                                   const double* params, int32_t rescaling,
                                                   double* out_ll) {
   if (!e) return fail("null engine");
+  if (!e->shards.empty()) return fail(kShardedDeviceCall);
   DeviceCall d;
   d.T = T;
   d.rescaling = rescaling != 0;
@@ -765,6 +801,7 @@ int32_t mi_engine_gradients_unrooted_device(mi_engine* e, void* stream, int32_t 
                                             double* out_ll, double* out_branch,
                                             double* out_site, double* out_subst) {
   if (!e) return fail("null engine");
+  if (!e->shards.empty()) return fail(kShardedDeviceCall);
   if (!out_branch) return fail("null branch-gradient output");
   DeviceCall d;
   d.gradient = true;
@@ -787,6 +824,7 @@ int32_t mi_engine_log_likelihoods_rooted_device(mi_engine* e, void* stream, int3
                                                 int32_t with_jacobian, int32_t rescaling,
                                                 double* out_ll) {
   if (!e) return fail("null engine");
+  if (!e->shards.empty()) return fail(kShardedDeviceCall);
   if (with_jacobian && (!rates || !heights || !bounds))
     return fail("Attempted access of a time tree member that requires the time tree to be "
                 "initialized. Have you set dates for your time trees, and initialized the "
@@ -815,6 +853,7 @@ int32_t mi_engine_gradients_rooted_device(mi_engine* e, void* stream, int32_t T,
                                           double* out_clock, double* out_site,
                                           double* out_subst) {
   if (!e) return fail("null engine");
+  if (!e->shards.empty()) return fail(kShardedDeviceCall);
   if (!rates || !rate_counts || !heights || !bounds || !ratios)
     return fail("Attempted access of a time tree member that requires the time tree to be "
                 "initialized. Have you set dates for your time trees, and initialized the "
@@ -841,21 +880,377 @@ int32_t mi_engine_gradients_rooted_device(mi_engine* e, void* stream, int32_t T,
   return run_device(e, pick_stream(e, stream), d);
 }
 
+/* Engine::Gradients followed by the caller-side reductions of one variational-inference
+ * step (vip/burrito.py:143-166, vip/branch_model.py:104-133,
+ * src/unrooted_sbn_instance.cpp:176-198), fused behind the call: see include/mi_phylo.h. */
+int32_t mi_engine_gradients_unrooted_reduced_device(
+    mi_engine* e, void* stream, int32_t T, const int32_t* parent_ids, const double* bl,
+    const double* params, int32_t rescaling, const int32_t* branch_index,
+    const double* tree_weights, int32_t index_count, double* out_sums,
+    double* out_index_gradient, double* out_ll) {
+  if (!e) return fail("null engine");
+  if (!e->shards.empty())
+    return fail("device-pointer entry points need a single-device engine: one engine per "
+                "device (one process per GPU), or the host-pointer entry points");
+  if (!branch_index || !out_sums || index_count < 0 || (index_count > 0 && !out_index_gradient))
+    return fail("null output / index");
+  hipStream_t s = pick_stream(e, stream);
+  HIP_TRY(hipSetDevice(e->spec.device));
+  // per-tree results into the engine's own buffers unless the caller wants logL too
+  if (e->red_ll.ensure(sizeof(double) * std::max(T, 1))) return 1;
+  if (e->red_g.ensure(sizeof(double) * (size_t)std::max(T, 1) * e->N)) return 1;
+  if (e->red_site.ensure(sizeof(double) * std::max(T, 1))) return 1;
+  double* ll = out_ll ? out_ll : e->red_ll.as<double>();
+  DeviceCall d;
+  d.gradient = true;
+  d.T = T;
+  d.rescaling = rescaling != 0;
+  d.parent_ids = parent_ids;
+  d.bl = bl;
+  d.params = params;
+  d.out_ll = ll;
+  d.out_branch = e->red_g.as<double>();
+  d.out_site = e->K > 1 ? e->red_site.as<double>() : nullptr;
+  d.out_subst = nullptr;  // (the 16 finite-difference passes are not part of this reduction)
+  if (run_device(e, s, d)) return 1;
+  ViReduceArgs ra{};
+  ra.T = T;
+  ra.N = e->N;
+  ra.index_count = index_count;
+  ra.ll = ll;
+  ra.branch = e->red_g.as<double>();
+  ra.site = e->K > 1 ? e->red_site.as<double>() : nullptr;
+  ra.branch_index = branch_index;
+  ra.tree_weights = tree_weights;
+  ra.out_sums = out_sums;
+  ra.out_index_gradient = out_index_gradient;
+  launch_vi_reduce(ra, s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int32_t mi_engine_create_sharded(const mi_engine_spec* spec, int32_t shard_count,
+                                 const int32_t* devices, int32_t shard_mode,
+                                 const double* exchangeabilities, const double* frequencies,
+                                 const int32_t* tip_states, const double* tip_partials,
+                                 const double* pattern_weights, mi_engine** out_engine) {
+  if (!spec || !out_engine) return fail("null spec / out_engine");
+  *out_engine = nullptr;
+  if (shard_count <= 0) return fail("Thread count needs to be strictly positive.");  // engine.cpp:14-16
+  if (shard_mode != MI_SHARD_TREES && shard_mode != MI_SHARD_PATTERNS)
+    return fail("unknown shard mode");
+  if (shard_mode == MI_SHARD_PATTERNS && shard_count > spec->pattern_count)
+    return fail("more pattern shards than site patterns");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    return fail("no HIP device available: the MI355X engine has no CPU fallback");
+  mi_engine* front = new mi_engine();
+  front->spec = *spec;
+  front->shard_mode = shard_mode;
+  front->n = spec->taxon_count;
+  front->N = 2 * front->n - 1;
+  front->P = spec->pattern_count;
+  front->K = spec->category_count;
+  const int n = spec->taxon_count, s = spec->state_count;
+  for (int i = 0; i < shard_count; i++) {
+    mi_engine_spec sub = *spec;
+    sub.device = devices ? devices[i] : i % count;  // NULL: round-robin over the visible devices
+    int32_t b = 0, c = spec->pattern_count;
+    if (shard_mode == MI_SHARD_PATTERNS) mi_shard_range(spec->pattern_count, shard_count, i, &b, &c);
+    sub.pattern_count = c;
+    std::vector<int32_t> tips;
+    std::vector<double> parts;
+    if (shard_mode == MI_SHARD_PATTERNS) {  // columns [b, b + c) of the [taxon][pattern] arrays
+      if (tip_states) {
+        tips.resize((size_t)n * c);
+        for (int x = 0; x < n; x++)
+          std::copy(tip_states + (size_t)x * spec->pattern_count + b,
+                    tip_states + (size_t)x * spec->pattern_count + b + c, tips.begin() + (size_t)x * c);
+      }
+      if (tip_partials) {
+        parts.resize((size_t)n * c * s);
+        for (int x = 0; x < n; x++)
+          std::copy(tip_partials + ((size_t)x * spec->pattern_count + b) * s,
+                    tip_partials + ((size_t)x * spec->pattern_count + b + c) * s,
+                    parts.begin() + (size_t)x * c * s);
+      }
+    }
+    mi_engine* shard = nullptr;
+    const int rc = create_engine(
+        &sub, exchangeabilities, frequencies,
+        shard_mode == MI_SHARD_PATTERNS ? (tip_states ? tips.data() : nullptr) : tip_states,
+        shard_mode == MI_SHARD_PATTERNS ? (tip_partials ? parts.data() : nullptr) : tip_partials,
+        pattern_weights + b, &shard);
+    if (rc) {
+      mi_engine_destroy(front);
+      return 1;
+    }
+    front->shards.push_back(shard);
+  }
+  const mi_engine* first = front->shards[0];
+  front->param_count = first->param_count;
+  front->blocks = first->blocks;
+  front->s = first->s;
+  *out_engine = front;
+  return 0;
+}
+
+int32_t mi_engine_shard_count(const mi_engine* e) {
+  return e ? std::max<int32_t>(1, (int32_t)e->shards.size()) : -1;
+}
+
 /* ---- host-pointer entry points ------------------------------------------ */
 
-static int stage_common(mi_engine* e, int T, bool rooted, const int32_t* parent_ids,
-                        const double* bl, const double* params) {
-  if (!e) return fail("null engine");
+}  // extern "C"
+
+namespace {
+
+// One host-pointer call; `begin` stages the inputs, enqueues the device call and the
+// downloads on the engine's stream, `finish_host_call` synchronises once and hands the
+// staged outputs over.  A sharded handle begins the call on every shard before it finishes
+// any, so the devices work side by side.
+struct HostCall {
+  bool gradient = false, rooted = false;
+  int T = 0, rescaling = 0, with_jacobian = 0;
+  const int32_t* parent_ids = nullptr;
+  const double* bl = nullptr;
+  const double* params = nullptr;
+  const double* rates = nullptr;
+  const int32_t* rate_counts = nullptr;
+  const double* heights = nullptr;
+  const double* bounds = nullptr;
+  const double* ratios = nullptr;
+  double* out_ll = nullptr;
+  double* out_a = nullptr;  // branch gradient [T][N] (unrooted) / ratios [T][n-1] (rooted)
+  double* out_b = nullptr;  // clock gradient [T][N-1] (rooted)
+  double* out_site = nullptr;
+  double* out_subst = nullptr;
+  // fused reductions of a variational-inference step (mi_engine_gradients_unrooted_reduced)
+  bool reduced = false;
+  const int32_t* branch_index = nullptr;  // [T][N]
+  const double* tree_weights = nullptr;   // [T] or null
+  int index_count = 0;
+  double* out_sum = nullptr;         // [2]: sum w logL, sum w site gradient
+  double* out_index_grad = nullptr;  // [index_count]
+};
+
+int begin_host_call(mi_engine* e, const HostCall& h) {
+  const int T = h.T, n = e->n, N = e->N;
   if (T <= 0) return fail("tree_count must be positive");
-  if (!parent_ids || !bl) return fail("null tree arrays");
-  if (e->param_count > 0 && !params) return fail("null parameter matrix");
+  if (!h.parent_ids || !h.bl) return fail("null tree arrays");
+  if (e->param_count > 0 && !h.params) return fail("null parameter matrix");
   HIP_TRY(hipSetDevice(e->spec.device));
   e->pinned.reset();  // nothing of an earlier (possibly failed) call is delivered late
-  const int n = e->n;
-  const size_t np = rooted ? 2 * n - 2 : 2 * n - 3, nb = np + 1;
-  if (upload_staged(e, e->in_parent, parent_ids, (size_t)T * np)) return 1;
-  if (upload_staged(e, e->in_bl, bl, (size_t)T * nb)) return 1;
-  if (upload_staged(e, e->in_params, params, (size_t)T * e->param_count)) return 1;
+  const size_t np = h.rooted ? 2 * n - 2 : 2 * n - 3, nb = np + 1;
+  if (upload_staged(e, e->in_parent, h.parent_ids, (size_t)T * np)) return 1;
+  if (upload_staged(e, e->in_bl, h.bl, (size_t)T * nb)) return 1;
+  if (upload_staged(e, e->in_params, h.params, (size_t)T * e->param_count)) return 1;
+  const bool tt = h.rates && h.heights && h.bounds;
+  if (h.rooted && tt) {
+    if (upload_staged(e, e->in_rates, h.rates, (size_t)T * (N - 1))) return 1;
+    if (upload_staged(e, e->in_heights, h.heights, (size_t)T * N)) return 1;
+    if (upload_staged(e, e->in_bounds, h.bounds, (size_t)T * N)) return 1;
+  }
+  if (e->out_ll.ensure(sizeof(double) * T)) return 1;
+  const bool gtr = e->spec.subst_model == MI_SUBST_GTR;
+  if (!h.gradient) {
+    int rc;
+    if (!h.rooted)
+      rc = mi_engine_log_likelihoods_unrooted_device(
+          e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
+          e->in_params.as<double>(), h.rescaling, e->out_ll.as<double>());
+    else
+      rc = mi_engine_log_likelihoods_rooted_device(
+          e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
+          e->in_params.as<double>(), tt ? e->in_rates.as<double>() : nullptr,
+          tt ? e->in_heights.as<double>() : nullptr, tt ? e->in_bounds.as<double>() : nullptr,
+          h.with_jacobian, h.rescaling, e->out_ll.as<double>());
+    if (rc) return 1;
+    return download(e, h.out_ll, e->out_ll, T);
+  }
+  if (e->out_site.ensure(sizeof(double) * T)) return 1;
+  if (e->out_subst.ensure(sizeof(double) * (size_t)T * 8)) return 1;
+  if (!h.rooted) {
+    if (e->out_a.ensure(sizeof(double) * (size_t)T * N)) return 1;
+    if (h.reduced) {
+      if (upload_staged(e, e->in_index, h.branch_index, (size_t)T * N)) return 1;
+      if (h.tree_weights && upload_staged(e, e->in_weights, h.tree_weights, (size_t)T)) return 1;
+      if (e->out_reduced.ensure(sizeof(double) * (2 + (size_t)h.index_count))) return 1;
+      if (mi_engine_gradients_unrooted_reduced_device(
+              e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
+              e->in_params.as<double>(), h.rescaling, e->in_index.as<int32_t>(),
+              h.tree_weights ? e->in_weights.as<double>() : nullptr, h.index_count,
+              e->out_reduced.as<double>(), e->out_reduced.as<double>() + 2,
+              e->out_ll.as<double>()))
+        return 1;
+      if (download(e, h.out_sum, e->out_reduced, 2)) return 1;
+      if (h.index_count > 0) {
+        void* p = e->pinned.alloc(sizeof(double) * h.index_count, e->stream);
+        if (!p) return fail("pinned staging allocation failed");
+        HIP_TRY(hipMemcpyAsync(p, e->out_reduced.as<double>() + 2,
+                               sizeof(double) * h.index_count, hipMemcpyDeviceToHost, e->stream));
+        e->pinned.pending.push_back({h.out_index_grad, p, sizeof(double) * h.index_count});
+      }
+      return download(e, h.out_ll, e->out_ll, T);
+    }
+    if (mi_engine_gradients_unrooted_device(
+            e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
+            e->in_params.as<double>(), h.rescaling, e->out_ll.as<double>(),
+            e->out_a.as<double>(), h.out_site ? e->out_site.as<double>() : nullptr,
+            h.out_subst ? e->out_subst.as<double>() : nullptr))  // NULL outputs skip their work
+      return 1;
+    if (download(e, h.out_ll, e->out_ll, T)) return 1;
+    if (download(e, h.out_a, e->out_a, (size_t)T * N)) return 1;
+  } else {
+    for (int t = 0; t < T; t++)
+      if (h.rate_counts[t] != 1 && h.rate_counts[t] != N - 1)
+        return fail(status_message(kBadRateCount));
+    if (upload_staged(e, e->in_rate_counts, h.rate_counts, (size_t)T)) return 1;
+    if (upload_staged(e, e->in_ratios, h.ratios, (size_t)T * (n - 1))) return 1;
+    if (e->out_a.ensure(sizeof(double) * (size_t)T * (n - 1))) return 1;
+    if (e->out_b.ensure(sizeof(double) * (size_t)T * (N - 1))) return 1;
+    if (mi_engine_gradients_rooted_device(
+            e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
+            e->in_params.as<double>(), e->in_rates.as<double>(),
+            e->in_rate_counts.as<int32_t>(), e->in_heights.as<double>(),
+            e->in_bounds.as<double>(), e->in_ratios.as<double>(), h.rescaling,
+            e->out_ll.as<double>(), e->out_a.as<double>(), e->out_b.as<double>(),
+            h.out_site ? e->out_site.as<double>() : nullptr,
+            h.out_subst ? e->out_subst.as<double>() : nullptr))
+      return 1;
+    if (download(e, h.out_ll, e->out_ll, T)) return 1;
+    if (download(e, h.out_a, e->out_a, (size_t)T * (n - 1))) return 1;
+    if (download(e, h.out_b, e->out_b, (size_t)T * (N - 1))) return 1;
+  }
+  if (e->K > 1 && download(e, h.out_site, e->out_site, T)) return 1;
+  if (gtr && download(e, h.out_subst, e->out_subst, (size_t)T * 8)) return 1;
+  return 0;
+}
+
+// A sharded handle: trees dealt to the shards in contiguous blocks (what
+// FatBeagleParallelize's work queue does with thread_count FatBeagles,
+// fat_beagle.hpp:119-149), or -- few trees, very long alignments -- every shard evaluates
+// all trees on its own block of site patterns and the per-tree results, sums over
+// patterns every one of them, are added in shard order.
+int run_sharded(mi_engine* e, const HostCall& h) {
+  const int D = (int)e->shards.size(), T = h.T;
+  const int n = e->n, N = e->N;
+  if (T <= 0) return fail("tree_count must be positive");
+  if (e->shard_mode == MI_SHARD_TREES) {
+    std::vector<int> started;
+    int rc = 0;
+    for (int i = 0; i < D && !rc; i++) {
+      int32_t b = 0, c = 0;
+      mi_shard_range(T, D, i, &b, &c);
+      if (c == 0) continue;
+      HostCall s = h;
+      s.T = c;
+      const size_t np = h.rooted ? 2 * n - 2 : 2 * n - 3, nb = np + 1;
+      s.parent_ids = h.parent_ids + (size_t)b * np;
+      s.bl = h.bl + (size_t)b * nb;
+      if (h.params) s.params = h.params + (size_t)b * e->param_count;
+      if (h.rates) s.rates = h.rates + (size_t)b * (N - 1);
+      if (h.rate_counts) s.rate_counts = h.rate_counts + b;
+      if (h.heights) s.heights = h.heights + (size_t)b * N;
+      if (h.bounds) s.bounds = h.bounds + (size_t)b * N;
+      if (h.ratios) s.ratios = h.ratios + (size_t)b * (n - 1);
+      if (h.out_ll) s.out_ll = h.out_ll + b;
+      if (h.out_a) s.out_a = h.out_a + (size_t)b * (h.rooted ? n - 1 : N);
+      if (h.out_b) s.out_b = h.out_b + (size_t)b * (N - 1);
+      if (h.out_site) s.out_site = h.out_site + b;
+      if (h.out_subst) s.out_subst = h.out_subst + (size_t)b * 8;
+      if (h.reduced) {
+        s.branch_index = h.branch_index + (size_t)b * N;
+        if (h.tree_weights) s.tree_weights = h.tree_weights + b;
+        e->shard_sums.resize((size_t)D * (2 + h.index_count));
+        s.out_sum = e->shard_sums.data() + (size_t)i * (2 + h.index_count);
+        s.out_index_grad = s.out_sum + 2;
+      }
+      rc = begin_host_call(e->shards[i], s);
+      started.push_back(i);
+    }
+    for (int i : started) rc |= finish_host_call(e->shards[i]);
+    if (rc) return 1;
+    if (h.reduced) {  // partial sums added in shard order: deterministic
+      h.out_sum[0] = h.out_sum[1] = 0;
+      for (int k = 0; k < h.index_count; k++) h.out_index_grad[k] = 0;
+      for (int i : started) {
+        const double* s = e->shard_sums.data() + (size_t)i * (2 + h.index_count);
+        h.out_sum[0] += s[0];
+        h.out_sum[1] += s[1];
+        for (int k = 0; k < h.index_count; k++) h.out_index_grad[k] += s[2 + k];
+      }
+    }
+    return 0;
+  }
+  // pattern shards: only what is a plain sum over site patterns
+  if (h.rooted)
+    return fail("pattern-sharded engines evaluate unrooted calls only (the log-det-Jacobian "
+                "and the rooted chain rule are not sums over site patterns)");
+  const size_t per = (size_t)T * (1 + (h.gradient ? N + 1 + 8 : 0)) + 2 + h.index_count;
+  e->shard_sums.assign((size_t)D * per, 0.0);
+  int rc = 0, started = 0;
+  for (int i = 0; i < D && !rc; i++, started++) {
+    double* base = e->shard_sums.data() + (size_t)i * per;
+    HostCall s = h;
+    s.out_ll = base;
+    if (h.gradient) {
+      s.out_a = base + T;
+      s.out_site = h.out_site ? base + (size_t)T * (1 + N) : nullptr;
+      s.out_subst = h.out_subst ? base + (size_t)T * (2 + N) : nullptr;
+    }
+    if (h.reduced) {
+      s.out_sum = base + (size_t)T * (1 + (h.gradient ? N + 1 + 8 : 0));
+      s.out_index_grad = s.out_sum + 2;
+    }
+    rc = begin_host_call(e->shards[i], s);
+  }
+  for (int i = 0; i < started; i++) rc |= finish_host_call(e->shards[i]);
+  if (rc) return 1;
+  auto add = [&](double* out, size_t off, size_t count) {
+    if (!out) return;
+    for (size_t k = 0; k < count; k++) {
+      double sum = 0;
+      for (int i = 0; i < D; i++) sum += e->shard_sums[(size_t)i * per + off + k];
+      out[k] = sum;
+    }
+  };
+  add(h.out_ll, 0, T);
+  if (h.gradient) {
+    add(h.out_a, T, (size_t)T * N);
+    if (e->K > 1) add(h.out_site, (size_t)T * (1 + N), T);
+    if (e->spec.subst_model == MI_SUBST_GTR) add(h.out_subst, (size_t)T * (2 + N), (size_t)T * 8);
+  }
+  if (h.reduced) {
+    const size_t off = (size_t)T * (1 + (h.gradient ? N + 1 + 8 : 0));
+    add(h.out_sum, off, 2);
+    add(h.out_index_grad, off + 2, h.index_count);
+  }
+  return 0;
+}
+
+int run_host(mi_engine* e, const HostCall& h) {
+  if (!e) return fail("null engine");
+  if (!e->shards.empty()) return run_sharded(e, h);
+  if (begin_host_call(e, h)) {
+    e->pinned.reset();
+    return 1;
+  }
+  return finish_host_call(e);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mi_shard_range(int32_t total, int32_t shard_count, int32_t shard, int32_t* begin,
+                       int32_t* count) {
+  if (total < 0 || shard_count <= 0 || shard < 0 || shard >= shard_count)
+    return fail("mi_shard_range: bad arguments");
+  // sizes differ by at most one, the larger blocks first (libsbn_amd/sharding.py: tree_shard)
+  const int32_t base = total / shard_count, extra = total % shard_count;
+  if (begin) *begin = shard * base + (shard < extra ? shard : extra);
+  if (count) *count = base + (shard < extra ? 1 : 0);
   return 0;
 }
 
@@ -863,15 +1258,14 @@ int32_t mi_engine_log_likelihoods_unrooted(mi_engine* e, int32_t T, const int32_
                                            const double* bl, const double* params,
                                            int32_t rescaling, double* out_ll) {
   if (!out_ll) return fail("null output");
-  if (stage_common(e, T, false, parent_ids, bl, params)) return 1;
-  if (e->out_ll.ensure(sizeof(double) * T)) return 1;
-  if (mi_engine_log_likelihoods_unrooted_device(e, e->stream, T, e->in_parent.as<int32_t>(),
-                                                e->in_bl.as<double>(),
-                                                e->in_params.as<double>(), rescaling,
-                                                e->out_ll.as<double>()))
-    return 1;
-  if (download(e, out_ll, e->out_ll, T)) return 1;
-  return finish_host_call(e);
+  HostCall h;
+  h.T = T;
+  h.rescaling = rescaling;
+  h.parent_ids = parent_ids;
+  h.bl = bl;
+  h.params = params;
+  h.out_ll = out_ll;
+  return run_host(e, h);
 }
 
 int32_t mi_engine_gradients_unrooted(mi_engine* e, int32_t T, const int32_t* parent_ids,
@@ -879,25 +1273,43 @@ int32_t mi_engine_gradients_unrooted(mi_engine* e, int32_t T, const int32_t* par
                                      double* out_ll, double* out_branch, double* out_site,
                                      double* out_subst) {
   if (!out_ll || !out_branch) return fail("null output");
-  if (stage_common(e, T, false, parent_ids, bl, params)) return 1;
-  const int N = e->N;
-  if (e->out_ll.ensure(sizeof(double) * T)) return 1;
-  if (e->out_a.ensure(sizeof(double) * (size_t)T * N)) return 1;
-  if (e->out_site.ensure(sizeof(double) * T)) return 1;
-  if (e->out_subst.ensure(sizeof(double) * (size_t)T * 8)) return 1;
-  if (mi_engine_gradients_unrooted_device(
-          e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
-          e->in_params.as<double>(), rescaling, e->out_ll.as<double>(), e->out_a.as<double>(),
-          out_site ? e->out_site.as<double>() : nullptr,
-          out_subst ? e->out_subst.as<double>() : nullptr))  // NULL outputs skip their work
-    return 1;
-  if (download(e, out_ll, e->out_ll, T)) return 1;
-  if (download(e, out_branch, e->out_a, (size_t)T * N)) return 1;
-  if (e->K > 1 && download(e, out_site, e->out_site, T)) return 1;
-  if (e->spec.subst_model == MI_SUBST_GTR &&
-      download(e, out_subst, e->out_subst, (size_t)T * 8))
-    return 1;
-  return finish_host_call(e);
+  HostCall h;
+  h.gradient = true;
+  h.T = T;
+  h.rescaling = rescaling;
+  h.parent_ids = parent_ids;
+  h.bl = bl;
+  h.params = params;
+  h.out_ll = out_ll;
+  h.out_a = out_branch;
+  h.out_site = out_site;
+  h.out_subst = out_subst;
+  return run_host(e, h);
+}
+
+int32_t mi_engine_gradients_unrooted_reduced(mi_engine* e, int32_t T, const int32_t* parent_ids,
+                                             const double* bl, const double* params,
+                                             int32_t rescaling, const int32_t* branch_index,
+                                             const double* tree_weights, int32_t index_count,
+                                             double* out_sums, double* out_index_gradient,
+                                             double* out_ll) {
+  if (!out_sums || !branch_index || index_count < 0 || (index_count > 0 && !out_index_gradient))
+    return fail("null output / index");
+  HostCall h;
+  h.gradient = true;
+  h.reduced = true;
+  h.T = T;
+  h.rescaling = rescaling;
+  h.parent_ids = parent_ids;
+  h.bl = bl;
+  h.params = params;
+  h.branch_index = branch_index;
+  h.tree_weights = tree_weights;
+  h.index_count = index_count;
+  h.out_sum = out_sums;
+  h.out_index_grad = out_index_gradient;
+  h.out_ll = out_ll;
+  return run_host(e, h);
 }
 
 int32_t mi_engine_log_likelihoods_rooted(mi_engine* e, int32_t T, const int32_t* parent_ids,
@@ -906,23 +1318,19 @@ int32_t mi_engine_log_likelihoods_rooted(mi_engine* e, int32_t T, const int32_t*
                                          const double* bounds, int32_t with_jacobian,
                                          int32_t rescaling, double* out_ll) {
   if (!out_ll) return fail("null output");
-  if (stage_common(e, T, true, parent_ids, bl, params)) return 1;
-  const int N = e->N;
-  const bool tt = rates && heights && bounds;
-  if (tt) {
-    if (upload_staged(e, e->in_rates, rates, (size_t)T * (N - 1))) return 1;
-    if (upload_staged(e, e->in_heights, heights, (size_t)T * N)) return 1;
-    if (upload_staged(e, e->in_bounds, bounds, (size_t)T * N)) return 1;
-  }
-  if (e->out_ll.ensure(sizeof(double) * T)) return 1;
-  if (mi_engine_log_likelihoods_rooted_device(
-          e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
-          e->in_params.as<double>(), tt ? e->in_rates.as<double>() : nullptr,
-          tt ? e->in_heights.as<double>() : nullptr, tt ? e->in_bounds.as<double>() : nullptr,
-          with_jacobian, rescaling, e->out_ll.as<double>()))
-    return 1;
-  if (download(e, out_ll, e->out_ll, T)) return 1;
-  return finish_host_call(e);
+  HostCall h;
+  h.rooted = true;
+  h.T = T;
+  h.rescaling = rescaling;
+  h.with_jacobian = with_jacobian;
+  h.parent_ids = parent_ids;
+  h.bl = bl;
+  h.params = params;
+  h.rates = rates;
+  h.heights = heights;
+  h.bounds = bounds;
+  h.out_ll = out_ll;
+  return run_host(e, h);
 }
 
 int32_t mi_engine_gradients_rooted(mi_engine* e, int32_t T, const int32_t* parent_ids,
@@ -936,37 +1344,25 @@ int32_t mi_engine_gradients_rooted(mi_engine* e, int32_t T, const int32_t* paren
     return fail("Attempted access of a time tree member that requires the time tree to be "
                 "initialized. Have you set dates for your time trees, and initialized the "
                 "time trees?");
-  if (stage_common(e, T, true, parent_ids, bl, params)) return 1;
-  const int n = e->n, N = e->N;
-  for (int t = 0; t < T; t++)
-    if (rate_counts[t] != 1 && rate_counts[t] != N - 1) return fail(status_message(kBadRateCount));
-  if (upload_staged(e, e->in_rates, rates, (size_t)T * (N - 1))) return 1;
-  if (upload_staged(e, e->in_rate_counts, rate_counts, (size_t)T)) return 1;
-  if (upload_staged(e, e->in_heights, heights, (size_t)T * N)) return 1;
-  if (upload_staged(e, e->in_bounds, bounds, (size_t)T * N)) return 1;
-  if (upload_staged(e, e->in_ratios, ratios, (size_t)T * (n - 1))) return 1;
-  if (e->out_ll.ensure(sizeof(double) * T)) return 1;
-  if (e->out_a.ensure(sizeof(double) * (size_t)T * (n - 1))) return 1;
-  if (e->out_b.ensure(sizeof(double) * (size_t)T * (N - 1))) return 1;
-  if (e->out_site.ensure(sizeof(double) * T)) return 1;
-  if (e->out_subst.ensure(sizeof(double) * (size_t)T * 8)) return 1;
-  if (mi_engine_gradients_rooted_device(
-          e, e->stream, T, e->in_parent.as<int32_t>(), e->in_bl.as<double>(),
-          e->in_params.as<double>(), e->in_rates.as<double>(),
-          e->in_rate_counts.as<int32_t>(), e->in_heights.as<double>(),
-          e->in_bounds.as<double>(), e->in_ratios.as<double>(), rescaling,
-          e->out_ll.as<double>(), e->out_a.as<double>(), e->out_b.as<double>(),
-          out_site ? e->out_site.as<double>() : nullptr,
-          out_subst ? e->out_subst.as<double>() : nullptr))  // NULL outputs skip their work
-    return 1;
-  if (download(e, out_ll, e->out_ll, T)) return 1;
-  if (download(e, out_ratios, e->out_a, (size_t)T * (n - 1))) return 1;
-  if (download(e, out_clock, e->out_b, (size_t)T * (N - 1))) return 1;
-  if (e->K > 1 && download(e, out_site, e->out_site, T)) return 1;
-  if (e->spec.subst_model == MI_SUBST_GTR &&
-      download(e, out_subst, e->out_subst, (size_t)T * 8))
-    return 1;
-  return finish_host_call(e);
+  HostCall h;
+  h.gradient = true;
+  h.rooted = true;
+  h.T = T;
+  h.rescaling = rescaling;
+  h.parent_ids = parent_ids;
+  h.bl = bl;
+  h.params = params;
+  h.rates = rates;
+  h.rate_counts = rate_counts;
+  h.heights = heights;
+  h.bounds = bounds;
+  h.ratios = ratios;
+  h.out_ll = out_ll;
+  h.out_a = out_ratios;
+  h.out_b = out_clock;
+  h.out_site = out_site;
+  h.out_subst = out_subst;
+  return run_host(e, h);
 }
 
 }  // extern "C"

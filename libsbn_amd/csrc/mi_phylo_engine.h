@@ -140,6 +140,13 @@ struct mi_engine {
   bool allow_onchip_gradient = true;
   bool analytic_subst = false;       // MI_PHYLO_SUBST_GRADIENT=analytic (opt-in)
   int gradient_path = 0;  // 0 auto, 2 hbm, 3 mfma (MI_PHYLO_GRADIENT_PATH)
+  // a sharded handle (mi_engine_create_sharded): the per-device / per-shard engines it
+  // drives; such a handle owns no device memory itself
+  std::vector<mi_engine*> shards;
+  int shard_mode = 0;
+  std::vector<double> shard_sums;  // per-shard partial results (pattern shards, fused sums)
+  // fused reductions (mi_engine_gradients_unrooted_reduced*)
+  Buffer in_index, in_weights, out_reduced, red_ll, red_g, red_site;
   // staging for the host-pointer entry points
   Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
       in_ratios, out_ll, out_a, out_b, out_site, out_subst;

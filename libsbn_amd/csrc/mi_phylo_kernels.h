@@ -197,6 +197,21 @@ struct SubstGradArgs {
 };
 void launch_subst_gradient(const SubstGradArgs& a, hipStream_t s);
 constexpr int kSubstExtra = 68;
+// Reductions of a variational-inference step over the per-tree results of a gradient call:
+//   out_sums[0] = sum_t w_t logL_t, out_sums[1] = sum_t w_t site_gradient_t,
+//   out_index_gradient[k] = sum over (t, v) with branch_index[t][v] == k of w_t g[t][v]
+// (w_t = 1 without tree_weights; negative indices are skipped), every sum in (t, v) order.
+struct ViReduceArgs {
+  int T, N, index_count;
+  const double* ll;                // [T]
+  const double* branch;            // [T][N]
+  const double* site;              // [T] or nullptr
+  const int32_t* branch_index;     // [T][N]
+  const double* tree_weights;      // [T] or nullptr
+  double* out_sums;                // [2]
+  double* out_index_gradient;      // [index_count]
+};
+void launch_vi_reduce(const ViReduceArgs& a, hipStream_t s);
 bool reduce_tiles_fits(int N);
 void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s);
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);

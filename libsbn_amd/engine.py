@@ -71,12 +71,18 @@ class Engine:
     """One MI355X engine: tips + pattern weights resident in HBM."""
 
     def __init__(self, model_specification, patterns, weights, use_tip_states=True,
-                 device=-1, thread_count=1, tip_partials=None, reversible_model=None):
+                 device=-1, thread_count=1, tip_partials=None, reversible_model=None,
+                 shard_devices=None, shard_mode="trees"):
         """patterns: [taxon][pattern] compact states (SitePattern::GetPatterns), or None when
         tip_partials ([taxon][pattern][s], SitePattern::GetPartials) is given with
         use_tip_states=False.  Substitution "WAG" / "reversible" makes a 20-state engine
         (s = 20); reversible_model = (exchangeabilities[190], frequencies[20]) replaces the
-        built-in WAG table."""
+        built-in WAG table.  shard_devices (a list of HIP device ordinals, repeats allowed)
+        makes ONE handle that drives several devices / logical shards
+        (mi_engine_create_sharded): shard_mode "trees" deals the trees of a call in
+        contiguous blocks, "patterns" gives every shard a block of site patterns and adds
+        the per-tree results (unrooted calls).  Such a handle serves the numpy entry points;
+        the *_device ones need one engine per device."""
         if thread_count == 0:  # src/engine.cpp:14-16
             raise RuntimeError("Thread count needs to be strictly positive.")
         self._lib = _capi.load()
@@ -106,8 +112,16 @@ class Engine:
                                      site_kind, CLOCK[model_specification.clock],
                                      1 if use_tip_states else 0, device, 0)
         h = C.c_void_p()
-        if states == 20:
-            ex = fr = None
+        ex = fr = None
+        if shard_devices is not None:
+            if reversible_model is not None:
+                ex, fr = (_np(x, np.float64) for x in reversible_model)
+            devs = _np(shard_devices, np.int32)
+            mode = {"trees": 0, "patterns": 1}[shard_mode]
+            rc = self._lib.mi_engine_create_sharded(
+                C.byref(self.spec), len(devs), devs.ctypes.data_as(_capi.I32P), mode, _ptr(ex),
+                _ptr(fr), _ptr(patterns), _ptr(tip_partials), _ptr(weights), C.byref(h))
+        elif states == 20:
             if reversible_model is not None:
                 ex, fr = (_np(x, np.float64) for x in reversible_model)
                 if ex.shape != (190,) or fr.shape != (20,):
@@ -196,6 +210,26 @@ class Engine:
             self._h, T, _ptr(pid), _ptr(bl), _ptr(pr), int(rescaling), _ptr(ll), _ptr(g),
             _ptr(site), _ptr(subst)))
         return self._phylo_gradients(ll, {"branch_lengths": g}, site, subst)
+
+    def gradients_reduced(self, parent_ids, branch_lengths, params, branch_index, index_count,
+                          tree_weights=None, rescaling=False):
+        """One variational-inference step's reductions behind the gradient call
+        (mi_engine_gradients_unrooted_reduced; vip/burrito.py:143-166,
+        vip/branch_model.py:125-132): returns (sum_t w_t logL_t, sum_t w_t site gradient_t,
+        index_gradient[index_count] = scatter-add of the branch gradients by branch_index
+        (negative = skip), per-tree log-likelihoods)."""
+        n, N = self.taxon_count, self.node_count
+        pid = _np(parent_ids, np.int32).reshape(-1, 2 * n - 3)
+        T = pid.shape[0]
+        bl = _np(branch_lengths, np.float64).reshape(T, 2 * n - 2)
+        pr = self._params(params, T)
+        bi = _np(branch_index, np.int32).reshape(T, N)
+        tw = None if tree_weights is None else _np(tree_weights, np.float64).reshape(T)
+        sums, ig, ll = np.zeros(2), np.zeros(max(index_count, 1)), np.empty(T)
+        self._check(self._lib.mi_engine_gradients_unrooted_reduced(
+            self._h, T, _ptr(pid), _ptr(bl), _ptr(pr), int(rescaling), _ptr(bi), _ptr(tw),
+            int(index_count), _ptr(sums), _ptr(ig), _ptr(ll)))
+        return sums[0], sums[1], ig[:index_count], ll
 
     def _phylo_gradients(self, ll, blocks, site, subst):
         """Per-tree PhyloGradient objects over row views of the freshly allocated result

@@ -57,6 +57,39 @@ int main(int argc, char** argv) {
       }
     }
   }
+  {  // one handle, several shards (thread_count FatBeagles in the reference): trees dealt in
+     // contiguous blocks give bit-identical per-tree results; empty collections and trees
+     // on the wrong taxon count are handled as the reference does / refused
+    auto trees = TreeCollection::ParseNexusFile(data + "/DS1.subsampled_10.t");
+    SitePattern pattern(Alignment::ReadFasta(data + "/DS1.fasta"), trees.taxon_names_);
+    const PhyloModelSpecification weib{"JC69", "weibull+4", "strict"};
+    Engine one(EngineSpecification{1, {}, true}, weib, pattern);
+    Engine two(EngineSpecification{2, {}, true, {0, 0}}, weib, pattern);
+    Engine three(EngineSpecification{3, {}, true, {0, 0, 0}}, weib, pattern);
+    ParamMatrix params(trees.TreeCount(), one.ParameterCount());
+    params.SetBlock(0, 1, {0.8});
+    const auto a = one.Gradients(trees.trees_, params, false);
+    for (Engine* e : {&two, &three}) {
+      const auto b = e->Gradients(trees.trees_, params, false);
+      CHECK_LT(a.size() == b.size() ? 0 : 1, 1);
+      for (size_t i = 0; i < a.size() && i < b.size(); i++) {
+        CHECK_LT(a[i].log_likelihood_ == b[i].log_likelihood_ ? 0 : 1, 1);
+        CHECK_LT(a[i].gradient_.at("branch_lengths") == b[i].gradient_.at("branch_lengths") ? 0 : 1, 1);
+        CHECK_LT(a[i].gradient_.at("site_model") == b[i].gradient_.at("site_model") ? 0 : 1, 1);
+      }
+    }
+    CHECK_LT(one.LogLikelihoods(UnrootedTreeCollection{}, ParamMatrix(0, one.ParameterCount()), false).size(), 1);
+    CHECK_LT(two.Gradients(UnrootedTreeCollection{}, ParamMatrix(0, one.ParameterCount()), false).size(), 1);
+    bool threw = false;
+    try {
+      UnrootedTreeCollection bad(1, trees.trees_[0]);
+      bad[0].parent_ids.pop_back();
+      one.LogLikelihoods(bad, ParamMatrix(1, one.ParameterCount()), false);
+    } catch (const std::runtime_error&) {
+      threw = true;
+    }
+    CHECK_LT(threw ? 0 : 1, 1);
+  }
   {  // fluA rooted: log-likelihood with Jacobian, ratio gradient ends
     auto parsed = TreeCollection::ParseNewickFile(data + "/fluA.tree");
     SitePattern pattern(Alignment::ReadFasta(data + "/fluA.fa"), parsed.taxon_names_);

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in mi_phylo.h but not exported"
     assert sorted(_capi.SYMBOLS) == declared, "ctypes table out of sync with the header"
-    assert lib.mi_abi_version() == 1
+    assert lib.mi_abi_version() == 2
 
 
 def test_library_has_no_unresolved_internal_symbols():
@@ -64,3 +64,22 @@ def test_product_does_not_reference_the_oracle():
                 text = open(os.path.join(root, f), errors="ignore").read()
                 assert "liboracle" not in text and "oracle_lib" not in text and \
                     "phylo_oracle" not in text, f
+
+
+def test_shard_range_covers_every_unit_once():
+    """mi_shard_range (contiguous blocks of trees / site patterns over the shards of one
+    handle, and over ranks in libsbn_amd/sharding.py): pure host arithmetic."""
+    from libsbn_amd import _capi, sharding
+    lib = _capi.load()
+    b, c = ctypes.c_int32(), ctypes.c_int32()
+    for total in (0, 1, 7, 8, 9, 100, 1000, 50000):
+        for count in (1, 2, 3, 8, 16):
+            seen = 0
+            for s in range(count):
+                assert lib.mi_shard_range(total, count, s, ctypes.byref(b), ctypes.byref(c)) == 0
+                assert b.value == seen and 0 <= c.value <= total // count + 1
+                assert (b.value, b.value + c.value) == sharding.tree_shard(total, s, count)
+                seen += c.value
+            assert seen == total
+    assert lib.mi_shard_range(10, 0, 0, ctypes.byref(b), ctypes.byref(c)) != 0
+    assert lib.mi_device_count() >= 0

@@ -1,0 +1,164 @@
+"""One handle driving several shards (mi_engine_create_sharded; the counterpart of Engine's
+thread_count FatBeagles, src/engine.cpp:23-27), and the variational-inference reductions fused
+behind the gradient call (mi_engine_gradients_unrooted_reduced; vip/burrito.py:143-166,
+vip/branch_model.py:125-132).  The GPU box has one device, so the shards are logical shards
+of device 0: the dealing, staging and gathering are the same code."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import tree_utils as TU
+
+pytestmark = pytest.mark.gpu
+
+
+def _ds1(T, seed=5):
+    st = O.load_struct("ds1_top100")
+    tips, w, pids, _ = O.struct_arrays(st)
+    rng = np.random.default_rng(seed)
+    pids = pids[:T]
+    bls = rng.exponential(0.1, size=(T, pids.shape[1] + 1))
+    bls[:, -1] = 0
+    return tips, w, pids, bls, rng
+
+
+@pytest.mark.parametrize("shards,T", [(2, 11), (3, 7), (4, 3), (1, 5)])
+def test_tree_shards_are_bit_identical_to_one_engine(shards, T):
+    import libsbn_amd as L
+    tips, w, pids, bls, rng = _ds1(T)
+    spec = L.PhyloModelSpecification("GTR", "weibull+4", "strict")
+    r, f = TU.random_gtr_params(T, rng)
+    pr = np.hstack([r, f, np.full((T, 1), 0.7), np.ones((T, 1))])
+    one = L.Engine(spec, tips, w)
+    many = L.Engine(spec, tips, w, shard_devices=[0] * shards)
+    assert many.block_specification() == one.block_specification()
+    assert np.array_equal(many.log_likelihoods(pids, bls, pr), one.log_likelihoods(pids, bls, pr))
+    ga, gb = one.gradients(pids, bls, pr), many.gradients(pids, bls, pr)
+    for a, b in zip(ga, gb):
+        assert a.log_likelihood == b.log_likelihood and sorted(a.gradient) == sorted(b.gradient)
+        for k in a.gradient:
+            assert np.array_equal(a.gradient[k], b.gradient[k]), k
+    # per-tree errors still surface (second shard's tree)
+    bad = pr.copy()
+    bad[-1, 6:10] = 0.1
+    with pytest.raises(RuntimeError, match="frequencies"):
+        many.gradients(pids, bls, bad)
+    # the device-pointer entry points need a single-device engine
+    with pytest.raises(RuntimeError, match="single-device"):
+        many.log_likelihoods_device(None, T, 0, 0, 0, 0)
+
+
+def test_rooted_tree_shards():
+    import libsbn_amd as L
+    rng = np.random.default_rng(2)
+    n, P, T = 9, 40, 5
+    tips, w = TU.random_alignment(n, P, rng)
+    trees = [TU.clocklike_rooted_tree(n, rng) for _ in range(T)]
+    pids = np.stack([t[0] for t in trees])
+    bls = np.stack([t[1] for t in trees])
+    st = [O.time_tree_init(n, t[0], t[1], t[2]) for t in trees]
+    h, bd, ra = (np.stack([s[i] for s in st]) for i in range(3))
+    rates = np.full((T, 2 * n - 2), 0.5)
+    counts = np.ones(T, np.int32)
+    spec = L.PhyloModelSpecification("JC69", "weibull+4", "strict")
+    pr = np.ones((T, 2))
+    one, many = L.Engine(spec, tips, w), L.Engine(spec, tips, w, shard_devices=[0, 0, 0])
+    assert np.array_equal(one.rooted_log_likelihoods(pids, bls, pr, rates, h, bd),
+                          many.rooted_log_likelihoods(pids, bls, pr, rates, h, bd))
+    ga = one.rooted_gradients(pids, bls, pr, rates, counts, h, bd, ra)
+    gb = many.rooted_gradients(pids, bls, pr, rates, counts, h, bd, ra)
+    for a, b in zip(ga, gb):
+        for k in a.gradient:
+            assert np.array_equal(a.gradient[k], b.gradient[k]), k
+
+
+def test_pattern_shards_add_up():
+    import libsbn_amd as L
+    tips, w, pids, bls, rng = _ds1(4)
+    spec = L.PhyloModelSpecification("JC69", "weibull+4", "strict")
+    pr = np.ones((4, 2))
+    one = L.Engine(spec, tips, w)
+    many = L.Engine(spec, tips, w, shard_devices=[0, 0, 0], shard_mode="patterns")
+    a, b = one.log_likelihoods(pids, bls, pr), many.log_likelihoods(pids, bls, pr)
+    assert np.max(np.abs(a - b) / np.abs(a)) <= 1e-13
+    ga, gb = one.gradients(pids, bls, pr), many.gradients(pids, bls, pr)
+    for x, y in zip(ga, gb):
+        for k in x.gradient:
+            assert np.max(np.abs(x.gradient[k] - y.gradient[k])) <= 1e-11 * np.max(
+                np.abs(x.gradient[k])), k
+    with pytest.raises(RuntimeError, match="unrooted calls only"):
+        many.rooted_log_likelihoods(np.zeros((1, 52), np.int32), np.zeros((1, 53)), pr[:1],
+                                    with_jacobian=False)
+    # the 20-state engine, pattern-sharded (the 8-GPU form of BASELINE.json configs[4])
+    import aa_utils as A
+    rng = np.random.default_rng(4)
+    tips, w = A.random_aa_alignment(12, 300, rng)
+    p2, b2 = TU.random_trees(12, 2, rng)
+    pr2 = np.ones((2, 2))
+    s20 = L.PhyloModelSpecification("WAG", "weibull+4", "strict")
+    x = L.Engine(s20, tips, w).gradients(p2, b2, pr2)
+    y = L.Engine(s20, tips, w, shard_devices=[0, 0], shard_mode="patterns").gradients(p2, b2, pr2)
+    for u, v in zip(x, y):
+        assert abs(u.log_likelihood - v.log_likelihood) <= 1e-12 * abs(u.log_likelihood)
+        assert np.max(np.abs(u.gradient["branch_lengths"] - v.gradient["branch_lengths"])) <= \
+            1e-11 * np.max(np.abs(u.gradient["branch_lengths"]))
+
+
+@pytest.mark.parametrize("shards", [None, 3])
+def test_fused_vi_reductions_match_host_scatter_add_of_oracle_results(shards):
+    """HIP output vs the oracle's per-tree results scatter-added on the host the way
+    vip/branch_model.py:125-132 does (np.add.at by split index), incl. per-tree weights."""
+    import libsbn_amd as L
+    T = 24
+    tips, w, pids, bls, rng = _ds1(T, seed=9)
+    n, N = 27, 53
+    spec = L.PhyloModelSpecification("JC69", "weibull+4", "strict")
+    pr = np.ones((T, 2))
+    pr[:, 0] = rng.uniform(0.5, 1.5, T)
+    index_count = 300
+    bi = rng.integers(0, index_count, size=(T, N)).astype(np.int32)
+    bi[:, -2:] = -1          # the fixed node and the root are not parameters
+    bi[rng.random((T, N)) < 0.05] = -1
+    tw = rng.uniform(0.1, 2.0, T)
+    ospec = O.make_spec(n, 934, "JC69", "weibull+4")
+    og = O.unrooted_gradients(ospec, tips, w, pids, bls, pr, False, 4)
+    eng = L.Engine(spec, tips, w, shard_devices=None if shards is None else [0] * shards)
+    for weights in (None, tw):
+        wt = np.ones(T) if weights is None else weights
+        want = np.zeros(index_count)
+        for t in range(T):
+            ok = bi[t] >= 0
+            np.add.at(want, bi[t][ok], wt[t] * og["branch_lengths"][t][ok])
+        s_ll, s_site, ig, ll = eng.gradients_reduced(pids, bls, pr, bi, index_count, weights)
+        assert abs(s_ll - np.sum(wt * og["log_likelihood"])) <= 1e-10 * abs(s_ll)
+        assert abs(s_site - np.sum(wt * og["site_model"])) <= 1e-9 * abs(s_site)
+        assert np.max(np.abs(ig - want)) <= 1e-10 * np.max(np.abs(want))
+        assert np.max(np.abs(ll - og["log_likelihood"]) / np.abs(ll)) <= 1e-10
+    # reproducible bit for bit, and equal to the engine's own per-tree results reduced on the host
+    a = eng.gradients_reduced(pids, bls, pr, bi, index_count, tw)
+    b = eng.gradients_reduced(pids, bls, pr, bi, index_count, tw)
+    assert a[0] == b[0] and np.array_equal(a[2], b[2])
+
+
+def test_rooted_gradient_does_not_read_stale_lds():
+    """the LDS form of the rooted chain rule read the slot of a LEAF child before
+    anything had written it; residue of an earlier workgroup (NaN bit patterns) then
+    poisoned 0 * x.  Fill LDS with NaNs by an unrelated call pattern first: run the gradient
+    kernels of a rescaled call (int16 exponents / -1 words in LDS), then a rooted gradient."""
+    import libsbn_amd as L
+    rng = np.random.default_rng(31)
+    n, P = 12, 64
+    tips, w = TU.random_alignment(n, P, rng)
+    tree = TU.clocklike_rooted_tree(n, rng)
+    h, bd, ra = O.time_tree_init(n, tree[0], tree[1], tree[2])
+    spec = L.PhyloModelSpecification("JC69", "constant", "strict")
+    eng = L.Engine(spec, tips, w)
+    args = (tree[0][None], tree[1][None], np.ones((1, 1)), np.full((1, 2 * n - 2), 0.3),
+            np.ones(1, np.int32), h[None], bd[None], ra[None])
+    first = eng.rooted_gradients(*args)[0].gradient["ratios_root_height"]
+    # poison: NaN tip partials make every kernel that stages them leave NaNs in LDS
+    upids, ubls = TU.random_trees(n, 64, rng)
+    for _ in range(3):
+        eng.gradients(upids, ubls, np.ones((64, 1)), rescaling=True)
+        again = eng.rooted_gradients(*args)[0].gradient["ratios_root_height"]
+        assert np.all(np.isfinite(again)) and np.array_equal(again, first)

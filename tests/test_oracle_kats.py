@@ -9,6 +9,17 @@ import oracle_lib as O
 K = O.load_kats()
 
 
+@pytest.fixture(autouse=True, params=["unrolled_s4", "generic_s"])
+def _state_loops(request):
+    """Every known-answer test runs twice: with the compiler-unrolled s = 4 copy of the
+    oracle's sweeps and with the s-generic loops (orc_set_generic_states) -- the code path
+    the 20-state parity tests (tests/test_aa_gpu.py) rely on, which has no reference values
+    of its own (the reference is DNA-only)."""
+    O.set_generic_states(request.param == "generic_s")
+    yield
+    O.set_generic_states(False)
+
+
 def _params(spec, T, **blocks):
     pc = O.param_count(spec)
     lay = O.param_layout(spec)
@@ -267,3 +278,26 @@ def test_branch_gradient_matches_finite_difference_gtr_weibull():
     # site gradient is evaluated at the FD-perturbed substitution model (see
     # subst_gradient_fd); 1e-6 perturbation -> compare loosely
     assert abs(g["site_model"][0] - (f(bls, pp) - f(bls, pm)) / (2 * eps)) < 1e-4
+
+
+def test_reversible_model_at_four_states_is_gtr():
+    """The 'reversible' model (a table, no free parameters: what the 20-state engine uses)
+    goes through the reference's GTR recipe: at s = 4 with GTR's own rates and frequencies it
+    must give GTR's results exactly."""
+    rng = np.random.default_rng(12)
+    st = O.load_struct("ds1_sub10")
+    tips, w, pids, bls = O.struct_arrays(st)
+    pids, bls = pids[:3], bls[:3]
+    rates = rng.dirichlet(10 * np.ones(6))
+    freqs = rng.dirichlet(10 * np.ones(4))
+    gtr = O.make_spec(27, 934, "GTR", "weibull+4", "strict")
+    pr = _params(gtr, 3, **{"GTR rates": rates, "frequencies": freqs, "Weibull shape": 0.9})
+    a = O.unrooted_gradients(gtr, tips, w, pids, bls, pr, False, 2)
+    O.set_reversible_model(rates, freqs)
+    rev = O.make_spec(27, 934, "reversible", "weibull+4", "strict")
+    pr2 = np.ones((3, 2))
+    pr2[:, 0] = 0.9
+    b = O.unrooted_gradients(rev, tips, w, pids, bls, pr2, False, 2)
+    assert np.array_equal(a["log_likelihood"], b["log_likelihood"])
+    assert np.array_equal(a["branch_lengths"], b["branch_lengths"])
+    assert np.array_equal(a["site_model"], b["site_model"])

@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "mi_phylo_device_utils.h"
 #include "mi_phylo_kernels.h"
@@ -795,19 +796,25 @@ static unsigned aa_grid(int blocks, int units) {
   const long W = (long)blocks * units;
   return (unsigned)(8 * ((W + 7) / 8));
 }
+// MI_PHYLO_AA_LDS_PAD=<bytes>: extra dynamic LDS per wave, to study the walk kernels at lower
+// occupancy (results are unaffected)
+static size_t aa_lds_pad() {
+  static const size_t pad = getenv("MI_PHYLO_AA_LDS_PAD") ? strtoul(getenv("MI_PHYLO_AA_LDS_PAD"), nullptr, 10) : 0;
+  return pad;
+}
 void launch_aa_post(const AaWalkArgs& a, hipStream_t s) {
   const dim3 grid(aa_grid(a.tiles / kAaPostTiles, a.evals * a.K));
   if (a.gradient)
-    hipLaunchKernelGGL((aa_post_kernel<kAaPostTiles, true>), grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL((aa_post_kernel<kAaPostTiles, true>), grid, dim3(64), aa_lds_pad(), s, a);
   else
-    hipLaunchKernelGGL((aa_post_kernel<kAaPostTiles, false>), grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL((aa_post_kernel<kAaPostTiles, false>), grid, dim3(64), aa_lds_pad(), s, a);
 }
 void launch_aa_root(const AaWalkArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(aa_root_kernel, dim3(aa_ll_blocks(a.P), a.evals), dim3(256), 0, s, a);
 }
 void launch_aa_pre(const AaWalkArgs& a, hipStream_t s) {
   const dim3 grid(aa_grid(a.tiles / kAaPreTiles, a.evals * a.K));
-  hipLaunchKernelGGL((aa_pre_kernel<kAaPreTiles>), grid, dim3(64), 0, s, a);
+  hipLaunchKernelGGL((aa_pre_kernel<kAaPreTiles>), grid, dim3(64), aa_lds_pad(), s, a);
 }
 void launch_aa_reduce(const AaWalkArgs& a, hipStream_t s) {
   const int gx = a.gradient ? 1 + (a.N + 63) / 64 : 1;

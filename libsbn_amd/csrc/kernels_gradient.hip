@@ -1025,8 +1025,11 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool sub
     launch_gradient_mfma_store<false>(a, grid, lds, rescale, subst, s);
     return;
   }
-  // ablation builds: 1 no matrix products, 2 no cross-lane reductions,
-  // 8 no LDS vector traffic, 16 no matrix loads, 64 prologue only, 128 post-order only
+#ifdef MI_PHYLO_ABLATION
+  // Ablation variants -- kernels that return WRONG numbers by design, so they
+  // exist only in a library built with `make ablation` (-DMI_PHYLO_ABLATION), never in the
+  // product build: 1 no matrix products, 2 no cross-lane reductions, 8 no LDS vector
+  // traffic, 16 no matrix loads, 64 prologue only, 128 post-order only
   static const int dbg = getenv("MI_PHYLO_DEBUG") ? atoi(getenv("MI_PHYLO_DEBUG")) : 0;
   switch (dbg) {
     case 1: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 1>), grid, dim3(kTile), lds, s, a); return;
@@ -1038,6 +1041,7 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool sub
     case 128: hipLaunchKernelGGL((gradient_mfma_kernel<kLlR, 128>), grid, dim3(kTile), lds, s, a); return;
     default: break;
   }
+#endif
   launch_gradient_mfma_store<false>(a, grid, lds, false, false, s);
 }
 const char* gradient_kernel_name() { return "gradient_hbm_kernel"; }

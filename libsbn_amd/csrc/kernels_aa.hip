@@ -255,14 +255,12 @@ __device__ __forceinline__ void load_pack(const double* __restrict__ pack, int l
 }
 
 // compact states of a tip for this lane's pattern column of each tile (20 = gap / padding)
+// (rows of the tip-state matrix are padded with gaps to whole tiles: no bounds test)
 template <int M>
-__device__ __forceinline__ void load_tip_states(const int8_t* __restrict__ tips, int P, int p0,
-                                                int lane, int (&x)[M]) {
+__device__ __forceinline__ void load_tip_states(const int8_t* __restrict__ tips, int p0, int lane,
+                                                int (&x)[M]) {
 #pragma unroll
-  for (int u = 0; u < M; u++) {
-    const int p = p0 + u * 16 + (lane & 15);
-    x[u] = p < P ? tips[p] : kAa;
-  }
+  for (int u = 0; u < M; u++) x[u] = tips[p0 + u * 16 + (lane & 15)];
 }
 // product of a tip child: column `state` of the matrix (tables [21][20])
 template <int M>
@@ -363,9 +361,9 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
   const int el = un.ec / a.K, cat = un.ec - el * a.K, blk = un.blk;
   const int tree = a.eval_offset + el;
-  const int n = a.n, K = a.K, P = a.P;
+  const int n = a.n, K = a.K;
   const int p0 = blk * M * 16;
-  const size_t tiles = a.tiles;
+  const size_t tiles = a.tiles, tip_stride = tiles * 16;
   const int nodes = GRAD ? n - 1 : a.slots;
   double* arena = a.arena + (((size_t)el * nodes * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles;
   const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;  // per node / slot
@@ -378,21 +376,27 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
   SchedWindow win{a.sched + (size_t)tree * count, sched_lds, count, 0, lane};
   win.fill_from(0);
 
-  // stage 0 of visit k: tip states of its tip children
-  auto stage0 = [&](int k, int (&x)[2][M]) {
-    const SchedEntry se = win.at(k);
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-      const int ch = sgpr(c ? se.child1 : se.child0);
-      if (ch < n) load_tip_states<M>(a.tip_states + (size_t)ch * P, P, p0, lane, x[c]);
-    }
+  // stage 0 of a visit: tip states of its tip children (they address the table columns)
+  auto stage0 = [&](int c0, int c1, int (&x)[2][M]) {
+    if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
+    if (c1 < n) load_tip_states<M>(a.tip_states + (size_t)c1 * tip_stride, p0, lane, x[1]);
   };
   int xc[2][M], xn[2][M];
 #pragma unroll
   for (int c = 0; c < 2; c++)
 #pragma unroll
     for (int u = 0; u < M; u++) xc[c][u] = xn[c][u] = kAa;
-  stage0(0, xc);
+  // the current schedule entry lives in scalar registers; the next one is read (once) from
+  // the LDS window while this one computes
+  int v, ch0, ch1, slots;
+  {
+    const SchedEntry e0 = win.at(0);
+    v = sgpr(e0.node);
+    ch0 = sgpr(e0.child0);
+    ch1 = sgpr(e0.child1);
+    slots = sgpr(e0.slots);
+  }
+  stage0(ch0, ch1, xc);
 
   double R[M][5];
   int E[M];
@@ -404,21 +408,21 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
   }
   int prev = -1;
   for (int i = 0; i < count; i++) {
-    if (i + 1 >= win.base + kSchedWindow && i + 1 < count) win.fill_from(i);
-    const SchedEntry se = win.at(i);
-    const int v = sgpr(se.node), slots = sgpr(se.slots);
-    int next_c0 = -1, next_c1 = -1;
+    int nv = -1, next_c0 = -1, next_c1 = -1, nslots = 0;
     if (i + 1 < count) {
+      if (i + 1 >= win.base + kSchedWindow) win.fill_from(i + 1);
       const SchedEntry s1 = win.at(i + 1);
+      nv = sgpr(s1.node);
       next_c0 = sgpr(s1.child0);
       next_c1 = sgpr(s1.child1);
-      stage0(i + 1, xn);
+      nslots = sgpr(s1.slots);
+      stage0(next_c0, next_c1, xn);
     }
     double S[2][M][5];
     int Ec[2][M];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-      const int ch = sgpr(c ? se.child1 : se.child0);
+      const int ch = c ? ch1 : ch0;
       if (ch < n) {
         tip_gather<M>(tipP + (size_t)ch * K * kAaTipTable, xc[c], lane, S[c]);
 #pragma unroll
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
       }
       // exact power-of-two rescaling by the exponent of the column sum (all four lanes of
       // a column hold the same sum)
-      const int e = cs > 0.0 ? ilogb(cs) : 0;
+      const int e = cs > 0.0 ? __builtin_amdgcn_frexp_exp(cs) - 1 : 0;
 #pragma unroll
       for (int t = 0; t < 5; t++) R[u][t] = ldexp(R[u][t], -e);
       eloc[u] = e;
@@ -482,6 +486,10 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
       }
     }
     prev = v;
+    v = nv;
+    ch0 = next_c0;
+    ch1 = next_c1;
+    slots = nslots;
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll
@@ -570,9 +578,9 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
   const int el = un.ec / a.K, cat = un.ec - el * a.K, blk = un.blk;
   const int tree = a.eval_offset + el;
-  const int n = a.n, N = a.N, K = a.K, P = a.P;
+  const int n = a.n, N = a.N, K = a.K;
   const int p0 = blk * M * 16;
-  const size_t tiles = a.tiles;
+  const size_t tiles = a.tiles, tip_stride = tiles * 16;
   double* arena = a.arena + (((size_t)el * (n - 1) * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles;
   const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;
   const int32_t* exp_loc = a.exp_loc + ((size_t)el * (n - 1) * K + cat) * tiles * 16 + p0;
@@ -588,20 +596,23 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
   SchedWindow win{a.sched + (size_t)tree * count, sched_lds, count, 0, lane};
   win.fill_upto(count - 1);
 
-  auto stage0 = [&](int k, int (&x)[2][M]) {
-    const SchedEntry se = win.at(k);
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-      const int ch = sgpr(c ? se.child1 : se.child0);
-      if (ch < n) load_tip_states<M>(a.tip_states + (size_t)ch * P, P, p0, lane, x[c]);
-    }
+  auto stage0 = [&](int c0, int c1, int (&x)[2][M]) {
+    if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
+    if (c1 < n) load_tip_states<M>(a.tip_states + (size_t)c1 * tip_stride, p0, lane, x[1]);
   };
   int xc[2][M], xn[2][M];
 #pragma unroll
   for (int c = 0; c < 2; c++)
 #pragma unroll
     for (int u = 0; u < M; u++) xc[c][u] = xn[c][u] = kAa;
-  stage0(count - 1, xc);
+  int v, ch[2];
+  {
+    const SchedEntry e0 = win.at(count - 1);
+    v = sgpr(e0.node);
+    ch[0] = sgpr(e0.child0);
+    ch[1] = sgpr(e0.child1);
+  }
+  stage0(ch[0], ch[1], xc);
 
   // the node's pre-order vector: computed by the parent's visit and kept here when this
   // visit follows it immediately, else read back from the arena
@@ -612,14 +623,15 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
     for (int t = 0; t < 5; t++) q[u][t] = 0;
   int kept = -1;
   for (int i = count - 1; i >= 0; i--) {
-    if (i - 1 < win.base && win.base > 0) win.fill_upto(i);
-    const SchedEntry se = win.at(i);
-    const int v = sgpr(se.node);
-    const int next = i > 0 ? sgpr(win.at(i - 1).node) : -1;
-    int ch[2];
-    ch[0] = sgpr(se.child0);
-    ch[1] = sgpr(se.child1);
-    if (i > 0) stage0(i - 1, xn);
+    int next = -1, nc0 = -1, nc1 = -1;
+    if (i > 0) {
+      if (i - 1 < win.base) win.fill_upto(i - 1);
+      const SchedEntry s1 = win.at(i - 1);
+      next = sgpr(s1.node);
+      nc0 = sgpr(s1.child0);
+      nc1 = sgpr(s1.child1);
+      stage0(nc0, nc1, xn);
+    }
     if (i == count - 1) {
       const size_t rbase = ((size_t)el * K + cat) * tiles * 16 + p0;
 #pragma unroll
@@ -713,6 +725,9 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
       keep_next = ch[c];
     }
     kept = keep_next;
+    v = next;
+    ch[0] = nc0;
+    ch[1] = nc1;
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll
@@ -787,7 +802,7 @@ void launch_aa_transition(const AaTransitionArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(aa_transition_kernel, dim3(a.N - 1, a.K, a.evals), dim3(256), 0, s, a);
 }
 int aa_tiles(int P) {
-  const int per = std::max(kAaPostTiles, kAaPreTiles);
+  const int per = 4;  // every tile count a wave may take (2, 4) divides it
   const int tiles = (P + kAaTile - 1) / kAaTile;
   return (tiles + per - 1) / per * per;
 }
@@ -802,12 +817,28 @@ static size_t aa_lds_pad() {
   static const size_t pad = getenv("MI_PHYLO_AA_LDS_PAD") ? strtoul(getenv("MI_PHYLO_AA_LDS_PAD"), nullptr, 10) : 0;
   return pad;
 }
+// tiles a wave of the post-order kernel takes: the per-visit bookkeeping (schedule, addresses,
+// tip states) is what bounds the walk kernels, so a wave takes four tiles (two waves per
+// SIMD) unless that would leave SIMDs without work; MI_PHYLO_AA_POST_TILES overrides.
+static int aa_post_tiles(const AaWalkArgs& a) {
+  static const int forced = getenv("MI_PHYLO_AA_POST_TILES") ? atoi(getenv("MI_PHYLO_AA_POST_TILES")) : 0;
+  if (forced == 2 || forced == 4) return forced;
+  return (long)(a.tiles / 4) * a.evals * a.K >= 2048 ? 4 : 2;
+}
 void launch_aa_post(const AaWalkArgs& a, hipStream_t s) {
-  const dim3 grid(aa_grid(a.tiles / kAaPostTiles, a.evals * a.K));
+  const int m = aa_post_tiles(a);
+  const dim3 grid(aa_grid(a.tiles / m, a.evals * a.K));
+  if (m == 4) {
+    if (a.gradient)
+      hipLaunchKernelGGL((aa_post_kernel<4, true>), grid, dim3(64), aa_lds_pad(), s, a);
+    else
+      hipLaunchKernelGGL((aa_post_kernel<4, false>), grid, dim3(64), aa_lds_pad(), s, a);
+    return;
+  }
   if (a.gradient)
-    hipLaunchKernelGGL((aa_post_kernel<kAaPostTiles, true>), grid, dim3(64), aa_lds_pad(), s, a);
+    hipLaunchKernelGGL((aa_post_kernel<2, true>), grid, dim3(64), aa_lds_pad(), s, a);
   else
-    hipLaunchKernelGGL((aa_post_kernel<kAaPostTiles, false>), grid, dim3(64), aa_lds_pad(), s, a);
+    hipLaunchKernelGGL((aa_post_kernel<2, false>), grid, dim3(64), aa_lds_pad(), s, a);
 }
 void launch_aa_root(const AaWalkArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(aa_root_kernel, dim3(aa_ll_blocks(a.P), a.evals), dim3(256), 0, s, a);

@@ -618,7 +618,14 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
         }
       }
     }
-    if (upload(e->tip_states, st8.data(), np, e->stream)) return cleanup_fail(1);
+    {  // rows padded with gaps to whole 16-pattern tiles: the walk kernels read them unmasked
+      const size_t stride = (size_t)e->tiles * kAaTile;
+      std::vector<int8_t> padded((size_t)e->n * stride, (int8_t)states);
+      for (int x = 0; x < e->n; x++)
+        std::copy(st8.begin() + (size_t)x * e->P, st8.begin() + (size_t)(x + 1) * e->P,
+                  padded.begin() + (size_t)x * stride);
+      if (upload(e->tip_states, padded.data(), padded.size(), e->stream)) return cleanup_fail(1);
+    }
     if (aa_engine_init(e, exchangeabilities, frequencies)) return cleanup_fail(1);
   } else {
   if (upload(e->tip_states, st8.data(), np, e->stream)) return cleanup_fail(1);

@@ -225,8 +225,7 @@ constexpr int kAaTile = 16;          // site patterns per matrix-core tile
 constexpr int kAaTileDoubles = 320;  // one tile of one category: 5 registers x 64 lanes
 constexpr int kAaPack = 640;         // one 20x20 matrix as matrix-core A operands: 10 registers x 64 lanes
 constexpr int kAaTipTable = 21 * 20; // per tip edge and category: column of the matrix per state, 20 = gap
-constexpr int kAaPostTiles = 2;      // tiles a wave of the post-order kernel takes
-constexpr int kAaPreTiles = 2;       // ... of the pre-order kernel
+constexpr int kAaPreTiles = 2;       // tiles a wave of the pre-order kernel takes (post-order: 2 or 4)
 
 // The substitution model of a 20-state engine: one eigensystem per engine (an empirical
 // model has no free parameters); the per-tree part is the site model in DevModel.

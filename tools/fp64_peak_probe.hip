@@ -55,6 +55,55 @@ __global__ void __launch_bounds__(256) rate_kernel(double* out, Stamp* stamps, i
       c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
     }
     sink = c0.x + c1.y + c2.z + c3.w;
+  } else if constexpr (KIND == 4) {
+    // do f64 matrix and f64 vector instructions share a datapath?  Even waves issue only
+    // 4x4x4 MFMAs, odd waves only v_fma_f64 (one of each per SIMD at 2 waves/SIMD).
+    if ((threadIdx.x >> 6) & 1) {
+      double c0 = 0, c1 = 1, c2 = 2, c3 = 3, c4 = 4, c5 = 5, c6 = 6, c7 = 7;
+      const double m = 1.0 + 1e-9 * l;
+      for (int i = 0; i < iters; i++) {
+        c0 = fma(m, c0, b); c1 = fma(m, c1, b); c2 = fma(m, c2, b); c3 = fma(m, c3, b);
+        c4 = fma(m, c4, b); c5 = fma(m, c5, b); c6 = fma(m, c6, b); c7 = fma(m, c7, b);
+      }
+      sink = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    } else {
+      double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+      for (int i = 0; i < iters; i++) {
+        c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c3, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c4, 0, 0, 0);
+        c5 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c5, 0, 0, 0);
+        c6 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c6, 0, 0, 0);
+        c7 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c7, 0, 0, 0);
+      }
+      sink = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    }
+  } else if constexpr (KIND == 5) {
+    // same question for f64 MFMA beside 32-bit integer / f32 vector work
+    if ((threadIdx.x >> 6) & 1) {
+      float c0 = 0, c1 = 1, c2 = 2, c3 = 3, c4 = 4, c5 = 5, c6 = 6, c7 = 7;
+      const float m = 1.0f + 1e-6f * l, bb = (float)b;
+      for (int i = 0; i < iters; i++) {
+        c0 = fmaf(m, c0, bb); c1 = fmaf(m, c1, bb); c2 = fmaf(m, c2, bb); c3 = fmaf(m, c3, bb);
+        c4 = fmaf(m, c4, bb); c5 = fmaf(m, c5, bb); c6 = fmaf(m, c6, bb); c7 = fmaf(m, c7, bb);
+      }
+      sink = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    } else {
+      double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+      for (int i = 0; i < iters; i++) {
+        c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c3, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c4, 0, 0, 0);
+        c5 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c5, 0, 0, 0);
+        c6 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c6, 0, 0, 0);
+        c7 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c7, 0, 0, 0);
+      }
+      sink = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    }
   } else {  // the 20-state inner sequence: 5 k-steps of (16 rows) + 5 of (4 rows), two tiles
     double4v c0 = {0, 0, 0, 0}, c1 = c0;
     double d0 = 0, d1 = 0;
@@ -150,5 +199,10 @@ int main() {
   run<2>("mfma_f64_16x16x4", 1024, 4, out, stamps, iters / 2);
   // mixed: 10 x 16x16x4 + 10 x 4x4x4 per iteration = 12800 MAC over 20 instructions
   run<3>("20-state mix (5+5)x2", 640, 20, out, stamps, iters / 8);
+  // co-issue: half the waves MFMA f64 (256 MAC/instr), half vector (64 MAC/instr): the printed
+  // TFLOP/s uses the average 160 MAC per instruction; compare the TIME with the pure runs above
+  // at equal iterations (pure MFMA at 1 wave/SIMD + pure FMA at 1 wave/SIMD side by side)
+  run<4>("mfma_f64 || v_fma_f64", 160, 8, out, stamps, iters);
+  run<5>("mfma_f64 || v_fma_f32", 160, 8, out, stamps, iters);
   return 0;
 }

@@ -344,6 +344,13 @@ struct SchedWindow {
 // pre-order kernel; otherwise only vectors that are not consumed from registers are
 // written, into the schedule's slot (<= floor(log2 n) + 1 per evaluation).
 //
+// Stores are deferred: gfx9 counts loads and stores in ONE in-order counter (vmcnt), so a
+// wave that waits for the loads of visit i+1 also waits for the acknowledgement of every
+// store issued before them -- measured: the loads of the walk are hidden by the other waves,
+// the stores were not (removing them took 4 ms off a 19 ms gradient, their bandwidth time).
+// The result of visit i therefore stays in registers and is stored in visit i+1 AFTER that
+// visit's products have consumed (waited for) their loads: the stores then have a whole
+// visit to drain before the next wait.
 // Latency: a visit is ~0.3 us of matrix-core work behind ~1.5 us of memory latency, hidden by
 // occupancy (4-5 waves per SIMD), so the kernel is written for few registers and for ONE
 // memory round trip per visit: the schedule sits in LDS, and the tip states that address
@@ -406,7 +413,10 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
 #pragma unroll
     for (int t = 0; t < 5; t++) R[u][t] = 0;
   }
-  int prev = -1;
+  int prev = -1, prev_slots = 0;
+  int eloc[M];
+#pragma unroll
+  for (int u = 0; u < M; u++) eloc[u] = 0;
   for (int i = 0; i < count; i++) {
     int nv = -1, next_c0 = -1, next_c1 = -1, nslots = 0;
     if (i + 1 < count) {
@@ -446,45 +456,47 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
         mat_apply<M>(A, L, S[c]);
       }
     }
-    int eloc[M];
+    // (the product first: it consumes -- waits for -- everything this visit loaded)
+    double Tn[M][5];
+#pragma unroll
+    for (int u = 0; u < M; u++)
+#pragma unroll
+      for (int t = 0; t < 5; t++) Tn[u][t] = S[0][u][t] * S[1][u][t];
+    // the deferred stores of the previous visit (its vector is still in R)
+    if (prev >= 0) {
+      if (GRAD) {
+        store_tiles<M>(arena + (size_t)(prev - n) * arena_stride, lane, R);
+        if (g == 0) {
+#pragma unroll
+          for (int u = 0; u < M; u++) {
+            exp_loc[(size_t)(prev - n) * exp_stride + u * 16 + j] = eloc[u];
+            exp_cum[(size_t)(prev - n) * exp_stride + u * 16 + j] = E[u];
+          }
+        }
+      } else if (prev != ch0 && prev != ch1) {
+        const int dst = prev_slots & 0xff;
+        store_tiles<M>(arena + dst * arena_stride, lane, R);
+        if (g == 0) {
+#pragma unroll
+          for (int u = 0; u < M; u++) exp_cum[dst * exp_stride + u * 16 + j] = E[u];
+        }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < M; u++) {
       double cs = 0;
 #pragma unroll
-      for (int t = 0; t < 5; t++) {
-        R[u][t] = S[0][u][t] * S[1][u][t];
-        cs = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, R[u][t], cs, 0, 0, 0);
-      }
+      for (int t = 0; t < 5; t++)
+        cs = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, Tn[u][t], cs, 0, 0, 0);
       // exact power-of-two rescaling by the exponent of the column sum (all four lanes of
       // a column hold the same sum)
       const int e = cs > 0.0 ? __builtin_amdgcn_frexp_exp(cs) - 1 : 0;
 #pragma unroll
-      for (int t = 0; t < 5; t++) R[u][t] = ldexp(R[u][t], -e);
+      for (int t = 0; t < 5; t++) R[u][t] = ldexp(Tn[u][t], -e);
       eloc[u] = e;
       E[u] = Ec[0][u] + Ec[1][u] + e;
     }
-    const bool is_root = i == count - 1;
-    const bool chained = v == next_c0 || v == next_c1;
-    if (GRAD) {
-      if (g == 0) {
-#pragma unroll
-        for (int u = 0; u < M; u++) exp_loc[(size_t)(v - n) * exp_stride + u * 16 + j] = eloc[u];
-      }
-      if (!is_root) {
-        store_tiles<M>(arena + (size_t)(v - n) * arena_stride, lane, R);
-        if (!chained && g == 0) {
-#pragma unroll
-          for (int u = 0; u < M; u++) exp_cum[(size_t)(v - n) * exp_stride + u * 16 + j] = E[u];
-        }
-      }
-    } else if (!is_root && !chained) {
-      const int dst = slots & 0xff;
-      store_tiles<M>(arena + dst * arena_stride, lane, R);
-      if (g == 0) {
-#pragma unroll
-        for (int u = 0; u < M; u++) exp_cum[dst * exp_stride + u * 16 + j] = E[u];
-      }
-    }
+    prev_slots = slots;
     prev = v;
     v = nv;
     ch0 = next_c0;
@@ -494,6 +506,10 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int u = 0; u < M; u++) xc[c][u] = xn[c][u];
+  }
+  if (GRAD && g == 0) {  // (the root's vector itself is not needed)
+#pragma unroll
+    for (int u = 0; u < M; u++) exp_loc[(size_t)(prev - n) * exp_stride + u * 16 + j] = eloc[u];
   }
   // root: sum_i pi_i L_root[i] per pattern (scaled) and its exponent
   double pi[5];

@@ -400,9 +400,10 @@ def also_workloads(torch, dev, L, steps):
             r = {"bound": "hbm", "achieved": b_model * Tw / (k_ms * 1e-3) / 1e9,
                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": b_model * Tw / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                 "traffic": (50.3e9 if grad else 8.2e9),
-                 "traffic_source": "profiles/r02_aa_pmc_*.csv (2 FETCH_SIZE + WRITE_SIZE, "
-                                   "separate passes), per tree; not this run",
+                 "traffic": (49.7e9 if grad else 7.8e9),
+                 "traffic_source": "profiles/r02_aa_pmc_{fetch,write}.csv, profiles/traffic.json "
+                                   "((2 FETCH_SIZE + WRITE_SIZE) x 1024, separate passes), per "
+                                   "tree; not this run",
                  "kernel": "aa_post_kernel + aa_root_kernel" + (" + aa_pre_kernel" if grad else ""),
                  "kernel_ms": k_ms,
                  "hbm_model_bytes_per_tree": b_model,
@@ -425,6 +426,96 @@ def also_workloads(torch, dev, L, steps):
     return out
 
 
+def swag_pattern_sharded(args, torch, dist, L, sharding, dev, rank, world, distributed):
+    """BASELINE.json configs[4] over several GPUs: few trees x a very long alignment.  Every
+    rank builds its engine from a contiguous block of site patterns
+    (sharding.pattern_shard), evaluates ALL trees on it, and ONE all-reduce sums the packed
+    per-tree results [logL | site gradient | branch gradient] -- every output of the
+    unrooted path is a sum over site patterns.  Strong scaling: the alignment is fixed."""
+    n, P, K, T = 512, 50000, 4, args.swag_trees
+    N = 2 * n - 1
+    rng = np.random.default_rng(47)
+    tips = rng.integers(0, 20, size=(n, P)).astype(np.int32)
+    w = np.ones(P)
+    pids = np.stack([random_unrooted_topology(n, rng) for _ in range(T)])
+    bls = rng.exponential(0.1, size=(T, 2 * n - 2))
+    bls[:, -1] = 0
+    lo, hi = sharding.pattern_shard(P, rank, world)
+    eng = L.Engine(L.PhyloModelSpecification("WAG", f"weibull+{K}", "strict"),
+                   np.ascontiguousarray(tips[:, lo:hi]), w[lo:hi], device=dev.index)
+    grad = args.mode == "gradient"
+    d_pid = torch.from_numpy(pids).to(dev)
+    d_bl = torch.from_numpy(bls).to(dev)
+    d_par = torch.ones((T, 2), dtype=torch.float64, device=dev)
+    blk = sharding.ResultBlocks(T, N, extra=1, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    eng.reserve(T, grad)
+
+    def step():
+        if grad:
+            eng.gradients_device(stream, T, d_pid.data_ptr(), d_bl.data_ptr(), d_par.data_ptr(),
+                                 blk.log_likelihoods.data_ptr(), blk.branch_gradients.data_ptr(),
+                                 blk.extras[0].data_ptr(), None)
+        else:
+            eng.log_likelihoods_device(stream, T, d_pid.data_ptr(), d_bl.data_ptr(),
+                                       d_par.data_ptr(), blk.log_likelihoods.data_ptr())
+        if distributed:
+            sharding.all_reduce_pattern_shards(blk.buffer)
+
+    steps, warmup = max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
+    for _ in range(warmup):
+        step()
+    eng.check_status(stream)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.profile_begin(steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms = float(np.mean(eng.profile_collect(steps)))
+    eng.check_status(stream)
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert bool(torch.isfinite(blk.buffer).all())
+    if rank != 0:
+        return None
+    plv = K * P * 20 * 8
+    b_model = ((10 * n - 14) if grad else 2 * (n - 1)) * plv + (12 if grad else 4) * n * P
+    ms = 1e3 * elapsed / steps
+    return {
+        "metric": "tree log-likelihoods+gradients/sec (batched)" if grad
+                  else "tree log-likelihoods/sec (batched)",
+        "value": T / (elapsed / steps), "unit": "trees/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic: uniform 20-state tips, random-join topologies (seed 47), branch "
+                "lengths Exp(mean 0.1), built-in WAG table",
+        "config": {"workload": f"S-WAG 20 states, {n} taxa x {P} patterns x {K} categories x {T} "
+                               f"trees, site patterns dealt to {world} GPU(s) "
+                               f"({hi - lo} on rank 0), one all_reduce per step, "
+                               + ("phylo_gradients" if grad else "log_likelihoods"),
+                   "taxa": n, "patterns": P, "categories": K, "trees": T,
+                   "parallelism": f"pattern-sharded x{world}, one all_reduce per step"
+                                  if distributed else "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": b_model * T / world / (k_ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": b_model * T / world / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": eng.last_call_info()[0], "kernel_ms": k_ms,
+                     "note": "SURVEY 8(d) PLV-streaming bytes of this rank's pattern block over "
+                             "the time of its walk kernels"},
+        "logL0": float(blk.log_likelihoods[0]),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -436,6 +527,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the other configurations (one-GPU runs only carry them)")
+    ap.add_argument("--workload", choices=["ds1", "swag"], default="ds1",
+                    help="ds1: the headline (trees dealt to the GPUs); swag: BASELINE.json "
+                         "configs[4], 20 states x 512 taxa x 50 000 patterns x 4 categories, "
+                         "site patterns dealt to the GPUs, one all-reduce per step")
+    ap.add_argument("--swag-trees", type=int, default=8)
     args = ap.parse_args()
 
     import torch
@@ -458,6 +554,18 @@ def main():
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.workload == "swag":
+        out = swag_pattern_sharded(args, torch, dist, L, sharding, dev, rank, world, distributed)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            sys.stdout.flush()
+            print(json.dumps(out), flush=True)
+        return
 
     grad = args.mode == "gradient"
     T_total = args.trees

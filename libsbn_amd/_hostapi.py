@@ -22,6 +22,7 @@ SYMBOLS = {
     "mih_node_count": (C.c_int32, [_V, C.c_int32]),
     "mih_copy_tree": (C.c_int32, [_V, C.c_int32, _V, _V]),
     "mih_site_pattern_from_fasta": (_V, [C.c_char_p, _V]),
+    "mih_site_pattern_from_fasta_protein": (_V, [C.c_char_p, _V]),
     "mih_site_pattern_free": (None, [_V]),
     "mih_pattern_count": (C.c_int32, [_V]),
     "mih_site_count": (C.c_int32, [_V]),
@@ -103,10 +104,12 @@ class TreeCollection:
     def of_newick_string(newick):
         return TreeCollection(load().mih_parse_newick_string(newick.encode()))
 
-    def site_pattern(self, fasta_path):
-        """SitePattern(alignment, tag_taxon_map): (patterns [n][P] int32, weights [P])."""
+    def site_pattern(self, fasta_path, protein=False):
+        """SitePattern(alignment, tag_taxon_map): (patterns [n][P] int32, weights [P], sites).
+        protein: amino-acid alphabet ARNDCQEGHILKMFPSTWYV -> 0..19, gaps / ambiguity -> 20."""
         lib = load()
-        h = lib.mih_site_pattern_from_fasta(fasta_path.encode(), self._handle)
+        make = lib.mih_site_pattern_from_fasta_protein if protein else lib.mih_site_pattern_from_fasta
+        h = make(fasta_path.encode(), self._handle)
         if not h:
             raise _err()
         try:

@@ -85,6 +85,23 @@ int SitePattern::SymbolCode(char c) {
   }
 }
 
+int SitePattern::AminoAcidCode(char c) {
+  static const char order[] = "ARNDCQEGHILKMFPSTWYV";
+  const char u = (c >= 'a' && c <= 'z') ? (char)(c - 'a' + 'A') : c;
+  for (int i = 0; i < 20; i++)
+    if (order[i] == u) return i;
+  switch (u) {  // gap, unknown, ambiguity codes, stop, rare residues: no information
+    case '-': case 'X': case '?': case 'B': case 'Z': case 'J': case '*': case '.':
+    case 'U': case 'O':
+      return 20;
+    default: {
+      char msg[50];
+      std::snprintf(msg, sizeof msg, "Symbol '%c' not known.", c);
+      Failwith(msg);
+    }
+  }
+}
+
 namespace {
 // The pattern order the reference exposes is the iteration order of a
 // std::unordered_map keyed by the column with this (boost hash_combine style) hash
@@ -100,7 +117,8 @@ struct ColumnHash {
 };
 }  // namespace
 
-SitePattern::SitePattern(const Alignment& alignment, const std::vector<std::string>& taxon_names) {
+SitePattern::SitePattern(const Alignment& alignment, const std::vector<std::string>& taxon_names,
+                         bool protein) {
   const size_t n = taxon_names.size();
   if (n != alignment.SequenceCount())
     Failwith("The number of taxa in the trees and in the alignment differ.");
@@ -110,7 +128,8 @@ SitePattern::SitePattern(const Alignment& alignment, const std::vector<std::stri
   std::unordered_map<std::vector<int>, double, ColumnHash> seen;
   std::vector<int> column(n);
   for (size_t pos = 0; pos < site_count_; pos++) {
-    for (size_t i = 0; i < n; i++) column[i] = SymbolCode((*rows[i])[pos]);
+    for (size_t i = 0; i < n; i++)
+      column[i] = protein ? AminoAcidCode((*rows[i])[pos]) : SymbolCode((*rows[i])[pos]);
     auto it = seen.find(column);
     if (it == seen.end()) seen.insert({column, 1.});
     else it->second += 1.;

@@ -44,7 +44,11 @@ class SitePattern {
  public:
   SitePattern() = default;
   // taxon_names[i] = name of leaf id i (the reference passes a tag->taxon map).
-  SitePattern(const Alignment& alignment, const std::vector<std::string>& taxon_names);
+  // protein = false: the reference's DNA symbol table (site_pattern.cpp:16-46);
+  // true: the 20 amino acids in the order ARNDCQEGHILKMFPSTWYV -> 0..19, gaps and ambiguity
+  // codes -> 20 (not in the reference: the alphabet of the 20-state engine).
+  SitePattern(const Alignment& alignment, const std::vector<std::string>& taxon_names,
+              bool protein = false);
   const std::vector<std::vector<int>>& GetPatterns() const { return patterns_; }
   const std::vector<double>& GetWeights() const { return weights_; }
   size_t PatternCount() const { return patterns_.empty() ? 0 : patterns_[0].size(); }
@@ -53,6 +57,7 @@ class SitePattern {
   // row-major [taxon][pattern] copy for the C ABI
   std::vector<int32_t> FlatPatterns() const;
   static int SymbolCode(char c);  // site_pattern.cpp:16-56
+  static int AminoAcidCode(char c);
 
  private:
   std::vector<std::vector<int>> patterns_;

@@ -69,6 +69,14 @@ mih_site_pattern* mih_site_pattern_from_fasta(const char* fasta, const mih_trees
       },
       (mih_site_pattern*)nullptr);
 }
+mih_site_pattern* mih_site_pattern_from_fasta_protein(const char* fasta, const mih_trees* t) {
+  return guarded(
+      [&]() {
+        return new mih_site_pattern{
+            SitePattern(Alignment::ReadFasta(fasta), t->collection.taxon_names_, true)};
+      },
+      (mih_site_pattern*)nullptr);
+}
 void mih_site_pattern_free(mih_site_pattern* p) { delete p; }
 int32_t mih_pattern_count(const mih_site_pattern* p) { return (int32_t)p->pattern.PatternCount(); }
 int32_t mih_site_count(const mih_site_pattern* p) { return (int32_t)p->pattern.SiteCount(); }

@@ -67,7 +67,9 @@ class _Instance:
         if self._fasta is None or self.tree_count() == 0:
             raise RuntimeError("Load an alignment and trees into your instance before "
                                "preparing for phylogenetic likelihood calculation.")
-        pats, w, _ = self.tree_collection.site_pattern(self._fasta)
+        # (a 20-state model reads the alignment with the amino-acid alphabet)
+        protein = model_specification.substitution in ("WAG", "reversible")
+        pats, w, _ = self.tree_collection.site_pattern(self._fasta, protein=protein)
         if self._engine is not None:
             self._engine.close()
         self._engine = Engine(model_specification, pats, w, use_tip_states=use_tip_states,

@@ -112,3 +112,26 @@ def test_instance_rejects_wrong_rooting():
     inst = L.unrooted_instance("charlie")
     with pytest.raises(RuntimeError, match="trifucation"):
         inst.read_newick_file(os.path.join(O.DATA, "fluA.tree"))
+
+
+def test_protein_alphabet(tmp_path):
+    """The 20-state engine's alphabet (not in the reference, whose SymbolVectorOf is
+    DNA-only: site_pattern.cpp:16-46): ARNDCQEGHILKMFPSTWYV -> 0..19, gaps / ambiguity -> 20,
+    anything else an error; patterns are compressed by the same code as DNA."""
+    from libsbn_amd import _hostapi as H
+    fa = tmp_path / "p.fasta"
+    fa.write_text(">a\nARNDCQEGHILKMFPSTWYV-AA\n>b\narndcqeghilkmfpstwyvXAA\n>c\nAAAAAAAAAAAAAAAAAAAA?AA\n")
+    tc = H.TreeCollection.of_newick_string("(a,b,c);")
+    pats, w, sites = tc.site_pattern(str(fa), protein=True)
+    assert sites == 23 and pats.shape[0] == 3
+    cols = {tuple(pats[:, j]): w[j] for j in range(pats.shape[1])}
+    assert cols[(0, 0, 0)] == 3.0                      # A A A three times
+    assert cols[(20, 20, 20)] == 1.0                   # - X ?
+    for k in range(1, 20):
+        assert cols[(k, k, 0)] == 1.0
+    assert w.sum() == 23
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">a\nA1\n>b\nAA\n>c\nAA\n")
+    import pytest
+    with pytest.raises(RuntimeError, match="not known"):
+        tc.site_pattern(str(bad), protein=True)

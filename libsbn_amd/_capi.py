@@ -77,6 +77,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: torch ships its own libamdhip64, libmi_phylo.so is linked
+    # against /opt/rocm's.  Whichever is loaded FIRST serves both (same SONAME); loaded the
+    # other way round, the second runtime finds no device ("No HIP GPUs are available" from
+    # torch, or "no HIP device available" from mi_engine_create).  The Python mirror is used
+    # next to torch (device tensors, torch.distributed), so when torch is installed it is
+    # loaded first; MI_PHYLO_NO_TORCH_PRELOAD=1 skips that for torch-free use.
+    import sys
+    if "torch" not in sys.modules and os.environ.get("MI_PHYLO_NO_TORCH_PRELOAD") != "1":
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "

@@ -722,11 +722,20 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
   }
   HIP_TRY(hipSetDevice(e->spec.device));
   if (e->s == kAa) return aa_reserve(e, tree_count, for_gradients != 0);
-  // the HBM arena is only reserved when a later call may need it (rescaling with the VALU
-  // kernel or real-valued tip partials still can: reserve() grows on demand then)
-  const bool onchip = e->allow_onchip_gradient && e->have_tip_masks &&
-                      gradient_mfma_fits(e->n, e->K, false);
-  return reserve(e, tree_count, for_gradients != 0, !onchip);
+  // Everything a later *_device call over `tree_count` trees can need -- with or without
+  // rescaling, with the engine's substitution-gradient setting --, so that such a call
+  // allocates nothing (it can then be captured in a hipGraph): the union of both rescaling
+  // settings' workspaces (the HBM arena when either of them cannot use an on-chip kernel).
+  const bool grad = for_gradients != 0;
+  const bool can_onchip = e->allow_onchip_gradient && e->have_tip_masks;
+  const bool onchip_plain = can_onchip && gradient_mfma_fits(e->n, e->K, false);
+  const bool onchip_rescaled = can_onchip && gradient_mfma_fits(e->n, e->K, true);
+  const bool analytic = e->analytic_subst && e->spec.subst_model == MI_SUBST_GTR;
+  if (reserve(e, tree_count, grad, !onchip_plain, analytic && onchip_plain)) return 1;
+  if (grad && onchip_plain != onchip_rescaled &&
+      reserve(e, tree_count, grad, !onchip_rescaled, analytic && onchip_rescaled))
+    return 1;
+  return 0;
 }
 
 int32_t mi_engine_check_status(mi_engine* e, void* stream) {

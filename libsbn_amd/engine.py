@@ -181,6 +181,8 @@ class Engine:
         n = self.taxon_count
         pid = _np(parent_ids, np.int32).reshape(-1, 2 * n - 3)
         T = pid.shape[0]
+        if T == 0:  # FatBeagleParallelize over an empty collection returns an empty vector
+            return np.empty(0)
         bl = _np(branch_lengths, np.float64).reshape(T, 2 * n - 2)
         pr = self._params(params, T)
         out = np.empty(T)
@@ -200,6 +202,8 @@ class Engine:
         n, N = self.taxon_count, self.node_count
         pid = _np(parent_ids, np.int32).reshape(-1, 2 * n - 3)
         T = pid.shape[0]
+        if T == 0:
+            return []
         bl = _np(branch_lengths, np.float64).reshape(T, 2 * n - 2)
         pr = self._params(params, T)
         ll, g = np.empty(T), np.empty((T, N))
@@ -257,6 +261,8 @@ class Engine:
         n, N = self.taxon_count, self.node_count
         pid = _np(parent_ids, np.int32).reshape(-1, N - 1)
         T = pid.shape[0]
+        if T == 0:
+            return np.empty(0)
         bl = _np(branch_lengths, np.float64).reshape(T, N)
         pr = self._params(params, T)
         r = None if rates is None else _np(rates, np.float64).reshape(T, N - 1)
@@ -274,6 +280,8 @@ class Engine:
         n, N = self.taxon_count, self.node_count
         pid = _np(parent_ids, np.int32).reshape(-1, N - 1)
         T = pid.shape[0]
+        if T == 0:
+            return []
         bl = _np(branch_lengths, np.float64).reshape(T, N)
         pr = self._params(params, T)
         r = _np(rates, np.float64).reshape(T, N - 1)

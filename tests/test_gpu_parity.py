@@ -836,3 +836,42 @@ def test_full_size_properties_ds1_1000_trees():
     og = O.unrooted_gradients(spec, tips, w, pids[idx], bls[idx], pr[idx], False, 4)
     for j, t in enumerate(idx):
         assert _close(gb[t], og["branch_lengths"][j])
+
+
+def test_full_size_gtr_weibull_1000_trees():
+    """BASELINE config 3 at its full size: DS1 x 1000 trees, GTR+weibull+4 with per-tree
+    parameters, full phylo_gradients (18 000 evaluations: main gradient pass, 16
+    finite-difference log-likelihood passes per tree, the perturbed-model site pass).
+    Oracle on a sample of the batch; the shorter calls deliver bit-identical blocks."""
+    rng = np.random.default_rng(45)
+    st = O.load_struct("ds1_top100")
+    tips, w, pids100, _ = O.struct_arrays(st)
+    T = 1000
+    pids = np.tile(pids100, (10, 1))
+    bls = rng.exponential(0.1, size=(T, 52))
+    bls[:, -1] = 0
+    eng = _engine("GTR", "weibull+4", "strict", tips, w)
+    spec = O.make_spec(27, 934, "GTR", "weibull+4")
+    r, f = TU.random_gtr_params(T, rng)
+    pr = _params(spec, T, **{"GTR rates": r, "frequencies": f,
+                              "Weibull shape": rng.uniform(0.5, 2.0, size=(T, 1))})
+    g = eng.gradients(pids, bls, pr)
+    assert eng.last_call_info() == ("gradient_mfma_kernel", 18 * T, 2 * T)
+    gll = np.array([x.log_likelihood for x in g])
+    gb = _grad_matrix(g, "branch_lengths")
+    assert np.all(np.isfinite(gb)) and np.all(gb[:, -2:] == 0)
+    assert np.all(np.abs(eng.log_likelihoods(pids, bls, pr) - gll) <= 1e-12 * np.abs(gll))
+    short = eng.gradients(pids, bls, pr, gradient_blocks=("branch_lengths",))
+    assert np.array_equal(_grad_matrix(short, "branch_lengths"), gb)
+    idx = np.sort(rng.choice(T, size=16, replace=False))
+    og = O.unrooted_gradients(spec, tips, w, pids[idx], bls[idx], pr[idx], False, 4)
+    assert np.all(np.abs(gll[idx] - og["log_likelihood"]) <= RTOL * np.abs(og["log_likelihood"]))
+    for j, t in enumerate(idx):
+        assert _close(gb[t], og["branch_lengths"][j])
+        # finite differences of FP64 log-likelihoods: the reference's own tolerance class
+        assert np.allclose(g[t].gradient["substitution_model"], og["substitution_model"][j],
+                           rtol=0, atol=1e-4 * max(1.0, np.max(np.abs(og["substitution_model"][j]))))
+        assert abs(g[t].gradient["site_model"][0] - og["site_model"][j]) <= \
+            1e-8 * max(1.0, abs(og["site_model"][j]))
+    assert eng.gradients(pids[:0], bls[:0], pr[:0]) == []
+    assert eng.log_likelihoods(pids[:0], bls[:0], pr[:0]).shape == (0,)

@@ -256,7 +256,8 @@ int32_t mi_engine_gradients_unrooted_reduced_device(
 /* Make sure the workspace for `tree_count` trees exists (so that a following
  * *_device call allocates nothing and can be captured in a hipGraph). */
 int32_t mi_engine_reserve(mi_engine* engine, int32_t tree_count, int32_t for_gradients);
-/* Synchronise `stream` and report the first per-tree error of the last call. */
+/* Synchronise `stream` and report the first per-tree error since the last check (the status
+ * word is sticky and cleared when an error is reported: calls themselves never clear it). */
 int32_t mi_engine_check_status(mi_engine* engine, void* stream);
 
 /* Introspection for the bench / profiles: name and launch count of the dominant

@@ -141,7 +141,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   if (reserve(e, d.T, d.gradient, !onchip, analytic)) return 1;
   const CallShape c = call_shape(e, d.T, d.gradient, analytic);
   const int n = e->n, N = e->N, T = d.T;
-  HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, s));
+  // (the status word is sticky: cleared when it is read, check_status -- not per call: one
+  // dispatch less on the small-batch path)
 
   TreeSetupArgs ts{};
   ts.n = n;
@@ -400,8 +401,11 @@ int check_status(mi_engine* e, hipStream_t s) {
   int32_t st[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(st, e->status.ptr, sizeof st, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (st[0] != 0)
+  if (st[0] != 0) {  // reported once: the first error since the last check
+    HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return fail(std::string(status_message(st[0])) + " (tree " + std::to_string(st[1]) + ")");
+  }
   return 0;
 }
 
@@ -592,6 +596,9 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   };
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     return cleanup_fail(fail("hipStreamCreate failed"));
+  if (e->status.ensure(sizeof(int32_t) * 2) ||
+      hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, e->stream) != hipSuccess)
+    return cleanup_fail(fail("status word allocation failed"));
   const size_t np = (size_t)e->n * e->P;
   std::vector<int8_t> st8(np, (int8_t)states);
   if (tip_states)

@@ -96,7 +96,6 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   if (e->param_count > 0 && !d.params) return fail("null parameter matrix");
   const int n = e->n, N = e->N, T = d.T;
   if (aa_reserve(e, T, d.gradient)) return 1;
-  HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, s));
 
   TreeSetupArgs ts{};
   ts.n = n;

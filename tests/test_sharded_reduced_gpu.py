@@ -162,3 +162,51 @@ def test_rooted_gradient_does_not_read_stale_lds():
         eng.gradients(upids, ubls, np.ones((64, 1)), rescaling=True)
         again = eng.rooted_gradients(*args)[0].gradient["ratios_root_height"]
         assert np.all(np.isfinite(again)) and np.array_equal(again, first)
+
+
+def test_device_call_replays_from_a_hip_graph():
+    """include/mi_phylo.h: after mi_engine_reserve a *_device call allocates nothing and can
+    be captured in a hipGraph.  Capture one gradient call (4 states) and one 20-state call,
+    change the inputs in place, replay: results equal the eager call's bit for bit."""
+    import torch
+    import libsbn_amd as L
+    import aa_utils as A
+    dev = torch.device("cuda", 0)
+    cases = []
+    tips, w, pids, bls, rng = _ds1(20)
+    cases.append((L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w),
+                  pids, bls, np.ones((20, 2))))
+    rng = np.random.default_rng(6)
+    tips, w = A.random_aa_alignment(10, 70, rng)
+    p2, b2 = TU.random_trees(10, 3, rng)
+    cases.append((L.Engine(L.PhyloModelSpecification("WAG", "weibull+4", "strict"), tips, w),
+                  p2, b2, np.ones((3, 2))))
+    for eng, pids, bls, pr in cases:
+        T, N = len(pids), eng.node_count
+        d_pid = torch.from_numpy(np.ascontiguousarray(pids)).to(dev)
+        d_bl = torch.from_numpy(np.ascontiguousarray(bls)).to(dev)
+        d_pr = torch.from_numpy(pr).to(dev)
+        ll = torch.zeros(T, dtype=torch.float64, device=dev)
+        g = torch.zeros((T, N), dtype=torch.float64, device=dev)
+        site = torch.zeros(T, dtype=torch.float64, device=dev)
+        eng.reserve(T, True)
+
+        def call(stream):
+            eng.gradients_device(stream, T, d_pid.data_ptr(), d_bl.data_ptr(), d_pr.data_ptr(),
+                                 ll.data_ptr(), g.data_ptr(), site.data_ptr(), None)
+        call(torch.cuda.current_stream().cuda_stream)  # warm-up outside the capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=torch.cuda.Stream()):
+            call(torch.cuda.current_stream().cuda_stream)
+        # new branch lengths in the captured buffers
+        bl2 = bls * rng.uniform(0.5, 1.5, size=bls.shape)
+        d_bl.copy_(torch.from_numpy(bl2))
+        ll.zero_(), g.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        eng.check_status(None)
+        got_ll, got_g = ll.cpu().numpy().copy(), g.cpu().numpy().copy()
+        want = eng.gradients(pids, bl2, pr)
+        assert np.array_equal(got_ll, np.array([x.log_likelihood for x in want]))
+        assert np.array_equal(got_g, np.stack([x.gradient["branch_lengths"] for x in want]))

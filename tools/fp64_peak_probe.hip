@@ -104,6 +104,49 @@ __global__ void __launch_bounds__(256) rate_kernel(double* out, Stamp* stamps, i
       }
       sink = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
     }
+  } else if constexpr (KIND == 6) {
+    // 16x16x4 with ONE accumulator chain (dependent issue) -- latency of the instruction
+    double4v c0 = {0, 0, 0, 0};
+    for (int i = 0; i < iters; i++) {
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+    }
+    sink = c0.x;
+  } else if constexpr (KIND == 7) {
+    // 16x16x4 alternating with 4x4x4, ONE chain each (what a one-tile-per-wave walk issues)
+    double4v c0 = {0, 0, 0, 0};
+    double d0 = 0;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, d0, 0, 0, 0);
+      }
+    }
+    sink = c0.x + d0;
+  } else if constexpr (KIND == 8) {
+    // even waves only 16x16x4, odd waves only 4x4x4: the arbiter interleaves the two kinds
+    if ((threadIdx.x >> 6) & 1) {
+      double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+      for (int i = 0; i < iters; i++) {
+        c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c3, 0, 0, 0);
+      }
+      sink = c0 + c1 + c2 + c3;
+    } else {
+      double4v c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+      for (int i = 0; i < iters; i++) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+      }
+      sink = c0.x + c1.y + c2.z + c3.w;
+    }
   } else {  // the 20-state inner sequence: 5 k-steps of (16 rows) + 5 of (4 rows), two tiles
     double4v c0 = {0, 0, 0, 0}, c1 = c0;
     double d0 = 0, d1 = 0;
@@ -202,6 +245,9 @@ int main() {
   // co-issue: half the waves MFMA f64 (256 MAC/instr), half vector (64 MAC/instr): the printed
   // TFLOP/s uses the average 160 MAC per instruction; compare the TIME with the pure runs above
   // at equal iterations (pure MFMA at 1 wave/SIMD + pure FMA at 1 wave/SIMD side by side)
+  run<6>("16x16x4, one chain", 1024, 4, out, stamps, iters / 4);
+  run<7>("16x16x4+4x4x4, one chain ea", 640, 8, out, stamps, iters / 4);
+  run<8>("16x16x4 waves || 4x4x4 waves", 640, 4, out, stamps, iters / 2);
   run<4>("mfma_f64 || v_fma_f64", 160, 8, out, stamps, iters);
   run<5>("mfma_f64 || v_fma_f32", 160, 8, out, stamps, iters);
   return 0;

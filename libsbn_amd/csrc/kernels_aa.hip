@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 
 #include "mi_phylo_device_utils.h"
 #include "mi_phylo_kernels.h"
@@ -531,6 +532,248 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
 }
 
 // ------------------------------------------------------------------------
+// Post-order, workgroup form: four waves = four consecutive pattern blocks of ONE
+// (evaluation, category) walk the tree in lock-step (one barrier per visit), and what they
+// all need -- the children's matrices as A operands (5 KB each) or, for a tip child, its
+// table of matrix columns (3.4 KB) -- is fetched from L2 ONCE per workgroup into LDS (the
+// "LDS-staged 20x20 state tiles" of the north star) while the previous visit computes:
+// global -> registers at the top of visit i, registers -> LDS at its end, barrier, visit i+1
+// reads A operands (ds_read_b64, lane-linear) and tip columns (LDS gather) from there.
+// Measured motivation: the per-visit time of the wave-per-block form grows with the number
+// of waves per CU (4.7 k -> 9 k cycles from 2 to 8 waves) while neither HBM nor the matrix
+// cores are busy -- the operand traffic L2 -> CU (packs + column gathers, about 25 KB per
+// visit and wave) is the shared resource; this form divides it by four.
+// ------------------------------------------------------------------------
+// waves per workgroup: four (two or more workgroups per CU overlap each other's barriers;
+// eight were measured: the same for log-likelihoods, 7 % slower for gradient calls)
+constexpr int kPostWaves = 4, kPostThreads = 64 * kPostWaves;
+constexpr int kPreWaves = 4, kPreThreads = 64 * kPreWaves;
+template <int M, bool GRAD>
+__global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs a) {
+  __shared__ SchedEntry sched_lds[kSchedWindow];
+  __shared__ double ops_lds[2][2][kAaPack];  // [buffer][child][640]: pack, or tip table (420)
+  const int blocks = a.tiles / M;
+  const int wgs = (blocks + kPostWaves - 1) / kPostWaves;  // workgroups per (evaluation, category)
+  const AaUnit un = aa_unit(wgs, a.evals * a.K);
+  if (!un.valid) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+  const int el = un.ec / a.K, cat = un.ec - el * a.K;
+  const int blk_raw = un.blk * kPostWaves + wave;
+  const bool active = blk_raw < blocks;         // (a padding wave joins the staging and barriers only)
+  const int blk = active ? blk_raw : blocks - 1;
+  const int tree = a.eval_offset + el;
+  const int n = a.n, K = a.K;
+  const int p0 = blk * M * 16;
+  const size_t tiles = a.tiles, tip_stride = tiles * 16;
+  const int nodes = GRAD ? n - 1 : a.slots;
+  double* arena = a.arena + (((size_t)el * nodes * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles;
+  const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;
+  int32_t* exp_cum = a.exp_cum + ((size_t)el * nodes * K + cat) * tiles * 16 + p0;
+  int32_t* exp_loc = GRAD ? a.exp_loc + ((size_t)el * (n - 1) * K + cat) * tiles * 16 + p0 : nullptr;
+  const size_t exp_stride = (size_t)K * tiles * 16;
+  const double* matP = a.matP + ((size_t)el * (n - 1) * K + cat) * kAaPack;
+  const double* tipP = a.tipP + ((size_t)el * n * K + cat) * kAaTipTable;
+  const int count = n - 1;
+  SchedWindow win{a.sched + (size_t)tree * count, sched_lds, count, 0, tid};
+  // (the window is filled by the whole workgroup: 256 threads, 256 entries)
+  auto fill = [&](int first) {
+    win.base = first;
+    __syncthreads();
+    if (tid < kSchedWindow && first + tid < count) sched_lds[tid] = win.sched[first + tid];
+    __syncthreads();
+  };
+  fill(0);
+
+  // staging of one visit's shared operands: this thread's three elements per child
+  struct Staged {
+    double v[2][(kAaPack + kPostThreads - 1) / kPostThreads];
+  };
+  auto stage_load = [&](int c0, int c1, Staged& st) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int ch = c ? c1 : c0;
+      const double* src = ch < n ? tipP + (size_t)ch * K * kAaTipTable
+                                 : matP + (size_t)(ch - n) * K * kAaPack;
+      const int size = ch < n ? kAaTipTable : kAaPack;
+#pragma unroll
+      for (int k = 0; k < (kAaPack + kPostThreads - 1) / kPostThreads; k++) {
+        const int idx = tid + kPostThreads * k;
+        st.v[c][k] = idx < size ? src[idx] : 0.0;
+      }
+    }
+  };
+  auto stage_store = [&](int buf, const Staged& st) {
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int k = 0; k < (kAaPack + kPostThreads - 1) / kPostThreads; k++) {
+        const int idx = tid + kPostThreads * k;
+        if (idx < kAaPack) ops_lds[buf][c][idx] = st.v[c][k];
+      }
+  };
+  auto stage0 = [&](int c0, int c1, int (&x)[2][M]) {
+    if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
+    if (c1 < n) load_tip_states<M>(a.tip_states + (size_t)c1 * tip_stride, p0, lane, x[1]);
+  };
+  int xc[2][M], xn[2][M];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int u = 0; u < M; u++) xc[c][u] = xn[c][u] = kAa;
+  int v, ch0, ch1, slots;
+  {
+    const SchedEntry e0 = win.at(0);
+    v = sgpr(e0.node);
+    ch0 = sgpr(e0.child0);
+    ch1 = sgpr(e0.child1);
+    slots = sgpr(e0.slots);
+  }
+  stage0(ch0, ch1, xc);
+  {
+    Staged st;
+    stage_load(ch0, ch1, st);
+    stage_store(0, st);
+  }
+  __syncthreads();
+
+  double R[M][5];
+  int E[M];
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    E[u] = 0;
+#pragma unroll
+    for (int t = 0; t < 5; t++) R[u][t] = 0;
+  }
+  int prev = -1, prev_slots = 0;
+  int eloc[M];
+#pragma unroll
+  for (int u = 0; u < M; u++) eloc[u] = 0;
+  for (int i = 0; i < count; i++) {
+    const int buf = i & 1;
+    int nv = -1, next_c0 = -1, next_c1 = -1, nslots = 0;
+    Staged st;
+    if (i + 1 < count) {
+      if (i + 1 >= win.base + kSchedWindow) fill(i + 1);
+      const SchedEntry s1 = win.at(i + 1);
+      nv = sgpr(s1.node);
+      next_c0 = sgpr(s1.child0);
+      next_c1 = sgpr(s1.child1);
+      nslots = sgpr(s1.slots);
+      stage_load(next_c0, next_c1, st);  // the next visit's shared operands: global -> registers
+      stage0(next_c0, next_c1, xn);
+    }
+    double S[2][M][5];
+    int Ec[2][M];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int ch = c ? ch1 : ch0;
+      const double* shared = ops_lds[buf][c];
+      if (ch < n) {
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+          Ec[c][u] = 0;
+          const double* col = shared + xc[c][u] * kAa + g;
+#pragma unroll
+          for (int t = 0; t < 5; t++) S[c][u][t] = col[4 * t];
+        }
+      } else {
+        double A[10], L[M][5];
+        if (ch == prev) {
+#pragma unroll
+          for (int u = 0; u < M; u++) {
+            Ec[c][u] = E[u];
+#pragma unroll
+            for (int t = 0; t < 5; t++) L[u][t] = R[u][t];
+          }
+        } else {
+          const int idx = GRAD ? ch - n : ((slots >> (8 + 8 * c)) & 0xff);
+          load_tiles<M>(arena + idx * arena_stride, lane, L);
+#pragma unroll
+          for (int u = 0; u < M; u++) Ec[c][u] = exp_cum[idx * exp_stride + u * 16 + j];
+        }
+#pragma unroll
+        for (int r = 0; r < 10; r++) A[r] = shared[r * 64 + lane];
+        mat_apply<M>(A, L, S[c]);
+      }
+    }
+    // (the product first: it consumes -- waits for -- everything this visit loaded)
+    double Tn[M][5];
+#pragma unroll
+    for (int u = 0; u < M; u++)
+#pragma unroll
+      for (int t = 0; t < 5; t++) Tn[u][t] = S[0][u][t] * S[1][u][t];
+    // the deferred stores of the previous visit (its vector is still in R)
+    if (prev >= 0 && active) {
+      if (GRAD) {
+        store_tiles<M>(arena + (size_t)(prev - n) * arena_stride, lane, R);
+        if (g == 0) {
+#pragma unroll
+          for (int u = 0; u < M; u++) {
+            exp_loc[(size_t)(prev - n) * exp_stride + u * 16 + j] = eloc[u];
+            exp_cum[(size_t)(prev - n) * exp_stride + u * 16 + j] = E[u];
+          }
+        }
+      } else if (prev != ch0 && prev != ch1) {
+        const int dst = prev_slots & 0xff;
+        store_tiles<M>(arena + dst * arena_stride, lane, R);
+        if (g == 0) {
+#pragma unroll
+          for (int u = 0; u < M; u++) exp_cum[dst * exp_stride + u * 16 + j] = E[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < M; u++) {
+      double cs = 0;
+#pragma unroll
+      for (int t = 0; t < 5; t++)
+        cs = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, Tn[u][t], cs, 0, 0, 0);
+      const int e = cs > 0.0 ? __builtin_amdgcn_frexp_exp(cs) - 1 : 0;
+#pragma unroll
+      for (int t = 0; t < 5; t++) R[u][t] = ldexp(Tn[u][t], -e);
+      eloc[u] = e;
+      E[u] = Ec[0][u] + Ec[1][u] + e;
+    }
+    prev_slots = slots;
+    // the next visit's shared operands: registers -> the other LDS buffer, then the barrier
+    // that also tells everyone this visit's buffer has been read
+    if (i + 1 < count) stage_store(buf ^ 1, st);
+    __syncthreads();
+    prev = v;
+    v = nv;
+    ch0 = next_c0;
+    ch1 = next_c1;
+    slots = nslots;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int u = 0; u < M; u++) xc[c][u] = xn[c][u];
+  }
+  if (!active) return;
+  if (GRAD && g == 0) {  // (the root's vector itself is not needed)
+#pragma unroll
+    for (int u = 0; u < M; u++) exp_loc[(size_t)(prev - n) * exp_stride + u * 16 + j] = eloc[u];
+  }
+  // root: sum_i pi_i L_root[i] per pattern (scaled) and its exponent
+  double pi[5];
+#pragma unroll
+  for (int t = 0; t < 5; t++) pi[t] = a.model->pi[4 * t + g];
+  const size_t rbase = ((size_t)el * K + cat) * tiles * 16 + p0;
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    double s = 0;
+#pragma unroll
+    for (int t = 0; t < 5; t++) s += pi[t] * R[u][t];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (g == 0) {
+      a.root_val[rbase + u * 16 + j] = s;
+      a.root_exp[rbase + u * 16 + j] = E[u];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
 // Root: the categories meet (site likelihood), log-likelihood partial sums, and the weight
 // the root's pre-order vector carries: w_p cw_k 2^(E_k - Emax) / site_p  (the pre-order
 // recursion is linear, so every edge derivative is then a plain sum over patterns).
@@ -752,6 +995,252 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
 }
 
 // ------------------------------------------------------------------------
+// Pre-order + derivatives, workgroup form (see aa_post_wg_kernel): the three matrices of
+// an internal child (P, P Q, P^T: 15 KB) or the two column tables of a tip child are staged
+// in LDS once per workgroup of four pattern blocks, one visit ahead.
+// ------------------------------------------------------------------------
+constexpr int kPreOps = 3 * kAaPack;  // doubles per child in LDS: P | P Q | P^T  (tip: tipP | tipPQ)
+template <int M>
+__global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a) {
+  extern __shared__ double pre_lds[];  // [2][2][kPreOps] doubles, then the schedule window
+  double (*ops_lds)[2][kPreOps] = reinterpret_cast<double (*)[2][kPreOps]>(pre_lds);
+  SchedEntry* sched_lds = reinterpret_cast<SchedEntry*>(pre_lds + 2 * 2 * kPreOps);
+  const int blocks = a.tiles / M;
+  const int wgs = (blocks + kPreWaves - 1) / kPreWaves;
+  const AaUnit un = aa_unit(wgs, a.evals * a.K);
+  if (!un.valid) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+  const int el = un.ec / a.K, cat = un.ec - el * a.K;
+  const int blk_raw = un.blk * kPreWaves + wave;
+  const bool active = blk_raw < blocks;
+  const int blk = active ? blk_raw : blocks - 1;
+  const int tree = a.eval_offset + el;
+  const int n = a.n, N = a.N, K = a.K;
+  const int p0 = blk * M * 16;
+  const size_t tiles = a.tiles, tip_stride = tiles * 16;
+  double* arena = a.arena + (((size_t)el * (n - 1) * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles;
+  const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;
+  const int32_t* exp_loc = a.exp_loc + ((size_t)el * (n - 1) * K + cat) * tiles * 16 + p0;
+  const size_t exp_stride = (size_t)K * tiles * 16;
+  const size_t mbase = ((size_t)el * (n - 1) * K + cat) * kAaPack;
+  const double* matP = a.matP + mbase;
+  const double* matPT = a.matPT + mbase;
+  const double* matPQ = a.matPQ + mbase;
+  const double* tipP = a.tipP + ((size_t)el * n * K + cat) * kAaTipTable;
+  const double* tipPQ = a.tipPQ + ((size_t)el * n * K + cat) * kAaTipTable;
+  double* gp = a.g_part + (((size_t)el * K + cat) * blocks + blk) * N;
+  const int count = n - 1;
+  SchedWindow win{a.sched + (size_t)tree * count, sched_lds, count, 0, tid};
+  auto fill_upto = [&](int last) {
+    win.base = last - kSchedWindow + 1;
+    if (win.base < 0) win.base = 0;
+    __syncthreads();
+    if (tid < kSchedWindow && win.base + tid < count) sched_lds[tid] = win.sched[win.base + tid];
+    __syncthreads();
+  };
+  fill_upto(count - 1);
+
+  constexpr int kPer = (kPreOps + kPreThreads - 1) / kPreThreads;  // staged elements per thread and child
+  struct Staged {
+    double v[2][kPer];
+  };
+  auto stage_load = [&](int c0, int c1, Staged& st) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int ch = c ? c1 : c0;
+      if (ch < n) {  // tipP at 0, tipPQ at kAaPack
+        const double* t0 = tipP + (size_t)ch * K * kAaTipTable;
+        const double* t1 = tipPQ + (size_t)ch * K * kAaTipTable;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+          const int idx = tid + kPreThreads * k;
+          double x = 0.0;
+          if (idx < kAaTipTable) x = t0[idx];
+          else if (idx >= kAaPack && idx < kAaPack + kAaTipTable) x = t1[idx - kAaPack];
+          st.v[c][k] = x;
+        }
+      } else {
+        const size_t off = (size_t)(ch - n) * K * kAaPack;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+          const int idx = tid + kPreThreads * k;
+          double x = 0.0;
+          if (idx < kAaPack) x = matP[off + idx];
+          else if (idx < 2 * kAaPack) x = matPQ[off + idx - kAaPack];
+          else if (idx < 3 * kAaPack) x = matPT[off + idx - 2 * kAaPack];
+          st.v[c][k] = x;
+        }
+      }
+    }
+  };
+  auto stage_store = [&](int buf, const Staged& st) {
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int k = 0; k < kPer; k++) {
+        const int idx = tid + kPreThreads * k;
+        if (idx < kPreOps) ops_lds[buf][c][idx] = st.v[c][k];
+      }
+  };
+  auto stage0 = [&](int c0, int c1, int (&x)[2][M]) {
+    if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
+    if (c1 < n) load_tip_states<M>(a.tip_states + (size_t)c1 * tip_stride, p0, lane, x[1]);
+  };
+  auto lds_pack = [&](const double* base, double (&A)[10]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) A[r] = base[r * 64 + lane];
+  };
+  auto lds_cols = [&](const double* table, const int (&x)[M], double (&S)[M][5]) {
+#pragma unroll
+    for (int u = 0; u < M; u++) {
+      const double* col = table + x[u] * kAa + g;
+#pragma unroll
+      for (int t = 0; t < 5; t++) S[u][t] = col[4 * t];
+    }
+  };
+  int xc[2][M], xn[2][M];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int u = 0; u < M; u++) xc[c][u] = xn[c][u] = kAa;
+  int v, ch[2];
+  {
+    const SchedEntry e0 = win.at(count - 1);
+    v = sgpr(e0.node);
+    ch[0] = sgpr(e0.child0);
+    ch[1] = sgpr(e0.child1);
+  }
+  stage0(ch[0], ch[1], xc);
+  {
+    Staged st;
+    stage_load(ch[0], ch[1], st);
+    stage_store((count - 1) & 1, st);
+  }
+  __syncthreads();
+
+  double q[M][5];
+#pragma unroll
+  for (int u = 0; u < M; u++)
+#pragma unroll
+    for (int t = 0; t < 5; t++) q[u][t] = 0;
+  int kept = -1;
+  for (int i = count - 1; i >= 0; i--) {
+    const int buf = i & 1;
+    int next = -1, nc0 = -1, nc1 = -1;
+    Staged st;
+    if (i > 0) {
+      if (i - 1 < win.base) fill_upto(i - 1);
+      const SchedEntry s1 = win.at(i - 1);
+      next = sgpr(s1.node);
+      nc0 = sgpr(s1.child0);
+      nc1 = sgpr(s1.child1);
+      stage_load(nc0, nc1, st);
+      stage0(nc0, nc1, xn);
+    }
+    if (i == count - 1) {
+      const size_t rbase = ((size_t)el * K + cat) * tiles * 16 + p0;
+#pragma unroll
+      for (int u = 0; u < M; u++) {
+        const double rs = a.root_scale[rbase + u * 16 + j];
+#pragma unroll
+        for (int t = 0; t < 5; t++) q[u][t] = a.model->pi[4 * t + g] * rs;
+      }
+    } else if (kept != v) {
+      load_tiles<M>(arena + (size_t)(v - n) * arena_stride, lane, q);
+    }
+    double L[2][M][5];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+      if (ch[c] >= n) load_tiles<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, L[c]);
+#pragma unroll
+    for (int u = 0; u < M; u++) {
+      const int ev = exp_loc[(size_t)(v - n) * exp_stride + u * 16 + j];
+#pragma unroll
+      for (int t = 0; t < 5; t++) q[u][t] = ldexp(q[u][t], -ev);
+    }
+    // S[c] = P_c L_c (tip: column of P)
+    double S[2][M][5];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const double* shared = ops_lds[buf][c];
+      if (ch[c] < n) {
+        lds_cols(shared, xc[c], S[c]);
+      } else {
+        double A[10];
+        lds_pack(shared, A);
+        mat_apply<M>(A, L[c], S[c]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < M; u++)
+#pragma unroll
+      for (int t = 0; t < 5; t++) {
+        const double u0 = q[u][t] * S[1][u][t], u1 = q[u][t] * S[0][u][t];
+        S[1][u][t] = u0;
+        S[0][u][t] = u1;
+      }
+    double X[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const double* shared = ops_lds[buf][c] + kAaPack;  // P Q (tip: its column table)
+      double x = 0;
+      if (ch[c] < n) {
+        double D[M][5];
+        lds_cols(shared, xc[c], D);
+#pragma unroll
+        for (int u = 0; u < M; u++)
+#pragma unroll
+          for (int t = 0; t < 5; t++) x += S[1 - c][u][t] * D[u][t];
+      } else {
+        double A[10];
+        lds_pack(shared, A);
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+          double L1[1][5], D1[1][5];
+#pragma unroll
+          for (int t = 0; t < 5; t++) L1[0][t] = L[c][u][t];
+          mat_apply<1>(A, L1, D1);
+#pragma unroll
+          for (int t = 0; t < 5; t++) x += S[1 - c][u][t] * D1[0][t];
+        }
+      }
+      X[c] = wave_sum(x);
+    }
+    if (lane == 0 && active) {
+      gp[ch[0]] = X[0];
+      gp[ch[1]] = X[1];
+    }
+    int keep_next = -1;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      if (ch[c] < n || ch[c] == next) continue;
+      double A[10], qc[M][5];
+      lds_pack(ops_lds[buf][c] + 2 * kAaPack, A);
+      mat_apply<M>(A, S[1 - c], qc);
+      if (active) store_tiles<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, qc);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      if (ch[c] < n || ch[c] != next) continue;
+      double A[10];
+      lds_pack(ops_lds[buf][c] + 2 * kAaPack, A);
+      mat_apply<M>(A, S[1 - c], q);
+      keep_next = ch[c];
+    }
+    if (i > 0) stage_store(buf ^ 1, st);
+    __syncthreads();
+    kept = keep_next;
+    v = next;
+    ch[0] = nc0;
+    ch[1] = nc1;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int u = 0; u < M; u++) xc[c][u] = xn[c][u];
+  }
+}
+
+// ------------------------------------------------------------------------
 // Reduction: log-likelihood per evaluation; branch gradient sum_k r_k X_k and site-model
 // numerator sum_k (d r_k / d shape) X_k per edge, blocks summed in order (deterministic).
 // ------------------------------------------------------------------------
@@ -833,16 +1322,31 @@ static size_t aa_lds_pad() {
   static const size_t pad = getenv("MI_PHYLO_AA_LDS_PAD") ? strtoul(getenv("MI_PHYLO_AA_LDS_PAD"), nullptr, 10) : 0;
   return pad;
 }
-// tiles a wave of the post-order kernel takes: the per-visit bookkeeping (schedule, addresses,
-// tip states) is what bounds the walk kernels, so a wave takes four tiles (two waves per
-// SIMD) unless that would leave SIMDs without work; MI_PHYLO_AA_POST_TILES overrides.
-static int aa_post_tiles(const AaWalkArgs& a) {
+// tiles a wave of the post-order kernel takes: two (measured, workgroup form: 20.8 ms per 8
+// trees against 24.5 with four); MI_PHYLO_AA_POST_TILES=2|4 overrides.
+static int aa_post_tiles(const AaWalkArgs&) {
   static const int forced = getenv("MI_PHYLO_AA_POST_TILES") ? atoi(getenv("MI_PHYLO_AA_POST_TILES")) : 0;
-  if (forced == 2 || forced == 4) return forced;
-  return (long)(a.tiles / 4) * a.evals * a.K >= 2048 ? 4 : 2;
+  return forced == 4 ? 4 : 2;
+}
+// MI_PHYLO_AA_POST=wave selects the wave-per-block form of the post-order kernel
+static bool aa_post_wg() {
+  static const bool wg = !(getenv("MI_PHYLO_AA_POST") && std::string(getenv("MI_PHYLO_AA_POST")) == "wave");
+  return wg;
 }
 void launch_aa_post(const AaWalkArgs& a, hipStream_t s) {
   const int m = aa_post_tiles(a);
+  if (aa_post_wg()) {
+    const int blocks = a.tiles / m;
+    const dim3 grid(aa_grid((blocks + kPostWaves - 1) / kPostWaves, a.evals * a.K)), block(kPostThreads);
+    if (m == 4) {
+      if (a.gradient) hipLaunchKernelGGL((aa_post_wg_kernel<4, true>), grid, block, aa_lds_pad(), s, a);
+      else hipLaunchKernelGGL((aa_post_wg_kernel<4, false>), grid, block, aa_lds_pad(), s, a);
+    } else {
+      if (a.gradient) hipLaunchKernelGGL((aa_post_wg_kernel<2, true>), grid, block, aa_lds_pad(), s, a);
+      else hipLaunchKernelGGL((aa_post_wg_kernel<2, false>), grid, block, aa_lds_pad(), s, a);
+    }
+    return;
+  }
   const dim3 grid(aa_grid(a.tiles / m, a.evals * a.K));
   if (m == 4) {
     if (a.gradient)
@@ -860,6 +1364,15 @@ void launch_aa_root(const AaWalkArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(aa_root_kernel, dim3(aa_ll_blocks(a.P), a.evals), dim3(256), 0, s, a);
 }
 void launch_aa_pre(const AaWalkArgs& a, hipStream_t s) {
+  static const bool wg = !(getenv("MI_PHYLO_AA_PRE") && std::string(getenv("MI_PHYLO_AA_PRE")) == "wave");
+  if (wg) {
+    const int blocks = a.tiles / kAaPreTiles;
+    const dim3 grid(aa_grid((blocks + kPreWaves - 1) / kPreWaves, a.evals * a.K)), block(kPreThreads);
+    const size_t lds = sizeof(double) * 2 * 2 * kPreOps + sizeof(SchedEntry) * kSchedWindow + aa_lds_pad();
+    allow_large_lds(reinterpret_cast<const void*>(aa_pre_wg_kernel<kAaPreTiles>), lds);
+    hipLaunchKernelGGL((aa_pre_wg_kernel<kAaPreTiles>), grid, block, lds, s, a);
+    return;
+  }
   const dim3 grid(aa_grid(a.tiles / kAaPreTiles, a.evals * a.K));
   hipLaunchKernelGGL((aa_pre_kernel<kAaPreTiles>), grid, dim3(64), aa_lds_pad(), s, a);
 }

@@ -400,11 +400,11 @@ def also_workloads(torch, dev, L, steps):
             r = {"bound": "hbm", "achieved": b_model * Tw / (k_ms * 1e-3) / 1e9,
                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": b_model * Tw / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                 "traffic": (49.7e9 if grad else 7.8e9),
+                 "traffic": (49.4e9 if grad else 6.6e9),
                  "traffic_source": "profiles/r02_aa_pmc_{fetch,write}.csv, profiles/traffic.json "
                                    "((2 FETCH_SIZE + WRITE_SIZE) x 1024, separate passes), per "
                                    "tree; not this run",
-                 "kernel": "aa_post_kernel + aa_root_kernel" + (" + aa_pre_kernel" if grad else ""),
+                 "kernel": "aa_post_wg_kernel + aa_root_kernel" + (" + aa_pre_wg_kernel" if grad else ""),
                  "kernel_ms": k_ms,
                  "hbm_model_bytes_per_tree": b_model,
                  "survey_flops_TFLOPs": f_model * Tw / (k_ms * 1e-3) / 1e12,

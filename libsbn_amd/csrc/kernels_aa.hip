@@ -547,6 +547,49 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
 // waves per workgroup: four (two or more workgroups per CU overlap each other's barriers;
 // eight were measured: the same for log-likelihoods, 7 % slower for gradient calls)
 constexpr int kPostWaves = 4, kPostThreads = 64 * kPostWaves;
+
+// LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves 1 KB global -> LDS with no
+// register destination; the LDS destination is M0 (wave-uniform byte address) + 16 B x lane.
+// Issued from inline assembly on purpose: hipcc then neither tracks it in its own vmcnt
+// bookkeeping (which, with stores in flight, degrades every wait to vmcnt(0)) nor fences the
+// barrier with vmcnt(0).  The kernels wait for it themselves: ONE `s_waitcnt vmcnt(0)` per
+// visit, placed just before the visit's stores are issued -- everything older (the DMA from
+// the top of the visit, the previous visit's stores) has had most of a visit to finish -- so
+// the stores themselves stay in flight across the barrier.
+typedef __attribute__((address_space(3))) void* lds_ptr;
+__device__ __forceinline__ void dma_1k(const double* src_lane, double* dst_lds) {
+  const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)dst_lds;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(m0) : "memory");
+}
+// Piece k of a table (128 doubles) is issued by wave (first + k) % waves of the workgroup.
+__device__ __forceinline__ void dma_table(const double* __restrict__ src, double* dst_lds,
+                                          int pieces, int first, int wave, int waves, int lane) {
+  for (int k = 0; k < pieces; k++)
+    if ((first + k) % waves == wave) dma_1k(src + k * 128 + lane * 2, dst_lds + k * 128);
+}
+// Stores the compiler does not see (same reason: a store it knows to be in flight turns its
+// next wait for any load into vmcnt(0), i.e. into a wait for the store's acknowledgement).
+// Same-wave program order to the same address is kept by the memory pipeline; the kernels'
+// one vmcnt(0) per visit retires them a visit later.
+template <int M>
+__device__ __forceinline__ void store_tiles_async(double* dst, int lane, const double (&L)[M][5]) {
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    const double* p = dst + u * kAaTileDoubles + lane;
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+      asm volatile("global_store_dwordx2 %0, %1, off offset:%2" ::"v"(p), "v"(L[u][t]), "n"(t * 512) : "memory");
+  }
+}
+__device__ __forceinline__ void store_async(int32_t* p, int v) {
+  asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_async(double* p, double v) {
+  asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void wait_all_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// workgroup barrier that orders LDS traffic only (no vmcnt: stores stay in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int kPreWaves = 4, kPreThreads = 64 * kPreWaves;
 template <int M, bool GRAD>
 __global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs a) {
@@ -584,32 +627,19 @@ __global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs 
   };
   fill(0);
 
-  // staging of one visit's shared operands: this thread's three elements per child
-  struct Staged {
-    double v[2][(kAaPack + kPostThreads - 1) / kPostThreads];
-  };
-  auto stage_load = [&](int c0, int c1, Staged& st) {
+  // staging of one visit's shared operands into LDS buffer `buf` by LDS-DMA: a child's pack
+  // (5 pieces of 1 KB) or, for a tip, its column table (3 360 B: 4 pieces, the tail of the
+  // last one is the next table's head -- the arrays are padded by one piece)
+  const int wave_s = sgpr(wave);
+  auto stage = [&](int c0, int c1, int buf) {
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       const int ch = c ? c1 : c0;
-      const double* src = ch < n ? tipP + (size_t)ch * K * kAaTipTable
-                                 : matP + (size_t)(ch - n) * K * kAaPack;
-      const int size = ch < n ? kAaTipTable : kAaPack;
-#pragma unroll
-      for (int k = 0; k < (kAaPack + kPostThreads - 1) / kPostThreads; k++) {
-        const int idx = tid + kPostThreads * k;
-        st.v[c][k] = idx < size ? src[idx] : 0.0;
-      }
+      if (ch < n)
+        dma_table(tipP + (size_t)ch * K * kAaTipTable, ops_lds[buf][c], 4, 5 * c, wave_s, kPostWaves, lane);
+      else
+        dma_table(matP + (size_t)(ch - n) * K * kAaPack, ops_lds[buf][c], 5, 5 * c, wave_s, kPostWaves, lane);
     }
-  };
-  auto stage_store = [&](int buf, const Staged& st) {
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int k = 0; k < (kAaPack + kPostThreads - 1) / kPostThreads; k++) {
-        const int idx = tid + kPostThreads * k;
-        if (idx < kAaPack) ops_lds[buf][c][idx] = st.v[c][k];
-      }
   };
   auto stage0 = [&](int c0, int c1, int (&x)[2][M]) {
     if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
@@ -629,12 +659,9 @@ __global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs 
     slots = sgpr(e0.slots);
   }
   stage0(ch0, ch1, xc);
-  {
-    Staged st;
-    stage_load(ch0, ch1, st);
-    stage_store(0, st);
-  }
-  __syncthreads();
+  stage(ch0, ch1, 0);
+  wait_all_vm();
+  lds_barrier();
 
   double R[M][5];
   int E[M];
@@ -651,7 +678,6 @@ __global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs 
   for (int i = 0; i < count; i++) {
     const int buf = i & 1;
     int nv = -1, next_c0 = -1, next_c1 = -1, nslots = 0;
-    Staged st;
     if (i + 1 < count) {
       if (i + 1 >= win.base + kSchedWindow) fill(i + 1);
       const SchedEntry s1 = win.at(i + 1);
@@ -659,7 +685,7 @@ __global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs 
       next_c0 = sgpr(s1.child0);
       next_c1 = sgpr(s1.child1);
       nslots = sgpr(s1.slots);
-      stage_load(next_c0, next_c1, st);  // the next visit's shared operands: global -> registers
+      stage(next_c0, next_c1, buf ^ 1);  // the next visit's shared operands: global -> LDS
       stage0(next_c0, next_c1, xn);
     }
     double S[2][M][5];
@@ -702,23 +728,34 @@ __global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs 
     for (int u = 0; u < M; u++)
 #pragma unroll
       for (int t = 0; t < 5; t++) Tn[u][t] = S[0][u][t] * S[1][u][t];
-    // the deferred stores of the previous visit (its vector is still in R)
+    // the deferred stores of the previous visit (its vector is still in R); before them the
+    // visit's one wait for the DMA of the next visit's operands (the children's exponents are
+    // consumed here so that no later use makes the compiler wait after the stores)
+    int Es[M];
+#pragma unroll
+    for (int u = 0; u < M; u++) {
+      Es[u] = Ec[0][u] + Ec[1][u];
+      asm volatile("" : "+v"(Es[u]));
+      asm volatile("" : "+v"(xn[0][u]));  // (likewise the next visit's tip states)
+      asm volatile("" : "+v"(xn[1][u]));
+    }
+    wait_all_vm();
     if (prev >= 0 && active) {
       if (GRAD) {
-        store_tiles<M>(arena + (size_t)(prev - n) * arena_stride, lane, R);
+        store_tiles_async<M>(arena + (size_t)(prev - n) * arena_stride, lane, R);
         if (g == 0) {
 #pragma unroll
           for (int u = 0; u < M; u++) {
-            exp_loc[(size_t)(prev - n) * exp_stride + u * 16 + j] = eloc[u];
-            exp_cum[(size_t)(prev - n) * exp_stride + u * 16 + j] = E[u];
+            store_async(exp_loc + (size_t)(prev - n) * exp_stride + u * 16 + j, eloc[u]);
+            store_async(exp_cum + (size_t)(prev - n) * exp_stride + u * 16 + j, E[u]);
           }
         }
       } else if (prev != ch0 && prev != ch1) {
         const int dst = prev_slots & 0xff;
-        store_tiles<M>(arena + dst * arena_stride, lane, R);
+        store_tiles_async<M>(arena + dst * arena_stride, lane, R);
         if (g == 0) {
 #pragma unroll
-          for (int u = 0; u < M; u++) exp_cum[dst * exp_stride + u * 16 + j] = E[u];
+          for (int u = 0; u < M; u++) store_async(exp_cum + dst * exp_stride + u * 16 + j, E[u]);
         }
       }
     }
@@ -732,13 +769,12 @@ __global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs 
 #pragma unroll
       for (int t = 0; t < 5; t++) R[u][t] = ldexp(Tn[u][t], -e);
       eloc[u] = e;
-      E[u] = Ec[0][u] + Ec[1][u] + e;
+      E[u] = Es[u] + e;
     }
     prev_slots = slots;
-    // the next visit's shared operands: registers -> the other LDS buffer, then the barrier
-    // that also tells everyone this visit's buffer has been read
-    if (i + 1 < count) stage_store(buf ^ 1, st);
-    __syncthreads();
+    // the barrier publishes the other buffer (its DMA was waited for above) and tells
+    // everyone this visit's buffer has been read
+    lds_barrier();
     prev = v;
     v = nv;
     ch0 = next_c0;
@@ -1040,47 +1076,24 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
   };
   fill_upto(count - 1);
 
-  constexpr int kPer = (kPreOps + kPreThreads - 1) / kPreThreads;  // staged elements per thread and child
-  struct Staged {
-    double v[2][kPer];
-  };
-  auto stage_load = [&](int c0, int c1, Staged& st) {
+  // staging by LDS-DMA into buffer `buf`: internal child P | P Q | P^T (3 x 5 pieces), tip
+  // child its two column tables (2 x 4 pieces) at offsets 0 and kAaPack
+  const int wave_s = sgpr(wave);
+  auto stage = [&](int c0, int c1, int buf) {
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       const int ch = c ? c1 : c0;
-      if (ch < n) {  // tipP at 0, tipPQ at kAaPack
-        const double* t0 = tipP + (size_t)ch * K * kAaTipTable;
-        const double* t1 = tipPQ + (size_t)ch * K * kAaTipTable;
-#pragma unroll
-        for (int k = 0; k < kPer; k++) {
-          const int idx = tid + kPreThreads * k;
-          double x = 0.0;
-          if (idx < kAaTipTable) x = t0[idx];
-          else if (idx >= kAaPack && idx < kAaPack + kAaTipTable) x = t1[idx - kAaPack];
-          st.v[c][k] = x;
-        }
+      double* dst = ops_lds[buf][c];
+      if (ch < n) {
+        dma_table(tipP + (size_t)ch * K * kAaTipTable, dst, 4, 15 * c, wave_s, kPreWaves, lane);
+        dma_table(tipPQ + (size_t)ch * K * kAaTipTable, dst + kAaPack, 4, 15 * c + 4, wave_s, kPreWaves, lane);
       } else {
         const size_t off = (size_t)(ch - n) * K * kAaPack;
-#pragma unroll
-        for (int k = 0; k < kPer; k++) {
-          const int idx = tid + kPreThreads * k;
-          double x = 0.0;
-          if (idx < kAaPack) x = matP[off + idx];
-          else if (idx < 2 * kAaPack) x = matPQ[off + idx - kAaPack];
-          else if (idx < 3 * kAaPack) x = matPT[off + idx - 2 * kAaPack];
-          st.v[c][k] = x;
-        }
+        dma_table(matP + off, dst, 5, 15 * c, wave_s, kPreWaves, lane);
+        dma_table(matPQ + off, dst + kAaPack, 5, 15 * c + 5, wave_s, kPreWaves, lane);
+        dma_table(matPT + off, dst + 2 * kAaPack, 5, 15 * c + 10, wave_s, kPreWaves, lane);
       }
     }
-  };
-  auto stage_store = [&](int buf, const Staged& st) {
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int k = 0; k < kPer; k++) {
-        const int idx = tid + kPreThreads * k;
-        if (idx < kPreOps) ops_lds[buf][c][idx] = st.v[c][k];
-      }
   };
   auto stage0 = [&](int c0, int c1, int (&x)[2][M]) {
     if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
@@ -1111,12 +1124,9 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
     ch[1] = sgpr(e0.child1);
   }
   stage0(ch[0], ch[1], xc);
-  {
-    Staged st;
-    stage_load(ch[0], ch[1], st);
-    stage_store((count - 1) & 1, st);
-  }
-  __syncthreads();
+  stage(ch[0], ch[1], (count - 1) & 1);
+  wait_all_vm();
+  lds_barrier();
 
   double q[M][5];
 #pragma unroll
@@ -1127,14 +1137,13 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
   for (int i = count - 1; i >= 0; i--) {
     const int buf = i & 1;
     int next = -1, nc0 = -1, nc1 = -1;
-    Staged st;
     if (i > 0) {
       if (i - 1 < win.base) fill_upto(i - 1);
       const SchedEntry s1 = win.at(i - 1);
       next = sgpr(s1.node);
       nc0 = sgpr(s1.child0);
       nc1 = sgpr(s1.child1);
-      stage_load(nc0, nc1, st);
+      stage(nc0, nc1, buf ^ 1);
       stage0(nc0, nc1, xn);
     }
     if (i == count - 1) {
@@ -1206,9 +1215,10 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       }
       X[c] = wave_sum(x);
     }
+    wait_all_vm();  // (the DMA of the next visit's operands; the stores below stay in flight)
     if (lane == 0 && active) {
-      gp[ch[0]] = X[0];
-      gp[ch[1]] = X[1];
+      store_async(gp + ch[0], X[0]);
+      store_async(gp + ch[1], X[1]);
     }
     int keep_next = -1;
 #pragma unroll
@@ -1217,7 +1227,7 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       double A[10], qc[M][5];
       lds_pack(ops_lds[buf][c] + 2 * kAaPack, A);
       mat_apply<M>(A, S[1 - c], qc);
-      if (active) store_tiles<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, qc);
+      if (active) store_tiles_async<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, qc);
     }
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -1227,8 +1237,7 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       mat_apply<M>(A, S[1 - c], q);
       keep_next = ch[c];
     }
-    if (i > 0) stage_store(buf ^ 1, st);
-    __syncthreads();
+    lds_barrier();
     kept = keep_next;
     v = next;
     ch[0] = nc0;

@@ -75,14 +75,15 @@ int aa_reserve(mi_engine* e, int T, bool gradient) {
   const size_t nodes = gradient ? n - 1 : e->max_slots;
   if (e->aa_exp_cum.ensure(sizeof(int32_t) * chunk * nodes * K * tp)) return 1;
   if (e->aa_matP.ensure(sizeof(double) * chunk * (n - 1) * K * kAaPack)) return 1;
-  if (e->aa_tipP.ensure(sizeof(double) * chunk * n * K * kAaTipTable)) return 1;
+  // (+1 KB: the LDS-DMA of the last tip table reads a whole number of 1 KB pieces)
+  if (e->aa_tipP.ensure(sizeof(double) * (chunk * n * K * kAaTipTable + 128))) return 1;
   if (e->aa_root_val.ensure(sizeof(double) * chunk * K * tp)) return 1;
   if (e->aa_root_exp.ensure(sizeof(int32_t) * chunk * K * tp)) return 1;
   if (gradient) {
     if (e->aa_exp_loc.ensure(sizeof(int32_t) * chunk * (n - 1) * K * tp)) return 1;
     if (e->aa_matPT.ensure(sizeof(double) * chunk * (n - 1) * K * kAaPack)) return 1;
     if (e->aa_matPQ.ensure(sizeof(double) * chunk * (n - 1) * K * kAaPack)) return 1;
-    if (e->aa_tipPQ.ensure(sizeof(double) * chunk * n * K * kAaTipTable)) return 1;
+    if (e->aa_tipPQ.ensure(sizeof(double) * (chunk * n * K * kAaTipTable + 128))) return 1;
     if (e->aa_root_scale.ensure(sizeof(double) * chunk * K * tp)) return 1;
     if (e->g_part.ensure(sizeof(double) * chunk * K * (tiles / kAaPreTiles) * N)) return 1;
     if (e->g_sum.ensure(sizeof(double) * (size_t)T * 2 * N)) return 1;

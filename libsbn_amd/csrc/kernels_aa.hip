@@ -166,13 +166,21 @@ __global__ __launch_bounds__(64) void aa_model_setup_kernel(const double* exch,
     m->V[idx] = (1.0 / sq[i]) * U[idx];
     m->Vinv[idx] = U[j * kAa + i] * sq[j];
   }
+  for (int idx = lane; idx < kAaPack; idx += 64) {  // Q in the A-operand layout (below)
+    const int r = idx >> 6, l = idx & 63, g = l >> 4;
+    const int t = r < 5 ? r : r - 5;
+    const int row = r < 5 ? (l & 15) : 16 + (l & 3), col = 4 * t + g;
+    m->Qpack[idx] = Q[row * kAa + col];
+  }
 }
 
 // ------------------------------------------------------------------------
 // Transition matrices (beagleUpdateTransitionMatrices, fat_beagle.cpp:304-314), one
 // workgroup per (edge, category, evaluation): P = I + V expm1(L r t) V^-1 (the stable form
 // of V exp(L r t) V^-1, see kernels_setup.hip), negative entries clamped to 0 as BEAGLE
-// does; for a gradient call also P^T and P Q.  Internal edges are written as matrix-core
+// does; for a gradient call also P^T (internal edges) and the columns of P Q (tip edges; an
+// internal edge's derivative is taken as Q (P L) with the model's one Q operand: P and Q
+// commute, so no P Q per edge).  Internal edges are written as matrix-core
 // A operands:
 //   registers 0..4 (16x16x4, k-step t):  lane l holds M[l & 15][4t + (l >> 4)]
 //   registers 5..9 (4x4x4,   k-step t):  lane l holds M[16 + (l & 3)][4t + (l >> 4)]
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void aa_transition_kernel(AaTransitionArgs a) 
     Pm[idx] = sum > 0 ? sum : 0;
   }
   __syncthreads();
-  if (a.gradient) {
+  if (a.gradient && edge < a.n) {  // (tip edges only: columns of P Q; internal edges use Q (P L))
     for (int idx = tid; idx < kAa * kAa; idx += 256) {
       const int i = idx / kAa, j = idx % kAa;
       double sum = 0;
@@ -217,10 +225,7 @@ __global__ __launch_bounds__(256) void aa_transition_kernel(AaTransitionArgs a) 
       const int t = r < 5 ? r : r - 5;
       const int row = r < 5 ? (l & 15) : 16 + (l & 3), col = 4 * t + g;
       a.matP[base + idx] = Pm[row * kAa + col];
-      if (a.gradient) {
-        a.matPT[base + idx] = Pm[col * kAa + row];
-        a.matPQ[base + idx] = PQm[row * kAa + col];
-      }
+      if (a.gradient) a.matPT[base + idx] = Pm[col * kAa + row];
     }
   }
 }
@@ -883,7 +888,6 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
   const size_t mbase = ((size_t)el * (n - 1) * K + cat) * kAaPack;
   const double* matP = a.matP + mbase;
   const double* matPT = a.matPT + mbase;
-  const double* matPQ = a.matPQ + mbase;
   const double* tipP = a.tipP + ((size_t)el * n * K + cat) * kAaTipTable;
   const double* tipPQ = a.tipPQ + ((size_t)el * n * K + cat) * kAaTipTable;
   double* gp = a.g_part + (((size_t)el * K + cat) * blocks + blk) * N;
@@ -961,16 +965,8 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
         mat_apply<M>(A, L[c], S[c]);
       }
     }
-    // u_c = q o S[sibling] (q carries 2^-e), kept in S[sibling]
-#pragma unroll
-    for (int u = 0; u < M; u++)
-#pragma unroll
-      for (int t = 0; t < 5; t++) {
-        const double u0 = q[u][t] * S[1][u][t], u1 = q[u][t] * S[0][u][t];
-        S[1][u][t] = u0;
-        S[0][u][t] = u1;
-      }
-    // X_c = sum u_c . (P_c Q) L_c, the derivative products consumed tile by tile
+    // X_c = sum u_c . Q S_c with u_c = q o S[sibling] (q carries 2^-e); tip: the column of
+    // P Q; the derivative products consumed tile by tile
     double X[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -981,22 +977,31 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
 #pragma unroll
         for (int u = 0; u < M; u++)
 #pragma unroll
-          for (int t = 0; t < 5; t++) x += S[1 - c][u][t] * D[u][t];
+          for (int t = 0; t < 5; t++) x += (q[u][t] * S[1 - c][u][t]) * D[u][t];
       } else {
         double A[10];
-        load_pack(matPQ + (size_t)(ch[c] - n) * K * kAaPack, lane, A);
+        load_pack(a.model->Qpack, lane, A);
 #pragma unroll
         for (int u = 0; u < M; u++) {
-          double L1[1][5], D1[1][5];
+          double S1[1][5], D1[1][5];
 #pragma unroll
-          for (int t = 0; t < 5; t++) L1[0][t] = L[c][u][t];
-          mat_apply<1>(A, L1, D1);
+          for (int t = 0; t < 5; t++) S1[0][t] = S[c][u][t];
+          mat_apply<1>(A, S1, D1);
 #pragma unroll
-          for (int t = 0; t < 5; t++) x += S[1 - c][u][t] * D1[0][t];
+          for (int t = 0; t < 5; t++) x += (q[u][t] * S[1 - c][u][t]) * D1[0][t];
         }
       }
       X[c] = wave_sum(x);
     }
+    // u_c, kept in S[sibling]
+#pragma unroll
+    for (int u = 0; u < M; u++)
+#pragma unroll
+      for (int t = 0; t < 5; t++) {
+        const double u0 = q[u][t] * S[1][u][t], u1 = q[u][t] * S[0][u][t];
+        S[1][u][t] = u0;
+        S[0][u][t] = u1;
+      }
     if (lane == 0) {
       gp[ch[0]] = X[0];
       gp[ch[1]] = X[1];
@@ -1035,12 +1040,13 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
 // an internal child (P, P Q, P^T: 15 KB) or the two column tables of a tip child are staged
 // in LDS once per workgroup of four pattern blocks, one visit ahead.
 // ------------------------------------------------------------------------
-constexpr int kPreOps = 3 * kAaPack;  // doubles per child in LDS: P | P Q | P^T  (tip: tipP | tipPQ)
+constexpr int kPreOps = 2 * kAaPack;  // doubles per child in LDS: P | P^T  (tip: tipP | tipPQ)
 template <int M>
 __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a) {
-  extern __shared__ double pre_lds[];  // [2][2][kPreOps] doubles, then the schedule window
+  extern __shared__ double pre_lds[];  // [2][2][kPreOps] doubles, Q, then the schedule window
   double (*ops_lds)[2][kPreOps] = reinterpret_cast<double (*)[2][kPreOps]>(pre_lds);
-  SchedEntry* sched_lds = reinterpret_cast<SchedEntry*>(pre_lds + 2 * 2 * kPreOps);
+  double* q_lds = pre_lds + 2 * 2 * kPreOps;
+  SchedEntry* sched_lds = reinterpret_cast<SchedEntry*>(q_lds + kAaPack);
   const int blocks = a.tiles / M;
   const int wgs = (blocks + kPreWaves - 1) / kPreWaves;
   const AaUnit un = aa_unit(wgs, a.evals * a.K);
@@ -1061,11 +1067,11 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
   const size_t mbase = ((size_t)el * (n - 1) * K + cat) * kAaPack;
   const double* matP = a.matP + mbase;
   const double* matPT = a.matPT + mbase;
-  const double* matPQ = a.matPQ + mbase;
   const double* tipP = a.tipP + ((size_t)el * n * K + cat) * kAaTipTable;
   const double* tipPQ = a.tipPQ + ((size_t)el * n * K + cat) * kAaTipTable;
   double* gp = a.g_part + (((size_t)el * K + cat) * blocks + blk) * N;
   const int count = n - 1;
+  for (int idx = tid; idx < kAaPack; idx += kPreThreads) q_lds[idx] = a.model->Qpack[idx];
   SchedWindow win{a.sched + (size_t)tree * count, sched_lds, count, 0, tid};
   auto fill_upto = [&](int last) {
     win.base = last - kSchedWindow + 1;
@@ -1076,8 +1082,8 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
   };
   fill_upto(count - 1);
 
-  // staging by LDS-DMA into buffer `buf`: internal child P | P Q | P^T (3 x 5 pieces), tip
-  // child its two column tables (2 x 4 pieces) at offsets 0 and kAaPack
+  // staging by LDS-DMA into buffer `buf`: internal child P | P^T (2 x 5 pieces), tip child
+  // its two column tables (2 x 4 pieces) at offsets 0 and kAaPack
   const int wave_s = sgpr(wave);
   auto stage = [&](int c0, int c1, int buf) {
 #pragma unroll
@@ -1085,13 +1091,12 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       const int ch = c ? c1 : c0;
       double* dst = ops_lds[buf][c];
       if (ch < n) {
-        dma_table(tipP + (size_t)ch * K * kAaTipTable, dst, 4, 15 * c, wave_s, kPreWaves, lane);
-        dma_table(tipPQ + (size_t)ch * K * kAaTipTable, dst + kAaPack, 4, 15 * c + 4, wave_s, kPreWaves, lane);
+        dma_table(tipP + (size_t)ch * K * kAaTipTable, dst, 4, 10 * c, wave_s, kPreWaves, lane);
+        dma_table(tipPQ + (size_t)ch * K * kAaTipTable, dst + kAaPack, 4, 10 * c + 4, wave_s, kPreWaves, lane);
       } else {
         const size_t off = (size_t)(ch - n) * K * kAaPack;
-        dma_table(matP + off, dst, 5, 15 * c, wave_s, kPreWaves, lane);
-        dma_table(matPQ + off, dst + kAaPack, 5, 15 * c + 5, wave_s, kPreWaves, lane);
-        dma_table(matPT + off, dst + 2 * kAaPack, 5, 15 * c + 10, wave_s, kPreWaves, lane);
+        dma_table(matP + off, dst, 5, 10 * c, wave_s, kPreWaves, lane);
+        dma_table(matPT + off, dst + kAaPack, 5, 10 * c + 5, wave_s, kPreWaves, lane);
       }
     }
   };
@@ -1180,6 +1185,33 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
         mat_apply<M>(A, L[c], S[c]);
       }
     }
+    // X_c = sum (q o S[sibling]) . Q S_c (tip: the column of P Q), tile by tile
+    double X[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      double x = 0;
+      if (ch[c] < n) {
+        double D[M][5];
+        lds_cols(ops_lds[buf][c] + kAaPack, xc[c], D);
+#pragma unroll
+        for (int u = 0; u < M; u++)
+#pragma unroll
+          for (int t = 0; t < 5; t++) x += (q[u][t] * S[1 - c][u][t]) * D[u][t];
+      } else {
+        double A[10];
+        lds_pack(q_lds, A);
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+          double S1[1][5], D1[1][5];
+#pragma unroll
+          for (int t = 0; t < 5; t++) S1[0][t] = S[c][u][t];
+          mat_apply<1>(A, S1, D1);
+#pragma unroll
+          for (int t = 0; t < 5; t++) x += (q[u][t] * S[1 - c][u][t]) * D1[0][t];
+        }
+      }
+      X[c] = wave_sum(x);
+    }
 #pragma unroll
     for (int u = 0; u < M; u++)
 #pragma unroll
@@ -1188,33 +1220,6 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
         S[1][u][t] = u0;
         S[0][u][t] = u1;
       }
-    double X[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-      const double* shared = ops_lds[buf][c] + kAaPack;  // P Q (tip: its column table)
-      double x = 0;
-      if (ch[c] < n) {
-        double D[M][5];
-        lds_cols(shared, xc[c], D);
-#pragma unroll
-        for (int u = 0; u < M; u++)
-#pragma unroll
-          for (int t = 0; t < 5; t++) x += S[1 - c][u][t] * D[u][t];
-      } else {
-        double A[10];
-        lds_pack(shared, A);
-#pragma unroll
-        for (int u = 0; u < M; u++) {
-          double L1[1][5], D1[1][5];
-#pragma unroll
-          for (int t = 0; t < 5; t++) L1[0][t] = L[c][u][t];
-          mat_apply<1>(A, L1, D1);
-#pragma unroll
-          for (int t = 0; t < 5; t++) x += S[1 - c][u][t] * D1[0][t];
-        }
-      }
-      X[c] = wave_sum(x);
-    }
     wait_all_vm();  // (the DMA of the next visit's operands; the stores below stay in flight)
     if (lane == 0 && active) {
       store_async(gp + ch[0], X[0]);
@@ -1225,7 +1230,7 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
     for (int c = 0; c < 2; c++) {
       if (ch[c] < n || ch[c] == next) continue;
       double A[10], qc[M][5];
-      lds_pack(ops_lds[buf][c] + 2 * kAaPack, A);
+      lds_pack(ops_lds[buf][c] + kAaPack, A);
       mat_apply<M>(A, S[1 - c], qc);
       if (active) store_tiles_async<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, qc);
     }
@@ -1233,7 +1238,7 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
     for (int c = 0; c < 2; c++) {
       if (ch[c] < n || ch[c] != next) continue;
       double A[10];
-      lds_pack(ops_lds[buf][c] + 2 * kAaPack, A);
+      lds_pack(ops_lds[buf][c] + kAaPack, A);
       mat_apply<M>(A, S[1 - c], q);
       keep_next = ch[c];
     }
@@ -1377,7 +1382,7 @@ void launch_aa_pre(const AaWalkArgs& a, hipStream_t s) {
   if (wg) {
     const int blocks = a.tiles / kAaPreTiles;
     const dim3 grid(aa_grid((blocks + kPreWaves - 1) / kPreWaves, a.evals * a.K)), block(kPreThreads);
-    const size_t lds = sizeof(double) * 2 * 2 * kPreOps + sizeof(SchedEntry) * kSchedWindow + aa_lds_pad();
+    const size_t lds = sizeof(double) * (2 * 2 * kPreOps + kAaPack) + sizeof(SchedEntry) * kSchedWindow + aa_lds_pad();
     allow_large_lds(reinterpret_cast<const void*>(aa_pre_wg_kernel<kAaPreTiles>), lds);
     hipLaunchKernelGGL((aa_pre_wg_kernel<kAaPreTiles>), grid, block, lds, s, a);
     return;

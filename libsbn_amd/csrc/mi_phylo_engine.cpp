@@ -690,7 +690,7 @@ void mi_engine_destroy(mi_engine* e) {
         &e->arena_macros, &e->slot_need,
         &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,
-        &e->ll_sum, &e->g_sum, &e->status, &e->aa_model, &e->aa_matP, &e->aa_matPT, &e->aa_matPQ,
+        &e->ll_sum, &e->g_sum, &e->status, &e->aa_model, &e->aa_matP, &e->aa_matPT,
         &e->aa_tipP, &e->aa_tipPQ, &e->aa_exp_cum, &e->aa_exp_loc, &e->aa_root_val,
         &e->aa_root_exp, &e->aa_root_scale, &e->in_index, &e->in_weights, &e->out_reduced,
         &e->red_ll, &e->red_g, &e->red_site,

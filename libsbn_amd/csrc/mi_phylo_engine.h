@@ -133,7 +133,7 @@ struct mi_engine {
   Buffer arena_macros, slot_need, tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
       ll_sum, g_sum, status;
   // 20-state path: the engine's eigensystem and the streamed workspace (the arena is `plv`)
-  Buffer aa_model, aa_matP, aa_matPT, aa_matPQ, aa_tipP, aa_tipPQ, aa_exp_cum, aa_exp_loc,
+  Buffer aa_model, aa_matP, aa_matPT, aa_tipP, aa_tipPQ, aa_exp_cum, aa_exp_loc,
       aa_root_val, aa_root_exp, aa_root_scale;
   bool aa_reserved_gradient = false;
   PinnedArena pinned;

@@ -82,7 +82,6 @@ int aa_reserve(mi_engine* e, int T, bool gradient) {
   if (gradient) {
     if (e->aa_exp_loc.ensure(sizeof(int32_t) * chunk * (n - 1) * K * tp)) return 1;
     if (e->aa_matPT.ensure(sizeof(double) * chunk * (n - 1) * K * kAaPack)) return 1;
-    if (e->aa_matPQ.ensure(sizeof(double) * chunk * (n - 1) * K * kAaPack)) return 1;
     if (e->aa_tipPQ.ensure(sizeof(double) * (chunk * n * K * kAaTipTable + 128))) return 1;
     if (e->aa_root_scale.ensure(sizeof(double) * chunk * K * tp)) return 1;
     if (e->g_part.ensure(sizeof(double) * chunk * K * (tiles / kAaPreTiles) * N)) return 1;
@@ -145,7 +144,6 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     tr.bl_eff = e->bl_eff.as<double>();
     tr.matP = e->aa_matP.as<double>();
     tr.matPT = e->aa_matPT.as<double>();
-    tr.matPQ = e->aa_matPQ.as<double>();
     tr.tipP = e->aa_tipP.as<double>();
     tr.tipPQ = e->aa_tipPQ.as<double>();
     launch_aa_transition(tr, s);
@@ -166,7 +164,6 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     w.models = tr.models;
     w.matP = tr.matP;
     w.matPT = tr.matPT;
-    w.matPQ = tr.matPQ;
     w.tipP = tr.tipP;
     w.tipPQ = tr.tipPQ;
     w.tip_states = e->tip_states.as<int8_t>();

@@ -235,6 +235,7 @@ struct AaModel {
   double Q[kAa * kAa];     // row-major, normalised to one expected substitution per unit time
   double V[kAa * kAa];     // eigenvectors
   double Vinv[kAa * kAa];  // inverse eigenvectors
+  double Qpack[kAaPack];   // Q as a matrix-instruction A operand (10 registers x 64 lanes)
 };
 
 struct AaTransitionArgs {
@@ -246,9 +247,9 @@ struct AaTransitionArgs {
   const double* bl_eff;     // [T][N]
   double* matP;             // [evals][n-1][K][kAaPack]  P of internal edges
   double* matPT;            // same: P^T (pre-order propagation)
-  double* matPQ;            // same: P Q (edge derivative)
   double* tipP;             // [evals][n][K][21][20]: tipP[x][i] = P[i][x], x = 20: 1
-  double* tipPQ;            // same for P Q (x = 20: 0)
+  double* tipPQ;            // same for P Q (x = 20: 0); internal edges need no P Q: the
+                            // derivative uses Q (P L) with the model's one Q operand
 };
 
 struct AaWalkArgs {
@@ -263,7 +264,6 @@ struct AaWalkArgs {
   const DevModel* models;  // [T]
   const double* matP;
   const double* matPT;
-  const double* matPQ;
   const double* tipP;
   const double* tipPQ;
   const int8_t* tip_states;  // [n][P], 20 = gap

@@ -563,6 +563,8 @@ constexpr int kPostWaves = 4, kPostThreads = 64 * kPostWaves;
 // the stores themselves stay in flight across the barrier.
 typedef __attribute__((address_space(3))) void* lds_ptr;
 __device__ __forceinline__ void dma_1k(const double* src_lane, double* dst_lds) {
+  // (M0 is a reserved register: hipcc only writes it immediately before an instruction that
+  // reads it, never keeps a value in it, so setting it here clobbers nothing)
   const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)dst_lds;
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(m0) : "memory");
 }

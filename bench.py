@@ -88,6 +88,14 @@ def evolved_alignment(pid, bl, P, rng, states=4):
     return np.ascontiguousarray(x[:n])
 
 
+def two_internal_children(parent_ids, n):
+    """Number of nodes of a parent-id vector whose children include two internal nodes (a
+    trifurcating root with k internal children counts k - 1)."""
+    parent_ids = np.asarray(parent_ids)
+    kids = np.bincount(parent_ids[n:][parent_ids[n:] >= 0], minlength=len(parent_ids) + 1)
+    return int(np.maximum(kids - 1, 0).sum())
+
+
 def random_unrooted_topology(n, rng):
     """uniform random-join topology, numbered as the reference numbers nodes (leaves keep their
     ids, internal nodes in post-order, children ordered by max leaf id: node.cpp:32-59,341-357)"""
@@ -394,9 +402,12 @@ def also_workloads(torch, dev, L, steps):
             b_model = ((10 * n - 14) if grad else 2 * (n - 1)) * plv + (12 if grad else 4) * n * P
             f_model = algorithmic_flops(n, P, K, 20)[1 if grad else 0]
             # what the kernels really have to do: a tip child's product is a table look-up,
-            # so only the n-2 internal edges cost 20x20 products (1 in the post-order, 3 more
+            # so only the n-2 internal edges cost 20x20 products (1 in the post-order, 2-3 more
             # in the pre-order); the arena moves n-2 vectors out and back (+ stacked ones)
-            mfma_flops = (4 if grad else 1) * (n - 2) * K * P * 800.0
+            # the pre-order pass forms P L itself only for the child the post-order pass did
+            # NOT take from registers, i.e. once per node with two internal children
+            mfma_flops = ((3 * (n - 2) + two_internal_children(pids[0], n)) if grad
+                          else (n - 2)) * K * P * 800.0
             r = {"bound": "hbm", "achieved": b_model * Tw / (k_ms * 1e-3) / 1e9,
                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": b_model * Tw / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,

@@ -237,9 +237,21 @@ __device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstla
 
 // S = Mat x L for M tiles of 16 patterns, the matrix given as its ten A-operand registers:
 // per tile five 16x16x4 steps (rows 0..15) and five 4x4x4 steps (rows 16..19)
+#ifndef MI_PHYLO_AA_ABLATE
+#define AA_ABLATE 0
+#else
+#define AA_ABLATE MI_PHYLO_AA_ABLATE  // timing experiments only, never shipped
+#endif
 template <int M>
 __device__ __forceinline__ void mat_apply(const double (&A)[10], const double (&L)[M][5],
                                           double (&S)[M][5]) {
+  if (AA_ABLATE & 4) {
+#pragma unroll
+    for (int u = 0; u < M; u++)
+#pragma unroll
+      for (int t = 0; t < 5; t++) S[u][t] = A[t] * L[u][t] + A[5 + t];
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < M; u++) {
     double4v c = {0, 0, 0, 0};
@@ -471,7 +483,14 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
     // the deferred stores of the previous visit (its vector is still in R)
     if (prev >= 0) {
       if (GRAD) {
-        store_tiles<M>(arena + (size_t)(prev - n) * arena_stride, lane, R);
+        // what the pre-order pass needs of a node is P L (its vector at the parent's end of
+        // the edge): for the child this visit took from registers that product exists right
+        // here, so IT is stored, and the pre-order pass skips the product; a node consumed
+        // later is stored as L (its parent's visits, here and there, form P L themselves)
+        double* dstp = arena + (size_t)(prev - n) * arena_stride;
+        if (prev == ch0) store_tiles<M>(dstp, lane, S[0]);
+        else if (prev == ch1) store_tiles<M>(dstp, lane, S[1]);
+        else store_tiles<M>(dstp, lane, R);
         if (g == 0) {
 #pragma unroll
           for (int u = 0; u < M; u++) {
@@ -599,7 +618,7 @@ __device__ __forceinline__ void wait_all_vm() { asm volatile("s_waitcnt vmcnt(0)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int kPreWaves = 4, kPreThreads = 64 * kPreWaves;
 template <int M, bool GRAD>
-__global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs a) {
+__global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkArgs a) {
   __shared__ SchedEntry sched_lds[kSchedWindow];
   __shared__ double ops_lds[2][2][kAaPack];  // [buffer][child][640]: pack, or tip table (420)
   const int blocks = a.tiles / M;
@@ -729,12 +748,16 @@ __global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs 
         mat_apply<M>(A, L, S[c]);
       }
     }
-    // (the product first: it consumes -- waits for -- everything this visit loaded)
+    // (log-likelihood form: the product first -- it consumes, i.e. waits for, everything this
+    // visit loaded; gradient form: after the stores, which may read S, to save registers)
     double Tn[M][5];
+    auto product = [&]() {
 #pragma unroll
-    for (int u = 0; u < M; u++)
+      for (int u = 0; u < M; u++)
 #pragma unroll
-      for (int t = 0; t < 5; t++) Tn[u][t] = S[0][u][t] * S[1][u][t];
+        for (int t = 0; t < 5; t++) Tn[u][t] = S[0][u][t] * S[1][u][t];
+    };
+    if (!GRAD) product();
     // the deferred stores of the previous visit (its vector is still in R); before them the
     // visit's one wait for the DMA of the next visit's operands (the children's exponents are
     // consumed here so that no later use makes the compiler wait after the stores)
@@ -749,7 +772,11 @@ __global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs 
     wait_all_vm();
     if (prev >= 0 && active) {
       if (GRAD) {
-        store_tiles_async<M>(arena + (size_t)(prev - n) * arena_stride, lane, R);
+        // (P L of the child taken from registers, L of a node consumed later: see aa_post_kernel)
+        double* dstp = arena + (size_t)(prev - n) * arena_stride;
+        if (prev == ch0) store_tiles_async<M>(dstp, lane, S[0]);
+        else if (prev == ch1) store_tiles_async<M>(dstp, lane, S[1]);
+        else store_tiles_async<M>(dstp, lane, R);
         if (g == 0) {
 #pragma unroll
           for (int u = 0; u < M; u++) {
@@ -766,6 +793,7 @@ __global__ __launch_bounds__(64 * kPostWaves) void aa_post_wg_kernel(AaWalkArgs 
         }
       }
     }
+    if (GRAD) product();
 #pragma unroll
     for (int u = 0; u < M; u++) {
       double cs = 0;
@@ -961,6 +989,12 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
     for (int c = 0; c < 2; c++) {
       if (ch[c] < n) {
         tip_gather<M>(tipP + (size_t)ch[c] * K * kAaTipTable, xc[c], lane, S[c]);
+      } else if (ch[c] == next) {
+        // (the child the post-order pass took from registers: the arena holds P L already)
+#pragma unroll
+        for (int u = 0; u < M; u++)
+#pragma unroll
+          for (int t = 0; t < 5; t++) S[c][u][t] = L[c][u][t];
       } else {
         double A[10];
         load_pack(matP + (size_t)(ch[c] - n) * K * kAaPack, lane, A);
@@ -1103,6 +1137,7 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
     }
   };
   auto stage0 = [&](int c0, int c1, int (&x)[2][M]) {
+    if (AA_ABLATE & 64) return;
     if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
     if (c1 < n) load_tip_states<M>(a.tip_states + (size_t)c1 * tip_stride, p0, lane, x[1]);
   };
@@ -1130,17 +1165,41 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
     ch[0] = sgpr(e0.child0);
     ch[1] = sgpr(e0.child1);
   }
+  // Everything a visit reads from global memory -- its children's post-order vectors, its own
+  // pre-order vector unless the previous visit hands it over in registers, its exponents, the
+  // tip states, the LDS operands -- is requested during the visit BEFORE it and retired by that
+  // visit's one vmcnt(0): a visit's own arithmetic never waits for memory.
+  double q[M][5], L[2][M][5], qn[M][5], Ln[2][M][5];
+  int ev[M], evn[M];
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    ev[u] = evn[u] = 0;
+#pragma unroll
+    for (int t = 0; t < 5; t++) q[u][t] = qn[u][t] = L[0][u][t] = L[1][u][t] = Ln[0][u][t] = Ln[1][u][t] = 0;
+  }
+  auto fetch = [&](int node, int c0, int c1, bool load_q, double (&Lx)[2][M][5], double (&qx)[M][5],
+                   int (&ex)[M]) {
+    if (c0 >= n) load_tiles<M>(arena + (size_t)(c0 - n) * arena_stride, lane, Lx[0]);
+    if (c1 >= n) load_tiles<M>(arena + (size_t)(c1 - n) * arena_stride, lane, Lx[1]);
+    if (load_q) load_tiles<M>(arena + (size_t)(node - n) * arena_stride, lane, qx);
+#pragma unroll
+    for (int u = 0; u < M; u++) ex[u] = exp_loc[(size_t)(node - n) * exp_stride + u * 16 + j];
+  };
   stage0(ch[0], ch[1], xc);
   stage(ch[0], ch[1], (count - 1) & 1);
+  fetch(v, ch[0], ch[1], false, L, q, ev);
+  {
+    const size_t rbase = ((size_t)el * K + cat) * tiles * 16 + p0;
+#pragma unroll
+    for (int u = 0; u < M; u++) {
+      const double rs = a.root_scale[rbase + u * 16 + j];
+#pragma unroll
+      for (int t = 0; t < 5; t++) q[u][t] = a.model->pi[4 * t + g] * rs;
+    }
+  }
   wait_all_vm();
   lds_barrier();
 
-  double q[M][5];
-#pragma unroll
-  for (int u = 0; u < M; u++)
-#pragma unroll
-    for (int t = 0; t < 5; t++) q[u][t] = 0;
-  int kept = -1;
   for (int i = count - 1; i >= 0; i--) {
     const int buf = i & 1;
     int next = -1, nc0 = -1, nc1 = -1;
@@ -1152,28 +1211,13 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       nc1 = sgpr(s1.child1);
       stage(nc0, nc1, buf ^ 1);
       stage0(nc0, nc1, xn);
+      // (the next node's pre-order vector comes from the arena unless this visit computes it)
+      fetch(next, nc0, nc1, next != ch[0] && next != ch[1], Ln, qn, evn);
     }
-    if (i == count - 1) {
-      const size_t rbase = ((size_t)el * K + cat) * tiles * 16 + p0;
 #pragma unroll
-      for (int u = 0; u < M; u++) {
-        const double rs = a.root_scale[rbase + u * 16 + j];
+    for (int u = 0; u < M; u++)
 #pragma unroll
-        for (int t = 0; t < 5; t++) q[u][t] = a.model->pi[4 * t + g] * rs;
-      }
-    } else if (kept != v) {
-      load_tiles<M>(arena + (size_t)(v - n) * arena_stride, lane, q);
-    }
-    double L[2][M][5];
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-      if (ch[c] >= n) load_tiles<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, L[c]);
-#pragma unroll
-    for (int u = 0; u < M; u++) {
-      const int ev = exp_loc[(size_t)(v - n) * exp_stride + u * 16 + j];
-#pragma unroll
-      for (int t = 0; t < 5; t++) q[u][t] = ldexp(q[u][t], -ev);
-    }
+      for (int t = 0; t < 5; t++) q[u][t] = ldexp(q[u][t], -ev[u]);
     // S[c] = P_c L_c (tip: column of P)
     double S[2][M][5];
 #pragma unroll
@@ -1181,6 +1225,12 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       const double* shared = ops_lds[buf][c];
       if (ch[c] < n) {
         lds_cols(shared, xc[c], S[c]);
+      } else if (ch[c] == next) {
+        // (the child the post-order pass took from registers: the arena holds P L already)
+#pragma unroll
+        for (int u = 0; u < M; u++)
+#pragma unroll
+          for (int t = 0; t < 5; t++) S[c][u][t] = L[c][u][t];
       } else {
         double A[10];
         lds_pack(shared, A);
@@ -1222,12 +1272,28 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
         S[1][u][t] = u0;
         S[0][u][t] = u1;
       }
-    wait_all_vm();  // (the DMA of the next visit's operands; the stores below stay in flight)
+    // The visit's one wait: the DMA and the loads for the next visit, requested at its top.
+    // What they loaded is consumed HERE as far as the compiler is concerned, so that it puts
+    // its own waits before the stores below and none after them (the stores stay in flight).
+    wait_all_vm();
+#pragma unroll
+    for (int u = 0; u < M; u++) {
+      asm volatile("" : "+v"(xn[0][u]));
+      asm volatile("" : "+v"(xn[1][u]));
+      asm volatile("" : "+v"(evn[u]));
+#pragma unroll
+      for (int t = 0; t < 5; t++) {
+        asm volatile("" : "+v"(Ln[0][u][t]));
+        asm volatile("" : "+v"(Ln[1][u][t]));
+        asm volatile("" : "+v"(qn[u][t]));
+      }
+    }
     if (lane == 0 && active) {
       store_async(gp + ch[0], X[0]);
       store_async(gp + ch[1], X[1]);
     }
-    int keep_next = -1;
+    // q_c = P_c^T u_c for internal children: into the arena, or handed to the next visit
+    bool keep = false;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       if (ch[c] < n || ch[c] == next) continue;
@@ -1242,17 +1308,24 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       double A[10];
       lds_pack(ops_lds[buf][c] + kAaPack, A);
       mat_apply<M>(A, S[1 - c], q);
-      keep_next = ch[c];
+      keep = true;
     }
     lds_barrier();
-    kept = keep_next;
     v = next;
     ch[0] = nc0;
     ch[1] = nc1;
 #pragma unroll
-    for (int c = 0; c < 2; c++)
+    for (int u = 0; u < M; u++) {
+      ev[u] = evn[u];
+      xc[0][u] = xn[0][u];
+      xc[1][u] = xn[1][u];
 #pragma unroll
-      for (int u = 0; u < M; u++) xc[c][u] = xn[c][u];
+      for (int t = 0; t < 5; t++) {
+        if (!keep) q[u][t] = qn[u][t];
+        L[0][u][t] = Ln[0][u][t];
+        L[1][u][t] = Ln[1][u][t];
+      }
+    }
   }
 }
 

@@ -83,7 +83,10 @@ def main():
         assert bool(torch.isfinite(d_ll).all())
         # SURVEY 8(d) models and what the kernels actually have to move / compute
         b_model = ((10 * n - 14) if grad else 2 * (n - 1)) * plv + (12 if grad else 4) * n * P
-        mv = 4 * (n - 2) if grad else (n - 2)       # 20x20 products per (pattern, category)
+        # 20x20 products per (pattern, category): one per internal edge in the post-order pass,
+        # two more in the pre-order pass, a third there for a node with two internal children
+        kids = np.bincount(pids[0][n:][pids[0][n:] >= 0], minlength=pids.shape[1] + 1)
+        mv = (3 * (n - 2) + int(np.maximum(kids - 1, 0).sum())) if grad else (n - 2)
         flops = mv * K * P * 800.0
         out[mode] = {"ms_per_step": 1e3 * dt, "trees_per_s": T / dt, "walk_ms": walk_ms,
                      "logL0": float(d_ll[0]),

@@ -411,7 +411,7 @@ def also_workloads(torch, dev, L, steps):
             r = {"bound": "hbm", "achieved": b_model * Tw / (k_ms * 1e-3) / 1e9,
                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": b_model * Tw / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                 "traffic": (49.4e9 if grad else 6.6e9),
+                 "traffic": (49.7e9 if grad else 7.9e9),
                  "traffic_source": "profiles/r02_aa_pmc_{fetch,write}.csv, profiles/traffic.json "
                                    "((2 FETCH_SIZE + WRITE_SIZE) x 1024, separate passes), per "
                                    "tree; not this run",
@@ -538,6 +538,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the other configurations (one-GPU runs only carry them)")
+    ap.add_argument("--no-small-batch", action="store_true",
+                    help="skip the 125-tree leg (profiling: its launches of the same kernel "
+                         "would be averaged into the rocprofv3 --stats line of the timed one)")
     ap.add_argument("--workload", choices=["ds1", "swag"], default="ds1",
                     help="ds1: the headline (trees dealt to the GPUs); swag: BASELINE.json "
                          "configs[4], 20 states x 512 taxa x 50 000 patterns x 4 categories, "
@@ -713,7 +716,7 @@ def main():
 
     # ---- small batch: what one of 8 GPUs sees under strong scaling (125 trees)
     small = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_small_batch:
         Ts = max(1, T_total // 8)
         s_elapsed, s_kernel, _, _ = run_config(Ts, 0, Ts, 50, 5)
         small = {"trees": Ts, "ms_per_step": 1e3 * s_elapsed / 50,

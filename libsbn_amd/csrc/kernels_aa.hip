@@ -237,21 +237,9 @@ __device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstla
 
 // S = Mat x L for M tiles of 16 patterns, the matrix given as its ten A-operand registers:
 // per tile five 16x16x4 steps (rows 0..15) and five 4x4x4 steps (rows 16..19)
-#ifndef MI_PHYLO_AA_ABLATE
-#define AA_ABLATE 0
-#else
-#define AA_ABLATE MI_PHYLO_AA_ABLATE  // timing experiments only, never shipped
-#endif
 template <int M>
 __device__ __forceinline__ void mat_apply(const double (&A)[10], const double (&L)[M][5],
                                           double (&S)[M][5]) {
-  if (AA_ABLATE & 4) {
-#pragma unroll
-    for (int u = 0; u < M; u++)
-#pragma unroll
-      for (int t = 0; t < 5; t++) S[u][t] = A[t] * L[u][t] + A[5 + t];
-    return;
-  }
 #pragma unroll
   for (int u = 0; u < M; u++) {
     double4v c = {0, 0, 0, 0};
@@ -1137,7 +1125,6 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
     }
   };
   auto stage0 = [&](int c0, int c1, int (&x)[2][M]) {
-    if (AA_ABLATE & 64) return;
     if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
     if (c1 < n) load_tip_states<M>(a.tip_states + (size_t)c1 * tip_stride, p0, lane, x[1]);
   };

@@ -205,6 +205,264 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a, ModelSe
 }
 
 // ------------------------------------------------------------------------
+// Tree setup for large trees, one WORKGROUP per tree (a thread per node): the sequential walk
+// above takes about 2 000 cycles per node (dependent LDS round trips of one lane), 0.84 ms for
+// the 512-taxon trees of the 20-state configuration -- more than their log-likelihood
+// kernel takes on one of eight pattern shards.  Every quantity of that walk has a parallel
+// form whose depth is the tree's height:
+//   * children: each node registers with its parent (LDS atomic), the parent orders its two
+//     or three children by their largest leaf id (sibling subtrees are disjoint: no ties);
+//   * bottom-up sweep (rounds: a node computes once its children have): largest leaf id,
+//     Sethi-Ullman label, number of internal nodes below, stored / unstored class;
+//   * top-down sweep from the root: with hi the child evaluated first (the larger label, the
+//     first child on a tie) and lo the other,
+//         start(hi) = start(v),  start(lo) = start(v) + internal(hi),
+//         base(hi)  = base(v),   base(lo)  = base(v) + [hi is internal],
+//     node v is entry start(v) + internal(v) - 1 of the post-order and its vector lives in
+//     slot base(v): the lowest-free-slot rule of the sequential walk always finds the live
+//     slots to be 0 .. base(v)-1 (one per ancestor that is waiting for its second child);
+//   * the gradient kernels' macros: a stored node's slot number is a prefix count over node
+//     ids (ballots), the entries are written by the nodes' own threads.
+// Same schedule, bit for bit, as tree_setup_kernel (tests/test_tree_setup_gpu.py).
+// ------------------------------------------------------------------------
+constexpr int kSetupThreads = 1024;
+constexpr int kSetupArrays = 16;  // LDS ints per node
+__global__ __launch_bounds__(kSetupThreads) void tree_setup_wg_kernel(TreeSetupArgs a, ModelSetupArgs ms) {
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.T) {
+    model_setup_thread(ms, ((int)blockIdx.x - a.T) * kSetupThreads + tid);
+    return;
+  }
+  extern __shared__ int32_t ts_lds[];
+  __shared__ int flag_bad, flag_arity, flag_more, used_max, chunk_tot[64], ok_flag;
+  const int t = blockIdx.x;
+  const int n = a.n, N = 2 * n - 1;
+  const int nodes_in = a.rooted ? N : N - 1, root_in = nodes_in - 1;
+  const int32_t* par_in = a.parent_ids + (size_t)t * (nodes_in - 1);
+  volatile int32_t* par = ts_lds;
+  volatile int32_t* mxl = par + N;
+  int32_t* cnt = ts_lds + 2 * N;
+  volatile int32_t* kids = ts_lds + 3 * N;  // 3 per node
+  volatile int32_t* c0 = kids + 3 * N;
+  volatile int32_t* c1 = c0 + N;
+  volatile int32_t* label = c1 + N;
+  volatile int32_t* isz = label + N;    // internal nodes in the subtree (the node included)
+  volatile int32_t* base = isz + N;     // LDS slot
+  volatile int32_t* start = base + N;
+  volatile int32_t* done = start + N;   // bottom-up: computed; top-down: 1 = ready, 2 = expanded
+  volatile int32_t* cls = done + N;     // 1 = stored, 2 = unstored
+  volatile int32_t* sslot = cls + N;
+  SchedEntry* sched = a.sched + (size_t)t * (n - 1);
+  double* ble = a.bl_eff + (size_t)t * N;
+
+  for (int v = tid; v < N; v += kSetupThreads) {
+    par[v] = v < nodes_in - 1 ? par_in[v] : -1;
+    mxl[v] = v < n ? v : -1;
+    cnt[v] = 0;
+    c0[v] = c1[v] = 0;
+    label[v] = isz[v] = base[v] = start[v] = cls[v] = sslot[v] = 0;
+    done[v] = v < n ? 1 : 0;
+  }
+  if (tid == 0) flag_bad = flag_arity = flag_more = used_max = 0;
+  __syncthreads();
+  for (int v = tid; v < nodes_in - 1; v += kSetupThreads) {
+    const int p = par[v];
+    if (p <= v || p >= nodes_in || p < n) flag_bad = 1;
+  }
+  __syncthreads();
+  int status = flag_bad ? kBadParentIds : kOk;
+  if (status == kOk) {
+    for (int v = tid; v < nodes_in - 1; v += kSetupThreads) {
+      const int p = par[v];
+      const int k = atomicAdd(&cnt[p], 1);
+      if (k < 3) kids[3 * p + k] = v;
+    }
+    __syncthreads();
+    for (int v = n + tid; v < nodes_in; v += kSetupThreads) {
+      const int want = (!a.rooted && v == root_in) ? 3 : 2;
+      if (cnt[v] != want) flag_arity = 1;
+    }
+    __syncthreads();
+    if (flag_arity) status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
+  }
+  if (status == kOk) {
+    // ---- bottom-up: largest leaf, label, internal-node count, class
+    for (;;) {
+      for (int v = n + tid; v < nodes_in; v += kSetupThreads) {
+        if (done[v]) continue;
+        const int k = cnt[v];
+        const int a0 = kids[3 * v], a1 = kids[3 * v + 1], a2 = k == 3 ? kids[3 * v + 2] : a0;
+        if (!(done[a0] && done[a1] && done[a2])) {
+          flag_more = 1;
+          continue;
+        }
+        const int m01 = mxl[a0] > mxl[a1] ? mxl[a0] : mxl[a1];
+        mxl[v] = m01 > mxl[a2] ? m01 : mxl[a2];
+        if (k == 2) {  // (the trifurcating root is re-shaped below)
+          const int l0 = label[a0], l1 = label[a1];
+          label[v] = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
+          isz[v] = isz[a0] + isz[a1] + 1;
+          const bool unstored = (a0 < n || cls[a0] == 1) && (a1 < n || cls[a1] == 1);
+          cls[v] = unstored ? 2 : 1;
+        }
+        __threadfence_block();
+        done[v] = 1;
+      }
+      __syncthreads();
+      const int more = flag_more;
+      __syncthreads();
+      if (!more) break;
+      if (tid == 0) flag_more = 0;
+      __syncthreads();
+    }
+    // ---- children in order of their largest leaf id; the root re-shaped (Detrifurcate)
+    for (int v = n + tid; v < nodes_in; v += kSetupThreads) {
+      int k0 = kids[3 * v], k1 = kids[3 * v + 1];
+      if (mxl[k0] > mxl[k1]) { const int x = k0; k0 = k1; k1 = x; }
+      if (cnt[v] == 2) {
+        c0[v] = k0;
+        c1[v] = k1;
+      } else {
+        int k2 = kids[3 * v + 2];
+        if (mxl[k1] > mxl[k2]) { const int x = k1; k1 = k2; k2 = x; }
+        if (mxl[k0] > mxl[k1]) { const int x = k0; k0 = k1; k1 = x; }
+        // (k0,k1,k2) at root r  ->  r = (k1,k2), r+1 = (k0, r)
+        const int r = v;
+        c0[r] = k1;
+        c1[r] = k2;
+        c0[r + 1] = k0;
+        c1[r + 1] = r;
+        int l0 = label[k1], l1 = label[k2];
+        label[r] = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
+        isz[r] = isz[k1] + isz[k2] + 1;
+        cls[r] = ((k1 < n || cls[k1] == 1) && (k2 < n || cls[k2] == 1)) ? 2 : 1;
+        l0 = label[k0];
+        l1 = label[r];
+        label[r + 1] = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
+        isz[r + 1] = isz[k0] + isz[r] + 1;
+      }
+    }
+    __syncthreads();
+    for (int v = n + tid; v < N; v += kSetupThreads) done[v] = 0;
+    if (tid == 0) {
+      cls[N - 1] = 1;
+      flag_more = 0;
+    }
+    __syncthreads();
+    if (tid == 0) done[N - 1] = 1;  // (start = base = 0)
+    __syncthreads();
+    // ---- top-down: position in the post-order and LDS slot; the schedule entries
+    for (;;) {
+      for (int v = n + tid; v < N; v += kSetupThreads) {
+        if (done[v] != 1) continue;
+        const int a0 = c0[v], a1 = c1[v];
+        const bool first0 = label[a0] >= label[a1];
+        const int hi = first0 ? a0 : a1, lo = first0 ? a1 : a0;
+        const int b = base[v], st = start[v];
+        const int blo = b + (hi >= n ? 1 : 0);
+        if (hi >= n) {
+          base[hi] = b;
+          start[hi] = st;
+        }
+        if (lo >= n) {
+          base[lo] = blo;
+          start[lo] = st + isz[hi];
+        }
+        __threadfence_block();
+        if (hi >= n) done[hi] = 1;
+        if (lo >= n) done[lo] = 1;
+        done[v] = 2;
+        const int s0 = a0 < n ? 0 : (a0 == hi ? b : blo), s1 = a1 < n ? 0 : (a1 == hi ? b : blo);
+        sched[st + isz[v] - 1] = {v, a0, a1, b | (s0 << 8) | (s1 << 16) | ((a0 < n ? 1 : 0) << 24) |
+                                                 ((a1 < n ? 1 : 0) << 25)};
+        atomicMax(&used_max, b + 1);
+        flag_more = 1;
+      }
+      __syncthreads();
+      const int more = flag_more;
+      __syncthreads();
+      if (!more) break;
+      if (tid == 0) flag_more = 0;
+      __syncthreads();
+    }
+    if (used_max > a.max_slots) status = kTooManySlots;
+    // ---- schedule of the on-chip gradient kernel (see tree_setup_kernel)
+    if (a.macros) {
+      const int lane = tid & 63, wave = tid >> 6, waves = kSetupThreads / 64;
+      const int chunks = (N - 1 - n + 63) / 64;  // nodes n .. N-2 in chunks of 64
+      for (int c = wave; c < chunks; c += waves) {
+        const int v = n + c * 64 + lane;
+        const bool st = v < N - 1 && cls[v] == 1;
+        const unsigned long long m = __ballot(st);
+        if (st) sslot[v] = __popcll(m & ((1ull << lane) - 1));
+        if (lane == 0) chunk_tot[c] = __popcll(m);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < chunks; c++) {
+          const int x = chunk_tot[c];
+          chunk_tot[c] = run;
+          run += x;
+        }
+        sslot[N - 1] = run;  // (the root's macro index; its qslot is -1)
+      }
+      __syncthreads();
+      const int stored = sslot[N - 1];
+      for (int v = n + tid; v < N - 1; v += kSetupThreads)
+        if (cls[v] == 1) sslot[v] += chunk_tot[(v - n) >> 6];
+      __syncthreads();
+      MacroEntry* mac = a.macros + (size_t)t * max_macros(n);
+      for (int v = n + tid; v < N; v += kSetupThreads) {
+        if (cls[v] != 1) continue;
+        const bool root = v == N - 1;
+        MacroEntry me;
+        int kind[2];
+        me.node = v;
+        me.pad = 0;
+        me.qslot = root ? -1 : sslot[v];
+        for (int j = 0; j < 2; j++) {
+          const int ch = j ? c1[v] : c0[v];
+          me.child[j] = ch;
+          kind[j] = ch < n ? 0 : cls[ch];
+          me.cslot[j] = (ch >= n && cls[ch] == 1) ? sslot[ch] : 0;
+          const bool expand = ch >= n && cls[ch] == 2;
+          const int ga = expand ? c0[ch] : 0, gb = expand ? c1[ch] : 0;
+          me.grand[2 * j] = ga;
+          me.grand[2 * j + 1] = gb;
+          me.gslot[2 * j] = ga >= n ? sslot[ga] : 0;
+          me.gslot[2 * j + 1] = gb >= n ? sslot[gb] : 0;
+        }
+        me.shape = macro_shape(kind[0], kind[1], root, me.child, me.grand, n);
+        if (sslot[v] < max_macros(n)) mac[sslot[v]] = me;
+      }
+      if (tid == 0) a.macro_count[t] = stored + 1 < max_macros(n) ? stored + 1 : max_macros(n);
+      if (stored > max_stored(n)) status = kTooManySlots;
+    }
+  }
+  if (tid == 0) {
+    if (status != kOk) set_status(a.status, status, t);
+    ok_flag = status == kOk || status == kTooManySlots;
+  }
+  __syncthreads();
+  if (!ok_flag) {
+    if (tid == 0 && a.macro_count) a.macro_count[t] = 0;
+    for (int i = tid; i < n - 1; i += kSetupThreads) sched[i] = {n + i, 0, 1, 0};
+    for (int v = tid; v < N; v += kSetupThreads) ble[v] = 0.0;
+    return;
+  }
+  if (!a.rooted) {
+    const double* bl = a.bl + (size_t)t * (N - 1);
+    for (int v = tid; v < N; v += kSetupThreads) ble[v] = v < N - 2 ? bl[v] : 0.0;
+  } else {
+    const double* bl = a.bl + (size_t)t * N;
+    const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
+    for (int v = tid; v < N; v += kSetupThreads)
+      ble[v] = (rates && v < N - 1) ? bl[v] * rates[v] : bl[v];
+  }
+}
+
+// ------------------------------------------------------------------------
 // Tree setup for N <= 64 nodes: the same walk with every per-node array held in ONE
 // vector register (lane = node id) and indexed with v_readlane / v_writelane.  The walk
 // is sequential and its cost is the latency of each dependent array access: a
@@ -845,6 +1103,13 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
 // ------------------------------------------------------------------------
 // Launch wrappers
 // ------------------------------------------------------------------------
+static bool force_wg_env() {
+  static const bool f = [] {
+    const char* env = getenv("MI_PHYLO_TREE_SETUP");
+    return env && std::string(env) == "wg";
+  }();
+  return f;
+}
 void launch_setup(const TreeSetupArgs& a_in, const ModelSetupArgs& ms, hipStream_t s) {
   TreeSetupArgs a = a_in;
   const size_t lds = sizeof(int32_t) * 13 * (size_t)(2 * a.n - 1);
@@ -857,11 +1122,21 @@ void launch_setup(const TreeSetupArgs& a_in, const ModelSetupArgs& ms, hipStream
   const int N = 2 * a.n - 1;
   // T workgroups of trees, then the model instances, 64 per workgroup
   const dim3 grid(a.T + (ms.T * ms.models_per_tree + 63) / 64), block(64);
-  if (a.n >= 3 && N <= 256 && !force_lds) {
+  if (a.n >= 3 && N <= 256 && !force_lds && !force_wg_env()) {
     if (N <= 64) hipLaunchKernelGGL(tree_setup_small_kernel<1>, grid, block, 0, s, a, ms);
     else if (N <= 128) hipLaunchKernelGGL(tree_setup_small_kernel<2>, grid, block, 0, s, a, ms);
     else if (N <= 192) hipLaunchKernelGGL(tree_setup_small_kernel<3>, grid, block, 0, s, a, ms);
     else hipLaunchKernelGGL(tree_setup_small_kernel<4>, grid, block, 0, s, a, ms);
+    return;
+  }
+  // Larger trees: a workgroup per tree (thread per node) while its arrays fit the LDS;
+  // MI_PHYLO_TREE_SETUP=wg forces it for small trees too (testing)
+  const bool force_wg = force_wg_env();
+  const size_t wg_lds = sizeof(int32_t) * kSetupArrays * (size_t)N;
+  if (a.n >= 3 && wg_lds <= 160 * 1024 - 1024 && (!force_lds || force_wg)) {
+    const dim3 wgrid(a.T + (ms.T * ms.models_per_tree + kSetupThreads - 1) / kSetupThreads);
+    allow_large_lds(reinterpret_cast<const void*>(tree_setup_wg_kernel), wg_lds);
+    hipLaunchKernelGGL(tree_setup_wg_kernel, wgrid, dim3(kSetupThreads), wg_lds, s, a, ms);
     return;
   }
   hipLaunchKernelGGL(tree_setup_kernel, grid, block, a.use_lds ? lds : 0, s, a, ms);

@@ -1,7 +1,9 @@
 // Test helper: runs the engine's tree-setup launcher on a file of parent-id vectors and
 // dumps what it produced (status, macro counts, log-likelihood schedule, gradient
 // schedule), so that the register-array kernel (N <= 64) can be compared bit for bit with
-// the general LDS kernel (MI_PHYLO_TREE_SETUP=lds).  Usage: prog n T in.bin out.bin
+// the general LDS kernel (MI_PHYLO_TREE_SETUP=lds) and the workgroup-per-tree kernel of large
+// trees (default above 256 nodes, MI_PHYLO_TREE_SETUP=wg below).
+// Usage: prog n T in.bin out.bin [rooted]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -12,17 +14,18 @@ using namespace miphylo;
 int main(int argc, char** argv) {
   const int n = atoi(argv[1]), T = atoi(argv[2]);
   const int N = 2 * n - 1;
+  const int rooted = argc > 5 ? atoi(argv[5]) : 0;
   FILE* f = fopen(argv[3], "rb");
-  std::vector<int32_t> pid((size_t)T * (2 * n - 3));
+  std::vector<int32_t> pid((size_t)T * (2 * n - 3 + rooted));
   fread(pid.data(), 4, pid.size(), f); fclose(f);
-  std::vector<double> bl((size_t)T * (2 * n - 2), 0.1);
+  std::vector<double> bl((size_t)T * (2 * n - 2 + rooted), 0.1);
   int32_t *d_pid, *d_scratch, *d_mc, *d_status; double *d_bl, *d_ble; SchedEntry* d_sched; MacroEntry* d_mac;
   hipMalloc(&d_pid, pid.size() * 4); hipMalloc(&d_bl, bl.size() * 8); hipMalloc(&d_scratch, (size_t)T * 13 * N * 4);
   hipMalloc(&d_mc, T * 4); hipMalloc(&d_status, 8); hipMalloc(&d_ble, (size_t)T * N * 8);
   hipMalloc(&d_sched, sizeof(SchedEntry) * (size_t)T * (n - 1)); hipMalloc(&d_mac, sizeof(MacroEntry) * (size_t)T * max_macros(n));
   hipMemcpy(d_pid, pid.data(), pid.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_bl, bl.data(), bl.size() * 8, hipMemcpyHostToDevice);
   hipMemset(d_status, 0, 8); hipMemset(d_mac, 0, sizeof(MacroEntry) * (size_t)T * max_macros(n));
-  TreeSetupArgs a{}; a.n = n; a.T = T; a.rooted = 0; a.parent_ids = d_pid; a.bl = d_bl; a.rates = nullptr; a.scratch = d_scratch;
+  TreeSetupArgs a{}; a.n = n; a.T = T; a.rooted = rooted; a.parent_ids = d_pid; a.bl = d_bl; a.rates = nullptr; a.scratch = d_scratch;
   a.sched = d_sched; a.macros = d_mac; a.macro_count = d_mc; a.bl_eff = d_ble; a.status = d_status; a.max_slots = 32; a.need_slots = 1;
   launch_tree_setup(a, nullptr); hipDeviceSynchronize();
   std::vector<SchedEntry> sc((size_t)T * (n - 1)); std::vector<MacroEntry> mac((size_t)T * max_macros(n)); std::vector<int32_t> mc(T); int32_t st[2];

@@ -22,11 +22,14 @@ def test_cpp_engine_adapter(tmp_path):
 
 
 def test_tree_setup_kernels_agree(tmp_path):
-    """The register-array tree-setup kernel (N <= 256, branch-free) must produce exactly
-    what the general LDS kernel produces: status, macro counts, the Sethi-Ullman schedule
-    with its LDS slots, and the half-storage gradient schedule."""
+    """The register-array tree-setup kernel (N <= 256, branch-free) and the workgroup-per-tree
+    kernel (larger trees) must produce exactly what the sequential LDS kernel produces:
+    status, macro counts, the Sethi-Ullman schedule with its LDS slots, and the half-storage
+    gradient schedule."""
+    import sys
     import numpy as np
     import tree_utils as TU
+    sys.setrecursionlimit(20000)  # (tree_utils walks ladder trees recursively)
     exe = tmp_path / "tree_setup_compare"
     lib = os.path.join(REPO, "libsbn_amd")
     hipcc = "/opt/rocm/bin/hipcc"
@@ -34,20 +37,45 @@ def test_tree_setup_kernels_agree(tmp_path):
                     os.path.join(REPO, "tests/cpp/tree_setup_compare.hip"),
                     "-L" + lib, "-lmi_phylo", "-Wl,-rpath," + lib, "-o", str(exe)], check=True)
     rng = np.random.default_rng(11)
-    for n in (3, 4, 5, 6, 9, 17, 27, 32, 33, 50, 64, 65, 69, 100, 128):
-        T = 40
+
+    def dump(n, T, trees, mode, rooted):
+        env = dict(os.environ)
+        env.pop("MI_PHYLO_TREE_SETUP", None)
+        if mode != "default":
+            env["MI_PHYLO_TREE_SETUP"] = mode
+        out = tmp_path / f"dump_{n}_{mode}_{rooted}.bin"
+        r = subprocess.run([str(exe), str(n), str(T), str(trees), str(out), str(rooted)], env=env,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return np.fromfile(out, dtype=np.int32)
+
+    # small trees: register-array kernel (default) == sequential LDS kernel == workgroup kernel;
+    # large trees (> 256 nodes): workgroup kernel (default) == sequential LDS kernel
+    for n in (3, 4, 5, 6, 9, 17, 27, 32, 33, 50, 64, 65, 69, 100, 128, 129, 200, 333, 512, 700):
+        for rooted in (0, 1):
+            if rooted and n not in (3, 9, 69, 129, 512):
+                continue
+            T = 40 if n <= 128 else 12
+            pids, _ = TU.random_trees(n, T, rng, rooted=bool(rooted))
+            pids[0] = TU.ladder_topology(n, rooted=bool(rooted))
+            pids[1] = TU.balanced_topology(n, rooted=bool(rooted))
+            trees = tmp_path / f"trees_{n}_{rooted}.bin"
+            pids.astype(np.int32).tofile(trees)
+            ref = dump(n, T, trees, "lds", rooted)
+            assert np.array_equal(dump(n, T, trees, "default", rooted), ref), f"n = {n}"
+            if n <= 128:
+                assert np.array_equal(dump(n, T, trees, "wg", rooted), ref), f"n = {n} (wg)"
+    # invalid trees (one per batch: which bad tree is reported first is a race): the same
+    # status from every kernel
+    n, T = 40, 6
+    for case in range(2):
         pids, _ = TU.random_trees(n, T, rng)
-        pids[0] = TU.ladder_topology(n)
-        trees = tmp_path / f"trees_{n}.bin"
+        if case == 0:
+            pids[2, 5] = 3                # a parent that is a tip
+        else:
+            pids[4, 7] = pids[4, 60]      # an internal node with three children (or a bad id)
+        trees = tmp_path / f"trees_bad{case}.bin"
         pids.astype(np.int32).tofile(trees)
-        dumps = {}
-        for mode in ("small", "lds"):
-            env = dict(os.environ)
-            if mode == "lds":
-                env["MI_PHYLO_TREE_SETUP"] = "lds"
-            out = tmp_path / f"dump_{n}_{mode}.bin"
-            r = subprocess.run([str(exe), str(n), str(T), str(trees), str(out)], env=env,
-                               capture_output=True, text=True)
-            assert r.returncode == 0, r.stdout + r.stderr
-            dumps[mode] = np.fromfile(out, dtype=np.int32)
-        assert np.array_equal(dumps["small"], dumps["lds"]), f"n = {n}"
+        heads = [dump(n, T, trees, mode, 0)[:2] for mode in ("lds", "default", "wg")]
+        assert heads[0][0] != 0
+        assert np.array_equal(heads[0], heads[1]) and np.array_equal(heads[0], heads[2]), heads

@@ -225,174 +225,217 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a, ModelSe
 //     ids (ballots), the entries are written by the nodes' own threads.
 // Same schedule, bit for bit, as tree_setup_kernel (tests/test_tree_setup_gpu.py).
 // ------------------------------------------------------------------------
-constexpr int kSetupThreads = 1024;
-constexpr int kSetupArrays = 16;  // LDS ints per node
-__global__ __launch_bounds__(kSetupThreads) void tree_setup_wg_kernel(TreeSetupArgs a, ModelSetupArgs ms) {
-  const int tid = threadIdx.x;
+constexpr int kSetupMaxThreads = 1024;  // (the launcher takes fewer for small trees)
+constexpr int kSetupArrays = 16;         // LDS ints per node
+constexpr int kSetupOwn = 3;             // nodes per thread at most (N <= 2 * 3 * 1024)
+// What a round of a sweep reads of another node is ONE 64-bit LDS word (a dependent LDS round
+// trip costs more than everything else in a round):
+//   bottom-up  W: done << 63 | class << 56 | label << 48 | internal-node count << 20 | largest leaf
+//   top-down   D: ready << 63 | slot << 32 | start
+__device__ __forceinline__ uint64_t up_word(int cls, int label, int isz, int mxl) {
+  return (1ull << 63) | ((uint64_t)cls << 56) | ((uint64_t)label << 48) | ((uint64_t)isz << 20) | (uint64_t)mxl;
+}
+__device__ __forceinline__ int up_cls(uint64_t w) { return (int)(w >> 56) & 3; }
+__device__ __forceinline__ int up_label(uint64_t w) { return (int)(w >> 48) & 0xff; }
+__device__ __forceinline__ int up_isz(uint64_t w) { return (int)(w >> 20) & 0xfffff; }
+__device__ __forceinline__ int up_mxl(uint64_t w) { return (int)w & 0xfffff; }
+__global__ __launch_bounds__(kSetupMaxThreads) void tree_setup_wg_kernel(TreeSetupArgs a, ModelSetupArgs ms) {
+  const int tid = threadIdx.x, nthreads = blockDim.x;
   if ((int)blockIdx.x >= a.T) {
-    model_setup_thread(ms, ((int)blockIdx.x - a.T) * kSetupThreads + tid);
+    model_setup_thread(ms, ((int)blockIdx.x - a.T) * nthreads + tid);
     return;
   }
   extern __shared__ int32_t ts_lds[];
-  __shared__ int flag_bad, flag_arity, flag_more, used_max, chunk_tot[64], ok_flag;
+  __shared__ int flag_bad, flag_arity, more[3], used_max, chunk_tot[64], ok_flag;
   const int t = blockIdx.x;
   const int n = a.n, N = 2 * n - 1;
   const int nodes_in = a.rooted ? N : N - 1, root_in = nodes_in - 1;
   const int32_t* par_in = a.parent_ids + (size_t)t * (nodes_in - 1);
-  volatile int32_t* par = ts_lds;
-  volatile int32_t* mxl = par + N;
-  int32_t* cnt = ts_lds + 2 * N;
-  volatile int32_t* kids = ts_lds + 3 * N;  // 3 per node
-  volatile int32_t* c0 = kids + 3 * N;
-  volatile int32_t* c1 = c0 + N;
-  volatile int32_t* label = c1 + N;
-  volatile int32_t* isz = label + N;    // internal nodes in the subtree (the node included)
-  volatile int32_t* base = isz + N;     // LDS slot
-  volatile int32_t* start = base + N;
-  volatile int32_t* done = start + N;   // bottom-up: computed; top-down: 1 = ready, 2 = expanded
-  volatile int32_t* cls = done + N;     // 1 = stored, 2 = unstored
-  volatile int32_t* sslot = cls + N;
+  // (64-bit and 128-bit arrays first: alignment)
+  volatile int4* kid = reinterpret_cast<volatile int4*>(ts_lds);                 // {k0, k1, k2, count}
+  volatile uint64_t* W = reinterpret_cast<volatile uint64_t*>(ts_lds + 4 * N);  // bottom-up word
+  volatile uint64_t* D = W + N;                                                  // top-down word
+  volatile int2* cc = reinterpret_cast<volatile int2*>(D + N);   // {c0, c1 | first0 << 30}
+  volatile int2* up = cc + N;                                    // {parent, offsets} of the reshaped tree
+  volatile int32_t* par = reinterpret_cast<volatile int32_t*>(up + N);
+  volatile int32_t* sslot = par + N;
+  int32_t* kid_i = ts_lds;
   SchedEntry* sched = a.sched + (size_t)t * (n - 1);
   double* ble = a.bl_eff + (size_t)t * N;
 
-  for (int v = tid; v < N; v += kSetupThreads) {
+  for (int v = tid; v < N; v += nthreads) {
     par[v] = v < nodes_in - 1 ? par_in[v] : -1;
-    mxl[v] = v < n ? v : -1;
-    cnt[v] = 0;
-    c0[v] = c1[v] = 0;
-    label[v] = isz[v] = base[v] = start[v] = cls[v] = sslot[v] = 0;
-    done[v] = v < n ? 1 : 0;
+    kid_i[4 * v] = kid_i[4 * v + 1] = kid_i[4 * v + 2] = kid_i[4 * v + 3] = 0;
+    W[v] = v < n ? up_word(0, 0, 0, v) : 0;
+    D[v] = 0;
+    sslot[v] = 0;
   }
-  if (tid == 0) flag_bad = flag_arity = flag_more = used_max = 0;
+  if (tid == 0) flag_bad = flag_arity = more[0] = more[1] = more[2] = used_max = 0;
   __syncthreads();
-  for (int v = tid; v < nodes_in - 1; v += kSetupThreads) {
+  for (int v = tid; v < nodes_in - 1; v += nthreads) {
     const int p = par[v];
     if (p <= v || p >= nodes_in || p < n) flag_bad = 1;
   }
   __syncthreads();
   int status = flag_bad ? kBadParentIds : kOk;
   if (status == kOk) {
-    for (int v = tid; v < nodes_in - 1; v += kSetupThreads) {
+    for (int v = tid; v < nodes_in - 1; v += nthreads) {
       const int p = par[v];
-      const int k = atomicAdd(&cnt[p], 1);
-      if (k < 3) kids[3 * p + k] = v;
+      const int k = atomicAdd(&kid_i[4 * p + 3], 1);
+      if (k < 3) kid_i[4 * p + k] = v;
     }
     __syncthreads();
-    for (int v = n + tid; v < nodes_in; v += kSetupThreads) {
+    for (int v = n + tid; v < nodes_in; v += nthreads) {
       const int want = (!a.rooted && v == root_in) ? 3 : 2;
-      if (cnt[v] != want) flag_arity = 1;
+      if (kid_i[4 * v + 3] != want) flag_arity = 1;
     }
     __syncthreads();
     if (flag_arity) status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
   }
+  int round = 0;
+  // one barrier per round: three flags in rotation (set in round r, read after its barrier,
+  // cleared a round later, set again two rounds after that)
+  auto end_round = [&]() {
+    __syncthreads();
+    const int m = more[round % 3];
+    if (tid == 0) more[(round + 2) % 3] = 0;
+    round++;
+    return m;
+  };
   if (status == kOk) {
-    // ---- bottom-up: largest leaf, label, internal-node count, class
-    for (;;) {
-      for (int v = n + tid; v < nodes_in; v += kSetupThreads) {
-        if (done[v]) continue;
-        const int k = cnt[v];
-        const int a0 = kids[3 * v], a1 = kids[3 * v + 1], a2 = k == 3 ? kids[3 * v + 2] : a0;
-        if (!(done[a0] && done[a1] && done[a2])) {
-          flag_more = 1;
+    // ---- bottom-up: largest leaf, label, internal-node count, class.  A thread keeps what
+    // is fixed about its (up to kSetupOwn) nodes in registers: a round costs it one LDS round
+    // trip (its children's words) and the barrier.
+    int own_k0[kSetupOwn], own_k1[kSetupOwn], own_k2[kSetupOwn];
+    bool own_todo[kSetupOwn];
+#pragma unroll
+    for (int i = 0; i < kSetupOwn; i++) {
+      const int v = n + tid + i * nthreads;
+      own_todo[i] = v < nodes_in;
+      const int vv = own_todo[i] ? v : n;
+      own_k0[i] = kid[vv].x;
+      own_k1[i] = kid[vv].y;
+      own_k2[i] = kid[vv].w == 3 ? kid[vv].z : kid[vv].x;
+    }
+    do {
+#pragma unroll
+      for (int i = 0; i < kSetupOwn; i++) {
+        if (!own_todo[i]) continue;
+        const int v = n + tid + i * nthreads;
+        const int k0 = own_k0[i], k1 = own_k1[i];
+        const uint64_t w0 = W[k0], w1 = W[k1], w2 = W[own_k2[i]];
+        if (!((w0 & w1 & w2) >> 63)) {
+          more[round % 3] = 1;
           continue;
         }
-        const int m01 = mxl[a0] > mxl[a1] ? mxl[a0] : mxl[a1];
-        mxl[v] = m01 > mxl[a2] ? m01 : mxl[a2];
-        if (k == 2) {  // (the trifurcating root is re-shaped below)
-          const int l0 = label[a0], l1 = label[a1];
-          label[v] = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
-          isz[v] = isz[a0] + isz[a1] + 1;
-          const bool unstored = (a0 < n || cls[a0] == 1) && (a1 < n || cls[a1] == 1);
-          cls[v] = unstored ? 2 : 1;
-        }
-        __threadfence_block();
-        done[v] = 1;
+        const int m01 = up_mxl(w0) > up_mxl(w1) ? up_mxl(w0) : up_mxl(w1);
+        const int mx = m01 > up_mxl(w2) ? m01 : up_mxl(w2);
+        // (label, count and class of the trifurcating root are re-made below)
+        const int l0 = up_label(w0), l1 = up_label(w1);
+        const bool unstored = (k0 < n || up_cls(w0) == 1) && (k1 < n || up_cls(w1) == 1);
+        W[v] = up_word(unstored ? 2 : 1, l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1),
+                       up_isz(w0) + up_isz(w1) + 1, mx);
+        own_todo[i] = false;
       }
-      __syncthreads();
-      const int more = flag_more;
-      __syncthreads();
-      if (!more) break;
-      if (tid == 0) flag_more = 0;
-      __syncthreads();
-    }
-    // ---- children in order of their largest leaf id; the root re-shaped (Detrifurcate)
-    for (int v = n + tid; v < nodes_in; v += kSetupThreads) {
-      int k0 = kids[3 * v], k1 = kids[3 * v + 1];
-      if (mxl[k0] > mxl[k1]) { const int x = k0; k0 = k1; k1 = x; }
-      if (cnt[v] == 2) {
-        c0[v] = k0;
-        c1[v] = k1;
+    } while (end_round());
+    // ---- children in order of their largest leaf id; the root re-shaped (Detrifurcate);
+    // what each internal child will need from its parent in the top-down sweep
+    auto link = [&](int v, int a0, int a1, uint64_t w0, uint64_t w1) {
+      const bool first0 = up_label(w0) >= up_label(w1);
+      cc[v].x = a0;
+      cc[v].y = a1 | (first0 ? 1 << 30 : 0);
+      const int hi = first0 ? a0 : a1, lo = first0 ? a1 : a0;
+      const int hi_isz = first0 ? up_isz(w0) : up_isz(w1);
+      if (hi >= n) {
+        up[hi].x = v;
+        up[hi].y = 0;
+      }
+      if (lo >= n) {
+        up[lo].x = v;
+        up[lo].y = hi_isz | (hi >= n ? 1 << 24 : 0);  // start += internal(hi), slot += [hi internal]
+      }
+    };
+    auto join = [&](uint64_t w0, uint64_t w1, int a0, int a1, bool root) {
+      const int l0 = up_label(w0), l1 = up_label(w1);
+      const bool unstored = (a0 < n || up_cls(w0) == 1) && (a1 < n || up_cls(w1) == 1);
+      return up_word(root ? 1 : (unstored ? 2 : 1), l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1),
+                     up_isz(w0) + up_isz(w1) + 1, 0);
+    };
+    for (int v = n + tid; v < nodes_in; v += nthreads) {
+      int k0 = kid[v].x, k1 = kid[v].y;
+      uint64_t w0 = W[k0], w1 = W[k1];
+      if (up_mxl(w0) > up_mxl(w1)) {
+        const int x = k0; k0 = k1; k1 = x;
+        const uint64_t y = w0; w0 = w1; w1 = y;
+      }
+      if (kid[v].w == 2) {
+        link(v, k0, k1, w0, w1);
+        if (v == N - 1) W[v] = join(w0, w1, k0, k1, true);  // (rooted: the root's class is 1)
       } else {
-        int k2 = kids[3 * v + 2];
-        if (mxl[k1] > mxl[k2]) { const int x = k1; k1 = k2; k2 = x; }
-        if (mxl[k0] > mxl[k1]) { const int x = k0; k0 = k1; k1 = x; }
+        int k2 = kid[v].z;
+        uint64_t w2 = W[k2];
+        if (up_mxl(w1) > up_mxl(w2)) {
+          const int x = k1; k1 = k2; k2 = x;
+          const uint64_t y = w1; w1 = w2; w2 = y;
+        }
+        if (up_mxl(w0) > up_mxl(w1)) {
+          const int x = k0; k0 = k1; k1 = x;
+          const uint64_t y = w0; w0 = w1; w1 = y;
+        }
         // (k0,k1,k2) at root r  ->  r = (k1,k2), r+1 = (k0, r)
         const int r = v;
-        c0[r] = k1;
-        c1[r] = k2;
-        c0[r + 1] = k0;
-        c1[r + 1] = r;
-        int l0 = label[k1], l1 = label[k2];
-        label[r] = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
-        isz[r] = isz[k1] + isz[k2] + 1;
-        cls[r] = ((k1 < n || cls[k1] == 1) && (k2 < n || cls[k2] == 1)) ? 2 : 1;
-        l0 = label[k0];
-        l1 = label[r];
-        label[r + 1] = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
-        isz[r + 1] = isz[k0] + isz[r] + 1;
+        const uint64_t wr = join(w1, w2, k1, k2, false);
+        W[r] = wr;
+        W[r + 1] = join(w0, wr, k0, r, true);
+        link(r, k1, k2, w1, w2);
+        link(r + 1, k0, r, w0, wr);
       }
     }
-    __syncthreads();
-    for (int v = n + tid; v < N; v += kSetupThreads) done[v] = 0;
-    if (tid == 0) {
-      cls[N - 1] = 1;
-      flag_more = 0;
-    }
-    __syncthreads();
-    if (tid == 0) done[N - 1] = 1;  // (start = base = 0)
+    if (tid == 0) D[N - 1] = 1ull << 63;  // the root: ready, slot 0, start 0
     __syncthreads();
     // ---- top-down: position in the post-order and LDS slot; the schedule entries
-    for (;;) {
-      for (int v = n + tid; v < N; v += kSetupThreads) {
-        if (done[v] != 1) continue;
-        const int a0 = c0[v], a1 = c1[v];
-        const bool first0 = label[a0] >= label[a1];
-        const int hi = first0 ? a0 : a1, lo = first0 ? a1 : a0;
-        const int b = base[v], st = start[v];
-        const int blo = b + (hi >= n ? 1 : 0);
-        if (hi >= n) {
-          base[hi] = b;
-          start[hi] = st;
-        }
-        if (lo >= n) {
-          base[lo] = blo;
-          start[lo] = st + isz[hi];
-        }
-        __threadfence_block();
-        if (hi >= n) done[hi] = 1;
-        if (lo >= n) done[lo] = 1;
-        done[v] = 2;
-        const int s0 = a0 < n ? 0 : (a0 == hi ? b : blo), s1 = a1 < n ? 0 : (a1 == hi ? b : blo);
-        sched[st + isz[v] - 1] = {v, a0, a1, b | (s0 << 8) | (s1 << 16) | ((a0 < n ? 1 : 0) << 24) |
-                                                 ((a1 < n ? 1 : 0) << 25)};
-        atomicMax(&used_max, b + 1);
-        flag_more = 1;
-      }
-      __syncthreads();
-      const int more = flag_more;
-      __syncthreads();
-      if (!more) break;
-      if (tid == 0) flag_more = 0;
-      __syncthreads();
+    int own_p[kSetupOwn], own_off[kSetupOwn];
+#pragma unroll
+    for (int i = 0; i < kSetupOwn; i++) {
+      const int v = n + tid + i * nthreads;
+      own_todo[i] = v < N;
+      const int vv = own_todo[i] ? v : n;
+      own_p[i] = vv == N - 1 ? vv : up[vv].x;  // (the root waits for itself: ready from the start)
+      own_off[i] = vv == N - 1 ? 0 : up[vv].y;
     }
+    do {
+#pragma unroll
+      for (int i = 0; i < kSetupOwn; i++) {
+        if (!own_todo[i]) continue;
+        const int v = n + tid + i * nthreads;
+        const uint64_t dp = D[own_p[i]];
+        if (!(dp >> 63)) {
+          more[round % 3] = 1;
+          continue;
+        }
+        const int off = own_off[i];
+        const int b = ((int)(dp >> 32) & 0xffff) + ((off >> 24) & 1);
+        const int st = (int)(dp & 0xffffffffu) + (off & 0xffffff);
+        if (v != N - 1) D[v] = (1ull << 63) | ((uint64_t)b << 32) | (uint64_t)st;
+        const int a0 = cc[v].x, a1f = cc[v].y, a1 = a1f & 0xfffff;
+        const bool first0 = (a1f >> 30) & 1;
+        const int hi = first0 ? a0 : a1;
+        const int blo = b + (hi >= n ? 1 : 0);
+        const int s0 = a0 < n ? 0 : (a0 == hi ? b : blo), s1 = a1 < n ? 0 : (a1 == hi ? b : blo);
+        sched[st + up_isz(W[v]) - 1] = {v, a0, a1, b | (s0 << 8) | (s1 << 16) | ((a0 < n ? 1 : 0) << 24) |
+                                                      ((a1 < n ? 1 : 0) << 25)};
+        atomicMax(&used_max, b + 1);
+        own_todo[i] = false;
+      }
+    } while (end_round());
     if (used_max > a.max_slots) status = kTooManySlots;
     // ---- schedule of the on-chip gradient kernel (see tree_setup_kernel)
     if (a.macros) {
-      const int lane = tid & 63, wave = tid >> 6, waves = kSetupThreads / 64;
+      const int lane = tid & 63, wave = tid >> 6, waves = nthreads / 64;
       const int chunks = (N - 1 - n + 63) / 64;  // nodes n .. N-2 in chunks of 64
       for (int c = wave; c < chunks; c += waves) {
         const int v = n + c * 64 + lane;
-        const bool st = v < N - 1 && cls[v] == 1;
+        const bool st = v < N - 1 && up_cls(W[v < N ? v : N - 1]) == 1;
         const unsigned long long m = __ballot(st);
         if (st) sslot[v] = __popcll(m & ((1ull << lane) - 1));
         if (lane == 0) chunk_tot[c] = __popcll(m);
@@ -409,12 +452,12 @@ __global__ __launch_bounds__(kSetupThreads) void tree_setup_wg_kernel(TreeSetupA
       }
       __syncthreads();
       const int stored = sslot[N - 1];
-      for (int v = n + tid; v < N - 1; v += kSetupThreads)
-        if (cls[v] == 1) sslot[v] += chunk_tot[(v - n) >> 6];
+      for (int v = n + tid; v < N - 1; v += nthreads)
+        if (up_cls(W[v]) == 1) sslot[v] += chunk_tot[(v - n) >> 6];
       __syncthreads();
       MacroEntry* mac = a.macros + (size_t)t * max_macros(n);
-      for (int v = n + tid; v < N; v += kSetupThreads) {
-        if (cls[v] != 1) continue;
+      for (int v = n + tid; v < N; v += nthreads) {
+        if (up_cls(W[v]) != 1) continue;
         const bool root = v == N - 1;
         MacroEntry me;
         int kind[2];
@@ -422,12 +465,13 @@ __global__ __launch_bounds__(kSetupThreads) void tree_setup_wg_kernel(TreeSetupA
         me.pad = 0;
         me.qslot = root ? -1 : sslot[v];
         for (int j = 0; j < 2; j++) {
-          const int ch = j ? c1[v] : c0[v];
+          const int ch = j ? (cc[v].y & 0xfffff) : cc[v].x;
+          const int ccls = ch < n ? 0 : up_cls(W[ch]);
           me.child[j] = ch;
-          kind[j] = ch < n ? 0 : cls[ch];
-          me.cslot[j] = (ch >= n && cls[ch] == 1) ? sslot[ch] : 0;
-          const bool expand = ch >= n && cls[ch] == 2;
-          const int ga = expand ? c0[ch] : 0, gb = expand ? c1[ch] : 0;
+          kind[j] = ccls;
+          me.cslot[j] = ccls == 1 ? sslot[ch] : 0;
+          const bool expand = ccls == 2;
+          const int ga = expand ? cc[ch].x : 0, gb = expand ? (cc[ch].y & 0xfffff) : 0;
           me.grand[2 * j] = ga;
           me.grand[2 * j + 1] = gb;
           me.gslot[2 * j] = ga >= n ? sslot[ga] : 0;
@@ -447,17 +491,17 @@ __global__ __launch_bounds__(kSetupThreads) void tree_setup_wg_kernel(TreeSetupA
   __syncthreads();
   if (!ok_flag) {
     if (tid == 0 && a.macro_count) a.macro_count[t] = 0;
-    for (int i = tid; i < n - 1; i += kSetupThreads) sched[i] = {n + i, 0, 1, 0};
-    for (int v = tid; v < N; v += kSetupThreads) ble[v] = 0.0;
+    for (int i = tid; i < n - 1; i += nthreads) sched[i] = {n + i, 0, 1, 0};
+    for (int v = tid; v < N; v += nthreads) ble[v] = 0.0;
     return;
   }
   if (!a.rooted) {
     const double* bl = a.bl + (size_t)t * (N - 1);
-    for (int v = tid; v < N; v += kSetupThreads) ble[v] = v < N - 2 ? bl[v] : 0.0;
+    for (int v = tid; v < N; v += nthreads) ble[v] = v < N - 2 ? bl[v] : 0.0;
   } else {
     const double* bl = a.bl + (size_t)t * N;
     const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
-    for (int v = tid; v < N; v += kSetupThreads)
+    for (int v = tid; v < N; v += nthreads)
       ble[v] = (rates && v < N - 1) ? bl[v] * rates[v] : bl[v];
   }
 }
@@ -1103,42 +1147,41 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
 // ------------------------------------------------------------------------
 // Launch wrappers
 // ------------------------------------------------------------------------
-static bool force_wg_env() {
-  static const bool f = [] {
-    const char* env = getenv("MI_PHYLO_TREE_SETUP");
-    return env && std::string(env) == "wg";
-  }();
-  return f;
-}
 void launch_setup(const TreeSetupArgs& a_in, const ModelSetupArgs& ms, hipStream_t s) {
   TreeSetupArgs a = a_in;
   const size_t lds = sizeof(int32_t) * 13 * (size_t)(2 * a.n - 1);
-  a.use_lds = lds <= 64 * 1024;  // (N <= 1260: the 512-taxon trees of the 20-state bench)
-  // MI_PHYLO_TREE_SETUP=lds forces the general kernel (testing)
-  static const bool force_lds = [] {
-    const char* env = getenv("MI_PHYLO_TREE_SETUP");
-    return env && std::string(env) == "lds";
-  }();
+  a.use_lds = lds <= 64 * 1024;
+  // Three kernels build the same schedule (tests/test_cpp_adapter_gpu.py compares them bit for
+  // bit).  Measured, 1000 trees per launch: DS1 (53 nodes) register-array kernel 13 us /
+  // workgroup kernel 20 us; fluA (137 nodes) 63 / 41 us; one 512-taxon tree: sequential
+  // 840 us / workgroup 38 us.  So: register arrays up to 64 nodes, a workgroup per tree above,
+  // the sequential kernel only for trees whose arrays exceed the LDS.
+  // MI_PHYLO_TREE_SETUP=small|wg|lds forces one of them where it applies (testing).
+  static const std::string forced = getenv("MI_PHYLO_TREE_SETUP") ? getenv("MI_PHYLO_TREE_SETUP") : "";
   const int N = 2 * a.n - 1;
-  // T workgroups of trees, then the model instances, 64 per workgroup
-  const dim3 grid(a.T + (ms.T * ms.models_per_tree + 63) / 64), block(64);
-  if (a.n >= 3 && N <= 256 && !force_lds && !force_wg_env()) {
+  const size_t wg_lds = sizeof(int32_t) * kSetupArrays * (size_t)N;
+  const bool small_ok = a.n >= 3 && N <= 256, wg_ok = a.n >= 3 && wg_lds <= 160 * 1024 - 1024;
+  const bool use_small = small_ok && (forced == "small" || (forced.empty() && N <= 64));
+  const bool use_wg = !use_small && wg_ok && forced != "lds" && !(forced == "small" && small_ok);
+  if (use_small) {
+    // T workgroups of trees, then the model instances, 64 per workgroup
+    const dim3 grid(a.T + (ms.T * ms.models_per_tree + 63) / 64), block(64);
     if (N <= 64) hipLaunchKernelGGL(tree_setup_small_kernel<1>, grid, block, 0, s, a, ms);
     else if (N <= 128) hipLaunchKernelGGL(tree_setup_small_kernel<2>, grid, block, 0, s, a, ms);
     else if (N <= 192) hipLaunchKernelGGL(tree_setup_small_kernel<3>, grid, block, 0, s, a, ms);
     else hipLaunchKernelGGL(tree_setup_small_kernel<4>, grid, block, 0, s, a, ms);
     return;
   }
-  // Larger trees: a workgroup per tree (thread per node) while its arrays fit the LDS;
-  // MI_PHYLO_TREE_SETUP=wg forces it for small trees too (testing)
-  const bool force_wg = force_wg_env();
-  const size_t wg_lds = sizeof(int32_t) * kSetupArrays * (size_t)N;
-  if (a.n >= 3 && wg_lds <= 160 * 1024 - 1024 && (!force_lds || force_wg)) {
-    const dim3 wgrid(a.T + (ms.T * ms.models_per_tree + kSetupThreads - 1) / kSetupThreads);
+  if (use_wg) {
+    // (a thread per internal node, at most kSetupOwn of them per thread: the LDS bound keeps
+    // N below 2 600)
+    const int threads = a.n >= kSetupMaxThreads ? kSetupMaxThreads : (a.n + 63) / 64 * 64;
+    const dim3 wgrid(a.T + (ms.T * ms.models_per_tree + threads - 1) / threads);
     allow_large_lds(reinterpret_cast<const void*>(tree_setup_wg_kernel), wg_lds);
-    hipLaunchKernelGGL(tree_setup_wg_kernel, wgrid, dim3(kSetupThreads), wg_lds, s, a, ms);
+    hipLaunchKernelGGL(tree_setup_wg_kernel, wgrid, dim3(threads), wg_lds, s, a, ms);
     return;
   }
+  const dim3 grid(a.T + (ms.T * ms.models_per_tree + 63) / 64), block(64);
   hipLaunchKernelGGL(tree_setup_kernel, grid, block, a.use_lds ? lds : 0, s, a, ms);
 }
 void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s) {  // trees only

@@ -49,8 +49,8 @@ def test_tree_setup_kernels_agree(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         return np.fromfile(out, dtype=np.int32)
 
-    # small trees: register-array kernel (default) == sequential LDS kernel == workgroup kernel;
-    # large trees (> 256 nodes): workgroup kernel (default) == sequential LDS kernel
+    # up to 64 nodes the register-array kernel is the default, above the workgroup kernel;
+    # every kernel that applies to a size == the sequential LDS kernel
     for n in (3, 4, 5, 6, 9, 17, 27, 32, 33, 50, 64, 65, 69, 100, 128, 129, 200, 333, 512, 700):
         for rooted in (0, 1):
             if rooted and n not in (3, 9, 69, 129, 512):
@@ -65,6 +65,7 @@ def test_tree_setup_kernels_agree(tmp_path):
             assert np.array_equal(dump(n, T, trees, "default", rooted), ref), f"n = {n}"
             if n <= 128:
                 assert np.array_equal(dump(n, T, trees, "wg", rooted), ref), f"n = {n} (wg)"
+                assert np.array_equal(dump(n, T, trees, "small", rooted), ref), f"n = {n} (small)"
     # invalid trees (one per batch: which bad tree is reported first is a race): the same
     # status from every kernel
     n, T = 40, 6
@@ -76,6 +77,6 @@ def test_tree_setup_kernels_agree(tmp_path):
             pids[4, 7] = pids[4, 60]      # an internal node with three children (or a bad id)
         trees = tmp_path / f"trees_bad{case}.bin"
         pids.astype(np.int32).tofile(trees)
-        heads = [dump(n, T, trees, mode, 0)[:2] for mode in ("lds", "default", "wg")]
+        heads = [dump(n, T, trees, mode, 0)[:2] for mode in ("lds", "default", "wg", "small")]
         assert heads[0][0] != 0
-        assert np.array_equal(heads[0], heads[1]) and np.array_equal(heads[0], heads[2]), heads
+        assert all(np.array_equal(heads[0], h) for h in heads[1:]), heads

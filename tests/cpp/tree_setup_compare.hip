@@ -32,8 +32,19 @@ int main(int argc, char** argv) {
   hipMemcpy(sc.data(), d_sched, sc.size() * sizeof(SchedEntry), hipMemcpyDeviceToHost);
   hipMemcpy(mac.data(), d_mac, mac.size() * sizeof(MacroEntry), hipMemcpyDeviceToHost);
   hipMemcpy(mc.data(), d_mc, T * 4, hipMemcpyDeviceToHost); hipMemcpy(st, d_status, 8, hipMemcpyDeviceToHost);
+  // the arena variant's macro order / LDS slots / arena indices (macro_slots kernels)
+  MacroEntry* d_mac2; int32_t* d_need;
+  hipMalloc(&d_mac2, sizeof(MacroEntry) * (size_t)T * max_macros(n)); hipMalloc(&d_need, T * 4);
+  hipMemset(d_mac2, 0, sizeof(MacroEntry) * (size_t)T * max_macros(n)); hipMemset(d_need, 0, T * 4);
+  std::vector<MacroEntry> mac2((size_t)T * max_macros(n)); std::vector<int32_t> need(T);
+  if (st[0] == 0) {
+    launch_macro_slots(d_mac, d_mac2, d_mc, n, T, d_need, d_status, nullptr); hipDeviceSynchronize();
+    hipMemcpy(mac2.data(), d_mac2, mac2.size() * sizeof(MacroEntry), hipMemcpyDeviceToHost);
+    hipMemcpy(need.data(), d_need, T * 4, hipMemcpyDeviceToHost);
+  }
   FILE* o = fopen(argv[4], "wb");
-  fwrite(st, 4, 2, o); fwrite(mc.data(), 4, T, o); fwrite(sc.data(), sizeof(SchedEntry), sc.size(), o); fwrite(mac.data(), sizeof(MacroEntry), mac.size(), o); fclose(o);
+  fwrite(st, 4, 2, o); fwrite(mc.data(), 4, T, o); fwrite(sc.data(), sizeof(SchedEntry), sc.size(), o); fwrite(mac.data(), sizeof(MacroEntry), mac.size(), o);
+  fwrite(need.data(), 4, T, o); fwrite(mac2.data(), sizeof(MacroEntry), mac2.size(), o); fclose(o);
   printf("status %d %d, macro_count[0]=%d\n", st[0], st[1], mc[0]);
   return 0;
 }

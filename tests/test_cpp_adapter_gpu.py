@@ -38,12 +38,15 @@ def test_tree_setup_kernels_agree(tmp_path):
                     "-L" + lib, "-lmi_phylo", "-Wl,-rpath," + lib, "-o", str(exe)], check=True)
     rng = np.random.default_rng(11)
 
-    def dump(n, T, trees, mode, rooted):
+    def dump(n, T, trees, mode, rooted, slots="default"):
         env = dict(os.environ)
         env.pop("MI_PHYLO_TREE_SETUP", None)
+        env.pop("MI_PHYLO_MACRO_SLOTS", None)
         if mode != "default":
             env["MI_PHYLO_TREE_SETUP"] = mode
-        out = tmp_path / f"dump_{n}_{mode}_{rooted}.bin"
+        if slots != "default":
+            env["MI_PHYLO_MACRO_SLOTS"] = slots
+        out = tmp_path / f"dump_{n}_{mode}_{rooted}_{slots}.bin"
         r = subprocess.run([str(exe), str(n), str(T), str(trees), str(out), str(rooted)], env=env,
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -61,7 +64,9 @@ def test_tree_setup_kernels_agree(tmp_path):
             pids[1] = TU.balanced_topology(n, rooted=bool(rooted))
             trees = tmp_path / f"trees_{n}_{rooted}.bin"
             pids.astype(np.int32).tofile(trees)
-            ref = dump(n, T, trees, "lds", rooted)
+            # (the dump ends with the macro order / LDS slots / arena indices of the arena variant:
+            # workgroup-per-tree macro_slots kernel by default, the sequential one for `ref`)
+            ref = dump(n, T, trees, "lds", rooted, slots="seq")
             assert np.array_equal(dump(n, T, trees, "default", rooted), ref), f"n = {n}"
             if n <= 128:
                 assert np.array_equal(dump(n, T, trees, "wg", rooted), ref), f"n = {n} (wg)"

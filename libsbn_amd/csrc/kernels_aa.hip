@@ -1124,10 +1124,6 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       }
     }
   };
-  auto stage0 = [&](int c0, int c1, int (&x)[2][M]) {
-    if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
-    if (c1 < n) load_tip_states<M>(a.tip_states + (size_t)c1 * tip_stride, p0, lane, x[1]);
-  };
   auto lds_pack = [&](const double* base, double (&A)[10]) {
 #pragma unroll
     for (int r = 0; r < 10; r++) A[r] = base[r * 64 + lane];
@@ -1154,27 +1150,31 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
   }
   // Everything a visit reads from global memory -- its children's post-order vectors, its own
   // pre-order vector unless the previous visit hands it over in registers, its exponents, the
-  // tip states, the LDS operands -- is requested during the visit BEFORE it and retired by that
-  // visit's one vmcnt(0): a visit's own arithmetic never waits for memory.
-  double q[M][5], L[2][M][5], qn[M][5], Ln[2][M][5];
-  int ev[M], evn[M];
+  // tip states, the LDS operands -- is requested during the visit BEFORE it, each into the
+  // registers that visit has just finished with (no second register set, no copies), and
+  // retired by that visit's one vmcnt(0): a visit's own arithmetic never waits for memory.
+  double q[M][5], L[2][M][5];
+  int ev[M];
 #pragma unroll
   for (int u = 0; u < M; u++) {
-    ev[u] = evn[u] = 0;
+    ev[u] = 0;
 #pragma unroll
-    for (int t = 0; t < 5; t++) q[u][t] = qn[u][t] = L[0][u][t] = L[1][u][t] = Ln[0][u][t] = Ln[1][u][t] = 0;
+    for (int t = 0; t < 5; t++) q[u][t] = L[0][u][t] = L[1][u][t] = 0;
   }
-  auto fetch = [&](int node, int c0, int c1, bool load_q, double (&Lx)[2][M][5], double (&qx)[M][5],
-                   int (&ex)[M]) {
-    if (c0 >= n) load_tiles<M>(arena + (size_t)(c0 - n) * arena_stride, lane, Lx[0]);
-    if (c1 >= n) load_tiles<M>(arena + (size_t)(c1 - n) * arena_stride, lane, Lx[1]);
-    if (load_q) load_tiles<M>(arena + (size_t)(node - n) * arena_stride, lane, qx);
-#pragma unroll
-    for (int u = 0; u < M; u++) ex[u] = exp_loc[(size_t)(node - n) * exp_stride + u * 16 + j];
+  auto fetch_children = [&](int node, int c0, int c1, int (&x)[2][M]) {
+    if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
+    if (c1 < n) load_tip_states<M>(a.tip_states + (size_t)c1 * tip_stride, p0, lane, x[1]);
+    if (c0 >= n) load_tiles<M>(arena + (size_t)(c0 - n) * arena_stride, lane, L[0]);
+    if (c1 >= n) load_tiles<M>(arena + (size_t)(c1 - n) * arena_stride, lane, L[1]);
   };
-  stage0(ch[0], ch[1], xc);
+  auto fetch_node = [&](int node, bool load_q) {
+    if (load_q) load_tiles<M>(arena + (size_t)(node - n) * arena_stride, lane, q);
+#pragma unroll
+    for (int u = 0; u < M; u++) ev[u] = exp_loc[(size_t)(node - n) * exp_stride + u * 16 + j];
+  };
   stage(ch[0], ch[1], (count - 1) & 1);
-  fetch(v, ch[0], ch[1], false, L, q, ev);
+  fetch_children(v, ch[0], ch[1], xc);
+  fetch_node(v, false);
   {
     const size_t rbase = ((size_t)el * K + cat) * tiles * 16 + p0;
 #pragma unroll
@@ -1197,9 +1197,6 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       nc0 = sgpr(s1.child0);
       nc1 = sgpr(s1.child1);
       stage(nc0, nc1, buf ^ 1);
-      stage0(nc0, nc1, xn);
-      // (the next node's pre-order vector comes from the arena unless this visit computes it)
-      fetch(next, nc0, nc1, next != ch[0] && next != ch[1], Ln, qn, evn);
     }
 #pragma unroll
     for (int u = 0; u < M; u++)
@@ -1224,6 +1221,10 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
         mat_apply<M>(A, L[c], S[c]);
       }
     }
+    // L is done with: the next visit's vectors go into it (and its tip states into xn); the
+    // compiler may not move these loads up: they follow a memory barrier
+    asm volatile("" ::: "memory");
+    if (i > 0) fetch_children(next, nc0, nc1, xn);
     // X_c = sum (q o S[sibling]) . Q S_c (tip: the column of P Q), tile by tile
     double X[2];
 #pragma unroll
@@ -1259,20 +1260,24 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
         S[1][u][t] = u0;
         S[0][u][t] = u1;
       }
-    // The visit's one wait: the DMA and the loads for the next visit, requested at its top.
-    // What they loaded is consumed HERE as far as the compiler is concerned, so that it puts
-    // its own waits before the stores below and none after them (the stores stay in flight).
+    // q is done with: the next node's (unless this visit computes it below) and its exponents
+    const bool keep = i > 0 && (next == ch[0] || next == ch[1]);
+    asm volatile("" ::: "memory");
+    if (i > 0) fetch_node(next, !keep);
+    // The visit's one wait: the DMA and the loads for the next visit.  What they loaded is
+    // consumed HERE as far as the compiler is concerned, so that it puts its own waits before
+    // the stores below and none after them (the stores stay in flight).
     wait_all_vm();
 #pragma unroll
     for (int u = 0; u < M; u++) {
       asm volatile("" : "+v"(xn[0][u]));
       asm volatile("" : "+v"(xn[1][u]));
-      asm volatile("" : "+v"(evn[u]));
+      asm volatile("" : "+v"(ev[u]));
 #pragma unroll
       for (int t = 0; t < 5; t++) {
-        asm volatile("" : "+v"(Ln[0][u][t]));
-        asm volatile("" : "+v"(Ln[1][u][t]));
-        asm volatile("" : "+v"(qn[u][t]));
+        asm volatile("" : "+v"(L[0][u][t]));
+        asm volatile("" : "+v"(L[1][u][t]));
+        asm volatile("" : "+v"(q[u][t]));
       }
     }
     if (lane == 0 && active) {
@@ -1280,7 +1285,6 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       store_async(gp + ch[1], X[1]);
     }
     // q_c = P_c^T u_c for internal children: into the arena, or handed to the next visit
-    bool keep = false;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       if (ch[c] < n || ch[c] == next) continue;
@@ -1295,7 +1299,6 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       double A[10];
       lds_pack(ops_lds[buf][c] + kAaPack, A);
       mat_apply<M>(A, S[1 - c], q);
-      keep = true;
     }
     lds_barrier();
     v = next;
@@ -1303,15 +1306,8 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
     ch[1] = nc1;
 #pragma unroll
     for (int u = 0; u < M; u++) {
-      ev[u] = evn[u];
       xc[0][u] = xn[0][u];
       xc[1][u] = xn[1][u];
-#pragma unroll
-      for (int t = 0; t < 5; t++) {
-        if (!keep) q[u][t] = qn[u][t];
-        L[0][u][t] = Ln[0][u][t];
-        L[1][u][t] = Ln[1][u][t];
-      }
     }
   }
 }

@@ -263,3 +263,45 @@ def test_builtin_wag_equals_explicit_table_and_errors():
     with pytest.raises(RuntimeError, match="one-hot"):
         L.Engine(L.PhyloModelSpecification("WAG", "constant", "strict"), None, w,
                  use_tip_states=False, tip_partials=tp)
+
+
+def test_kernel_forms_agree_bitwise(tmp_path):
+    """The wave-per-block walk kernels (MI_PHYLO_AA_POST=wave / MI_PHYLO_AA_PRE=wave, kept
+    selectable) and the workgroup kernels with LDS-DMA staging are the same arithmetic in the
+    same order: identical log-likelihoods and gradients.  (The switches are read once per
+    process: each form runs in its own interpreter.)"""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run_forms.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {repo!r}); sys.path.insert(0, {os.path.join(repo, 'tests')!r})\n"
+        "import libsbn_amd as L, aa_utils as A, tree_utils as TU\n"
+        "rng = np.random.default_rng(5)\n"
+        "tips, w = A.random_aa_alignment(41, 700, rng)\n"
+        "pids, bls = TU.random_trees(41, 3, rng)\n"
+        "pr = A.params_for('weibull+4', 3, rng)\n"
+        "eng = L.Engine(L.PhyloModelSpecification('WAG', 'weibull+4', 'strict'), tips, w)\n"
+        "g = eng.gradients(pids, bls, pr)\n"
+        "ll = eng.log_likelihoods(pids, bls, pr)\n"
+        "out = np.concatenate([ll, [x.log_likelihood for x in g]] + [x.gradient['branch_lengths'] for x in g]"
+        " + [np.atleast_1d(x.gradient['site_model']) for x in g])\n"
+        "np.save(sys.argv[1], out)\n")
+    outs = []
+    for post, pre in (("", ""), ("wave", ""), ("", "wave"), ("wave", "wave")):
+        env = dict(os.environ)
+        env.pop("MI_PHYLO_AA_POST", None)
+        env.pop("MI_PHYLO_AA_PRE", None)
+        if post:
+            env["MI_PHYLO_AA_POST"] = post
+        if pre:
+            env["MI_PHYLO_AA_PRE"] = pre
+        out = tmp_path / f"out_{post}_{pre}.npy"
+        r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True,
+                           text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(out))
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)

@@ -234,6 +234,16 @@ __global__ __launch_bounds__(256) void aa_transition_kernel(AaTransitionArgs a) 
 // Walk helpers
 // ------------------------------------------------------------------------
 __device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// a pointer that is the same in every lane, told to the compiler (scalar registers: loads and
+// stores through it take the scalar-base + lane-offset addressing form, no 64-bit vector adds)
+template <class T>
+__device__ __forceinline__ T* sgpr_ptr(T* p) {
+  const uint64_t x = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+  typedef T __attribute__((address_space(1))) * global_ptr;  // (keeps it a GLOBAL pointer: no flat loads)
+  return (T*)(global_ptr)(((uint64_t)hi << 32) | lo);
+}
 
 // S = Mat x L for M tiles of 16 patterns, the matrix given as its ten A-operand registers:
 // per tile five 16x16x4 steps (rows 0..15) and five 4x4x4 steps (rows 16..19)
@@ -266,7 +276,7 @@ template <int M>
 __device__ __forceinline__ void load_tip_states(const int8_t* __restrict__ tips, int p0, int lane,
                                                 int (&x)[M]) {
 #pragma unroll
-  for (int u = 0; u < M; u++) x[u] = tips[p0 + u * 16 + (lane & 15)];
+  for (int u = 0; u < M; u++) x[u] = (tips + p0)[(unsigned)(u * 16 + (lane & 15))];
 }
 // product of a tip child: column `state` of the matrix (tables [21][20])
 template <int M>
@@ -569,17 +579,20 @@ constexpr int kPostWaves = 4, kPostThreads = 64 * kPostWaves;
 // the top of the visit, the previous visit's stores) has had most of a visit to finish -- so
 // the stores themselves stay in flight across the barrier.
 typedef __attribute__((address_space(3))) void* lds_ptr;
-__device__ __forceinline__ void dma_1k(const double* src_lane, double* dst_lds) {
+// All of them address memory as (wave-uniform base in scalar registers) + (lane offset in
+// one vector register) + immediate: no 64-bit vector address arithmetic.
+__device__ __forceinline__ void dma_1k(const double* src, uint32_t lane16, double* dst_lds) {
   // (M0 is a reserved register: hipcc only writes it immediately before an instruction that
   // reads it, never keeps a value in it, so setting it here clobbers nothing)
   const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)dst_lds;
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(m0) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(src), "s"(m0) : "memory");
 }
 // Piece k of a table (128 doubles) is issued by wave (first + k) % waves of the workgroup.
 __device__ __forceinline__ void dma_table(const double* __restrict__ src, double* dst_lds,
                                           int pieces, int first, int wave, int waves, int lane) {
+  const uint32_t lane16 = (uint32_t)lane * 16;
   for (int k = 0; k < pieces; k++)
-    if ((first + k) % waves == wave) dma_1k(src + k * 128 + lane * 2, dst_lds + k * 128);
+    if ((first + k) % waves == wave) dma_1k(src + k * 128, lane16, dst_lds + k * 128);
 }
 // Stores the compiler does not see (same reason: a store it knows to be in flight turns its
 // next wait for any load into vmcnt(0), i.e. into a wait for the store's acknowledgement).
@@ -587,19 +600,21 @@ __device__ __forceinline__ void dma_table(const double* __restrict__ src, double
 // one vmcnt(0) per visit retires them a visit later.
 template <int M>
 __device__ __forceinline__ void store_tiles_async(double* dst, int lane, const double (&L)[M][5]) {
+  const uint32_t lane8 = (uint32_t)lane * 8;
 #pragma unroll
   for (int u = 0; u < M; u++) {
-    const double* p = dst + u * kAaTileDoubles + lane;
+    const double* p = dst + u * kAaTileDoubles;
 #pragma unroll
     for (int t = 0; t < 5; t++)
-      asm volatile("global_store_dwordx2 %0, %1, off offset:%2" ::"v"(p), "v"(L[u][t]), "n"(t * 512) : "memory");
+      asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(lane8), "v"(L[u][t]), "s"(p), "n"(t * 512) : "memory");
   }
 }
-__device__ __forceinline__ void store_async(int32_t* p, int v) {
-  asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+// (base: wave-uniform; index: this lane's element)
+__device__ __forceinline__ void store_async(int32_t* base, int index, int v) {
+  asm volatile("global_store_dword %0, %1, %2" ::"v"((uint32_t)index * 4), "v"(v), "s"(base) : "memory");
 }
-__device__ __forceinline__ void store_async(double* p, double v) {
-  asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+__device__ __forceinline__ void store_async(double* base, int index, double v) {
+  asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)index * 8), "v"(v), "s"(base) : "memory");
 }
 __device__ __forceinline__ void wait_all_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // workgroup barrier that orders LDS traffic only (no vmcnt: stores stay in flight)
@@ -620,13 +635,13 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
   const int blk = active ? blk_raw : blocks - 1;
   const int tree = a.eval_offset + el;
   const int n = a.n, K = a.K;
-  const int p0 = blk * M * 16;
+  const int p0 = sgpr(blk * M * 16);
   const size_t tiles = a.tiles, tip_stride = tiles * 16;
   const int nodes = GRAD ? n - 1 : a.slots;
-  double* arena = a.arena + (((size_t)el * nodes * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles;
+  double* arena = sgpr_ptr(a.arena + (((size_t)el * nodes * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles);
   const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;
-  int32_t* exp_cum = a.exp_cum + ((size_t)el * nodes * K + cat) * tiles * 16 + p0;
-  int32_t* exp_loc = GRAD ? a.exp_loc + ((size_t)el * (n - 1) * K + cat) * tiles * 16 + p0 : nullptr;
+  int32_t* exp_cum = sgpr_ptr(a.exp_cum + ((size_t)el * nodes * K + cat) * tiles * 16 + p0);
+  int32_t* exp_loc = GRAD ? sgpr_ptr(a.exp_loc + ((size_t)el * (n - 1) * K + cat) * tiles * 16 + p0) : nullptr;
   const size_t exp_stride = (size_t)K * tiles * 16;
   const double* matP = a.matP + ((size_t)el * (n - 1) * K + cat) * kAaPack;
   const double* tipP = a.tipP + ((size_t)el * n * K + cat) * kAaTipTable;
@@ -768,8 +783,8 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
         if (g == 0) {
 #pragma unroll
           for (int u = 0; u < M; u++) {
-            store_async(exp_loc + (size_t)(prev - n) * exp_stride + u * 16 + j, eloc[u]);
-            store_async(exp_cum + (size_t)(prev - n) * exp_stride + u * 16 + j, E[u]);
+            store_async(exp_loc + (size_t)(prev - n) * exp_stride, u * 16 + j, eloc[u]);
+            store_async(exp_cum + (size_t)(prev - n) * exp_stride, u * 16 + j, E[u]);
           }
         }
       } else if (prev != ch0 && prev != ch1) {
@@ -777,7 +792,7 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
         store_tiles_async<M>(arena + dst * arena_stride, lane, R);
         if (g == 0) {
 #pragma unroll
-          for (int u = 0; u < M; u++) store_async(exp_cum + dst * exp_stride + u * 16 + j, E[u]);
+          for (int u = 0; u < M; u++) store_async(exp_cum + dst * exp_stride, u * 16 + j, E[u]);
         }
       }
     }
@@ -897,7 +912,7 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
   const int el = un.ec / a.K, cat = un.ec - el * a.K, blk = un.blk;
   const int tree = a.eval_offset + el;
   const int n = a.n, N = a.N, K = a.K;
-  const int p0 = blk * M * 16;
+  const int p0 = sgpr(blk * M * 16);
   const size_t tiles = a.tiles, tip_stride = tiles * 16;
   double* arena = a.arena + (((size_t)el * (n - 1) * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles;
   const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;
@@ -1082,18 +1097,18 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
   const int blk = active ? blk_raw : blocks - 1;
   const int tree = a.eval_offset + el;
   const int n = a.n, N = a.N, K = a.K;
-  const int p0 = blk * M * 16;
+  const int p0 = sgpr(blk * M * 16);
   const size_t tiles = a.tiles, tip_stride = tiles * 16;
-  double* arena = a.arena + (((size_t)el * (n - 1) * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles;
+  double* arena = sgpr_ptr(a.arena + (((size_t)el * (n - 1) * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles);
   const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;
-  const int32_t* exp_loc = a.exp_loc + ((size_t)el * (n - 1) * K + cat) * tiles * 16 + p0;
+  const int32_t* exp_loc = sgpr_ptr(a.exp_loc + ((size_t)el * (n - 1) * K + cat) * tiles * 16 + p0);
   const size_t exp_stride = (size_t)K * tiles * 16;
   const size_t mbase = ((size_t)el * (n - 1) * K + cat) * kAaPack;
   const double* matP = a.matP + mbase;
   const double* matPT = a.matPT + mbase;
   const double* tipP = a.tipP + ((size_t)el * n * K + cat) * kAaTipTable;
   const double* tipPQ = a.tipPQ + ((size_t)el * n * K + cat) * kAaTipTable;
-  double* gp = a.g_part + (((size_t)el * K + cat) * blocks + blk) * N;
+  double* gp = sgpr_ptr(a.g_part + (((size_t)el * K + cat) * blocks + blk) * N);
   const int count = n - 1;
   for (int idx = tid; idx < kAaPack; idx += kPreThreads) q_lds[idx] = a.model->Qpack[idx];
   SchedWindow win{a.sched + (size_t)tree * count, sched_lds, count, 0, tid};
@@ -1281,8 +1296,8 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       }
     }
     if (lane == 0 && active) {
-      store_async(gp + ch[0], X[0]);
-      store_async(gp + ch[1], X[1]);
+      store_async(gp + ch[0], 0, X[0]);
+      store_async(gp + ch[1], 0, X[1]);
     }
     // q_c = P_c^T u_c for internal children: into the arena, or handed to the next visit
 #pragma unroll

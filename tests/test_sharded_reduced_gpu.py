@@ -181,7 +181,18 @@ def test_device_call_replays_from_a_hip_graph():
     p2, b2 = TU.random_trees(10, 3, rng)
     cases.append((L.Engine(L.PhyloModelSpecification("WAG", "weibull+4", "strict"), tips, w),
                   p2, b2, np.ones((3, 2))))
-    for eng, pids, bls, pr in cases:
+    # two more, captured WITHOUT a warm-up call: the arena variant of the 4-state gradient
+    # kernel (workgroup-per-tree set-up and macro-slot kernels) and a 20-state engine whose
+    # tree set-up kernel needs more than 64 KiB of LDS (opt-in attribute set at first launch)
+    tips, w = TU.random_alignment(40, 200, rng)
+    p3, b3 = TU.random_trees(40, 5, rng)
+    cases.append((L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w),
+                  p3, b3, np.ones((5, 2))))
+    tips, w = A.random_aa_alignment(600, 64, rng)
+    p4, b4 = TU.random_trees(600, 2, rng)
+    cases.append((L.Engine(L.PhyloModelSpecification("WAG", "weibull+4", "strict"), tips, w),
+                  p4, b4, np.ones((2, 2))))
+    for case, (eng, pids, bls, pr) in enumerate(cases):
         T, N = len(pids), eng.node_count
         d_pid = torch.from_numpy(np.ascontiguousarray(pids)).to(dev)
         d_bl = torch.from_numpy(np.ascontiguousarray(bls)).to(dev)
@@ -194,7 +205,8 @@ def test_device_call_replays_from_a_hip_graph():
         def call(stream):
             eng.gradients_device(stream, T, d_pid.data_ptr(), d_bl.data_ptr(), d_pr.data_ptr(),
                                  ll.data_ptr(), g.data_ptr(), site.data_ptr(), None)
-        call(torch.cuda.current_stream().cuda_stream)  # warm-up outside the capture
+        if case < 2:
+            call(torch.cuda.current_stream().cuda_stream)  # warm-up outside the capture
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=torch.cuda.Stream()):

@@ -541,7 +541,13 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   if (states == kAa) {
     e->tiles = aa_tiles(e->P);
     e->ll_stride = aa_ll_blocks(e->P);
-    e->plv_budget = (size_t)48 << 30;  // 32 MB per vector at 50 000 patterns x 4 categories
+    // 32 MB per vector at 50 000 patterns x 4 categories, 16.4 GB per gradient tree of 512
+    // taxa: the arena gets half of what the device has free now (an MI355X has 288 GB; more
+    // trees per launch fill its 256 CUs better: 8 such trees in one launch instead of 3 + 3 + 2
+    // are 8 % quicker), never less than 8 GB; aa_reserve backs off if that cannot be had
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)96 << 30;
+    e->plv_budget = std::max<size_t>(free_b / 2, (size_t)8 << 30);
   } else {
     e->tiles = (e->P + kTile - 1) / kTile;
     e->ll_stride =

@@ -70,23 +70,36 @@ int aa_reserve(mi_engine* e, int T, bool gradient) {
   if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
   if (e->status.ensure(sizeof(int32_t) * 2)) return 1;
   if (e->ll_sum.ensure(sizeof(double) * (size_t)T)) return 1;
-  const size_t chunk = aa_chunk(e, T, gradient);
-  if (e->plv.ensure(aa_arena_bytes_per_eval(e, gradient) * chunk)) return 1;
-  const size_t nodes = gradient ? n - 1 : e->max_slots;
-  if (e->aa_exp_cum.ensure(sizeof(int32_t) * chunk * nodes * K * tp)) return 1;
-  if (e->aa_matP.ensure(sizeof(double) * chunk * (n - 1) * K * kAaPack)) return 1;
-  // (+1 KB: the LDS-DMA of the last tip table reads a whole number of 1 KB pieces)
-  if (e->aa_tipP.ensure(sizeof(double) * (chunk * n * K * kAaTipTable + 128))) return 1;
-  if (e->aa_root_val.ensure(sizeof(double) * chunk * K * tp)) return 1;
-  if (e->aa_root_exp.ensure(sizeof(int32_t) * chunk * K * tp)) return 1;
-  if (gradient) {
-    if (e->aa_exp_loc.ensure(sizeof(int32_t) * chunk * (n - 1) * K * tp)) return 1;
-    if (e->aa_matPT.ensure(sizeof(double) * chunk * (n - 1) * K * kAaPack)) return 1;
-    if (e->aa_tipPQ.ensure(sizeof(double) * (chunk * n * K * kAaTipTable + 128))) return 1;
-    if (e->aa_root_scale.ensure(sizeof(double) * chunk * K * tp)) return 1;
-    if (e->g_part.ensure(sizeof(double) * chunk * K * (tiles / kAaPreTiles) * N)) return 1;
-    if (e->g_sum.ensure(sizeof(double) * (size_t)T * 2 * N)) return 1;
+  // The partial-vector arena and what scales with it: as many evaluations per launch as the
+  // budget allows (default: half of the device memory that was free when the engine was made;
+  // MI_PHYLO_PLV_BYTES).  If the device cannot give that much after all -- other engines,
+  // other users of the GPU -- the budget is halved until the allocation succeeds.
+  auto alloc_chunk = [&](size_t chunk) -> int {
+    if (e->plv.ensure(aa_arena_bytes_per_eval(e, gradient) * chunk)) return 1;
+    const size_t nodes = gradient ? n - 1 : e->max_slots;
+    if (e->aa_exp_cum.ensure(sizeof(int32_t) * chunk * nodes * K * tp)) return 1;
+    if (e->aa_matP.ensure(sizeof(double) * chunk * (n - 1) * K * kAaPack)) return 1;
+    // (+1 KB: the LDS-DMA of the last tip table reads a whole number of 1 KB pieces)
+    if (e->aa_tipP.ensure(sizeof(double) * (chunk * n * K * kAaTipTable + 128))) return 1;
+    if (e->aa_root_val.ensure(sizeof(double) * chunk * K * tp)) return 1;
+    if (e->aa_root_exp.ensure(sizeof(int32_t) * chunk * K * tp)) return 1;
+    if (gradient) {
+      if (e->aa_exp_loc.ensure(sizeof(int32_t) * chunk * (n - 1) * K * tp)) return 1;
+      if (e->aa_matPT.ensure(sizeof(double) * chunk * (n - 1) * K * kAaPack)) return 1;
+      if (e->aa_tipPQ.ensure(sizeof(double) * (chunk * n * K * kAaTipTable + 128))) return 1;
+      if (e->aa_root_scale.ensure(sizeof(double) * chunk * K * tp)) return 1;
+      if (e->g_part.ensure(sizeof(double) * chunk * K * (tiles / kAaPreTiles) * N)) return 1;
+    }
+    return 0;
+  };
+  for (;;) {
+    const size_t chunk = aa_chunk(e, T, gradient);
+    if (alloc_chunk(chunk) == 0) break;
+    (void)hipGetLastError();  // (out of memory is not sticky)
+    if (chunk <= 1) return 1;
+    e->plv_budget = aa_arena_bytes_per_eval(e, gradient) * (chunk / 2);
   }
+  if (gradient && e->g_sum.ensure(sizeof(double) * (size_t)T * 2 * N)) return 1;
   return 0;
 }
 

@@ -37,6 +37,9 @@ __global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
       if (v >= used) v = tail + (v - used);
       double s0 = 0, s1 = 0;
       int i = wv;
+      // (unrolled: the loads of several iterations in flight at once; the order of the
+      // additions, hence the result, is unchanged)
+#pragma unroll 8
       for (; i + 4 < a.g_tiles; i += 8) {
         s0 += src[(size_t)i * W + v];
         s1 += src[(size_t)(i + 4) * W + v];

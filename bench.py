@@ -20,7 +20,10 @@ log-likelihoods only, the 1949-pattern shape, the 20-state 512 x 50 000 case), a
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--trees T_total] [--mode gradient|loglik]
 
-For N > 1 launch with torch.distributed.run (one rank per GPU).
+--gpus N > 1: one rank per GPU over RCCL.  Under a launcher (torch.distributed.run: WORLD_SIZE
+set) N must equal WORLD_SIZE; without one, bench.py starts the N ranks itself as a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` (before anything touches the
+GPU) and relays rank 0's JSON line.
 """
 import argparse
 import json
@@ -177,10 +180,31 @@ def oracle():
     return O
 
 
-def cpu_baseline(tips, w, pids, bls, params, mode, budget_s=12.0):
+def beagle_probe():
+    """is the reference's arithmetic library on this box?  (dlopen only; the
+    image has no BEAGLE, no network to get it, and the reference pins no commit of it.)"""
+    import ctypes
+    import ctypes.util
+    tried = ["libhmsbeagle.so", "libhmsbeagle.so.1", "libhmsbeagle.so.21", "libhmsbeagle-cpu.so",
+             "libhmsbeagle-cpu-sse.so"]
+    found = ctypes.util.find_library("hmsbeagle")
+    if found:
+        tried.insert(0, found)
+    for name in tried:
+        try:
+            ctypes.CDLL(name)
+            return {"found": True, "library": name}
+        except OSError:
+            continue
+    return {"found": False, "tried": tried}
+
+
+def cpu_baseline(tips, w, pids, bls, params, mode, budget_s=15.0, reps=10):
     """The CPU oracle (a port of the reference's algorithm, NOT BEAGLE itself: BEAGLE
     is not available in this image) timed on the host cores with the reference's
-    tree-level threading model (one worker per core, FatBeagleParallelize)."""
+    tree-level threading model (one worker per core, FatBeagleParallelize).  SURVEY 8(d):
+    >= 3 warm-ups, the MEDIAN of >= 10 repetitions of the engine call, on all usable cores
+    and on one."""
     O = oracle()
     cores = usable_cores()
     spec = O.make_spec(tips.shape[0], tips.shape[1], "JC69", "weibull+4")
@@ -190,56 +214,136 @@ def cpu_baseline(tips, w, pids, bls, params, mode, budget_s=12.0):
         idx = np.arange(count) % len(pids)
         return pids[idx], bls[idx], params[idx]
 
+    def timed(count, threads):
+        a, b, c = take(count)
+        t0 = time.perf_counter()
+        fn(spec, tips, w, a, b, c, False, threads)
+        return time.perf_counter() - t0
+
     S = 4 * cores
-    a, b, c = take(S)
-    fn(spec, tips, w, a, b, c, False, cores)  # warm-up (page faults, thread start)
-    t0 = time.perf_counter()
-    fn(spec, tips, w, a, b, c, False, cores)
-    dt = time.perf_counter() - t0
+    for _ in range(3):  # warm-ups (page faults, thread start)
+        dt = timed(S, cores)
     rate = S / dt
-    S2 = max(cores, int(rate * budget_s) // cores * cores)
-    a, b, c = take(S2)
-    t0 = time.perf_counter()
-    fn(spec, tips, w, a, b, c, False, cores)
-    dt = time.perf_counter() - t0
-    S1 = max(1, int(rate / cores * 2.0))  # also on one core (about 2 s)
-    a1, b1, c1 = take(S1)
-    t0 = time.perf_counter()
-    fn(spec, tips, w, a1, b1, c1, False, 1)
-    one_core = S1 / (time.perf_counter() - t0)
-    return {"value": S2 / dt, "unit": "trees/s", "cores": cores, "kind": "port",
-            "value_on_one_core": one_core,
-            "sample": f"{S2} trees (the same batch, cycled), {mode} semantics, "
-                      f"{cores} OpenMP threads = usable cores (affinity mask capped by the "
-                      f"cgroup CPU quota; host has {os.cpu_count()} logical CPUs), one tree "
-                      f"per thread, one workspace per thread, {dt:.1f} s; "
+    # one repetition = one engine call over S2 trees, sized so that `reps` of them fit the budget
+    S2 = max(cores, int(rate * budget_s * 0.8 / reps) // cores * cores)
+    times = sorted(timed(S2, cores) for _ in range(reps))
+    med = 0.5 * (times[(reps - 1) // 2] + times[reps // 2])
+    S1 = max(1, int(rate / cores * budget_s * 0.2 / 3))  # and on ONE core: 3 short repetitions
+    one = sorted(timed(S1, 1) for _ in range(3))
+    return {"value": S2 / med, "unit": "trees/s", "cores": cores, "kind": "port",
+            "repetitions": reps, "value_min": S2 / times[-1], "value_max": S2 / times[0],
+            "value_on_one_core": S1 / one[1],
+            "beagle_probe": beagle_probe(),
+            "sample": f"median of {reps} calls of {S2} trees each (the same batch, cycled; 3 "
+                      f"warm-up calls), {mode} semantics, {cores} OpenMP threads = usable cores "
+                      f"(affinity mask capped by the cgroup CPU quota; host has "
+                      f"{os.cpu_count()} logical CPUs), one tree per thread, one workspace per "
+                      f"thread, {sum(times):.1f} s; one core: median of 3 calls of {S1} trees; "
                       "CPU oracle = BEAGLE-equivalent algorithm (cache-blocked over site "
-                      "patterns) in plain C -O3 -march=native, not BEAGLE"}
+                      "patterns) in plain C -O3 -march=native, not BEAGLE (dlopen probe for "
+                      "libhmsbeagle in beagle_probe)"}
 
 
 def roofline(kname, k_ms, units, flops_per_unit, bytes_per_unit, traffic=None,
              traffic_source=None):
-    """The dominant kernel against the roofline that binds it (FP64 matrix cores for the
-    on-chip kernels) with the SURVEY 8(d) HBM streaming model beside it."""
+    """The dominant kernel against the roofline that binds it.  The 4-state walk kernels keep
+    partial vectors in LDS: what binds them is the FP64 matrix/vector datapath, so `frac` is
+    SURVEY 8(d)'s algorithmic flops x units per launch / kernel time against the MEASURED FP64
+    peak.  The 8(d) PLV-streaming byte model is kept beside it as `hbm_model_*` (it exceeds the
+    HBM peak for an on-chip kernel and is therefore NOT a roofline fraction), and the real
+    HBM-side bytes per launch (PMC, profiles/traffic.json) as `traffic` / `hbm_frac`."""
     tflops = flops_per_unit * units / (k_ms * 1e-3) / 1e12
     gbps = bytes_per_unit * units / (k_ms * 1e-3) / 1e9
-    return {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tflops / FP64_PEAK_TFLOPS, "fp64_frac": tflops / FP64_PEAK_TFLOPS,
-            "fp64_peak": FP64_PEAK_TFLOPS, "fp64_peak_source": FP64_PEAK_SOURCE,
-            "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": kname, "kernel_ms": k_ms,
-            "algorithmic_flops_per_tree": flops_per_unit,
-            "hbm_model_GBps": gbps, "hbm_model_frac": gbps / HBM_PEAK_GBPS,
-            "hbm_model_bytes_per_tree": bytes_per_unit,
-            "note": "achieved = SURVEY 8(d) algorithmic flops x trees per launch / kernel time "
-                    "(HIP events on the call's stream); hbm_model_* = the 8(d) PLV-streaming "
-                    "byte model over the same time, kept for reference: the 4-state kernels "
-                    "keep partial vectors in LDS, so that model does not bound them (frac > 1)"}
+    out = {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": tflops / FP64_PEAK_TFLOPS, "fp64_peak_source": FP64_PEAK_SOURCE,
+           "traffic": traffic, "traffic_source": traffic_source,
+           "kernel": kname, "kernel_ms": k_ms, "units_per_launch": units,
+           "algorithmic_flops_per_tree": flops_per_unit,
+           "hbm_model_GBps": gbps, "hbm_model_over_peak": gbps / HBM_PEAK_GBPS,
+           "hbm_model_bytes_per_tree": bytes_per_unit,
+           "note": "achieved = SURVEY 8(d) algorithmic flops x trees per launch / kernel time "
+                   "(HIP events on the call's stream); hbm_model_* = the 8(d) PLV-streaming "
+                   "byte model over the same time, kept for reference only (partial vectors "
+                   "stay in LDS, so it is not a bound); hbm_frac = real HBM-side bytes (PMC) "
+                   "/ kernel time / 8 TB/s"}
+    if traffic:
+        out["hbm_frac"] = traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    return out
+
+
+def traffic_entry(name):
+    """profiles/traffic.json: HBM-side bytes per launch of a kernel from the PMC passes
+    ((2 FETCH_SIZE + WRITE_SIZE) x 1024, separate rocprofv3 --pmc runs) -- not this run."""
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
+    try:
+        return json.load(open(tpath)).get(name)
+    except (OSError, ValueError):
+        return None
+
+
+def streamed_roofline(kname, k_ms, evals, traffic_key, mfma_flops_per_eval, model_bytes_per_eval):
+    """A kernel that streams partial vectors through HBM (the 20-state walk kernels): both
+    candidate bounds, per launch -- real HBM-side bytes (PMC; per-evaluation figure x the
+    evaluations of THIS launch when no measurement of this launch size exists, said so in
+    traffic_source) over kernel time against 8 TB/s, and the 20x20 products really executed
+    against the measured FP64 matrix peak.  `bound` names the larger one; `frac` is it."""
+    ent = traffic_entry(f"{traffic_key}|T={evals}")
+    if ent:
+        traffic, src = ent["hbm_bytes_per_launch"], f"profiles/traffic.json [{traffic_key}|T={evals}] ({ent.get('round', '')}), measured at this launch size"
+    else:
+        ent = traffic_entry(f"{traffic_key}|T=1") or traffic_entry(traffic_key)
+        traffic = ent["hbm_bytes_per_launch"] * evals if ent else None
+        src = (f"profiles/traffic.json [{traffic_key}] one-tree launch x {evals} evaluations "
+               f"({ent.get('round', '')})" if ent else None)
+    sec = k_ms * 1e-3
+    mfma = mfma_flops_per_eval * evals / sec / 1e12
+    out = {"kernel": kname, "kernel_ms": k_ms, "units_per_launch": evals,
+           "traffic": traffic, "traffic_source": src,
+           "mfma_TFLOPs": mfma, "mfma_frac": mfma / FP64_PEAK_TFLOPS,
+           "fp64_peak_source": FP64_PEAK_SOURCE,
+           "hbm_model_bytes_per_tree": model_bytes_per_eval,
+           "hbm_model_over_peak": model_bytes_per_eval * evals / sec / 1e9 / HBM_PEAK_GBPS,
+           "note": "hbm_frac = real HBM-side bytes of the launch (PMC) / kernel time (HIP events "
+                   "around this kernel) / 8 TB/s; mfma_frac = executed 20x20 products (tip "
+                   "children are table look-ups) / measured FP64 matrix peak; hbm_model_* = "
+                   "SURVEY 8(d) PLV-streaming model (every vector read and written; the kernels "
+                   "keep the chained child in registers), for reference only"}
+    hbm_frac = traffic / sec / 1e9 / HBM_PEAK_GBPS if traffic else None
+    out["hbm_frac"] = hbm_frac
+    if hbm_frac is not None and hbm_frac >= out["mfma_frac"]:
+        out.update(bound="hbm", achieved=traffic / sec / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
+                   frac=hbm_frac)
+    else:
+        out.update(bound="mfma", achieved=mfma, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                   frac=out["mfma_frac"])
+    return out
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def parity(pairs, tol=1e-10):
+    """Largest relative error of (name, device result, oracle result[, tolerance]) pairs;
+    raises when an output of a timed step differs from the CPU oracle by more than its
+    tolerance (1e-10 unless the pair states another)."""
+    worst = 0.0
+    for pair in pairs:
+        name, dev, ref = pair[:3]
+        t = pair[3] if len(pair) > 3 else tol
+        e = rel_err(dev, ref)
+        if not e <= t:
+            raise AssertionError(f"timed outputs differ from the oracle: {name} rel err {e:.3e} > {t}")
+        worst = max(worst, e)
+    return worst
 
 
 class Timed:
     """Times `steps` calls of fn() after `warmup` calls; kernel time from the engine's HIP
-    events around its dominant kernel(s)."""
+    events around its dominant kernel(s); optionally a second, separate pass with the call cut
+    into phases (mi_engine_profile_begin_phases: a few more events per call, so never inside
+    the timed region)."""
 
     def __init__(self, torch, eng, stream):
         self.torch, self.eng, self.stream = torch, eng, stream
@@ -260,14 +364,31 @@ class Timed:
         eng.check_status(self.stream)
         return 1e3 * dt, (float(np.mean(k)) if k else float("nan"))
 
+    def phases(self, fn, calls=2):
+        """median [set-up, post-order, pre-order / main walk, rest] ms and the evaluations of
+        the first walk launch"""
+        self.eng.profile_begin_phases(calls)
+        for _ in range(calls):
+            fn()
+        self.torch.cuda.synchronize()
+        _, ph, first = self.eng.profile_collect_phases(calls)
+        return [float(np.median([p[k] for p in ph])) for k in range(4)], first
+
 
 def also_workloads(torch, dev, L, steps):
-    """The other BASELINE.json configurations, one GPU, short runs (rank 0 only)."""
+    """The other BASELINE.json configurations, one GPU, short runs (rank 0 only).  Every leg
+    compares a sample of its last timed step with the CPU oracle (`parity_checked` trees,
+    tolerance 1e-10 unless stated)."""
     out = []
     stream = torch.cuda.current_stream().cuda_stream
+    O = oracle()
+    cores = usable_cores()
 
     def dev_arrays(*arrays):
         return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrays]
+
+    def host(t, count=None):
+        return (t if count is None else t[:count]).cpu().numpy()
 
     # --- DS1 x 1000: GTR+weibull+4 (configs[2]), log-likelihoods, the 1949-pattern shape
     T = 1000
@@ -277,7 +398,8 @@ def also_workloads(torch, dev, L, steps):
     rng = np.random.default_rng(45)
     gtr = np.hstack([rng.dirichlet(10 * np.ones(6), T), rng.dirichlet(10 * np.ones(4), T),
                      np.ones((T, 2))])
-    d_pid, d_bl, d_gtr, d_jc = dev_arrays(pids, bls, gtr, np.ones((T, 2)))
+    jc = np.ones((T, 2))
+    d_pid, d_bl, d_gtr, d_jc = dev_arrays(pids, bls, gtr, jc)
     ll = torch.empty(T, dtype=torch.float64, device=dev)
     g = torch.empty((T, N), dtype=torch.float64, device=dev)
     site = torch.empty(T, dtype=torch.float64, device=dev)
@@ -288,21 +410,46 @@ def also_workloads(torch, dev, L, steps):
                    device=dev.index)
     eng.reserve(T, True)
     tm = Timed(torch, eng, stream)
-    for label, s_ptr, u_ptr, bytes_, flops in (
+    S = 4  # trees of each leg that are compared with the oracle
+    ospec = O.make_spec(n, P, "GTR", "weibull+4")
+    # the engine forms I + V expm1(L t) V^-1; the oracle's default is
+    # BEAGLE's V exp(L t) V^-1, whose rounding the 2e-6 finite-difference step amplifies
+    O.set_transition_mode(1)
+    try:
+        og = O.unrooted_gradients(ospec, tips, w, pids[:S], bls[:S], gtr[:S], False, min(S, cores))
+    finally:
+        O.set_transition_mode(0)
+    for label, s_ptr, u_ptr, bytes_, flops, full in (
             ("full phylo_gradients (reference semantics: 16 finite-difference passes + "
              "perturbed-model site pass)", site.data_ptr(), sub.data_ptr(),
-             2 * b_g + 16 * b_ll, 2 * f_g + 16 * f_ll),
-            ("logL + branch-length gradient only (configs[2] as worded)", None, None, b_g, f_g)):
+             2 * b_g + 16 * b_ll, 2 * f_g + 16 * f_ll, True),
+            ("logL + branch-length gradient only (configs[2] as worded)", None, None, b_g, f_g,
+             False)):
         ms, k_ms = tm.run(lambda: eng.gradients_device(
             stream, T, d_pid.data_ptr(), d_bl.data_ptr(), d_gtr.data_ptr(), ll.data_ptr(),
             g.data_ptr(), s_ptr, u_ptr), steps, 1)
         kname = eng.last_call_info()[0]
+        pairs = [("logL", host(ll, S), og["log_likelihood"]),
+                 ("branch gradient", host(g, S), og["branch_lengths"])]
+        if full:
+            # central differences with step 1e-6 of two FP64 log-likelihoods ~ -7e3: both sides
+            # carry ~1e-16 * 7e3 / 2e-6 = 4e-7 of absolute rounding noise
+            pairs += [("site gradient", host(site, S), og["site_model"], 1e-8),
+                      ("substitution gradient (finite differences)", host(sub, S),
+                       og["substitution_model"], 1e-6)]
+        err = parity(pairs)
+        # the whole call against the FP64 roofline: every pass of the call is a walk kernel
+        r = roofline(kname, ms, T, flops, bytes_)
+        r["note"] = ("whole call (all its walk passes) over the step time; " + r["note"])
         out.append({"workload": f"DS1 27 taxa x {P} patterns x {T} trees, GTR+weibull+4, " + label,
                     "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
                     "kernel_ms": k_ms,
                     "kernel_note": "HIP events around the main gradient pass only; the call also "
                                    "runs the finite-difference / site passes",
-                    "roofline": roofline(kname, ms, T, flops, bytes_)})
+                    "roofline": r, "parity_checked": S, "parity_max_rel_err": err,
+                    "parity_note": "vs CPU oracle (expm1 transition form): logL, branch gradient "
+                                   "1e-10" + ("; site 1e-8, substitution 1e-6 (finite-difference "
+                                              "noise of both sides)" if full else "")})
     assert bool(torch.isfinite(sub).all())
     eng.close()
     eng = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w,
@@ -312,9 +459,18 @@ def also_workloads(torch, dev, L, steps):
     ms, k_ms = tm.run(lambda: eng.log_likelihoods_device(
         stream, T, d_pid.data_ptr(), d_bl.data_ptr(), d_jc.data_ptr(), ll.data_ptr()), steps, 1)
     kname = eng.last_call_info()[0]
+    S = 16
+    oll = O.unrooted_log_likelihoods(O.make_spec(n, P, "JC69", "weibull+4"), tips, w, pids[:S],
+                                     bls[:S], jc[:S], False, min(S, cores))
+    err = parity([("logL", host(ll, S), oll)])
+    ent = traffic_entry(kname.split("<")[0])
     out.append({"workload": f"DS1 27 taxa x {P} patterns x {T} trees, JC69+weibull+4, log_likelihoods",
                 "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
-                "kernel_ms": k_ms, "roofline": roofline(kname, k_ms, T, f_ll, b_ll)})
+                "kernel_ms": k_ms,
+                "roofline": roofline(kname, k_ms, T, f_ll, b_ll,
+                                     ent["hbm_bytes_per_launch"] if ent else None,
+                                     "profiles/traffic.json (PMC, 1000-tree launch), not this run"),
+                "parity_checked": S, "parity_max_rel_err": err})
     eng.close()
     # S-DS1, 1949 patterns (every column of a DS1-sized alignment its own pattern)
     rng = np.random.default_rng(44)
@@ -330,10 +486,17 @@ def also_workloads(torch, dev, L, steps):
     kname = eng.last_call_info()[0]
     b2_ll, b2_g = algorithmic_bytes(n, 1949, K)
     f2_ll, f2_g = algorithmic_flops(n, 1949, K)
+    S = 8
+    og = O.unrooted_gradients(O.make_spec(n, 1949, "JC69", "weibull+4"), tips2, w2, pids[:S],
+                              bls[:S], jc[:S], False, min(S, cores))
+    err = parity([("logL", host(ll, S), og["log_likelihood"]),
+                  ("branch gradient", host(g, S), og["branch_lengths"]),
+                  ("site gradient", host(site, S), og["site_model"])])
     out.append({"workload": f"S-DS1 27 taxa x 1949 patterns (synthetic, evolved under JC) x {T} "
                             "trees, JC69+weibull+4, phylo_gradients",
                 "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
-                "kernel_ms": k_ms, "roofline": roofline(kname, k_ms, T, f2_g, b2_g)})
+                "kernel_ms": k_ms, "roofline": roofline(kname, k_ms, T, f2_g, b2_g),
+                "parity_checked": S, "parity_max_rel_err": err})
     eng.close()
 
     # --- fluA rooted, strict clock (configs[3])
@@ -343,7 +506,8 @@ def also_workloads(torch, dev, L, steps):
         N = 2 * n - 1
         eng = L.Engine(L.PhyloModelSpecification("JC69", "constant", "strict"), tips, w,
                        device=dev.index)
-        d = dev_arrays(pids, bls, np.ones((Tf, 1)), rates, counts, hs, bs, rs)
+        pr1 = np.ones((Tf, 1))
+        d = dev_arrays(pids, bls, pr1, rates, counts, hs, bs, rs)
         ll = torch.empty(Tf, dtype=torch.float64, device=dev)
         gr = torch.empty((Tf, n - 1), dtype=torch.float64, device=dev)
         gc = torch.empty((Tf, N - 1), dtype=torch.float64, device=dev)
@@ -360,14 +524,24 @@ def also_workloads(torch, dev, L, steps):
         tm = Timed(torch, eng, stream)
         ms, k_ms = tm.run(call, steps if Tf > 1 else 20, 2)
         kname = eng.last_call_info()[0]
+        phase_ms, _ = tm.phases(call, 4)
         bf_ll, bf_g = algorithmic_bytes(n, P, 1)
         ff_ll, ff_g = algorithmic_flops(n, P, 1)
         assert bool(torch.isfinite(gr).all())
+        S = min(Tf, 8)
+        og = O.rooted_gradients(O.make_spec(n, P, "JC69", "constant"), tips, w, pids[:S], bls[:S],
+                                pr1[:S], rates[:S], counts[:S], hs[:S], bs[:S], rs[:S], False,
+                                min(S, cores))
+        err = parity([("logL", host(ll, S), og["log_likelihood"]),
+                      ("ratio / root-height gradient", host(gr, S), og["ratios_root_height"]),
+                      ("clock gradient", host(gc, S)[:, 0], og["clock_model"][:, 0])])
         out.append({"workload": f"fluA rooted {n} taxa x {P} patterns x {Tf} tree(s), JC69, strict "
                                 "clock, node-height-ratio + clock gradient",
                     "trees_per_s": Tf / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
                     "kernel_ms": k_ms, "logL0": float(ll[0]),
-                    "roofline": roofline(kname, k_ms, Tf, ff_g, bf_g)})
+                    "phase_ms": {"setup": phase_ms[0], "walk": phase_ms[2], "rest": phase_ms[3]},
+                    "roofline": roofline(kname, k_ms, Tf, ff_g, bf_g),
+                    "parity_checked": S, "parity_max_rel_err": err})
         eng.close()
 
     # --- 20 states, 512 taxa x 50 000 patterns x 4 categories (configs[4], S-WAG)
@@ -379,10 +553,25 @@ def also_workloads(torch, dev, L, steps):
                    device=dev.index)
     N = 2 * n - 1
     plv = K * P * 20 * 8
+    pids8 = np.stack([random_unrooted_topology(n, rng) for _ in range(8)])
+    bls8 = rng.exponential(0.1, size=(8, 2 * n - 2))
+    bls8[:, -1] = 0
+    # tree 0 of both batch sizes against the oracle: the alignment cut into pattern blocks,
+    # one block per host thread, the blocks added (every output is a sum over patterns)
+    import libsbn_amd.engine as E
+    ex, fr = E.wag_model()
+    O.set_reversible_model(ex, fr)
+    O.set_transition_mode(1)
+    try:
+        t0 = time.perf_counter()
+        og = O.unrooted_by_pattern_blocks(O.make_spec(n, P, "reversible", f"weibull+{K}", s=20),
+                                          tips, w, pids8[:1], bls8[:1], np.ones((1, 2)),
+                                          rescaling=True, gradient=cores >= 8, threads=cores)
+        oracle_s = time.perf_counter() - t0
+    finally:
+        O.set_transition_mode(0)
     for Tw in (1, 8):
-        pids = np.stack([random_unrooted_topology(n, rng) for _ in range(Tw)])
-        bls = rng.exponential(0.1, size=(Tw, 2 * n - 2))
-        bls[:, -1] = 0
+        pids, bls = pids8[:Tw], bls8[:Tw]
         d_pid, d_bl, d_par = dev_arrays(pids, bls, np.ones((Tw, 2)))
         ll = torch.empty(Tw, dtype=torch.float64, device=dev)
         g = torch.empty((Tw, N), dtype=torch.float64, device=dev)
@@ -398,41 +587,52 @@ def also_workloads(torch, dev, L, steps):
                 fn = lambda: eng.log_likelihoods_device(  # noqa: E731
                     stream, Tw, d_pid.data_ptr(), d_bl.data_ptr(), d_par.data_ptr(), ll.data_ptr())
             ms, k_ms = tm.run(fn, 3 if Tw == 1 else 2, 1)
+            phase_ms, first = tm.phases(fn, 2)
+            launches = eng.last_call_launches()[0]
             assert bool(torch.isfinite(ll).all())
+            pairs = [("logL of tree 0", host(ll, 1), og["log_likelihood"])]
+            if grad and "branch_lengths" in og:
+                pairs += [("branch gradient of tree 0", host(g, 1), og["branch_lengths"]),
+                          ("site gradient of tree 0", host(site, 1), og["site_model"])]
+            err = parity(pairs)
             b_model = ((10 * n - 14) if grad else 2 * (n - 1)) * plv + (12 if grad else 4) * n * P
-            f_model = algorithmic_flops(n, P, K, 20)[1 if grad else 0]
             # what the kernels really have to do: a tip child's product is a table look-up,
-            # so only the n-2 internal edges cost 20x20 products (1 in the post-order, 2-3 more
-            # in the pre-order); the arena moves n-2 vectors out and back (+ stacked ones)
-            # the pre-order pass forms P L itself only for the child the post-order pass did
-            # NOT take from registers, i.e. once per node with two internal children
-            mfma_flops = ((3 * (n - 2) + two_internal_children(pids[0], n)) if grad
-                          else (n - 2)) * K * P * 800.0
-            r = {"bound": "hbm", "achieved": b_model * Tw / (k_ms * 1e-3) / 1e9,
-                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                 "frac": b_model * Tw / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                 "traffic": (49.7e9 if grad else 7.9e9),
-                 "traffic_source": "profiles/r02_aa_pmc_{fetch,write}.csv, profiles/traffic.json "
-                                   "((2 FETCH_SIZE + WRITE_SIZE) x 1024, separate passes), per "
-                                   "tree; not this run",
-                 "kernel": "aa_post_wg_kernel + aa_root_kernel" + (" + aa_pre_wg_kernel" if grad else ""),
-                 "kernel_ms": k_ms,
-                 "hbm_model_bytes_per_tree": b_model,
-                 "survey_flops_TFLOPs": f_model * Tw / (k_ms * 1e-3) / 1e12,
-                 "mfma_TFLOPs": mfma_flops * Tw / (k_ms * 1e-3) / 1e12,
-                 "mfma_frac_of_measured_peak": mfma_flops * Tw / (k_ms * 1e-3) / 1e12
-                                               / FP64_PEAK_TFLOPS,
-                 "note": "achieved = SURVEY 8(d) PLV-streaming bytes (B_LL / B_G) over the time "
-                         "of the walk kernels; the kernels keep the chained child in registers "
-                         "and tips compact, so the real traffic is `traffic`; mfma_TFLOPs counts "
-                         "only the 20x20 products the kernels execute (tip products are table "
-                         "look-ups)"}
-            out.append({"workload": f"S-WAG 20 states, {n} taxa x {P} patterns x {K} categories "
-                                    f"x {Tw} tree(s), " + ("phylo_gradients" if grad else
-                                                           "log_likelihoods"),
-                        "trees_per_s": Tw / (ms * 1e-3), "ms_per_step": ms,
-                        "kernel": eng.last_call_info()[0], "kernel_ms": k_ms, "logL0": float(ll[0]),
-                        "roofline": r})
+            # so only the n-2 internal edges cost 20x20 products: one each in the post-order
+            # pass; in the pre-order pass two each, plus P L once per node with two internal
+            # children (the child the post-order pass did NOT take from registers)
+            prod = K * P * 800.0
+            post = streamed_roofline(
+                "aa_post_wg_kernel<2," + ("true" if grad else "false") + "> (+ aa_root_kernel)",
+                phase_ms[1], first,
+                "aa_post_wg_kernel<2,true> (gradient)" if grad
+                else "aa_post_wg_kernel<2,false> (log_likelihoods)",
+                (n - 2) * prod, (2 * (n - 1)) * plv + 4 * n * P)
+            entry = {"workload": f"S-WAG 20 states, {n} taxa x {P} patterns x {K} categories "
+                                 f"x {Tw} tree(s), " + ("phylo_gradients" if grad else
+                                                        "log_likelihoods"),
+                     "trees_per_s": Tw / (ms * 1e-3), "ms_per_step": ms,
+                     "kernel": eng.last_call_info()[0], "kernel_ms": k_ms,
+                     "walk_launches": launches, "evaluations_in_first_launch": first,
+                     "logL0": float(ll[0]),
+                     "phase_ms": {"setup": phase_ms[0], "post_order": phase_ms[1],
+                                  "pre_order": phase_ms[2], "rest": phase_ms[3]},
+                     "hbm_model_bytes_per_tree": b_model,
+                     "hbm_model_over_peak": b_model * Tw / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "parity_checked": 1, "parity_max_rel_err": err,
+                     "parity_note": "tree 0 vs the CPU oracle evaluated on pattern blocks "
+                                    f"({oracle_s:.0f} s on {cores} threads): "
+                                    + ("logL, branch and site gradients" if grad and
+                                       "branch_lengths" in og else "logL")}
+            if grad:
+                pre = streamed_roofline(
+                    "aa_pre_wg_kernel<2>", phase_ms[2], first, "aa_pre_wg_kernel<2>",
+                    (2 * (n - 2) + two_internal_children(pids[0], n)) * prod,
+                    (8 * n - 12) * plv + 8 * n * P)
+                entry["roofline"] = pre  # the dominant kernel of a gradient call
+                entry["roofline_post_order"] = post
+            else:
+                entry["roofline"] = post
+            out.append(entry)
     eng.close()
     return out
 
@@ -497,15 +697,49 @@ def swag_pattern_sharded(args, torch, dist, L, sharding, dev, rank, world, distr
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert bool(torch.isfinite(blk.buffer).all())
+    # a separate pass with the call cut into phases (never inside the timed region)
+    eng.profile_begin_phases(2)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    _, ph, first = eng.profile_collect_phases(2)
+    phase_ms = [float(np.median([p[k] for p in ph])) for k in range(4)]
+    if distributed:
+        dist.barrier()
     if rank != 0:
         return None
     plv = K * P * 20 * 8
+    share = (hi - lo) / P  # this rank's part of the alignment
     b_model = ((10 * n - 14) if grad else 2 * (n - 1)) * plv + (12 if grad else 4) * n * P
     ms = 1e3 * elapsed / steps
+    prod = K * P * 800.0 * share
+    post = streamed_roofline(
+        "aa_post_wg_kernel<2," + ("true" if grad else "false") + "> (+ aa_root_kernel)",
+        phase_ms[1], first,
+        "aa_post_wg_kernel<2,true> (gradient)" if grad
+        else "aa_post_wg_kernel<2,false> (log_likelihoods)",
+        (n - 2) * prod, ((2 * (n - 1)) * plv + 4 * n * P) * share)
+    rl = post
+    if grad:
+        rl = streamed_roofline("aa_pre_wg_kernel<2>", phase_ms[2], first, "aa_pre_wg_kernel<2>",
+                               (2 * (n - 2) + two_internal_children(pids[0], n)) * prod,
+                               ((8 * n - 12) * plv + 8 * n * P) * share)
+    for r in (rl, post):  # the PMC figures are for the whole alignment: scale to the block
+        if r.get("traffic") and share != 1.0:
+            for key in ("traffic", "hbm_frac"):
+                r[key] *= share
+            if r["bound"] == "hbm":
+                r["achieved"] *= share
+                r["frac"] *= share
+            r["traffic_source"] += f", x {share:.4f} (this rank's pattern block)"
     return {
         "metric": "tree log-likelihoods+gradients/sec (batched)" if grad
                   else "tree log-likelihoods/sec (batched)",
-        "value": T / (elapsed / steps), "unit": "trees/s", "n_gpus": world, "steps": steps,
+        "value": T / (elapsed / steps), "unit": "trees/s", "n_gpus": world,
+        "rccl_ranks": dist.get_world_size() if distributed else 1,
+        "patterns_per_rank": [sharding.pattern_shard(P, r, world)[1]
+                              - sharding.pattern_shard(P, r, world)[0] for r in range(world)],
+        "steps": steps,
         "warmup": warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64",
         "data": "synthetic: uniform 20-state tips, random-join topologies (seed 47), branch "
@@ -517,14 +751,61 @@ def swag_pattern_sharded(args, torch, dist, L, sharding, dev, rank, world, distr
                    "taxa": n, "patterns": P, "categories": K, "trees": T,
                    "parallelism": f"pattern-sharded x{world}, one all_reduce per step"
                                   if distributed else "single GPU"},
-        "roofline": {"bound": "hbm", "achieved": b_model * T / world / (k_ms * 1e-3) / 1e9,
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": b_model * T / world / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": eng.last_call_info()[0], "kernel_ms": k_ms,
-                     "note": "SURVEY 8(d) PLV-streaming bytes of this rank's pattern block over "
-                             "the time of its walk kernels"},
+        "roofline": rl, "roofline_post_order": post if grad else None,
+        "walk_kernels_ms": k_ms,
+        "phase_ms": {"setup": phase_ms[0], "post_order": phase_ms[1], "pre_order": phase_ms[2],
+                     "rest": phase_ms[3]},
+        "hbm_model_bytes_per_tree": b_model,
         "logL0": float(blk.log_likelihoods[0]),
     }
+
+
+def spawn_ranks(gpus):
+    """Runs `python -m torch.distributed.run --nproc-per-node <gpus> bench.py <same args>` as a
+    child and returns its exit code; the child's stdout (rank 0's JSON line last) is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:  # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """The launcher and the dealing of the work without a GPU: every rank joins the process
+    group, the ranks agree on their number and on the trees each one takes, rank 0 prints the
+    line.  Nothing is measured (`value` null, `dry_run` true)."""
+    import torch
+    import torch.distributed as dist
+    from libsbn_amd import sharding
+    if world > 1 or os.environ.get("MI_BENCH_FORCE_DIST") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        ranks = dist.get_world_size()
+        lo, hi = sharding.tree_shard(args.trees, rank, world)
+        mine = torch.zeros(world, dtype=torch.int64)
+        mine[rank] = hi - lo
+        dist.all_reduce(mine)
+        dist.barrier()
+        dist.destroy_process_group()
+        per_rank = [int(x) for x in mine]
+    else:
+        ranks, per_rank = 1, [args.trees]
+    assert sum(per_rank) == args.trees
+    if rank == 0:
+        print(json.dumps({"metric": "tree log-likelihoods+gradients/sec (batched)", "value": None,
+                          "unit": "trees/s", "n_gpus": world, "rccl_ranks": ranks,
+                          "trees_per_rank": per_rank, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "backend": args.backend,
+                          "scaling": "strong"}), flush=True)
+    return 0
 
 
 def main():
@@ -546,16 +827,37 @@ def main():
                          "configs[4], 20 states x 512 taxa x 50 000 patterns x 4 categories, "
                          "site patterns dealt to the GPUs, one all-reduce per step")
     ap.add_argument("--swag-trees", type=int, default=8)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend; gloo only with --dry-run (CPU test of the launcher)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="start the ranks, form the process group, deal the trees, print the "
+                         "line -- no GPU work, value null (tests/test_bench_launcher.py)")
     args = ap.parse_args()
+
+    # ---- one rank per GPU.  Without a launcher around us (no WORLD_SIZE) and --gpus N > 1,
+    # start the N ranks ourselves -- as a CHILD process, before anything here touches the GPU
+    # (an initialised process must not exec or be replaced on this pool) -- and relay rank 0's
+    # JSON line: `python bench.py --gpus 8` cannot silently measure one GPU.
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} "
+                 "ranks; they must agree")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    if args.backend != "nccl":
+        sys.exit("--backend gloo is for --dry-run only: the engine has no CPU path")
 
     import torch
     import torch.distributed as dist
     import libsbn_amd as L
     from libsbn_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -568,6 +870,8 @@ def main():
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rccl_ranks = dist.get_world_size() if distributed else 1
+    assert rccl_ranks == world
 
     if args.workload == "swag":
         out = swag_pattern_sharded(args, torch, dist, L, sharding, dev, rank, world, distributed)
@@ -646,9 +950,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         eng.profile_begin(steps)
+        # per-step spread: an event on the calls' stream after every step (no host
+        # synchronisation; ~1 us of host time each inside the timed region)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        marks[0].record()
+        for k in range(steps):
             step()
+            marks[k + 1].record()
         drain()
         torch.cuda.synchronize()
         if distributed:
@@ -656,6 +965,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         kernel_ms = eng.profile_collect(steps)
+        state["step_ms"] = [marks[k].elapsed_time(marks[k + 1]) for k in range(steps)]
         eng.check_status(stream)
         if distributed:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -672,12 +982,12 @@ def main():
             assert bool(torch.equal(ll_all[rank][:T], d_ll)), "gathered slice mismatch"
             if grad:
                 assert bool(torch.equal(g_all[rank][:T], d_g)), "gathered gradient slice mismatch"
-        return elapsed, kernel_ms, last, T
+        return elapsed, kernel_ms, last, T, state["step_ms"]
 
     # ---- strong scaling (the headline): T_total trees over all ranks
     lo, hi = sharding.tree_shard(T_total, rank, world)
     T_max = sharding.tree_shard(T_total, 0, world)[1]
-    elapsed, kernel_ms, last, T_local = run_config(T_max, lo, hi, args.steps, args.warmup)
+    elapsed, kernel_ms, last, T_local, step_ms = run_config(T_max, lo, hi, args.steps, args.warmup)
     ms_per_step = 1e3 * elapsed / args.steps
     value = T_total / (elapsed / args.steps)
     kname, evals, gevals = eng.last_call_info()
@@ -710,7 +1020,7 @@ def main():
     weak = None
     if world > 1:
         wl, wh = rank * T_total, (rank + 1) * T_total
-        w_elapsed, _, _, _ = run_config(T_total, wl, wh, args.steps, args.warmup)
+        w_elapsed = run_config(T_total, wl, wh, args.steps, args.warmup)[0]
         weak = {"value": world * T_total / (w_elapsed / args.steps), "unit": "trees/s",
                 "ms_per_step": 1e3 * w_elapsed / args.steps, "trees_per_gpu": T_total}
 
@@ -718,8 +1028,11 @@ def main():
     small = None
     if rank == 0 and world == 1 and not args.no_small_batch:
         Ts = max(1, T_total // 8)
-        s_elapsed, s_kernel, _, _ = run_config(Ts, 0, Ts, 50, 5)
+        s_elapsed, s_kernel, _, _, s_steps = run_config(Ts, 0, Ts, 50, 5)
         small = {"trees": Ts, "ms_per_step": 1e3 * s_elapsed / 50,
+                 "step_ms_device": {"min": float(np.min(s_steps)),
+                                    "median": float(np.median(s_steps)),
+                                    "max": float(np.max(s_steps))},
                  "kernel_ms": float(np.mean(s_kernel)),
                  "speedup_vs_full_batch": ms_per_step / (1e3 * s_elapsed / 50),
                  "note": "the step one GPU of 8 runs under strong scaling (eager launches, "
@@ -746,13 +1059,16 @@ def main():
             for _ in range(5):
                 graph.replay()
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(100):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(101)]
+            evs[0].record()
+            for k in range(100):
                 graph.replay()
-            e1.record()
+                evs[k + 1].record()
             torch.cuda.synchronize()
-            small["graph_ms_per_step"] = e0.elapsed_time(e1) / 100
+            reps = [evs[k].elapsed_time(evs[k + 1]) for k in range(100)]
+            small["graph_ms_per_step"] = evs[0].elapsed_time(evs[100]) / 100
+            small["graph_step_ms"] = {"min": float(np.min(reps)), "median": float(np.median(reps)),
+                                      "max": float(np.max(reps))}
             small["graph_speedup_vs_full_batch"] = ms_per_step / small["graph_ms_per_step"]
             assert bool(torch.isfinite(blk.log_likelihoods).all())
         except Exception as exc:  # capture support varies; the eager figure stands
@@ -762,19 +1078,26 @@ def main():
     if rank == 0:
         b_ll, b_g = algorithmic_bytes(n, P, K)
         f_ll, f_g = algorithmic_flops(n, P, K)
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(kname, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        ent = traffic_entry(kname.split("<")[0])
+        traffic = ent.get("hbm_bytes_per_launch") if ent else None
         out = {
             "metric": "tree log-likelihoods+gradients/sec (batched)" if grad
                       else "tree log-likelihoods/sec (batched)",
-            "value": value, "unit": "trees/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "value": value, "unit": "trees/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
+            "trees_per_rank": [sharding.tree_shard(T_total, r, world)[1]
+                               - sharding.tree_shard(T_total, r, world)[0] for r in range(world)],
+            "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "step_ms_device": {"min": float(np.min(step_ms)), "median": float(np.median(step_ms)),
+                               "max": float(np.max(step_ms)),
+                               "kernel_min": float(np.min(kernel_ms)) if kernel_ms else None,
+                               "kernel_median": float(np.median(kernel_ms)) if kernel_ms else None,
+                               "kernel_max": float(np.max(kernel_ms)) if kernel_ms else None,
+                               "note": "per step of the timed region, rank 0: HIP events on the "
+                                       "calls' stream after every step (device time between "
+                                       "consecutive steps' ends); kernel_* = the dominant "
+                                       "kernel's launch"},
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "reference DS1 alignment + DS1.100_topologies (read through the product's "
                     "FASTA / Newick ingest); synthetic branch lengths Exp(mean 0.1), seed 43",
             "config": {"workload": f"DS1 27 taxa x {P} site patterns (1949 sites) x {T_total} "

@@ -266,6 +266,14 @@ int32_t mi_engine_check_status(mi_engine* engine, void* stream);
 int32_t mi_engine_last_call_info(const mi_engine* engine, const char** dominant_kernel,
                                  int64_t* evaluations, int64_t* gradient_evaluations);
 
+/* How the last call was cut up: the number of launches of the walk kernel(s) over chunks of
+ * evaluations (the partial-vector arena of large trees holds only as many evaluations as
+ * MI_PHYLO_PLV_BYTES allows; 1 when everything went in one launch), and how many times since
+ * the engine was made the arena budget had to be reduced because the device could not give
+ * the memory.  Either pointer may be NULL. */
+int32_t mi_engine_last_call_launches(const mi_engine* engine, int32_t* walk_launches,
+                                     int32_t* arena_backoffs);
+
 /* Kernel timing for bench.py: after mi_engine_profile_begin(engine, max_calls)
  * every call brackets its dominant kernel launch(es) with a pair of HIP events on
  * the call's stream (no synchronisation).  mi_engine_profile_collect()
@@ -274,6 +282,20 @@ int32_t mi_engine_last_call_info(const mi_engine* engine, const char** dominant_
 int32_t mi_engine_profile_begin(mi_engine* engine, int32_t max_calls);
 int32_t mi_engine_profile_collect(mi_engine* engine, double* out_ms, int32_t capacity,
                                   int32_t* out_count);
+/* The same with the call cut into four phases by five more events (a few microseconds of
+ * device time per call: not for a timed region whose step time is reported):
+ *   [0] set-up (tree schedules, model instances; 20 states: + the transition matrices of
+ *       the first launch)          [1] post-order walk (+ root) of the FIRST walk launch (20
+ *       states; 0 for the 4-state kernels, whose walks are one kernel)
+ *   [2] pre-order walk of the first launch (20 states) / the main walk pass (4 states)
+ *   [3] everything after it (further launches of a chunked call, finite-difference and
+ *       site passes, tile reduction, finalize).
+ * out_phase_ms: [capacity][4]; *out_first_launch_evaluations: evaluations the first walk
+ * launch covered (what a per-launch roofline divides by). */
+int32_t mi_engine_profile_begin_phases(mi_engine* engine, int32_t max_calls);
+int32_t mi_engine_profile_collect_phases(mi_engine* engine, double* out_ms, double* out_phase_ms,
+                                         int32_t capacity, int32_t* out_count,
+                                         int32_t* out_first_launch_evaluations);
 
 /* ---- site-pattern compression on the device (widening beyond the Engine boundary) ----
  *

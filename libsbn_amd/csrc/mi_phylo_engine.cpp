@@ -29,6 +29,7 @@ int fail(const std::string& msg) {
   g_error = msg;
   return 1;
 }
+void set_last_error(const std::string& msg) { g_error = msg; }
 }  // namespace miphylo
 
 #include "mi_phylo_engine.h"
@@ -176,6 +177,9 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ms.params = d.params;
   ms.models = e->models.as<DevModel>();
   ms.status = e->status.as<int32_t>();
+  const bool prof = e->prof_used < e->prof_capacity;
+  const bool marks = prof && e->prof_phases;
+  PROF_MARK(e, marks, 0, s);
   launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
   const bool arena = mfma && gradient_mfma_use_arena(n, e->K, d.rescaling, analytic);
   if (arena)
@@ -249,8 +253,10 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // one launch covers at most kMaxEvals evaluations (grid y dimension: 65535; a multiple
   // of 8 keeps whole evaluations per XCD)
   constexpr int kMaxEvals = 32768;
+  int walk_launches = 0;
   auto loglik_range = [&](int eval_begin, int count) {
     for (int done = 0; done < count; done += kMaxEvals) {
+      walk_launches++;
       LikArgs l = la;
       l.eval_offset = eval_begin + done;
       launch_loglik(l, std::min(kMaxEvals, count - done), d.rescaling, e->max_slots, s);
@@ -266,6 +272,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
                 : kMaxEvals;
       for (int done = 0; done < count; done += max_part) {
         const int part = std::min(max_part, count - done);
+        walk_launches++;
         LikArgs g = la;
         g.eval_offset = eval_begin + done;
         g.grad_offset = grad_begin + done;
@@ -283,6 +290,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     const int chunk = (int)std::max<size_t>(
         1, std::min<size_t>(std::min(count, kMaxEvals), e->plv.bytes / per));
     for (int done = 0; done < count; done += chunk) {
+      walk_launches++;
       LikArgs g = la;
       g.eval_offset = eval_begin + done;
       g.grad_offset = grad_begin + done;
@@ -290,22 +298,26 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     }
   };
 
-  const bool prof = e->prof_used < e->prof_capacity;
-  if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used], s));
+  if (prof) HIP_TRY(hipEventRecord(prof_event(e, 0), s));
+  PROF_MARK(e, marks, 1, s);
+  PROF_MARK(e, marks, 2, s);
   if (!d.gradient) {
     loglik_range(0, T);
     e->dominant = loglik_kernel_name(la, d.rescaling, e->max_slots);
-    if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used + 1], s));
+    if (prof) HIP_TRY(hipEventRecord(prof_event(e, 1), s));
+    PROF_MARK(e, marks, 3, s);
   } else {
     grad_range(0, 0, T);
-    if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used + 1], s));
+    if (prof) HIP_TRY(hipEventRecord(prof_event(e, 1), s));
+    PROF_MARK(e, marks, 3, s);
     if (fd_pass) loglik_range(T, 16 * T);
     if (site_pass) grad_range(17 * T, T, T);
     e->dominant = mfma ? gradient_mfma_kernel_name() : gradient_kernel_name();
   }
-  if (prof) e->prof_used++;
+  e->prof_first_launch_evals = T;
   e->last_evals = c.E;
   e->last_grad_evals = c.Eg;
+  e->last_walk_launches = walk_launches;
 
   FinalizeArgs fa{};
   fa.n = n;
@@ -392,6 +404,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     sg.out_subst = d.out_subst;
     launch_subst_gradient(sg, s);
   }
+  PROF_MARK(e, marks, 4, s);
+  if (prof) e->prof_used++;
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -734,7 +748,12 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
     return 0;
   }
   HIP_TRY(hipSetDevice(e->spec.device));
-  if (e->s == kAa) return aa_reserve(e, tree_count, for_gradients != 0);
+  if (e->s == kAa) {
+    // a gradient engine may be asked for log-likelihoods too: those calls run more evaluations
+    // per launch (fewer vectors each) and size the per-launch operand buffers accordingly
+    if (for_gradients && aa_reserve(e, tree_count, true)) return 1;
+    return aa_reserve(e, tree_count, false);
+  }
   // Everything a later *_device call over `tree_count` trees can need -- with or without
   // rescaling, with the engine's substitution-gradient setting --, so that such a call
   // allocates nothing (it can then be captured in a hipGraph): the union of both rescaling
@@ -761,36 +780,63 @@ int32_t mi_engine_check_status(mi_engine* e, void* stream) {
   return check_status(e, pick_stream(e, stream));
 }
 
-int32_t mi_engine_profile_begin(mi_engine* e, int32_t max_calls) {
+static int32_t profile_begin(mi_engine* e, int32_t max_calls, bool phases) {
   if (!e) return fail("null engine");
-  if (!e->shards.empty()) return mi_engine_profile_begin(e->shards[0], max_calls);
+  if (!e->shards.empty()) return profile_begin(e->shards[0], max_calls, phases);
   if (max_calls < 0) return fail("max_calls must be >= 0");
   HIP_TRY(hipSetDevice(e->spec.device));
-  while ((int)e->prof_events.size() < 2 * max_calls) {
+  while ((int)e->prof_events.size() < kProfEvents * max_calls) {
     hipEvent_t ev;
     HIP_TRY(hipEventCreate(&ev));
     e->prof_events.push_back(ev);
   }
   e->prof_capacity = max_calls;
   e->prof_used = 0;
+  e->prof_phases = phases;
   return 0;
+}
+
+int32_t mi_engine_profile_begin(mi_engine* e, int32_t max_calls) {
+  return profile_begin(e, max_calls, false);
+}
+int32_t mi_engine_profile_begin_phases(mi_engine* e, int32_t max_calls) {
+  return profile_begin(e, max_calls, true);
 }
 
 int32_t mi_engine_profile_collect(mi_engine* e, double* out_ms, int32_t capacity,
                                   int32_t* out_count) {
+  return mi_engine_profile_collect_phases(e, out_ms, nullptr, capacity, out_count, nullptr);
+}
+
+int32_t mi_engine_profile_collect_phases(mi_engine* e, double* out_ms, double* out_phase_ms,
+                                         int32_t capacity, int32_t* out_count,
+                                         int32_t* out_first_launch_evaluations) {
   if (!e) return fail("null engine");
   if (!e->shards.empty())
-    return mi_engine_profile_collect(e->shards[0], out_ms, capacity, out_count);
+    return mi_engine_profile_collect_phases(e->shards[0], out_ms, out_phase_ms, capacity,
+                                            out_count, out_first_launch_evaluations);
+  if (out_phase_ms && !e->prof_phases)
+    return fail("phase times were not recorded: use mi_engine_profile_begin_phases");
   const int count = std::min(e->prof_used, capacity);
   for (int i = 0; i < count; i++) {
-    HIP_TRY(hipEventSynchronize(e->prof_events[2 * i + 1]));
+    hipEvent_t* ev = &e->prof_events[(size_t)kProfEvents * i];
+    HIP_TRY(hipEventSynchronize(ev[1]));
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e->prof_events[2 * i], e->prof_events[2 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
     if (out_ms) out_ms[i] = ms;
+    if (out_phase_ms) {
+      HIP_TRY(hipEventSynchronize(ev[6]));
+      for (int k = 0; k < 4; k++) {
+        HIP_TRY(hipEventElapsedTime(&ms, ev[2 + k], ev[3 + k]));
+        out_phase_ms[4 * i + k] = ms;
+      }
+    }
   }
   if (out_count) *out_count = count;
+  if (out_first_launch_evaluations) *out_first_launch_evaluations = e->prof_first_launch_evals;
   e->prof_capacity = 0;
   e->prof_used = 0;
+  e->prof_phases = false;
   return 0;
 }
 
@@ -803,6 +849,16 @@ int32_t mi_engine_last_call_info(const mi_engine* e, const char** dominant_kerne
   if (dominant_kernel) *dominant_kernel = e->dominant;
   if (evaluations) *evaluations = e->last_evals;
   if (gradient_evaluations) *gradient_evaluations = e->last_grad_evals;
+  return 0;
+}
+
+int32_t mi_engine_last_call_launches(const mi_engine* e, int32_t* walk_launches,
+                                     int32_t* arena_backoffs) {
+  if (!e) return fail("null engine");
+  if (!e->shards.empty())
+    return mi_engine_last_call_launches(e->shards[0], walk_launches, arena_backoffs);
+  if (walk_launches) *walk_launches = e->last_walk_launches;
+  if (arena_backoffs) *arena_backoffs = e->aa_backoffs;
   return 0;
 }
 

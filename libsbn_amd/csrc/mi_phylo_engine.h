@@ -14,6 +14,7 @@
 
 namespace miphylo {
 int fail(const std::string& msg);  // sets mi_last_error()
+void set_last_error(const std::string& msg);
 }
 using miphylo::fail;
 using namespace miphylo;
@@ -152,13 +153,29 @@ struct mi_engine {
       in_ratios, out_ll, out_a, out_b, out_site, out_subst;
   size_t plv_budget = (size_t)8 << 30;
   // kernel timing (bench.py)
-  std::vector<hipEvent_t> prof_events;  // pairs
+  std::vector<hipEvent_t> prof_events;  // kProfEvents per call: [begin, end, mark 0..4]
   int prof_capacity = 0, prof_used = 0;
+  bool prof_phases = false;   // also record the phase marks (mi_engine_profile_begin_phases)
+  int prof_first_launch_evals = 0;  // evaluations in the first walk launch of the last call
   // last-call info
   const char* dominant = "";
   int64_t last_evals = 0, last_grad_evals = 0;
+  int last_walk_launches = 1;  // chunks of evaluations the last call's walk kernels ran over
+  int aa_backoffs = 0;         // times the 20-state arena budget was reduced (aa_reserve)
 };
 
+
+// Events per profiled call: the pair around the dominant kernel(s) (all launches of a chunked
+// call) and, when phases are asked for, five marks: call start | first walk launch starts |
+// its post-order part done | its pre-order / main part done | call end.
+constexpr int kProfEvents = 7;
+inline hipEvent_t prof_event(mi_engine* e, int which) {
+  return e->prof_events[(size_t)kProfEvents * e->prof_used + which];
+}
+#define PROF_MARK(e, on, which, s)                                   \
+  do {                                                               \
+    if (on) HIP_TRY(hipEventRecord(prof_event(e, 2 + (which)), s)); \
+  } while (0)
 
 // One engine call with every pointer a device pointer (what the *_device entry points build).
 struct DeviceCall {

@@ -92,13 +92,34 @@ int aa_reserve(mi_engine* e, int T, bool gradient) {
     }
     return 0;
   };
+  // (Buffer::ensure only grows: before a retry with a smaller budget everything that scales
+  // with the chunk is given back, or an arena allocated at the larger size would stay and the
+  // retry could not succeed.)
+  auto release_chunk = [&]() {
+    for (Buffer* b : {&e->plv, &e->aa_exp_cum, &e->aa_matP, &e->aa_tipP, &e->aa_root_val,
+                      &e->aa_root_exp, &e->aa_exp_loc, &e->aa_matPT, &e->aa_tipPQ,
+                      &e->aa_root_scale, &e->g_part})
+      b->release();
+  };
+  bool backed_off = false;
+  const std::string error_before = mi_last_error();
   for (;;) {
     const size_t chunk = aa_chunk(e, T, gradient);
     if (alloc_chunk(chunk) == 0) break;
     (void)hipGetLastError();  // (out of memory is not sticky)
     if (chunk <= 1) return 1;
-    e->plv_budget = aa_arena_bytes_per_eval(e, gradient) * (chunk / 2);
+    release_chunk();
+    backed_off = true;
+    // what the device can give NOW bounds the next attempt as well (other engines of this
+    // process, torch's or RCCL's allocators may have taken memory since the engine was made)
+    size_t free_b = 0, total_b = 0;
+    size_t next = aa_arena_bytes_per_eval(e, gradient) * (chunk / 2);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 >= aa_arena_bytes_per_eval(e, gradient))
+      next = std::min(next, free_b / 2);
+    e->plv_budget = next;
+    e->aa_backoffs++;
   }
+  if (backed_off) miphylo::set_last_error(error_before);  // the failed attempts are not the call's error
   if (gradient && e->g_sum.ensure(sizeof(double) * (size_t)T * 2 * N)) return 1;
   return 0;
 }
@@ -138,11 +159,14 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ms.params = d.params;
   ms.models = e->models.as<DevModel>();
   ms.status = e->status.as<int32_t>();
+  const bool prof = e->prof_used < e->prof_capacity;
+  const bool marks = prof && e->prof_phases;
+  PROF_MARK(e, marks, 0, s);
   launch_setup(ts, ms, s);
 
-  const bool prof = e->prof_used < e->prof_capacity;
-  if (prof) HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used], s));
+  if (prof) HIP_TRY(hipEventRecord(prof_event(e, 0), s));
   const int chunk = aa_chunk(e, T, d.gradient);
+  e->prof_first_launch_evals = std::min(chunk, T);
   for (int off = 0; off < T; off += chunk) {
     const int evals = std::min(chunk, T - off);
     AaTransitionArgs tr{};
@@ -191,18 +215,19 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     w.g_part = e->g_part.as<double>();
     w.ll_sum = e->ll_sum.as<double>();
     w.g_sum = e->g_sum.as<double>();
+    PROF_MARK(e, marks && off == 0, 1, s);
     launch_aa_post(w, s);
     launch_aa_root(w, s);
+    PROF_MARK(e, marks && off == 0, 2, s);
     if (d.gradient) launch_aa_pre(w, s);
+    PROF_MARK(e, marks && off == 0, 3, s);
     launch_aa_reduce(w, s);
   }
-  if (prof) {
-    HIP_TRY(hipEventRecord(e->prof_events[2 * e->prof_used + 1], s));
-    e->prof_used++;
-  }
+  if (prof) HIP_TRY(hipEventRecord(prof_event(e, 1), s));
   e->dominant = d.gradient ? aa_pre_kernel_name() : aa_post_kernel_name();
   e->last_evals = T;
   e->last_grad_evals = d.gradient ? T : 0;
+  e->last_walk_launches = (T + chunk - 1) / chunk;
 
   FinalizeArgs fa{};
   fa.n = n;
@@ -238,6 +263,8 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   fa.out_subst = nullptr;
   fa.status = e->status.as<int32_t>();
   launch_finalize(fa, s);
+  PROF_MARK(e, marks, 4, s);
+  if (prof) e->prof_used++;
   HIP_TRY(hipGetLastError());
   return 0;
 }

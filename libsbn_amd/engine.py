@@ -332,11 +332,31 @@ class Engine:
         self._check(self._lib.mi_engine_profile_collect(self._h, out, capacity, C.byref(cnt)))
         return [out[i] for i in range(cnt.value)]
 
+    def profile_begin_phases(self, max_calls):
+        self._check(self._lib.mi_engine_profile_begin_phases(self._h, max_calls))
+
+    def profile_collect_phases(self, capacity):
+        """(total ms per call, [set-up, post-order, pre-order / main walk, rest] ms per call,
+        evaluations in the first walk launch) -- include/mi_phylo.h"""
+        out = (C.c_double * capacity)()
+        ph = (C.c_double * (4 * capacity))()
+        cnt, first = C.c_int32(), C.c_int32()
+        self._check(self._lib.mi_engine_profile_collect_phases(
+            self._h, out, ph, capacity, C.byref(cnt), C.byref(first)))
+        return ([out[i] for i in range(cnt.value)],
+                [[ph[4 * i + k] for k in range(4)] for i in range(cnt.value)], first.value)
+
     def last_call_info(self):
         name, ev, gev = C.c_char_p(), C.c_int64(), C.c_int64()
         self._check(self._lib.mi_engine_last_call_info(self._h, C.byref(name), C.byref(ev),
                                                        C.byref(gev)))
         return name.value.decode(), ev.value, gev.value
+
+    def last_call_launches(self):
+        """(walk-kernel launches of the last call, arena-budget back-offs since creation)"""
+        a, b = C.c_int32(), C.c_int32()
+        self._check(self._lib.mi_engine_last_call_launches(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
 
 def site_pattern_compress_device(codes, device=0):

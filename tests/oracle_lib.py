@@ -353,3 +353,38 @@ def struct_arrays(st):
     pids = np.array([t["parent_ids"] for t in st["trees"]], dtype=np.int32)
     bls = np.array([t["branch_lengths"] for t in st["trees"]], dtype=np.float64)
     return tips, weights, pids, bls
+
+
+def unrooted_by_pattern_blocks(spec, tips, weights, parent_ids, bl, params, rescaling=True,
+                               gradient=True, blocks=None, threads=None):
+    """Every output of the unrooted path is a sum over site patterns (rescaling is per
+    pattern): the oracle evaluated on `blocks` disjoint pattern blocks -- one call per block,
+    on a thread each (ctypes releases the GIL; the oracle's process-wide settings are only
+    read) -- and the per-block results added in block order.  This is how a full-size
+    configs[4] evaluation (512 taxa x 50 000 patterns x 4 categories: ~0.8 TFLOP for one
+    gradient) finishes in tens of seconds on the host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    tips, weights = _tips_w(tips, weights)
+    P = tips.shape[1]
+    threads = threads or min(32, os.cpu_count() or 1)
+    blocks = blocks or max(1, min(P // 64, 4 * threads))
+    cuts = [P * i // blocks for i in range(blocks + 1)]
+    lib()  # load (and, if need be, build) once, before the threads start
+
+    def one(i):
+        lo, hi = cuts[i], cuts[i + 1]
+        sub = Spec(spec.taxon_count, hi - lo, spec.state_count, spec.category_count,
+                   spec.subst_model, spec.site_model, spec.clock_model, spec.use_tip_states)
+        t, w = np.ascontiguousarray(tips[:, lo:hi]), np.ascontiguousarray(weights[lo:hi])
+        if gradient:
+            return unrooted_gradients(sub, t, w, parent_ids, bl, params, rescaling, 1)
+        return {"log_likelihood": unrooted_log_likelihoods(sub, t, w, parent_ids, bl, params,
+                                                           rescaling, 1)}
+
+    with ThreadPoolExecutor(threads) as pool:
+        parts = list(pool.map(one, range(blocks)))
+    out = {k: np.zeros_like(v) for k, v in parts[0].items()}
+    for part in parts:
+        for k, v in part.items():
+            out[k] += v
+    return out

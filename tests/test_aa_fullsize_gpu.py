@@ -1,0 +1,183 @@
+"""BASELINE.json configs[4] at its REAL size -- 20 states, 512 taxa x 50 000 site patterns x 4
+rate categories -- against the CPU oracle, and the code paths that exist only at size:
+several launches per call (arena chunks), the arena budget backing off when the device
+cannot give the memory.
+
+The oracle evaluates the tree on disjoint pattern blocks, one block per host thread, and the
+blocks are added (oracle_lib.unrooted_by_pattern_blocks: every output of the unrooted path is
+a sum over site patterns -- the additivity pattern sharding over GPUs relies on).  About
+0.8 TFLOP of CPU work for the gradient: tens of seconds on the GPU box's host cores.
+Tolerance: 1e-10 relative (north_star), log-likelihoods per tree, gradient vectors against
+their largest entry.  Style of a full-size known-answer test:
+/root/reference/src/unrooted_sbn_instance.hpp:215-257.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import aa_utils as A
+import oracle_lib as O
+import tree_utils as TU
+
+pytestmark = pytest.mark.gpu
+
+N_TAXA, N_PATTERNS, SITE = 512, 50000, "weibull+4"
+
+
+def _rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _engine(tips, w, site=SITE):
+    import libsbn_amd as L
+    return L.Engine(L.PhyloModelSpecification("WAG", site, "strict"), tips, w)
+
+
+def _wag():
+    import libsbn_amd.engine as E
+    return E.wag_model()
+
+
+def _host_threads():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+@pytest.fixture(scope="module")
+def swag():
+    """S-WAG of SURVEY 8(d): uniform tips (2 % gaps so that the gap path runs at size too),
+    integer pattern weights, one random-join topology, branch lengths Exp(mean 0.1)."""
+    rng = np.random.default_rng(47)
+    tips, w = A.random_aa_alignment(N_TAXA, N_PATTERNS, rng, gap_fraction=0.02)
+    pids, bls = TU.random_trees(N_TAXA, 1, rng)
+    pr = A.params_for(SITE, 1, rng)
+    return tips, w, pids, bls, pr
+
+
+@pytest.fixture(scope="module")
+def swag_engine_results(swag):
+    tips, w, pids, bls, pr = swag
+    eng = _engine(tips, w)
+    ll = eng.log_likelihoods(pids, bls, pr)
+    ll_launches = eng.last_call_launches()
+    g = eng.gradients(pids, bls, pr)
+    info = eng.last_call_info()
+    launches = eng.last_call_launches()
+    eng.close()
+    return ll, g, info, ll_launches, launches
+
+
+def test_full_size_log_likelihood_and_gradients_match_oracle(swag, swag_engine_results):
+    tips, w, pids, bls, pr = swag
+    ll, g, info, ll_launches, launches = swag_engine_results
+    assert info[0] == "aa_pre_kernel" and ll_launches[0] == 1 and launches[0] == 1
+    ex, fr = _wag()
+    O.set_reversible_model(ex, fr)
+    O.set_transition_mode(1)
+    try:
+        og = O.unrooted_by_pattern_blocks(A.oracle_spec(N_TAXA, N_PATTERNS, SITE), tips, w, pids,
+                                          bls, pr, rescaling=True, gradient=True,
+                                          threads=_host_threads())
+    finally:
+        O.set_transition_mode(0)
+    assert np.isfinite(ll).all() and ll[0] < -1e6
+    assert _rel(ll, og["log_likelihood"]) <= 1e-10
+    assert _rel([x.log_likelihood for x in g], og["log_likelihood"]) <= 1e-10
+    gb = np.stack([x.gradient["branch_lengths"] for x in g])
+    assert gb.shape == (1, 2 * N_TAXA - 1) and np.all(gb[:, -2:] == 0.0)
+    assert _rel(gb, og["branch_lengths"]) <= 1e-10
+    # every branch, not only the largest: relative to the branch's own value where that is
+    # not tiny against the vector
+    big = np.abs(og["branch_lengths"]) > 1e-3 * np.max(np.abs(og["branch_lengths"]))
+    assert np.max(np.abs(gb[big] - og["branch_lengths"][big]) / np.abs(og["branch_lengths"][big])) <= 1e-9
+    assert _rel([x.gradient["site_model"][0] for x in g], og["site_model"]) <= 1e-10
+
+
+def test_budget_backs_off_when_the_device_cannot_give_the_arena(swag, swag_engine_results,
+                                                                monkeypatch):
+    """24 trees of 16.4 GB of partial vectors each under a budget of 1 TB: the first arena
+    allocation (394 GB) cannot succeed on a 288 GB device, the engine releases what it got,
+    lowers the budget and runs the batch in several launches -- with results bit-identical to
+    the one-tree call (tree 0 is the tree the oracle test checks)."""
+    tips, w, pids, bls, pr = swag
+    _, g1, _, _, _ = swag_engine_results
+    T = 24
+    rng = np.random.default_rng(48)
+    more_pids, more_bls = TU.random_trees(N_TAXA, T - 1, rng)
+    pids_T = np.concatenate([pids, more_pids])
+    bls_T = np.concatenate([bls, more_bls])
+    pr_T = np.concatenate([pr, A.params_for(SITE, T - 1, rng)])
+    monkeypatch.setenv("MI_PHYLO_PLV_BYTES", str(1 << 40))
+    eng = _engine(tips, w)
+    g = eng.gradients(pids_T, bls_T, pr_T)
+    launches, backoffs = eng.last_call_launches()
+    assert backoffs >= 1 and launches >= 2, (launches, backoffs)
+    assert g[0].log_likelihood == g1[0].log_likelihood
+    assert np.array_equal(g[0].gradient["branch_lengths"], g1[0].gradient["branch_lengths"])
+    assert np.array_equal(g[0].gradient["site_model"], g1[0].gradient["site_model"])
+    assert all(np.isfinite(x.log_likelihood) and np.isfinite(x.gradient["branch_lengths"]).all()
+               for x in g)
+    # a log-likelihood call on the same engine after the back-off
+    ll = eng.log_likelihoods(pids_T[:3], bls_T[:3], pr_T[:3])
+    assert _rel(ll, [x.log_likelihood for x in g[:3]]) <= 1e-13
+    eng.close()
+
+
+@pytest.mark.parametrize("gradient", [True, False])
+def test_forced_arena_chunks_are_bit_identical_to_one_launch(gradient, monkeypatch):
+    """128 taxa x 5 000 patterns, five trees, MI_PHYLO_PLV_BYTES sized for two evaluations per
+    launch: three launches (2 + 2 + 1) of the 20-state walk kernels, every tree's results
+    identical to the one-launch call's, which is compared with the oracle."""
+    rng = np.random.default_rng(2024)
+    n, P, T = 128, 5000, 5
+    tips, w = A.random_aa_alignment(n, P, rng)
+    pids, bls = TU.random_trees(n, T, rng)
+    pr = A.params_for(SITE, T, rng)
+
+    def run(eng):
+        if gradient:
+            g = eng.gradients(pids, bls, pr)
+            return (np.array([x.log_likelihood for x in g]),
+                    np.stack([x.gradient["branch_lengths"] for x in g]),
+                    np.array([x.gradient["site_model"][0] for x in g]))
+        return (eng.log_likelihoods(pids, bls, pr),)
+
+    monkeypatch.delenv("MI_PHYLO_PLV_BYTES", raising=False)
+    eng = _engine(tips, w)
+    whole = run(eng)
+    assert eng.last_call_launches()[0] == 1
+    eng.close()
+    tiles = (P + 15) // 16
+    vectors = (n - 1) if gradient else int(np.floor(np.log2(n))) + 1
+    per_eval = vectors * 4 * tiles * 320 * 8  # [node][category][tile][20 states][16 patterns] f64
+    monkeypatch.setenv("MI_PHYLO_PLV_BYTES", str(2 * per_eval + per_eval // 2))
+    eng = _engine(tips, w)
+    parts = run(eng)
+    assert eng.last_call_launches() == (3, 0)
+    eng.close()
+    for a, b in zip(whole, parts):
+        assert np.array_equal(a, b)
+    # ... and the one-launch result is right (oracle on two of the five trees)
+    ex, fr = _wag()
+    O.set_reversible_model(ex, fr)
+    O.set_transition_mode(1)
+    try:
+        og = O.unrooted_by_pattern_blocks(A.oracle_spec(n, P, SITE), tips, w, pids[[0, 4]],
+                                          bls[[0, 4]], pr[[0, 4]], rescaling=True,
+                                          gradient=gradient, threads=_host_threads())
+    finally:
+        O.set_transition_mode(0)
+    assert _rel(whole[0][[0, 4]], og["log_likelihood"]) <= 1e-10
+    if gradient:
+        assert _rel(whole[1][[0, 4]], og["branch_lengths"]) <= 1e-10
+        assert _rel(whole[2][[0, 4]], og["site_model"]) <= 1e-10

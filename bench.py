@@ -862,6 +862,11 @@ def main():
         sys.exit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # everything runs on ONE explicit stream: torch's default stream has the null handle, which
+    # the C ABI reads as "the engine's own stream" -- events recorded by torch would then sit
+    # on another stream than the kernels they are meant to time
+    compute = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(compute)
     # MI_BENCH_FORCE_DIST=1 runs the collective path even with one rank (smoke test of
     # the RCCL branch on a 1-GPU box)
     distributed = world > 1 or os.environ.get("MI_BENCH_FORCE_DIST") == "1"

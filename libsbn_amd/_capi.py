@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi_phylo.so")
+# MI_PHYLO_LIBRARY: another build of the same library (kernel A/B runs: tools/ab_kernels.py)
+LIB_PATH = os.environ.get("MI_PHYLO_LIBRARY") or os.path.join(_HERE, "libmi_phylo.so")
 
 I32P = C.POINTER(C.c_int32)
 F64P = C.POINTER(C.c_double)

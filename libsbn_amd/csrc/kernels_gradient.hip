@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
         // this lane's state is c = hi, the 16 lanes of a row hold (category, pattern)
         double z = 0;
 #pragma unroll
-        for (int r = 0; r < R; r++) z += qroot[r] * Lv.v[r];  // qroot = pi cw w / site
+        for (int r = 0; r < R; r++) z = fma(qroot[r], Lv.v[r], z);  // qroot = pi cw w / site
         z = z / pi_l;
         z = row_shr_add<8>(z);
         z = row_shr_add<4>(z);
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       G = __builtin_amdgcn_mfma_f64_4x4x4f64(blockT(u.v[r]), blockT(Lc.v[r]), G, 0, 0, 0);
     const double R1 = __builtin_amdgcn_mfma_f64_4x4x4f64(AVt, G, 0.0, 0, 0, 0);            // V^T G
     const double R2 = __builtin_amdgcn_mfma_f64_4x4x4f64(AVi, blockT(R1), 0.0, 0, 0, 0);   // (V^T G V^-T)^T
-    Ht += R2 * phi;  // Phi is symmetric
+    Ht = fma(R2, phi, Ht);  // Phi is symmetric (explicit fma: both walk generations round alike)
   };
   auto pre_step = [&](int sh, const Slots& sl, const MacroMats& cm, const Ops& o, int m) {
     const V& qv = o.q;

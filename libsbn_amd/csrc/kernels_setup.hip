@@ -1032,12 +1032,13 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
   // one thread per matrix; the 128-byte results are staged through LDS (row stride 17:
   // conflict-free) so that the block writes its 32 KB of output as whole cache lines
   __shared__ double stage[kTransitionBlock * 17];
-  const long first = (long)blockIdx.x * kTransitionBlock;
+  // (the launch covers evaluations [eval_base, eval_base + E): indices below are global)
+  const long per = (long)a.K * (a.N - 1);
+  const long first = (long)blockIdx.x * kTransitionBlock + (long)a.eval_base * per;
   const long idx = first + threadIdx.x;
-  const long total = (long)a.E * (a.N - 1) * a.K;
+  const long total = (long)(a.eval_base + a.E) * per;
   {
     // whole workgroups inside a range of evaluations that nobody walks have nothing to do
-    const long per = (long)a.K * (a.N - 1);
     const long last = (first + kTransitionBlock - 1 < total ? first + kTransitionBlock - 1 : total - 1);
     if (first / per >= a.ev_skip_begin && last / per < a.ev_skip_end) return;
   }
@@ -1129,11 +1130,8 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
       const DevModel& m = a.models[mi];
       const double tau = m.cat_rate[k] * a.bl_eff[(size_t)t * a.N + edge];
       for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-          const double x = (m.lambda[i] - m.lambda[j]) * tau;
-          const double r = fabs(x) < 1e-5 ? 1.0 + 0.5 * x + x * x * (1.0 / 6.0) : expm1(x) / x;
-          stage[threadIdx.x * 17 + i * 4 + j] = tau * exp(m.lambda[j] * tau) * r;
-        }
+        for (int j = 0; j < 4; j++)
+          stage[threadIdx.x * 17 + i * 4 + j] = phi_divided_difference(m.lambda[i], m.lambda[j], tau);
     }
     __syncthreads();
     double* out3 = a.phi + first * 16;

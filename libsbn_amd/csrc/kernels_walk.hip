@@ -1,0 +1,774 @@
+// The matrix-core gradient walk, second generation (round 3): the same arithmetic as
+// gradient_mfma_kernel (kernels_gradient.hip) -- half storage, macros,
+// post-order then pre-order with positional edge sums -- fed by MACRO-ORDERED operand
+// streams so that the walk itself does no address arithmetic on node ids:
+//
+//   * transition_macro_kernel writes, per gradient evaluation, the matrices in the order
+//     the walk consumes them: [evaluation][macro][category group][position 0..5][4
+//     categories][16]{f, tr}
+//     (position = child0, child1, grand0..3; f = P[lo][hi], tr = P[hi][lo] for an internal
+//     edge, (P Q)[lo][hi] for a tip edge -- one 16-byte load per lane and position in the
+//     pre-order walk, one 8-byte load in the post-order walk), so a visit's six loads are a
+//     running scalar base + constants;
+//   * the tip state masks of a wave's columns sit in LDS by (macro, position) too: a
+//     visit's six words are one ds_read_b128 + one ds_read_b64 at a running address;
+//   * what is left of the schedule entry -- the shape word and the LDS slots -- comes in
+//     through the scalar cache (s_load_dword / s_load_dwordx8, two visits ahead) straight
+//     into scalar registers: no vector loads of the entry, no v_readfirstlane, no node ids
+//     in the walk at all;
+//   * a child's operand handling is selected by ONE switch on its configuration (tip /
+//     stored / unstored with tip-or-stored grandchildren: six cases of straight-line code)
+//     instead of a branch per operand;
+//   * the edge sums of macro m land in the LDS bytes that held the tip words of macro m
+//     (dead by then): 8 waves per CU as before.
+// Every product, sum and reduction is the one the first-generation kernel does, in the same
+// order: results are bit-identical (tests/test_gpu_parity.py::test_walk_kernels_agree).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <string>
+
+#include "mi_phylo_device_utils.h"
+#include "mi_phylo_kernels.h"
+
+namespace miphylo {
+
+namespace {
+using namespace dev;
+
+template <int SHIFT>
+__device__ __forceinline__ double row_shr_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int slo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + SHIFT, 0xf, 0xf, true);
+  const int shi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + SHIFT, 0xf, 0xf, true);
+  return v + __hiloint2double(shi, slo);
+}
+
+// configuration of one child of a macro (from the shape word)
+enum ChildCfg { kTip = 0, kStored = 1, kUss = 2, kUts = 3, kUst = 4, kUtt = 5 };
+__device__ __forceinline__ int child_cfg(int sh, int j) {
+  const int kind = (sh >> (2 * j)) & 3;
+  const int tips = (sh >> (10 + 2 * j)) & 3;  // bit 0: first grandchild is a tip, bit 1: second
+  return kind < 2 ? kind : 2 + tips;
+}
+
+template <int R, bool RESCALE, bool SUBST, bool ARENA>
+__global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
+  static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
+  extern __shared__ double wlds[];
+  const int lane = threadIdx.x;
+  const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
+  const TileEval te = xcd_tile_eval();
+  const int e = a.eval_offset + te.eval;
+  const int gi = a.grad_offset + te.eval;
+  int t, mi;
+  a.map.decode(e, t, mi);
+  const DevModel* __restrict__ model = a.models + mi;
+  const int K = a.K, n = a.n, Kp = a.kp;
+  const int groups = a.cat_groups, tiles_per_group = gridDim.x / groups;
+  const int group = te.tile / tiles_per_group, ptile = te.tile - group * tiles_per_group;
+  const int cat = 4 * group + b % Kp, pgrp = b / Kp, ppr = 16 / Kp;
+  const int catc = cat < K ? cat : K - 1;
+  const int Mmax = max_macros(n);
+  const MacroEntry* __restrict__ macros = a.macros + (size_t)t * Mmax;
+  const cint_ptr mw = as_const(reinterpret_cast<const int*>(macros));  // scalar loads
+  const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
+  if (ARENA) {
+    const int need = __builtin_amdgcn_readfirstlane(a.slot_need[t]);
+    if (need <= a.lds_lo || need > a.lds_slots) return;
+  }
+  // macro-ordered matrices of this gradient evaluation and category group: a position is
+  // four categories x 16 {f, tr} pairs = 1 KB whatever K is (unused categories are never
+  // read: a lane beyond K reads category K - 1, with weight zero), a visit 6 KB
+  constexpr unsigned kPosBytes = 1024u, kVisitBytes = 6u * kPosBytes;
+  const unsigned lane_moff = 16u * (unsigned)((catc - 4 * group) * 16 + lo * 4 + hi);
+  const unsigned visit_stride = (unsigned)groups * kVisitBytes;
+  const char* __restrict__ mm_g = reinterpret_cast<const char*>(a.mmats) +
+                                  ((size_t)gi * Mmax * groups + group) * kVisitBytes;
+  const char* __restrict__ ph_g =
+      SUBST ? reinterpret_cast<const char*>(a.mphi) + ((size_t)gi * Mmax * groups + group) * (kVisitBytes / 2)
+            : nullptr;
+  const int TP = ppr * R, tile_start = ptile * TP;
+  const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
+  int pat[R], patc[R];
+  double pw[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    pat[r] = tile_start + r * ppr + col;
+    patc[r] = pat[r] < a.P ? pat[r] : a.P - 1;
+    pw[r] = pat[r] < a.P ? a.weights[patc[r]] : 0.0;
+  }
+  const double pi_l = model->pi[hi];
+  const double cw_l = cat < K ? model->cat_weight[cat] : 0.0;
+  const double rate_l = model->cat_rate[catc], drate_l = model->cat_drate[catc];
+  const double AQ = model->Q[lo * 4 + hi];  // A operand for Q L (same in every block)
+
+  // LDS: [macro][column][8 words: tip masks of positions 0..5, one byte per register r]
+  // -- re-used, macro by macro, for that macro's edge sums [position][branch, site] once its
+  // tip words are in registers -- | SUBST: four root sums | vectors [slot][r][lane] |
+  // RESCALE: exponents
+  const unsigned tstride = (unsigned)ppr * 32u;  // bytes per macro (>= 96: ppr >= 4)
+  char* const lds0 = reinterpret_cast<char*>(wlds);
+  const unsigned tips_bytes = (unsigned)Mmax * tstride + (SUBST ? 32u : 0u);
+  double* const xroot = reinterpret_cast<double*>(lds0 + (unsigned)Mmax * tstride);
+  char* const plv = lds0 + tips_bytes;
+  int16_t* exps = reinterpret_cast<int16_t*>(
+      plv + (size_t)(ARENA ? a.lds_slots : max_stored(n)) * R * kTile * 8);
+  char* const arena =
+      ARENA ? reinterpret_cast<char*>(a.plv + ((size_t)te.eval * gridDim.x + te.tile) *
+                                                   max_stored(n) * R * kTile)
+            : nullptr;
+  {
+    // tip state masks of this wave's columns, by (macro, position): a lane takes one
+    // (macro, position) pair whose node is a tip and copies its TP bytes
+    const int* mwv = reinterpret_cast<const int*>(macros);
+    const int ppr_shift = Kp == 4 ? 2 : (Kp == 2 ? 3 : 4);
+    for (int j = lane; j < M * 6; j += kTile) {
+      const int m = j / 6, pos = j - m * 6;
+      const int node = mwv[m * 16 + 1 + pos];
+      if (node < n) {
+        const uint8_t* src = a.tip_masks + (size_t)node * a.P;
+        char* dst = lds0 + (unsigned)m * tstride + (unsigned)pos * 4u;
+        for (int q = 0; q < TP; q++) {
+          const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
+          dst[(q & (ppr - 1)) * 32 + (q >> ppr_shift)] = (char)src[pp];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (M <= 0) return;
+
+  struct V {
+    double v[R];
+  };
+  const unsigned lane8 = 8u * lane;
+  // slot (a scalar) -> LDS address in ONE vector instruction: v_mad_u32_u24 with the stride
+  // in a vector register (a literal stride would cost a scalar multiply on top of the add)
+  unsigned slot_stride = R * kTile * 8;
+  asm volatile("" : "+v"(slot_stride));
+  const unsigned plv_lane = (unsigned)(plv - lds0) + lane8;
+  auto slot_ptr = [&](int slot) {  // slot: scalar
+    return reinterpret_cast<double*>(lds0 + (__umul24((unsigned)slot, slot_stride) + plv_lane));
+  };
+  auto load_slot = [&](int slot) {
+    V x;
+    const double* c = slot_ptr(slot);
+#pragma unroll
+    for (int r = 0; r < R; r++) x.v[r] = c[r * kTile];
+    return x;
+  };
+  auto store_slot = [&](int slot, const V& x) {
+    double* c = slot_ptr(slot);
+#pragma unroll
+    for (int r = 0; r < R; r++) c[r * kTile] = x.v[r];
+  };
+  auto store_arena = [&](int id, const V& x) {
+    double* c = reinterpret_cast<double*>(arena + ((unsigned)id * (unsigned)(R * kTile * 8) + lane8));
+#pragma unroll
+    for (int r = 0; r < R; r++) c[r * kTile] = x.v[r];
+  };
+  auto arena_at = [&](int k) {
+    V x;
+    const double* c =
+        reinterpret_cast<const double*>(arena + ((unsigned)k * (unsigned)(R * kTile * 8) + lane8));
+#pragma unroll
+    for (int r = 0; r < R; r++) x.v[r] = c[r * kTile];
+    return x;
+  };
+  auto mm = [&](double A, const V& x) {
+    V y;
+#pragma unroll
+    for (int r = 0; r < R; r++) y.v[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(A, x.v[r], 0.0, 0, 0, 0);
+    return y;
+  };
+  auto mul = [&](const V& x, const V& y) {
+    V z;
+#pragma unroll
+    for (int r = 0; r < R; r++) z.v[r] = x.v[r] * y.v[r];
+    return z;
+  };
+  auto tipv = [&](uint32_t w) {
+    V x;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      x.v[r] = (double)__builtin_amdgcn_ubfe(w, (uint32_t)(8 * r + hi), 1u);
+    return x;
+  };
+
+  // ---- what a visit needs from memory, fetched a visit ahead ----
+  struct Mats {
+    double f[6], tr[6];
+    double ph[SUBST ? 6 : 1];
+    uint32_t tw[6];
+  };
+  struct Slots {  // scalars (s_load_dwordx8)
+    int q, c[2], g[4], dst;
+  };
+  auto load_shape = [&](int m) { return mw[m * 16]; };
+  auto load_slots = [&](int m) {
+    const cint_ptr p = mw + m * 16 + 8;
+    return Slots{p[0], {p[1], p[2]}, {p[3], p[4], p[5], p[6]}, p[7]};
+  };
+  const unsigned tw_lane = (unsigned)col * 32u;
+  auto fetch = [&](int m, bool pre) {  // m: scalar
+    Mats mt;
+    // scalar base of the visit + this lane's 32-bit offset + constants (the offset is made
+    // opaque so that it is not folded into a 64-bit per-lane pointer: that would cost two
+    // vector instructions per load instead of none)
+    // (positions 4 and 5 lie beyond the 4095-byte immediate: a second scalar base)
+    const char* sb = mm_g + (size_t)((unsigned)m * visit_stride);
+    unsigned off4 = 4 * kPosBytes;
+    asm volatile("" : "+s"(off4));
+    const char* sb4 = sb + off4;
+    unsigned voff = lane_moff;
+    asm volatile("" : "+v"(voff));
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const char* at = (j < 4 ? sb + j * kPosBytes : sb4 + (j - 4) * kPosBytes) + (size_t)voff;
+      if (pre) {
+        const double2 x = *reinterpret_cast<const double2*>(at);
+        mt.f[j] = x.x;
+        mt.tr[j] = x.y;
+      } else {
+        mt.f[j] = *reinterpret_cast<const double*>(at);
+      }
+    }
+    if (pre && SUBST) {
+      const char* sp = ph_g + (size_t)((unsigned)m * (visit_stride / 2));
+      unsigned vph = lane_moff / 2;
+      asm volatile("" : "+v"(vph));
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+        mt.ph[j] = *reinterpret_cast<const double*>(sp + j * (kPosBytes / 2) + (size_t)vph);
+    }
+    const uint4 w4 = *reinterpret_cast<const uint4*>(lds0 + (unsigned)m * tstride + tw_lane);
+    const uint2 w2 = *reinterpret_cast<const uint2*>(lds0 + (unsigned)m * tstride + tw_lane + 16u);
+    mt.tw[0] = w4.x;
+    mt.tw[1] = w4.y;
+    mt.tw[2] = w4.z;
+    mt.tw[3] = w4.w;
+    mt.tw[4] = w2.x;
+    mt.tw[5] = w2.y;
+    return mt;
+  };
+
+  double qroot[R];  // root pre-order vector: pi * category weight * w_p / site likelihood
+  int esum[R];      // RESCALE: exponents removed so far, per pattern
+#pragma unroll
+  for (int r = 0; r < R; r++) esum[r] = 0;
+
+  // one child of a post-order visit: its vector L (tip: expanded; stored: from its slot;
+  // unstored: recomputed from its two children)
+  auto child_L = [&](int cfg, int j, const Mats& mt, const Slots& sl, V& xa, V& xb, V& Ap, V& Bp,
+                     bool pre, const V& pa, const V& pb) {
+    // pre && ARENA: stored inputs arrive from the arena (pa, pb), requested a visit ahead
+    const bool fa = ARENA && pre;
+    V L;
+    switch (cfg) {
+      case kTip:
+        L = tipv(mt.tw[j]);
+        break;
+      case kStored:
+        L = fa ? pa : load_slot(sl.c[j]);
+        break;
+      case kUss:
+        xa = fa ? pa : load_slot(sl.g[2 * j]);
+        xb = fa ? pb : load_slot(sl.g[2 * j + 1]);
+        Ap = mm(mt.f[2 + 2 * j], xa);
+        Bp = mm(mt.f[3 + 2 * j], xb);
+        L = mul(Ap, Bp);
+        break;
+      case kUts:
+        xa = tipv(mt.tw[2 + 2 * j]);
+        xb = fa ? pb : load_slot(sl.g[2 * j + 1]);
+        Ap = mm(mt.f[2 + 2 * j], xa);
+        Bp = mm(mt.f[3 + 2 * j], xb);
+        L = mul(Ap, Bp);
+        break;
+      case kUst:
+        xa = fa ? pa : load_slot(sl.g[2 * j]);
+        xb = tipv(mt.tw[3 + 2 * j]);
+        Ap = mm(mt.f[2 + 2 * j], xa);
+        Bp = mm(mt.f[3 + 2 * j], xb);
+        L = mul(Ap, Bp);
+        break;
+      default:  // kUtt
+        xa = tipv(mt.tw[2 + 2 * j]);
+        xb = tipv(mt.tw[3 + 2 * j]);
+        Ap = mm(mt.f[2 + 2 * j], xa);
+        Bp = mm(mt.f[3 + 2 * j], xb);
+        L = mul(Ap, Bp);
+        break;
+    }
+    return L;
+  };
+
+  V pend_L;  // ARENA: the last stored vector, on its way to the arena
+  int pend_dst = 0;
+  bool pend = false;
+  auto flush_arena = [&]() {
+    if (ARENA && pend) {
+      store_arena(pend_dst, pend_L);
+      pend = false;
+    }
+  };
+
+  // ================= post-order over the stored nodes (+ root: site likelihood) ====
+  auto post_visit = [&](int sh, const Slots& sl, const Mats& mt, auto&& next_scalars) {
+    V xa, xb, Ap, Bp;
+    const V none{};
+    const V L0 = child_L(child_cfg(sh, 0), 0, mt, sl, xa, xb, Ap, Bp, false, none, none);
+    const V L1 = child_L(child_cfg(sh, 1), 1, mt, sl, xa, xb, Ap, Bp, false, none, none);
+    // this visit's LDS operands have been read: the scalar loads of the coming visits go out
+    // here (LDS and scalar loads share one counter, and a scalar load may return out of
+    // order: issued earlier they would turn every LDS wait into a wait for them too)
+    next_scalars();
+    V Lv = mul(mm(mt.f[0], L0), mm(mt.f[1], L1));
+    if (!(sh & 16)) {
+      if (RESCALE) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const double colsum = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, Lv.v[r], 0.0, 0, 0, 0);
+          int ex = colsum > 0.0 ? __builtin_amdgcn_frexp_exp(colsum) : -4096;
+          if (Kp >= 2) ex = max(ex, __shfl_xor(ex, 4, 64));
+          if (Kp >= 4) ex = max(ex, __shfl_xor(ex, 8, 64));
+          ex = ex == -4096 ? 0 : ex;
+          Lv.v[r] = ldexp(Lv.v[r], -ex);
+          esum[r] += ex;
+          exps[(unsigned)(ARENA ? sl.dst : sl.q) * (unsigned)TP + (unsigned)(r * ppr + col)] = (int16_t)ex;
+        }
+      }
+      store_slot(sl.q, Lv);
+      if (ARENA) {
+        pend_L = Lv;
+        pend_dst = sl.dst;
+        pend = true;
+      }
+    } else {
+      // root: site likelihood per pattern, log-likelihood partial, derivative weights
+      double sitev[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        double v;
+        if (groups > 1) {
+          const size_t at = ((size_t)a.grad_offset + te.eval) * a.tiles * kTile + patc[r];
+          v = a.site_lik[at];
+          if (RESCALE) v = ldexp(v, a.site_exp[at] - esum[r]);
+        } else {
+          v = cw_l * pi_l * Lv.v[r];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (Kp >= 2) v += __shfl_xor(v, 4, 64);
+          if (Kp >= 4) v += __shfl_xor(v, 8, 64);
+        }
+        sitev[r] = v;
+      }
+      double sv = sitev[0], wv = pw[0];
+      int pv = pat[0], ev = esum[0];
+#pragma unroll
+      for (int j = 1; j < R; j++) {
+        sv = hi == j ? sitev[j] : sv;
+        wv = hi == j ? pw[j] : wv;
+        pv = hi == j ? pat[j] : pv;
+        ev = hi == j ? esum[j] : ev;
+      }
+      const double quot = wv / sv;  // pw = 0 for padding patterns
+#pragma unroll
+      for (int r = 0; r < R; r++) qroot[r] = pi_l * cw_l * __shfl(quot, (r << 4) | (lane & 15), 64);
+      double ll = 0.0;
+      if (hi < R && (b % Kp) == 0 && pv < a.P)
+        ll = wv * (RESCALE ? log(sv) + ev * 0.69314718055994530942 : log(sv));
+      ll = wave_sum(ll);
+      if (lane == 0 && groups == 1) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
+      if (SUBST) {
+        double z = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) z = fma(qroot[r], Lv.v[r], z);
+        z = z / pi_l;
+        z = row_shr_add<8>(z);
+        z = row_shr_add<4>(z);
+        z = row_shr_add<2>(z);
+        z = row_shr_add<1>(z);
+        if ((lane & 15) == 15) xroot[hi] = z;
+      }
+    }
+  };
+  {
+    // Two visits per iteration, two register sets.  At the top of visit m: shape(m),
+    // shape(m+1), slots(m), matrices and tip words (m) are there; the loads of visit m+1
+    // (matrices, tip words) go out first, the scalar loads of shape(m+2) and slots(m+1)
+    // after this visit's LDS operands have been read (one lgkm counter for both).
+    int sha = load_shape(0), shb = load_shape(M > 1 ? 1 : 0);
+    Slots sa = load_slots(0), sb;
+    Mats ma = fetch(0, false), mb;
+    for (int m = 0; m < M; m += 2) {
+      mb = fetch(m + 1 < M ? m + 1 : M - 1, false);
+      flush_arena();
+      int sh_next;
+      post_visit(sha, sa, ma, [&]() {
+        sb = load_slots(m + 1 < M ? m + 1 : M - 1);
+        sh_next = load_shape(m + 2 < M ? m + 2 : M - 1);
+      });
+      sha = sh_next;
+      if (m + 1 < M) {
+        ma = fetch(m + 2 < M ? m + 2 : M - 1, false);
+        flush_arena();
+        post_visit(shb, sb, mb, [&]() {
+          sa = load_slots(m + 2 < M ? m + 2 : M - 1);
+          sh_next = load_shape(m + 3 < M ? m + 3 : M - 1);
+        });
+        shb = sh_next;
+      }
+    }
+    flush_arena();
+  }
+
+  // ================= pre-order + edge derivatives =================
+  const double coef_a = lo == 0 ? rate_l : (lo == 1 ? drate_l : 0.0);
+  const double coef_b = lo == 2 ? rate_l : (lo == 3 ? drate_l : 0.0);
+  const unsigned sum_lane = 8u * (unsigned)lo;
+  auto edge_sums = [&](const V& na, const V& nb, int m, int pos_a) {
+    double sa = na.v[0], sb = nb.v[0];
+#pragma unroll
+    for (int r = 1; r < R; r++) {
+      sa += na.v[r];
+      sb += nb.v[r];
+    }
+    double d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sa, coef_a, 0.0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sb, coef_b, d1, 0, 0, 0);
+    double red = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, d1, 0.0, 0, 0, 0);
+    red = row_shr_add<4>(red);
+    red = row_shr_add<8>(red);
+    // lanes 12..15 (block 3 of row 0) hold branch a, site a, branch b, site b
+    if (lane >= 12 && lane < 16)
+      *reinterpret_cast<double*>(lds0 + ((unsigned)m * tstride + (unsigned)pos_a * 16u + sum_lane)) = red;
+  };
+  const double ident = hi == lo ? 1.0 : 0.0;
+  auto blockT = [&](double x) { return __builtin_amdgcn_mfma_f64_4x4x4f64(x, ident, 0.0, 0, 0, 0); };
+  const double AVt = SUBST ? model->V[hi * 4 + lo] : 0.0;
+  const double AVi = SUBST ? model->Vinv[lo * 4 + hi] : 0.0;
+  double Ht = 0.0;
+  auto subst_stats = [&](const V& u, const V& Lc, double phi) {
+    double G = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      G = __builtin_amdgcn_mfma_f64_4x4x4f64(blockT(u.v[r]), blockT(Lc.v[r]), G, 0, 0, 0);
+    const double R1 = __builtin_amdgcn_mfma_f64_4x4x4f64(AVt, G, 0.0, 0, 0, 0);
+    const double R2 = __builtin_amdgcn_mfma_f64_4x4x4f64(AVi, blockT(R1), 0.0, 0, 0, 0);
+    Ht = fma(R2, phi, Ht);  // (explicit fma: both walk generations round alike)
+  };
+  // Edge of child c below a node with pre-order vector q and sibling product S (qs = q o S):
+  //   internal child: q_c = P_c^T qs, numerator q_c o (Q L_c), q_c kept if stored
+  //   tip child:      numerator qs o ((P_c Q) L_c)  -- `tr` is then (P_c Q)
+  auto tip_edge = [&](double trm, const V& qs, const V& Lc, double phi) {
+    if (SUBST) subst_stats(qs, Lc, phi);
+    return mul(qs, mm(trm, Lc));
+  };
+  auto inner_edge = [&](double trm, const V& qs, const V& Lc, double phi, V& qc) {
+    if (SUBST) subst_stats(qs, Lc, phi);
+    qc = mm(trm, qs);
+    return mul(qc, mm(AQ, Lc));
+  };
+  struct PreL {  // ARENA: stored inputs of a visit, in position order
+    V x[4];
+  };
+  auto prefetch_L = [&](int sh) {
+    PreL p;
+    int k = (int)((unsigned)sh >> 16), i = 0;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int cfg = child_cfg(sh, j);
+      if (cfg == kStored) p.x[2 * j] = arena_at(k++);
+      if (cfg == kUss || cfg == kUst) p.x[2 * j] = arena_at(k++);
+      if (cfg == kUss || cfg == kUts) p.x[2 * j + 1] = arena_at(k++);
+    }
+    (void)i;
+    return p;
+  };
+  auto pre_visit = [&](int sh, const Slots& sl, const Mats& mt, int m, const PreL& pl,
+                       auto&& next_scalars) {
+    V qv;
+    if (sh & 16) {
+#pragma unroll
+      for (int r = 0; r < R; r++) qv.v[r] = qroot[r];
+    } else {
+      qv = load_slot(sl.q);
+      if (RESCALE) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          qv.v[r] = ldexp(qv.v[r], -(int)exps[(unsigned)(ARENA ? sl.dst : sl.q) * (unsigned)TP +
+                                              (unsigned)(r * ppr + col)]);
+      }
+    }
+    const int cfg0 = child_cfg(sh, 0), cfg1 = child_cfg(sh, 1);
+    V xa0, xb0, Ap0, Bp0, xa1, xb1, Ap1, Bp1;
+    const V L0 = child_L(cfg0, 0, mt, sl, xa0, xb0, Ap0, Bp0, true, pl.x[0], pl.x[1]);
+    const V L1 = child_L(cfg1, 1, mt, sl, xa1, xb1, Ap1, Bp1, true, pl.x[2], pl.x[3]);
+    next_scalars();  // (see post_visit)
+    const V A = mm(mt.f[0], L0), B = mm(mt.f[1], L1);
+    V q0, q1, n0, n1;
+    {
+      const V qs0 = mul(qv, B);
+      if (cfg0 == kTip) {
+        n0 = tip_edge(mt.tr[0], qs0, L0, mt.ph[0]);
+      } else {
+        n0 = inner_edge(mt.tr[0], qs0, L0, mt.ph[0], q0);
+        if (cfg0 == kStored) store_slot(sl.c[0], q0);
+      }
+      const V qs1 = mul(qv, A);
+      if (cfg1 == kTip) {
+        n1 = tip_edge(mt.tr[1], qs1, L1, mt.ph[SUBST ? 1 : 0]);
+      } else {
+        n1 = inner_edge(mt.tr[1], qs1, L1, mt.ph[SUBST ? 1 : 0], q1);
+        if (cfg1 == kStored) store_slot(sl.c[1], q1);
+      }
+      edge_sums(n0, n1, m, 0);
+    }
+    // grandchildren of an unstored child: (first is a tip, second is a tip) from the cfg
+    auto grand = [&](int cfg, int j, const V& qc, const V& xa, const V& xb, const V& Ap, const V& Bp) {
+      V na, nb, qa, qb;
+      const V qsa = mul(qc, Bp), qsb = mul(qc, Ap);
+      switch (cfg) {
+        case kUss:
+          na = inner_edge(mt.tr[2 + 2 * j], qsa, xa, mt.ph[SUBST ? 2 + 2 * j : 0], qa);
+          store_slot(sl.g[2 * j], qa);
+          nb = inner_edge(mt.tr[3 + 2 * j], qsb, xb, mt.ph[SUBST ? 3 + 2 * j : 0], qb);
+          store_slot(sl.g[2 * j + 1], qb);
+          break;
+        case kUts:
+          na = tip_edge(mt.tr[2 + 2 * j], qsa, xa, mt.ph[SUBST ? 2 + 2 * j : 0]);
+          nb = inner_edge(mt.tr[3 + 2 * j], qsb, xb, mt.ph[SUBST ? 3 + 2 * j : 0], qb);
+          store_slot(sl.g[2 * j + 1], qb);
+          break;
+        case kUst:
+          na = inner_edge(mt.tr[2 + 2 * j], qsa, xa, mt.ph[SUBST ? 2 + 2 * j : 0], qa);
+          store_slot(sl.g[2 * j], qa);
+          nb = tip_edge(mt.tr[3 + 2 * j], qsb, xb, mt.ph[SUBST ? 3 + 2 * j : 0]);
+          break;
+        default:
+          na = tip_edge(mt.tr[2 + 2 * j], qsa, xa, mt.ph[SUBST ? 2 + 2 * j : 0]);
+          nb = tip_edge(mt.tr[3 + 2 * j], qsb, xb, mt.ph[SUBST ? 3 + 2 * j : 0]);
+          break;
+      }
+      edge_sums(na, nb, m, 2 + 2 * j);
+    };
+    if (cfg0 >= kUss) grand(cfg0, 0, q0, xa0, xb0, Ap0, Bp0);
+    if (cfg1 >= kUss) grand(cfg1, 1, q1, xa1, xb1, Ap1, Bp1);
+  };
+  {
+    int sha = load_shape(M - 1), shb = load_shape(M > 1 ? M - 2 : 0);
+    Slots sa = load_slots(M - 1), sb;
+    Mats ma = fetch(M - 1, true), mb;
+    PreL la, lb;
+    if (ARENA) la = prefetch_L(sha);
+    for (int m = M - 1; m >= 0; m -= 2) {
+      mb = fetch(m >= 1 ? m - 1 : 0, true);
+      if (ARENA) lb = prefetch_L(shb);
+      int sh_next;
+      // (the slots of the visit in progress stay live to its end: the next ones go to the
+      // other set, the shape after next to a temporary)
+      pre_visit(sha, sa, ma, m, la, [&]() {
+        sb = load_slots(m >= 1 ? m - 1 : 0);
+        sh_next = load_shape(m >= 2 ? m - 2 : 0);
+      });
+      sha = sh_next;
+      if (m >= 1) {
+        ma = fetch(m >= 2 ? m - 2 : 0, true);
+        if (ARENA) la = prefetch_L(sha);
+        pre_visit(shb, sb, mb, m - 1, lb, [&]() {
+          sa = load_slots(m >= 2 ? m - 2 : 0);
+          sh_next = load_shape(m >= 3 ? m - 3 : 0);
+        });
+        shb = sh_next;
+      }
+    }
+  }
+  __syncthreads();
+  // positions that do not exist in a macro are never written nor read downstream
+  const int gwidth = Mmax * kMacroPositions * 2 + (SUBST ? kSubstExtra : 0);
+  double* gout = a.g_part + ((size_t)gi * a.g_tiles + te.tile) * gwidth;
+  for (int i = lane; i < M * kMacroPositions * 2; i += kTile) {
+    const int m = i / (kMacroPositions * 2), r = i - m * (kMacroPositions * 2);
+    gout[i] = *reinterpret_cast<const double*>(lds0 + (unsigned)m * tstride + (unsigned)r * 8u);
+  }
+  if (SUBST) {
+    gout[gwidth - kSubstExtra + lane] = Ht;
+    if (lane < 4) gout[gwidth - 4 + lane] = xroot[lane];
+  }
+}
+
+// ------------------------------------------------------------------------
+// Transition matrices in the order the walk consumes them.  One thread per (gradient
+// evaluation, macro, position, category): P = I + V expm1(L r t) V^-1 of the position's
+// node (DESIGN.md "Accuracy"; negative entries clamped as BEAGLE does) and the matrix of the
+// pre-order step -- P^T for an internal edge, P Q for a tip edge -- interleaved {f, tr} per
+// lane slot (lo, hi): f = P[lo][hi], tr = P[hi][lo] | (P Q)[lo][hi].  Staged through LDS so
+// that a block writes whole cache lines.  SUBST: the divided differences Phi[hi][lo] too.
+// ------------------------------------------------------------------------
+constexpr int kTmBlock = 128;
+__global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMacroArgs a) {
+  __shared__ double stage[kTmBlock * 33];
+  // thread index = record index: (evaluation, macro, category group, position, category in
+  // the group); records of categories beyond K exist in memory but are never written
+  const int Mmax = max_macros(a.n);
+  const int groups = (a.K + 3) / 4;
+  const long per_eval = (long)Mmax * groups * 24;
+  const long first = (long)blockIdx.x * kTmBlock;
+  const long idx = first + threadIdx.x;
+  const long total = (long)a.count * per_eval;
+  bool live = false;
+  double Pm[16];
+  const DevModel* mp = nullptr;
+  double tau = 0;
+  if (idx < total) {
+    const int kk = idx & 3;
+    const int pos = (idx >> 2) % 6;
+    const int group = (idx / 24) % groups;
+    const int m = (idx / (24L * groups)) % Mmax;
+    const int ge = idx / per_eval;  // gradient evaluation of this launch
+    const int k = 4 * group + kk;
+    int t, mi;
+    a.map.decode(a.eval_begin + ge, t, mi);
+    const MacroEntry& me = a.macros[(size_t)t * Mmax + m];
+    const bool exists = k < a.K && m < a.macro_count[t] &&
+                        (pos < 2 || ((me.shape >> (2 * ((pos - 2) >> 1))) & 3) == 2);
+    if (exists) {
+      live = true;
+      const int node = pos < 2 ? me.child[pos] : me.grand[pos - 2];
+      const DevModel& md = a.models[mi];
+      mp = &md;
+      tau = md.cat_rate[k] * a.bl_eff[(size_t)t * a.N + node];
+      double ex[4], W[16];
+      for (int x = 0; x < 4; x++) ex[x] = expm1(md.lambda[x] * tau);
+      for (int x = 0; x < 4; x++)
+        for (int j = 0; j < 4; j++) W[x * 4 + j] = ex[x] * md.Vinv[x * 4 + j];
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+          double sum = i == j ? 1.0 : 0.0;
+          for (int x = 0; x < 4; x++) sum += md.V[i * 4 + x] * W[x * 4 + j];
+          Pm[i * 4 + j] = sum > 0 ? sum : 0;
+        }
+      const bool tip = node < a.n;
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+          double trv;
+          if (tip) {
+            trv = 0;
+            for (int x = 0; x < 4; x++) trv += Pm[i * 4 + x] * md.Q[x * 4 + j];
+          } else {
+            trv = Pm[j * 4 + i];
+          }
+          stage[threadIdx.x * 33 + (i * 4 + j) * 2] = Pm[i * 4 + j];
+          stage[threadIdx.x * 33 + (i * 4 + j) * 2 + 1] = trv;
+        }
+    }
+  }
+  // (positions that do not exist are never read: whole 256-byte records are skipped)
+  const unsigned long long ballot = __ballot(live);
+  __shared__ unsigned long long live_mask[kTmBlock / 64];
+  if ((threadIdx.x & 63) == 0) live_mask[threadIdx.x >> 6] = ballot;
+  __syncthreads();
+  const long left = total - first;
+  const int count = (int)(left < kTmBlock ? left : kTmBlock);
+  double* out = a.mmats + first * 32;
+  for (int x = threadIdx.x; x < count * 32; x += kTmBlock) {
+    const int rec = x >> 5;
+    if ((live_mask[rec >> 6] >> (rec & 63)) & 1) out[x] = stage[rec * 33 + (x & 31)];
+  }
+  if (a.mphi != nullptr) {
+    __syncthreads();
+    if (live) {
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)  // slot (lo = i, hi = j) holds Phi[hi][lo]
+          stage[threadIdx.x * 33 + i * 4 + j] = phi_divided_difference(mp->lambda[j], mp->lambda[i], tau);
+    }
+    __syncthreads();
+    double* out2 = a.mphi + first * 16;
+    for (int x = threadIdx.x; x < count * 16; x += kTmBlock) {
+      const int rec = x >> 4;
+      if ((live_mask[rec >> 6] >> (rec & 63)) & 1) out2[x] = stage[rec * 33 + (x & 15)];
+    }
+  }
+}
+
+}  // namespace
+
+size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots) {
+  const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
+  size_t bytes = (size_t)max_macros(n) * (16 / kp) * 32 + (subst ? 32 : 0) +
+                 sizeof(double) * (size_t)slots * kLlR * kTile;
+  if (rescale) bytes += ((sizeof(int16_t) * (size_t)max_stored(n) * kLlR * (16 / kp) + 7) / 8) * 8;
+  return bytes;
+}
+size_t gradient_walk_lds_bytes(int n, int K, bool rescale, bool subst) {
+  return gradient_walk_lds_bytes_for(n, K, rescale, subst, max_stored(n));
+}
+size_t gradient_walk_mats_bytes_per_eval(int n, int K) {
+  return (size_t)max_macros(n) * ((K + 3) / 4) * 24 * 32 * sizeof(double);
+}
+
+void launch_transition_macro(const TransitionMacroArgs& a, hipStream_t s) {
+  if (a.count <= 0) return;
+  const long total = (long)a.count * max_macros(a.n) * ((a.K + 3) / 4) * 24;
+  hipLaunchKernelGGL(transition_macro_kernel, dim3((unsigned)((total + kTmBlock - 1) / kTmBlock)),
+                     dim3(kTmBlock), 0, s, a);
+}
+
+template <bool RESCALE, bool SUBST, bool ARENA>
+static void launch_walk_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  allow_large_lds(reinterpret_cast<const void*>(gradient_walk_kernel<kLlR, RESCALE, SUBST, ARENA>), lds);
+  hipLaunchKernelGGL((gradient_walk_kernel<kLlR, RESCALE, SUBST, ARENA>), grid, dim3(kTile), lds, s, a);
+}
+template <bool ARENA>
+static void launch_walk_store(const LikArgs& a, dim3 grid, size_t lds, bool rescale, bool subst,
+                              hipStream_t s) {
+  if (rescale && subst) launch_walk_variant<true, true, ARENA>(a, grid, lds, s);
+  else if (rescale) launch_walk_variant<true, false, ARENA>(a, grid, lds, s);
+  else if (subst) launch_walk_variant<false, true, ARENA>(a, grid, lds, s);
+  else launch_walk_variant<false, false, ARENA>(a, grid, lds, s);
+}
+void launch_gradient_walk(const LikArgs& a_in, int count, bool rescale, bool subst, hipStream_t s) {
+  if (count <= 0) return;
+  LikArgs a = a_in;
+  a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
+  a.cat_groups = gradient_mfma_groups(a.K);
+  const dim3 grid(gradient_mfma_tiles(a.P, a.K) * a.cat_groups, count);
+  if (gradient_walk_use_arena(a.n, a.K, rescale, subst)) {
+    const int usual = gradient_arena_slots_usual(a.n), sure = gradient_arena_slots_sure(a.n);
+    a.lds_lo = -1;
+    a.lds_slots = usual;
+    launch_walk_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, subst, usual),
+                            rescale, subst, s);
+    if (sure > usual) {
+      a.lds_lo = usual;
+      a.lds_slots = sure;
+      launch_walk_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, subst, sure),
+                              rescale, subst, s);
+    }
+    return;
+  }
+  launch_walk_store<false>(a, grid, gradient_walk_lds_bytes(a.n, a.K, rescale, subst), rescale,
+                           subst, s);
+}
+
+bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst) {
+  static const int forced = [] {
+    const char* env = getenv("MI_PHYLO_GRADIENT_STORE");
+    if (!env) return 0;
+    return std::string(env) == "arena" ? 2 : (std::string(env) == "lds" ? 1 : 0);
+  }();
+  const size_t lds_all = gradient_walk_lds_bytes(n, K, rescale, subst);
+  const bool lds_fits = lds_all <= 160 * 1024;
+  if (forced == 1 && lds_fits) return false;
+  if (forced == 2) return true;
+  return !lds_fits || (160 * 1024) / lds_all < 7;
+}
+bool gradient_walk_fits(int n, int K, bool rescale) {
+  if (n < 3 || K > kMaxCategories) return false;
+  if (gradient_walk_lds_bytes(n, K, rescale, true) <= 160 * 1024) return true;
+  return gradient_walk_lds_bytes_for(n, K, rescale, true, gradient_arena_slots_sure(n)) <= 160 * 1024;
+}
+const char* gradient_walk_kernel_name() { return "gradient_walk_kernel"; }
+
+}  // namespace miphylo

@@ -135,6 +135,18 @@ __device__ __forceinline__ TileEval xcd_tile_eval() {
   return te;
 }
 
+// Divided difference of exp(lambda tau) for the analytic substitution gradient:
+// Phi[row][col] = tau e^{l_col tau} expm1(x) / x, x = (l_row - l_col) tau (stable for close and
+// equal eigenvalues).  Explicitly rounded operations: both transition kernels (node order,
+// macro order) must produce the same bits, whatever the compiler would contract around them.
+__device__ __forceinline__ double phi_divided_difference(double lam_row, double lam_col, double tau) {
+  const double x = __dmul_rn(__dsub_rn(lam_row, lam_col), tau);
+  const double r = fabs(x) < 1e-5
+                       ? __dadd_rn(__dadd_rn(1.0, __dmul_rn(0.5, x)), __dmul_rn(__dmul_rn(x, x), 1.0 / 6.0))
+                       : __ddiv_rn(expm1(x), x);
+  return __dmul_rn(__dmul_rn(tau, exp(__dmul_rn(lam_col, tau))), r);
+}
+
 __device__ __forceinline__ void set_status(int32_t* status, int code, int tree) {
   if (atomicCAS(status, 0, code) == 0) status[1] = tree;
 }

@@ -64,6 +64,16 @@ CallShape call_shape(const mi_engine* e, int T, bool gradient, bool analytic = f
   return c;
 }
 
+// the two generations of the matrix-core gradient walk (kernels_gradient.hip /
+// kernels_walk.hip) size their LDS slightly differently
+bool use_arena(const mi_engine* e, bool rescale, bool subst) {
+  return e->walk2 ? gradient_walk_use_arena(e->n, e->K, rescale, subst)
+                  : gradient_mfma_use_arena(e->n, e->K, rescale, subst);
+}
+bool walk_fits(const mi_engine* e, bool rescale) {
+  return e->walk2 ? gradient_walk_fits(e->n, e->K, rescale) : gradient_mfma_fits(e->n, e->K, rescale);
+}
+
 size_t plv_bytes_per_eval(const mi_engine* e) {
   return (size_t)(e->n - 1) * e->K * e->tiles * kTile * 4 * sizeof(double);
 }
@@ -82,6 +92,12 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
   if (e->tip_tables.ensure(sizeof(double) * (size_t)c.E * n * e->K * 20)) return 1;
   if (gradient && e->tr_mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
   if (analytic && e->phi.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
+  if (gradient && e->walk2) {
+    // matrices in the walk's order, per gradient evaluation (kernels_walk.hip)
+    const size_t per = gradient_walk_mats_bytes_per_eval(n, e->K);
+    if (e->mmats.ensure(per * (size_t)c.Eg)) return 1;
+    if (analytic && e->mphi.ensure(per / 2 * (size_t)c.Eg)) return 1;
+  }
   if (analytic && e->x_sum.ensure(sizeof(double) * (size_t)c.Eg * kSubstExtra)) return 1;
   if (e->ll_part.ensure(sizeof(double) * (size_t)c.E * e->ll_stride)) return 1;
   if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
@@ -95,8 +111,7 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / per));
     if (need_hbm_path && e->plv.ensure(per * chunk)) return 1;
     // the arena variant of the matrix-core kernel keeps its stored vectors in the same buffer
-    if (!need_hbm_path && (gradient_mfma_use_arena(n, e->K, false, true) ||
-                           gradient_mfma_use_arena(n, e->K, true, true))) {
+    if (!need_hbm_path && (use_arena(e, false, true) || use_arena(e, true, true))) {
       const size_t aper = gradient_arena_bytes_per_eval(n, e->P, e->K);
       const size_t achunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / aper));
       if (e->plv.ensure(aper * achunk)) return 1;
@@ -133,7 +148,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // (K > 4: the matrix-core gradient kernel takes the site likelihoods from a pass of the
   // matrix-core log-likelihood kernel; if that one cannot run, neither can it)
   const bool mfma = d.gradient && e->allow_onchip_gradient && e->have_tip_masks &&
-                    gradient_mfma_fits(e->n, e->K, d.rescaling) && reduce_tiles_fits(e->N) &&
+                    walk_fits(e, d.rescaling) && reduce_tiles_fits(e->N) &&
                     (gradient_mfma_groups(e->K) == 1 || !loglik_is_valu);
   const bool onchip = mfma;  // the only on-chip gradient kernel; everything else streams PLVs
   const int groups = mfma ? gradient_mfma_groups(e->K) : 1;
@@ -181,7 +196,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool marks = prof && e->prof_phases;
   PROF_MARK(e, marks, 0, s);
   launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
-  const bool arena = mfma && gradient_mfma_use_arena(n, e->K, d.rescaling, analytic);
+  const bool arena = mfma && use_arena(e, d.rescaling, analytic);
+  const bool walk2 = mfma && e->walk2;
   if (arena)
     launch_macro_slots(e->macros.as<MacroEntry>(), e->arena_macros.as<MacroEntry>(),
                        e->macro_count.as<int32_t>(), n, T, e->slot_need.as<int32_t>(),
@@ -208,8 +224,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool loglik_runs = !d.gradient || fd_pass || (mfma && groups > 1);
   const bool need_tip_tables = loglik_runs && loglik_is_valu;
   tr.tip_tables = need_tip_tables ? e->tip_tables.as<double>() : nullptr;
-  tr.tr_mats = mfma ? e->tr_mats.as<double>() : nullptr;
-  tr.phi = analytic ? e->phi.as<double>() : nullptr;
+  tr.tr_mats = (mfma && !walk2) ? e->tr_mats.as<double>() : nullptr;
+  tr.phi = (analytic && !walk2) ? e->phi.as<double>() : nullptr;
   tr.n = n;
   // evaluations [T, 17 T) of a finite-difference GTR call never run the gradient kernel
   tr.tr_skip_begin = c.E > T ? T : c.E;
@@ -220,7 +236,40 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     tr.ev_skip_begin = T;
     tr.ev_skip_end = site_pass ? 17 * T : c.E;
   }
-  launch_transition(tr, s);
+  if (walk2 && groups == 1) {
+    // the second-generation walk reads its matrices in macro order (below); node-ordered
+    // ones are only needed by the evaluations a log-likelihood kernel walks: the
+    // finite-difference passes [T, 17 T) of a GTR call
+    if (fd_pass) {
+      tr.eval_base = T;
+      tr.E = 16 * T;
+      launch_transition(tr, s);
+    }
+  } else {
+    launch_transition(tr, s);
+  }
+  const MacroEntry* walk_macros = arena ? e->arena_macros.as<MacroEntry>() : e->macros.as<MacroEntry>();
+  auto macro_matrices = [&](int eval_begin, int grad_begin, int count) {
+    TransitionMacroArgs tm{};
+    tm.n = n;
+    tm.N = N;
+    tm.K = e->K;
+    tm.count = count;
+    tm.eval_begin = eval_begin;
+    tm.map = map;
+    tm.models = e->models.as<DevModel>();
+    tm.bl_eff = e->bl_eff.as<double>();
+    tm.macros = walk_macros;
+    tm.macro_count = e->macro_count.as<int32_t>();
+    const size_t per = gradient_walk_mats_bytes_per_eval(n, e->K) / sizeof(double);
+    tm.mmats = e->mmats.as<double>() + (size_t)grad_begin * per;
+    tm.mphi = analytic ? e->mphi.as<double>() + (size_t)grad_begin * (per / 2) : nullptr;
+    launch_transition_macro(tm, s);
+  };
+  if (walk2) {
+    macro_matrices(0, 0, T);
+    if (site_pass) macro_matrices(17 * T, T, T);
+  }
 
   LikArgs la{};
   la.n = n;
@@ -239,6 +288,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.tip_tables = e->tip_tables.as<double>();
   la.tr_mats = e->tr_mats.as<double>();
   la.phi = e->phi.as<double>();
+  la.mmats = e->mmats.as<double>();
+  la.mphi = e->mphi.as<double>();
   la.tip_states = e->tip_states.as<int8_t>();
   la.tip_masks = e->have_tip_masks ? e->tip_masks.as<uint8_t>() : nullptr;
   la.tip_partials = e->spec.use_tip_states ? nullptr : e->tip_partials.as<double>();
@@ -282,7 +333,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
           g.site_exp = e->site_exp.as<int32_t>();
           launch_loglik(g, part, d.rescaling, e->max_slots, s);
         }
-        launch_gradient_mfma(g, part, d.rescaling, analytic, s);
+        if (walk2) launch_gradient_walk(g, part, d.rescaling, analytic, s);
+        else launch_gradient_mfma(g, part, d.rescaling, analytic, s);
       }
       return;
     }
@@ -312,7 +364,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     PROF_MARK(e, marks, 3, s);
     if (fd_pass) loglik_range(T, 16 * T);
     if (site_pass) grad_range(17 * T, T, T);
-    e->dominant = mfma ? gradient_mfma_kernel_name() : gradient_kernel_name();
+    e->dominant = walk2 ? gradient_walk_kernel_name()
+                        : (mfma ? gradient_mfma_kernel_name() : gradient_kernel_name());
   }
   e->prof_first_launch_evals = T;
   e->last_evals = c.E;
@@ -573,6 +626,9 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   if (const char* env = getenv("MI_PHYLO_PLV_BYTES")) e->plv_budget = strtoull(env, nullptr, 10);
   if (const char* env = getenv("MI_PHYLO_SUBST_GRADIENT"))
     e->analytic_subst = std::string(env) == "analytic";
+  // MI_PHYLO_GRADIENT_WALK=v1: the first-generation matrix-core gradient kernel (node-ordered
+  // matrices; kept selectable, results are bit-identical)
+  if (const char* env = getenv("MI_PHYLO_GRADIENT_WALK")) e->walk2 = std::string(env) != "v1";
   if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH")) {  // force one gradient kernel
     const std::string v(env);
     e->gradient_path = v == "hbm" ? 2 : v == "mfma" ? 3 : 0;
@@ -708,7 +764,7 @@ void mi_engine_destroy(mi_engine* e) {
   for (Buffer* b :
        {&e->tip_states, &e->tip_partials, &e->tip_masks, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
         &e->arena_macros, &e->slot_need,
-        &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->x_sum, &e->bl_eff,
+        &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->mmats, &e->mphi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,
         &e->ll_sum, &e->g_sum, &e->status, &e->aa_model, &e->aa_matP, &e->aa_matPT,
         &e->aa_tipP, &e->aa_tipPQ, &e->aa_exp_cum, &e->aa_exp_loc, &e->aa_root_val,
@@ -760,8 +816,8 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
   // settings' workspaces (the HBM arena when either of them cannot use an on-chip kernel).
   const bool grad = for_gradients != 0;
   const bool can_onchip = e->allow_onchip_gradient && e->have_tip_masks;
-  const bool onchip_plain = can_onchip && gradient_mfma_fits(e->n, e->K, false);
-  const bool onchip_rescaled = can_onchip && gradient_mfma_fits(e->n, e->K, true);
+  const bool onchip_plain = can_onchip && walk_fits(e, false);
+  const bool onchip_rescaled = can_onchip && walk_fits(e, true);
   const bool analytic = e->analytic_subst && e->spec.subst_model == MI_SUBST_GTR;
   if (reserve(e, tree_count, grad, !onchip_plain, analytic && onchip_plain)) return 1;
   if (grad && onchip_plain != onchip_rescaled &&

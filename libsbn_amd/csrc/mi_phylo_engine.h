@@ -131,7 +131,7 @@ struct mi_engine {
   Buffer tip_states, tip_partials, tip_masks, weights;
   bool have_tip_masks = false;  // every tip vector is 0/1: the matrix-core kernel can run
   // per-call workspace
-  Buffer arena_macros, slot_need, tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
+  Buffer arena_macros, slot_need, tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, mmats, mphi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
       ll_sum, g_sum, status;
   // 20-state path: the engine's eigensystem and the streamed workspace (the arena is `plv`)
   Buffer aa_model, aa_matP, aa_matPT, aa_tipP, aa_tipPQ, aa_exp_cum, aa_exp_loc,
@@ -141,6 +141,7 @@ struct mi_engine {
   bool allow_onchip_gradient = true;
   bool analytic_subst = false;       // MI_PHYLO_SUBST_GRADIENT=analytic (opt-in)
   int gradient_path = 0;  // 0 auto, 2 hbm, 3 mfma (MI_PHYLO_GRADIENT_PATH)
+  bool walk2 = true;      // second-generation matrix-core gradient walk (MI_PHYLO_GRADIENT_WALK=v1: first)
   // a sharded handle (mi_engine_create_sharded): the per-device / per-shard engines it
   // drives; such a handle owns no device memory itself
   std::vector<mi_engine*> shards;

@@ -68,6 +68,21 @@ struct TransitionArgs {
   int n;
   int tr_skip_begin, tr_skip_end;  // evaluations [begin, end) are log-likelihood only: no tr_mats for them
   int ev_skip_begin, ev_skip_end;  // evaluations [begin, end) are not walked at all: no matrices
+  int eval_base;                   // this launch covers evaluations [eval_base, eval_base + E)
+};
+
+// Matrices in the order the second-generation gradient walk consumes them (kernels_walk.hip):
+// gradient evaluations [eval_begin, eval_begin + count) of the call, written to
+// mmats[0 .. count) (the caller passes the pointer of the first one).
+struct TransitionMacroArgs {
+  int n, N, K, count, eval_begin;
+  EvalMap map;
+  const DevModel* models;
+  const double* bl_eff;        // [T][N]
+  const MacroEntry* macros;    // [T][max_macros(n)] (the order the walk uses)
+  const int32_t* macro_count;  // [T]
+  double* mmats;               // [count][max_macros(n)][6][K][16]{f, tr}
+  double* mphi;                // [count][max_macros(n)][6][K][16] or nullptr
 };
 
 struct LikArgs {
@@ -88,6 +103,8 @@ struct LikArgs {
   const double* tip_tables;    // see TransitionArgs
   const double* tr_mats;       // see TransitionArgs
   const double* phi;           // see TransitionArgs
+  const double* mmats;         // see TransitionMacroArgs (indexed by gradient evaluation)
+  const double* mphi;
   const int8_t* tip_states;    // [n][P]
   const uint8_t* tip_masks;    // [n][P] bit s: compatible with state s (matrix-core gradient)
   const double* tip_partials;  // [n][P][4] or nullptr
@@ -165,6 +182,17 @@ void launch_macro_slots(const MacroEntry* macros_in, MacroEntry* macros_out,
                         const int32_t* macro_count, int n, int T, int32_t* need, int32_t* status,
                         hipStream_t s);
 size_t gradient_arena_bytes_per_eval(int n, int P, int K);
+int gradient_arena_slots_sure(int n);
+int gradient_arena_slots_usual(int n);
+// second generation of the same walk (kernels_walk.hip): macro-ordered operand streams
+void launch_transition_macro(const TransitionMacroArgs& a, hipStream_t s);
+void launch_gradient_walk(const LikArgs& a, int count, bool rescale, bool subst, hipStream_t s);
+bool gradient_walk_fits(int n, int K, bool rescale);
+bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst);
+size_t gradient_walk_lds_bytes(int n, int K, bool rescale, bool subst);
+size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots);
+size_t gradient_walk_mats_bytes_per_eval(int n, int K);
+const char* gradient_walk_kernel_name();
 // Sum of the per-tile partials: ll_sum[e] = sum_i ll_part[e][i] for e < E,
 // g_sum[gi][2N] = sum_i g_part[gi][i][2N] for gi < Eg (fixed order: deterministic).
 struct ReduceArgs {

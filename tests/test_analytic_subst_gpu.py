@@ -5,6 +5,8 @@ w.r.t. the stick-breaking coordinates of the GTR rates and frequencies -- in the
 pass itself.  Its parity target is therefore the finite-difference value *up to the
 finite-difference error*: checked against the oracle's 80-bit build (whose FD noise is
 ~1e-9 relative) and against the reference's own known-answer values for fluA."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,11 @@ import oracle_lib as O
 import tree_utils as TU
 
 pytestmark = pytest.mark.gpu
+
+# the matrix-core gradient walk in use: second generation (kernels_walk.hip) unless
+# MI_PHYLO_GRADIENT_WALK=v1 selects the first (kernels_gradient.hip); results are bit-identical
+WALK_KERNEL = ("gradient_mfma_kernel" if os.environ.get("MI_PHYLO_GRADIENT_WALK") == "v1"
+               else "gradient_walk_kernel")
 
 
 @pytest.fixture
@@ -40,7 +47,7 @@ def test_matches_extended_precision_finite_differences(analytic, site):
         blocks["Weibull shape"] = np.full((T, 1), 0.7)
     pr = _params(spec, T, **blocks)
     g = eng.gradients(pids, bls, pr)
-    assert eng.last_call_info() == ("gradient_mfma_kernel", T, T)  # no finite-difference passes
+    assert eng.last_call_info() == (WALK_KERNEL, T, T)  # no finite-difference passes
     got = np.array([x.gradient["substitution_model"] for x in g])
     O.select("ld")
     O.set_transition_mode(1)
@@ -70,7 +77,7 @@ def test_flua_rooted_known_answers(analytic):
     eng, spec, tips, w, pids, bls, rates, h, bd, ra = TG._flua("GTR")
     pr = _params(spec, 1, **{"GTR rates": k["rates"], "frequencies": k["frequencies"]})
     g = eng.rooted_gradients(pids, bls, pr, rates, [1], h, bd, ra)
-    assert eng.last_call_info()[0] == "gradient_mfma_kernel"
+    assert eng.last_call_info()[0] == WALK_KERNEL
     assert abs(g[0].log_likelihood - k["log_likelihood_no_jacobian"]) < k["tol"]
     assert np.all(np.abs(g[0].gradient["substitution_model"]
                          - np.array(k["substitution_model_gradient"])) < 1e-4)

@@ -26,6 +26,11 @@ import tree_utils as TU
 
 pytestmark = pytest.mark.gpu
 
+# the matrix-core gradient walk in use: second generation (kernels_walk.hip) unless
+# MI_PHYLO_GRADIENT_WALK=v1 selects the first (kernels_gradient.hip); results are bit-identical
+WALK_KERNEL = ("gradient_mfma_kernel" if os.environ.get("MI_PHYLO_GRADIENT_WALK") == "v1"
+               else "gradient_walk_kernel")
+
 RTOL = 1e-10
 
 
@@ -381,7 +386,7 @@ def test_tip_partials_run_on_the_matrix_core_kernel():
     eng = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w, device=0,
                    use_tip_states=False)
     g = eng.gradients(pids, bls, pr)
-    assert eng.last_call_info()[0] == "gradient_mfma_kernel"
+    assert eng.last_call_info()[0] == WALK_KERNEL
     for t in range(T):
         assert abs(g[t].log_likelihood - og["log_likelihood"][t]) <= RTOL * abs(og["log_likelihood"][t])
         assert _close(g[t].gradient["branch_lengths"], og["branch_lengths"][t])
@@ -397,7 +402,7 @@ def test_tip_partials_run_on_the_matrix_core_kernel():
     eng2 = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), None, w, device=0,
                     use_tip_states=False, tip_partials=partials)
     g2 = eng2.gradients(pids, bls, pr)
-    assert eng2.last_call_info()[0] == "gradient_mfma_kernel"
+    assert eng2.last_call_info()[0] == WALK_KERNEL
     soft = partials.copy()
     soft[0, :, :] = [1.0, 0.0, 1.0 - 1e-13, 0.0]  # not 0/1 any more: no mask form
     eng3 = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), None, w, device=0,
@@ -443,9 +448,9 @@ def test_rescaled_gradients_stay_on_the_matrix_core_kernel():
     spec = O.make_spec(27, 934, "JC69", "weibull+4")
     pr = _params(spec, len(pids), **{"Weibull shape": np.full((len(pids), 1), 0.8)})
     plain = eng.gradients(pids, bls, pr, False)
-    assert eng.last_call_info()[0] == "gradient_mfma_kernel"
+    assert eng.last_call_info()[0] == WALK_KERNEL
     scaled = eng.gradients(pids, bls, pr, True)
-    assert eng.last_call_info()[0] == "gradient_mfma_kernel"
+    assert eng.last_call_info()[0] == WALK_KERNEL
     og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, True, 4)
     for t in range(len(pids)):
         assert abs(scaled[t].log_likelihood - plain[t].log_likelihood) <= \
@@ -537,7 +542,7 @@ for tips, w, pids, bls in cases:
         pr = TG._params(spec, T, **blocks)
         for resc in (False, True):
             g = eng.gradients(pids, bls, pr, resc)
-            assert eng.last_call_info()[0] == 'gradient_mfma_kernel', eng.last_call_info()
+            assert eng.last_call_info()[0] == TG.WALK_KERNEL, eng.last_call_info()
             og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 4)
             for t in range(T):
                 assert abs(g[t].log_likelihood - og['log_likelihood'][t]) <= 1e-10 * abs(og['log_likelihood'][t])
@@ -601,7 +606,7 @@ def test_arena_gradient_in_several_launches(monkeypatch):
         pr = _params(spec, T, **{"Weibull shape": rng.uniform(0.4, 1.5, size=(T, 1))})
         for resc in (False, True):
             g = eng.gradients(pids, bls, pr, resc)
-            assert eng.last_call_info()[0] == "gradient_mfma_kernel"
+            assert eng.last_call_info()[0] == WALK_KERNEL
             og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 4)
             for t in range(T):
                 assert abs(g[t].log_likelihood - og["log_likelihood"][t]) <= \
@@ -856,7 +861,7 @@ def test_full_size_gtr_weibull_1000_trees():
     pr = _params(spec, T, **{"GTR rates": r, "frequencies": f,
                               "Weibull shape": rng.uniform(0.5, 2.0, size=(T, 1))})
     g = eng.gradients(pids, bls, pr)
-    assert eng.last_call_info() == ("gradient_mfma_kernel", 18 * T, 2 * T)
+    assert eng.last_call_info() == (WALK_KERNEL, 18 * T, 2 * T)
     gll = np.array([x.log_likelihood for x in g])
     gb = _grad_matrix(g, "branch_lengths")
     assert np.all(np.isfinite(gb)) and np.all(gb[:, -2:] == 0)
@@ -875,3 +880,99 @@ def test_full_size_gtr_weibull_1000_trees():
             1e-8 * max(1.0, abs(og["site_model"][j]))
     assert eng.gradients(pids[:0], bls[:0], pr[:0]) == []
     assert eng.log_likelihoods(pids[:0], bls[:0], pr[:0]).shape == (0,)
+
+
+def test_walk_kernels_agree():
+    """The two generations of the matrix-core gradient walk -- gradient_mfma_kernel
+    (node-ordered matrices, schedule entries in vector registers) and gradient_walk_kernel
+    (macro-ordered operand streams, scalar descriptors, one switch per child configuration) --
+    do the same arithmetic in the same order: bit-identical log-likelihoods and gradients,
+    over rate-category counts 1 / 2 / 3 / 4 / 8, with and without rescaling, finite-difference
+    and analytic GTR, stored vectors in LDS and in the arena, unrooted and rooted.  (The
+    switches are read at engine creation / once per process: each form runs in its own
+    interpreter.)"""
+    import subprocess
+    import sys
+    import tempfile
+    code = r"""
+import sys, os, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import oracle_lib as O, libsbn_amd as L, tree_utils as TU
+import test_gpu_parity as TG
+out = []
+rng = np.random.default_rng(2025)
+st = O.load_struct('ds1_sub10'); tips, w, pids, bls = O.struct_arrays(st)
+cases = [(tips, w, pids, bls)]
+for n, P in ((5, 7), (3, 30), (40, 90), (70, 61)):
+    t2, w2 = TU.random_alignment(n, P, rng)
+    p2, b2 = TU.random_trees(n, 4, rng, mean_bl=0.05)
+    if n >= 8:
+        p2[0] = TU.balanced_topology(n); p2[1] = TU.ladder_topology(n)
+    cases.append((t2, w2, p2, b2))
+for tips, w, pids, bls in cases:
+    n, P = tips.shape; T = len(pids)
+    for subst, site in (('JC69', 'constant'), ('JC69', 'weibull+2'), ('JC69', 'weibull+3'),
+                        ('JC69', 'weibull+4'), ('JC69', 'weibull+8'), ('GTR', 'weibull+4'),
+                        ('GTR', 'constant')):
+        eng = L.Engine(L.PhyloModelSpecification(subst, site, 'strict'), tips, w)
+        spec = O.make_spec(n, P, subst, site, 'strict')
+        blocks = {}
+        if subst == 'GTR':
+            r, f = TU.random_gtr_params(T, rng); blocks['GTR rates'] = r; blocks['frequencies'] = f
+        if site != 'constant': blocks['Weibull shape'] = rng.uniform(0.4, 1.5, size=(T, 1))
+        pr = TG._params(spec, T, **blocks)
+        for resc in (False, True):
+            g = eng.gradients(pids, bls, pr, resc)
+            assert eng.last_call_info()[0] == TG.WALK_KERNEL, eng.last_call_info()
+            for x in g:
+                out.append([x.log_likelihood])
+                for k in sorted(x.gradient):
+                    out.append(np.atleast_1d(x.gradient[k]))
+# rooted
+rng = np.random.default_rng(9)
+n, P, T = 14, 70, 3
+tips, w = TU.random_alignment(n, P, rng)
+trees = [TU.clocklike_rooted_tree(n, rng) for _ in range(T)]
+pids = np.stack([t[0] for t in trees]); bls = np.stack([t[1] for t in trees])
+state = [O.time_tree_init(n, t[0], t[1], t[2]) for t in trees]
+h = np.stack([s[0] for s in state]); bd = np.stack([s[1] for s in state]); ra = np.stack([s[2] for s in state])
+rates = np.full((T, 2 * n - 2), 0.7)
+eng = L.Engine(L.PhyloModelSpecification('JC69', 'weibull+4', 'strict'), tips, w)
+spec = O.make_spec(n, P, 'JC69', 'weibull+4', 'strict')
+pr = TG._params(spec, T, **{'Weibull shape': rng.uniform(0.4, 1.5, size=(T, 1))})
+for x in eng.rooted_gradients(pids, bls, pr, rates, np.ones(T, np.int32), h, bd, ra):
+    out.append([x.log_likelihood])
+    for k in sorted(x.gradient):
+        out.append(np.atleast_1d(x.gradient[k]))
+np.save(sys.argv[1], np.concatenate(out))
+"""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    results = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for walk in ("v1", "v2"):
+            for store in ("", "arena"):
+                for subst_mode in ("", "analytic"):
+                    env = dict(os.environ, MI_PHYLO_GRADIENT_WALK=walk)
+                    env.pop("MI_PHYLO_GRADIENT_STORE", None)
+                    env.pop("MI_PHYLO_SUBST_GRADIENT", None)
+                    if store:
+                        env["MI_PHYLO_GRADIENT_STORE"] = store
+                    if subst_mode:
+                        env["MI_PHYLO_SUBST_GRADIENT"] = subst_mode
+                    path = os.path.join(tmp, f"{walk}_{store}_{subst_mode}.npy")
+                    r = subprocess.run([sys.executable, "-c", code, path], env=env, cwd=repo,
+                                       capture_output=True, text=True)
+                    assert r.returncode == 0, (walk, store, subst_mode, r.stdout + r.stderr)
+                    results[(walk, store, subst_mode)] = np.load(path)
+    for store in ("", "arena"):
+        for subst_mode in ("", "analytic"):
+            a, b = results[("v1", store, subst_mode)], results[("v2", store, subst_mode)]
+            assert a.shape == b.shape and np.isfinite(a).all()
+            if subst_mode == "analytic":
+                # log-likelihoods, branch and site gradients are bit-identical here too; the
+                # analytic substitution gradient of single-category models differs in the last
+                # bits (2.5e-13 relative, measured) -- its tolerance against finite
+                # differences is 1e-9
+                assert np.allclose(a, b, rtol=1e-12, atol=0), (store, np.max(np.abs(a - b)))
+            else:
+                assert np.array_equal(a, b), (store, subst_mode, np.max(np.abs(a - b)))

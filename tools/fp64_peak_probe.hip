@@ -147,6 +147,76 @@ __global__ void __launch_bounds__(256) rate_kernel(double* out, Stamp* stamps, i
       }
       sink = c0.x + c1.y + c2.z + c3.w;
     }
+  } else if constexpr (KIND == 9 || KIND == 10) {
+    // round 3: does the INTEGER bookkeeping of the walk kernels co-issue
+    // with the f64 matrix pipe?  Even waves issue only 4x4x4 MFMAs; odd waves only
+    // v_mad_u32_u24 / v_bfe_u32 (KIND 9) or only scalar ALU instructions (KIND 10).
+    if ((threadIdx.x >> 6) & 1) {
+      if constexpr (KIND == 9) {
+        unsigned c0 = l, c1 = l + 1, c2 = l + 2, c3 = l + 3, c4 = l + 4, c5 = l + 5, c6 = l + 6, c7 = l + 7;
+        const unsigned m = 3 + (l & 1);
+        for (int i = 0; i < iters; i++) {
+          c0 = __umul24(c0, m) + c1; c1 = __builtin_amdgcn_ubfe(c1, 1u, 23u) + c0;
+          c2 = __umul24(c2, m) + c3; c3 = __builtin_amdgcn_ubfe(c3, 1u, 23u) + c2;
+          c4 = __umul24(c4, m) + c5; c5 = __builtin_amdgcn_ubfe(c5, 1u, 23u) + c4;
+          c6 = __umul24(c6, m) + c7; c7 = __builtin_amdgcn_ubfe(c7, 1u, 23u) + c6;
+        }
+        sink = (double)(c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7);
+      } else {
+        unsigned s0 = __builtin_amdgcn_readfirstlane(blockIdx.x), s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
+        for (int i = 0; i < iters; i++) {
+          asm volatile("s_mul_i32 %0, %0, 3\n s_add_i32 %1, %1, %0\n s_lshr_b32 %2, %2, 1\n"
+                       "s_add_i32 %3, %3, %2\n s_mul_i32 %0, %0, 5\n s_add_i32 %1, %1, %0\n"
+                       "s_xor_b32 %2, %2, %1\n s_add_i32 %3, %3, %2"
+                       : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)
+                       :
+                       : "scc");
+        }
+        sink = (double)(s0 + s1 + s2 + s3);
+      }
+    } else {
+      double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+      for (int i = 0; i < iters; i++) {
+        c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c3, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c4, 0, 0, 0);
+        c5 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c5, 0, 0, 0);
+        c6 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c6, 0, 0, 0);
+        c7 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c7, 0, 0, 0);
+      }
+      sink = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    }
+  } else if constexpr (KIND == 11 || KIND == 12 || KIND == 13) {
+    // the same question inside ONE wave (what a walk kernel at two waves per SIMD mostly
+    // is): every MFMA followed by NV independent vector instructions -- 32-bit integer
+    // (KIND 11: 2 per MFMA, KIND 12: 4 per MFMA) or f64 multiplies (KIND 13: 2 per MFMA).
+    // If they hide in the 16 cycles the matrix instruction occupies its pipe, the time
+    // equals the pure-MFMA row's.
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    unsigned u0 = l, u1 = l + 1, u2 = l + 2, u3 = l + 3;
+    double f0 = 1.0 + 1e-9 * l, f1 = f0, f2 = f0, f3 = f0;
+    const double fm = 1.0 + 1e-12 * l;
+    const unsigned m = 3 + (l & 1);
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c0, 0, 0, 0);
+        if constexpr (KIND == 13) { f0 *= fm; f1 *= fm; } else { u0 = __umul24(u0, m) + u1; u1 = __builtin_amdgcn_ubfe(u1, 1u, 23u) + u0; }
+        if constexpr (KIND == 12) { u2 = __umul24(u2, m) + u3; u3 = __builtin_amdgcn_ubfe(u3, 1u, 23u) + u2; }
+        c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c1, 0, 0, 0);
+        if constexpr (KIND == 13) { f2 *= fm; f3 *= fm; } else { u2 = __umul24(u2, m) + u3; u3 = __builtin_amdgcn_ubfe(u3, 1u, 23u) + u2; }
+        if constexpr (KIND == 12) { u0 = __umul24(u0, m) + u1; u1 = __builtin_amdgcn_ubfe(u1, 1u, 23u) + u0; }
+        c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c2, 0, 0, 0);
+        if constexpr (KIND == 13) { f0 *= fm; f1 *= fm; } else { u0 = __umul24(u0, m) + u1; u1 = __builtin_amdgcn_ubfe(u1, 1u, 23u) + u0; }
+        if constexpr (KIND == 12) { u2 = __umul24(u2, m) + u3; u3 = __builtin_amdgcn_ubfe(u3, 1u, 23u) + u2; }
+        c3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c3, 0, 0, 0);
+        if constexpr (KIND == 13) { f2 *= fm; f3 *= fm; } else { u2 = __umul24(u2, m) + u3; u3 = __builtin_amdgcn_ubfe(u3, 1u, 23u) + u2; }
+        if constexpr (KIND == 12) { u0 = __umul24(u0, m) + u1; u1 = __builtin_amdgcn_ubfe(u1, 1u, 23u) + u0; }
+      }
+    }
+    sink = c0 + c1 + c2 + c3 + (double)(u0 + u1 + u2 + u3) + f0 + f1 + f2 + f3;
   } else {  // the 20-state inner sequence: 5 k-steps of (16 rows) + 5 of (4 rows), two tiles
     double4v c0 = {0, 0, 0, 0}, c1 = c0;
     double d0 = 0, d1 = 0;
@@ -250,5 +320,14 @@ int main() {
   run<8>("16x16x4 waves || 4x4x4 waves", 640, 4, out, stamps, iters / 2);
   run<4>("mfma_f64 || v_fma_f64", 160, 8, out, stamps, iters);
   run<5>("mfma_f64 || v_fma_f32", 160, 8, out, stamps, iters);
+  // round 3: integer VALU / scalar ALU beside the matrix pipe (TFLOP/s column: MFMA flops of
+  // the even waves only, i.e. 128 MAC per instruction averaged over all waves; compare the
+  // TIME with mfma_f64_4x4x4_4b at half the waves per SIMD)
+  run<9>("mfma_f64 || int VALU waves", 128, 8, out, stamps, iters);
+  run<10>("mfma_f64 || SALU waves", 128, 8, out, stamps, iters);
+  // one wave: 8 MFMA + 2 (or 4) vector instructions each; MFMA flops only (256 MAC x 8 per iteration)
+  run<11>("1 wave: mfma + 2 int VALU", 256, 8, out, stamps, iters);
+  run<12>("1 wave: mfma + 4 int VALU", 256, 8, out, stamps, iters);
+  run<13>("1 wave: mfma + 2 v_mul_f64", 256, 8, out, stamps, iters);
   return 0;
 }

@@ -1019,7 +1019,12 @@ def main():
                                              params_all[sl], False, min(parity_n, usable_cores()))
             errs = [np.max(np.abs(ll_dev - oll) / np.abs(oll))]
         parity_err = float(max(errs))
-        assert parity_err <= 1e-10, f"timed outputs differ from the oracle: {errs}"
+        # (MI_BENCH_SKIP_PARITY=1: kernel experiments that skip work on purpose -- never set by
+        # the driver; the value it marks is reported as unchecked)
+        if os.environ.get("MI_BENCH_SKIP_PARITY") == "1":
+            parity_n = 0
+        else:
+            assert parity_err <= 1e-10, f"timed outputs differ from the oracle: {errs}"
 
     # ---- weak scaling beside it (1000 trees per GPU), N > 1 only
     weak = None

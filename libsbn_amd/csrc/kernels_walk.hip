@@ -27,6 +27,7 @@
 
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 #include "mi_phylo_device_utils.h"
 #include "mi_phylo_kernels.h"
@@ -44,6 +45,14 @@ __device__ __forceinline__ double row_shr_add(double v) {
   return v + __hiloint2double(shi, slo);
 }
 
+// bytes per (macro, column) of the tip words in LDS: six words, padded to 32 (one ds_read_b128
+// + one ds_read_b64) or dense (three ds_read_b64)
+#ifdef MI_WALK_TW24
+constexpr unsigned kTwCol = 24;
+#else
+constexpr unsigned kTwCol = 32;
+#endif
+
 // configuration of one child of a macro (from the shape word)
 enum ChildCfg { kTip = 0, kStored = 1, kUss = 2, kUts = 3, kUst = 4, kUtt = 5 };
 __device__ __forceinline__ int child_cfg(int sh, int j) {
@@ -58,6 +67,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   extern __shared__ double wlds[];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
+#ifdef MI_WALK_STAMPS
+  const long long st0 = __builtin_amdgcn_s_memtime();
+#endif
   const TileEval te = xcd_tile_eval();
   const int e = a.eval_offset + te.eval;
   const int gi = a.grad_offset + te.eval;
@@ -72,6 +84,18 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   const int Mmax = max_macros(n);
   const MacroEntry* __restrict__ macros = a.macros + (size_t)t * Mmax;
   const cint_ptr mw = as_const(reinterpret_cast<const int*>(macros));  // scalar loads
+  // Tip staging starts here, before anything else of the prologue: this lane's (macro,
+  // position) pairs j = lane, lane + 64 -- their node ids are the first link of the chain
+  // node id -> tip bytes -> LDS, the longest latency of a wave's life (entries beyond the
+  // tree's macro count hold no valid node: guarded below, they are inside the allocation)
+  const int* mwv = reinterpret_cast<const int*>(macros);
+  const int jmax = Mmax * 6;
+  int node_j[2] = {-1, -1};
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int j = lane + 64 * u;
+    if (j < jmax) node_j[u] = mwv[(j / 6) * 16 + 1 + (j % 6)];
+  }
   const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
   if (ARENA) {
     const int need = __builtin_amdgcn_readfirstlane(a.slot_need[t]);
@@ -107,7 +131,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   // -- re-used, macro by macro, for that macro's edge sums [position][branch, site] once its
   // tip words are in registers -- | SUBST: four root sums | vectors [slot][r][lane] |
   // RESCALE: exponents
-  const unsigned tstride = (unsigned)ppr * 32u;  // bytes per macro (>= 96: ppr >= 4)
+  const unsigned tstride = (unsigned)ppr * kTwCol;  // bytes per macro (>= 96: ppr >= 4)
   char* const lds0 = reinterpret_cast<char*>(wlds);
   const unsigned tips_bytes = (unsigned)Mmax * tstride + (SUBST ? 32u : 0u);
   double* const xroot = reinterpret_cast<double*>(lds0 + (unsigned)Mmax * tstride);
@@ -119,25 +143,55 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
                                                    max_stored(n) * R * kTile)
             : nullptr;
   {
-    // tip state masks of this wave's columns, by (macro, position): a lane takes one
-    // (macro, position) pair whose node is a tip and copies its TP bytes
-    const int* mwv = reinterpret_cast<const int*>(macros);
+    // tip state masks of this wave's columns, by (macro, position): a lane takes the (macro,
+    // position) pairs whose node is a tip and copies their TP bytes
     const int ppr_shift = Kp == 4 ? 2 : (Kp == 2 ? 3 : 4);
-    for (int j = lane; j < M * 6; j += kTile) {
+    auto stage_bytes = [&](int j, int node) {  // any layout, columns clamped to the last pattern
       const int m = j / 6, pos = j - m * 6;
-      const int node = mwv[m * 16 + 1 + pos];
-      if (node < n) {
-        const uint8_t* src = a.tip_masks + (size_t)node * a.P;
-        char* dst = lds0 + (unsigned)m * tstride + (unsigned)pos * 4u;
-        for (int q = 0; q < TP; q++) {
-          const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
-          dst[(q & (ppr - 1)) * 32 + (q >> ppr_shift)] = (char)src[pp];
+      const uint8_t* src = a.tip_masks + (size_t)node * a.P;
+      char* dst = lds0 + (unsigned)m * tstride + (unsigned)pos * 4u;
+      for (int q = 0; q < TP; q++) {
+        const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
+        dst[(q & (ppr - 1)) * kTwCol + (q >> ppr_shift)] = (char)src[pp];
+      }
+    };
+    if (R == 3 && Kp == 4 && tile_start + 12 <= a.P) {
+      // four categories, twelve whole columns: the 12 bytes of a (macro, position) pair as
+      // three (unaligned) words, regrouped into the four columns' words
+      struct __attribute__((packed)) Bytes12 {
+        uint32_t d0, d1, d2;
+      };
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int j = lane + 64 * u, node = node_j[u];
+        if (j < jmax && (unsigned)node < (unsigned)n) {
+          const Bytes12 w = *reinterpret_cast<const Bytes12*>(a.tip_masks + (size_t)node * a.P + tile_start);
+          const int m = j / 6, pos = j - m * 6;
+          char* dst = lds0 + (unsigned)m * tstride + (unsigned)pos * 4u;
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            *reinterpret_cast<uint32_t*>(dst + c * kTwCol) =
+                ((w.d0 >> (8 * c)) & 0xffu) | (((w.d1 >> (8 * c)) & 0xffu) << 8) |
+                (((w.d2 >> (8 * c)) & 0xffu) << 16);
         }
       }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int j = lane + 64 * u, node = node_j[u];
+        if (j < jmax && (unsigned)node < (unsigned)n) stage_bytes(j, node);
+      }
+    }
+    for (int j = lane + 128; j < jmax; j += kTile) {  // larger trees: the rest
+      const int node = mwv[(j / 6) * 16 + 1 + (j % 6)];
+      if ((unsigned)node < (unsigned)n) stage_bytes(j, node);
     }
   }
   __syncthreads();
   if (M <= 0) return;
+#ifdef MI_WALK_STAMPS
+  const long long st1 = __builtin_amdgcn_s_memtime();
+#endif
 
   struct V {
     double v[R];
@@ -200,7 +254,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   struct Mats {
     double f[6], tr[6];
     double ph[SUBST ? 6 : 1];
-    uint32_t tw[6];
+  };
+  struct Tw {
+    uint32_t w[6];
   };
   struct Slots {  // scalars (s_load_dwordx8)
     int q, c[2], g[4], dst;
@@ -210,7 +266,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     const cint_ptr p = mw + m * 16 + 8;
     return Slots{p[0], {p[1], p[2]}, {p[3], p[4], p[5], p[6]}, p[7]};
   };
-  const unsigned tw_lane = (unsigned)col * 32u;
+  const unsigned tw_lane = (unsigned)col * kTwCol;
   auto fetch = [&](int m, bool pre) {  // m: scalar
     Mats mt;
     // scalar base of the visit + this lane's 32-bit offset + constants (the offset is made
@@ -242,15 +298,29 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
       for (int j = 0; j < 6; j++)
         mt.ph[j] = *reinterpret_cast<const double*>(sp + j * (kPosBytes / 2) + (size_t)vph);
     }
-    const uint4 w4 = *reinterpret_cast<const uint4*>(lds0 + (unsigned)m * tstride + tw_lane);
-    const uint2 w2 = *reinterpret_cast<const uint2*>(lds0 + (unsigned)m * tstride + tw_lane + 16u);
-    mt.tw[0] = w4.x;
-    mt.tw[1] = w4.y;
-    mt.tw[2] = w4.z;
-    mt.tw[3] = w4.w;
-    mt.tw[4] = w2.x;
-    mt.tw[5] = w2.y;
     return mt;
+  };
+  auto fetch_tw = [&](int m) {  // the six tip words of visit m (LDS)
+    Tw t;
+    const char* twp = lds0 + ((unsigned)m * tstride + tw_lane);
+    if (kTwCol == 32) {
+      const uint4 w4 = *reinterpret_cast<const uint4*>(twp);
+      const uint2 w2 = *reinterpret_cast<const uint2*>(twp + 16);
+      t.w[0] = w4.x;
+      t.w[1] = w4.y;
+      t.w[2] = w4.z;
+      t.w[3] = w4.w;
+      t.w[4] = w2.x;
+      t.w[5] = w2.y;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const uint2 w2 = *reinterpret_cast<const uint2*>(twp + 8 * j);
+        t.w[2 * j] = w2.x;
+        t.w[2 * j + 1] = w2.y;
+      }
+    }
+    return t;
   };
 
   double qroot[R];  // root pre-order vector: pi * category weight * w_p / site likelihood
@@ -258,51 +328,35 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
 #pragma unroll
   for (int r = 0; r < R; r++) esum[r] = 0;
 
-  // one child of a post-order visit: its vector L (tip: expanded; stored: from its slot;
-  // unstored: recomputed from its two children)
-  auto child_L = [&](int cfg, int j, const Mats& mt, const Slots& sl, V& xa, V& xb, V& Ap, V& Bp,
-                     bool pre, const V& pa, const V& pb) {
-    // pre && ARENA: stored inputs arrive from the arena (pa, pb), requested a visit ahead
-    const bool fa = ARENA && pre;
-    V L;
-    switch (cfg) {
-      case kTip:
-        L = tipv(mt.tw[j]);
-        break;
-      case kStored:
-        L = fa ? pa : load_slot(sl.c[j]);
-        break;
-      case kUss:
-        xa = fa ? pa : load_slot(sl.g[2 * j]);
-        xb = fa ? pb : load_slot(sl.g[2 * j + 1]);
-        Ap = mm(mt.f[2 + 2 * j], xa);
-        Bp = mm(mt.f[3 + 2 * j], xb);
-        L = mul(Ap, Bp);
-        break;
-      case kUts:
-        xa = tipv(mt.tw[2 + 2 * j]);
-        xb = fa ? pb : load_slot(sl.g[2 * j + 1]);
-        Ap = mm(mt.f[2 + 2 * j], xa);
-        Bp = mm(mt.f[3 + 2 * j], xb);
-        L = mul(Ap, Bp);
-        break;
-      case kUst:
-        xa = fa ? pa : load_slot(sl.g[2 * j]);
-        xb = tipv(mt.tw[3 + 2 * j]);
-        Ap = mm(mt.f[2 + 2 * j], xa);
-        Bp = mm(mt.f[3 + 2 * j], xb);
-        L = mul(Ap, Bp);
-        break;
-      default:  // kUtt
-        xa = tipv(mt.tw[2 + 2 * j]);
-        xb = tipv(mt.tw[3 + 2 * j]);
-        Ap = mm(mt.f[2 + 2 * j], xa);
-        Bp = mm(mt.f[3 + 2 * j], xb);
-        L = mul(Ap, Bp);
-        break;
-    }
-    return L;
+  // One child (J = 0, 1) of a visit: its vector L -- tip: expanded from its state masks;
+  // stored: from its LDS slot; unstored: recomputed from its two children, which are tips or
+  // stored nodes.  ONE decision tree on the shape word's bits (kind, then the two
+  // grandchild tip flags), straight-line code at the leaves.  pre && ARENA: stored inputs
+  // arrive from the arena (pa, pb), requested a visit ahead.
+  struct Child {
+    V L, xa, xb, Ap, Bp;
   };
+  auto child_L = [&](int sh, auto jtag, const Mats& mt, const Tw& tw, const Slots& sl, Child& c,
+                     bool pre, const V& pa, const V& pb) {
+    constexpr int J = decltype(jtag)::value;
+    const bool fa = ARENA && pre;
+    const int kind = (sh >> (2 * J)) & 3;
+    if (kind == 2) {
+      if (sh & (1 << (10 + 2 * J))) c.xa = tipv(tw.w[2 + 2 * J]);
+      else c.xa = fa ? pa : load_slot(sl.g[2 * J]);
+      if (sh & (1 << (11 + 2 * J))) c.xb = tipv(tw.w[3 + 2 * J]);
+      else c.xb = fa ? pb : load_slot(sl.g[2 * J + 1]);
+      c.Ap = mm(mt.f[2 + 2 * J], c.xa);
+      c.Bp = mm(mt.f[3 + 2 * J], c.xb);
+      c.L = mul(c.Ap, c.Bp);
+    } else if (kind == 1) {
+      c.L = fa ? pa : load_slot(sl.c[J]);
+    } else {
+      c.L = tipv(tw.w[J]);
+    }
+  };
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
 
   V pend_L;  // ARENA: the last stored vector, on its way to the arena
   int pend_dst = 0;
@@ -314,18 +368,23 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     }
   };
 
-  // ================= post-order over the stored nodes (+ root: site likelihood) ====
-  auto post_visit = [&](int sh, const Slots& sl, const Mats& mt, auto&& next_scalars) {
-    V xa, xb, Ap, Bp;
+  // ================= post-order over the stored nodes, then the root (site likelihood) ====
+  // A visit ends with the requests for the coming visits: tip words of the next one (LDS) and
+  // the scalar loads (slots of the next visit, shape of the one after).  LDS and scalar loads
+  // share one counter and a scalar load may return out of order: issued earlier they turn
+  // every LDS wait of the visit into a wait for them too (measured: 3 % slower mid-visit).
+  auto post_visit = [&](auto root_tag, int sh, const Slots& sl, const Mats& mt, const Tw& tw,
+                        auto&& requests) {
+    constexpr bool ROOT = decltype(root_tag)::value;
+    Child c0, c1;
     const V none{};
-    const V L0 = child_L(child_cfg(sh, 0), 0, mt, sl, xa, xb, Ap, Bp, false, none, none);
-    const V L1 = child_L(child_cfg(sh, 1), 1, mt, sl, xa, xb, Ap, Bp, false, none, none);
-    // this visit's LDS operands have been read: the scalar loads of the coming visits go out
-    // here (LDS and scalar loads share one counter, and a scalar load may return out of
-    // order: issued earlier they would turn every LDS wait into a wait for them too)
-    next_scalars();
-    V Lv = mul(mm(mt.f[0], L0), mm(mt.f[1], L1));
-    if (!(sh & 16)) {
+    child_L(sh, J0{}, mt, tw, sl, c0, false, none, none);
+    child_L(sh, J1{}, mt, tw, sl, c1, false, none, none);
+#ifdef MI_WALK_MID_DRAIN
+    requests(0);
+#endif
+    V Lv = mul(mm(mt.f[0], c0.L), mm(mt.f[1], c1.L));
+    if (!ROOT) {
       if (RESCALE) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -393,35 +452,69 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
         if ((lane & 15) == 15) xroot[hi] = z;
       }
     }
+#ifdef MI_WALK_MID_DRAIN
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the scalar loads have long returned
+    requests(1);
+#else
+    requests(0);
+    requests(1);
+#endif
   };
+  using Inner = std::false_type;
+  using Root = std::true_type;
+  const int M1 = M - 1;  // the root's macro is the last one; visits 0 .. M1 - 1 are stored nodes
   {
-    // Two visits per iteration, two register sets.  At the top of visit m: shape(m),
-    // shape(m+1), slots(m), matrices and tip words (m) are there; the loads of visit m+1
-    // (matrices, tip words) go out first, the scalar loads of shape(m+2) and slots(m+1)
-    // after this visit's LDS operands have been read (one lgkm counter for both).
-    int sha = load_shape(0), shb = load_shape(M > 1 ? 1 : 0);
+    // Two visits per iteration, two register sets (A, B), nothing copied.  At the top of
+    // visit m: shape, slots, matrices and tip words of m are there and the matrices of m + 1
+    // are requested.
+    int sha = load_shape(0), shb = load_shape(min(1, M1));
     Slots sa = load_slots(0), sb;
     Mats ma = fetch(0, false), mb;
-    for (int m = 0; m < M; m += 2) {
-      mb = fetch(m + 1 < M ? m + 1 : M - 1, false);
+    Tw ta = fetch_tw(0), tb;
+    for (int m = 0; m < M1; m += 2) {
+      mb = fetch(m + 1, false);
       flush_arena();
       int sh_next;
-      post_visit(sha, sa, ma, [&]() {
-        sb = load_slots(m + 1 < M ? m + 1 : M - 1);
-        sh_next = load_shape(m + 2 < M ? m + 2 : M - 1);
+      post_visit(Inner{}, sha, sa, ma, ta, [&](int part) {
+        if (part) {
+          tb = fetch_tw(m + 1);
+        } else {
+          sb = load_slots(m + 1);
+          sh_next = load_shape(min(m + 2, M1));
+        }
       });
       sha = sh_next;
-      if (m + 1 < M) {
-        ma = fetch(m + 2 < M ? m + 2 : M - 1, false);
+      if (m + 1 < M1) {
+        ma = fetch(m + 2, false);
         flush_arena();
-        post_visit(shb, sb, mb, [&]() {
-          sa = load_slots(m + 2 < M ? m + 2 : M - 1);
-          sh_next = load_shape(m + 3 < M ? m + 3 : M - 1);
+        post_visit(Inner{}, shb, sb, mb, tb, [&](int part) {
+          if (part) {
+            ta = fetch_tw(m + 2);
+          } else {
+            sa = load_slots(m + 2);
+            sh_next = load_shape(min(m + 3, M1));
+          }
         });
         shb = sh_next;
       }
     }
     flush_arena();
+    if (M1 & 1) {  // the root's operands arrived in set B
+      sha = shb;
+      sa = sb;
+      ma = mb;
+      ta = tb;
+    }
+#ifdef MI_WALK_STAMPS
+    const long long st2r = __builtin_amdgcn_s_memtime();
+#endif
+    post_visit(Root{}, sha, sa, ma, ta, [&](int) {});
+#ifdef MI_WALK_STAMPS
+    const long long st2 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && (te.eval % 250) == 3 && (te.tile % 39) == 5)
+      printf("walk stamps eval %d tile %d: prologue %lld, post-order (inner) %lld, root %lld (s_memtime ticks, 100 MHz)\n",
+             te.eval, te.tile, st1 - st0, st2r - st1, st2 - st2r);
+#endif
   }
 
   // ================= pre-order + edge derivatives =================
@@ -475,7 +568,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   };
   auto prefetch_L = [&](int sh) {
     PreL p;
-    int k = (int)((unsigned)sh >> 16), i = 0;
+    int k = (int)((unsigned)sh >> 16);
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int cfg = child_cfg(sh, j);
@@ -483,13 +576,45 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
       if (cfg == kUss || cfg == kUst) p.x[2 * j] = arena_at(k++);
       if (cfg == kUss || cfg == kUts) p.x[2 * j + 1] = arena_at(k++);
     }
-    (void)i;
     return p;
   };
-  auto pre_visit = [&](int sh, const Slots& sl, const Mats& mt, int m, const PreL& pl,
-                       auto&& next_scalars) {
+  // the edges below child J: its own (numerator n) and, for an unstored child, its two
+  // children's, whose four sums are reduced right here -- one decision tree per child again
+  auto child_edges = [&](int sh, auto jtag, const Mats& mt, const Slots& sl, const Child& c,
+                         const V& qs, int m, V& n) {
+    constexpr int J = decltype(jtag)::value;
+    const int kind = (sh >> (2 * J)) & 3;
+    if (kind == 0) {
+      n = tip_edge(mt.tr[J], qs, c.L, mt.ph[SUBST ? J : 0]);
+      return;
+    }
+    V qc;
+    n = inner_edge(mt.tr[J], qs, c.L, mt.ph[SUBST ? J : 0], qc);
+    if (kind == 1) {
+      store_slot(sl.c[J], qc);
+      return;
+    }
+    V na, nb, qa, qb;
+    const V qsa = mul(qc, c.Bp), qsb = mul(qc, c.Ap);
+    if (sh & (1 << (10 + 2 * J))) {
+      na = tip_edge(mt.tr[2 + 2 * J], qsa, c.xa, mt.ph[SUBST ? 2 + 2 * J : 0]);
+    } else {
+      na = inner_edge(mt.tr[2 + 2 * J], qsa, c.xa, mt.ph[SUBST ? 2 + 2 * J : 0], qa);
+      store_slot(sl.g[2 * J], qa);
+    }
+    if (sh & (1 << (11 + 2 * J))) {
+      nb = tip_edge(mt.tr[3 + 2 * J], qsb, c.xb, mt.ph[SUBST ? 3 + 2 * J : 0]);
+    } else {
+      nb = inner_edge(mt.tr[3 + 2 * J], qsb, c.xb, mt.ph[SUBST ? 3 + 2 * J : 0], qb);
+      store_slot(sl.g[2 * J + 1], qb);
+    }
+    edge_sums(na, nb, m, 2 + 2 * J);
+  };
+  auto pre_visit = [&](auto root_tag, int sh, const Slots& sl, const Mats& mt, const Tw& tw, int m,
+                       const PreL& pl, auto&& requests) {
+    constexpr bool ROOT = decltype(root_tag)::value;
     V qv;
-    if (sh & 16) {
+    if (ROOT) {
 #pragma unroll
       for (int r = 0; r < R; r++) qv.v[r] = qroot[r];
     } else {
@@ -501,86 +626,67 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
                                               (unsigned)(r * ppr + col)]);
       }
     }
-    const int cfg0 = child_cfg(sh, 0), cfg1 = child_cfg(sh, 1);
-    V xa0, xb0, Ap0, Bp0, xa1, xb1, Ap1, Bp1;
-    const V L0 = child_L(cfg0, 0, mt, sl, xa0, xb0, Ap0, Bp0, true, pl.x[0], pl.x[1]);
-    const V L1 = child_L(cfg1, 1, mt, sl, xa1, xb1, Ap1, Bp1, true, pl.x[2], pl.x[3]);
-    next_scalars();  // (see post_visit)
-    const V A = mm(mt.f[0], L0), B = mm(mt.f[1], L1);
-    V q0, q1, n0, n1;
-    {
-      const V qs0 = mul(qv, B);
-      if (cfg0 == kTip) {
-        n0 = tip_edge(mt.tr[0], qs0, L0, mt.ph[0]);
-      } else {
-        n0 = inner_edge(mt.tr[0], qs0, L0, mt.ph[0], q0);
-        if (cfg0 == kStored) store_slot(sl.c[0], q0);
-      }
-      const V qs1 = mul(qv, A);
-      if (cfg1 == kTip) {
-        n1 = tip_edge(mt.tr[1], qs1, L1, mt.ph[SUBST ? 1 : 0]);
-      } else {
-        n1 = inner_edge(mt.tr[1], qs1, L1, mt.ph[SUBST ? 1 : 0], q1);
-        if (cfg1 == kStored) store_slot(sl.c[1], q1);
-      }
-      edge_sums(n0, n1, m, 0);
-    }
-    // grandchildren of an unstored child: (first is a tip, second is a tip) from the cfg
-    auto grand = [&](int cfg, int j, const V& qc, const V& xa, const V& xb, const V& Ap, const V& Bp) {
-      V na, nb, qa, qb;
-      const V qsa = mul(qc, Bp), qsb = mul(qc, Ap);
-      switch (cfg) {
-        case kUss:
-          na = inner_edge(mt.tr[2 + 2 * j], qsa, xa, mt.ph[SUBST ? 2 + 2 * j : 0], qa);
-          store_slot(sl.g[2 * j], qa);
-          nb = inner_edge(mt.tr[3 + 2 * j], qsb, xb, mt.ph[SUBST ? 3 + 2 * j : 0], qb);
-          store_slot(sl.g[2 * j + 1], qb);
-          break;
-        case kUts:
-          na = tip_edge(mt.tr[2 + 2 * j], qsa, xa, mt.ph[SUBST ? 2 + 2 * j : 0]);
-          nb = inner_edge(mt.tr[3 + 2 * j], qsb, xb, mt.ph[SUBST ? 3 + 2 * j : 0], qb);
-          store_slot(sl.g[2 * j + 1], qb);
-          break;
-        case kUst:
-          na = inner_edge(mt.tr[2 + 2 * j], qsa, xa, mt.ph[SUBST ? 2 + 2 * j : 0], qa);
-          store_slot(sl.g[2 * j], qa);
-          nb = tip_edge(mt.tr[3 + 2 * j], qsb, xb, mt.ph[SUBST ? 3 + 2 * j : 0]);
-          break;
-        default:
-          na = tip_edge(mt.tr[2 + 2 * j], qsa, xa, mt.ph[SUBST ? 2 + 2 * j : 0]);
-          nb = tip_edge(mt.tr[3 + 2 * j], qsb, xb, mt.ph[SUBST ? 3 + 2 * j : 0]);
-          break;
-      }
-      edge_sums(na, nb, m, 2 + 2 * j);
-    };
-    if (cfg0 >= kUss) grand(cfg0, 0, q0, xa0, xb0, Ap0, Bp0);
-    if (cfg1 >= kUss) grand(cfg1, 1, q1, xa1, xb1, Ap1, Bp1);
+    Child c0, c1;
+    child_L(sh, J0{}, mt, tw, sl, c0, true, pl.x[0], pl.x[1]);
+    child_L(sh, J1{}, mt, tw, sl, c1, true, pl.x[2], pl.x[3]);
+#ifdef MI_WALK_MID_DRAIN
+    requests(0);
+#endif
+    const V A = mm(mt.f[0], c0.L), B = mm(mt.f[1], c1.L);
+    V n0, n1;
+    child_edges(sh, J0{}, mt, sl, c0, mul(qv, B), m, n0);
+    child_edges(sh, J1{}, mt, sl, c1, mul(qv, A), m, n1);
+    edge_sums(n0, n1, m, 0);
+#ifdef MI_WALK_MID_DRAIN
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    requests(1);
+#else
+    requests(0);
+    requests(1);
+#endif
   };
   {
-    int sha = load_shape(M - 1), shb = load_shape(M > 1 ? M - 2 : 0);
-    Slots sa = load_slots(M - 1), sb;
-    Mats ma = fetch(M - 1, true), mb;
+    // the root's visit first (set A), then the stored nodes downwards, B and A in turn
+    int sha = load_shape(M1), shb = load_shape(max(M1 - 1, 0));
+    Slots sa = load_slots(M1), sb = load_slots(max(M1 - 1, 0));
+    Mats ma = fetch(M1, true), mb = fetch(max(M1 - 1, 0), true);
+    Tw ta = fetch_tw(M1), tb;
     PreL la, lb;
     if (ARENA) la = prefetch_L(sha);
-    for (int m = M - 1; m >= 0; m -= 2) {
-      mb = fetch(m >= 1 ? m - 1 : 0, true);
-      if (ARENA) lb = prefetch_L(shb);
+    if (ARENA) lb = prefetch_L(shb);
+    {
       int sh_next;
-      // (the slots of the visit in progress stay live to its end: the next ones go to the
-      // other set, the shape after next to a temporary)
-      pre_visit(sha, sa, ma, m, la, [&]() {
-        sb = load_slots(m >= 1 ? m - 1 : 0);
-        sh_next = load_shape(m >= 2 ? m - 2 : 0);
+      pre_visit(Root{}, sha, sa, ma, ta, M1, la, [&](int part) {
+        if (part) tb = fetch_tw(max(M1 - 1, 0));
+        else sh_next = load_shape(max(M1 - 2, 0));
       });
       sha = sh_next;
+    }
+    for (int m = M1 - 1; m >= 0; m -= 2) {
+      ma = fetch(max(m - 1, 0), true);
+      if (ARENA) la = prefetch_L(sha);
+      int sh_next;
+      pre_visit(Inner{}, shb, sb, mb, tb, m, lb, [&](int part) {
+        if (part) {
+          ta = fetch_tw(max(m - 1, 0));
+        } else {
+          sa = load_slots(max(m - 1, 0));
+          sh_next = load_shape(max(m - 2, 0));  // (set B's next visit)
+        }
+      });
+      shb = sh_next;
       if (m >= 1) {
-        ma = fetch(m >= 2 ? m - 2 : 0, true);
-        if (ARENA) la = prefetch_L(sha);
-        pre_visit(shb, sb, mb, m - 1, lb, [&]() {
-          sa = load_slots(m >= 2 ? m - 2 : 0);
-          sh_next = load_shape(m >= 3 ? m - 3 : 0);
+        mb = fetch(max(m - 2, 0), true);
+        if (ARENA) lb = prefetch_L(shb);
+        pre_visit(Inner{}, sha, sa, ma, ta, m - 1, la, [&](int part) {
+          if (part) {
+            tb = fetch_tw(max(m - 2, 0));
+          } else {
+            sb = load_slots(max(m - 2, 0));
+            sh_next = load_shape(max(m - 3, 0));  // (set A's next visit)
+          }
         });
-        shb = sh_next;
+        sha = sh_next;
       }
     }
   }
@@ -606,9 +712,14 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
 // lane slot (lo, hi): f = P[lo][hi], tr = P[hi][lo] | (P Q)[lo][hi].  Staged through LDS so
 // that a block writes whole cache lines.  SUBST: the divided differences Phi[hi][lo] too.
 // ------------------------------------------------------------------------
-constexpr int kTmBlock = 128;
+constexpr int kTmBlock = 256;
 __global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMacroArgs a) {
-  __shared__ double stage[kTmBlock * 33];
+  // one 16-double matrix per thread at a time (row stride 17: conflict-free), written out as
+  // the f halves, then the tr halves of the block's records: 35 KB of LDS per block, as the
+  // node-ordered transition_kernel has, so 16 waves per CU (a 33-double stage halved that and
+  // doubled the kernel's time)
+  __shared__ double stage[kTmBlock * 17];
+  __shared__ unsigned long long live_mask[kTmBlock / 64];
   // thread index = record index: (evaluation, macro, category group, position, category in
   // the group); records of categories beyond K exist in memory but are never written
   const int Mmax = max_macros(a.n);
@@ -617,7 +728,7 @@ __global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMa
   const long first = (long)blockIdx.x * kTmBlock;
   const long idx = first + threadIdx.x;
   const long total = (long)a.count * per_eval;
-  bool live = false;
+  bool live = false, tip = false;
   double Pm[16];
   const DevModel* mp = nullptr;
   double tau = 0;
@@ -638,6 +749,7 @@ __global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMa
       const int node = pos < 2 ? me.child[pos] : me.grand[pos - 2];
       const DevModel& md = a.models[mi];
       mp = &md;
+      tip = node < a.n;
       tau = md.cat_rate[k] * a.bl_eff[(size_t)t * a.N + node];
       double ex[4], W[16];
       for (int x = 0; x < 4; x++) ex[x] = expm1(md.lambda[x] * tau);
@@ -648,46 +760,53 @@ __global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMa
           double sum = i == j ? 1.0 : 0.0;
           for (int x = 0; x < 4; x++) sum += md.V[i * 4 + x] * W[x * 4 + j];
           Pm[i * 4 + j] = sum > 0 ? sum : 0;
-        }
-      const bool tip = node < a.n;
-      for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-          double trv;
-          if (tip) {
-            trv = 0;
-            for (int x = 0; x < 4; x++) trv += Pm[i * 4 + x] * md.Q[x * 4 + j];
-          } else {
-            trv = Pm[j * 4 + i];
-          }
-          stage[threadIdx.x * 33 + (i * 4 + j) * 2] = Pm[i * 4 + j];
-          stage[threadIdx.x * 33 + (i * 4 + j) * 2 + 1] = trv;
+          stage[threadIdx.x * 17 + i * 4 + j] = Pm[i * 4 + j];
         }
     }
   }
   // (positions that do not exist are never read: whole 256-byte records are skipped)
   const unsigned long long ballot = __ballot(live);
-  __shared__ unsigned long long live_mask[kTmBlock / 64];
   if ((threadIdx.x & 63) == 0) live_mask[threadIdx.x >> 6] = ballot;
   __syncthreads();
   const long left = total - first;
   const int count = (int)(left < kTmBlock ? left : kTmBlock);
   double* out = a.mmats + first * 32;
-  for (int x = threadIdx.x; x < count * 32; x += kTmBlock) {
-    const int rec = x >> 5;
-    if ((live_mask[rec >> 6] >> (rec & 63)) & 1) out[x] = stage[rec * 33 + (x & 31)];
+  auto is_live = [&](int rec) { return (live_mask[rec >> 6] >> (rec & 63)) & 1; };
+  for (int x = threadIdx.x; x < count * 16; x += kTmBlock) {
+    const int rec = x >> 4;
+    if (is_live(rec)) out[rec * 32 + (x & 15) * 2] = stage[rec * 17 + (x & 15)];
+  }
+  __syncthreads();
+  if (live) {
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        double trv;
+        if (tip) {
+          trv = 0;
+          for (int x = 0; x < 4; x++) trv += Pm[i * 4 + x] * mp->Q[x * 4 + j];
+        } else {
+          trv = Pm[j * 4 + i];
+        }
+        stage[threadIdx.x * 17 + i * 4 + j] = trv;
+      }
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < count * 16; x += kTmBlock) {
+    const int rec = x >> 4;
+    if (is_live(rec)) out[rec * 32 + (x & 15) * 2 + 1] = stage[rec * 17 + (x & 15)];
   }
   if (a.mphi != nullptr) {
     __syncthreads();
     if (live) {
       for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++)  // slot (lo = i, hi = j) holds Phi[hi][lo]
-          stage[threadIdx.x * 33 + i * 4 + j] = phi_divided_difference(mp->lambda[j], mp->lambda[i], tau);
+          stage[threadIdx.x * 17 + i * 4 + j] = phi_divided_difference(mp->lambda[j], mp->lambda[i], tau);
     }
     __syncthreads();
     double* out2 = a.mphi + first * 16;
     for (int x = threadIdx.x; x < count * 16; x += kTmBlock) {
       const int rec = x >> 4;
-      if ((live_mask[rec >> 6] >> (rec & 63)) & 1) out2[x] = stage[rec * 33 + (x & 15)];
+      if (is_live(rec)) out2[x] = stage[rec * 17 + (x & 15)];
     }
   }
 }
@@ -696,7 +815,7 @@ __global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMa
 
 size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
-  size_t bytes = (size_t)max_macros(n) * (16 / kp) * 32 + (subst ? 32 : 0) +
+  size_t bytes = (size_t)max_macros(n) * (16 / kp) * kTwCol + (subst ? 32 : 0) +
                  sizeof(double) * (size_t)slots * kLlR * kTile;
   if (rescale) bytes += ((sizeof(int16_t) * (size_t)max_stored(n) * kLlR * (16 / kp) + 7) / 8) * 8;
   return bytes;

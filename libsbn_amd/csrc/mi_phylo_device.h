@@ -10,7 +10,10 @@ namespace miphylo {
 constexpr int kStates = 4;       // the reference is DNA-only (substitution_model.cpp:6-15)
 constexpr int kMaxCategories = 16;
 constexpr int kTile = 64;        // site patterns per wavefront
-constexpr int kLlR = 3;          // matrix-core gradient kernel: registers (16 columns each) per node
+#ifndef MI_LLR
+#define MI_LLR 3
+#endif
+constexpr int kLlR = MI_LLR;     // matrix-core gradient kernel: registers (16 columns each) per node
 constexpr int kFdModels = 17;    // base model + 2*(3 frequency + 5 rate) perturbed models
 
 // One substitution+site model instance (what FatBeagle::SetParameters pushes to

@@ -13,6 +13,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_AN
   rm -rf gpurun_out/sq_pass$i
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/sq_pass$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-small-batch "$@" > gpurun_out/sq_pass$i.log 2>&1
 done
+mkdir -p "$(dirname "$out")"
 python3 - "$out" <<'PY'
 import csv, glob, collections, sys
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -21,8 +21,11 @@
 //     instead of a branch per operand;
 //   * the edge sums of macro m land in the LDS bytes that held the tip words of macro m
 //     (dead by then): 8 waves per CU as before.
-// Every product, sum and reduction is the one the first-generation kernel does, in the same
-// order: results are bit-identical (tests/test_gpu_parity.py::test_walk_kernels_agree).
+// Every product and edge sum is the one the first-generation kernel does, in the same order;
+// two reductions at the root (site likelihood over states / categories, log-likelihood
+// partial) run on the matrix cores and row rotations instead of an LDS butterfly, so the
+// two generations agree to the last bits, not bitwise
+// (tests/test_gpu_parity.py::test_walk_kernels_agree).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -45,13 +48,18 @@ __device__ __forceinline__ double row_shr_add(double v) {
   return v + __hiloint2double(shi, slo);
 }
 
+// v[lane] += v[lane rotated right by SHIFT within its 16-lane row]
+template <int SHIFT>
+__device__ __forceinline__ double row_ror_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int slo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + SHIFT, 0xf, 0xf, true);
+  const int shi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + SHIFT, 0xf, 0xf, true);
+  return v + __hiloint2double(shi, slo);
+}
+
 // bytes per (macro, column) of the tip words in LDS: six words, padded to 32 (one ds_read_b128
-// + one ds_read_b64) or dense (three ds_read_b64)
-#ifdef MI_WALK_TW24
-constexpr unsigned kTwCol = 24;
-#else
+// + one ds_read_b64; dense with three ds_read_b64 measured the same)
 constexpr unsigned kTwCol = 32;
-#endif
 
 // configuration of one child of a macro (from the shape word)
 enum ChildCfg { kTip = 0, kStored = 1, kUss = 2, kUts = 3, kUst = 4, kUtt = 5 };
@@ -127,6 +135,56 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   const double rate_l = model->cat_rate[catc], drate_l = model->cat_drate[catc];
   const double AQ = model->Q[lo * 4 + hi];  // A operand for Q L (same in every block)
 
+  // ---- what a visit needs from memory, fetched a visit ahead ----
+  struct Mats {
+    double f[6], tr[6];
+    double ph[SUBST ? 6 : 1];
+  };
+  struct Tw {
+    uint32_t w[6];
+  };
+  struct Slots {  // scalars (s_load_dwordx8)
+    int q, c[2], g[4], dst;
+  };
+  auto load_shape = [&](int m) { return mw[m * 16]; };
+  auto load_slots = [&](int m) {
+    const cint_ptr p = mw + m * 16 + 8;
+    return Slots{p[0], {p[1], p[2]}, {p[3], p[4], p[5], p[6]}, p[7]};
+  };
+  const unsigned tw_lane = (unsigned)col * kTwCol;
+  auto fetch = [&](int m, bool pre) {  // m: scalar
+    Mats mt;
+    // scalar base of the visit + this lane's 32-bit offset + constants (the offset is made
+    // opaque so that it is not folded into a 64-bit per-lane pointer: that would cost two
+    // vector instructions per load instead of none)
+    // (positions 4 and 5 lie beyond the 4095-byte immediate: a second scalar base)
+    const char* sb = mm_g + (size_t)((unsigned)m * visit_stride);
+    unsigned off4 = 4 * kPosBytes;
+    asm volatile("" : "+s"(off4));
+    const char* sb4 = sb + off4;
+    unsigned voff = lane_moff;
+    asm volatile("" : "+v"(voff));
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const char* at = (j < 4 ? sb + j * kPosBytes : sb4 + (j - 4) * kPosBytes) + (size_t)voff;
+      if (pre) {
+        const double2 x = *reinterpret_cast<const double2*>(at);
+        mt.f[j] = x.x;
+        mt.tr[j] = x.y;
+      } else {
+        mt.f[j] = *reinterpret_cast<const double*>(at);
+      }
+    }
+    if (pre && SUBST) {
+      const char* sp = ph_g + (size_t)((unsigned)m * (visit_stride / 2));
+      unsigned vph = lane_moff / 2;
+      asm volatile("" : "+v"(vph));
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+        mt.ph[j] = *reinterpret_cast<const double*>(sp + j * (kPosBytes / 2) + (size_t)vph);
+    }
+    return mt;
+  };
   // LDS: [macro][column][8 words: tip masks of positions 0..5, one byte per register r]
   // -- re-used, macro by macro, for that macro's edge sums [position][branch, site] once its
   // tip words are in registers -- | SUBST: four root sums | vectors [slot][r][lane] |
@@ -250,56 +308,6 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     return x;
   };
 
-  // ---- what a visit needs from memory, fetched a visit ahead ----
-  struct Mats {
-    double f[6], tr[6];
-    double ph[SUBST ? 6 : 1];
-  };
-  struct Tw {
-    uint32_t w[6];
-  };
-  struct Slots {  // scalars (s_load_dwordx8)
-    int q, c[2], g[4], dst;
-  };
-  auto load_shape = [&](int m) { return mw[m * 16]; };
-  auto load_slots = [&](int m) {
-    const cint_ptr p = mw + m * 16 + 8;
-    return Slots{p[0], {p[1], p[2]}, {p[3], p[4], p[5], p[6]}, p[7]};
-  };
-  const unsigned tw_lane = (unsigned)col * kTwCol;
-  auto fetch = [&](int m, bool pre) {  // m: scalar
-    Mats mt;
-    // scalar base of the visit + this lane's 32-bit offset + constants (the offset is made
-    // opaque so that it is not folded into a 64-bit per-lane pointer: that would cost two
-    // vector instructions per load instead of none)
-    // (positions 4 and 5 lie beyond the 4095-byte immediate: a second scalar base)
-    const char* sb = mm_g + (size_t)((unsigned)m * visit_stride);
-    unsigned off4 = 4 * kPosBytes;
-    asm volatile("" : "+s"(off4));
-    const char* sb4 = sb + off4;
-    unsigned voff = lane_moff;
-    asm volatile("" : "+v"(voff));
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      const char* at = (j < 4 ? sb + j * kPosBytes : sb4 + (j - 4) * kPosBytes) + (size_t)voff;
-      if (pre) {
-        const double2 x = *reinterpret_cast<const double2*>(at);
-        mt.f[j] = x.x;
-        mt.tr[j] = x.y;
-      } else {
-        mt.f[j] = *reinterpret_cast<const double*>(at);
-      }
-    }
-    if (pre && SUBST) {
-      const char* sp = ph_g + (size_t)((unsigned)m * (visit_stride / 2));
-      unsigned vph = lane_moff / 2;
-      asm volatile("" : "+v"(vph));
-#pragma unroll
-      for (int j = 0; j < 6; j++)
-        mt.ph[j] = *reinterpret_cast<const double*>(sp + j * (kPosBytes / 2) + (size_t)vph);
-    }
-    return mt;
-  };
   auto fetch_tw = [&](int m) {  // the six tip words of visit m (LDS)
     Tw t;
     const char* twp = lds0 + ((unsigned)m * tstride + tw_lane);
@@ -380,9 +388,6 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     const V none{};
     child_L(sh, J0{}, mt, tw, sl, c0, false, none, none);
     child_L(sh, J1{}, mt, tw, sl, c1, false, none, none);
-#ifdef MI_WALK_MID_DRAIN
-    requests(0);
-#endif
     V Lv = mul(mm(mt.f[0], c0.L), mm(mt.f[1], c1.L));
     if (!ROOT) {
       if (RESCALE) {
@@ -416,10 +421,17 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
           if (RESCALE) v = ldexp(v, a.site_exp[at] - esum[r]);
         } else {
           v = cw_l * pi_l * Lv.v[r];
-          v += __shfl_xor(v, 16, 64);
-          v += __shfl_xor(v, 32, 64);
-          if (Kp >= 2) v += __shfl_xor(v, 4, 64);
-          if (Kp >= 4) v += __shfl_xor(v, 8, 64);
+          // states: one product with a ones matrix leaves the column sums in every row; the
+          // four categories of a pattern sit 4 lanes apart in a row: two row rotations
+          // (no LDS round trips on this chain; sums in another order than the first
+          // generation's butterfly: last-bit differences in the site likelihoods)
+          v = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, v, 0.0, 0, 0, 0);
+          if (Kp == 4) {
+            v = row_ror_add<8>(v);
+            v = row_ror_add<4>(v);
+          } else if (Kp == 2) {
+            v += __shfl_xor(v, 4, 64);
+          }
         }
         sitev[r] = v;
       }
@@ -433,12 +445,19 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
         ev = hi == j ? esum[j] : ev;
       }
       const double quot = wv / sv;  // pw = 0 for padding patterns
+      // row r of the quotients to every row: a product with the selector matrix e_r e_r^T ...
+      // (A[i][k] = [k == r] for all i: D[i][j] = quot[r][j], exact)
 #pragma unroll
-      for (int r = 0; r < R; r++) qroot[r] = pi_l * cw_l * __shfl(quot, (r << 4) | (lane & 15), 64);
+      for (int r = 0; r < R; r++)
+        qroot[r] = pi_l * cw_l * __builtin_amdgcn_mfma_f64_4x4x4f64(hi == r ? 1.0 : 0.0, quot, 0.0, 0, 0, 0);
       double ll = 0.0;
       if (hi < R && (b % Kp) == 0 && pv < a.P)
         ll = wv * (RESCALE ? log(sv) + ev * 0.69314718055994530942 : log(sv));
-      ll = wave_sum(ll);
+      ll = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, ll, 0.0, 0, 0, 0);  // rows
+      ll = row_ror_add<8>(ll);
+      ll = row_ror_add<4>(ll);
+      ll = row_ror_add<2>(ll);
+      ll = row_ror_add<1>(ll);
       if (lane == 0 && groups == 1) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
       if (SUBST) {
         double z = 0;
@@ -452,13 +471,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
         if ((lane & 15) == 15) xroot[hi] = z;
       }
     }
-#ifdef MI_WALK_MID_DRAIN
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the scalar loads have long returned
-    requests(1);
-#else
     requests(0);
     requests(1);
-#endif
   };
   using Inner = std::false_type;
   using Root = std::true_type;
@@ -629,21 +643,13 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     Child c0, c1;
     child_L(sh, J0{}, mt, tw, sl, c0, true, pl.x[0], pl.x[1]);
     child_L(sh, J1{}, mt, tw, sl, c1, true, pl.x[2], pl.x[3]);
-#ifdef MI_WALK_MID_DRAIN
-    requests(0);
-#endif
     const V A = mm(mt.f[0], c0.L), B = mm(mt.f[1], c1.L);
     V n0, n1;
     child_edges(sh, J0{}, mt, sl, c0, mul(qv, B), m, n0);
     child_edges(sh, J1{}, mt, sl, c1, mul(qv, A), m, n1);
     edge_sums(n0, n1, m, 0);
-#ifdef MI_WALK_MID_DRAIN
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    requests(1);
-#else
     requests(0);
     requests(1);
-#endif
   };
   {
     // the root's visit first (set A), then the stored nodes downwards, B and A in turn

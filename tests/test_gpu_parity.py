@@ -886,8 +886,8 @@ def test_walk_kernels_agree():
     """The two generations of the matrix-core gradient walk -- gradient_mfma_kernel
     (node-ordered matrices, schedule entries in vector registers) and gradient_walk_kernel
     (macro-ordered operand streams, scalar descriptors, one switch per child configuration) --
-    do the same arithmetic in the same order: bit-identical log-likelihoods and gradients,
-    over rate-category counts 1 / 2 / 3 / 4 / 8, with and without rescaling, finite-difference
+    do the same products in the same order (only two root reductions are ordered differently):
+    log-likelihoods and gradients equal to the last bits, over rate-category counts 1 / 2 / 3 / 4 / 8, with and without rescaling, finite-difference
     and analytic GTR, stored vectors in LDS and in the arena, unrooted and rooted.  (The
     switches are read at engine creation / once per process: each form runs in its own
     interpreter.)"""
@@ -968,11 +968,10 @@ np.save(sys.argv[1], np.concatenate(out))
         for subst_mode in ("", "analytic"):
             a, b = results[("v1", store, subst_mode)], results[("v2", store, subst_mode)]
             assert a.shape == b.shape and np.isfinite(a).all()
-            if subst_mode == "analytic":
-                # log-likelihoods, branch and site gradients are bit-identical here too; the
-                # analytic substitution gradient of single-category models differs in the last
-                # bits (2.5e-13 relative, measured) -- its tolerance against finite
-                # differences is 1e-9
-                assert np.allclose(a, b, rtol=1e-12, atol=0), (store, np.max(np.abs(a - b)))
-            else:
-                assert np.array_equal(a, b), (store, subst_mode, np.max(np.abs(a - b)))
+            # Same products in the same order; what differs is the ORDER of two reductions at
+            # the root (states and categories of the site likelihood, the log-likelihood
+            # partial: matrix-core / row-rotation sums in the second generation, a cross-lane
+            # butterfly in the first), i.e. last-bit differences that the rest of the walk
+            # carries along.  Until that change the two were bit-identical (round 3 history).
+            assert np.allclose(a, b, rtol=1e-12, atol=1e-13 * np.max(np.abs(b))), (
+                store, subst_mode, np.max(np.abs(a - b)))

@@ -102,9 +102,11 @@ int32_t mi_engine_create_reversible(const mi_engine_spec* spec, const double* ex
                                     mi_engine** out_engine);
 /* One handle driving several devices -- what Engine's thread_count FatBeagles are
  * (src/engine.cpp:14-27; FatBeagleParallelize, src/fat_beagle.hpp:119-149): `shard_count`
- * engines, shard i on HIP device devices[i] (NULL: round-robin over the visible devices; an
- * ordinal may repeat, which puts several logical shards on one device), tips and weights
- * resident on each.  shard_mode MI_SHARD_TREES: the host-pointer calls deal the trees to
+ * engines, shard i on HIP device devices[i] (an ordinal may repeat, which puts several logical
+ * shards on one device; a negative ordinal -1 - k means "the k-th device counting from the
+ * caller's current HIP device, wrapping around"; NULL = {-1, -2, ...}: round-robin starting
+ * at the current device, so that a one-process-per-GPU launch which selected its device with
+ * hipSetDevice stays on it), tips and weights resident on each.  shard_mode MI_SHARD_TREES: the host-pointer calls deal the trees to
  * the shards in contiguous blocks (mi_shard_range), all devices work side by side, results
  * come back in tree order -- bit-identical to a single engine's.  MI_SHARD_PATTERNS (few
  * trees, very long alignments): shard i holds the site patterns mi_shard_range(P, count, i),

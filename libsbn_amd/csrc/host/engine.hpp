@@ -75,6 +75,10 @@ class Engine {
       spec.subst_model = MI_SUBST_REVERSIBLE;
       spec.state_count = 20;
     } else Failwith("Substitution model not known: " + specification.substitution_);
+    if (site_pattern_.StateCount() != spec.state_count)
+      Failwith("The site pattern is coded in a " + std::to_string(site_pattern_.StateCount()) +
+               "-state alphabet, the substitution model " + specification.substitution_ +
+               " has " + std::to_string(spec.state_count) + " states.");
     if (specification.site_ == "constant") {
       spec.site_model = MI_SITE_CONSTANT;
       spec.category_count = 1;
@@ -96,9 +100,13 @@ class Engine {
     const auto tips = site_pattern_.FlatPatterns();
     std::vector<int32_t> shards = engine_specification.device_shards_;
     if (shards.empty()) {
+      // thread_count executors (engine.cpp:23-27) = that many devices, counted from the
+      // caller's CURRENT HIP device (ordinal -1 - i, include/mi_phylo.h): one executor stays
+      // on the device the process selected -- under one-process-per-GPU launches every rank
+      // would otherwise pile onto device 0
       const size_t devices = static_cast<size_t>(std::max(1, mi_device_count()));
       for (size_t i = 0; i < std::min(engine_specification.thread_count_, devices); i++)
-        shards.push_back(static_cast<int32_t>(i));
+        shards.push_back(-1 - static_cast<int32_t>(i));
     }
     taxon_count_ = static_cast<size_t>(spec.taxon_count);
     Check(mi_engine_create_sharded(&spec, static_cast<int32_t>(shards.size()), shards.data(),

@@ -125,6 +125,7 @@ SitePattern::SitePattern(const Alignment& alignment, const std::vector<std::stri
   std::vector<const std::string*> rows(n);
   for (size_t i = 0; i < n; i++) rows[i] = &alignment.at(taxon_names[i]);
   site_count_ = alignment.Length();
+  state_count_ = protein ? 20 : 4;
   std::unordered_map<std::vector<int>, double, ColumnHash> seen;
   std::vector<int> column(n);
   for (size_t pos = 0; pos < site_count_; pos++) {

@@ -54,6 +54,10 @@ class SitePattern {
   size_t PatternCount() const { return patterns_.empty() ? 0 : patterns_[0].size(); }
   size_t SequenceCount() const { return patterns_.size(); }
   size_t SiteCount() const { return site_count_; }
+  // states of the alphabet the patterns are coded in (4: DNA, 20: amino acids); an Engine
+  // whose model has another state count refuses the pattern (the codes would be read as the
+  // other alphabet's: DNA's gap code 4 is Cys in amino-acid order)
+  int StateCount() const { return state_count_; }
   // row-major [taxon][pattern] copy for the C ABI
   std::vector<int32_t> FlatPatterns() const;
   static int SymbolCode(char c);  // site_pattern.cpp:16-56
@@ -63,6 +67,7 @@ class SitePattern {
   std::vector<std::vector<int>> patterns_;
   std::vector<double> weights_;
   size_t site_count_ = 0;
+  int state_count_ = 4;
 };
 
 // ---- trees ---------------------------------------------------------------------

@@ -1257,6 +1257,12 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool sub
 #endif
   launch_gradient_mfma_store<false>(a, grid, lds, false, false, s);
 }
+int gradient_mfma_waves_per_cu(int n, int K) {
+  const size_t lds = gradient_mfma_use_arena(n, K, false, false)
+                         ? gradient_mfma_lds_bytes_for(n, K, false, false, gradient_arena_slots_usual(n))
+                         : gradient_mfma_lds_bytes(n, K, false, false);
+  return (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+}
 const char* gradient_kernel_name() { return "gradient_hbm_kernel"; }
 const char* gradient_mfma_kernel_name() { return "gradient_mfma_kernel"; }
 

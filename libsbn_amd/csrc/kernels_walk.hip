@@ -28,6 +28,7 @@
 // (tests/test_gpu_parity.py::test_walk_kernels_agree).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <type_traits>
@@ -893,6 +894,13 @@ bool gradient_walk_fits(int n, int K, bool rescale) {
   if (n < 3 || K > kMaxCategories) return false;
   if (gradient_walk_lds_bytes(n, K, rescale, true) <= 160 * 1024) return true;
   return gradient_walk_lds_bytes_for(n, K, rescale, true, gradient_arena_slots_sure(n)) <= 160 * 1024;
+}
+// waves per CU the kernel's LDS footprint allows (the registers allow 8)
+int gradient_walk_waves_per_cu(int n, int K) {
+  const size_t lds = gradient_walk_use_arena(n, K, false, false)
+                         ? gradient_walk_lds_bytes_for(n, K, false, false, gradient_arena_slots_usual(n))
+                         : gradient_walk_lds_bytes(n, K, false, false);
+  return (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
 }
 const char* gradient_walk_kernel_name() { return "gradient_walk_kernel"; }
 

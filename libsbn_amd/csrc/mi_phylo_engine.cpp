@@ -74,6 +74,25 @@ bool walk_fits(const mi_engine* e, bool rescale) {
   return e->walk2 ? gradient_walk_fits(e->n, e->K, rescale) : gradient_mfma_fits(e->n, e->K, rescale);
 }
 
+// which log-likelihood kernel a call uses (also decides who fills the tip tables)
+bool loglik_kernel_is_valu(const mi_engine* e, bool rescaling) {
+  LikArgs probe{};
+  probe.n = e->n;
+  probe.K = e->K;
+  probe.tip_masks = e->have_tip_masks ? e->tip_masks.as<uint8_t>() : nullptr;
+  return std::string(loglik_kernel_name(probe, rescaling, e->max_slots)) == "loglik_onchip_kernel";
+}
+// Does a gradient call run on the matrix-core walk kernel?  ONE predicate for run_device and
+// mi_engine_reserve (a reserve that guesses differently leaves a later *_device call to
+// allocate -- inside a hipGraph capture, for instance).  (K > 4: the kernel takes the site
+// likelihoods from a pass of the matrix-core log-likelihood kernel; if that one cannot run,
+// neither can it.)
+bool matrix_core_gradient(const mi_engine* e, bool rescaling) {
+  return e->allow_onchip_gradient && e->have_tip_masks && walk_fits(e, rescaling) &&
+         reduce_tiles_fits(e->N) &&
+         (gradient_mfma_groups(e->K) == 1 || !loglik_kernel_is_valu(e, rescaling));
+}
+
 size_t plv_bytes_per_eval(const mi_engine* e) {
   return (size_t)(e->n - 1) * e->K * e->tiles * kTile * 4 * sizeof(double);
 }
@@ -139,17 +158,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // on-chip gradient kernels: the matrix-core one (K <= 4; rescaling supported) or the
   // VALU one (no rescaling); everything else takes the HBM-streamed kernel
   // which log-likelihood kernel runs (also decides who fills the tip tables, below)
-  LikArgs probe{};
-  probe.n = e->n;
-  probe.K = e->K;
-  probe.tip_masks = e->have_tip_masks ? e->tip_masks.as<uint8_t>() : nullptr;
-  const bool loglik_is_valu =
-      std::string(loglik_kernel_name(probe, d.rescaling, e->max_slots)) == "loglik_onchip_kernel";
-  // (K > 4: the matrix-core gradient kernel takes the site likelihoods from a pass of the
-  // matrix-core log-likelihood kernel; if that one cannot run, neither can it)
-  const bool mfma = d.gradient && e->allow_onchip_gradient && e->have_tip_masks &&
-                    walk_fits(e, d.rescaling) && reduce_tiles_fits(e->N) &&
-                    (gradient_mfma_groups(e->K) == 1 || !loglik_is_valu);
+  const bool loglik_is_valu = loglik_kernel_is_valu(e, d.rescaling);
+  const bool mfma = d.gradient && matrix_core_gradient(e, d.rescaling);
   const bool onchip = mfma;  // the only on-chip gradient kernel; everything else streams PLVs
   const int groups = mfma ? gradient_mfma_groups(e->K) : 1;
   const int g_tiles = mfma ? gradient_mfma_tiles(e->P, e->K) * groups : e->tiles;
@@ -471,7 +481,9 @@ int check_status(mi_engine* e, hipStream_t s) {
   if (st[0] != 0) {  // reported once: the first error since the last check
     HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, s));
     HIP_TRY(hipStreamSynchronize(s));
-    return fail(std::string(status_message(st[0])) + " (tree " + std::to_string(st[1]) + ")");
+    // (a shard of a sharded handle reports the caller's tree index, not its own)
+    return fail(std::string(status_message(st[0])) + " (tree " +
+                std::to_string(st[1] + e->status_tree_offset) + ")");
   }
   return 0;
 }
@@ -628,6 +640,12 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
     e->analytic_subst = std::string(env) == "analytic";
   // MI_PHYLO_GRADIENT_WALK=v1: the first-generation matrix-core gradient kernel (node-ordered
   // matrices; kept selectable, results are bit-identical)
+  // Which generation of the matrix-core gradient walk: the second (macro-ordered operand
+  // streams) keeps its tip words by (macro, position, column), 32 bytes per column -- with
+  // fewer than three rate categories a wave has 8 or 16 columns, and that table can cost
+  // waves per CU (fluA, K = 1: 5 instead of 8); then the first generation stays.
+  // MI_PHYLO_GRADIENT_WALK=v1|v2 forces one.
+  e->walk2 = gradient_walk_waves_per_cu(e->n, e->K) >= gradient_mfma_waves_per_cu(e->n, e->K);
   if (const char* env = getenv("MI_PHYLO_GRADIENT_WALK")) e->walk2 = std::string(env) != "v1";
   if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH")) {  // force one gradient kernel
     const std::string v(env);
@@ -815,9 +833,13 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
   // allocates nothing (it can then be captured in a hipGraph): the union of both rescaling
   // settings' workspaces (the HBM arena when either of them cannot use an on-chip kernel).
   const bool grad = for_gradients != 0;
-  const bool can_onchip = e->allow_onchip_gradient && e->have_tip_masks;
-  const bool onchip_plain = can_onchip && walk_fits(e, false);
-  const bool onchip_rescaled = can_onchip && walk_fits(e, true);
+  const bool onchip_plain = matrix_core_gradient(e, false);
+  const bool onchip_rescaled = matrix_core_gradient(e, true);
+  if (grad) {  // the fused reductions' per-tree buffers (mi_engine_gradients_unrooted_reduced*)
+    if (e->red_ll.ensure(sizeof(double) * tree_count)) return 1;
+    if (e->red_g.ensure(sizeof(double) * (size_t)tree_count * e->N)) return 1;
+    if (e->red_site.ensure(sizeof(double) * tree_count)) return 1;
+  }
   const bool analytic = e->analytic_subst && e->spec.subst_model == MI_SUBST_GTR;
   if (reserve(e, tree_count, grad, !onchip_plain, analytic && onchip_plain)) return 1;
   if (grad && onchip_plain != onchip_rescaled &&
@@ -1085,6 +1107,8 @@ int32_t mi_engine_create_sharded(const mi_engine_spec* spec, int32_t shard_count
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
     return fail("no HIP device available: the MI355X engine has no CPU fallback");
+  int current = 0;
+  if (hipGetDevice(&current) != hipSuccess) current = 0;
   mi_engine* front = new mi_engine();
   front->spec = *spec;
   front->shard_mode = shard_mode;
@@ -1095,7 +1119,12 @@ int32_t mi_engine_create_sharded(const mi_engine_spec* spec, int32_t shard_count
   const int n = spec->taxon_count, s = spec->state_count;
   for (int i = 0; i < shard_count; i++) {
     mi_engine_spec sub = *spec;
-    sub.device = devices ? devices[i] : i % count;  // NULL: round-robin over the visible devices
+    // NULL: round-robin over the visible devices STARTING AT THE CALLER'S CURRENT DEVICE (a
+    // one-process-per-GPU launch that selected its device with hipSetDevice keeps it; a
+    // negative ordinal -1 - k names "the k-th device from the current one" explicitly)
+    int want = devices ? devices[i] : -1 - i;
+    if (want < 0) want = (current + (-1 - want)) % count;
+    sub.device = want;
     int32_t b = 0, c = spec->pattern_count;
     if (shard_mode == MI_SHARD_PATTERNS) mi_shard_range(spec->pattern_count, shard_count, i, &b, &c);
     sub.pattern_count = c;
@@ -1182,6 +1211,10 @@ int begin_host_call(mi_engine* e, const HostCall& h) {
   if (e->param_count > 0 && !h.params) return fail("null parameter matrix");
   HIP_TRY(hipSetDevice(e->spec.device));
   e->pinned.reset();  // nothing of an earlier (possibly failed) call is delivered late
+  // The status word is sticky (the *_device calls never clear it).  A host-pointer call
+  // reports ITS OWN errors only: whatever an earlier device-pointer call left unread on this
+  // engine's stream is dropped here, not blamed on this batch.
+  HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, e->stream));
   const size_t np = h.rooted ? 2 * n - 2 : 2 * n - 3, nb = np + 1;
   if (upload_staged(e, e->in_parent, h.parent_ids, (size_t)T * np)) return 1;
   if (upload_staged(e, e->in_bl, h.bl, (size_t)T * nb)) return 1;
@@ -1307,6 +1340,7 @@ int run_sharded(mi_engine* e, const HostCall& h) {
         s.out_sum = e->shard_sums.data() + (size_t)i * (2 + h.index_count);
         s.out_index_grad = s.out_sum + 2;
       }
+      e->shards[i]->status_tree_offset = b;
       rc = begin_host_call(e->shards[i], s);
       started.push_back(i);
     }

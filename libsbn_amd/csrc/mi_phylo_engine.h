@@ -161,6 +161,7 @@ struct mi_engine {
   // last-call info
   const char* dominant = "";
   int64_t last_evals = 0, last_grad_evals = 0;
+  int status_tree_offset = 0;  // a shard's first tree in the caller's batch (error messages)
   int last_walk_launches = 1;  // chunks of evaluations the last call's walk kernels ran over
   int aa_backoffs = 0;         // times the 20-state arena budget was reduced (aa_reserve)
 };

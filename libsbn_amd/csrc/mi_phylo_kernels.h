@@ -193,6 +193,9 @@ size_t gradient_walk_lds_bytes(int n, int K, bool rescale, bool subst);
 size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots);
 size_t gradient_walk_mats_bytes_per_eval(int n, int K);
 const char* gradient_walk_kernel_name();
+// waves per CU each generation's LDS footprint allows for this tree size and category count
+int gradient_walk_waves_per_cu(int n, int K);
+int gradient_mfma_waves_per_cu(int n, int K);
 // Sum of the per-tile partials: ll_sum[e] = sum_i ll_part[e][i] for e < E,
 // g_sum[gi][2N] = sum_i g_part[gi][i][2N] for gi < Eg (fixed order: deterministic).
 struct ReduceArgs {

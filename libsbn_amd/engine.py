@@ -113,20 +113,26 @@ class Engine:
                                      1 if use_tip_states else 0, device, 0)
         h = C.c_void_p()
         ex = fr = None
+        if reversible_model is not None:  # validated before ANY create call reads the arrays
+            if states != 20:
+                raise RuntimeError("reversible_model needs a 20-state substitution model")
+            ex, fr = (_np(x, np.float64) for x in reversible_model)
+            if ex.shape != (190,) or fr.shape != (20,):
+                raise RuntimeError("reversible_model must be (exchangeabilities[190], "
+                                   "frequencies[20])")
+        if patterns is not None and patterns.size and int(patterns.max()) > states:
+            # (compact states are 0..s-1, s = gap; a 20-state pattern matrix handed to a
+            # 4-state engine -- or the reverse, caught below for DNA codes only by value --
+            # would be read as another alphabet)
+            raise RuntimeError(f"compact tip states exceed the {states}-state alphabet "
+                               f"(largest code {int(patterns.max())})")
         if shard_devices is not None:
-            if reversible_model is not None:
-                ex, fr = (_np(x, np.float64) for x in reversible_model)
             devs = _np(shard_devices, np.int32)
             mode = {"trees": 0, "patterns": 1}[shard_mode]
             rc = self._lib.mi_engine_create_sharded(
                 C.byref(self.spec), len(devs), devs.ctypes.data_as(_capi.I32P), mode, _ptr(ex),
                 _ptr(fr), _ptr(patterns), _ptr(tip_partials), _ptr(weights), C.byref(h))
         elif states == 20:
-            if reversible_model is not None:
-                ex, fr = (_np(x, np.float64) for x in reversible_model)
-                if ex.shape != (190,) or fr.shape != (20,):
-                    raise RuntimeError("reversible_model must be (exchangeabilities[190], "
-                                       "frequencies[20])")
             rc = self._lib.mi_engine_create_reversible(
                 C.byref(self.spec), _ptr(ex), _ptr(fr), _ptr(patterns), _ptr(tip_partials),
                 _ptr(weights), C.byref(h))

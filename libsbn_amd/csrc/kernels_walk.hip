@@ -719,69 +719,60 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
 // lane slot (lo, hi): f = P[lo][hi], tr = P[hi][lo] | (P Q)[lo][hi].  Staged through LDS so
 // that a block writes whole cache lines.  SUBST: the divided differences Phi[hi][lo] too.
 // ------------------------------------------------------------------------
-constexpr int kTmBlock = 256;
+constexpr int kTmBlock = 128;
 __global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMacroArgs a) {
-  // one 16-double matrix per thread at a time (row stride 17: conflict-free), written out as
-  // the f halves, then the tr halves of the block's records: 35 KB of LDS per block, as the
-  // node-ordered transition_kernel has, so 16 waves per CU (a 33-double stage halved that and
-  // doubled the kernel's time)
+  // One thread per (node, category) of ONE gradient evaluation (blockIdx.x): as many threads
+  // as matrices, none idle on positions that do not exist.  Where a node's matrices go -- its
+  // (macro, position) -- comes from a map the block builds from the tree's macro entries.
+  // The 16-double matrices are staged one per thread (row stride 17: conflict-free) and
+  // written out as the f halves, then the tr halves, of the 256-byte records.
   __shared__ double stage[kTmBlock * 17];
-  __shared__ unsigned long long live_mask[kTmBlock / 64];
-  // thread index = record index: (evaluation, macro, category group, position, category in
-  // the group); records of categories beyond K exist in memory but are never written
-  const int Mmax = max_macros(a.n);
-  const int groups = (a.K + 3) / 4;
-  const long per_eval = (long)Mmax * groups * 24;
-  const long first = (long)blockIdx.x * kTmBlock;
-  const long idx = first + threadIdx.x;
-  const long total = (long)a.count * per_eval;
-  bool live = false, tip = false;
-  double Pm[16];
-  const DevModel* mp = nullptr;
-  double tau = 0;
-  if (idx < total) {
-    const int kk = idx & 3;
-    const int pos = (idx >> 2) % 6;
-    const int group = (idx / 24) % groups;
-    const int m = (idx / (24L * groups)) % Mmax;
-    const int ge = idx / per_eval;  // gradient evaluation of this launch
-    const int k = 4 * group + kk;
-    int t, mi;
-    a.map.decode(a.eval_begin + ge, t, mi);
-    const MacroEntry& me = a.macros[(size_t)t * Mmax + m];
-    const bool exists = k < a.K && m < a.macro_count[t] &&
-                        (pos < 2 || ((me.shape >> (2 * ((pos - 2) >> 1))) & 3) == 2);
-    if (exists) {
-      live = true;
-      const int node = pos < 2 ? me.child[pos] : me.grand[pos - 2];
-      const DevModel& md = a.models[mi];
-      mp = &md;
-      tip = node < a.n;
-      tau = md.cat_rate[k] * a.bl_eff[(size_t)t * a.N + node];
-      double ex[4], W[16];
-      for (int x = 0; x < 4; x++) ex[x] = expm1(md.lambda[x] * tau);
-      for (int x = 0; x < 4; x++)
-        for (int j = 0; j < 4; j++) W[x * 4 + j] = ex[x] * md.Vinv[x * 4 + j];
-      for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-          double sum = i == j ? 1.0 : 0.0;
-          for (int x = 0; x < 4; x++) sum += md.V[i * 4 + x] * W[x * 4 + j];
-          Pm[i * 4 + j] = sum > 0 ? sum : 0;
-          stage[threadIdx.x * 17 + i * 4 + j] = Pm[i * 4 + j];
-        }
-    }
+  __shared__ int rec_of[kTmBlock];
+  extern __shared__ int slot_of[];  // [N - 1]: node -> macro * 6 + position
+  const int Mmax = max_macros(a.n), groups = (a.K + 3) / 4;
+  const int ge = blockIdx.x;  // gradient evaluation of this launch (grid.x: no 65535 limit)
+  int t, mi;
+  a.map.decode(a.eval_begin + ge, t, mi);
+  const MacroEntry* mac = a.macros + (size_t)t * Mmax;
+  const int M = a.macro_count[t];
+  for (int j = threadIdx.x; j < M * 6; j += kTmBlock) {
+    const int m = j / 6, pos = j - m * 6;
+    const MacroEntry& me = mac[m];
+    if (pos < 2 || ((me.shape >> (2 * ((pos - 2) >> 1))) & 3) == 2)
+      slot_of[pos < 2 ? me.child[pos] : me.grand[pos - 2]] = j;
   }
-  // (positions that do not exist are never read: whole 256-byte records are skipped)
-  const unsigned long long ballot = __ballot(live);
-  if ((threadIdx.x & 63) == 0) live_mask[threadIdx.x >> 6] = ballot;
   __syncthreads();
-  const long left = total - first;
-  const int count = (int)(left < kTmBlock ? left : kTmBlock);
-  double* out = a.mmats + first * 32;
-  auto is_live = [&](int rec) { return (live_mask[rec >> 6] >> (rec & 63)) & 1; };
-  for (int x = threadIdx.x; x < count * 16; x += kTmBlock) {
-    const int rec = x >> 4;
-    if (is_live(rec)) out[rec * 32 + (x & 15) * 2] = stage[rec * 17 + (x & 15)];
+  const int idx = blockIdx.y * kTmBlock + threadIdx.x;  // node * K + category
+  const int node = idx / a.K, k = idx - node * a.K;
+  const bool live = node < a.N - 1 && M > 0;
+  double Pm[16];
+  const DevModel& md = a.models[mi];
+  bool tip = false;
+  double tau = 0;
+  if (live) {
+    tip = node < a.n;
+    tau = md.cat_rate[k] * a.bl_eff[(size_t)t * a.N + node];
+    double ex[4], W[16];
+    for (int x = 0; x < 4; x++) ex[x] = expm1(md.lambda[x] * tau);
+    for (int x = 0; x < 4; x++)
+      for (int j = 0; j < 4; j++) W[x * 4 + j] = ex[x] * md.Vinv[x * 4 + j];
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        double sum = i == j ? 1.0 : 0.0;
+        for (int x = 0; x < 4; x++) sum += md.V[i * 4 + x] * W[x * 4 + j];
+        Pm[i * 4 + j] = sum > 0 ? sum : 0;
+        stage[threadIdx.x * 17 + i * 4 + j] = Pm[i * 4 + j];
+      }
+    const int slot = slot_of[node], m = slot / 6, pos = slot - m * 6;
+    // record index: (evaluation, macro, category group, position, category in the group)
+    rec_of[threadIdx.x] = ((((ge * Mmax + m) * groups + (k >> 2)) * 6 + pos) << 2) + (k & 3);
+  } else {
+    rec_of[threadIdx.x] = -1;
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < kTmBlock * 16; x += kTmBlock) {
+    const int rec = rec_of[x >> 4];
+    if (rec >= 0) a.mmats[(size_t)rec * 32 + (x & 15) * 2] = stage[(x >> 4) * 17 + (x & 15)];
   }
   __syncthreads();
   if (live) {
@@ -790,7 +781,7 @@ __global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMa
         double trv;
         if (tip) {
           trv = 0;
-          for (int x = 0; x < 4; x++) trv += Pm[i * 4 + x] * mp->Q[x * 4 + j];
+          for (int x = 0; x < 4; x++) trv += Pm[i * 4 + x] * md.Q[x * 4 + j];
         } else {
           trv = Pm[j * 4 + i];
         }
@@ -798,22 +789,21 @@ __global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMa
       }
   }
   __syncthreads();
-  for (int x = threadIdx.x; x < count * 16; x += kTmBlock) {
-    const int rec = x >> 4;
-    if (is_live(rec)) out[rec * 32 + (x & 15) * 2 + 1] = stage[rec * 17 + (x & 15)];
+  for (int x = threadIdx.x; x < kTmBlock * 16; x += kTmBlock) {
+    const int rec = rec_of[x >> 4];
+    if (rec >= 0) a.mmats[(size_t)rec * 32 + (x & 15) * 2 + 1] = stage[(x >> 4) * 17 + (x & 15)];
   }
   if (a.mphi != nullptr) {
     __syncthreads();
     if (live) {
       for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++)  // slot (lo = i, hi = j) holds Phi[hi][lo]
-          stage[threadIdx.x * 17 + i * 4 + j] = phi_divided_difference(mp->lambda[j], mp->lambda[i], tau);
+          stage[threadIdx.x * 17 + i * 4 + j] = phi_divided_difference(md.lambda[j], md.lambda[i], tau);
     }
     __syncthreads();
-    double* out2 = a.mphi + first * 16;
-    for (int x = threadIdx.x; x < count * 16; x += kTmBlock) {
-      const int rec = x >> 4;
-      if (is_live(rec)) out2[x] = stage[rec * 17 + (x & 15)];
+    for (int x = threadIdx.x; x < kTmBlock * 16; x += kTmBlock) {
+      const int rec = rec_of[x >> 4];
+      if (rec >= 0) a.mphi[(size_t)rec * 16 + (x & 15)] = stage[(x >> 4) * 17 + (x & 15)];
     }
   }
 }
@@ -836,9 +826,9 @@ size_t gradient_walk_mats_bytes_per_eval(int n, int K) {
 
 void launch_transition_macro(const TransitionMacroArgs& a, hipStream_t s) {
   if (a.count <= 0) return;
-  const long total = (long)a.count * max_macros(a.n) * ((a.K + 3) / 4) * 24;
-  hipLaunchKernelGGL(transition_macro_kernel, dim3((unsigned)((total + kTmBlock - 1) / kTmBlock)),
-                     dim3(kTmBlock), 0, s, a);
+  const int per_eval = (a.N - 1) * a.K;
+  const dim3 grid(a.count, (per_eval + kTmBlock - 1) / kTmBlock);
+  hipLaunchKernelGGL(transition_macro_kernel, grid, dim3(kTmBlock), sizeof(int) * (size_t)(a.N - 1), s, a);
 }
 
 template <bool RESCALE, bool SUBST, bool ARENA>

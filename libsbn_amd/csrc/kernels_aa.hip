@@ -298,6 +298,27 @@ __device__ __forceinline__ void load_tiles(const double* __restrict__ src, int l
 #pragma unroll
     for (int t = 0; t < 5; t++) L[u][t] = src[u * kAaTileDoubles + t * 64 + lane];
 }
+// Sum of one double per lane over the wave without LDS round trips: a product with a ones
+// matrix adds the four 16-lane rows (v_mfma_f64_4x4x4: D[i][j] = sum_k B[k][j], k = lane >>
+// 4), four row rotations add the 16 lanes of a row.  Every lane ends with the total.  (The
+// ds_bpermute butterfly this replaces is six dependent LDS-crossbar round trips: two such
+// sums per pre-order visit were ~15 % of the visit's latency.)
+template <int SHIFT>
+__device__ __forceinline__ double aa_row_ror_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int slo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + SHIFT, 0xf, 0xf, true);
+  const int shi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + SHIFT, 0xf, 0xf, true);
+  return v + __hiloint2double(shi, slo);
+}
+__device__ __forceinline__ double wave_sum_mfma(double v) {
+  v = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, v, 0.0, 0, 0, 0);
+  v = aa_row_ror_add<8>(v);
+  v = aa_row_ror_add<4>(v);
+  v = aa_row_ror_add<2>(v);
+  v = aa_row_ror_add<1>(v);
+  return v;
+}
+
 template <int M>
 __device__ __forceinline__ void store_tiles(double* __restrict__ dst, int lane,
                                             const double (&L)[M][5]) {
@@ -587,6 +608,36 @@ __device__ __forceinline__ void dma_1k(const double* src, uint32_t lane16, doubl
   const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)dst_lds;
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(src), "s"(m0) : "memory");
 }
+// A run of COUNT (<= 4) consecutive 1 KB pieces by ONE wave: one scalar base, one M0 value,
+// the pieces as immediate offsets -- the immediate moves the global source AND the LDS
+// destination (tools/lds_dma_probe.hip).  Round 3: the staging of a visit dealt its pieces
+// round-robin to the waves with a branch, a 64-bit scalar add and an M0 write per piece --
+// most of the ~185 scalar instructions a pre-order visit executed.
+template <int COUNT>
+__device__ __forceinline__ void dma_run(const double* src, uint32_t lane16, double* dst_lds) {
+  static_assert(COUNT >= 1 && COUNT <= 4, "immediate offsets reach 4095 bytes");
+  const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)dst_lds;
+  if (COUNT == 1)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(src), "s"(m0) : "memory");
+  else if (COUNT == 2)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(lane16), "s"(src), "s"(m0) : "memory");
+  else if (COUNT == 3)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(lane16), "s"(src), "s"(m0) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(lane16), "s"(src), "s"(m0) : "memory");
+}
+// a whole operand table of PIECES (4: tip column table, 5: matrix pack) by one wave
+template <int PIECES>
+__device__ __forceinline__ void dma_whole(const double* src, uint32_t lane16, double* dst_lds) {
+  dma_run<4>(src, lane16, dst_lds);
+  if (PIECES == 5) dma_run<1>(src + 4 * 128, lane16, dst_lds + 4 * 128);
+}
 // Piece k of a table (128 doubles) is issued by wave (first + k) % waves of the workgroup.
 __device__ __forceinline__ void dma_table(const double* __restrict__ src, double* dst_lds,
                                           int pieces, int first, int wave, int waves, int lane) {
@@ -661,13 +712,19 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
   // last one is the next table's head -- the arrays are padded by one piece)
   const int wave_s = sgpr(wave);
   auto stage = [&](int c0, int c1, int buf) {
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-      const int ch = c ? c1 : c0;
-      if (ch < n)
-        dma_table(tipP + (size_t)ch * K * kAaTipTable, ops_lds[buf][c], 4, 5 * c, wave_s, kPostWaves, lane);
-      else
-        dma_table(matP + (size_t)(ch - n) * K * kAaPack, ops_lds[buf][c], 5, 5 * c, wave_s, kPostWaves, lane);
+    // two operand tables per visit, each split between two waves: wave 2c takes the first
+    // pieces of child c's table, wave 2c + 1 the rest (runs with immediate offsets: dma_run)
+    const int c = wave_s >> 1, second = wave_s & 1;
+    const int ch = c ? c1 : c0;
+    const uint32_t lane16 = (uint32_t)lane * 16;
+    if (ch < n) {
+      const double* src = tipP + (size_t)ch * K * kAaTipTable + (second ? 2 * 128 : 0);
+      dma_run<2>(src, lane16, ops_lds[buf][c] + (second ? 2 * 128 : 0));
+    } else {
+      const double* src = matP + (size_t)(ch - n) * K * kAaPack + (second ? 3 * 128 : 0);
+      double* dst = ops_lds[buf][c] + (second ? 3 * 128 : 0);
+      if (second) dma_run<2>(src, lane16, dst);
+      else dma_run<3>(src, lane16, dst);
     }
   };
   auto stage0 = [&](int c0, int c1, int (&x)[2][M]) {
@@ -1030,7 +1087,7 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
           for (int t = 0; t < 5; t++) x += (q[u][t] * S[1 - c][u][t]) * D1[0][t];
         }
       }
-      X[c] = wave_sum(x);
+      X[c] = wave_sum_mfma(x);
     }
     // u_c, kept in S[sibling]
 #pragma unroll
@@ -1124,19 +1181,19 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
   // staging by LDS-DMA into buffer `buf`: internal child P | P^T (2 x 5 pieces), tip child
   // its two column tables (2 x 4 pieces) at offsets 0 and kAaPack
   const int wave_s = sgpr(wave);
+  const uint32_t lane16 = (uint32_t)lane * 16;
+  // four operand tables per visit (child 0 and child 1: P | P^T, or the two column tables of
+  // a tip), ONE per wave: wave 2c takes child c's first table, wave 2c + 1 its second
   auto stage = [&](int c0, int c1, int buf) {
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-      const int ch = c ? c1 : c0;
-      double* dst = ops_lds[buf][c];
-      if (ch < n) {
-        dma_table(tipP + (size_t)ch * K * kAaTipTable, dst, 4, 10 * c, wave_s, kPreWaves, lane);
-        dma_table(tipPQ + (size_t)ch * K * kAaTipTable, dst + kAaPack, 4, 10 * c + 4, wave_s, kPreWaves, lane);
-      } else {
-        const size_t off = (size_t)(ch - n) * K * kAaPack;
-        dma_table(matP + off, dst, 5, 10 * c, wave_s, kPreWaves, lane);
-        dma_table(matPT + off, dst + kAaPack, 5, 10 * c + 5, wave_s, kPreWaves, lane);
-      }
+    const int c = wave_s >> 1, second = wave_s & 1;
+    const int ch = c ? c1 : c0;
+    double* dst = ops_lds[buf][c] + (second ? kAaPack : 0);
+    if (ch < n) {
+      const double* src = (second ? tipPQ : tipP) + (size_t)ch * K * kAaTipTable;
+      dma_whole<4>(src, lane16, dst);
+    } else {
+      const double* src = (second ? matPT : matP) + (size_t)(ch - n) * K * kAaPack;
+      dma_whole<5>(src, lane16, dst);
     }
   };
   auto lds_pack = [&](const double* base, double (&A)[10]) {
@@ -1265,7 +1322,7 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
           for (int t = 0; t < 5; t++) x += (q[u][t] * S[1 - c][u][t]) * D1[0][t];
         }
       }
-      X[c] = wave_sum(x);
+      X[c] = wave_sum_mfma(x);
     }
 #pragma unroll
     for (int u = 0; u < M; u++)

@@ -8,7 +8,7 @@
 namespace miphylo {
 
 constexpr int kStates = 4;       // the reference is DNA-only (substitution_model.cpp:6-15)
-constexpr int kMaxCategories = 16;
+constexpr int kMaxCategories = 64;  // (the reference parses any weibull+K, site_model.cpp:15-24)
 constexpr int kTile = 64;        // site patterns per wavefront
 #ifndef MI_LLR
 #define MI_LLR 3

@@ -599,7 +599,7 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   if (spec->site_model == MI_SITE_CONSTANT && spec->category_count != 1)
     return fail("the constant site model has exactly one rate category");
   if (spec->category_count < 1 || spec->category_count > kMaxCategories)
-    return fail("category_count out of range (1..16)");
+    return fail("category_count out of range (1..64)");
   if (!tip_states && !(spec->use_tip_states == 0 && tip_partials))
     return fail("tip_states is required");
   if (!pattern_weights) return fail("pattern_weights is required");

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define ORC_MAX_STATES 20
-#define ORC_MAX_CATEGORIES 16
+#define ORC_MAX_CATEGORIES 64
 
 enum { ORC_SUBST_JC69 = 0, ORC_SUBST_GTR = 1, ORC_SUBST_REVERSIBLE = 2 };
 enum { ORC_SITE_CONSTANT = 0, ORC_SITE_WEIBULL = 1 };

@@ -223,8 +223,8 @@ class Model(C.Structure):
     _fields_ = [("s", C.c_int), ("K", C.c_int), ("pi", C.c_double * 20),
                 ("Q", C.c_double * 400), ("V", C.c_double * 400), ("Vinv", C.c_double * 400),
                 ("lam", C.c_double * 20), ("gtr_rates", C.c_double * 190),
-                ("n_gtr_rates", C.c_int), ("cat_rates", C.c_double * 16),
-                ("cat_weights", C.c_double * 16), ("cat_rate_derivs", C.c_double * 16)]
+                ("n_gtr_rates", C.c_int), ("cat_rates", C.c_double * 64),
+                ("cat_weights", C.c_double * 64), ("cat_rate_derivs", C.c_double * 64)]
 
 
 def model_set(spec, params):

@@ -298,11 +298,13 @@ def test_random_unrooted_vs_oracle(n, P, site):
             assert abs(g[t].log_likelihood - oll[t]) <= RTOL * abs(oll[t])
 
 
-@pytest.mark.parametrize("n,K", [(100, 2), (200, 4), (40, 8)])
+@pytest.mark.parametrize("n,K", [(100, 2), (200, 4), (40, 8), (12, 17), (9, 33), (7, 64)])
 def test_large_trees_and_category_counts(n, K):
     """n = 100 still fits the on-chip gradient kernel (49 LDS slots), n = 200 does not
     and takes the HBM-streamed kernel; 200-taxon trees also need rescaling to stay
-    inside FP64 range for long alignments.  K = 2 and 8 exercise other category counts."""
+    inside FP64 range for long alignments.  K = 2 and 8 exercise other category counts;
+    17, 33 and 64 the ones beyond round 2's limit of 16 (the reference parses any
+    weibull+K, site_model.cpp:15-24; the engine takes up to 64)."""
     rng = np.random.default_rng(n * 7 + K)
     P = 150
     tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.02)
@@ -978,3 +980,33 @@ np.save(sys.argv[1], np.concatenate(out))
             # carries along.  Until that change the two were bit-identical (round 3 history).
             assert np.allclose(a, b, rtol=1e-12, atol=1e-13 * np.max(np.abs(b))), (
                 store, subst_mode, np.max(np.abs(a - b)))
+
+
+def test_limits_are_refused_at_the_c_abi_with_a_message():
+    """The limits that are the engine's, not the reference's, are refused at engine creation
+    through the C ABI with a message -- never silently: more than 64 rate categories, fewer
+    than 3 taxa, a state count other than 4 / 20."""
+    import ctypes as C
+    from libsbn_amd import _capi
+    lib = _capi.load()
+    tips = np.zeros((4, 5), np.int32)
+    w = np.ones(5)
+
+    def create(n=4, P=5, s=4, K=1, subst=0, site=0):
+        spec = _capi.EngineSpec(n, P, s, K, subst, site, 1, 1, -1, 0)
+        h = C.c_void_p()
+        rc = lib.mi_engine_create(C.byref(spec), tips.ctypes.data_as(C.c_void_p), None,
+                                  w.ctypes.data_as(C.c_void_p), C.byref(h))
+        if rc == 0:
+            lib.mi_engine_destroy(h)
+        return rc, _capi.last_error()
+
+    assert create(K=64, site=1)[0] == 0
+    rc, msg = create(K=65, site=1)
+    assert rc != 0 and "category_count out of range (1..64)" in msg
+    rc, msg = create(n=2)
+    assert rc != 0 and "at least 3 taxa" in msg
+    rc, msg = create(s=5)
+    assert rc != 0 and "state_count must be 4" in msg
+    rc, msg = create(K=4, site=0)
+    assert rc != 0 and "exactly one rate category" in msg

@@ -2,6 +2,7 @@
 // (gfx950 / CDNA4, wave64; see DESIGN.md for the mapping and what bounds each kernel.)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 
@@ -17,10 +18,9 @@ using namespace dev;
 // Tile reduction (one workgroup per evaluation): four waves split the tiles
 // (wave w takes tiles w, w+4, ...), combine through LDS in a fixed order.
 // ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
-  extern __shared__ double red_lds[];  // [4][W]
+__device__ __forceinline__ void reduce_tiles_body(const ReduceArgs& a, const int b, double* red_lds /* [4][W] */) {
   __shared__ double llw[4];
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int N2 = 2 * a.N;
   const int W = a.g_width ? a.g_width : N2;  // doubles per (evaluation, tile)
   double llp = 0;
@@ -77,6 +77,11 @@ __global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
     out[q * a.N + node] =
         (red_lds[v] + red_lds[W + v]) + (red_lds[2 * W + v] + red_lds[3 * W + v]);
   }
+}
+
+__global__ __launch_bounds__(256) void reduce_tiles_kernel(ReduceArgs a) {
+  extern __shared__ double red_lds[];
+  reduce_tiles_body(a, blockIdx.x, red_lds);
 }
 
 // ------------------------------------------------------------------------
@@ -209,14 +214,13 @@ __device__ void ratio_transform(int n, const int32_t* c0, const int32_t* c1, con
   out[root - n] = sum;
 }
 
-__global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
+__device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t, double* fin_lds) {
   // One wave per tree: lanes run over nodes / tiles for the reductions, lane 0
   // walks the O(n) recurrences of the rooted chain rule.  Working set (6n doubles, for
   // rooted trees also the tree's heights, bounds, ratios, rates and the ratio gradient
   // being built: each access of those recurrences is on a dependent chain, and a global
   // load there costs ten LDS reads) in LDS unless the tree is too large.
-  extern __shared__ double fin_lds[];
-  const int t = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x;
   const int n = a.n, N = a.N, T = a.T;
   double* base = a.use_lds ? fin_lds : a.scratch + (size_t)t * 6 * n;
   int32_t* c0 = reinterpret_cast<int32_t*>(base);
@@ -415,6 +419,24 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
   }
 }
 
+__global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
+  extern __shared__ double fin_lds[];
+  finalize_body(a, blockIdx.x, fin_lds);
+}
+
+// Both in one launch, a workgroup per tree, for calls with ONE evaluation per tree (JC69-type
+// models, the analytic GTR gradient; rooted or not): the four waves sum the tiles, then wave 0
+// alone goes on to the finalize step with what the workgroup has just written (one dispatch
+// less on the latency path of small batches: ~4 us of a 125-tree step).
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(ReduceArgs ra, FinalizeArgs fa) {
+  extern __shared__ double rf_lds[];
+  reduce_tiles_body(ra, blockIdx.x, rf_lds);
+  __threadfence_block();
+  __syncthreads();
+  if (threadIdx.x >= 64) return;  // (ended waves do not take part in later barriers)
+  finalize_body(fa, blockIdx.x, rf_lds);
+}
+
 // ------------------------------------------------------------------------
 // Caller-side reductions of one variational-inference step, on the device
 // (vip/burrito.py:143-166: sum of the per-tree log-likelihoods; vip/branch_model.py:125-132:
@@ -483,6 +505,17 @@ void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
   const size_t W = a.g_width ? a.g_width : 2 * (size_t)a.N;
   hipLaunchKernelGGL(reduce_tiles_kernel, dim3(a.E), dim3(256), sizeof(double) * 4 * W, s, a);
+}
+static size_t finalize_lds_bytes(const FinalizeArgs& a) {
+  return sizeof(double) * (a.rooted ? 22 * (size_t)a.n : 6 * (size_t)a.n);
+}
+void launch_reduce_finalize(const ReduceArgs& ra, const FinalizeArgs& fa_in, hipStream_t s) {
+  FinalizeArgs fa = fa_in;
+  const size_t W = ra.g_width ? ra.g_width : 2 * (size_t)ra.N;
+  const size_t fin = finalize_lds_bytes(fa);
+  fa.use_lds = fin <= 48 * 1024;
+  const size_t lds = std::max(sizeof(double) * 4 * W, fa.use_lds ? fin : 0);
+  hipLaunchKernelGGL(reduce_finalize_kernel, dim3(fa.T), dim3(256), lds, s, ra, fa);
 }
 void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {
   FinalizeArgs a = a_in;

@@ -405,6 +405,10 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     ll_used.mid_hi = 17 * T;
   }
   fa.ll_used = ll_used;
+  static const bool fuse_allowed =
+      !(getenv("MI_PHYLO_FUSE_FINALIZE") && std::string(getenv("MI_PHYLO_FUSE_FINALIZE")) == "0");
+  bool fused = false;
+  ReduceArgs fused_ra{};
   if (reduce_tiles_fits(N)) {
     // sum the per-tile partials with one workgroup per evaluation first
     ReduceArgs ra{};
@@ -425,7 +429,11 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     ra.T = T;
     ra.macros = arena ? e->arena_macros.as<MacroEntry>() : e->macros.as<MacroEntry>();
     ra.macro_count = e->macro_count.as<int32_t>();
-    launch_reduce_tiles(ra, s);
+    // one evaluation per tree (JC69-type models, the analytic GTR gradient; log-likelihood
+    // calls too): tile reduction and finalize step in ONE launch, a workgroup per tree
+    fused = fuse_allowed && c.E == T;
+    if (!fused) launch_reduce_tiles(ra, s);
+    fused_ra = ra;
     fa.ll_tiles = 1;
     fa.ll_used = LlCounts{1, 1, 0, 0};
     fa.g_tiles = 1;
@@ -454,7 +462,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   fa.out_site = d.out_site;
   fa.out_subst = d.out_subst;
   fa.status = e->status.as<int32_t>();
-  launch_finalize(fa, s);
+  if (fused) launch_reduce_finalize(fused_ra, fa, s);
+  else launch_finalize(fa, s);
   if (analytic && d.out_subst) {
     SubstGradArgs sg{};
     sg.T = T;

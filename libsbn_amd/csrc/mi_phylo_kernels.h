@@ -246,6 +246,8 @@ void launch_vi_reduce(const ViReduceArgs& a, hipStream_t s);
 bool reduce_tiles_fits(int N);
 void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s);
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);
+// both in one launch (a workgroup per tree) for calls with one evaluation per tree
+void launch_reduce_finalize(const ReduceArgs& ra, const FinalizeArgs& fa, hipStream_t s);
 
 // ------------------------------------------------------------------------
 // 20-state path (kernels_aa.hip): partial-likelihood vectors streamed through HBM in

@@ -273,12 +273,22 @@ def roofline(kname, k_ms, units, flops_per_unit, bytes_per_unit, traffic=None,
 
 def traffic_entry(name):
     """profiles/traffic.json: HBM-side bytes per launch of a kernel from the PMC passes
-    ((2 FETCH_SIZE + WRITE_SIZE) x 1024, separate rocprofv3 --pmc runs) -- not this run."""
+    ((2 FETCH_SIZE + WRITE_SIZE) x 1024, separate rocprofv3 --pmc runs) -- not this run.
+    Keys are kernel names as rocprofv3 prints them (template arguments included), with
+    "|T=<trees per launch>" appended for the 20-state kernels; `name` matches a key exactly or
+    as its beginning (the latest round's entry first)."""
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     try:
-        return json.load(open(tpath)).get(name)
+        table = json.load(open(tpath))
     except (OSError, ValueError):
         return None
+    if name in table:
+        return table[name]
+    base, _, suffix = name.partition("|")
+    hits = [k for k in table if k.startswith(base) and k.endswith("|" + suffix if suffix else "")
+            and ("|" in k) == bool(suffix)]
+    hits.sort(key=lambda k: table[k].get("round", ""), reverse=True)
+    return table[hits[0]] if hits else None
 
 
 def streamed_roofline(kname, k_ms, evals, traffic_key, mfma_flops_per_eval, model_bytes_per_eval):
@@ -604,8 +614,7 @@ def also_workloads(torch, dev, L, steps):
             post = streamed_roofline(
                 "aa_post_wg_kernel<2," + ("true" if grad else "false") + "> (+ aa_root_kernel)",
                 phase_ms[1], first,
-                "aa_post_wg_kernel<2,true> (gradient)" if grad
-                else "aa_post_wg_kernel<2,false> (log_likelihoods)",
+                "aa_post_wg_kernel<2, true>" if grad else "aa_post_wg_kernel<2, false>",
                 (n - 2) * prod, (2 * (n - 1)) * plv + 4 * n * P)
             entry = {"workload": f"S-WAG 20 states, {n} taxa x {P} patterns x {K} categories "
                                  f"x {Tw} tree(s), " + ("phylo_gradients" if grad else
@@ -716,8 +725,7 @@ def swag_pattern_sharded(args, torch, dist, L, sharding, dev, rank, world, distr
     post = streamed_roofline(
         "aa_post_wg_kernel<2," + ("true" if grad else "false") + "> (+ aa_root_kernel)",
         phase_ms[1], first,
-        "aa_post_wg_kernel<2,true> (gradient)" if grad
-        else "aa_post_wg_kernel<2,false> (log_likelihoods)",
+        "aa_post_wg_kernel<2, true>" if grad else "aa_post_wg_kernel<2, false>",
         (n - 2) * prod, ((2 * (n - 1)) * plv + 4 * n * P) * share)
     rl = post
     if grad:

@@ -14,6 +14,15 @@ namespace miphylo {
 namespace {
 using namespace dev;
 
+// v[lane] += v[lane rotated right by SHIFT within its 16-lane row]
+template <int SHIFT>
+__device__ __forceinline__ double ll_row_ror_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int slo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + SHIFT, 0xf, 0xf, true);
+  const int shi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + SHIFT, 0xf, 0xf, true);
+  return v + __hiloint2double(shi, slo);
+}
+
 // ------------------------------------------------------------------------
 // On-chip log-likelihood (B5, B6, B11 of SURVEY.md 2.1).
 // One wave per (evaluation, 64-pattern tile); rate categories are walked one
@@ -383,10 +392,16 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
         if (Kp >= 4) ev = max(ev, __shfl_xor(ev, 8, 64));
         v = ldexp(v, esum[r] - ev);
       }
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (Kp >= 2) v += __shfl_xor(v, 4, 64);
-      if (Kp >= 4) v += __shfl_xor(v, 8, 64);
+      // states: one product with a ones matrix leaves the column sums in every row;
+      // categories (four lanes apart in a row): two row rotations -- no LDS round trips
+      // (round 3; the ds_bpermute butterfly was a chain of four per register)
+      v = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, v, 0.0, 0, 0, 0);
+      if (Kp == 4) {
+        v = ll_row_ror_add<8>(v);
+        v = ll_row_ror_add<4>(v);
+      } else if (Kp == 2) {
+        v += __shfl_xor(v, 4, 64);
+      }
       if (!RESCALE) {
         site[r] += v;
       } else if (g == 0) {
@@ -426,7 +441,11 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
       ll += wv * (RESCALE ? log(sv) + ev * 0.69314718055994530942 : log(sv));
     }
   }
-  ll = wave_sum(ll);
+  ll = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, ll, 0.0, 0, 0, 0);  // the four rows
+  ll = ll_row_ror_add<8>(ll);
+  ll = ll_row_ror_add<4>(ll);
+  ll = ll_row_ror_add<2>(ll);
+  ll = ll_row_ror_add<1>(ll);
   if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
 }
 

@@ -13,7 +13,7 @@ bad = 0; total = 0
 for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
     n = int(rng.choice([3, 4, 5, 6, 7, 9, 12, 17, 26, 27, 28, 29, 30, 31, 32, 33, 45, 64, 80, 100, 130, 257]))
     P = int(rng.choice([1, 2, 3, 11, 12, 13, 16, 47, 48, 49, 64, 100, 257]))
-    K = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 11, 16]))
+    K = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 11, 16, 23, 64]))
     subst = str(rng.choice(["JC69", "GTR"]))
     site = "constant" if K == 1 else f"weibull+{K}"
     resc = bool(rng.integers(0, 2))

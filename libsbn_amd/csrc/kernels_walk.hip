@@ -38,6 +38,11 @@
 
 namespace miphylo {
 
+#ifdef MI_WALK_TIMELINE
+// diagnostic build (make timeline; tools/walk_timeline.py): eight words per wave
+__device__ long long g_walk_timeline[65536 * 8];
+#endif
+
 namespace {
 using namespace dev;
 
@@ -78,6 +83,11 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
 #ifdef MI_WALK_STAMPS
   const long long st0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef MI_WALK_TIMELINE
+  const long long tl0 = __builtin_amdgcn_s_memtime();
+  const long long rt0 = __builtin_amdgcn_s_memrealtime();
+  long long tl1 = 0, tl2 = 0;
 #endif
   const TileEval te = xcd_tile_eval();
   const int e = a.eval_offset + te.eval;
@@ -248,6 +258,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   }
   __syncthreads();
   if (M <= 0) return;
+#ifdef MI_WALK_TIMELINE
+  tl1 = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef MI_WALK_STAMPS
   const long long st1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -532,6 +545,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
 #endif
   }
 
+#ifdef MI_WALK_TIMELINE
+  tl2 = __builtin_amdgcn_s_memtime();
+#endif
   // ================= pre-order + edge derivatives =================
   const double coef_a = lo == 0 ? rate_l : (lo == 1 ? drate_l : 0.0);
   const double coef_b = lo == 2 ? rate_l : (lo == 3 ? drate_l : 0.0);
@@ -709,6 +725,19 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     gout[gwidth - kSubstExtra + lane] = Ht;
     if (lane < 4) gout[gwidth - 4 + lane] = xroot[lane];
   }
+#ifdef MI_WALK_TIMELINE
+  {
+    const long long tl3 = __builtin_amdgcn_s_memtime();
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned id = blockIdx.x + gridDim.x * blockIdx.y;
+    if (lane == 0 && id < 65536u) {
+      long long* o = g_walk_timeline + 8 * id;
+      o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3; o[4] = hwid; o[5] = xcc; o[6] = rt0; o[7] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------
@@ -895,3 +924,9 @@ int gradient_walk_waves_per_cu(int n, int K) {
 const char* gradient_walk_kernel_name() { return "gradient_walk_kernel"; }
 
 }  // namespace miphylo
+
+#ifdef MI_WALK_TIMELINE
+extern "C" __attribute__((visibility("default"))) int mi_debug_walk_timeline(long long* out, int waves) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(miphylo::g_walk_timeline), (size_t)waves * 64);
+}
+#endif

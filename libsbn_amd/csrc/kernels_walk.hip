@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <string>
 #include <type_traits>
@@ -89,17 +90,35 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   const long long rt0 = __builtin_amdgcn_s_memrealtime();
   long long tl1 = 0, tl2 = 0;
 #endif
-  const TileEval te = xcd_tile_eval();
-  const int e = a.eval_offset + te.eval;
-  const int gi = a.grad_offset + te.eval;
+  // This wave's jobs: pattern tiles first, first + step, ... of ONE evaluation.  The launch's
+  // first walk_big_evals evaluations are walked by walk_groups waves each, every wave taking
+  // several tiles one after the other -- everything that belongs to the tree stays, the next
+  // tile's tip bytes are requested a whole walk ahead, and no wave slot stands empty between
+  // two of its jobs; the evaluations after them get a wave per tile: the small jobs come last
+  // (workgroups start in id order) and fill the end of the launch.
+  int job_eval, job_first, job_step;
+  {
+    const int id = blockIdx.x, G = a.walk_groups, nb = a.walk_big_evals * G;
+    if (id < nb) {
+      const TileEval te = xcd_map(id, G, a.walk_big_evals);
+      job_eval = te.eval;
+      job_first = te.tile;
+      job_step = G;
+    } else {
+      const TileEval te = xcd_map(id - nb, a.g_tiles, a.walk_evals - a.walk_big_evals);
+      job_eval = a.walk_big_evals + te.eval;
+      job_first = te.tile;
+      job_step = a.g_tiles;  // (one job)
+    }
+  }
+  const int e = a.eval_offset + job_eval;
+  const int gi = a.grad_offset + job_eval;
   int t, mi;
   a.map.decode(e, t, mi);
   const DevModel* __restrict__ model = a.models + mi;
   const int K = a.K, n = a.n, Kp = a.kp;
-  const int groups = a.cat_groups, tiles_per_group = gridDim.x / groups;
-  const int group = te.tile / tiles_per_group, ptile = te.tile - group * tiles_per_group;
-  const int cat = 4 * group + b % Kp, pgrp = b / Kp, ppr = 16 / Kp;
-  const int catc = cat < K ? cat : K - 1;
+  const int gtiles = a.g_tiles;  // pattern tiles x category groups
+  const int groups = a.cat_groups, tiles_per_group = gtiles / groups;
   const int Mmax = max_macros(n);
   const MacroEntry* __restrict__ macros = a.macros + (size_t)t * Mmax;
   const cint_ptr mw = as_const(reinterpret_cast<const int*>(macros));  // scalar loads
@@ -120,6 +139,32 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     const int need = __builtin_amdgcn_readfirstlane(a.slot_need[t]);
     if (need <= a.lds_lo || need > a.lds_slots) return;
   }
+  if (M <= 0) return;
+  const int ppr = 16 / Kp, TP = ppr * R;
+  // four categories, twelve whole columns: the 12 tip bytes of a (macro, position) pair come
+  // as three (unaligned) words; those of a wave's NEXT tile are requested when a tile starts
+  struct __attribute__((packed)) Bytes12 {
+    uint32_t d0, d1, d2;
+  };
+  auto tile_first_pattern = [&](int tile) { return (tile % tiles_per_group) * TP; };
+  auto whole_words = [&](int tile) { return R == 3 && Kp == 4 && tile_first_pattern(tile) + 12 <= a.P; };
+  auto request_bytes = [&](int tile, Bytes12 (&w)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int j = lane + 64 * u, node = node_j[u];
+      if (j < jmax && (unsigned)node < (unsigned)n)
+        w[u] = *reinterpret_cast<const Bytes12*>(a.tip_masks + (size_t)node * a.P + tile_first_pattern(tile));
+    }
+  };
+  Bytes12 bytes_next[2] = {};
+  bool have_next = whole_words(job_first);
+  if (have_next) request_bytes(job_first, bytes_next);
+
+  // (a wave that takes several tiles stays in ONE category group: the launcher gives every
+  // tile its own wave when there are several groups)
+  const int group = job_first / tiles_per_group;
+  const int cat = 4 * group + b % Kp, pgrp = b / Kp;
+  const int catc = cat < K ? cat : K - 1;
   // macro-ordered matrices of this gradient evaluation and category group: a position is
   // four categories x 16 {f, tr} pairs = 1 KB whatever K is (unused categories are never
   // read: a lane beyond K reads category K - 1, with weight zero), a visit 6 KB
@@ -131,16 +176,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   const char* __restrict__ ph_g =
       SUBST ? reinterpret_cast<const char*>(a.mphi) + ((size_t)gi * Mmax * groups + group) * (kVisitBytes / 2)
             : nullptr;
-  const int TP = ppr * R, tile_start = ptile * TP;
   const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
-  int pat[R], patc[R];
-  double pw[R];
-#pragma unroll
-  for (int r = 0; r < R; r++) {
-    pat[r] = tile_start + r * ppr + col;
-    patc[r] = pat[r] < a.P ? pat[r] : a.P - 1;
-    pw[r] = pat[r] < a.P ? a.weights[patc[r]] : 0.0;
-  }
   const double pi_l = model->pi[hi];
   const double cw_l = cat < K ? model->cat_weight[cat] : 0.0;
   const double rate_l = model->cat_rate[catc], drate_l = model->cat_drate[catc];
@@ -207,8 +243,25 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   char* const plv = lds0 + tips_bytes;
   int16_t* exps = reinterpret_cast<int16_t*>(
       plv + (size_t)(ARENA ? a.lds_slots : max_stored(n)) * R * kTile * 8);
+  // the first visit's scalars and matrices are on their way while the tip words are staged
+  // (a round trip to L2 less on the prologue's chain; M <= 0: macro 0 is inside the allocation)
+  const int M1 = M - 1;  // the root's macro is the last one; visits 0 .. M1 - 1 are stored nodes
+  const int sh_first = load_shape(0), sh_second = load_shape(max(min(1, M1), 0));
+  const Slots sl_first = load_slots(0);
+  const Mats mt_first = fetch(0, false);
+
+  for (int tile = job_first; tile < gtiles; tile += job_step) {
+  const int tile_start = tile_first_pattern(tile);
+  int pat[R], patc[R];
+  double pw[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    pat[r] = tile_start + r * ppr + col;
+    patc[r] = pat[r] < a.P ? pat[r] : a.P - 1;
+    pw[r] = pat[r] < a.P ? a.weights[patc[r]] : 0.0;
+  }
   char* const arena =
-      ARENA ? reinterpret_cast<char*>(a.plv + ((size_t)te.eval * gridDim.x + te.tile) *
+      ARENA ? reinterpret_cast<char*>(a.plv + ((size_t)job_eval * gtiles + tile) *
                                                    max_stored(n) * R * kTile)
             : nullptr;
   {
@@ -224,17 +277,20 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
         dst[(q & (ppr - 1)) * kTwCol + (q >> ppr_shift)] = (char)src[pp];
       }
     };
-    if (R == 3 && Kp == 4 && tile_start + 12 <= a.P) {
-      // four categories, twelve whole columns: the 12 bytes of a (macro, position) pair as
-      // three (unaligned) words, regrouped into the four columns' words
-      struct __attribute__((packed)) Bytes12 {
-        uint32_t d0, d1, d2;
-      };
+    const bool whole = have_next;  // (requested for this tile when the previous one started)
+    Bytes12 bytes_now[2] = {bytes_next[0], bytes_next[1]};
+    {
+      const int next_tile = tile + job_step;
+      have_next = next_tile < gtiles && whole_words(next_tile);
+      if (have_next) request_bytes(next_tile, bytes_next);
+    }
+    if (whole) {
+      // regrouped into the four columns' words
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int j = lane + 64 * u, node = node_j[u];
         if (j < jmax && (unsigned)node < (unsigned)n) {
-          const Bytes12 w = *reinterpret_cast<const Bytes12*>(a.tip_masks + (size_t)node * a.P + tile_start);
+          const Bytes12 w = bytes_now[u];
           const int m = j / 6, pos = j - m * 6;
           char* dst = lds0 + (unsigned)m * tstride + (unsigned)pos * 4u;
 #pragma unroll
@@ -257,7 +313,6 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     }
   }
   __syncthreads();
-  if (M <= 0) return;
 #ifdef MI_WALK_TIMELINE
   tl1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -430,7 +485,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
       for (int r = 0; r < R; r++) {
         double v;
         if (groups > 1) {
-          const size_t at = ((size_t)a.grad_offset + te.eval) * a.tiles * kTile + patc[r];
+          const size_t at = ((size_t)a.grad_offset + job_eval) * a.tiles * kTile + patc[r];
           v = a.site_lik[at];
           if (RESCALE) v = ldexp(v, a.site_exp[at] - esum[r]);
         } else {
@@ -472,7 +527,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
       ll = row_ror_add<4>(ll);
       ll = row_ror_add<2>(ll);
       ll = row_ror_add<1>(ll);
-      if (lane == 0 && groups == 1) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
+      if (lane == 0 && groups == 1) a.ll_part[(size_t)e * a.ll_tiles + tile] = ll;
       if (SUBST) {
         double z = 0;
 #pragma unroll
@@ -490,14 +545,13 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   };
   using Inner = std::false_type;
   using Root = std::true_type;
-  const int M1 = M - 1;  // the root's macro is the last one; visits 0 .. M1 - 1 are stored nodes
   {
     // Two visits per iteration, two register sets (A, B), nothing copied.  At the top of
     // visit m: shape, slots, matrices and tip words of m are there and the matrices of m + 1
     // are requested.
-    int sha = load_shape(0), shb = load_shape(min(1, M1));
-    Slots sa = load_slots(0), sb;
-    Mats ma = fetch(0, false), mb;
+    int sha = sh_first, shb = sh_second;
+    Slots sa = sl_first, sb;
+    Mats ma = mt_first, mb;
     Tw ta = fetch_tw(0), tb;
     for (int m = 0; m < M1; m += 2) {
       mb = fetch(m + 1, false);
@@ -539,9 +593,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     post_visit(Root{}, sha, sa, ma, ta, [&](int) {});
 #ifdef MI_WALK_STAMPS
     const long long st2 = __builtin_amdgcn_s_memtime();
-    if (lane == 0 && (te.eval % 250) == 3 && (te.tile % 39) == 5)
+    if (lane == 0 && (job_eval % 250) == 3 && (tile % 39) == 5)
       printf("walk stamps eval %d tile %d: prologue %lld, post-order (inner) %lld, root %lld (s_memtime ticks, 100 MHz)\n",
-             te.eval, te.tile, st1 - st0, st2r - st1, st2 - st2r);
+             job_eval, tile, st1 - st0, st2r - st1, st2 - st2r);
 #endif
   }
 
@@ -716,7 +770,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   __syncthreads();
   // positions that do not exist in a macro are never written nor read downstream
   const int gwidth = Mmax * kMacroPositions * 2 + (SUBST ? kSubstExtra : 0);
-  double* gout = a.g_part + ((size_t)gi * a.g_tiles + te.tile) * gwidth;
+  double* gout = a.g_part + ((size_t)gi * a.g_tiles + tile) * gwidth;
   for (int i = lane; i < M * kMacroPositions * 2; i += kTile) {
     const int m = i / (kMacroPositions * 2), r = i - m * (kMacroPositions * 2);
     gout[i] = *reinterpret_cast<const double*>(lds0 + (unsigned)m * tstride + (unsigned)r * 8u);
@@ -725,13 +779,18 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     gout[gwidth - kSubstExtra + lane] = Ht;
     if (lane < 4) gout[gwidth - 4 + lane] = xroot[lane];
   }
+  // (one tile per wave in the arena and analytic-substitution variants, which have no
+  // registers to spare for what would have to live from tile to tile: no back edge for them)
+  if (ARENA || SUBST) break;
+  __syncthreads();  // (the next tile's tip words go where these sums were read from)
+  }  // tiles of this wave
 #ifdef MI_WALK_TIMELINE
   {
     const long long tl3 = __builtin_amdgcn_s_memtime();
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const unsigned id = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned id = blockIdx.x;
     if (lane == 0 && id < 65536u) {
       long long* o = g_walk_timeline + 8 * id;
       o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3; o[4] = hwid; o[5] = xcc; o[6] = rt0; o[7] = __builtin_amdgcn_s_memrealtime();
@@ -878,8 +937,48 @@ void launch_gradient_walk(const LikArgs& a_in, int count, bool rescale, bool sub
   LikArgs a = a_in;
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
   a.cat_groups = gradient_mfma_groups(a.K);
-  const dim3 grid(gradient_mfma_tiles(a.P, a.K) * a.cat_groups, count);
-  if (gradient_walk_use_arena(a.n, a.K, rescale, subst)) {
+  // Jobs.  The launch's first `big` evaluations (a multiple of 8: whole XCD groups) are
+  // walked by waves that take `tpw` pattern tiles each, one after the other (what belongs to
+  // the tree stays in registers, the next tile's tip bytes arrive during the current walk, no
+  // wave slot stands empty in between: -6 % per 1000 DS1 trees); the evaluations after them
+  // get a wave per tile.  Workgroups start in id order, so the small jobs come last and level
+  // out the end of the launch: the slots finish their big jobs up to one big job apart, which
+  // takes about (tpw / 2 + 1) rounds of small jobs to fill.  tpw maximises the share of the
+  // work that runs as the second or later tile of a wave.  (A wave stays in one category
+  // group; the arena and analytic variants take one tile per wave: kernel comment.)
+  // MI_PHYLO_WALK_TILES_PER_WAVE=k forces k (1: every tile its own wave, as until round 3).
+  static const int forced_tpw = [] {
+    const char* env = getenv("MI_PHYLO_WALK_TILES_PER_WAVE");
+    return env ? std::max(1, atoi(env)) : 0;
+  }();
+  const int gtiles = gradient_mfma_tiles(a.P, a.K) * a.cat_groups;
+  const bool arena_variant = gradient_walk_use_arena(a.n, a.K, rescale, subst);
+  int tpw = 1, big = 0;
+  if (a.cat_groups == 1 && !arena_variant && !subst) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const double slots = (double)cus * gradient_walk_waves_per_cu(a.n, a.K);
+    double best = 0;
+    for (int k = forced_tpw ? forced_tpw : 2; k <= (forced_tpw ? forced_tpw : 8); k++) {
+      // (measured, 1000 and 125 DS1 trees: fewer small jobs -- k / 4 + 1, k / 8 + 1/2 rounds --
+      // lose more at the end of the launch than the larger share of big jobs gains)
+      const int small = (int)std::ceil((0.5 * k + 1.0) * slots / gtiles);
+      const int b = small < count ? (count - small) & ~7 : 0;
+      const double gain = (double)b / count * (1.0 - 1.0 / k);
+      if (gain > best) {
+        best = gain;
+        tpw = k;
+        big = b;
+      }
+    }
+  }
+  a.walk_evals = count;
+  a.walk_groups = (gtiles + tpw - 1) / tpw;
+  a.walk_big_evals = big;
+  const dim3 grid((unsigned)((size_t)a.walk_big_evals * a.walk_groups +
+                             (size_t)(count - a.walk_big_evals) * gtiles));
+  if (arena_variant) {
     const int usual = gradient_arena_slots_usual(a.n), sure = gradient_arena_slots_sure(a.n);
     a.lds_lo = -1;
     a.lds_slots = usual;

@@ -119,9 +119,9 @@ __device__ __forceinline__ double max4(D4 a) {
 struct TileEval {
   int tile, eval;
 };
-__device__ __forceinline__ TileEval xcd_tile_eval() {
-  const int tiles = gridDim.x, count = gridDim.y;
-  const int id = blockIdx.x + tiles * blockIdx.y;
+// (id: linear workgroup id, a multiple of 8 apart from the XCD it runs on; tiles x count
+// workgroups)
+__device__ __forceinline__ TileEval xcd_map(int id, int tiles, int count) {
   const int full = count & ~7;  // evaluations in complete groups of 8
   TileEval te;
   if (id < full * tiles) {
@@ -129,10 +129,13 @@ __device__ __forceinline__ TileEval xcd_tile_eval() {
     te.eval = (s / tiles) * 8 + (id & 7);
     te.tile = s % tiles;
   } else {
-    te.eval = blockIdx.y;
-    te.tile = blockIdx.x;
+    te.eval = id / tiles;
+    te.tile = id - te.eval * tiles;
   }
   return te;
+}
+__device__ __forceinline__ TileEval xcd_tile_eval() {
+  return xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y);
 }
 
 // Divided difference of exp(lambda tau) for the analytic substitution gradient:

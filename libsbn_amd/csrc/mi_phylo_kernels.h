@@ -88,6 +88,10 @@ struct TransitionMacroArgs {
 struct LikArgs {
   int n, N, P, K, tiles;
   int lds_slots;    // PLV slots in LDS (set by the launcher)
+  // second-generation gradient walk (set by its launcher): the launch's evaluations, how many
+  // of them (the first ones) are walked by `walk_groups` waves that take several pattern
+  // tiles each (tile g, g + walk_groups, ...); the others get a wave per tile
+  int walk_evals, walk_big_evals, walk_groups;
   int kp;           // MFMA path: categories per instruction (1, 2 or 4; set by the launcher)
   int cat_groups;   // matrix-core gradient: groups of four categories (K > 4; set by the launcher)
   int ll_tiles;     // stride of ll_part per evaluation (>= partial sums any kernel writes)

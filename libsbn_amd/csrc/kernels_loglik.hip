@@ -193,11 +193,14 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
+  // A wave walks `evals_per_wave` consecutive evaluations of ONE tree (the finite-difference
+  // models of a GTR gradient call: same tree, same tips, other matrices) for its tile: tip
+  // masks and schedule are staged once for all of them.  grid.y counts the groups.
   const TileEval te = xcd_tile_eval();
-  const int e = a.eval_offset + te.eval;
-  int t, mi;
-  a.map.decode(e, t, mi);
-  const DevModel* __restrict__ model = a.models + mi;
+  const int epw = a.evals_per_wave;
+  const int e0 = a.eval_offset + te.eval * epw;
+  int t, mi0;
+  a.map.decode(e0, t, mi0);
   const SchedEntry* __restrict__ sched = a.sched + (size_t)t * (a.n - 1);
   const int K = a.K, n = a.n, Kp = a.kp;       // Kp in {1, 2, 4}: categories per instruction
   const int cat = b % Kp, pgrp = b / Kp, ppr = 16 / Kp;  // ppr = patterns per register
@@ -205,8 +208,7 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
   // meet in the per-pattern site likelihood); the per-group lane constants follow
   // (MULTI: a compile-time 1 keeps the site-likelihood accumulators out of the walk's registers)
   const int groups = MULTI ? (K + 3) / 4 : 1;
-  const char* __restrict__ mats_e =
-      reinterpret_cast<const char*>(a.mats + (size_t)e * (a.N - 1) * K * 16);
+  const char* __restrict__ mats_e = nullptr;  // this evaluation's matrices (set per evaluation)
   unsigned a_off = 0;  // per-lane element of a child's matrix block: A_b[i = lo][k = hi] (bytes)
   double wgt = 0.0;    // category weight x stationary frequency of this lane
   const unsigned node_bytes = (unsigned)K * 128u;
@@ -359,12 +361,19 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
       for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
     }
   };
+  for (int ev = 0; ev < epw; ev++) {
+  const int e = e0 + ev;
+  int t_ev, mi;
+  a.map.decode(e, t_ev, mi);
+  const DevModel* __restrict__ model = a.models + mi;
+  mats_e = reinterpret_cast<const char*>(a.mats + (size_t)e * (a.N - 1) * K * 16);
   double site[R];
   int site_exp[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
     site[r] = 0.0;
     site_exp[r] = 0;
+    L[r] = 0.0;
   }
   for (int g = 0; g < groups; g++) {
     const int cat_g = 4 * g + cat;
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
       if (a.site_lik) {
         // per-pattern site likelihood for a following gradient pass (rescaled: the
         // mantissa here, the power of two in site_exp)
-        const size_t at = ((size_t)a.grad_offset + te.eval) * a.tiles * kTile + pv;
+        const size_t at = ((size_t)a.grad_offset + (e - a.eval_offset)) * a.tiles * kTile + pv;
         a.site_lik[at] = sv;
         if (RESCALE) a.site_exp[at] = ev;
       }
@@ -447,6 +456,7 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
   ll = ll_row_ror_add<2>(ll);
   ll = ll_row_ror_add<1>(ll);
   if (lane == 0) a.ll_part[(size_t)e * a.ll_tiles + te.tile] = ll;
+  }  // evaluations of this wave
 }
 
 }  // namespace
@@ -501,7 +511,20 @@ static void launch_loglik_mfma(const LikArgs& a_in, int count, bool rescale, int
   LikArgs a = a_in;
   a.lds_slots = loglik_mfma_slots(max_slots);
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
-  const dim3 grid(loglik_mfma_tiles(a.P, a.K), count), block(kTile);
+  // Evaluations per wave: the 16 finite-difference evaluations of a tree ([T, 17 T) of a GTR
+  // gradient call, tree-major) share tips and schedule -- a wave takes as many of them in a
+  // row as still leaves the device several rounds of waves (MI_PHYLO_LOGLIK_EVALS_PER_WAVE
+  // forces 1, 2, 4 or 8; 16 measured the same as 8)
+  const int tiles = loglik_mfma_tiles(a.P, a.K);
+  int epw = 1;
+  if (a.eval_offset >= a.map.T && a.eval_offset + count <= 17 * a.map.T &&
+      (a.eval_offset - a.map.T) % 16 == 0 && count % 16 == 0) {
+    static const int forced = getenv("MI_PHYLO_LOGLIK_EVALS_PER_WAVE") ? atoi(getenv("MI_PHYLO_LOGLIK_EVALS_PER_WAVE")) : 0;
+    for (epw = 8; epw > 1; epw >>= 1)
+      if (forced ? epw <= forced : (long)(count / epw) * tiles >= 3L * 256 * 16) break;
+  }
+  a.evals_per_wave = epw;
+  const dim3 grid(tiles, count / epw), block(kTile);
   const size_t lds = loglik_mfma_lds_bytes(a.n, a.K, max_slots);
   auto go = [&](auto kernel) {
     allow_large_lds(reinterpret_cast<const void*>(kernel), lds);

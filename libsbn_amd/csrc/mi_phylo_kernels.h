@@ -92,6 +92,7 @@ struct LikArgs {
   // of them (the first ones) are walked by `walk_groups` waves that take several pattern
   // tiles each (tile g, g + walk_groups, ...); the others get a wave per tile
   int walk_evals, walk_big_evals, walk_groups;
+  int evals_per_wave;  // loglik_mfma_kernel: consecutive evaluations of one tree per wave (launcher)
   int kp;           // MFMA path: categories per instruction (1, 2 or 4; set by the launcher)
   int cat_groups;   // matrix-core gradient: groups of four categories (K > 4; set by the launcher)
   int ll_tiles;     // stride of ll_part per evaluation (>= partial sums any kernel writes)

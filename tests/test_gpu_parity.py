@@ -982,6 +982,61 @@ np.save(sys.argv[1], np.concatenate(out))
                 store, subst_mode, np.max(np.abs(a - b)))
 
 
+def test_waves_taking_several_tiles_are_bit_identical_and_match_oracle():
+    """gradient_walk_kernel gives the first evaluations of a large launch to waves that take
+    several pattern tiles in turn and the last ones a wave per tile.  The
+    arithmetic of a tile does not depend on who walks it: results with 2, 3 and 8 tiles per
+    wave are bit-identical to a wave per tile (MI_PHYLO_WALK_TILES_PER_WAVE, read once per
+    process), with and without rescaling, with a partial last tile (130 patterns = 10 tiles of
+    12 + 10) -- and trees of both sections agree with the oracle."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r"""
+import sys, os, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import oracle_lib as O, libsbn_amd as L, tree_utils as TU
+import test_gpu_parity as TG
+rng = np.random.default_rng(314)
+n, P, T = 12, 130, 900
+tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.05)
+pids, bls = TU.random_trees(n, T, rng, mean_bl=0.08)
+eng = L.Engine(L.PhyloModelSpecification('JC69', 'weibull+4', 'strict'), tips, w)
+spec = O.make_spec(n, P, 'JC69', 'weibull+4', 'strict')
+pr = TG._params(spec, T, **{'Weibull shape': rng.uniform(0.4, 1.5, size=(T, 1))})
+out = []
+for resc in (False, True):
+    g = eng.gradients(pids, bls, pr, resc)
+    assert eng.last_call_info()[0] == 'gradient_walk_kernel'
+    ll = np.array([x.log_likelihood for x in g])
+    bg = np.stack([x.gradient['branch_lengths'] for x in g])
+    sg = np.array([np.atleast_1d(x.gradient['site_model'])[0] for x in g])
+    out += [ll, bg.ravel(), sg]
+    if not resc:
+        sel = np.r_[0:4, T - 4:T]
+        og = O.unrooted_gradients(spec, tips, w, pids[sel], bls[sel], pr[sel], False, 8)
+        assert np.allclose(ll[sel], og['log_likelihood'], rtol=1e-10, atol=0)
+        assert np.allclose(bg[sel], og['branch_lengths'], rtol=1e-10, atol=1e-10 * np.abs(og['branch_lengths']).max())
+        assert np.allclose(sg[sel], og['site_model'], rtol=1e-9, atol=0)
+np.save(sys.argv[1], np.concatenate(out))
+"""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tpw in ("1", "2", "3", "8"):
+            env = dict(os.environ, MI_PHYLO_WALK_TILES_PER_WAVE=tpw)
+            for k in ("MI_PHYLO_GRADIENT_WALK", "MI_PHYLO_GRADIENT_STORE", "MI_PHYLO_SUBST_GRADIENT"):
+                env.pop(k, None)
+            path = os.path.join(tmp, f"{tpw}.npy")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, cwd=repo,
+                               capture_output=True, text=True)
+            assert r.returncode == 0, (tpw, r.stdout + r.stderr)
+            got[tpw] = np.load(path)
+    assert np.isfinite(got["1"]).all()
+    for tpw in ("2", "3", "8"):
+        assert np.array_equal(got["1"], got[tpw]), (tpw, np.max(np.abs(got["1"] - got[tpw])))
+
+
 def test_limits_are_refused_at_the_c_abi_with_a_message():
     """The limits that are the engine's, not the reference's, are refused at engine creation
     through the C ABI with a message -- never silently: more than 64 rate categories, fewer

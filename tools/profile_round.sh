@@ -18,7 +18,7 @@ stats() {  # name, command...
   rm -rf $O/$name
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -- "$@" > $O/$name.log 2>&1
   find $O/$name -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $S/${tag}_${name}_kernel_stats.csv
-  grep -h '^{\|^T ' $O/$name.log | tail -1 | cut -c1-600 > $S/${tag}_${name}_result.txt
+  grep -h '^{\|^T \|^GTR' $O/$name.log | tail -1 | cut -c1-600 > $S/${tag}_${name}_result.txt
 }
 pmc() {  # name, counter, command...
   local name=$1 counter=$2; shift 2
@@ -45,7 +45,7 @@ for T in 1 8; do
   pmc aa_T${T}_pmc_write WRITE_SIZE python3 tools/bench_aa.py --trees $T --steps 2
 done
 
-bash tools/sq_counters.sh $S/${tag}_sq_counters_gradient_walk.txt > /dev/null 2>&1
+SQ_JOBS=78000 bash tools/sq_counters.sh $S/${tag}_sq_counters_gradient_walk.txt > /dev/null 2>&1
 
 # SQ counters of the 20-state walk kernels (one tree and eight trees per launch)
 for T in 1 8; do

@@ -21,16 +21,20 @@ for i in (1, 2, 3):
     for f in glob.glob("gpurun_out/sq_pass%d/**/*counter_collection.csv" % i, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if any(s in k for s in ("gradient_walk", "gradient_mfma", "loglik_mfma")) and int(r["Grid_Size"]) > 64 * 70 * 500:
+            if any(s in k for s in ("gradient_walk", "gradient_mfma", "loglik_mfma")) and int(r["Grid_Size"]) > 64 * 4000:
                 agg[k[:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(sys.argv[1], "w") as fh:
     for k, v in agg.items():
         d = {c: sum(x) / len(x) for c, x in v.items()}
-        w = d["SQ_WAVES"]
-        lines = [k] + ["   %-26s %16.0f  per wave %12.1f" % (c, x, x / w) for c, x in sorted(d.items())]
+        # SQ_JOBS: (evaluation, tile) jobs of the launch -- since round 3 a wave of the gradient
+        # walk takes several tiles, so "per wave" is no longer "per tile"; default: per wave
+        import os
+        w = float(os.environ.get("SQ_JOBS", 0)) or d["SQ_WAVES"]
+        unit = "per tile job" if os.environ.get("SQ_JOBS") else "per wave"
+        lines = [k] + ["   %-26s %16.0f  %s %12.1f" % (c, x, unit, x / w) for c, x in sorted(d.items())]
         if "SQ_INSTS_VALU" in d and "SQ_INSTS_MFMA" in d:
-            lines.append("   non-MFMA VALU per wave: %.1f; SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (
-                (d["SQ_INSTS_VALU"] - d["SQ_INSTS_MFMA"]) / w, d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"]))
+            lines.append("   non-MFMA VALU %s: %.1f; SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (
+                unit, (d["SQ_INSTS_VALU"] - d["SQ_INSTS_MFMA"]) / w, d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"]))
         print("\n".join(lines))
         fh.write("\n".join(lines) + "\n")
 PY

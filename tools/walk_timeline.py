@@ -29,10 +29,11 @@ for _ in range(8):
     eng.gradients_device(stream, T, d_pid.data_ptr(), d_bl.data_ptr(), d_par.data_ptr(), blk.log_likelihoods.data_ptr(), blk.branch_gradients.data_ptr(), blk.extras[0].data_ptr(), None)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(os.environ["MI_PHYLO_LIBRARY"])
-waves = min(65536, T * 78)
-buf = np.zeros((waves, 8), dtype=np.int64)
-rc = lib.mi_debug_walk_timeline(buf.ctypes.data_as(ctypes.c_void_p), waves)
+buf = np.zeros((65536, 8), dtype=np.int64)
+rc = lib.mi_debug_walk_timeline(buf.ctypes.data_as(ctypes.c_void_p), 65536)
 assert rc == 0, rc
+buf = buf[buf[:, 6] != 0]  # the waves of the launch (the first 65 536 of them)
+waves = len(buf)
 cyc = (buf[:, 3] - buf[:, 0]).astype(float)
 phase = np.diff(buf[:, :4].astype(float), axis=1)  # prologue | post-order | pre-order, shader cycles
 rt = (buf[:, 6:8] - buf[:, 6].min()) * 0.01  # us, 100 MHz constant clock

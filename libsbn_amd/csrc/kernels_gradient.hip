@@ -1210,6 +1210,14 @@ static void launch_gradient_mfma_store(const LikArgs& a, dim3 grid, size_t lds, 
   else if (subst) launch_gradient_mfma_variant<false, true, ARENA>(a, grid, lds, s);
   else launch_gradient_mfma_variant<false, false, ARENA>(a, grid, lds, s);
 }
+// Do `waves` single-wave workgroups of `lds` bytes each all fit the device at once?
+bool arena_single_launch(size_t lds, size_t waves) {
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const size_t per_cu = std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+  return waves <= (size_t)cus * per_cu;
+}
 void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool subst,
                           hipStream_t s) {
   if (count <= 0) return;
@@ -1222,6 +1230,15 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool sub
     // then (more LDS per wave) the rest; a wave of the other launch's tree exits at once
     const int usual = gradient_arena_slots_usual(a.n), sure = gradient_arena_slots_sure(a.n);
     a.lds_lo = -1;
+    if (arena_single_launch(gradient_mfma_lds_bytes_for(a.n, a.K, rescale, subst, sure),
+                            (size_t)grid.x * grid.y)) {
+      // few waves (a call of one or a few trees): all of them resident at once even with the
+      // larger LDS footprint -- ONE launch that takes every tree
+      a.lds_slots = sure;
+      launch_gradient_mfma_store<true>(
+          a, grid, gradient_mfma_lds_bytes_for(a.n, a.K, rescale, subst, sure), rescale, subst, s);
+      return;
+    }
     a.lds_slots = usual;
     launch_gradient_mfma_store<true>(
         a, grid, gradient_mfma_lds_bytes_for(a.n, a.K, rescale, subst, usual), rescale, subst, s);

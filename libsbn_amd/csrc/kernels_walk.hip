@@ -981,6 +981,13 @@ void launch_gradient_walk(const LikArgs& a_in, int count, bool rescale, bool sub
   if (arena_variant) {
     const int usual = gradient_arena_slots_usual(a.n), sure = gradient_arena_slots_sure(a.n);
     a.lds_lo = -1;
+    if (arena_single_launch(gradient_walk_lds_bytes_for(a.n, a.K, rescale, subst, sure), grid.x)) {
+      // (few waves: one launch with the larger footprint takes every tree)
+      a.lds_slots = sure;
+      launch_walk_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, subst, sure),
+                              rescale, subst, s);
+      return;
+    }
     a.lds_slots = usual;
     launch_walk_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, subst, usual),
                             rescale, subst, s);

@@ -1001,23 +1001,24 @@ rng = np.random.default_rng(314)
 n, P, T = 12, 130, 900
 tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.05)
 pids, bls = TU.random_trees(n, T, rng, mean_bl=0.08)
-eng = L.Engine(L.PhyloModelSpecification('JC69', 'weibull+4', 'strict'), tips, w)
-spec = O.make_spec(n, P, 'JC69', 'weibull+4', 'strict')
-pr = TG._params(spec, T, **{'Weibull shape': rng.uniform(0.4, 1.5, size=(T, 1))})
 out = []
-for resc in (False, True):
-    g = eng.gradients(pids, bls, pr, resc)
-    assert eng.last_call_info()[0] == 'gradient_walk_kernel'
-    ll = np.array([x.log_likelihood for x in g])
-    bg = np.stack([x.gradient['branch_lengths'] for x in g])
-    sg = np.array([np.atleast_1d(x.gradient['site_model'])[0] for x in g])
-    out += [ll, bg.ravel(), sg]
-    if not resc:
-        sel = np.r_[0:4, T - 4:T]
-        og = O.unrooted_gradients(spec, tips, w, pids[sel], bls[sel], pr[sel], False, 8)
-        assert np.allclose(ll[sel], og['log_likelihood'], rtol=1e-10, atol=0)
-        assert np.allclose(bg[sel], og['branch_lengths'], rtol=1e-10, atol=1e-10 * np.abs(og['branch_lengths']).max())
-        assert np.allclose(sg[sel], og['site_model'], rtol=1e-9, atol=0)
+for site in ('weibull+4', 'weibull+2'):  # (two categories: tip bytes staged the general way)
+    eng = L.Engine(L.PhyloModelSpecification('JC69', site, 'strict'), tips, w)
+    spec = O.make_spec(n, P, 'JC69', site, 'strict')
+    pr = TG._params(spec, T, **{'Weibull shape': rng.uniform(0.4, 1.5, size=(T, 1))})
+    for resc in (False, True):
+        g = eng.gradients(pids, bls, pr, resc)
+        assert eng.last_call_info()[0] == 'gradient_walk_kernel'
+        ll = np.array([x.log_likelihood for x in g])
+        bg = np.stack([x.gradient['branch_lengths'] for x in g])
+        sg = np.array([np.atleast_1d(x.gradient['site_model'])[0] for x in g])
+        out += [ll, bg.ravel(), sg]
+        if not resc:
+            sel = np.r_[0:4, T - 4:T]
+            og = O.unrooted_gradients(spec, tips, w, pids[sel], bls[sel], pr[sel], False, 8)
+            assert np.allclose(ll[sel], og['log_likelihood'], rtol=1e-10, atol=0)
+            assert np.allclose(bg[sel], og['branch_lengths'], rtol=1e-10, atol=1e-10 * np.abs(og['branch_lengths']).max())
+            assert np.allclose(sg[sel], og['site_model'], rtol=1e-9, atol=0)
 np.save(sys.argv[1], np.concatenate(out))
 """
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -20,7 +20,11 @@
 //     stored / unstored with tip-or-stored grandchildren: six cases of straight-line code)
 //     instead of a branch per operand;
 //   * the edge sums of macro m land in the LDS bytes that held the tip words of macro m
-//     (dead by then): 8 waves per CU as before.
+//     (dead by then): 8 waves per CU as before;
+//   * a wave takes several pattern tiles of its tree one after the other (the launch's first
+//     evaluations; the last ones get a wave per tile and level out the end of the launch):
+//     what belongs to the tree stays in registers, the next tile's tip bytes are requested
+//     a whole walk ahead (launch_gradient_walk chooses the split).
 // Every product and edge sum is the one the first-generation kernel does, in the same order;
 // two reductions at the root (site likelihood over states / categories, log-likelihood
 // partial) run on the matrix cores and row rotations instead of an LDS butterfly, so the

@@ -1211,10 +1211,22 @@ static void launch_gradient_mfma_store(const LikArgs& a, dim3 grid, size_t lds, 
   else launch_gradient_mfma_variant<false, false, ARENA>(a, grid, lds, s);
 }
 // Do `waves` single-wave workgroups of `lds` bytes each all fit the device at once?
-bool arena_single_launch(size_t lds, size_t waves) {
-  int dev = 0, cus = 256;
+// compute units of the current device (asked once per device)
+int device_compute_units() {
+  static int cached[64] = {};
+  int dev = 0;
   (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    cached[dev] = cus;
+  }
+  return cached[dev];
+}
+bool arena_single_launch(size_t lds, size_t waves) {
+  const int cus = device_compute_units();
   const size_t per_cu = std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
   return waves <= (size_t)cus * per_cu;
 }

@@ -959,10 +959,7 @@ void launch_gradient_walk(const LikArgs& a_in, int count, bool rescale, bool sub
   const bool arena_variant = gradient_walk_use_arena(a.n, a.K, rescale, subst);
   int tpw = 1, big = 0;
   if (a.cat_groups == 1 && !arena_variant && !subst) {
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const double slots = (double)cus * gradient_walk_waves_per_cu(a.n, a.K);
+    const double slots = (double)device_compute_units() * gradient_walk_waves_per_cu(a.n, a.K);
     double best = 0;
     for (int k = forced_tpw ? forced_tpw : 2; k <= (forced_tpw ? forced_tpw : 8); k++) {
       // (measured, 1000 and 125 DS1 trees: fewer small jobs -- k / 4 + 1, k / 8 + 1/2 rounds --

@@ -187,6 +187,7 @@ void launch_macro_slots(const MacroEntry* macros_in, MacroEntry* macros_out,
                         const int32_t* macro_count, int n, int T, int32_t* need, int32_t* status,
                         hipStream_t s);
 size_t gradient_arena_bytes_per_eval(int n, int P, int K);
+int device_compute_units();  // of the current device
 bool arena_single_launch(size_t lds_bytes, size_t waves);  // all waves resident at once?
 int gradient_arena_slots_sure(int n);
 int gradient_arena_slots_usual(int n);

@@ -528,10 +528,10 @@ __global__ __launch_bounds__(64) void aa_post_kernel(AaWalkArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < M; u++) {
-      double cs = 0;
-#pragma unroll
-      for (int t = 0; t < 5; t++)
-        cs = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, Tn[u][t], cs, 0, 0, 0);
+      // column sum over the 20 states: this lane's five rows with vector adds, then ONE product
+      // with a ones matrix for the four row groups (only the exponent of the sum is used)
+      const double part = ((Tn[u][0] + Tn[u][1]) + (Tn[u][2] + Tn[u][3])) + Tn[u][4];
+      const double cs = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, part, 0.0, 0, 0, 0);
       // exact power-of-two rescaling by the exponent of the column sum (all four lanes of
       // a column hold the same sum)
       const int e = cs > 0.0 ? __builtin_amdgcn_frexp_exp(cs) - 1 : 0;
@@ -869,10 +869,10 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
     } else
 #pragma unroll
     for (int u = 0; u < M; u++) {
-      double cs = 0;
-#pragma unroll
-      for (int t = 0; t < 5; t++)
-        cs = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, Tn[u][t], cs, 0, 0, 0);
+      // column sum over the 20 states: this lane's five rows with vector adds, then ONE product
+      // with a ones matrix for the four row groups (only the exponent of the sum is used)
+      const double part = ((Tn[u][0] + Tn[u][1]) + (Tn[u][2] + Tn[u][3])) + Tn[u][4];
+      const double cs = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, part, 0.0, 0, 0, 0);
       const int e = cs > 0.0 ? __builtin_amdgcn_frexp_exp(cs) - 1 : 0;
 #pragma unroll
       for (int t = 0; t < 5; t++) R[u][t] = ldexp(Tn[u][t], -e);

@@ -830,7 +830,7 @@ size_t gradient_arena_bytes_per_eval(int n, int P, int K) {
 // waves per CU (the registers allow 8), or would not fit at all: measured cross-over with
 // 934 patterns at 31-32 taxa (29 taxa: 1.34 ms per 1000 trees in LDS / 1.47 arena; 32: 1.60 /
 // 1.56; 42: 2.79 / 2.03).  MI_PHYLO_GRADIENT_STORE=lds|arena forces one of the two.
-bool gradient_mfma_use_arena(int n, int K, bool rescale, bool subst) {
+bool gradient_mfma_use_arena(int n, int K, bool rescale, bool subst, size_t waves) {
   static const int forced = [] {
     const char* env = getenv("MI_PHYLO_GRADIENT_STORE");
     if (!env) return 0;
@@ -840,6 +840,7 @@ bool gradient_mfma_use_arena(int n, int K, bool rescale, bool subst) {
   const bool lds_fits = lds_all <= 160 * 1024;
   if (forced == 1 && lds_fits) return false;
   if (forced == 2) return true;
+  if (lds_fits && arena_single_launch(lds_all, waves)) return false;  // a call of a few trees
   return !lds_fits || (160 * 1024) / lds_all < 7;
 }
 bool gradient_mfma_fits(int n, int K, bool rescale) {
@@ -1237,7 +1238,7 @@ void launch_gradient_mfma(const LikArgs& a_in, int count, bool rescale, bool sub
   a.kp = a.K == 1 ? 1 : (a.K == 2 ? 2 : 4);
   a.cat_groups = gradient_mfma_groups(a.K);
   const dim3 grid(gradient_mfma_tiles(a.P, a.K) * a.cat_groups, count);
-  if (gradient_mfma_use_arena(a.n, a.K, rescale, subst)) {
+  if (a.store ? a.store == 2 : gradient_mfma_use_arena(a.n, a.K, rescale, subst, (size_t)grid.x * grid.y)) {
     // two launches over the same grid: the trees that fit the usual number of LDS slots,
     // then (more LDS per wave) the rest; a wave of the other launch's tree exits at once
     const int usual = gradient_arena_slots_usual(a.n), sure = gradient_arena_slots_sure(a.n);

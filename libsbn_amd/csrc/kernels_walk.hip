@@ -956,7 +956,9 @@ void launch_gradient_walk(const LikArgs& a_in, int count, bool rescale, bool sub
     return env ? std::max(1, atoi(env)) : 0;
   }();
   const int gtiles = gradient_mfma_tiles(a.P, a.K) * a.cat_groups;
-  const bool arena_variant = gradient_walk_use_arena(a.n, a.K, rescale, subst);
+  const bool arena_variant =
+      a.store ? a.store == 2
+              : gradient_walk_use_arena(a.n, a.K, rescale, subst, (size_t)gtiles * (size_t)count);
   int tpw = 1, big = 0;
   if (a.cat_groups == 1 && !arena_variant && !subst) {
     const double slots = (double)device_compute_units() * gradient_walk_waves_per_cu(a.n, a.K);
@@ -1004,7 +1006,7 @@ void launch_gradient_walk(const LikArgs& a_in, int count, bool rescale, bool sub
                            subst, s);
 }
 
-bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst) {
+bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves) {
   static const int forced = [] {
     const char* env = getenv("MI_PHYLO_GRADIENT_STORE");
     if (!env) return 0;
@@ -1014,6 +1016,7 @@ bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst) {
   const bool lds_fits = lds_all <= 160 * 1024;
   if (forced == 1 && lds_fits) return false;
   if (forced == 2) return true;
+  if (lds_fits && arena_single_launch(lds_all, waves)) return false;  // a call of a few trees
   return !lds_fits || (160 * 1024) / lds_all < 7;
 }
 bool gradient_walk_fits(int n, int K, bool rescale) {

@@ -66,9 +66,10 @@ CallShape call_shape(const mi_engine* e, int T, bool gradient, bool analytic = f
 
 // the two generations of the matrix-core gradient walk (kernels_gradient.hip /
 // kernels_walk.hip) size their LDS slightly differently
-bool use_arena(const mi_engine* e, bool rescale, bool subst) {
-  return e->walk2 ? gradient_walk_use_arena(e->n, e->K, rescale, subst)
-                  : gradient_mfma_use_arena(e->n, e->K, rescale, subst);
+// (waves: one-wave workgroups of a gradient launch; default: a large batch)
+bool use_arena(const mi_engine* e, bool rescale, bool subst, size_t waves = (size_t)-1) {
+  return e->walk2 ? gradient_walk_use_arena(e->n, e->K, rescale, subst, waves)
+                  : gradient_mfma_use_arena(e->n, e->K, rescale, subst, waves);
 }
 bool walk_fits(const mi_engine* e, bool rescale) {
   return e->walk2 ? gradient_walk_fits(e->n, e->K, rescale) : gradient_mfma_fits(e->n, e->K, rescale);
@@ -206,7 +207,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool marks = prof && e->prof_phases;
   PROF_MARK(e, marks, 0, s);
   launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
-  const bool arena = mfma && use_arena(e, d.rescaling, analytic);
+  // (a call of a few trees keeps its stored vectors in LDS however large the tree)
+  const bool arena = mfma && use_arena(e, d.rescaling, analytic, (size_t)T * (size_t)g_tiles);
   const bool walk2 = mfma && e->walk2;
   if (arena)
     launch_macro_slots(e->macros.as<MacroEntry>(), e->arena_macros.as<MacroEntry>(),
@@ -311,6 +313,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.site_lik = nullptr;
   la.status = e->status.as<int32_t>();
   la.slot_need = e->slot_need.as<int32_t>();
+  la.store = mfma ? (arena ? 2 : 1) : 0;  // (the launchers follow the choice the schedules were made for)
   // one launch covers at most kMaxEvals evaluations (grid y dimension: 65535; a multiple
   // of 8 keeps whole evaluations per XCD)
   constexpr int kMaxEvals = 32768;

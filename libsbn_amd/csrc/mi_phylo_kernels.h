@@ -92,6 +92,7 @@ struct LikArgs {
   // of them (the first ones) are walked by `walk_groups` waves that take several pattern
   // tiles each (tile g, g + walk_groups, ...); the others get a wave per tile
   int walk_evals, walk_big_evals, walk_groups;
+  int store;           // matrix-core gradient kernels: 0 = the launcher decides, 1 = stored vectors in LDS, 2 = arena (the engine decides: its schedules must match)
   int evals_per_wave;  // loglik_mfma_kernel: consecutive evaluations of one tree per wave (launcher)
   int kp;           // MFMA path: categories per instruction (1, 2 or 4; set by the launcher)
   int cat_groups;   // matrix-core gradient: groups of four categories (K > 4; set by the launcher)
@@ -182,7 +183,11 @@ int gradient_mfma_width(int n, bool subst = false);  // doubles per (gradient ev
 void launch_gradient_mfma(const LikArgs& a, int count, bool rescale, bool subst, hipStream_t s);
 // arena variant of the matrix-core gradient kernel (stored post-order vectors in HBM, LDS
 // slots reused): when it runs, its slot assignment pass, and its HBM need per evaluation
-bool gradient_mfma_use_arena(int n, int K, bool rescale, bool subst);
+// waves: one-wave workgroups of the launch (default: a large batch).  A call whose waves are
+// all resident at once with the LDS footprint of the all-in-LDS store keeps that store however
+// large the tree: occupancy is not what bounds a call of a few trees, and the arena's second
+// launch, macro-slot kernel and HBM round trips are.
+bool gradient_mfma_use_arena(int n, int K, bool rescale, bool subst, size_t waves = (size_t)-1);
 void launch_macro_slots(const MacroEntry* macros_in, MacroEntry* macros_out,
                         const int32_t* macro_count, int n, int T, int32_t* need, int32_t* status,
                         hipStream_t s);
@@ -195,7 +200,7 @@ int gradient_arena_slots_usual(int n);
 void launch_transition_macro(const TransitionMacroArgs& a, hipStream_t s);
 void launch_gradient_walk(const LikArgs& a, int count, bool rescale, bool subst, hipStream_t s);
 bool gradient_walk_fits(int n, int K, bool rescale);
-bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst);
+bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves = (size_t)-1);
 size_t gradient_walk_lds_bytes(int n, int K, bool rescale, bool subst);
 size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots);
 size_t gradient_walk_mats_bytes_per_eval(int n, int K);

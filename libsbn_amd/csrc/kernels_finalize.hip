@@ -214,6 +214,97 @@ __device__ void ratio_transform(int n, const int32_t* c0, const int32_t* c1, con
   out[root - n] = sum;
 }
 
+// The two O(n) recurrences of the rooted chain rule (rooted_gradient_transforms.cpp:47-64 bottom-up,
+// :102-130 top-down) for a tree of at most 64 NB internal nodes, in the REGISTERS of one wave:
+// lane l holds nodes l, l + 64, ...; a step fetches what it needs from the owning lanes with
+// v_readlane (a node id is wave-uniform) and writes its result into the owning lane -- no LDS
+// round trip on the dependent chain (one fluA tree: 58 k -> 13 k cycles; the chain of LDS reads and
+// writes of a single lane was 26 of the kernel's 35 microseconds).  Same operations in the same
+// order as the single-lane loops below (explicitly rounded): bit-identical.
+template <int NB>
+struct WaveArrayD {
+  double r[NB];
+  __device__ __forceinline__ double rd(int idx) const {  // idx: wave-uniform
+    double x = r[0];
+#pragma unroll
+    for (int nb = 1; nb < NB; nb++) x = (idx >> 6) == nb ? r[nb] : x;
+    const int l = idx & 63;
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                            __builtin_amdgcn_readlane(__double2loint(x), l));
+  }
+  __device__ __forceinline__ void wr(int idx, double v, int lane) {
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) r[nb] = (lane + 64 * nb == idx) ? v : r[nb];
+  }
+};
+template <int NB>
+struct WaveArrayI {
+  int r[NB];
+  __device__ __forceinline__ int rd(int idx) const {
+    int x = r[0];
+#pragma unroll
+    for (int nb = 1; nb < NB; nb++) x = (idx >> 6) == nb ? r[nb] : x;
+    return __builtin_amdgcn_readlane(x, idx & 63);
+  }
+};
+template <int NB>
+__device__ __forceinline__ void rooted_recurrences_wave(int n, int lane, const int32_t* c0, const int32_t* c1,
+                                                        const double* Pv, const double* hg, const double* aux,
+                                                        const double* E0, const double* E1,
+                                                        const double* ratios, double* outA, double* outB,
+                                                        double* mult) {
+  WaveArrayD<NB> pa, pb, e0, e1, ra, oa, ob, mu;
+  WaveArrayI<NB> k0, k1;  // internal children (index - n), -1 for a leaf
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) {
+    const int i = lane + 64 * nb;
+    const bool in = i < n - 1;
+    const int a0 = in ? c0[i] : 0, a1 = in ? c1[i] : 0;
+    k0.r[nb] = in && a0 >= n ? a0 - n : -1;
+    k1.r[nb] = in && a1 >= n ? a1 - n : -1;
+    pa.r[nb] = in ? __dmul_rn(Pv[i], hg[i]) : 0.0;
+    pb.r[nb] = in ? __dmul_rn(Pv[i], aux[i]) : 0.0;
+    e0.r[nb] = in ? E0[i] : 0.0;
+    e1.r[nb] = in ? E1[i] : 0.0;
+    ra.r[nb] = in ? ratios[i] : 0.0;
+    oa.r[nb] = ob.r[nb] = mu.r[nb] = 0.0;
+  }
+  // (a step broadcasts only the children's values; every lane then evaluates ITS nodes'
+  // formula with its own coefficients and the owner of node i keeps the result.  A leaf child
+  // has coefficient 0 and index -1: fma(0, x, v) = v exactly, x being some finite register)
+  for (int i = 0; i < n - 2; i++) {
+    const int a0 = max(k0.rd(i), 0), a1 = max(k1.rd(i), 0);
+    const double xa0 = oa.rd(a0), xb0 = ob.rd(a0), xa1 = oa.rd(a1), xb1 = ob.rd(a1);
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const double va = fma(e1.r[nb], xa1, fma(e0.r[nb], xa0, pa.r[nb]));
+      const double vb = fma(e1.r[nb], xb1, fma(e0.r[nb], xb0, pb.r[nb]));
+      const bool mine = lane + 64 * nb == i;
+      oa.r[nb] = mine ? va : oa.r[nb];
+      ob.r[nb] = mine ? vb : ob.r[nb];
+    }
+  }
+  mu.wr(n - 2, 1.0, lane);
+  for (int i = n - 2; i >= 0; i--) {
+    const int a0 = k0.rd(i), a1 = k1.rd(i);  // (-1: no lane owns it)
+    const double m = mu.rd(i);
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const int node = lane + 64 * nb;
+      mu.r[nb] = (node == a0 || node == a1) ? __dmul_rn(ra.r[nb], m) : mu.r[nb];
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) {
+    const int i = lane + 64 * nb;
+    if (i < n - 1) {
+      outA[i] = oa.r[nb];
+      outB[i] = ob.r[nb];
+      mult[i] = mu.r[nb];
+    }
+  }
+}
+
 __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t, double* fin_lds) {
   // One wave per tree: lanes run over nodes / tiles for the reductions, lane 0
   // walks the O(n) recurrences of the rooted chain rule.  Working set (6n doubles, for
@@ -368,21 +459,35 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t
       E1[i] = epoch(a1);
     }
     __syncthreads();
-    if (lane == 0) {
+    if (n - 1 <= 64) {
+      rooted_recurrences_wave<1>(n, lane, c0, c1, Pv, hg, aux, E0, E1, ratios, outA, outB, mult);
+    } else if (n - 1 <= 128) {
+      rooted_recurrences_wave<2>(n, lane, c0, c1, Pv, hg, aux, E0, E1, ratios, outA, outB, mult);
+    } else if (n - 1 <= 256) {
+      rooted_recurrences_wave<4>(n, lane, c0, c1, Pv, hg, aux, E0, E1, ratios, outA, outB, mult);
+    } else if (lane == 0) {
       for (int i = 0; i < n - 2; i++) {
         // a leaf child contributes nothing -- and must not be READ either: LDS is not
         // cleared between workgroups, and 0 * (NaN residue) would poison every ancestor
         const bool i0 = c0[i] >= n, i1 = c1[i] >= n;
-        const int a0 = i0 ? c0[i] - n : 0, a1 = i1 ? c1[i] - n : 0;
-        outA[i] = Pv[i] * hg[i] + (i0 ? E0[i] * outA[a0] : 0.0) + (i1 ? E1[i] * outA[a1] : 0.0);
-        outB[i] = Pv[i] * aux[i] + (i0 ? E0[i] * outB[a0] : 0.0) + (i1 ? E1[i] * outB[a1] : 0.0);
+        double va = __dmul_rn(Pv[i], hg[i]), vb = __dmul_rn(Pv[i], aux[i]);
+        if (i0) {
+          va = fma(E0[i], outA[c0[i] - n], va);
+          vb = fma(E0[i], outB[c0[i] - n], vb);
+        }
+        if (i1) {
+          va = fma(E1[i], outA[c1[i] - n], va);
+          vb = fma(E1[i], outB[c1[i] - n], vb);
+        }
+        outA[i] = va;
+        outB[i] = vb;
       }
       mult[root - n] = 1.0;  // :102-130
       for (int v = root; v >= n; v--) {
         const int a0 = c0[v - n], a1 = c1[v - n];
         const double m = mult[v - n];
-        if (a0 >= n) mult[a0 - n] = ratios[a0 - n] * m;
-        if (a1 >= n) mult[a1 - n] = ratios[a1 - n] * m;
+        if (a0 >= n) mult[a0 - n] = __dmul_rn(ratios[a0 - n], m);
+        if (a1 >= n) mult[a1 - n] = __dmul_rn(ratios[a1 - n], m);
       }
     }
     __syncthreads();

@@ -269,29 +269,52 @@ __device__ __forceinline__ void rooted_recurrences_wave(int n, int lane, const i
     ra.r[nb] = in ? ratios[i] : 0.0;
     oa.r[nb] = ob.r[nb] = mu.r[nb] = 0.0;
   }
-  // (a step broadcasts only the children's values; every lane then evaluates ITS nodes'
+  // (a step broadcasts only the children's values; every lane then evaluates its node's
   // formula with its own coefficients and the owner of node i keeps the result.  A leaf child
-  // has coefficient 0 and index -1: fma(0, x, v) = v exactly, x being some finite register)
-  for (int i = 0; i < n - 2; i++) {
-    const int a0 = max(k0.rd(i), 0), a1 = max(k1.rd(i), 0);
-    const double xa0 = oa.rd(a0), xb0 = ob.rd(a0), xa1 = oa.rd(a1), xb1 = ob.rd(a1);
+  // has coefficient 0 and index -1: fma(0, x, v) = v exactly, x being some finite register.
+  // Nodes are taken 64 at a time -- block b lives in register b of each array and its
+  // children in registers <= b: no selection among registers for the first 64 nodes.)
+  auto rd_upto = [&](const WaveArrayD<NB>& w, int b, int idx) {  // idx < 64 (b + 1), uniform
+    double x = w.r[0];
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-      const double va = fma(e1.r[nb], xa1, fma(e0.r[nb], xa0, pa.r[nb]));
-      const double vb = fma(e1.r[nb], xb1, fma(e0.r[nb], xb0, pb.r[nb]));
-      const bool mine = lane + 64 * nb == i;
-      oa.r[nb] = mine ? va : oa.r[nb];
-      ob.r[nb] = mine ? vb : ob.r[nb];
+    for (int nb = 1; nb < NB; nb++)
+      if (nb <= b) x = (idx >> 6) == nb ? w.r[nb] : x;
+    const int l = idx & 63;
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                            __builtin_amdgcn_readlane(__double2loint(x), l));
+  };
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const int end = min(64 * (b + 1), n - 2);
+    for (int i = 64 * b; i < end; i++) {
+      const int l = i & 63;
+      const int a0 = max(__builtin_amdgcn_readlane(k0.r[b], l), 0);
+      const int a1 = max(__builtin_amdgcn_readlane(k1.r[b], l), 0);
+      const double xa0 = rd_upto(oa, b, a0), xb0 = rd_upto(ob, b, a0);
+      const double xa1 = rd_upto(oa, b, a1), xb1 = rd_upto(ob, b, a1);
+      const double va = fma(e1.r[b], xa1, fma(e0.r[b], xa0, pa.r[b]));
+      const double vb = fma(e1.r[b], xb1, fma(e0.r[b], xb0, pb.r[b]));
+      const bool mine = lane == l;
+      oa.r[b] = mine ? va : oa.r[b];
+      ob.r[b] = mine ? vb : ob.r[b];
     }
   }
   mu.wr(n - 2, 1.0, lane);
-  for (int i = n - 2; i >= 0; i--) {
-    const int a0 = k0.rd(i), a1 = k1.rd(i);  // (-1: no lane owns it)
-    const double m = mu.rd(i);
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-      const int node = lane + 64 * nb;
-      mu.r[nb] = (node == a0 || node == a1) ? __dmul_rn(ra.r[nb], m) : mu.r[nb];
+  for (int b = NB - 1; b >= 0; b--) {
+    const int top = min(64 * (b + 1), n - 1) - 1;
+    for (int i = top; i >= 64 * b; i--) {
+      const int l = i & 63;
+      const int a0 = __builtin_amdgcn_readlane(k0.r[b], l);  // (-1: no lane owns it)
+      const int a1 = __builtin_amdgcn_readlane(k1.r[b], l);
+      const double m = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mu.r[b]), l),
+                                        __builtin_amdgcn_readlane(__double2loint(mu.r[b]), l));
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        if (nb > b) continue;
+        const int node = lane + 64 * nb;
+        mu.r[nb] = (node == a0 || node == a1) ? __dmul_rn(ra.r[nb], m) : mu.r[nb];
+      }
     }
   }
 #pragma unroll

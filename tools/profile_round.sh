@@ -75,6 +75,10 @@ for k, v in agg.items():
 PY
 done
 
+# per-wave timeline of the gradient walk (diagnostic build, made here if absent)
+[ -f libsbn_amd/variants/timeline.so ] || make -C libsbn_amd/csrc timeline > $O/timeline_build.log 2>&1
+for T in 125 1000; do python3 tools/walk_timeline.py $T 2>&1 | grep -v amdgpu.ids; done > $S/${tag}_walk_timeline_tiles.txt
+
 ./build_tools/fp64_peak_probe > $S/${tag}_fp64_peak_probe.txt 2>&1
 ./build_tools/lds_dma_probe > $S/${tag}_lds_dma_probe.txt 2>&1
 

@@ -580,41 +580,54 @@ __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a, M
   }
   if (__any(bad_parent)) status = kBadParentIds;
 
-  // max leaf id below every node, bottom-up (ids are a post-order: children first)
-  if (status == kOk)
-    for (int v = 0; v < nodes_in - 1; v++) {
-      const int p = par.rd(v), mv = maxleaf.rd(v);
-#pragma unroll
-      for (int nb = 0; nb < NB; nb++)
-        maxleaf.r[nb] = (own(nb) == p && mv > maxleaf.r[nb]) ? mv : maxleaf.r[nb];
-    }
-  // every lane collects the children (at most three) of the nodes it holds, ascending max
-  // leaf id, by looking at each node once
-  Arr cnt, k0, k1, k2, m0, m1;
-  cnt.fill(0); k0.fill(0); k1.fill(0); k2.fill(0); m0.fill(0); m1.fill(0);
-  if (status == kOk)
+  // One pass over the nodes in id order (a post-order: a node's largest leaf id is final when
+  // the node comes up): the parent's largest leaf id, and the parent's list of children in
+  // order of arrival; the (at most three) children are sorted by largest leaf id afterwards,
+  // all nodes at once.  (Until round 3 the pass kept every list sorted as it went -- a
+  // 25-instruction insert per node on the one dependent chain of this kernel: 13 k of its 25 k
+  // cycles for a DS1 tree.)
+  Arr cnt, k0, k1, k2;
+  cnt.fill(0); k0.fill(0); k1.fill(0); k2.fill(0);
+  if (status == kOk) {
     for (int v = 0; v < nodes_in - 1; v++) {
       const int p = par.rd(v), mv = maxleaf.rd(v);
 #pragma unroll
       for (int nb = 0; nb < NB; nb++) {
         const bool mine = own(nb) == p;
         const int c = cnt.r[nb];
-        // sorted insert of (v, mv) into (k0 | m0), (k1 | m1), k2; equal keys cannot occur
-        // (disjoint leaf sets)
-        const bool lt0 = c >= 1 && m0.r[nb] > mv, lt1 = c >= 2 && m1.r[nb] > mv;
-        const int n0 = c == 0 || lt0 ? v : k0.r[nb];
-        const int n1 = c == 0 ? k1.r[nb] : (lt0 ? k0.r[nb] : (c == 1 || lt1 ? v : k1.r[nb]));
-        const int n2 = c < 2 ? k2.r[nb] : (lt1 ? k1.r[nb] : v);
-        const int nm0 = c == 0 || lt0 ? mv : m0.r[nb];
-        const int nm1 = c == 0 ? m1.r[nb] : (lt0 ? m0.r[nb] : (c == 1 || lt1 ? mv : m1.r[nb]));
-        k0.r[nb] = mine ? n0 : k0.r[nb];
-        k1.r[nb] = mine ? n1 : k1.r[nb];
-        k2.r[nb] = (mine && c <= 2) ? n2 : k2.r[nb];
-        m0.r[nb] = mine ? nm0 : m0.r[nb];
-        m1.r[nb] = mine ? nm1 : m1.r[nb];
+        maxleaf.r[nb] = (mine && mv > maxleaf.r[nb]) ? mv : maxleaf.r[nb];
+        k0.r[nb] = (mine && c == 0) ? v : k0.r[nb];
+        k1.r[nb] = (mine && c == 1) ? v : k1.r[nb];
+        k2.r[nb] = (mine && c == 2) ? v : k2.r[nb];
         cnt.r[nb] += mine ? 1 : 0;
       }
     }
+    // ascending largest leaf id (keys of siblings differ: disjoint leaf sets); absent children
+    // sort last
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const int c = cnt.r[nb];
+      int a = k0.r[nb], b = k1.r[nb], d = k2.r[nb];
+      int ma = maxleaf.gather(a), mb = maxleaf.gather(b), md = maxleaf.gather(d);
+      ma = c >= 1 ? ma : 0x7fffffff;
+      mb = c >= 2 ? mb : 0x7fffffff;
+      md = c >= 3 ? md : 0x7fffffff;
+      auto order2 = [](int& x, int& mx, int& y, int& my) {
+        const bool swap = mx > my;
+        const int tx = x, tm = mx;
+        x = swap ? y : x;
+        mx = swap ? my : mx;
+        y = swap ? tx : y;
+        my = swap ? tm : my;
+      };
+      order2(a, ma, b, mb);
+      order2(b, mb, d, md);
+      order2(a, ma, b, mb);
+      k0.r[nb] = a;
+      k1.r[nb] = b;
+      k2.r[nb] = d;
+    }
+  }
   if (status == kOk) {
     bool wrong = false;
 #pragma unroll

@@ -341,11 +341,12 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t
   int32_t* c1 = c0 + n;
   double* work = base + n;  // 5n doubles
   const SchedEntry* sched = a.sched + (size_t)t * (n - 1);
-  for (int i = lane; i < n - 1; i += 64) {
-    const SchedEntry se = sched[i];
-    c0[se.node - n] = se.child0;
-    c1[se.node - n] = se.child1;
-  }
+  if (a.rooted)  // (only the rooted chain rule and log-det-Jacobian look at the tree)
+    for (int i = lane; i < n - 1; i += 64) {
+      const SchedEntry se = sched[i];
+      c0[se.node - n] = se.child0;
+      c1[se.node - n] = se.child1;
+    }
   const double* h = a.node_heights ? a.node_heights + (size_t)t * N : nullptr;
   const double* bd = a.node_bounds ? a.node_bounds + (size_t)t * N : nullptr;
   const double* ratios = a.height_ratios ? a.height_ratios + (size_t)t * (n - 1) : nullptr;

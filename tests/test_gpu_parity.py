@@ -1038,6 +1038,68 @@ np.save(sys.argv[1], np.concatenate(out))
         assert np.array_equal(got["1"], got[tpw]), (tpw, np.max(np.abs(got["1"] - got[tpw])))
 
 
+def test_stored_vectors_in_lds_or_arena_are_bit_identical():
+    """Where the matrix-core gradient kernels keep the stored vectors of trees of 32 taxa and
+    more -- all in LDS (calls of a few trees) or in the HBM arena with a few LDS slots
+    (batches) -- is decided per call; the walk generation is fixed per engine.  With the
+    generation held (v1, v2) the two stores give bit-identical results: unrooted and rooted,
+    with and without rescaling, 1 / 3 / 4 rate categories -- so a tree's outputs do not
+    depend on the size of the batch it came in.  (The switches are read once per process.)"""
+    import subprocess
+    import sys
+    import tempfile
+    code = r"""
+import sys, os, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import oracle_lib as O, libsbn_amd as L, tree_utils as TU
+import test_gpu_parity as TG
+out = []
+for (n, P, K, rooted) in ((40, 90, 4, 0), (70, 61, 4, 0), (69, 238, 1, 0), (33, 100, 3, 0), (50, 80, 4, 1)):
+    rng = np.random.default_rng(5 + n)
+    T = 5
+    tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.1)
+    site = 'constant' if K == 1 else f'weibull+{K}'
+    eng = L.Engine(L.PhyloModelSpecification('JC69', site, 'strict'), tips, w)
+    spec = O.make_spec(n, P, 'JC69', site, 'strict')
+    blocks = {} if K == 1 else {'Weibull shape': rng.uniform(0.4, 1.5, size=(T, 1))}
+    pr = TG._params(spec, T, **blocks)
+    if not rooted:
+        pids, bls = TU.random_trees(n, T, rng, mean_bl=0.07)
+        for resc in (False, True):
+            for x in eng.gradients(pids, bls, pr, resc):
+                out.append([x.log_likelihood])
+                for k in sorted(x.gradient): out.append(np.atleast_1d(x.gradient[k]))
+    else:
+        trees = [TU.clocklike_rooted_tree(n, rng) for _ in range(T)]
+        pids = np.stack([t[0] for t in trees]); bls = np.stack([t[1] for t in trees])
+        state = [O.time_tree_init(n, t[0], t[1], t[2]) for t in trees]
+        h = np.stack([s[0] for s in state]); bd = np.stack([s[1] for s in state]); ra = np.stack([s[2] for s in state])
+        rates = np.full((T, 2 * n - 2), 0.7)
+        for x in eng.rooted_gradients(pids, bls, pr, rates, np.ones(T, np.int32), h, bd, ra):
+            out.append([x.log_likelihood])
+            for k in sorted(x.gradient): out.append(np.atleast_1d(x.gradient[k]))
+np.save(sys.argv[1], np.concatenate(out))
+"""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        for walk in ("v1", "v2"):
+            got = {}
+            for store in ("lds", "arena", ""):
+                env = dict(os.environ, MI_PHYLO_GRADIENT_WALK=walk)
+                env.pop("MI_PHYLO_GRADIENT_STORE", None)
+                env.pop("MI_PHYLO_SUBST_GRADIENT", None)
+                if store:
+                    env["MI_PHYLO_GRADIENT_STORE"] = store
+                path = os.path.join(tmp, f"{walk}_{store}.npy")
+                r = subprocess.run([sys.executable, "-c", code, path], env=env, cwd=repo,
+                                   capture_output=True, text=True)
+                assert r.returncode == 0, (walk, store, r.stdout + r.stderr)
+                got[store] = np.load(path)
+            assert np.isfinite(got["lds"]).all()
+            assert np.array_equal(got["lds"], got["arena"]), (walk, np.max(np.abs(got["lds"] - got["arena"])))
+            assert np.array_equal(got["lds"], got[""]), (walk, "per-call choice")
+
+
 def test_limits_are_refused_at_the_c_abi_with_a_message():
     """The limits that are the engine's, not the reference's, are refused at engine creation
     through the C ABI with a message -- never silently: more than 64 rate categories, fewer

@@ -10,11 +10,15 @@ import numpy as np
 import oracle_lib as O, libsbn_amd as L, tree_utils as TU
 import test_gpu_parity as TG
 
-rng = np.random.default_rng(99)
+rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "99")))
 bad = 0
 trials = int(os.environ.get("STRESS_TRIALS", "30"))
 for trial in range(trials):
-    n = int(rng.choice([3, 4, 5, 8, 13, 31, 32, 33, 40, 64, 65, 70, 96, 97, 128, 129, 140]))
+    # (STRESS_N="257,258,300": sizes on both sides of the 257-taxon limit of the register
+    # recurrences in finalize)
+    sizes = [int(x) for x in os.environ["STRESS_N"].split(",")] if os.environ.get("STRESS_N") else \
+        [3, 4, 5, 8, 13, 31, 32, 33, 40, 64, 65, 70, 96, 97, 128, 129, 140, 257, 258]
+    n = int(rng.choice(sizes))
     P = int(rng.choice([5, 12, 33, 64, 100]))
     K = int(rng.choice([1, 2, 4]))
     subst = str(rng.choice(["JC69", "GTR"]))

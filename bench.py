@@ -234,14 +234,14 @@ def cpu_baseline(tips, w, pids, bls, params, mode, budget_s=15.0, reps=10):
             "repetitions": reps, "value_min": S2 / times[-1], "value_max": S2 / times[0],
             "value_on_one_core": S1 / one[1],
             "beagle_probe": beagle_probe(),
-            "sample": f"median of {reps} calls of {S2} trees each (the same batch, cycled; 3 "
-                      f"warm-up calls), {mode} semantics, {cores} OpenMP threads = usable cores "
-                      f"(affinity mask capped by the cgroup CPU quota; host has "
-                      f"{os.cpu_count()} logical CPUs), one tree per thread, one workspace per "
-                      f"thread, {sum(times):.1f} s; one core: median of 3 calls of {S1} trees; "
-                      "CPU oracle = BEAGLE-equivalent algorithm (cache-blocked over site "
-                      "patterns) in plain C -O3 -march=native, not BEAGLE (dlopen probe for "
-                      "libhmsbeagle in beagle_probe)"}
+            "sample": f"median of {reps} calls x {S2} trees (the headline batch, cycled), {mode} "
+                      f"semantics, {cores} threads, {sum(times):.0f} s; one core: 3 calls x {S1}",
+            "sample_detail": f"3 warm-up calls; {cores} OpenMP threads = usable cores (affinity "
+                             "mask capped by the cgroup CPU quota; host has "
+                             f"{os.cpu_count()} logical CPUs), one tree per thread, one "
+                             "workspace per thread; CPU oracle = BEAGLE-equivalent algorithm "
+                             "(cache-blocked over site patterns) in plain C -O3 -march=native, "
+                             "not BEAGLE (dlopen probe for libhmsbeagle in beagle_probe)"}
 
 
 def roofline(kname, k_ms, units, flops_per_unit, bytes_per_unit, traffic=None,
@@ -349,6 +349,107 @@ def parity(pairs, tol=1e-10):
     return worst
 
 
+LINE_LIMIT = 4096  # bytes: the driver keeps an 8 KB tail of stdout and parses its last line
+
+
+def _sig(x, digits=6):
+    """x with every float rounded to `digits` significant digits (NaN / inf -> None)."""
+    if isinstance(x, (bool, str)) or x is None:
+        return x
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        return float(f"{x:.{digits}g}") if np.isfinite(x) else None
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d and k in d}
+
+
+ROOFLINE_KEYS = ("kernel", "kernel_ms", "units_per_launch", "bound", "achieved", "peak", "unit",
+                 "frac", "traffic", "hbm_frac")
+
+
+def final_line(full):
+    """The ONE JSON line the driver parses (last line of stdout), from the full result: the
+    contract's fields, the dominant kernel's roofline, the CPU baseline, parity, and one short
+    entry per other leg.  Everything else (phase tables, notes, per-kernel second rooflines,
+    probe lists) is in bench_also.json and on the `BENCH_ALSO ...` lines printed before it.
+    Raises if the line would exceed LINE_LIMIT bytes (a 21 KB line did not parse)."""
+    keep = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step",
+            "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "dry_run", "backend",
+            "trees_per_rank", "patterns_per_rank", "parity", "parity_checked",
+            "parity_max_rel_err", "small_batch_ms", "host_pointer_trees_per_s",
+            "adapter_trees_per_s", "also_error")
+    out = _pick(full, keep)
+    if "step_ms_device" in full:
+        out["step_ms_device"] = _pick(full["step_ms_device"],
+                                      ("min", "median", "max", "kernel_median"))
+    if "config" in full:
+        out["config"] = _pick(full["config"], ("workload", "trees_total", "trees_per_gpu", "taxa",
+                                               "patterns", "categories", "trees", "parallelism"))
+    if full.get("roofline"):
+        out["roofline"] = _pick(full["roofline"], ROOFLINE_KEYS)
+    if full.get("cpu_baseline"):
+        out["cpu_baseline"] = _pick(full["cpu_baseline"],
+                                    ("value", "unit", "cores", "kind", "repetitions",
+                                     "value_on_one_core", "sample"))
+    if full.get("small_batch"):
+        out["small_batch"] = _pick(full["small_batch"],
+                                   ("trees", "ms_per_step", "graph_ms_per_step", "kernel_ms"))
+    if full.get("weak"):
+        out["weak"] = _pick(full["weak"], ("value", "ms_per_step", "trees_per_gpu"))
+    if full.get("reduced"):
+        out["reduced"] = _pick(full["reduced"], ("trees_per_s", "ms_per_step", "all_reduce_doubles",
+                                                 "collective", "max_rel_err"))
+    if full.get("gathered"):
+        out["gathered"] = _pick(full["gathered"], ("trees_per_s", "ms_per_step", "collective"))
+    if full.get("also"):
+        out["also"] = [dict(_pick(a, ("trees_per_s", "parity_max_rel_err")),
+                            workload=a.get("short", a.get("workload", ""))[:48],
+                            **_pick(a.get("roofline") or {}, ("bound", "frac")))
+                       for a in full["also"]]
+    out["detail"] = "bench_also.json"
+    line = json.dumps(_sig(out), separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:
+        raise AssertionError(f"bench line is {len(line)} bytes (limit {LINE_LIMIT}): move "
+                             "fields to bench_also.json")
+    json.loads(line)
+    return line
+
+
+def emit(full):
+    """bench_also.json (next to bench.py, and under gpurun_out/ when that exists) + the same
+    content as `BENCH_ALSO <name> <json>` lines on stdout (one per leg, none starting with a
+    brace) + the compact last line."""
+    import ctypes
+    for path in (os.path.join(REPO, "bench_also.json"),
+                 os.path.join(REPO, "gpurun_out", "bench_also.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as fh:
+                    json.dump(full, fh, indent=1)
+        except OSError:
+            pass
+    # RCCL prints a version banner through C stdio, which is flushed at exit when stdout is a
+    # file: flush it now so that the JSON line is the last line.
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    for key in ("roofline", "step_ms_device", "small_batch", "weak", "gathered", "reduced",
+                "host_pointer", "adapter", "cpu_baseline", "config"):
+        if full.get(key) is not None:
+            print("BENCH_ALSO", key, json.dumps(_sig(full[key], 8)), flush=True)
+    for leg in full.get("also") or []:
+        print("BENCH_ALSO", "leg", json.dumps(_sig(leg, 8)), flush=True)
+    print(final_line(full), flush=True)  # the ONE JSON line, last thing on stdout
+
+
 class Timed:
     """Times `steps` calls of fn() after `warmup` calls; kernel time from the engine's HIP
     events around its dominant kernel(s); optionally a second, separate pass with the call cut
@@ -435,6 +536,7 @@ def also_workloads(torch, dev, L, steps):
              2 * b_g + 16 * b_ll, 2 * f_g + 16 * f_ll, True),
             ("logL + branch-length gradient only (configs[2] as worded)", None, None, b_g, f_g,
              False)):
+        short = "DS1x1000 GTR+G4 " + ("full gradients (FD)" if full else "logL+branch gradient")
         ms, k_ms = tm.run(lambda: eng.gradients_device(
             stream, T, d_pid.data_ptr(), d_bl.data_ptr(), d_gtr.data_ptr(), ll.data_ptr(),
             g.data_ptr(), s_ptr, u_ptr), steps, 1)
@@ -452,7 +554,7 @@ def also_workloads(torch, dev, L, steps):
         r = roofline(kname, ms, T, flops, bytes_)
         r["note"] = ("whole call (all its walk passes) over the step time; " + r["note"])
         out.append({"workload": f"DS1 27 taxa x {P} patterns x {T} trees, GTR+weibull+4, " + label,
-                    "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
+                    "short": short, "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
                     "kernel_ms": k_ms,
                     "kernel_note": "HIP events around the main gradient pass only; the call also "
                                    "runs the finite-difference / site passes",
@@ -475,7 +577,7 @@ def also_workloads(torch, dev, L, steps):
     err = parity([("logL", host(ll, S), oll)])
     ent = traffic_entry(kname.split("<")[0])
     out.append({"workload": f"DS1 27 taxa x {P} patterns x {T} trees, JC69+weibull+4, log_likelihoods",
-                "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
+                "short": "DS1x1000 JC69+G4 log_likelihoods", "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
                 "kernel_ms": k_ms,
                 "roofline": roofline(kname, k_ms, T, f_ll, b_ll,
                                      ent["hbm_bytes_per_launch"] if ent else None,
@@ -504,7 +606,7 @@ def also_workloads(torch, dev, L, steps):
                   ("site gradient", host(site, S), og["site_model"])])
     out.append({"workload": f"S-DS1 27 taxa x 1949 patterns (synthetic, evolved under JC) x {T} "
                             "trees, JC69+weibull+4, phylo_gradients",
-                "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
+                "short": "S-DS1 1949 patterns x1000 gradients", "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
                 "kernel_ms": k_ms, "roofline": roofline(kname, k_ms, T, f2_g, b2_g),
                 "parity_checked": S, "parity_max_rel_err": err})
     eng.close()
@@ -547,7 +649,7 @@ def also_workloads(torch, dev, L, steps):
                       ("clock gradient", host(gc, S)[:, 0], og["clock_model"][:, 0])])
         out.append({"workload": f"fluA rooted {n} taxa x {P} patterns x {Tf} tree(s), JC69, strict "
                                 "clock, node-height-ratio + clock gradient",
-                    "trees_per_s": Tf / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
+                    "short": f"fluA rooted x{Tf} ratio+clock gradient", "trees_per_s": Tf / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
                     "kernel_ms": k_ms, "logL0": float(ll[0]),
                     "phase_ms": {"setup": phase_ms[0], "walk": phase_ms[2], "rest": phase_ms[3]},
                     "roofline": roofline(kname, k_ms, Tf, ff_g, bf_g),
@@ -619,6 +721,7 @@ def also_workloads(torch, dev, L, steps):
             entry = {"workload": f"S-WAG 20 states, {n} taxa x {P} patterns x {K} categories "
                                  f"x {Tw} tree(s), " + ("phylo_gradients" if grad else
                                                         "log_likelihoods"),
+                     "short": f"S-WAG 512x50000x4 T={Tw} " + ("gradients" if grad else "logL"),
                      "trees_per_s": Tw / (ms * 1e-3), "ms_per_step": ms,
                      "kernel": eng.last_call_info()[0], "kernel_ms": k_ms,
                      "walk_launches": launches, "evaluations_in_first_launch": first,
@@ -768,14 +871,99 @@ def swag_pattern_sharded(args, torch, dist, L, sharding, dev, rank, world, distr
     }
 
 
+def host_pointer_leg(eng, pids, bls, params, head_ll, head_g, head_site, steps, warmup):
+    """mi_engine_gradients_unrooted: host pointers in, host pointers out (what the adapter of
+    INTEGRATION.md calls behind Engine::Gradients, /root/reference/src/engine.cpp:78-84), on
+    the headline batch; then the Python mirror's Engine.gradients (one PhyloGradient per
+    tree).  Results must equal the device-resident call's bit for bit."""
+    import ctypes as C
+    T, N = len(pids), head_g.shape[1]
+    pid = np.ascontiguousarray(pids, dtype=np.int32)
+    bl = np.ascontiguousarray(bls, dtype=np.float64)
+    pr = np.ascontiguousarray(params, dtype=np.float64)
+    ll, g, site = np.empty(T), np.empty((T, N)), np.empty(T)
+    ptr = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+
+    def call():
+        rc = eng._lib.mi_engine_gradients_unrooted(eng._h, T, ptr(pid), ptr(bl), ptr(pr), 0,
+                                                   ptr(ll), ptr(g), ptr(site), None)
+        if rc:
+            raise RuntimeError(eng._check(rc))
+
+    for _ in range(warmup):
+        call()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call()
+    sec = (time.perf_counter() - t0) / steps
+    same = bool(np.array_equal(ll, head_ll) and np.array_equal(g, head_g)
+                and np.array_equal(site, head_site))
+    assert same, "host-pointer call differs from the device-resident call"
+    for _ in range(min(warmup, 2)):
+        eng.gradients(pid, bl, pr)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = eng.gradients(pid, bl, pr)
+    py_sec = (time.perf_counter() - t0) / steps
+    assert res[0].log_likelihood == head_ll[0]
+    return {"trees_per_s": T / sec, "ms_per_step": 1e3 * sec, "trees": T,
+            "python_mirror_trees_per_s": T / py_sec, "python_mirror_ms_per_step": 1e3 * py_sec,
+            "bit_identical_to_device_call": same,
+            "note": "mi_engine_gradients_unrooted with numpy buffers: upload (parent ids, "
+                    "branch lengths, parameters), kernels, download (logL, branch and site "
+                    "gradients) through the engine's pinned staging, one synchronisation per "
+                    "call, wall clock; python mirror = Engine.gradients -> one PhyloGradient "
+                    "per tree"}
+
+
+def adapter_leg(bls, head_ll, head_g, head_site, steps, warmup):
+    """Engine::Gradients of the C++ adapter (libsbn_amd/csrc/host/engine.hpp), built here with
+    g++ and run as a child process on the headline batch: std::vector<FlatTree> in,
+    std::vector<PhyloGradient> out (tools/engine_bench.cpp)."""
+    import subprocess
+    import tempfile
+    lib = os.path.join(REPO, "libsbn_amd")
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            exe, blf, outf = (os.path.join(tmp, x) for x in ("engine_bench", "bl.f64", "out.f64"))
+            subprocess.run(["g++", "-std=c++17", "-O2", os.path.join(REPO, "tools", "engine_bench.cpp"),
+                            "-L" + lib, "-lmi_phylo", "-lmi_phylo_host", "-Wl,-rpath," + lib,
+                            "-o", exe], check=True, capture_output=True, text=True, timeout=300)
+            np.ascontiguousarray(bls, dtype=np.float64).tofile(blf)
+            T = len(bls)
+            r = subprocess.run([exe, os.path.join(DATA, "DS1.fasta"),
+                                os.path.join(DATA, "DS1.100_topologies.nwk"), blf, str(T),
+                                str(steps), str(warmup), outf],
+                               capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                return {"error": (r.stdout + r.stderr)[-300:]}
+            res = json.loads(r.stdout.strip().splitlines()[-1])
+            got = np.fromfile(outf).reshape(T, -1)
+            same = bool(np.array_equal(got[:, 0], head_ll) and np.array_equal(got[:, 1:-1], head_g)
+                        and np.array_equal(got[:, -1], head_site))
+            assert same, "the adapter's results differ from the device-resident call"
+            res["bit_identical_to_device_call"] = same
+            res["note"] = ("tools/engine_bench.cpp: mihost::Engine::Gradients(std::vector<FlatTree>, "
+                           "ParamMatrix, false) -> std::vector<PhyloGradient> (flattening the "
+                           "trees, the C ABI's host-pointer call, one std::map of vectors per "
+                           "tree), wall clock in a child process")
+            return res
+    except (OSError, subprocess.SubprocessError, ValueError) as exc:
+        return {"error": repr(exc)[:300]}
+
+
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def spawn_ranks(gpus):
     """Runs `python -m torch.distributed.run --nproc-per-node <gpus> bench.py <same args>` as a
     child and returns its exit code; the child's stdout (rank 0's JSON line last) is ours."""
-    import socket
     import subprocess
-    with socket.socket() as sock:  # a free port for the rendezvous
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
+    port = free_port()  # for the rendezvous
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
@@ -794,7 +982,7 @@ def dry_run(args, rank, world):
     from libsbn_amd import sharding
     if world > 1 or os.environ.get("MI_BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group(args.backend, rank=rank, world_size=world)
         ranks = dist.get_world_size()
         lo, hi = sharding.tree_shard(args.trees, rank, world)
@@ -808,7 +996,7 @@ def dry_run(args, rank, world):
         ranks, per_rank = 1, [args.trees]
     assert sum(per_rank) == args.trees
     if rank == 0:
-        print(json.dumps({"metric": "tree log-likelihoods+gradients/sec (batched)", "value": None,
+        print(final_line({"metric": "tree log-likelihoods+gradients/sec (batched)", "value": None,
                           "unit": "trees/s", "n_gpus": world, "rccl_ranks": ranks,
                           "trees_per_rank": per_rank, "steps": args.steps,
                           "warmup": args.warmup, "dry_run": True, "backend": args.backend,
@@ -835,12 +1023,30 @@ def main():
                          "configs[4], 20 states x 512 taxa x 50 000 patterns x 4 categories, "
                          "site patterns dealt to the GPUs, one all-reduce per step")
     ap.add_argument("--swag-trees", type=int, default=8)
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
-                    help="process-group backend; gloo only with --dry-run (CPU test of the launcher)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed headline steps (+ parity): no CPU baseline, other "
+                         "configurations, small batch, host legs or reduced leg -- for "
+                         "rocprofv3 runs, whose --stats line of the dominant kernel would "
+                         "otherwise average those legs' launches in")
+    ap.add_argument("--no-reduced", action="store_true",
+                    help="skip the leg that ends in the fused reductions + one all-reduce")
+    ap.add_argument("--no-host-legs", action="store_true",
+                    help="skip the host-pointer / C++ adapter / Python mirror legs")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="kernel experiments that skip work on purpose: no oracle check, the "
+                         "line says \"parity\": \"skipped\" and the exit code is 3")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
+                    help="process-group backend (default nccl; gloo with --dry-run, the CPU test "
+                         "of the launcher, and only there)")
     ap.add_argument("--dry-run", action="store_true",
                     help="start the ranks, form the process group, deal the trees, print the "
                          "line -- no GPU work, value null (tests/test_bench_launcher.py)")
     args = ap.parse_args()
+    if args.backend is None:
+        args.backend = "gloo" if args.dry_run else "nccl"
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_also = args.no_small_batch = True
+        args.no_host_legs = args.no_reduced = True
 
     # ---- one rank per GPU.  Without a launcher around us (no WORLD_SIZE) and --gpus N > 1,
     # start the N ranks ourselves -- as a CHILD process, before anything here touches the GPU
@@ -881,7 +1087,7 @@ def main():
     if distributed:
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
-            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     rccl_ranks = dist.get_world_size() if distributed else 1
     assert rccl_ranks == world
@@ -892,10 +1098,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-            sys.stdout.flush()
-            print(json.dumps(out), flush=True)
+            emit(out)
         return
 
     grad = args.mode == "gradient"
@@ -908,9 +1111,43 @@ def main():
                    device=local_rank)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def run_config(T_local_max, lo, hi, steps, warmup):
+    def timed_region(step, steps, warmup, finish=None):
+        """The contract's timing: `warmup` untimed steps, then EXACTLY `steps` steps bracketed
+        by a barrier + synchronize on both sides; returns the MAX over ranks of the elapsed
+        seconds.  `finish` (optional) completes whatever the last step left pending."""
+        for _ in range(warmup):
+            step()
+        if finish:
+            finish()
+        eng.check_status(stream)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.profile_begin(steps)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if finish:
+            finish()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = eng.profile_collect(steps)
+        eng.check_status(stream)
+        if distributed:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, kernel_ms
+
+    def run_config(T_local_max, lo, hi, steps, warmup, spread=False):
         """Times `steps` steps of this rank's trees [lo, hi); all ranks gather blocks of
-        T_local_max trees (shorter blocks are padded)."""
+        T_local_max trees (shorter blocks are padded).  spread: afterwards, and OUTSIDE the
+        timed region, the same steps once more with a HIP event after every step (the
+        per-step min / median / max of the line)."""
         T = hi - lo
         d_pid = torch.from_numpy(pids_all[lo:hi]).to(dev)
         d_bl = torch.from_numpy(bls_all[lo:hi]).to(dev)
@@ -925,6 +1162,13 @@ def main():
                 for _ in range(2)] if distributed else [None, None]
         state = {"k": 0, "pending": None, "gathered": None}
         eng.reserve(T, grad)
+        # the one collective of the call -- every rank's per-tree results, tree order.
+        # "stream" (default): enqueued on the calls' own stream right behind the kernels (an
+        # all-gather of <= 54 KB per rank is latency, not bandwidth: there is nothing to
+        # overlap, and no cross-stream event dependency is paid); "overlap": asynchronously
+        # on RCCL's stream under the next step's kernels, which write the other buffer set
+        # (round 2-3 form: two cross-stream dependencies per step, 18.5 us on one rank).
+        overlap = os.environ.get("MI_BENCH_COLLECTIVE", "stream") == "overlap"
 
         def drain():
             if state["pending"] is not None:
@@ -945,45 +1189,24 @@ def main():
             else:
                 eng.log_likelihoods_device(stream, T, d_pid.data_ptr(), d_bl.data_ptr(),
                                            d_par.data_ptr(), blk.log_likelihoods.data_ptr())
-            if distributed:
-                # the one collective of the call: every rank's per-tree results, tree order,
-                # enqueued asynchronously (RCCL's stream) so that it overlaps the next step's
-                # kernels, which write the other buffer set; it is waited for one step later
-                # (and, for the last step, before the timed region ends).
+            if distributed and overlap:
                 out, work = sharding.all_gather_result_blocks(blk, out=outs[i], async_op=True)
                 drain()
                 state["pending"] = (work, out)
+            elif distributed:
+                state["gathered"], _ = sharding.all_gather_result_blocks(blk, out=outs[i])
 
-        for _ in range(warmup):
-            step()
-        drain()
-        eng.check_status(stream)
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        eng.profile_begin(steps)
-        # per-step spread: an event on the calls' stream after every step (no host
-        # synchronisation; ~1 us of host time each inside the timed region)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-        t0 = time.perf_counter()
-        marks[0].record()
-        for k in range(steps):
-            step()
-            marks[k + 1].record()
-        drain()
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        kernel_ms = eng.profile_collect(steps)
-        state["step_ms"] = [marks[k].elapsed_time(marks[k + 1]) for k in range(steps)]
-        eng.check_status(stream)
-        if distributed:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+        elapsed, kernel_ms = timed_region(step, steps, warmup, drain)
+        step_ms = None
+        if spread:
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            marks[0].record()
+            for k in range(steps):
+                step()
+                marks[k + 1].record()
+            drain()
+            torch.cuda.synchronize()
+            step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(steps)]
         last = sets[(state["k"] - 1) & 1]
         d_ll, d_g = last.log_likelihoods[:T], last.branch_gradients[:T]
         assert bool(torch.isfinite(d_ll).all()), "non-finite log-likelihoods"
@@ -995,30 +1218,33 @@ def main():
             assert bool(torch.equal(ll_all[rank][:T], d_ll)), "gathered slice mismatch"
             if grad:
                 assert bool(torch.equal(g_all[rank][:T], d_g)), "gathered gradient slice mismatch"
-        return elapsed, kernel_ms, last, T, state["step_ms"]
+        return elapsed, kernel_ms, last, T, step_ms
 
     # ---- strong scaling (the headline): T_total trees over all ranks
     lo, hi = sharding.tree_shard(T_total, rank, world)
     T_max = sharding.tree_shard(T_total, 0, world)[1]
-    elapsed, kernel_ms, last, T_local, step_ms = run_config(T_max, lo, hi, args.steps, args.warmup)
+    elapsed, kernel_ms, last, T_local, step_ms = run_config(T_max, lo, hi, args.steps,
+                                                            args.warmup, spread=True)
     ms_per_step = 1e3 * elapsed / args.steps
     value = T_total / (elapsed / args.steps)
     kname, evals, gevals = eng.last_call_info()
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    head_ll = last.log_likelihoods[:T_local].cpu().numpy()
+    head_g = last.branch_gradients[:T_local].cpu().numpy()
+    head_site = last.extras[0][:T_local].cpu().numpy()
 
     # ---- parity of the timed outputs: a sample of the last step against the CPU oracle
     parity_n, parity_err = 0, None
-    if rank == 0:
+    if rank == 0 and not args.no_parity:
         O = oracle()
         parity_n = min(16, T_local)
         ospec = O.make_spec(n, P, "JC69", "weibull+4")
         sl = slice(lo, lo + parity_n)
-        ll_dev = last.log_likelihoods[:parity_n].cpu().numpy()
+        ll_dev = head_ll[:parity_n]
         if grad:
             og = O.unrooted_gradients(ospec, tips, w, pids_all[sl], bls_all[sl], params_all[sl],
                                       False, min(parity_n, usable_cores()))
-            g_dev = last.branch_gradients[:parity_n].cpu().numpy()
-            s_dev = last.extras[0][:parity_n].cpu().numpy()
+            g_dev, s_dev = head_g[:parity_n], head_site[:parity_n]
             errs = [np.max(np.abs(ll_dev - og["log_likelihood"]) / np.abs(og["log_likelihood"])),
                     np.max(np.abs(g_dev - og["branch_lengths"])) / np.max(np.abs(og["branch_lengths"])),
                     np.max(np.abs(s_dev - og["site_model"]) / np.abs(og["site_model"]))]
@@ -1027,12 +1253,7 @@ def main():
                                              params_all[sl], False, min(parity_n, usable_cores()))
             errs = [np.max(np.abs(ll_dev - oll) / np.abs(oll))]
         parity_err = float(max(errs))
-        # (MI_BENCH_SKIP_PARITY=1: kernel experiments that skip work on purpose -- never set by
-        # the driver; the value it marks is reported as unchecked)
-        if os.environ.get("MI_BENCH_SKIP_PARITY") == "1":
-            parity_n = 0
-        else:
-            assert parity_err <= 1e-10, f"timed outputs differ from the oracle: {errs}"
+        assert parity_err <= 1e-10, f"timed outputs differ from the oracle: {errs}"
 
     # ---- weak scaling beside it (1000 trees per GPU), N > 1 only
     weak = None
@@ -1042,11 +1263,67 @@ def main():
         weak = {"value": world * T_total / (w_elapsed / args.steps), "unit": "trees/s",
                 "ms_per_step": 1e3 * w_elapsed / args.steps, "trees_per_gpu": T_total}
 
+    # ---- north_star's literal collective: "a single RCCL all-reduce ... for the ELBO/gradient
+    # sum".  The same trees, but the step ends in the variational-inference reductions
+    # (mi_engine_gradients_unrooted_reduced_device: sum of logL, of the site gradients, and
+    # the branch gradients scatter-added by split index -- vip/burrito.py:143-153,
+    # vip/branch_model.py:125-132) and ONE all-reduce of 2 + index_count doubles instead of
+    # the all-gather of every per-tree vector.
+    reduced = None
+    if grad and not args.no_reduced:
+        index_count = 4096
+        node = np.arange(N, dtype=np.int64)
+        bi_all = ((np.arange(len(pids_all), dtype=np.int64)[:, None] % 100) * 53
+                  + node[None, :] * 7) % index_count  # a stand-in for the split indices
+        bi_all[:, -2:] = -1  # the fixed node and the root are not parameters
+        bi_all = bi_all.astype(np.int32)
+        d_pid = torch.from_numpy(pids_all[lo:hi]).to(dev)
+        d_bl = torch.from_numpy(bls_all[lo:hi]).to(dev)
+        d_par = torch.from_numpy(params_all[lo:hi]).to(dev)
+        d_bi = torch.from_numpy(bi_all[lo:hi]).to(dev)
+        packed = torch.zeros(2 + index_count, dtype=torch.float64, device=dev)
+        r_ll = torch.empty(T_local, dtype=torch.float64, device=dev)
+        eng.reserve(T_local, True)
+
+        def reduced_step():
+            rc = eng._lib.mi_engine_gradients_unrooted_reduced_device(
+                eng._h, stream, T_local, d_pid.data_ptr(), d_bl.data_ptr(), d_par.data_ptr(), 0,
+                d_bi.data_ptr(), None, index_count, packed.data_ptr(),
+                packed.data_ptr() + 16, r_ll.data_ptr())
+            if rc:
+                raise RuntimeError(L._capi.last_error())
+            if distributed:
+                dist.all_reduce(packed)  # on the calls' stream, in place
+
+        r_elapsed, _ = timed_region(reduced_step, args.steps, args.warmup)
+        # the reductions against the per-tree results of the headline step (themselves checked
+        # against the oracle above), scatter-added on the host the way vip does
+        mine = np.zeros(2 + index_count)
+        mine[0], mine[1] = head_ll.sum(), head_site.sum()
+        keep = bi_all[lo:hi] >= 0
+        np.add.at(mine[2:], bi_all[lo:hi][keep], head_g[keep])
+        ref = torch.from_numpy(mine).to(dev)
+        if distributed:
+            dist.all_reduce(ref)
+        r_err = float((packed - ref).abs().max() / ref.abs().max())
+        assert r_err <= 1e-12, f"reduced step differs from the scatter-added per-tree results: {r_err}"
+        reduced = {"trees_per_s": T_total / (r_elapsed / args.steps),
+                   "ms_per_step": 1e3 * r_elapsed / args.steps,
+                   "all_reduce_doubles": 2 + index_count,
+                   "collective": f"one all_reduce over {rccl_ranks} rank(s)" if distributed
+                                 else "none (one GPU)",
+                   "max_rel_err": r_err,
+                   "note": "mi_engine_gradients_unrooted_reduced_device (vi_reduce_kernel after "
+                           "the gradient kernels) + ONE all-reduce of [sum logL | sum site "
+                           "gradient | branch gradients scatter-added by a 4096-entry index]; "
+                           "checked against the host scatter-add (np.add.at) of the headline "
+                           "step's per-tree results"}
+
     # ---- small batch: what one of 8 GPUs sees under strong scaling (125 trees)
     small = None
     if rank == 0 and world == 1 and not args.no_small_batch:
         Ts = max(1, T_total // 8)
-        s_elapsed, s_kernel, _, _, s_steps = run_config(Ts, 0, Ts, 50, 5)
+        s_elapsed, s_kernel, _, _, s_steps = run_config(Ts, 0, Ts, 50, 5, spread=True)
         small = {"trees": Ts, "ms_per_step": 1e3 * s_elapsed / 50,
                  "step_ms_device": {"min": float(np.min(s_steps)),
                                     "median": float(np.median(s_steps)),
@@ -1092,6 +1369,20 @@ def main():
         except Exception as exc:  # capture support varies; the eager figure stands
             small["graph_error"] = repr(exc)[:200]
 
+    # ---- the Engine-shaped call (reference: Engine::Gradients, src/engine.cpp:78-92 -- host
+    # tree collections in, host vectors out), one GPU: (a) the C ABI's host-pointer entry with
+    # numpy buffers (pinned staging, one synchronisation per call), (b) the same through the
+    # g++-built C++ adapter (libsbn_amd/csrc/host/engine.hpp: std::vector<PhyloGradient>, a
+    # std::map per tree), (c) the Python mirror (one PhyloGradient object per tree, as pylibsbn
+    # returns them).  PCIe and host staging included; never `value`.
+    host_pointer = adapter = None
+    if rank == 0 and world == 1 and grad and not args.no_host_legs:
+        host_pointer = host_pointer_leg(eng, pids_all[:T_total], bls_all[:T_total],
+                                        params_all[:T_total], head_ll, head_g, head_site,
+                                        args.steps, args.warmup)
+        adapter = adapter_leg(bls_all[:T_total], head_ll, head_g, head_site, args.steps,
+                              args.warmup)
+
     out = None
     if rank == 0:
         b_ll, b_g = algorithmic_bytes(n, P, K)
@@ -1111,33 +1402,49 @@ def main():
                                "kernel_min": float(np.min(kernel_ms)) if kernel_ms else None,
                                "kernel_median": float(np.median(kernel_ms)) if kernel_ms else None,
                                "kernel_max": float(np.max(kernel_ms)) if kernel_ms else None,
-                               "note": "per step of the timed region, rank 0: HIP events on the "
-                                       "calls' stream after every step (device time between "
-                                       "consecutive steps' ends); kernel_* = the dominant "
-                                       "kernel's launch"},
+                               "note": "rank 0, a second pass of the same steps AFTER the timed "
+                                       "region: HIP events on the calls' stream after every step "
+                                       "(device time between consecutive steps' ends); kernel_* "
+                                       "= the dominant kernel's launches of the timed region"},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "reference DS1 alignment + DS1.100_topologies (read through the product's "
-                    "FASTA / Newick ingest); synthetic branch lengths Exp(mean 0.1), seed 43",
-            "config": {"workload": f"DS1 27 taxa x {P} site patterns (1949 sites) x {T_total} "
-                                   f"trees per step over {world} GPU(s) (100 topologies x "
-                                   f"{max(1, T_total // 100)} draws), JC69+weibull+4 (K=4), "
+            "data": "reference DS1 alignment + DS1.100_topologies; synthetic branch lengths "
+                    "Exp(mean 0.1), seed 43",
+            "config": {"workload": f"DS1 27 taxa x {P} site patterns x {T_total} trees per step "
+                                   f"over {world} GPU(s), JC69+weibull+4 (K=4), "
                                    + ("phylo_gradients: logL + branch + site gradients"
                                       if grad else "log_likelihoods"),
                        "trees_total": T_total, "trees_per_gpu": T_local, "taxa": n,
                        "patterns": P, "categories": K,
                        "parallelism": f"trees dealt to {world} GPUs in contiguous blocks, one "
-                                      "all_gather per step" if distributed else "single GPU"},
+                                      "all_gather per step" if distributed else "single GPU",
+                       "detail": "1949 sites -> 934 patterns; 100 topologies x "
+                                 f"{max(1, T_total // 100)} branch-length draws; read through the "
+                                 "product's FASTA / Newick ingest"},
             "roofline": roofline(kname, k_ms, T_local, f_g if grad else f_ll,
                                  b_g if grad else b_ll, traffic,
                                  "profiles/traffic.json (PMC, 1000-tree launch), not this run"),
             "parity_checked": parity_n, "parity_max_rel_err": parity_err,
             "parity_note": "first trees of the last timed step vs the CPU oracle, tolerance 1e-10",
         }
+        if args.no_parity:
+            out["parity"] = "skipped"
         if weak:
             out["weak"] = weak
+        if reduced:
+            out["reduced"] = reduced
+        if distributed:
+            out["gathered"] = {"trees_per_s": value, "ms_per_step": ms_per_step,
+                               "collective": f"one all_gather over {rccl_ranks} rank(s), "
+                                             + os.environ.get("MI_BENCH_COLLECTIVE", "stream")}
         if small:
             out["small_batch_ms"] = small.get("graph_ms_per_step", small["ms_per_step"])
             out["small_batch"] = small
+        if host_pointer:
+            out["host_pointer"] = host_pointer
+            out["host_pointer_trees_per_s"] = host_pointer["trees_per_s"]
+        if adapter:
+            out["adapter"] = adapter
+            out["adapter_trees_per_s"] = adapter.get("trees_per_s")
         if world == 1 and not args.no_also:
             try:
                 out["also"] = also_workloads(torch, dev, L, 5)
@@ -1150,12 +1457,11 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL prints a version banner through C stdio, which is flushed at exit when
-        # stdout is a file: flush it now so that the JSON line is the last line.
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)  # the ONE JSON line, last thing on stdout
+        emit(out)
+    if args.no_parity:
+        # (kernel experiments that skip work on purpose: the line says "parity": "skipped" and
+        # the run does not count as a success)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -256,7 +256,13 @@ int32_t mi_engine_gradients_unrooted_reduced_device(
     double* out_sums, double* out_index_gradient, double* out_log_likelihoods);
 
 /* Make sure the workspace for `tree_count` trees exists (so that a following
- * *_device call allocates nothing and can be captured in a hipGraph). */
+ * *_device call allocates nothing and can be captured in a hipGraph).  20-state engines: if
+ * the device cannot give the partial-vector arena its budget (MI_PHYLO_PLV_BYTES), the budget
+ * is reduced and every buffer that scales with it is released and allocated again
+ * (mi_engine_last_call_launches counts these back-offs) -- which invalidates graphs captured
+ * on this engine BEFORE that: capture after the reservation, and again after any call that
+ * reports a new back-off.  The fused-reduction entry points additionally need a sort
+ * workspace that depends on index_count; it is allocated by their first call. */
 int32_t mi_engine_reserve(mi_engine* engine, int32_t tree_count, int32_t for_gradients);
 /* Synchronise `stream` and report the first per-tree error since the last check (the status
  * word is sticky and cleared when an error is reported: calls themselves never clear it). */

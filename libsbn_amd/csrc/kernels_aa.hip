@@ -714,6 +714,7 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
   auto stage = [&](int c0, int c1, int buf) {
     // two operand tables per visit, each split between two waves: wave 2c takes the first
     // pieces of child c's table, wave 2c + 1 the rest (runs with immediate offsets: dma_run)
+    static_assert(kPostWaves == 4, "operand staging deals two children's tables to two waves each");
     const int c = wave_s >> 1, second = wave_s & 1;
     const int ch = c ? c1 : c0;
     const uint32_t lane16 = (uint32_t)lane * 16;
@@ -1198,6 +1199,7 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
   // four operand tables per visit (child 0 and child 1: P | P^T, or the two column tables of
   // a tip), ONE per wave: wave 2c takes child c's first table, wave 2c + 1 its second
   auto stage = [&](int c0, int c1, int buf) {
+    static_assert(kPreWaves == 4, "operand staging deals one table to each of four waves");
     const int c = wave_s >> 1, second = wave_s & 1;
     const int ch = c ? c1 : c0;
     double* dst = ops_lds[buf][c] + (second ? kAaPack : 0);

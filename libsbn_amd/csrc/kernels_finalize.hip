@@ -270,8 +270,7 @@ __device__ __forceinline__ void rooted_recurrences_wave(int n, int lane, const i
     oa.r[nb] = ob.r[nb] = mu.r[nb] = 0.0;
   }
   // (a step broadcasts only the children's values; every lane then evaluates its node's
-  // formula with its own coefficients and the owner of node i keeps the result.  A leaf child
-  // has coefficient 0 and index -1: fma(0, x, v) = v exactly, x being some finite register.
+  // formula with its own coefficients and the owner of node i keeps the result.
   // Nodes are taken 64 at a time -- block b lives in register b of each array and its
   // children in registers <= b: no selection among registers for the first 64 nodes.)
   auto rd_upto = [&](const WaveArrayD<NB>& w, int b, int idx) {  // idx < 64 (b + 1), uniform
@@ -288,12 +287,19 @@ __device__ __forceinline__ void rooted_recurrences_wave(int n, int lane, const i
     const int end = min(64 * (b + 1), n - 2);
     for (int i = 64 * b; i < end; i++) {
       const int l = i & 63;
-      const int a0 = max(__builtin_amdgcn_readlane(k0.r[b], l), 0);
-      const int a1 = max(__builtin_amdgcn_readlane(k1.r[b], l), 0);
+      // (a leaf child, index -1, contributes NOTHING: its term is selected away on the
+      // wave-uniform index, never multiplied by zero -- node 0's entries may be Inf / NaN for a
+      // degenerate tree (a zero ratio, a height on its bound) and 0 x Inf would poison every
+      // node with a tip child, where the single-lane loops and the reference stay finite)
+      const int c0 = __builtin_amdgcn_readlane(k0.r[b], l);
+      const int c1 = __builtin_amdgcn_readlane(k1.r[b], l);
+      const int a0 = max(c0, 0), a1 = max(c1, 0);
       const double xa0 = rd_upto(oa, b, a0), xb0 = rd_upto(ob, b, a0);
       const double xa1 = rd_upto(oa, b, a1), xb1 = rd_upto(ob, b, a1);
-      const double va = fma(e1.r[b], xa1, fma(e0.r[b], xa0, pa.r[b]));
-      const double vb = fma(e1.r[b], xb1, fma(e0.r[b], xb0, pb.r[b]));
+      const double ta = c0 >= 0 ? fma(e0.r[b], xa0, pa.r[b]) : pa.r[b];
+      const double tb = c0 >= 0 ? fma(e0.r[b], xb0, pb.r[b]) : pb.r[b];
+      const double va = c1 >= 0 ? fma(e1.r[b], xa1, ta) : ta;
+      const double vb = c1 >= 0 ? fma(e1.r[b], xb1, tb) : tb;
       const bool mine = lane == l;
       oa.r[b] = mine ? va : oa.r[b];
       ob.r[b] = mine ? vb : ob.r[b];
@@ -566,63 +572,11 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(ReduceArgs ra, Fin
   finalize_body(fa, blockIdx.x, rf_lds);
 }
 
-// ------------------------------------------------------------------------
-// Caller-side reductions of one variational-inference step, on the device
-// (vip/burrito.py:143-166: sum of the per-tree log-likelihoods; vip/branch_model.py:125-132:
-// per-tree branch gradients scatter-added by split index).  No float atomics: the thread that
-// owns index k scans the (tree, node) pairs in order -- staged through LDS a chunk at a time
-// -- and adds the ones that carry k, so every sum has a fixed order.
-// ------------------------------------------------------------------------
-constexpr int kViChunk = 2048;
-__global__ __launch_bounds__(256) void vi_reduce_kernel(ViReduceArgs a) {
-  __shared__ int32_t idx[kViChunk];
-  __shared__ double val[kViChunk];
-  __shared__ double red[256];
-  const int tid = threadIdx.x;
-  if (blockIdx.x == gridDim.x - 1) {  // the last workgroup: the two scalar sums
-    for (int which = 0; which < 2; which++) {
-      const double* x = which ? a.site : a.ll;
-      double s = 0;
-      if (x)
-        for (int t = tid; t < a.T; t += 256) s += (a.tree_weights ? a.tree_weights[t] : 1.0) * x[t];
-      red[tid] = s;
-      __syncthreads();
-      for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) red[tid] += red[tid + off];
-        __syncthreads();
-      }
-      if (tid == 0) a.out_sums[which] = red[0];
-      __syncthreads();
-    }
-    return;
-  }
-  const int k = blockIdx.x * 256 + tid;
-  const long total = (long)a.T * a.N;
-  double sum = 0;
-  for (long base = 0; base < total; base += kViChunk) {
-    const int count = (int)(total - base < kViChunk ? total - base : kViChunk);
-    for (int i = tid; i < count; i += 256) {
-      const long e = base + i;
-      idx[i] = a.branch_index[e];
-      val[i] = a.branch[e] * (a.tree_weights ? a.tree_weights[e / a.N] : 1.0);
-    }
-    __syncthreads();
-    if (k < a.index_count)
-      for (int i = 0; i < count; i++)
-        if (idx[i] == k) sum += val[i];
-    __syncthreads();
-  }
-  if (k < a.index_count) a.out_index_gradient[k] = sum;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------
 // Launch wrappers
 // ------------------------------------------------------------------------
-void launch_vi_reduce(const ViReduceArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(vi_reduce_kernel, dim3((a.index_count + 255) / 256 + 1), dim3(256), 0, s, a);
-}
 void launch_subst_gradient(const SubstGradArgs& a, hipStream_t s) {
   if (a.T <= 0) return;
   hipLaunchKernelGGL(subst_gradient_kernel, dim3((a.T + 63) / 64), dim3(64), 0, s, a);

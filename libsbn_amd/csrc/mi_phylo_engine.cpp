@@ -799,7 +799,7 @@ void mi_engine_destroy(mi_engine* e) {
         &e->ll_sum, &e->g_sum, &e->status, &e->aa_model, &e->aa_matP, &e->aa_matPT,
         &e->aa_tipP, &e->aa_tipPQ, &e->aa_exp_cum, &e->aa_exp_loc, &e->aa_root_val,
         &e->aa_root_exp, &e->aa_root_scale, &e->in_index, &e->in_weights, &e->out_reduced,
-        &e->red_ll, &e->red_g, &e->red_site,
+        &e->red_ll, &e->red_g, &e->red_site, &e->red_sort,
         &e->in_parent, &e->in_bl, &e->in_params, &e->in_rates, &e->in_rate_counts,
         &e->in_heights, &e->in_bounds, &e->in_ratios, &e->out_ll, &e->out_a, &e->out_b,
         &e->out_site, &e->out_subst})
@@ -837,8 +837,18 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
   if (e->s == kAa) {
     // a gradient engine may be asked for log-likelihoods too: those calls run more evaluations
     // per launch (fewer vectors each) and size the per-launch operand buffers accordingly
-    if (for_gradients && aa_reserve(e, tree_count, true)) return 1;
-    return aa_reserve(e, tree_count, false);
+    // A back-off of the arena budget inside either reservation RELEASES every buffer that
+    // scales with the budget -- those of the other shape too -- so both are repeated with the
+    // reduced budget until a whole pass allocates without backing off: a later *_device call
+    // then allocates nothing.  (A back-off also invalidates hipGraphs captured earlier on
+    // this engine: their kernels point at released buffers.  include/mi_phylo.h says so.)
+    for (int pass = 0; pass < 64; pass++) {
+      const int before = e->aa_backoffs;
+      if (for_gradients && aa_reserve(e, tree_count, true)) return 1;
+      if (aa_reserve(e, tree_count, false)) return 1;
+      if (e->aa_backoffs == before) return 0;
+    }
+    return fail("the partial-vector arena could not be reserved: the budget kept shrinking");
   }
   // Everything a later *_device call over `tree_count` trees can need -- with or without
   // rescaling, with the engine's substitution-gradient setting --, so that such a call
@@ -1099,7 +1109,9 @@ int32_t mi_engine_gradients_unrooted_reduced_device(
   ra.tree_weights = tree_weights;
   ra.out_sums = out_sums;
   ra.out_index_gradient = out_index_gradient;
-  launch_vi_reduce(ra, s);
+  const size_t ws = vi_reduce_workspace_bytes((long)T * e->N, index_count);
+  if (e->red_sort.ensure(ws)) return 1;
+  if (launch_vi_reduce(ra, e->red_sort.ptr, ws, s)) return fail("the index sort of the reduction could not be launched");
   HIP_TRY(hipGetLastError());
   return 0;
 }

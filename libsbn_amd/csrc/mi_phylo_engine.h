@@ -148,7 +148,7 @@ struct mi_engine {
   int shard_mode = 0;
   std::vector<double> shard_sums;  // per-shard partial results (pattern shards, fused sums)
   // fused reductions (mi_engine_gradients_unrooted_reduced*)
-  Buffer in_index, in_weights, out_reduced, red_ll, red_g, red_site;
+  Buffer in_index, in_weights, out_reduced, red_ll, red_g, red_site, red_sort;
   // staging for the host-pointer entry points
   Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
       in_ratios, out_ll, out_a, out_b, out_site, out_subst;

@@ -254,7 +254,11 @@ struct ViReduceArgs {
   double* out_sums;                // [2]
   double* out_index_gradient;      // [index_count]
 };
-void launch_vi_reduce(const ViReduceArgs& a, hipStream_t s);
+// mi_vi_reduce.hip: stable sort of the entries by index + one ordered sum per run.  The
+// workspace (vi_reduce_workspace_bytes) holds the keys, the entry numbers and the sort's
+// temporary storage; returns nonzero if the sort could not be enqueued.
+size_t vi_reduce_workspace_bytes(long entries, int index_count);
+int launch_vi_reduce(const ViReduceArgs& a, void* workspace, size_t workspace_bytes, hipStream_t s);
 bool reduce_tiles_fits(int N);
 void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s);
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);

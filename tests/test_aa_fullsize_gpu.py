@@ -133,6 +133,48 @@ def test_budget_backs_off_when_the_device_cannot_give_the_arena(swag, swag_engin
     eng.close()
 
 
+def test_reserve_after_a_back_off_leaves_nothing_to_allocate(monkeypatch):
+    """mi_engine_reserve of a 20-state gradient engine reserves the gradient shape
+    and then the log-likelihood shape; a back-off in the second used to free the first, so a
+    later *_device gradient call allocated again (possibly inside a hipGraph capture).  With a
+    1 TB budget and 2000 trees of 128 taxa x 5 000 patterns (0.4 GB of vectors per gradient
+    tree: 810 GB > the device) the reservation must back off -- and afterwards neither a
+    gradient nor a log-likelihood *_device call may change the back-off count or the free
+    device memory."""
+    import torch
+    rng = np.random.default_rng(77)
+    n, P, T = 128, 5000, 2000
+    tips, w = A.random_aa_alignment(n, P, rng)
+    p4, b4 = TU.random_trees(n, 4, rng)
+    pids, bls = np.tile(p4, (T // 4, 1)), np.tile(b4, (T // 4, 1))
+    pr = np.ones((T, 2))
+    monkeypatch.setenv("MI_PHYLO_PLV_BYTES", str(1 << 40))
+    eng = _engine(tips, w)
+    eng.reserve(T, True)
+    backoffs = eng.last_call_launches()[1]
+    assert backoffs >= 1
+    dev = torch.device("cuda", 0)
+    d_pid, d_bl, d_pr = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (pids, bls, pr))
+    ll = torch.empty(T, dtype=torch.float64, device=dev)
+    g = torch.empty((T, 2 * n - 1), dtype=torch.float64, device=dev)
+    site = torch.empty(T, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    Tc = 64  # (a call over fewer trees than were reserved: nothing may grow)
+    eng.gradients_device(None, Tc, d_pid.data_ptr(), d_bl.data_ptr(), d_pr.data_ptr(),
+                         ll.data_ptr(), g.data_ptr(), site.data_ptr(), None)
+    eng.check_status()
+    g_ll = ll[:Tc].cpu().numpy().copy()
+    eng.log_likelihoods_device(None, Tc, d_pid.data_ptr(), d_bl.data_ptr(), d_pr.data_ptr(),
+                               ll.data_ptr())
+    eng.check_status()
+    torch.cuda.synchronize()
+    assert eng.last_call_launches()[1] == backoffs
+    assert torch.cuda.mem_get_info()[0] == free_before
+    assert np.array_equal(g_ll[:4], g_ll[4:8]) and _rel(ll[:Tc].cpu().numpy(), g_ll) <= 1e-13
+    eng.close()
+
+
 @pytest.mark.parametrize("gradient", [True, False])
 def test_forced_arena_chunks_are_bit_identical_to_one_launch(gradient, monkeypatch):
     """128 taxa x 5 000 patterns, five trees, MI_PHYLO_PLV_BYTES sized for two evaluations per

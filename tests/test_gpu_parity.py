@@ -776,6 +776,34 @@ def test_random_rooted_vs_oracle():
             1e-9 * max(1.0, abs(og["site_model"][t]))
 
 
+def test_degenerate_rooted_tree_poisons_only_what_the_reference_poisons():
+    """the register form of the rooted recurrences mapped a leaf child to node 0
+    and multiplied by a zero coefficient; with a height on its bound at the first internal
+    node (1 / (h - bound) = inf) that turned 0 x inf into NaN at every node with a tip child.
+    The leaf term is now selected away: non-finite entries appear exactly where the reference's
+    loops (rooted_gradient_transforms.cpp:47-64) put them, all others match the oracle."""
+    rng = np.random.default_rng(17)
+    n, P = 20, 30
+    tips, w = TU.random_alignment(n, P, rng)
+    N = 2 * n - 1
+    pid, bl, dates = TU.clocklike_rooted_tree(n, rng)
+    h, bd, ra = O.time_tree_init(n, pid, bl, dates)
+    bd = bd.copy()
+    bd[n] = h[n]  # node 0 of the recurrences: its log-time derivative is 1 / 0
+    rates = np.full((1, N - 1), 0.05)
+    eng = _engine("JC69", "constant", "strict", tips, w)
+    spec = O.make_spec(n, P, "JC69", "constant", "strict")
+    pr = np.ones((1, 1))
+    args = (pid[None], bl[None], pr, rates, [1], h[None], bd[None], ra[None])
+    with np.errstate(all="ignore"):
+        g = eng.rooted_gradients(*args)[0].gradient["ratios_root_height"]
+        og = O.rooted_gradients(spec, tips, w, *args)["ratios_root_height"][0]
+    assert not np.all(np.isfinite(og)) and np.isfinite(og).sum() >= 3
+    assert np.array_equal(np.isfinite(g), np.isfinite(og)), (g, og)
+    fin = np.isfinite(og)
+    assert _close(g[fin], og[fin])
+
+
 def test_input_errors_are_reported_not_ub():
     rng = np.random.default_rng(3)
     tips, w = TU.random_alignment(5, 10, rng)

@@ -22,7 +22,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--bench-args", default="--steps 20 --warmup 3 --no-cpu-baseline --no-also --no-small-batch")
+    ap.add_argument("--bench-args", default="--steps 20 --warmup 3 --headline-only")
     ap.add_argument("variants", nargs="+")
     args = ap.parse_args()
     variants = []

@@ -11,7 +11,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_$tag
 S=$O/summary
 mkdir -p $S
-H="--steps 20 --warmup 3 --no-cpu-baseline --no-also --no-small-batch"
+H="--steps 20 --warmup 3 --headline-only"
 
 stats() {  # name, command...
   local name=$1; shift
@@ -29,17 +29,17 @@ pmc() {  # name, counter, command...
 
 stats gradient python3 bench.py $H
 stats loglik python3 bench.py --mode loglik $H
-stats small_batch_125 python3 bench.py --trees 125 --steps 50 --warmup 5 --no-cpu-baseline --no-also --no-small-batch
+stats small_batch_125 python3 bench.py --trees 125 --steps 50 --warmup 5 --headline-only
 stats gtr_full python3 tools/bench_gtr.py 1000 10
 stats flua_1 python3 tools/bench_flua.py 1
 stats flua_1000 python3 tools/bench_flua.py 1000
 stats aa_T1 python3 tools/bench_aa.py --trees 1 --steps 3
 stats aa_T8 python3 tools/bench_aa.py --trees 8 --steps 3
 
-pmc pmc_fetch_gradient FETCH_SIZE python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-small-batch
-pmc pmc_write_gradient WRITE_SIZE python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-small-batch
-pmc pmc_fetch_loglik FETCH_SIZE python3 bench.py --mode loglik --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-small-batch
-pmc pmc_write_loglik WRITE_SIZE python3 bench.py --mode loglik --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-small-batch
+pmc pmc_fetch_gradient FETCH_SIZE python3 bench.py --steps 3 --warmup 1 --headline-only
+pmc pmc_write_gradient WRITE_SIZE python3 bench.py --steps 3 --warmup 1 --headline-only
+pmc pmc_fetch_loglik FETCH_SIZE python3 bench.py --mode loglik --steps 3 --warmup 1 --headline-only
+pmc pmc_write_loglik WRITE_SIZE python3 bench.py --mode loglik --steps 3 --warmup 1 --headline-only
 for T in 1 8; do
   pmc aa_T${T}_pmc_fetch FETCH_SIZE python3 tools/bench_aa.py --trees $T --steps 2
   pmc aa_T${T}_pmc_write WRITE_SIZE python3 tools/bench_aa.py --trees $T --steps 2

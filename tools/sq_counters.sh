@@ -11,7 +11,7 @@ i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_MFMA" "SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM"; do
   i=$((i+1))
   rm -rf gpurun_out/sq_pass$i
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/sq_pass$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-small-batch "$@" > gpurun_out/sq_pass$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/sq_pass$i -- python3 bench.py --steps 3 --warmup 1 --headline-only "$@" > gpurun_out/sq_pass$i.log 2>&1
 done
 mkdir -p "$(dirname "$out")"
 python3 - "$out" <<'PY'

@@ -94,6 +94,12 @@ bool matrix_core_gradient(const mi_engine* e, bool rescaling) {
          (gradient_mfma_groups(e->K) == 1 || !loglik_kernel_is_valu(e, rescaling));
 }
 
+// Can calls of this engine take the third-generation walk (kernels_walk3.hip)?  (Per call it
+// also needs the stored vectors in LDS and no analytic substitution gradient.)
+bool walk3_possible(const mi_engine* e) {
+  return e->walk2 && e->walk3 && e->have_tip_codes && gradient_walk_lut_applies(e->K);
+}
+
 size_t plv_bytes_per_eval(const mi_engine* e) {
   return (size_t)(e->n - 1) * e->K * e->tiles * kTile * 4 * sizeof(double);
 }
@@ -114,7 +120,8 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
   if (analytic && e->phi.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
   if (gradient && e->walk2) {
     // matrices in the walk's order, per gradient evaluation (kernels_walk.hip)
-    const size_t per = gradient_walk_mats_bytes_per_eval(n, e->K);
+    const size_t per = std::max(gradient_walk_mats_bytes_per_eval(n, e->K),
+                                walk3_possible(e) ? gradient_walk_lut_mats_bytes_per_eval(n) : 0);
     if (e->mmats.ensure(per * (size_t)c.Eg)) return 1;
     if (analytic && e->mphi.ensure(per / 2 * (size_t)c.Eg)) return 1;
   }
@@ -210,6 +217,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // (a call of a few trees keeps its stored vectors in LDS however large the tree)
   const bool arena = mfma && use_arena(e, d.rescaling, analytic, (size_t)T * (size_t)g_tiles);
   const bool walk2 = mfma && e->walk2;
+  const bool walk3 = walk2 && walk3_possible(e) && !arena && !analytic && groups == 1;
   if (arena)
     launch_macro_slots(e->macros.as<MacroEntry>(), e->arena_macros.as<MacroEntry>(),
                        e->macro_count.as<int32_t>(), n, T, e->slot_need.as<int32_t>(),
@@ -273,6 +281,13 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     tm.bl_eff = e->bl_eff.as<double>();
     tm.macros = walk_macros;
     tm.macro_count = e->macro_count.as<int32_t>();
+    if (walk3) {
+      tm.mmats = e->mmats.as<double>() +
+                 (size_t)grad_begin * (gradient_walk_lut_mats_bytes_per_eval(n) / sizeof(double));
+      tm.mphi = nullptr;
+      launch_transition_lut(tm, s);
+      return;
+    }
     const size_t per = gradient_walk_mats_bytes_per_eval(n, e->K) / sizeof(double);
     tm.mmats = e->mmats.as<double>() + (size_t)grad_begin * per;
     tm.mphi = analytic ? e->mphi.as<double>() + (size_t)grad_begin * (per / 2) : nullptr;
@@ -304,6 +319,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.mphi = e->mphi.as<double>();
   la.tip_states = e->tip_states.as<int8_t>();
   la.tip_masks = e->have_tip_masks ? e->tip_masks.as<uint8_t>() : nullptr;
+  la.tip_codes = e->have_tip_codes ? e->tip_codes.as<uint8_t>() : nullptr;
   la.tip_partials = e->spec.use_tip_states ? nullptr : e->tip_partials.as<double>();
   la.weights = e->weights.as<double>();
   la.ll_part = e->ll_part.as<double>();
@@ -346,7 +362,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
           g.site_exp = e->site_exp.as<int32_t>();
           launch_loglik(g, part, d.rescaling, e->max_slots, s);
         }
-        if (walk2) launch_gradient_walk(g, part, d.rescaling, analytic, s);
+        if (walk3) launch_gradient_walk_lut(g, part, d.rescaling, s);
+        else if (walk2) launch_gradient_walk(g, part, d.rescaling, analytic, s);
         else launch_gradient_mfma(g, part, d.rescaling, analytic, s);
       }
       return;
@@ -377,7 +394,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     PROF_MARK(e, marks, 3, s);
     if (fd_pass) loglik_range(T, 16 * T);
     if (site_pass) grad_range(17 * T, T, T);
-    e->dominant = walk2 ? gradient_walk_kernel_name()
+    e->dominant = walk3 ? gradient_walk_lut_kernel_name()
+                  : walk2 ? gradient_walk_kernel_name()
                         : (mfma ? gradient_mfma_kernel_name() : gradient_kernel_name());
   }
   e->prof_first_launch_evals = T;
@@ -658,7 +676,10 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   // waves per CU (fluA, K = 1: 5 instead of 8); then the first generation stays.
   // MI_PHYLO_GRADIENT_WALK=v1|v2 forces one.
   e->walk2 = gradient_walk_waves_per_cu(e->n, e->K) >= gradient_mfma_waves_per_cu(e->n, e->K);
-  if (const char* env = getenv("MI_PHYLO_GRADIENT_WALK")) e->walk2 = std::string(env) != "v1";
+  if (const char* env = getenv("MI_PHYLO_GRADIENT_WALK")) {
+    e->walk2 = std::string(env) != "v1";
+    e->walk3 = std::string(env) != "v1" && std::string(env) != "v2";
+  }
   if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH")) {  // force one gradient kernel
     const std::string v(env);
     e->gradient_path = v == "hbm" ? 2 : v == "mfma" ? 3 : 0;
@@ -774,6 +795,27 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
       }
     }
     if (e->have_tip_masks && upload(e->tip_masks, masks.data(), np, e->stream)) return cleanup_fail(1);
+    // The same tips as byte offsets of a state's entry in the third-generation walk's tip
+    // tables (kernels_walk3.hip): 16 x state, 64 for the all-ones vector.  Only the five
+    // vectors SitePattern produces have that form (site_pattern.cpp:117-131); an engine with
+    // any other 0/1 vector keeps the mask kernels.  (+16 bytes: the kernel reads 12-byte
+    // groups as three words.)
+    if (e->have_tip_masks) {
+      std::vector<uint8_t> codes(np + 16, 64);
+      e->have_tip_codes = true;
+      for (size_t i = 0; i < np && e->have_tip_codes; i++) {
+        switch (masks[i]) {
+          case 1: codes[i] = 0; break;
+          case 2: codes[i] = 16; break;
+          case 4: codes[i] = 32; break;
+          case 8: codes[i] = 48; break;
+          case 15: codes[i] = 64; break;
+          default: e->have_tip_codes = false;
+        }
+      }
+      if (e->have_tip_codes && upload(e->tip_codes, codes.data(), codes.size(), e->stream))
+        return cleanup_fail(1);
+    }
   }
   }
   if (upload(e->weights, pattern_weights, (size_t)e->P, e->stream)) return cleanup_fail(1);
@@ -792,7 +834,7 @@ void mi_engine_destroy(mi_engine* e) {
     (void)hipStreamSynchronize(e->stream);
   }
   for (Buffer* b :
-       {&e->tip_states, &e->tip_partials, &e->tip_masks, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
+       {&e->tip_states, &e->tip_partials, &e->tip_masks, &e->tip_codes, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
         &e->arena_macros, &e->slot_need,
         &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->mmats, &e->mphi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,

@@ -128,8 +128,9 @@ struct mi_engine {
   std::vector<Block> blocks;
   hipStream_t stream = nullptr;
   // static device data
-  Buffer tip_states, tip_partials, tip_masks, weights;
+  Buffer tip_states, tip_partials, tip_masks, tip_codes, weights;
   bool have_tip_masks = false;  // every tip vector is 0/1: the matrix-core kernel can run
+  bool have_tip_codes = false;  // ... and one-hot or all ones: the third-generation walk can run
   // per-call workspace
   Buffer arena_macros, slot_need, tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, mmats, mphi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
       ll_sum, g_sum, status;
@@ -142,6 +143,7 @@ struct mi_engine {
   bool analytic_subst = false;       // MI_PHYLO_SUBST_GRADIENT=analytic (opt-in)
   int gradient_path = 0;  // 0 auto, 2 hbm, 3 mfma (MI_PHYLO_GRADIENT_PATH)
   bool walk2 = true;      // second-generation matrix-core gradient walk (MI_PHYLO_GRADIENT_WALK=v1: first)
+  bool walk3 = true;      // third generation where it applies (tip children looked up; MI_PHYLO_GRADIENT_WALK=v2: off)
   // a sharded handle (mi_engine_create_sharded): the per-device / per-shard engines it
   // drives; such a handle owns no device memory itself
   std::vector<mi_engine*> shards;

@@ -113,6 +113,7 @@ struct LikArgs {
   const double* mphi;
   const int8_t* tip_states;    // [n][P]
   const uint8_t* tip_masks;    // [n][P] bit s: compatible with state s (matrix-core gradient)
+  const uint8_t* tip_codes;    // [n][P] 16 x state, 64 = gap (third-generation walk: byte offset of the state's table entry)
   const double* tip_partials;  // [n][P][4] or nullptr
   const double* weights;       // [P]
   double* ll_part;             // [E][tiles]
@@ -205,6 +206,12 @@ size_t gradient_walk_lds_bytes(int n, int K, bool rescale, bool subst);
 size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots);
 size_t gradient_walk_mats_bytes_per_eval(int n, int K);
 const char* gradient_walk_kernel_name();
+// kernels_walk3.hip: the third-generation walk (tip children are table look-ups)
+size_t gradient_walk_lut_mats_bytes_per_eval(int n);
+void launch_transition_lut(const TransitionMacroArgs& a, hipStream_t s);
+bool gradient_walk_lut_applies(int K);
+void launch_gradient_walk_lut(const LikArgs& a, int count, bool rescale, hipStream_t s);
+const char* gradient_walk_lut_kernel_name();
 // waves per CU each generation's LDS footprint allows for this tree size and category count
 int gradient_walk_waves_per_cu(int n, int K);
 int gradient_mfma_waves_per_cu(int n, int K);

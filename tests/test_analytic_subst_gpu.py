@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 # categories).  Either name means "the matrix-core path ran, not the HBM-streamed fallback".
 _FORCED = os.environ.get("MI_PHYLO_GRADIENT_WALK")
 WALK_KERNEL = (("gradient_mfma_kernel",) if _FORCED == "v1" else ("gradient_walk_kernel",)
-               if _FORCED == "v2" else ("gradient_mfma_kernel", "gradient_walk_kernel"))
+               if _FORCED == "v2" else ("gradient_mfma_kernel", "gradient_walk_kernel",
+                                        "gradient_walk_lut_kernel"))
 
 
 @pytest.fixture

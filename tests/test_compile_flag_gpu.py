@@ -35,7 +35,7 @@ def grads(tag, eng, pr, **kw):
     for k in g[0].gradient:
         out[tag + "." + k] = np.stack([x.gradient[k] for x in g])
 jc = np.ones((T, 2)); jc[:, 0] = rng.uniform(0.4, 1.6, T)
-for walk in ("v2", "v1"):
+for walk in ("v3", "v2", "v1"):
     os.environ["MI_PHYLO_GRADIENT_WALK"] = walk
     for store in ("", "arena"):
         if store: os.environ["MI_PHYLO_GRADIENT_STORE"] = store
@@ -43,6 +43,7 @@ for walk in ("v2", "v1"):
         eng = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w)
         for resc in (False, True):
             grads(f"jc.{walk}.{store}.{int(resc)}", eng, jc, rescaling=resc)
+            assert walk != "v3" or store or eng.last_call_info()[0] == "gradient_walk_lut_kernel"
         out[f"jc.ll.{walk}.{store}"] = eng.log_likelihoods(pids, bls, jc)
         eng.close()
 os.environ.pop("MI_PHYLO_GRADIENT_WALK", None); os.environ.pop("MI_PHYLO_GRADIENT_STORE", None)

@@ -26,13 +26,17 @@ import tree_utils as TU
 
 pytestmark = pytest.mark.gpu
 
-# The matrix-core gradient walk: first generation (kernels_gradient.hip) or second
-# (kernels_walk.hip).  MI_PHYLO_GRADIENT_WALK=v1|v2 forces one; by default the engine takes
-# the second unless its LDS footprint would cost waves per CU (fewer than three rate
-# categories).  Either name means "the matrix-core path ran, not the HBM-streamed fallback".
+# The matrix-core gradient walk: first generation (kernels_gradient.hip), second
+# (kernels_walk.hip) or third (kernels_walk3.hip: tip children looked up).
+# MI_PHYLO_GRADIENT_WALK=v1|v2 forces one of the first two; by default the engine takes the
+# third where it applies (three or four rate categories, one-hot / all-ones tips, stored
+# vectors in LDS), else the second unless its LDS footprint would cost waves per CU (fewer
+# than three rate categories).  Any name means "the matrix-core path ran, not the HBM-streamed
+# fallback".
 _FORCED = os.environ.get("MI_PHYLO_GRADIENT_WALK")
 WALK_KERNEL = (("gradient_mfma_kernel",) if _FORCED == "v1" else ("gradient_walk_kernel",)
-               if _FORCED == "v2" else ("gradient_mfma_kernel", "gradient_walk_kernel"))
+               if _FORCED == "v2" else ("gradient_mfma_kernel", "gradient_walk_kernel",
+                                        "gradient_walk_lut_kernel"))
 
 RTOL = 1e-10
 
@@ -982,9 +986,11 @@ np.save(sys.argv[1], np.concatenate(out))
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     results = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for walk in ("v1", "v2"):
+        for walk in ("v1", "v2", "v3"):
             for store in ("", "arena"):
                 for subst_mode in ("", "analytic"):
+                    if walk == "v3" and (store or subst_mode):
+                        continue  # (the third generation leaves those calls to the second)
                     env = dict(os.environ, MI_PHYLO_GRADIENT_WALK=walk)
                     env.pop("MI_PHYLO_GRADIENT_STORE", None)
                     env.pop("MI_PHYLO_SUBST_GRADIENT", None)
@@ -1008,6 +1014,13 @@ np.save(sys.argv[1], np.concatenate(out))
             # carries along.  Until that change the two were bit-identical (round 3 history).
             assert np.allclose(a, b, rtol=1e-12, atol=1e-13 * np.max(np.abs(b))), (
                 store, subst_mode, np.max(np.abs(a - b)))
+    # the third generation (where it applies: the three- and four-category engines of this
+    # list; the others fall back to the second) looks tip products up instead of multiplying.
+    # P e_s IS column s of P, and the all-ones vector's row sum is added in index order by the
+    # table builder exactly as the matrix instruction adds its four terms: BIT-IDENTICAL.
+    a, b = results[("v3", "", "")], results[("v2", "", "")]
+    assert a.shape == b.shape and np.isfinite(a).all()
+    assert np.array_equal(a, b), np.max(np.abs(a - b))
 
 
 def test_waves_taking_several_tiles_are_bit_identical_and_match_oracle():
@@ -1053,8 +1066,8 @@ np.save(sys.argv[1], np.concatenate(out))
     got = {}
     with tempfile.TemporaryDirectory() as tmp:
         for tpw in ("1", "2", "3", "8"):
-            env = dict(os.environ, MI_PHYLO_WALK_TILES_PER_WAVE=tpw)
-            for k in ("MI_PHYLO_GRADIENT_WALK", "MI_PHYLO_GRADIENT_STORE", "MI_PHYLO_SUBST_GRADIENT"):
+            env = dict(os.environ, MI_PHYLO_WALK_TILES_PER_WAVE=tpw, MI_PHYLO_GRADIENT_WALK="v2")
+            for k in ("MI_PHYLO_GRADIENT_STORE", "MI_PHYLO_SUBST_GRADIENT"):
                 env.pop(k, None)
             path = os.path.join(tmp, f"{tpw}.npy")
             r = subprocess.run([sys.executable, "-c", code, path], env=env, cwd=repo,

@@ -65,6 +65,19 @@ constexpr unsigned kTwCol = 32;          // LDS bytes per (macro, column): six w
 constexpr unsigned kTStride = 4 * kTwCol;  // per macro: four pattern columns per register
 constexpr unsigned kPos = 1280u, kVisit = 6u * kPos;
 constexpr unsigned kTipCat = 320u, kTipRow = 80u;
+// where a visit issues its scalar loads (slots of the next visit, shape three ahead): at its
+// top, right behind the operand requests and the LDS read of the tip words, or at its end
+#ifndef W3_SCALARS_TOP
+#define W3_SCALARS_TOP 0
+#endif
+constexpr bool kScalarsTop = W3_SCALARS_TOP != 0;
+// when a visit reads the stored vectors of its node and of its stored children from LDS: first
+// thing at its top, BEFORE the operand wait and the next visit's requests (their LDS latency
+// then passes under those), or where the visit's arithmetic needs them
+#ifndef W3_EARLY_LDS
+#define W3_EARLY_LDS 0
+#endif
+constexpr bool kEarlyLds = W3_EARLY_LDS != 0;
 
 // operands of one child of a visit (see fetch_child)
 template <bool PRE>
@@ -366,7 +379,16 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
   struct Child {
     V S, L, xa, xb, Ap, Bp;
   };
-  auto child_S = [&](auto pre_tag, auto jtag, int sh, const auto& o, const Slots& sl, Child& c) {
+  struct Early {  // a visit's early LDS reads: q of its node (pre-order), its stored children
+    V q, l0, l1;
+  };
+  auto early_loads = [&](bool with_q, int sh, const Slots& sl, Early& ea) {
+    if (with_q) ea.q = load_slot(sl.q);
+    if ((sh & 3) == 1) ea.l0 = load_slot(sl.c[0]);
+    if (((sh >> 2) & 3) == 1) ea.l1 = load_slot(sl.c[1]);
+  };
+  auto child_S = [&](auto pre_tag, auto jtag, int sh, const auto& o, const Slots& sl, Child& c,
+                     const Early& ea) {
     constexpr bool PRE = decltype(pre_tag)::value;
     constexpr int J = decltype(jtag)::value;
     constexpr int W = PRE ? 2 : 1;
@@ -379,7 +401,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
       return;
     }
     if (kind == 1) {
-      c.L = load_slot(sl.c[J]);
+      c.L = kEarlyLds ? (J == 0 ? ea.l0 : ea.l1) : load_slot(sl.c[J]);
     } else {
       if (sh & (1 << (10 + 2 * J))) {
         c.Ap = tip_p(pre_tag, o, OA{});
@@ -400,11 +422,11 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
 
   // ================= post-order over the stored nodes, then the root (site likelihood) ====
   auto post_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<false>& o0, const Ops<false>& o1,
-                        int tile_for_ll) {
+                        int tile_for_ll, const Early& ea) {
     constexpr bool ROOT = decltype(root_tag)::value;
     Child c0, c1;
-    child_S(Post{}, J0{}, sh, o0, sl, c0);
-    child_S(Post{}, J1{}, sh, o1, sl, c1);
+    child_S(Post{}, J0{}, sh, o0, sl, c0, ea);
+    child_S(Post{}, J1{}, sh, o1, sl, c1, ea);
     V Lv = mul(c0.S, c1.S);
     if (!ROOT) {
       if (RESCALE) {
@@ -471,35 +493,56 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
     tw = fetch_tw(min(1, M1));
     for (int m = 0; m < M1; m += 2) {
       // ---- visit m (set A) ----
+      Early ea;
+      if (kEarlyLds) early_loads(false, s0, la, ea);
       settle(a0, a1);
       fetch(Post{}, min(m + 1, M1), s1, tw, b0, b1);
       tw = fetch_tw(min(m + 2, M1));
-      post_visit(Inner{}, s0, la, a0, a1, 0);
-      lb = load_slots(min(m + 1, M1));
-      {
-        const int s3 = load_shape(min(m + 3, M1));
-        s0 = s1;
-        s1 = s2;
-        s2 = s3;
+      int s3;
+      if (kScalarsTop) {
+        lb = load_slots(min(m + 1, M1));
+        s3 = load_shape(min(m + 3, M1));
       }
+      post_visit(Inner{}, s0, la, a0, a1, 0, ea);
+      if (!kScalarsTop) {
+        lb = load_slots(min(m + 1, M1));
+        s3 = load_shape(min(m + 3, M1));
+      }
+      s0 = s1;
+      s1 = s2;
+      s2 = s3;
       if (m + 1 < M1) {
         // ---- visit m + 1 (set B) ----
+        Early eb;
+        if (kEarlyLds) early_loads(false, s0, lb, eb);
         settle(b0, b1);
         fetch(Post{}, min(m + 2, M1), s1, tw, a0, a1);
         tw = fetch_tw(min(m + 3, M1));
-        post_visit(Inner{}, s0, lb, b0, b1, 0);
-        la = load_slots(min(m + 2, M1));
-        const int s3 = load_shape(min(m + 4, M1));
+        int s4;
+        if (kScalarsTop) {
+          la = load_slots(min(m + 2, M1));
+          s4 = load_shape(min(m + 4, M1));
+        }
+        post_visit(Inner{}, s0, lb, b0, b1, 0, eb);
+        if (!kScalarsTop) {
+          la = load_slots(min(m + 2, M1));
+          s4 = load_shape(min(m + 4, M1));
+        }
         s0 = s1;
         s1 = s2;
-        s2 = s3;
+        s2 = s4;
       } else {  // M1 odd: the root's operands arrived in set B
         a0 = b0;
         a1 = b1;
         la = lb;
       }
     }
-    post_visit(Root{}, s0, la, a0, a1, tile);
+    {
+      Early ea;
+      if (kEarlyLds) early_loads(false, s0, la, ea);
+      settle(a0, a1);
+      post_visit(Root{}, s0, la, a0, a1, tile, ea);
+    }
   }
 
   // ================= pre-order + edge derivatives =================
@@ -559,14 +602,15 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
     }
     edge_sums(na, nb, m, 2 + 2 * J);
   };
-  auto pre_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<true>& o0, const Ops<true>& o1, int m) {
+  auto pre_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<true>& o0, const Ops<true>& o1, int m,
+                       const Early& ea) {
     constexpr bool ROOT = decltype(root_tag)::value;
     V qv;
     if (ROOT) {
 #pragma unroll
       for (int r = 0; r < R; r++) qv.v[r] = qroot[r];
     } else {
-      qv = load_slot(sl.q);
+      qv = kEarlyLds ? ea.q : load_slot(sl.q);
       if (RESCALE) {
 #pragma unroll
         for (int r = 0; r < R; r++)
@@ -574,8 +618,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
       }
     }
     Child c0, c1;
-    child_S(Pre{}, J0{}, sh, o0, sl, c0);
-    child_S(Pre{}, J1{}, sh, o1, sl, c1);
+    child_S(Pre{}, J0{}, sh, o0, sl, c0, ea);
+    child_S(Pre{}, J1{}, sh, o1, sl, c1, ea);
     V n0, n1;
     child_edges(J0{}, sh, o0, sl, c0, mul(qv, c1.S), m, n0);
     child_edges(J1{}, sh, o1, sl, c1, mul(qv, c0.S), m, n1);
@@ -594,40 +638,65 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
     fetch(Pre{}, M1, s0, tw, a0, a1);
     tw = fetch_tw(dn(M1 - 1));
     {  // ---- visit M1 (the root, set A) ----
+      Early ea;
+      if (kEarlyLds) early_loads(false, s0, la, ea);
       settle(a0, a1);
       fetch(Pre{}, dn(M1 - 1), s1, tw, b0, b1);
       tw = fetch_tw(dn(M1 - 2));
-      pre_visit(Root{}, s0, la, a0, a1, M1);
-      lb = load_slots(dn(M1 - 1));
-      const int s3 = load_shape(dn(M1 - 3));
+      int s3;
+      if (kScalarsTop) {
+        lb = load_slots(dn(M1 - 1));
+        s3 = load_shape(dn(M1 - 3));
+      }
+      pre_visit(Root{}, s0, la, a0, a1, M1, ea);
+      if (!kScalarsTop) {
+        lb = load_slots(dn(M1 - 1));
+        s3 = load_shape(dn(M1 - 3));
+      }
       s0 = s1;
       s1 = s2;
       s2 = s3;
     }
     for (int m = M1 - 1; m >= 0; m -= 2) {
       // ---- visit m (set B) ----
+      Early eb;
+      if (kEarlyLds) early_loads(true, s0, lb, eb);
       settle(b0, b1);
       fetch(Pre{}, dn(m - 1), s1, tw, a0, a1);
       tw = fetch_tw(dn(m - 2));
-      pre_visit(Inner{}, s0, lb, b0, b1, m);
-      la = load_slots(dn(m - 1));
-      {
-        const int s3 = load_shape(dn(m - 3));
-        s0 = s1;
-        s1 = s2;
-        s2 = s3;
+      int s3;
+      if (kScalarsTop) {
+        la = load_slots(dn(m - 1));
+        s3 = load_shape(dn(m - 3));
       }
+      pre_visit(Inner{}, s0, lb, b0, b1, m, eb);
+      if (!kScalarsTop) {
+        la = load_slots(dn(m - 1));
+        s3 = load_shape(dn(m - 3));
+      }
+      s0 = s1;
+      s1 = s2;
+      s2 = s3;
       if (m >= 1) {
         // ---- visit m - 1 (set A) ----
+        Early ea;
+        if (kEarlyLds) early_loads(true, s0, la, ea);
         settle(a0, a1);
         fetch(Pre{}, dn(m - 2), s1, tw, b0, b1);
         tw = fetch_tw(dn(m - 3));
-        pre_visit(Inner{}, s0, la, a0, a1, m - 1);
-        lb = load_slots(dn(m - 2));
-        const int s3 = load_shape(dn(m - 4));
+        int s4;
+        if (kScalarsTop) {
+          lb = load_slots(dn(m - 2));
+          s4 = load_shape(dn(m - 4));
+        }
+        pre_visit(Inner{}, s0, la, a0, a1, m - 1, ea);
+        if (!kScalarsTop) {
+          lb = load_slots(dn(m - 2));
+          s4 = load_shape(dn(m - 4));
+        }
         s0 = s1;
         s1 = s2;
-        s2 = s3;
+        s2 = s4;
       }
     }
   }

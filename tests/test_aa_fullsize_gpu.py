@@ -103,6 +103,26 @@ def test_full_size_log_likelihood_and_gradients_match_oracle(swag, swag_engine_r
     assert _rel([x.gradient["site_model"][0] for x in g], og["site_model"]) <= 1e-10
 
 
+def test_full_size_against_the_beagle_transition_form(swag, swag_engine_results):
+    """VERDICT r3 (parity note 1): the full-size test above lets the ORACLE form its transition
+    matrices the engine's way, I + V expm1(L t) V^-1; BEAGLE's form is V exp(L t) V^-1 (the
+    oracle's default, orc_set_transition_mode(0)).  The two differ by rounding only: the same
+    full-size tree against the default form, same 1e-10 bar (what the small 20-state cases
+    check in test_beagle_transition_form_agrees_too)."""
+    tips, w, pids, bls, pr = swag
+    ll, g, _, _, _ = swag_engine_results
+    ex, fr = _wag()
+    O.set_reversible_model(ex, fr)
+    O.set_transition_mode(0)
+    og = O.unrooted_by_pattern_blocks(A.oracle_spec(N_TAXA, N_PATTERNS, SITE), tips, w, pids, bls,
+                                      pr, rescaling=True, gradient=True, threads=_host_threads())
+    assert _rel(ll, og["log_likelihood"]) <= 1e-10
+    assert _rel([x.log_likelihood for x in g], og["log_likelihood"]) <= 1e-10
+    gb = np.stack([x.gradient["branch_lengths"] for x in g])
+    assert _rel(gb, og["branch_lengths"]) <= 1e-10
+    assert _rel([x.gradient["site_model"][0] for x in g], og["site_model"]) <= 1e-10
+
+
 def test_budget_backs_off_when_the_device_cannot_give_the_arena(swag, swag_engine_results,
                                                                 monkeypatch):
     """24 trees of 16.4 GB of partial vectors each under a budget of 1 TB: the first arena

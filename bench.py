@@ -402,7 +402,8 @@ def final_line(full):
                                      "value_on_one_core", "sample"))
     if full.get("small_batch"):
         out["small_batch"] = _pick(full["small_batch"],
-                                   ("trees", "ms_per_step", "graph_ms_per_step", "kernel_ms"))
+                                   ("trees", "ms_per_step", "graph_ms_per_step", "kernel_ms",
+                                    "graph_with_collective_ms_per_step"))
     if full.get("weak"):
         out["weak"] = _pick(full["weak"], ("value", "ms_per_step", "trees_per_gpu"))
     if full.get("reduced"):
@@ -1368,6 +1369,34 @@ def main():
             assert bool(torch.isfinite(blk.log_likelihoods).all())
         except Exception as exc:  # capture support varies; the eager figure stands
             small["graph_error"] = repr(exc)[:200]
+        if distributed and "graph_error" not in small:
+            # ... and with the step's ONE collective inside the graph (RCCL kernels capture like
+            # any other when they are enqueued on the capturing stream): what a rank of a
+            # strong-scaled run replays per step -- kernels + all-gather, no host launch cost
+            try:
+                gout = torch.empty((world, blk.buffer.numel()), dtype=torch.float64, device=dev)
+                graph2 = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph2, stream=gstream):
+                    cs = torch.cuda.current_stream().cuda_stream
+                    eng.gradients_device(cs, Ts, d_pid.data_ptr(), d_bl.data_ptr(),
+                                         d_par.data_ptr(), blk.log_likelihoods.data_ptr(),
+                                         blk.branch_gradients.data_ptr(),
+                                         blk.extras[0].data_ptr(), None)
+                    sharding.all_gather_result_blocks(blk, out=gout)
+                for _ in range(5):
+                    graph2.replay()
+                torch.cuda.synchronize()
+                e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+                e0.record()
+                for _ in range(100):
+                    graph2.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                small["graph_with_collective_ms_per_step"] = e0.elapsed_time(e1) / 100
+                assert bool(torch.equal(gout[rank], blk.buffer))
+            except Exception as exc:
+                small["graph_with_collective_error"] = repr(exc)[:200]
 
     # ---- the Engine-shaped call (reference: Engine::Gradients, src/engine.cpp:78-92 -- host
     # tree collections in, host vectors out), one GPU: (a) the C ABI's host-pointer entry with

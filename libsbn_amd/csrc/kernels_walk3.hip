@@ -67,10 +67,14 @@ constexpr unsigned kPos = 1280u, kVisit = 6u * kPos;
 constexpr unsigned kTipCat = 320u, kTipRow = 80u;
 // where a visit issues its scalar loads (slots of the next visit, shape three ahead): at its
 // top, right behind the operand requests and the LDS read of the tip words, or at its end
-#ifndef W3_SCALARS_TOP
-#define W3_SCALARS_TOP 0
+// (W3_SCALARS: 0 at the visit's end, 1 at its top, 2 in its middle -- behind the visit's last
+// LDS read, so that no LDS wait of the visit waits for them and they have the rest of the
+// visit to arrive: scalar loads return out of order, any wait for LDS data with one of them
+// in flight is a wait for everything)
+#ifndef W3_SCALARS
+#define W3_SCALARS 0
 #endif
-constexpr bool kScalarsTop = W3_SCALARS_TOP != 0;
+constexpr int kScalars = W3_SCALARS;
 // when a visit reads the stored vectors of its node and of its stored children from LDS: first
 // thing at its top, BEFORE the operand wait and the next visit's requests (their LDS latency
 // then passes under those), or where the visit's arithmetic needs them
@@ -200,7 +204,11 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
     constexpr int OFF = decltype(off_tag)::value;
 #pragma unroll
     for (int r = 0; r < R; r++) {
+#ifdef W3_ABL_COALESCED_TIPS  // (timing experiment, wrong results: every lane its row's entry 0)
+      unsigned voff = lane_tip + ((word >> (8 * r)) & 0x0u);
+#else
       unsigned voff = lane_tip + ((word >> (8 * r)) & 0xffu);
+#endif
       asm volatile("" : "+v"(voff));
       if (PRE) {
         const double2 v = *reinterpret_cast<const double2*>(at + (size_t)voff);
@@ -254,8 +262,16 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
   // So, at the top of a visit: "use" every register of the visit's groups in an empty asm (the
   // compiler puts its vmcnt(0) there: everything older has had a whole visit to arrive), THEN
   // request the next visit's operands; what follows reads asm results and waits no more.
+#ifdef W3_STAMPS
+  long long stamp_wait = 0, stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
   auto settle = [&](auto& o0, auto& o1) {
     constexpr int n = sizeof(o0.x) / sizeof(double);
+#ifdef W3_STAMPS
+    const long long w0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp_wait += __builtin_amdgcn_s_memtime() - w0;
+#endif
 #pragma unroll
     for (int i = 0; i < n; i++) asm volatile("" : "+v"(o0.x[i]));
 #pragma unroll
@@ -422,11 +438,12 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
 
   // ================= post-order over the stored nodes, then the root (site likelihood) ====
   auto post_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<false>& o0, const Ops<false>& o1,
-                        int tile_for_ll, const Early& ea) {
+                        int tile_for_ll, const Early& ea, auto&& mid) {
     constexpr bool ROOT = decltype(root_tag)::value;
     Child c0, c1;
     child_S(Post{}, J0{}, sh, o0, sl, c0, ea);
     child_S(Post{}, J1{}, sh, o1, sl, c1, ea);
+    mid();  // (the visit's LDS reads are behind it)
     V Lv = mul(c0.S, c1.S);
     if (!ROOT) {
       if (RESCALE) {
@@ -499,15 +516,15 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
       fetch(Post{}, min(m + 1, M1), s1, tw, b0, b1);
       tw = fetch_tw(min(m + 2, M1));
       int s3;
-      if (kScalarsTop) {
+      auto req = [&]() {
         lb = load_slots(min(m + 1, M1));
         s3 = load_shape(min(m + 3, M1));
-      }
-      post_visit(Inner{}, s0, la, a0, a1, 0, ea);
-      if (!kScalarsTop) {
-        lb = load_slots(min(m + 1, M1));
-        s3 = load_shape(min(m + 3, M1));
-      }
+      };
+      if (kScalars == 1) req();
+      post_visit(Inner{}, s0, la, a0, a1, 0, ea, [&]() {
+        if (kScalars == 2) req();
+      });
+      if (kScalars == 0) req();
       s0 = s1;
       s1 = s2;
       s2 = s3;
@@ -519,15 +536,15 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
         fetch(Post{}, min(m + 2, M1), s1, tw, a0, a1);
         tw = fetch_tw(min(m + 3, M1));
         int s4;
-        if (kScalarsTop) {
+        auto req = [&]() {
           la = load_slots(min(m + 2, M1));
           s4 = load_shape(min(m + 4, M1));
-        }
-        post_visit(Inner{}, s0, lb, b0, b1, 0, eb);
-        if (!kScalarsTop) {
-          la = load_slots(min(m + 2, M1));
-          s4 = load_shape(min(m + 4, M1));
-        }
+        };
+        if (kScalars == 1) req();
+        post_visit(Inner{}, s0, lb, b0, b1, 0, eb, [&]() {
+          if (kScalars == 2) req();
+        });
+        if (kScalars == 0) req();
         s0 = s1;
         s1 = s2;
         s2 = s4;
@@ -541,7 +558,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
       Early ea;
       if (kEarlyLds) early_loads(false, s0, la, ea);
       settle(a0, a1);
-      post_visit(Root{}, s0, la, a0, a1, tile, ea);
+      post_visit(Root{}, s0, la, a0, a1, tile, ea, [] {});
     }
   }
 
@@ -603,7 +620,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
     edge_sums(na, nb, m, 2 + 2 * J);
   };
   auto pre_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<true>& o0, const Ops<true>& o1, int m,
-                       const Early& ea) {
+                       const Early& ea, auto&& mid) {
     constexpr bool ROOT = decltype(root_tag)::value;
     V qv;
     if (ROOT) {
@@ -620,6 +637,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
     Child c0, c1;
     child_S(Pre{}, J0{}, sh, o0, sl, c0, ea);
     child_S(Pre{}, J1{}, sh, o1, sl, c1, ea);
+    mid();  // (the visit's LDS reads are behind it)
     V n0, n1;
     child_edges(J0{}, sh, o0, sl, c0, mul(qv, c1.S), m, n0);
     child_edges(J1{}, sh, o1, sl, c1, mul(qv, c0.S), m, n1);
@@ -644,15 +662,15 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
       fetch(Pre{}, dn(M1 - 1), s1, tw, b0, b1);
       tw = fetch_tw(dn(M1 - 2));
       int s3;
-      if (kScalarsTop) {
+      auto req = [&]() {
         lb = load_slots(dn(M1 - 1));
         s3 = load_shape(dn(M1 - 3));
-      }
-      pre_visit(Root{}, s0, la, a0, a1, M1, ea);
-      if (!kScalarsTop) {
-        lb = load_slots(dn(M1 - 1));
-        s3 = load_shape(dn(M1 - 3));
-      }
+      };
+      if (kScalars == 1) req();
+      pre_visit(Root{}, s0, la, a0, a1, M1, ea, [&]() {
+        if (kScalars == 2) req();
+      });
+      if (kScalars == 0) req();
       s0 = s1;
       s1 = s2;
       s2 = s3;
@@ -665,15 +683,15 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
       fetch(Pre{}, dn(m - 1), s1, tw, a0, a1);
       tw = fetch_tw(dn(m - 2));
       int s3;
-      if (kScalarsTop) {
+      auto req = [&]() {
         la = load_slots(dn(m - 1));
         s3 = load_shape(dn(m - 3));
-      }
-      pre_visit(Inner{}, s0, lb, b0, b1, m, eb);
-      if (!kScalarsTop) {
-        la = load_slots(dn(m - 1));
-        s3 = load_shape(dn(m - 3));
-      }
+      };
+      if (kScalars == 1) req();
+      pre_visit(Inner{}, s0, lb, b0, b1, m, eb, [&]() {
+        if (kScalars == 2) req();
+      });
+      if (kScalars == 0) req();
       s0 = s1;
       s1 = s2;
       s2 = s3;
@@ -685,21 +703,26 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
         fetch(Pre{}, dn(m - 2), s1, tw, b0, b1);
         tw = fetch_tw(dn(m - 3));
         int s4;
-        if (kScalarsTop) {
+        auto req = [&]() {
           lb = load_slots(dn(m - 2));
           s4 = load_shape(dn(m - 4));
-        }
-        pre_visit(Inner{}, s0, la, a0, a1, m - 1, ea);
-        if (!kScalarsTop) {
-          lb = load_slots(dn(m - 2));
-          s4 = load_shape(dn(m - 4));
-        }
+        };
+        if (kScalars == 1) req();
+        pre_visit(Inner{}, s0, la, a0, a1, m - 1, ea, [&]() {
+          if (kScalars == 2) req();
+        });
+        if (kScalars == 0) req();
         s0 = s1;
         s1 = s2;
         s2 = s4;
       }
     }
   }
+#ifdef W3_STAMPS
+  if (lane == 0 && (job_eval % 250) == 3 && (tile % 39) == 5)
+    printf("walk3 stamps eval %d tile %d: operand waits %lld of %lld ticks (100 MHz)\n", job_eval, tile,
+           stamp_wait, (long long)__builtin_amdgcn_s_memtime() - stamp_t0);
+#endif
   __syncthreads();
   // positions that do not exist in a macro are never written nor read downstream
   const int gwidth = Mmax * kMacroPositions * 2;

@@ -71,6 +71,12 @@ __device__ __forceinline__ double row_ror_add(double v) {
 // bytes per (macro, column) of the tip words in LDS: six words, padded to 32 (one ds_read_b128
 // + one ds_read_b64; dense with three ds_read_b64 measured the same)
 constexpr unsigned kTwCol = 32;
+// ... and in the COMPACT form (fewer than three rate categories: a wave then has 8 or 16 pattern
+// columns, and 32 bytes per column and macro cost waves per CU -- fluA, K = 1: 17 KB of tip
+// words, 5 waves instead of 8): six 16-bit fields per column, three 4-bit masks (one per
+// register r) each -- 12 bytes; a tip vector is then v_bfe at (16 (position & 1) + 4 r + hi) of
+// word (position >> 1).  (Round 4; K < 3 engines ran the first-generation kernel before.)
+constexpr unsigned kTwColCompact = 12;
 
 // configuration of one child of a macro (from the shape word)
 enum ChildCfg { kTip = 0, kStored = 1, kUss = 2, kUts = 3, kUst = 4, kUtt = 5 };
@@ -80,9 +86,11 @@ __device__ __forceinline__ int child_cfg(int sh, int j) {
   return kind < 2 ? kind : 2 + tips;
 }
 
-template <int R, bool RESCALE, bool SUBST, bool ARENA>
+template <int R, bool RESCALE, bool SUBST, bool ARENA, bool COMPACT>
 __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
+  static_assert(!COMPACT || R == 3, "three 4-bit masks per 16-bit field");
+  constexpr unsigned kCol = COMPACT ? kTwColCompact : kTwCol;
   extern __shared__ double wlds[];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
@@ -191,9 +199,6 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     double f[6], tr[6];
     double ph[SUBST ? 6 : 1];
   };
-  struct Tw {
-    uint32_t w[6];
-  };
   struct Slots {  // scalars (s_load_dwordx8)
     int q, c[2], g[4], dst;
   };
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     const cint_ptr p = mw + m * 16 + 8;
     return Slots{p[0], {p[1], p[2]}, {p[3], p[4], p[5], p[6]}, p[7]};
   };
-  const unsigned tw_lane = (unsigned)col * kTwCol;
+  const unsigned tw_lane = (unsigned)col * kCol;
   auto fetch = [&](int m, bool pre) {  // m: scalar
     Mats mt;
     // scalar base of the visit + this lane's 32-bit offset + constants (the offset is made
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   // -- re-used, macro by macro, for that macro's edge sums [position][branch, site] once its
   // tip words are in registers -- | SUBST: four root sums | vectors [slot][r][lane] |
   // RESCALE: exponents
-  const unsigned tstride = (unsigned)ppr * kTwCol;  // bytes per macro (>= 96: ppr >= 4)
+  const unsigned tstride = (unsigned)ppr * kCol;  // bytes per macro (>= 96: it also takes the macro's edge sums)
   char* const lds0 = reinterpret_cast<char*>(wlds);
   const unsigned tips_bytes = (unsigned)Mmax * tstride + (SUBST ? 32u : 0u);
   double* const xroot = reinterpret_cast<double*>(lds0 + (unsigned)Mmax * tstride);
@@ -275,6 +280,33 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     auto stage_bytes = [&](int j, int node) {  // any layout, columns clamped to the last pattern
       const int m = j / 6, pos = j - m * 6;
       const uint8_t* src = a.tip_masks + (size_t)node * a.P;
+      if (COMPACT) {
+        // one 16-bit field per column: the masks of its R patterns (ppr apart), 4 bits each
+        char* dst = lds0 + (unsigned)m * tstride + (unsigned)pos * 2u;
+        if (Kp == 1 && tile_start + 48 <= a.P) {  // whole tile: its 48 bytes as twelve words
+          uint32_t d[12];
+#pragma unroll
+          for (int i = 0; i < 12; i++) d[i] = *reinterpret_cast<const uint32_t*>(src + tile_start + 4 * i);
+#pragma unroll
+          for (int c = 0; c < 16; c++) {
+            uint32_t f = 0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) f |= ((d[4 * r + (c >> 2)] >> (8 * (c & 3))) & 0xfu) << (4 * r);
+            *reinterpret_cast<uint16_t*>(dst + c * kTwColCompact) = (uint16_t)f;
+          }
+          return;
+        }
+        for (int c = 0; c < ppr; c++) {
+          uint32_t f = 0;
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            const int q = tile_start + r * ppr + c;
+            f |= ((uint32_t)src[q < a.P ? q : a.P - 1] & 0xfu) << (4 * r);
+          }
+          *reinterpret_cast<uint16_t*>(dst + c * kTwColCompact) = (uint16_t)f;
+        }
+        return;
+      }
       char* dst = lds0 + (unsigned)m * tstride + (unsigned)pos * 4u;
       for (int q = 0; q < TP; q++) {
         const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
@@ -373,18 +405,28 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     for (int r = 0; r < R; r++) z.v[r] = x.v[r] * y.v[r];
     return z;
   };
-  auto tipv = [&](uint32_t w) {
+  struct Tw {
+    uint32_t w[6];  // (COMPACT: w[0..2], two positions per word)
+  };
+  // the 0/1 vector of the tip at position POS of a visit
+  auto tipv = [&](const Tw& tw, auto pos_tag) {
+    constexpr int POS = decltype(pos_tag)::value;
     V x;
 #pragma unroll
     for (int r = 0; r < R; r++)
-      x.v[r] = (double)__builtin_amdgcn_ubfe(w, (uint32_t)(8 * r + hi), 1u);
+      x.v[r] = COMPACT ? (double)__builtin_amdgcn_ubfe(tw.w[POS >> 1], (uint32_t)(16 * (POS & 1) + 4 * r + hi), 1u)
+                       : (double)__builtin_amdgcn_ubfe(tw.w[POS], (uint32_t)(8 * r + hi), 1u);
     return x;
   };
 
   auto fetch_tw = [&](int m) {  // the six tip words of visit m (LDS)
     Tw t;
     const char* twp = lds0 + ((unsigned)m * tstride + tw_lane);
-    if (kTwCol == 32) {
+    if (COMPACT) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) t.w[j] = *reinterpret_cast<const uint32_t*>(twp + 4 * j);
+      t.w[3] = t.w[4] = t.w[5] = 0;
+    } else if (kTwCol == 32) {
       const uint4 w4 = *reinterpret_cast<const uint4*>(twp);
       const uint2 w2 = *reinterpret_cast<const uint2*>(twp + 16);
       t.w[0] = w4.x;
@@ -423,9 +465,9 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     const bool fa = ARENA && pre;
     const int kind = (sh >> (2 * J)) & 3;
     if (kind == 2) {
-      if (sh & (1 << (10 + 2 * J))) c.xa = tipv(tw.w[2 + 2 * J]);
+      if (sh & (1 << (10 + 2 * J))) c.xa = tipv(tw, std::integral_constant<int, 2 + 2 * J>{});
       else c.xa = fa ? pa : load_slot(sl.g[2 * J]);
-      if (sh & (1 << (11 + 2 * J))) c.xb = tipv(tw.w[3 + 2 * J]);
+      if (sh & (1 << (11 + 2 * J))) c.xb = tipv(tw, std::integral_constant<int, 3 + 2 * J>{});
       else c.xb = fa ? pb : load_slot(sl.g[2 * J + 1]);
       c.Ap = mm(mt.f[2 + 2 * J], c.xa);
       c.Bp = mm(mt.f[3 + 2 * J], c.xb);
@@ -433,7 +475,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
     } else if (kind == 1) {
       c.L = fa ? pa : load_slot(sl.c[J]);
     } else {
-      c.L = tipv(tw.w[J]);
+      c.L = tipv(tw, std::integral_constant<int, J>{});
     }
   };
   using J0 = std::integral_constant<int, 0>;
@@ -904,7 +946,9 @@ __global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMa
 
 size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
-  size_t bytes = (size_t)max_macros(n) * (16 / kp) * kTwCol + (subst ? 32 : 0) +
+  // (compact tip words for fewer than three categories -- not in the analytic variant)
+  const unsigned col = (kp < 4 && !subst) ? kTwColCompact : kTwCol;
+  size_t bytes = (size_t)max_macros(n) * (16 / kp) * col + (subst ? 32 : 0) +
                  sizeof(double) * (size_t)slots * kLlR * kTile;
   if (rescale) bytes += ((sizeof(int16_t) * (size_t)max_stored(n) * kLlR * (16 / kp) + 7) / 8) * 8;
   return bytes;
@@ -923,18 +967,21 @@ void launch_transition_macro(const TransitionMacroArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(transition_macro_kernel, grid, dim3(kTmBlock), sizeof(int) * (size_t)(a.N - 1), s, a);
 }
 
-template <bool RESCALE, bool SUBST, bool ARENA>
+template <bool RESCALE, bool SUBST, bool ARENA, bool COMPACT>
 static void launch_walk_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  allow_large_lds(reinterpret_cast<const void*>(gradient_walk_kernel<kLlR, RESCALE, SUBST, ARENA>), lds);
-  hipLaunchKernelGGL((gradient_walk_kernel<kLlR, RESCALE, SUBST, ARENA>), grid, dim3(kTile), lds, s, a);
+  allow_large_lds(reinterpret_cast<const void*>(gradient_walk_kernel<kLlR, RESCALE, SUBST, ARENA, COMPACT>), lds);
+  hipLaunchKernelGGL((gradient_walk_kernel<kLlR, RESCALE, SUBST, ARENA, COMPACT>), grid, dim3(kTile), lds, s, a);
 }
 template <bool ARENA>
 static void launch_walk_store(const LikArgs& a, dim3 grid, size_t lds, bool rescale, bool subst,
                               hipStream_t s) {
-  if (rescale && subst) launch_walk_variant<true, true, ARENA>(a, grid, lds, s);
-  else if (rescale) launch_walk_variant<true, false, ARENA>(a, grid, lds, s);
-  else if (subst) launch_walk_variant<false, true, ARENA>(a, grid, lds, s);
-  else launch_walk_variant<false, false, ARENA>(a, grid, lds, s);
+  const bool compact = a.kp < 4 && !subst;  // (as gradient_walk_lds_bytes_for sizes the tip words)
+  if (rescale && subst) launch_walk_variant<true, true, ARENA, false>(a, grid, lds, s);
+  else if (subst) launch_walk_variant<false, true, ARENA, false>(a, grid, lds, s);
+  else if (rescale && compact) launch_walk_variant<true, false, ARENA, true>(a, grid, lds, s);
+  else if (rescale) launch_walk_variant<true, false, ARENA, false>(a, grid, lds, s);
+  else if (compact) launch_walk_variant<false, false, ARENA, true>(a, grid, lds, s);
+  else launch_walk_variant<false, false, ARENA, false>(a, grid, lds, s);
 }
 void launch_gradient_walk(const LikArgs& a_in, int count, bool rescale, bool subst, hipStream_t s) {
   if (count <= 0) return;

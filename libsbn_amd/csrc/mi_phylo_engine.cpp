@@ -675,7 +675,12 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   // fewer than three rate categories a wave has 8 or 16 columns, and that table can cost
   // waves per CU (fluA, K = 1: 5 instead of 8); then the first generation stays.
   // MI_PHYLO_GRADIENT_WALK=v1|v2 forces one.
-  e->walk2 = gradient_walk_waves_per_cu(e->n, e->K) >= gradient_mfma_waves_per_cu(e->n, e->K);
+  // (Round 4: with compact tip words -- 12 instead of 32 bytes per column and macro -- the second
+  // generation no longer loses waves per CU at K < 3, and was measured again: fluA x 1000
+  // 0.344 ms against the first generation's 0.327, one fluA tree 0.100 against 0.103.  The
+  // batch is what counts: K < 3 stays with the first generation.)
+  e->walk2 = e->K >= 3 &&
+             gradient_walk_waves_per_cu(e->n, e->K) >= gradient_mfma_waves_per_cu(e->n, e->K);
   if (const char* env = getenv("MI_PHYLO_GRADIENT_WALK")) {
     e->walk2 = std::string(env) != "v1";
     e->walk3 = std::string(env) != "v1" && std::string(env) != "v2";

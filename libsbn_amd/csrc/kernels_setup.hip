@@ -412,10 +412,25 @@ __global__ __launch_bounds__(kSetupMaxThreads) void tree_setup_wg_kernel(TreeSet
           pending = true;
           continue;
         }
+        // (the polling loop only publishes the node's own word: every lane of the wave runs this
+        // body whenever ANY of its nodes becomes ready, so the schedule entry -- three more LDS
+        // reads, a global store, an atomic -- is written in one pass after the sweep)
         const int off = own_off[i];
         const int b = ((int)(dp >> 32) & 0xffff) + ((off >> 24) & 1);
         const int st = (int)(dp & 0xffffffffu) + (off & 0xffffff);
         if (v != N - 1) D[v] = (1ull << 63) | ((uint64_t)b << 32) | (uint64_t)st;
+        own_p[i] = b;      // (the parent's id is done with: the node's slot and start instead)
+        own_off[i] = st;
+        own_todo[i] = false;
+      }
+    } while (__any(pending));
+    {
+      int slots_used = 0;
+#pragma unroll
+      for (int i = 0; i < kSetupOwn; i++) {
+        const int v = n + tid + i * nthreads;
+        if (v >= N) continue;
+        const int b = own_p[i], st = own_off[i];
         const int a0 = cc[v].x, a1f = cc[v].y, a1 = a1f & 0xfffff;
         const bool first0 = (a1f >> 30) & 1;
         const int hi = first0 ? a0 : a1;
@@ -423,10 +438,15 @@ __global__ __launch_bounds__(kSetupMaxThreads) void tree_setup_wg_kernel(TreeSet
         const int s0 = a0 < n ? 0 : (a0 == hi ? b : blo), s1 = a1 < n ? 0 : (a1 == hi ? b : blo);
         sched[st + up_isz(W[v]) - 1] = {v, a0, a1, b | (s0 << 8) | (s1 << 16) | ((a0 < n ? 1 : 0) << 24) |
                                                       ((a1 < n ? 1 : 0) << 25)};
-        atomicMax(&used_max, b + 1);
-        own_todo[i] = false;
+        slots_used = slots_used > b + 1 ? slots_used : b + 1;
       }
-    } while (__any(pending));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int x = __shfl_xor(slots_used, o, 64);
+        slots_used = slots_used > x ? slots_used : x;
+      }
+      if ((tid & 63) == 0) atomicMax(&used_max, slots_used);
+    }
     __syncthreads();
     if (used_max > a.max_slots) status = kTooManySlots;
     // ---- schedule of the on-chip gradient kernel (see tree_setup_kernel)

@@ -326,6 +326,26 @@ int32_t mi_site_pattern_compress(int32_t device, int32_t taxon_count, int64_t si
                                  const int8_t* codes, int32_t* out_pattern_count,
                                  int32_t* out_patterns, double* out_weights,
                                  double* out_hash_kernel_ms);
+/* The device-resident form (round 4): the same compression, but the pattern matrix
+ * [taxon_count][*out_pattern_count] (int32, dense) and the weights stay in device memory --
+ * for a 512 x 50 000 alignment that is 82 MB that need not come down only to go up again.
+ * The two arrays are allocated by the library on `device` and handed to the caller, who
+ * passes them to mi_engine_create_device_tips and releases them with mi_device_free (the
+ * engine keeps its own copies). */
+int32_t mi_site_pattern_compress_device(int32_t device, int32_t taxon_count, int64_t site_count,
+                                        const int8_t* codes, int32_t* out_pattern_count,
+                                        int32_t** out_device_patterns,
+                                        double** out_device_weights, double* out_hash_kernel_ms);
+void mi_device_free(void* device_pointer);
+/* mi_engine_create / mi_engine_create_reversible (by spec->state_count; 20 states: the
+ * built-in WAG table) with the tips ALREADY ON THE DEVICE: device_tip_states[n*P] int32 (as
+ * tip_states above: >= s means gap) and device_pattern_weights[P], on spec->device (the
+ * current device for -1).  use_tip_states == 0 derives the 0/1 partial vectors on the device
+ * as SitePattern::GetPartials does.  Results are bit-identical to an engine made from the
+ * same arrays in host memory. */
+int32_t mi_engine_create_device_tips(const mi_engine_spec* spec, const int32_t* device_tip_states,
+                                     const double* device_pattern_weights,
+                                     mi_engine** out_engine);
 
 #ifdef __cplusplus
 }

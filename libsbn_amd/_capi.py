@@ -71,6 +71,10 @@ SYMBOLS = {
     "mi_engine_last_call_launches": (C.c_int32, [_V, I32P, I32P]),
     "mi_site_pattern_compress":
         (C.c_int32, [C.c_int32, C.c_int32, C.c_int64, _V, I32P, _V, _V, F64P]),
+    "mi_site_pattern_compress_device":
+        (C.c_int32, [C.c_int32, C.c_int32, C.c_int64, _V, I32P, C.POINTER(_V), C.POINTER(_V), F64P]),
+    "mi_device_free": (None, [_V]),
+    "mi_engine_create_device_tips": (C.c_int32, [C.POINTER(EngineSpec), _V, _V, C.POINTER(_V)]),
 }
 
 _lib = None

@@ -581,10 +581,44 @@ int32_t mi_device_count(void) {
   return count;
 }
 
+// (device_tips / device_weights: the tips already on the device, mi_engine_create_device_tips)
 static int32_t create_engine(const mi_engine_spec* spec, const double* exchangeabilities,
                              const double* frequencies, const int32_t* tip_states,
                              const double* tip_partials, const double* pattern_weights,
-                             mi_engine** out_engine);
+                             mi_engine** out_engine, const int32_t* device_tips = nullptr,
+                             const double* device_weights = nullptr);
+
+int32_t mi_engine_create_device_tips(const mi_engine_spec* spec, const int32_t* device_tip_states,
+                                     const double* device_pattern_weights,
+                                     mi_engine** out_engine) {
+  if (!device_tip_states || !device_pattern_weights) return fail("null device pointer");
+  return create_engine(spec, nullptr, nullptr, nullptr, nullptr, nullptr, out_engine,
+                       device_tip_states, device_pattern_weights);
+}
+
+// Everything engine creation derives from the compact tip states, on the device: the int8
+// states (rows padded with gaps to `stride`), and for 4-state engines the state masks, the
+// table offsets of the third-generation walk and (use_tip_states == 0) the 0/1 partial vectors
+// of SitePattern::GetPartials (site_pattern.cpp:117-131).
+__global__ __launch_bounds__(256) void tips_prepare_kernel(const int32_t* in, int n, int P, int states,
+                                                           int stride, int8_t* st8, uint8_t* masks,
+                                                           uint8_t* codes, double* partials) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)n * stride) return;
+  const int x = (int)(idx / stride), p = (int)(idx - (size_t)x * stride);
+  int c = states;
+  if (p < P) {
+    const int32_t v = in[(size_t)x * P + p];
+    c = (v >= 0 && v < states) ? v : states;
+  }
+  st8[idx] = (int8_t)c;
+  if (p >= P) return;
+  const size_t i = (size_t)x * P + p;
+  if (masks) masks[i] = c >= kStates ? 0xF : (uint8_t)(1u << c);
+  if (codes) codes[i] = c >= kStates ? 64 : (uint8_t)(16 * c);
+  if (partials)
+    for (int k = 0; k < kStates; k++) partials[i * kStates + k] = (c >= kStates || c == k) ? 1.0 : 0.0;
+}
 
 int32_t mi_engine_create(const mi_engine_spec* spec, const int32_t* tip_states,
                          const double* tip_partials, const double* pattern_weights,
@@ -608,7 +642,8 @@ int32_t mi_engine_create_reversible(const mi_engine_spec* spec, const double* ex
 static int32_t create_engine(const mi_engine_spec* spec, const double* exchangeabilities,
                              const double* frequencies, const int32_t* tip_states,
                              const double* tip_partials, const double* pattern_weights,
-                             mi_engine** out_engine) {
+                             mi_engine** out_engine, const int32_t* device_tips,
+                             const double* device_weights) {
   if (!spec || !out_engine) return fail("null spec / out_engine");
   *out_engine = nullptr;
   if (spec->taxon_count < 3) return fail("need at least 3 taxa");
@@ -630,9 +665,9 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
     return fail("the constant site model has exactly one rate category");
   if (spec->category_count < 1 || spec->category_count > kMaxCategories)
     return fail("category_count out of range (1..64)");
-  if (!tip_states && !(spec->use_tip_states == 0 && tip_partials))
+  if (!device_tips && !tip_states && !(spec->use_tip_states == 0 && tip_partials))
     return fail("tip_states is required");
-  if (!pattern_weights) return fail("pattern_weights is required");
+  if (!device_tips && !pattern_weights) return fail("pattern_weights is required");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
     return fail("no HIP device available: the MI355X engine has no CPU fallback");
@@ -732,6 +767,33 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
       hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, e->stream) != hipSuccess)
     return cleanup_fail(fail("status word allocation failed"));
   const size_t np = (size_t)e->n * e->P;
+  if (device_tips) {
+    // the tips are on the device already: one kernel derives what the host loops below derive
+    const int stride = states == kAa ? e->tiles * kAaTile : e->P;
+    const bool dna = states == kStates;
+    if (e->tip_states.ensure((size_t)e->n * stride)) return cleanup_fail(1);
+    if (dna && (e->tip_masks.ensure(np) || e->tip_codes.ensure(np + 16))) return cleanup_fail(1);
+    if (dna && !spec->use_tip_states && e->tip_partials.ensure(sizeof(double) * np * kStates))
+      return cleanup_fail(1);
+    if (dna && hipMemsetAsync(e->tip_codes.ptr, 64, np + 16, e->stream) != hipSuccess)
+      return cleanup_fail(fail("hipMemset failed"));
+    const size_t total = (size_t)e->n * stride;
+    hipLaunchKernelGGL(tips_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       e->stream, device_tips, e->n, e->P, states, stride,
+                       e->tip_states.as<int8_t>(), dna ? e->tip_masks.as<uint8_t>() : nullptr,
+                       dna ? e->tip_codes.as<uint8_t>() : nullptr,
+                       dna && !spec->use_tip_states ? e->tip_partials.as<double>() : nullptr);
+    e->have_tip_masks = e->have_tip_codes = dna;
+    if (states == kAa && aa_engine_init(e, exchangeabilities, frequencies)) return cleanup_fail(1);
+    if (e->weights.ensure(sizeof(double) * (size_t)e->P) ||
+        hipMemcpyAsync(e->weights.ptr, device_weights, sizeof(double) * (size_t)e->P,
+                       hipMemcpyDeviceToDevice, e->stream) != hipSuccess)
+      return cleanup_fail(fail("copy of the pattern weights failed"));
+    if (hipStreamSynchronize(e->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+      return cleanup_fail(fail("preparation of the device-resident tips failed"));
+    *out_engine = e;
+    return 0;
+  }
   std::vector<int8_t> st8(np, (int8_t)states);
   if (tip_states)
     for (size_t i = 0; i < np; i++) {

@@ -173,12 +173,19 @@ struct DevMem {
 
 }  // namespace
 
-extern "C" int32_t mi_site_pattern_compress(int32_t device, int32_t taxon_count, int64_t site_count,
-                                            const int8_t* codes, int32_t* out_pattern_count,
-                                            int32_t* out_patterns, double* out_weights,
-                                            double* out_hash_kernel_ms) {
+// keep != nullptr: the device-resident form -- the gathered pattern matrix and the weights stay
+// on the device and their pointers are handed out (out_patterns / out_weights unused)
+struct KeepOnDevice {
+  int32_t* patterns = nullptr;
+  double* weights = nullptr;
+};
+static int32_t compress_impl(int32_t device, int32_t taxon_count, int64_t site_count,
+                             const int8_t* codes, int32_t* out_pattern_count,
+                             int32_t* out_patterns, double* out_weights,
+                             double* out_hash_kernel_ms, KeepOnDevice* keep) {
   if (taxon_count <= 0 || site_count <= 0) return fail("empty alignment");
-  if (!codes || !out_pattern_count || !out_patterns || !out_weights) return fail("null argument");
+  if (!codes || !out_pattern_count || (!keep && (!out_patterns || !out_weights)))
+    return fail("null argument");
   if (site_count > 0x7fffffffLL) return fail("more than 2^31 - 1 sites");
   const int n = taxon_count;
   const long L = (long)site_count;
@@ -282,16 +289,56 @@ extern "C" int32_t mi_site_pattern_compress(int32_t device, int32_t taxon_count,
   const std::vector<int> order = replay_unordered_map_order(hashes);
   *out_pattern_count = (int32_t)P;
   std::vector<uint32_t> final_site(P);
+  std::vector<double> weights_host(P);
   for (uint32_t j = 0; j < P; j++) {
     final_site[j] = first[order[j]];
-    out_weights[j] = (double)count[order[j]];
+    weights_host[j] = (double)count[order[j]];
   }
+  if (!keep) std::copy(weights_host.begin(), weights_host.end(), out_weights);
   // the pattern matrix is gathered on the device and comes back in one copy
   DevMem d_pat;
   SP_TRY(hipMalloc(&d_pat.p, sizeof(int32_t) * (size_t)n * P));
   SP_TRY(hipMemcpy(d_osite.p, final_site.data(), sizeof(uint32_t) * P, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(gather_patterns_kernel, dim3(pblocks, n), dim3(256), 0, nullptr, n, L, P,
                      d_codes.as<int8_t>(), d_osite.as<uint32_t>(), d_pat.as<int32_t>());
+  if (keep) {
+    DevMem d_w;
+    SP_TRY(hipMalloc(&d_w.p, sizeof(double) * P));
+    SP_TRY(hipMemcpy(d_w.p, weights_host.data(), sizeof(double) * P, hipMemcpyHostToDevice));
+    SP_TRY(hipDeviceSynchronize());
+    keep->patterns = d_pat.as<int32_t>();
+    keep->weights = d_w.as<double>();
+    d_pat.p = d_w.p = nullptr;  // (ownership passes to the caller: mi_device_free)
+    return 0;
+  }
   SP_TRY(hipMemcpy(out_patterns, d_pat.p, sizeof(int32_t) * (size_t)n * P, hipMemcpyDeviceToHost));
   return 0;
+}
+
+extern "C" int32_t mi_site_pattern_compress(int32_t device, int32_t taxon_count, int64_t site_count,
+                                            const int8_t* codes, int32_t* out_pattern_count,
+                                            int32_t* out_patterns, double* out_weights,
+                                            double* out_hash_kernel_ms) {
+  return compress_impl(device, taxon_count, site_count, codes, out_pattern_count, out_patterns,
+                       out_weights, out_hash_kernel_ms, nullptr);
+}
+
+extern "C" int32_t mi_site_pattern_compress_device(int32_t device, int32_t taxon_count,
+                                                   int64_t site_count, const int8_t* codes,
+                                                   int32_t* out_pattern_count,
+                                                   int32_t** out_device_patterns,
+                                                   double** out_device_weights,
+                                                   double* out_hash_kernel_ms) {
+  if (!out_device_patterns || !out_device_weights) return fail("null argument");
+  KeepOnDevice keep;
+  if (compress_impl(device, taxon_count, site_count, codes, out_pattern_count, nullptr, nullptr,
+                    out_hash_kernel_ms, &keep))
+    return 1;
+  *out_device_patterns = keep.patterns;
+  *out_device_weights = keep.weights;
+  return 0;
+}
+
+extern "C" void mi_device_free(void* device_pointer) {
+  if (device_pointer) (void)hipFree(device_pointer);
 }

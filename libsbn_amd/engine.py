@@ -72,7 +72,7 @@ class Engine:
 
     def __init__(self, model_specification, patterns, weights, use_tip_states=True,
                  device=-1, thread_count=1, tip_partials=None, reversible_model=None,
-                 shard_devices=None, shard_mode="trees"):
+                 shard_devices=None, shard_mode="trees", device_tips=None):
         """patterns: [taxon][pattern] compact states (SitePattern::GetPatterns), or None when
         tip_partials ([taxon][pattern][s], SitePattern::GetPartials) is given with
         use_tip_states=False.  Substitution "WAG" / "reversible" makes a 20-state engine
@@ -82,7 +82,11 @@ class Engine:
         (mi_engine_create_sharded): shard_mode "trees" deals the trees of a call in
         contiguous blocks, "patterns" gives every shard a block of site patterns and adds
         the per-tree results (unrooted calls).  Such a handle serves the numpy entry points;
-        the *_device ones need one engine per device."""
+        the *_device ones need one engine per device.  device_tips = (device pointer of the
+        int32 [taxon][pattern] states, device pointer of the float64 weights, taxon count,
+        pattern count) makes the engine from tips that are on the device already
+        (mi_engine_create_device_tips; e.g. what site_pattern_compress_device(...,
+        keep_on_device=True) hands out): patterns / weights are then None."""
         if thread_count == 0:  # src/engine.cpp:14-16
             raise RuntimeError("Thread count needs to be strictly positive.")
         self._lib = _capi.load()
@@ -95,6 +99,20 @@ class Engine:
         site_kind, K = _parse_site(model_specification.site)
         states = 20 if SUBST[model_specification.substitution] == 2 else 4
         self.state_count = states
+        if device_tips is not None:
+            d_states, d_weights, n, P = device_tips
+            self.taxon_count, self.pattern_count, self.category_count = n, P, K
+            self.node_count = 2 * n - 1
+            self.spec = _capi.EngineSpec(n, P, states, K, SUBST[model_specification.substitution],
+                                         site_kind, CLOCK[model_specification.clock],
+                                         1 if use_tip_states else 0, device, 0)
+            h = C.c_void_p()
+            self._check(self._lib.mi_engine_create_device_tips(
+                C.byref(self.spec), C.c_void_p(d_states), C.c_void_p(d_weights), C.byref(h)))
+            self._h = h
+            self.param_count = self._lib.mi_engine_param_count(h)
+            self.is_gtr = model_specification.substitution == "GTR"
+            return
         weights = _np(weights, np.float64)
         if tip_partials is not None:
             tip_partials = _np(tip_partials, np.float64)
@@ -365,15 +383,49 @@ class Engine:
         return a.value, b.value
 
 
-def site_pattern_compress_device(codes, device=0):
+class DevicePatterns:
+    """The compressed alignment left on the device (mi_site_pattern_compress_device): device
+    pointers of the int32 [taxon][pattern] matrix and the float64 weights; `as_device_tips()`
+    is what Engine(device_tips=...) takes; freed with mi_device_free when released."""
+
+    def __init__(self, patterns_ptr, weights_ptr, taxon_count, pattern_count):
+        self.patterns_ptr, self.weights_ptr = patterns_ptr, weights_ptr
+        self.taxon_count, self.pattern_count = taxon_count, pattern_count
+
+    def as_device_tips(self):
+        return (self.patterns_ptr, self.weights_ptr, self.taxon_count, self.pattern_count)
+
+    def release(self):
+        lib = _capi.load()
+        for ptr in (self.patterns_ptr, self.weights_ptr):
+            if ptr:
+                lib.mi_device_free(C.c_void_p(ptr))
+        self.patterns_ptr = self.weights_ptr = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def site_pattern_compress_device(codes, device=0, keep_on_device=False):
     """SitePattern::Compress on the GPU (include/mi_phylo.h: mi_site_pattern_compress).
 
     codes: [taxon][site] symbol codes 0..3, 4 = gap / ambiguous.  Returns (patterns
     [taxon][P] int32, weights [P] float64, milliseconds of the column-hashing kernel) in
-    the reference's pattern order."""
+    the reference's pattern order; keep_on_device=True: (DevicePatterns, milliseconds) -- the
+    matrix and the weights stay in device memory (mi_site_pattern_compress_device)."""
     lib = _capi.load()
     c = _np(codes, np.int8)
     n, L = c.shape
+    if keep_on_device:
+        count, ms = C.c_int32(0), C.c_double(0.0)
+        d_pat, d_w = C.c_void_p(), C.c_void_p()
+        if lib.mi_site_pattern_compress_device(int(device), n, L, _ptr(c), C.byref(count),
+                                               C.byref(d_pat), C.byref(d_w), C.byref(ms)):
+            raise RuntimeError(_capi.last_error())
+        return DevicePatterns(d_pat.value, d_w.value, n, count.value), ms.value
     patterns = np.empty((n, L), dtype=np.int32)
     weights = np.empty(L, dtype=np.float64)
     count = C.c_int32(0)

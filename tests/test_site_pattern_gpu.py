@@ -50,3 +50,50 @@ def test_random_alignments_match_the_oracle(n, L, alphabet):
     assert np.array_equal(pats, want_p)
     assert np.array_equal(w, want_w)
     assert w.sum() == L and ms >= 0.0
+
+
+def test_device_resident_patterns_feed_an_engine_without_the_round_trip():
+    """VERDICT r3 (housekeeping): mi_site_pattern_compress_device leaves the pattern matrix
+    and the weights in device memory, mi_engine_create_device_tips makes the engine from them
+    (states, masks, table offsets and -- use_tip_states=False -- the 0/1 partial vectors are
+    derived by a kernel).  The engine's results equal, bit for bit, those of an engine made the
+    usual way from the host arrays of the plain compression."""
+    import torch
+    import libsbn_amd as L
+    import tree_utils as TU
+    st = O.load_struct("ds1_sub10")
+    seqs = O.read_fasta(os.path.join(O.DATA, st["source"]["fasta"]))
+    codes = _codes([seqs[t] for t in st["taxon_names"]])
+    pats, w, _ = L.site_pattern_compress_device(codes)
+    dp, ms = L.site_pattern_compress_device(codes, keep_on_device=True)
+    n, P = pats.shape
+    assert (dp.taxon_count, dp.pattern_count) == (n, P) and ms >= 0.0
+    _, _, pids, bls = O.struct_arrays(st)
+    rng = np.random.default_rng(3)
+    for subst, site, tip_states in (("JC69", "weibull+4", True), ("GTR", "constant", False)):
+        spec = L.PhyloModelSpecification(subst, site, "strict")
+        a = L.Engine(spec, pats, w, use_tip_states=tip_states)
+        b = L.Engine(spec, None, None, use_tip_states=tip_states, device_tips=dp.as_device_tips())
+        T = len(pids)
+        pr = np.ones((T, a.param_count))
+        if subst == "GTR":
+            r, f = TU.random_gtr_params(T, rng)
+            pr[:, :6], pr[:, 6:10] = r, f
+        assert np.array_equal(a.log_likelihoods(pids, bls, pr), b.log_likelihoods(pids, bls, pr))
+        ga, gb = a.gradients(pids, bls, pr), b.gradients(pids, bls, pr)
+        assert a.last_call_info() == b.last_call_info()
+        for x, y in zip(ga, gb):
+            for k in x.gradient:
+                assert np.array_equal(x.gradient[k], y.gradient[k]), k
+    # 20 states: a random protein alignment through the same two doors
+    import aa_utils as A
+    tips, aw = A.random_aa_alignment(12, 333, rng)
+    d_t = torch.from_numpy(tips).to("cuda:0")
+    d_w = torch.from_numpy(aw).to("cuda:0")
+    s20 = L.PhyloModelSpecification("WAG", "weibull+4", "strict")
+    a = L.Engine(s20, tips, aw)
+    b = L.Engine(s20, None, None, device_tips=(d_t.data_ptr(), d_w.data_ptr(), 12, 333))
+    p2, b2 = TU.random_trees(12, 2, rng)
+    assert np.array_equal(a.log_likelihoods(p2, b2, np.ones((2, 2))),
+                          b.log_likelihoods(p2, b2, np.ones((2, 2))))
+    dp.release()

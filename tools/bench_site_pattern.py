@@ -37,6 +37,22 @@ def main():
         dt = time.perf_counter() - t0
         if dt < best:
             best, ms = dt, kms
+    # the device-resident door: patterns and weights stay in HBM and feed the engine directly
+    best_dev, best_dev_engine = 1e9, 1e9
+    spec = L.PhyloModelSpecification("JC69", "weibull+4", "strict")
+    for _ in range(args.reps):
+        t0 = time.perf_counter()
+        dp, _ = L.site_pattern_compress_device(codes, keep_on_device=True)
+        t1 = time.perf_counter()
+        eng = L.Engine(spec, None, None, device_tips=dp.as_device_tips())
+        t2 = time.perf_counter()
+        best_dev, best_dev_engine = min(best_dev, t1 - t0), min(best_dev_engine, t2 - t0)
+        eng.close()
+        dp.release()
+    t0 = time.perf_counter()
+    eng = L.Engine(spec, pats, w)
+    host_engine = time.perf_counter() - t0
+    eng.close()
     rows = ["".join("ACGT-"[c] for c in row) for row in codes]
     t0 = time.perf_counter()
     op, ow = O.site_pattern_compress(rows)
@@ -46,6 +62,9 @@ def main():
     print(json.dumps({
         "workload": f"{n} taxa x {S} columns, {pats.shape[1]} distinct patterns",
         "device_end_to_end_ms": best * 1e3, "cpu_oracle_ms": cpu * 1e3,
+        "device_resident_ms": best_dev * 1e3,
+        "device_resident_plus_engine_ms": best_dev_engine * 1e3,
+        "host_arrays_plus_engine_ms": (best + host_engine) * 1e3,
         "hash_kernel_ms": ms, "hash_kernel_GBps": nbytes / (ms * 1e-3) / 1e9 if ms else None,
         "hbm_peak_GBps": 8000.0, "identical_to_cpu": True}))
 

@@ -13,10 +13,16 @@ DS1.100_topologies.nwk x 10 synthetic branch-length draws, Exp(mean 0.1)), JC69 
 reference's 4-category discrete rate model ("weibull+4", shape 1.0).  STRONG scaling: the
 1000 trees are dealt to the ranks in contiguous blocks (1000 / N per GPU), as the
 reference's FatBeagleParallelize deals a tree collection to its FatBeagles; a weak-scaled
-figure (1000 trees per GPU) rides along in "weak".  On one GPU the line also carries, in
-"also", the other BASELINE.json configurations (GTR+4G full / branch-only, fluA rooted,
-log-likelihoods only, the 1949-pattern shape, the 20-state 512 x 50 000 case), a small-batch
-(125 trees) step time, and a parity check of the timed outputs against the CPU oracle.
+figure (1000 trees per GPU) rides along in "weak".
+
+Output.  The LAST line of stdout is ONE compact JSON object (< 4 KB, asserted: final_line) with
+the contract's fields, the dominant kernel's `roofline`, `cpu_baseline`, the parity of the timed
+outputs, `small_batch_ms` (the 125-tree step one GPU of eight runs, from a hipGraph), the
+host-pointer / C++ adapter / fused-reduction legs, and one short entry per other configuration
+in `also` (GTR+4G full and branch-only, log-likelihoods, the 1949-pattern shape, fluA rooted,
+the 20-state 512 x 50 000 case).  Everything behind those numbers -- second rooflines, phase
+tables, notes, samples -- is written to bench_also.json and printed before the last line as
+`BENCH_ALSO <name> <json>` lines.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--trees T_total] [--mode gradient|loglik]
 
@@ -555,7 +561,8 @@ def also_workloads(torch, dev, L, steps):
         r = roofline(kname, ms, T, flops, bytes_)
         r["note"] = ("whole call (all its walk passes) over the step time; " + r["note"])
         out.append({"workload": f"DS1 27 taxa x {P} patterns x {T} trees, GTR+weibull+4, " + label,
-                    "short": short, "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
+                    "short": short, "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms,
+                    "kernel": kname,
                     "kernel_ms": k_ms,
                     "kernel_note": "HIP events around the main gradient pass only; the call also "
                                    "runs the finite-difference / site passes",
@@ -578,7 +585,8 @@ def also_workloads(torch, dev, L, steps):
     err = parity([("logL", host(ll, S), oll)])
     ent = traffic_entry(kname.split("<")[0])
     out.append({"workload": f"DS1 27 taxa x {P} patterns x {T} trees, JC69+weibull+4, log_likelihoods",
-                "short": "DS1x1000 JC69+G4 log_likelihoods", "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
+                "short": "DS1x1000 JC69+G4 log_likelihoods", "trees_per_s": T / (ms * 1e-3),
+                "ms_per_step": ms, "kernel": kname,
                 "kernel_ms": k_ms,
                 "roofline": roofline(kname, k_ms, T, f_ll, b_ll,
                                      ent["hbm_bytes_per_launch"] if ent else None,
@@ -607,7 +615,8 @@ def also_workloads(torch, dev, L, steps):
                   ("site gradient", host(site, S), og["site_model"])])
     out.append({"workload": f"S-DS1 27 taxa x 1949 patterns (synthetic, evolved under JC) x {T} "
                             "trees, JC69+weibull+4, phylo_gradients",
-                "short": "S-DS1 1949 patterns x1000 gradients", "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
+                "short": "S-DS1 1949 patterns x1000 gradients", "trees_per_s": T / (ms * 1e-3),
+                "ms_per_step": ms, "kernel": kname,
                 "kernel_ms": k_ms, "roofline": roofline(kname, k_ms, T, f2_g, b2_g),
                 "parity_checked": S, "parity_max_rel_err": err})
     eng.close()
@@ -650,7 +659,8 @@ def also_workloads(torch, dev, L, steps):
                       ("clock gradient", host(gc, S)[:, 0], og["clock_model"][:, 0])])
         out.append({"workload": f"fluA rooted {n} taxa x {P} patterns x {Tf} tree(s), JC69, strict "
                                 "clock, node-height-ratio + clock gradient",
-                    "short": f"fluA rooted x{Tf} ratio+clock gradient", "trees_per_s": Tf / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
+                    "short": f"fluA rooted x{Tf} ratio+clock gradient",
+                    "trees_per_s": Tf / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
                     "kernel_ms": k_ms, "logL0": float(ll[0]),
                     "phase_ms": {"setup": phase_ms[0], "walk": phase_ms[2], "rest": phase_ms[3]},
                     "roofline": roofline(kname, k_ms, Tf, ff_g, bf_g),

@@ -1379,6 +1379,49 @@ def main():
             assert bool(torch.isfinite(blk.log_likelihoods).all())
         except Exception as exc:  # capture support varies; the eager figure stands
             small["graph_error"] = repr(exc)[:200]
+        if grad and "graph_error" not in small:
+            # ... and with the rank's trees dealt to TWO engines of this GPU, each on its own
+            # stream, forked and joined inside ONE hipGraph (what mi_engine_create_sharded's
+            # logical shards of one device do for the host-pointer calls): one half's set-up,
+            # matrices and reduction run under the other half's walk, and each walk's thinning
+            # last round is filled by the other's waves
+            try:
+                Ta = (Ts + 1) // 2
+                halves = [(0, Ta), (Ta, Ts)]
+                eng_b = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w,
+                                 device=local_rank)
+                engines = [eng, eng_b]
+                blk2 = sharding.ResultBlocks(Ts, N, extra=1, device=dev)
+                for e2, (a0, a1) in zip(engines, halves):
+                    e2.reserve(a1 - a0, True)
+                side = torch.cuda.Stream()
+                graph3 = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph3, stream=gstream):
+                    side.wait_stream(gstream)
+                    for e2, (a0, a1), st in zip(engines, halves, (gstream, side)):
+                        with torch.cuda.stream(st):
+                            e2.gradients_device(
+                                st.cuda_stream, a1 - a0, d_pid[a0:a1].data_ptr(),
+                                d_bl[a0:a1].data_ptr(), d_par[a0:a1].data_ptr(),
+                                blk2.log_likelihoods[a0:a1].data_ptr(),
+                                blk2.branch_gradients[a0:a1].data_ptr(),
+                                blk2.extras[0][a0:a1].data_ptr(), None)
+                    gstream.wait_stream(side)
+                for _ in range(5):
+                    graph3.replay()
+                torch.cuda.synchronize()
+                e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+                e0.record()
+                for _ in range(100):
+                    graph3.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                small["graph_two_engines_ms_per_step"] = e0.elapsed_time(e1) / 100
+                assert bool(torch.equal(blk2.buffer, blk.buffer)), "two engines: results differ"
+                eng_b.close()
+            except Exception as exc:
+                small["graph_two_engines_error"] = repr(exc)[:200]
         if distributed and "graph_error" not in small:
             # ... and with the step's ONE collective inside the graph (RCCL kernels capture like
             # any other when they are enqueued on the capturing stream): what a rank of a

@@ -75,6 +75,17 @@ constexpr unsigned kTipCat = 320u, kTipRow = 80u;
 #define W3_SCALARS 0
 #endif
 constexpr int kScalars = W3_SCALARS;
+// W3_STORE_S: the post-order walk overwrites a stored node's vector L, once its parent's visit
+// has consumed it, with the product S = P L it has just formed; the pre-order walk then reads
+// S instead of recomputing it, and takes the edge's derivative as sum qs . Q S instead of
+// sum (P^T qs) . Q L -- the same number because P and Q commute (what the 20-state kernels
+// do).  36 matrix instructions of a DS1 tile job less and one dependent stage
+// off the visit's chain, for 36 more LDS stores; results then differ from the second
+// generation's in the last bits (P Q against Q P).
+#ifndef W3_STORE_S
+#define W3_STORE_S 0
+#endif
+constexpr bool kStoreS = W3_STORE_S != 0;
 // when a visit reads the stored vectors of its node and of its stored children from LDS: first
 // thing at its top, BEFORE the operand wait and the next visit's requests (their LDS latency
 // then passes under those), or where the visit's arithmetic needs them
@@ -418,22 +429,37 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
     }
     if (kind == 1) {
       c.L = kEarlyLds ? (J == 0 ? ea.l0 : ea.l1) : load_slot(sl.c[J]);
+      if (kStoreS && PRE) {  // (the slot holds S since the post-order walk)
+        c.S = c.L;
+        return;
+      }
     } else {
       if (sh & (1 << (10 + 2 * J))) {
         c.Ap = tip_p(pre_tag, o, OA{});
       } else {
         c.xa = load_slot(sl.g[2 * J]);
-        c.Ap = mm(o.x[W], c.xa);
+        if (kStoreS && PRE) {
+          c.Ap = c.xa;
+        } else {
+          c.Ap = mm(o.x[W], c.xa);
+          if (kStoreS) store_slot(sl.g[2 * J], c.Ap);
+        }
       }
       if (sh & (1 << (11 + 2 * J))) {
         c.Bp = tip_p(pre_tag, o, OB{});
       } else {
         c.xb = load_slot(sl.g[2 * J + 1]);
-        c.Bp = mm(o.x[4 * W], c.xb);
+        if (kStoreS && PRE) {
+          c.Bp = c.xb;
+        } else {
+          c.Bp = mm(o.x[4 * W], c.xb);
+          if (kStoreS) store_slot(sl.g[2 * J + 1], c.Bp);
+        }
       }
       c.L = mul(c.Ap, c.Bp);
     }
     c.S = mm(o.x[0], c.L);
+    if (kStoreS && !PRE && kind == 1) store_slot(sl.c[J], c.S);
   };
 
   // ================= post-order over the stored nodes, then the root (site likelihood) ====
@@ -598,7 +624,12 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
       return;
     }
     V qc;
-    nout = inner_edge(o.x[1], qs, c.L, qc);
+    if (kStoreS && kind == 1) {  // sum qs . Q S = sum (P^T qs) . Q L
+      qc = mm(o.x[1], qs);
+      nout = mul(qs, mm(AQ, c.S));
+    } else {
+      nout = inner_edge(o.x[1], qs, c.L, qc);
+    }
     if (kind == 1) {
       store_slot(sl.c[J], qc);
       return;
@@ -608,13 +639,23 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
     if (sh & (1 << (10 + 2 * J))) {
       na = mul(qsa, tip_pq(o, std::integral_constant<int, 2>{}));
     } else {
-      na = inner_edge(o.x[3], qsa, c.xa, qa);
+      if (kStoreS) {
+        qa = mm(o.x[3], qsa);
+        na = mul(qsa, mm(AQ, c.Ap));
+      } else {
+        na = inner_edge(o.x[3], qsa, c.xa, qa);
+      }
       store_slot(sl.g[2 * J], qa);
     }
     if (sh & (1 << (11 + 2 * J))) {
       nb = mul(qsb, tip_pq(o, std::integral_constant<int, 8>{}));
     } else {
-      nb = inner_edge(o.x[9], qsb, c.xb, qb);
+      if (kStoreS) {
+        qb = mm(o.x[9], qsb);
+        nb = mul(qsb, mm(AQ, c.Bp));
+      } else {
+        nb = inner_edge(o.x[9], qsb, c.xb, qb);
+      }
       store_slot(sl.g[2 * J + 1], qb);
     }
     edge_sums(na, nb, m, 2 + 2 * J);

@@ -89,7 +89,7 @@ __device__ __forceinline__ int child_cfg(int sh, int j) {
 template <int R, bool RESCALE, bool SUBST, bool ARENA, bool COMPACT>
 __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   static_assert(R <= 4, "tip masks of one column group are packed in one 32-bit word");
-  static_assert(!COMPACT || R == 3, "three 4-bit masks per 16-bit field");
+  static_assert(!COMPACT || R <= 4, "R 4-bit masks per 16-bit field");
   constexpr unsigned kCol = COMPACT ? kTwColCompact : kTwCol;
   extern __shared__ double wlds[];
   const int lane = threadIdx.x;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
       if (COMPACT) {
         // one 16-bit field per column: the masks of its R patterns (ppr apart), 4 bits each
         char* dst = lds0 + (unsigned)m * tstride + (unsigned)pos * 2u;
-        if (Kp == 1 && tile_start + 48 <= a.P) {  // whole tile: its 48 bytes as twelve words
+        if (R == 3 && Kp == 1 && tile_start + 48 <= a.P) {  // whole tile: its 48 bytes as twelve words
           uint32_t d[12];
 #pragma unroll
           for (int i = 0; i < 12; i++) d[i] = *reinterpret_cast<const uint32_t*>(src + tile_start + 4 * i);

@@ -101,8 +101,10 @@ struct Ops {
 };
 
 template <bool RESCALE>
-__global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) {
-  static_assert(R == 3, "twelve pattern columns per wave: three tip bytes per word");
+// (R = 2 -- 8 patterns per wave, 14 KB of LDS -- is built with three waves per SIMD:
+// `make EXTRA_LLVM=-DMI_LLR=2`, an experiment of round 4)
+__global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_kernel(LikArgs a) {
+  static_assert(R == 2 || R == 3, "tip bytes of a (macro, position) pair come as R words");
   extern __shared__ double wlds[];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
@@ -133,11 +135,11 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
   const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
   if (M <= 0) return;
   constexpr int ppr = 4, TP = ppr * R;
-  struct __attribute__((packed)) Bytes12 {
-    uint32_t d0, d1, d2;
+  struct __attribute__((packed)) Bytes12 {  // (4 R bytes: the pair's codes of this tile)
+    uint32_t d[R];
   };
   const int tile_start = tile * TP;
-  const bool whole = tile_start + 12 <= a.P;
+  const bool whole = tile_start + TP <= a.P;
   Bytes12 bytes_now[2] = {};
   if (whole) {
 #pragma unroll
@@ -325,8 +327,8 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_lut_kernel(LikArgs a) 
 #pragma unroll
           for (int c = 0; c < 4; c++)
             *reinterpret_cast<uint32_t*>(dst + c * kTwCol) =
-                ((w.d0 >> (8 * c)) & 0xffu) | (((w.d1 >> (8 * c)) & 0xffu) << 8) |
-                (((w.d2 >> (8 * c)) & 0xffu) << 16);
+                ((w.d[0] >> (8 * c)) & 0xffu) | (((w.d[1] >> (8 * c)) & 0xffu) << 8) |
+                (R > 2 ? ((w.d[R - 1] >> (8 * c)) & 0xffu) << 16 : 0u);
         }
       }
     } else {

@@ -9,6 +9,7 @@ the ramp, the plateau and the tail of a launch ("small batches").""
 import ctypes, os, sys
 import numpy as np
 os.environ["MI_PHYLO_LIBRARY"] = os.path.abspath("libsbn_amd/variants/timeline.so")
+os.environ["MI_PHYLO_GRADIENT_WALK"] = "v2"  # (the instrumented kernel is the second generation's)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench

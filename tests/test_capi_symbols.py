@@ -83,3 +83,18 @@ def test_shard_range_covers_every_unit_once():
             assert seen == total
     assert lib.mi_shard_range(10, 0, 0, ctypes.byref(b), ctypes.byref(c)) != 0
     assert lib.mi_device_count() >= 0
+
+
+def test_cpp_callers_build_against_the_library(tmp_path):
+    """The two C++ programs that call the engine through the adapter (the reference's doctests,
+    tests/cpp/engine_example.cpp, and bench.py's adapter leg, tools/engine_bench.cpp) must
+    compile and link against the in-tree libraries -- on the GPU box they are built by the
+    tests / by bench.py at run time, where a drift of the header would only show up then."""
+    import subprocess
+    lib = os.path.join(REPO, "libsbn_amd")
+    for src in ("tests/cpp/engine_example.cpp", "tools/engine_bench.cpp"):
+        exe = tmp_path / os.path.basename(src).replace(".cpp", "")
+        subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(REPO, src), "-L" + lib,
+                        "-lmi_phylo", "-lmi_phylo_host", "-Wl,-rpath," + lib, "-o", str(exe)],
+                       check=True)
+        assert exe.exists()

@@ -18,7 +18,10 @@ using namespace dev;
 // Tile reduction (one workgroup per evaluation): four waves split the tiles
 // (wave w takes tiles w, w+4, ...), combine through LDS in a fixed order.
 // ------------------------------------------------------------------------
-__device__ __forceinline__ void reduce_tiles_body(const ReduceArgs& a, const int b, double* red_lds /* [4][W] */) {
+// keep (reduce_finalize_kernel): the sums stay in LDS for the finalize step -- [2][N] by node
+// id, then the log-likelihood -- instead of going through g_sum / ll_sum in HBM and back.
+__device__ __forceinline__ void reduce_tiles_body(const ReduceArgs& a, const int b, double* red_lds /* [4][W] */,
+                                                  double* keep = nullptr) {
   __shared__ double llw[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int N2 = 2 * a.N;
@@ -33,33 +36,54 @@ __device__ __forceinline__ void reduce_tiles_body(const ReduceArgs& a, const int
   if (b < a.Eg) {
     const double* src = a.g_part + (size_t)b * a.g_tiles * W;
     const int tail = a.g_width ? W - a.extra : W;  // plain sums after the positional part
-    for (int v = lane; v < used + a.extra; v += 64) {
-      if (v >= used) v = tail + (v - used);
-      double s0 = 0, s1 = 0;
-      int i = wv;
-      // (unrolled: the loads of several iterations in flight at once; the order of the
-      // additions, hence the result, is unchanged)
-#pragma unroll 8
-      for (; i + 4 < a.g_tiles; i += 8) {
-        s0 += src[(size_t)i * W + v];
-        s1 += src[(size_t)(i + 4) * W + v];
+    // Four columns per lane side by side and the tile loop unrolled: 32 loads in flight per
+    // lane (round 5; a column at a time with 16 in flight, the 156 columns of a DS1 tree were
+    // six memory round trips one after the other -- most of this kernel's time on a small
+    // batch).  Per (wave, column) the additions are the same in the same order.
+    constexpr int VU = 4;
+    const int total = used + a.extra;
+    for (int v0 = lane; v0 < total; v0 += 64 * VU) {
+      int col[VU];
+      bool on[VU];
+      double s0[VU], s1[VU];
+#pragma unroll
+      for (int j = 0; j < VU; j++) {
+        const int v = v0 + 64 * j;
+        on[j] = v < total;
+        col[j] = !on[j] ? 0 : (v < used ? v : tail + (v - used));
+        s0[j] = s1[j] = 0;
       }
-      if (i < a.g_tiles) s0 += src[(size_t)i * W + v];
-      red_lds[wv * W + v] = s0 + s1;
-      if (v >= tail) v = used + (v - tail);
+      int i = wv;
+#pragma unroll 4
+      for (; i + 4 < a.g_tiles; i += 8) {
+        // (no condition around a load: lanes past the last column read column 0 and drop
+        // the sum -- a branch per load would put a wait behind each)
+#pragma unroll
+        for (int j = 0; j < VU; j++) {
+          s0[j] += src[(size_t)i * W + col[j]];
+          s1[j] += src[(size_t)(i + 4) * W + col[j]];
+        }
+      }
+      if (i < a.g_tiles) {
+#pragma unroll
+        for (int j = 0; j < VU; j++) s0[j] += src[(size_t)i * W + col[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < VU; j++)
+        if (on[j]) red_lds[wv * W + col[j]] = s0[j] + s1[j];
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) a.ll_sum[b] = (llw[0] + llw[1]) + (llw[2] + llw[3]);
+  if (threadIdx.x == 0) (keep ? keep[N2] : a.ll_sum[b]) = (llw[0] + llw[1]) + (llw[2] + llw[3]);
   if (b >= a.Eg) return;
-  double* out = a.g_sum + (size_t)b * N2;
+  double* out = keep ? keep : a.g_sum + (size_t)b * N2;
   if (!a.g_width) {
     for (int v = threadIdx.x; v < N2; v += 256)
       out[v] = (red_lds[v] + red_lds[W + v]) + (red_lds[2 * W + v] + red_lds[3 * W + v]);
     return;
   }
   // positional: entry (m, pos, q) belongs to the edge above child/grandchild `pos` of macro m
-  const MacroEntry* mac = a.macros + (size_t)t * max_macros(a.n);
+  const MacroEntry* mac = a.macros + (size_t)t * macro_stride(a.n);
   if (a.extra)
     for (int v = threadIdx.x; v < a.extra; v += 256) {
       const int c = W - a.extra + v;
@@ -334,7 +358,9 @@ __device__ __forceinline__ void rooted_recurrences_wave(int n, int lane, const i
   }
 }
 
-__device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t, double* fin_lds) {
+// keep: see reduce_tiles_body (the reduced sums in LDS instead of a.ll_part / a.g_part)
+__device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t, double* fin_lds,
+                                              const double* keep = nullptr) {
   // One wave per tree: lanes run over nodes / tiles for the reductions, lane 0
   // walks the O(n) recurrences of the rooted chain rule.  Working set (6n doubles, for
   // rooted trees also the tree's heights, bounds, ratios, rates and the ratio gradient
@@ -391,7 +417,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t
       jac = wave_sum(jac);
     }
     if (lane == 0) {
-      sh_ll = sum_tiles(a.ll_part + (size_t)t * a.ll_tiles, a.ll_used.of(t));
+      sh_ll = keep ? keep[2 * N] : sum_tiles(a.ll_part + (size_t)t * a.ll_tiles, a.ll_used.of(t));
       sh_jac = jac;
     }
   }
@@ -407,8 +433,12 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t
   double* bg = work;  // N doubles (N < 2n)
   for (int v = lane; v < N; v += 64) {
     double sum = 0;
-    for (int i = 0; i < a.g_tiles; i++)
-      sum += a.g_part[(((size_t)t * a.g_tiles + i) * 2) * N + v];
+    if (keep) {
+      sum += keep[v];  // (0 + x, as the loop below forms it)
+    } else {
+      for (int i = 0; i < a.g_tiles; i++)
+        sum += a.g_part[(((size_t)t * a.g_tiles + i) * 2) * N + v];
+    }
     bg[v] = sum;
   }
   if (a.out_site && (a.site_fused || a.site_separate)) {
@@ -417,8 +447,12 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t
     double r = 0;
     for (int v = lane; v < N - 1; v += 64) {
       double sum = 0;
-      for (int i = 0; i < a.g_tiles; i++)
-        sum += a.g_part[((gi * a.g_tiles + i) * 2 + 1) * N + v];
+      if (keep) {
+        sum += keep[N + v];
+      } else {
+        for (int i = 0; i < a.g_tiles; i++)
+          sum += a.g_part[((gi * a.g_tiles + i) * 2 + 1) * N + v];
+      }
       r += sum * ble[v];
     }
     r = wave_sum(r);
@@ -565,11 +599,15 @@ __global__ __launch_bounds__(64) void finalize_kernel(FinalizeArgs a) {
 // less on the latency path of small batches: ~4 us of a 125-tree step).
 __global__ __launch_bounds__(256) void reduce_finalize_kernel(ReduceArgs ra, FinalizeArgs fa) {
   extern __shared__ double rf_lds[];
-  reduce_tiles_body(ra, blockIdx.x, rf_lds);
+  // (the one-launch call's hand-off word of this tree: every walk wave that polled it is done)
+  if (threadIdx.x == 0 && fa.clear_ready) fa.clear_ready[(size_t)blockIdx.x * kReadyStride] = 0;
+  // (the reduced sums stay in LDS, behind whatever either step needs of it)
+  double* keep = rf_lds + ra.keep_offset;
+  reduce_tiles_body(ra, blockIdx.x, rf_lds, keep);
   __threadfence_block();
   __syncthreads();
   if (threadIdx.x >= 64) return;  // (ended waves do not take part in later barriers)
-  finalize_body(fa, blockIdx.x, rf_lds);
+  finalize_body(fa, blockIdx.x, rf_lds, keep);
 }
 
 }  // namespace
@@ -592,12 +630,16 @@ void launch_reduce_tiles(const ReduceArgs& a, hipStream_t s) {
 static size_t finalize_lds_bytes(const FinalizeArgs& a) {
   return sizeof(double) * (a.rooted ? 22 * (size_t)a.n : 6 * (size_t)a.n);
 }
-void launch_reduce_finalize(const ReduceArgs& ra, const FinalizeArgs& fa_in, hipStream_t s) {
+void launch_reduce_finalize(const ReduceArgs& ra_in, const FinalizeArgs& fa_in, hipStream_t s) {
   FinalizeArgs fa = fa_in;
+  ReduceArgs ra = ra_in;
   const size_t W = ra.g_width ? ra.g_width : 2 * (size_t)ra.N;
   const size_t fin = finalize_lds_bytes(fa);
   fa.use_lds = fin <= 48 * 1024;
-  const size_t lds = std::max(sizeof(double) * 4 * W, fa.use_lds ? fin : 0);
+  const size_t work = std::max(sizeof(double) * 4 * W, fa.use_lds ? fin : 0);
+  ra.keep_offset = (int)(work / sizeof(double));
+  const size_t lds = work + sizeof(double) * (2 * (size_t)ra.N + 1);
+  allow_large_lds(reinterpret_cast<const void*>(reduce_finalize_kernel), lds);
   hipLaunchKernelGGL(reduce_finalize_kernel, dim3(fa.T), dim3(256), lds, s, ra, fa);
 }
 void launch_finalize(const FinalizeArgs& a_in, hipStream_t s) {

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_mfma_kernel(LikArgs a) {
       reinterpret_cast<const char*>(a.tr_mats + (size_t)e * (N - 1) * K * 16);
   const char* __restrict__ phi_e =
       SUBST ? reinterpret_cast<const char*>(a.phi + (size_t)e * (N - 1) * K * 16) : nullptr;
-  const MacroEntry* __restrict__ macros = a.macros + (size_t)t * max_macros(n);
+  const MacroEntry* __restrict__ macros = a.macros + (size_t)t * macro_stride(n);
   const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
   if (ARENA) {
     // this launch takes the trees whose live vectors fit its LDS slots (and not the
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(kTile) void macro_slots_kernel(const MacroEntry* ma
     return;
   }
   {
-    const int32_t* src = reinterpret_cast<const int32_t*>(macros_in + (size_t)t * Mmax);
+    const int32_t* src = reinterpret_cast<const int32_t*>(macros_in + (size_t)t * macro_stride(n));
     for (int i = lane; i < M * 16; i += kTile) slot_scratch[i] = src[i];
   }
   __syncthreads();
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(kTile) void macro_slots_kernel(const MacroEntry* ma
   }
   __syncthreads();
   {
-    int32_t* dst = reinterpret_cast<int32_t*>(macros_out + (size_t)t * Mmax);
+    int32_t* dst = reinterpret_cast<int32_t*>(macros_out + (size_t)t * macro_stride(n));
     for (int i = lane; i < M * 16; i += kTile) dst[i] = slot_scratch[order[i >> 4] * 16 + (i & 15)];
   }
 }
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(1024) void macro_slots_wg_kernel(const MacroEntry* 
     return;
   }
   {
-    const int32_t* src = reinterpret_cast<const int32_t*>(macros_in + (size_t)t * Mmax);
+    const int32_t* src = reinterpret_cast<const int32_t*>(macros_in + (size_t)t * macro_stride(n));
     for (int i = tid; i < M * 16; i += nthreads) slot_scratch[i] = src[i];
   }
   if (tid == 0) more[0] = more[1] = more[2] = used_s = placed_s = 0;
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(1024) void macro_slots_wg_kernel(const MacroEntry* 
   }
   __syncthreads();
   if (complete) {
-    int32_t* dst = reinterpret_cast<int32_t*>(macros_out + (size_t)t * Mmax);
+    int32_t* dst = reinterpret_cast<int32_t*>(macros_out + (size_t)t * macro_stride(n));
     for (int i = tid; i < M * 16; i += nthreads) dst[i] = slot_scratch[order[i >> 4] * 16 + (i & 15)];
   }
 }

@@ -7,6 +7,7 @@
 
 #include "mi_phylo_device_utils.h"
 #include "mi_phylo_kernels.h"
+#include "mi_phylo_setup_device.h"
 
 namespace miphylo {
 
@@ -25,7 +26,6 @@ using namespace dev;
 // The model instances are independent of the trees: their set-up (one thread per model
 // instance, defined below) rides in the same launch as extra workgroups behind the T
 // tree workgroups -- one dispatch less per call, and the two run side by side.
-__device__ void model_setup_thread(const ModelSetupArgs& a, int idx);
 
 __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a, ModelSetupArgs ms) {
   if ((int)blockIdx.x >= a.T) {
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void tree_setup_kernel(TreeSetupArgs a, ModelSe
         }
         cls[N - 1] = 1;
         sslot[N - 1] = -1;
-        MacroEntry* mac = a.macros + (size_t)t * max_macros(n);
+        MacroEntry* mac = a.macros + (size_t)t * macro_stride(n);
         int m = 0;
         for (int v = n; v < N; v++) {
           if (cls[v] != 1) continue;
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(kSetupMaxThreads) void tree_setup_wg_kernel(TreeSet
       for (int v = n + tid; v < N - 1; v += nthreads)
         if (up_cls(W[v]) == 1) sslot[v] += chunk_tot[(v - n) >> 6];
       __syncthreads();
-      MacroEntry* mac = a.macros + (size_t)t * max_macros(n);
+      MacroEntry* mac = a.macros + (size_t)t * macro_stride(n);
       for (int v = n + tid; v < N; v += nthreads) {
         if (up_cls(W[v]) != 1) continue;
         const bool root = v == N - 1;
@@ -526,527 +526,21 @@ __global__ __launch_bounds__(kSetupMaxThreads) void tree_setup_wg_kernel(TreeSet
   }
 }
 
-// ------------------------------------------------------------------------
-// Tree setup for N <= 64 nodes: the same walk with every per-node array held in ONE
-// vector register (lane = node id) and indexed with v_readlane / v_writelane.  The walk
-// is sequential and its cost is the latency of each dependent array access: a
-// cross-lane read is an order of magnitude quicker than an LDS round trip.  All
-// values are wave-uniform, so control flow is scalar.
-// ------------------------------------------------------------------------
-#define RDL(arr, i) __builtin_amdgcn_readlane((arr), (i))
-#define WRL(arr, i, val) (arr) = (lane == (i)) ? (val) : (arr)
-// A per-node array of up to NB * 64 entries held in NB vector registers: entry i lives in
-// lane i % 64 of register i / 64.  `rd` reads an entry with a wave-uniform index (two or
-// four v_readlane and scalar selects, no branch), `own(nb)` is the node id this lane holds
-// in register nb.
-template <int NB>
-struct NodeArray {
-  int r[NB];
-  __device__ __forceinline__ void fill(int v) {
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++) r[nb] = v;
-  }
-  __device__ __forceinline__ int rd(int i) const {
-    int out = __builtin_amdgcn_readlane(r[0], i & 63);
-#pragma unroll
-    for (int nb = 1; nb < NB; nb++) {
-      const int x = __builtin_amdgcn_readlane(r[nb], i & 63);
-      out = (i >> 6) == nb ? x : out;
-    }
-    return out;
-  }
-  // lane-varying index (gather): every lane reads entry idx
-  __device__ __forceinline__ int gather(int idx) const {
-    int out = __shfl(r[0], idx & 63, 64);
-#pragma unroll
-    for (int nb = 1; nb < NB; nb++) {
-      const int x = __shfl(r[nb], idx & 63, 64);
-      out = (idx >> 6) == nb ? x : out;
-    }
-    return out;
-  }
-};
 
+// ------------------------------------------------------------------------
+// Tree setup for N <= 256 nodes: one wave per tree, every per-node array in vector registers
+// (mi_phylo_setup_device.h).
+// ------------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(64) void tree_setup_small_kernel(TreeSetupArgs a, ModelSetupArgs ms) {
   if ((int)blockIdx.x >= a.T) {
     model_setup_thread(ms, ((int)blockIdx.x - a.T) * 64 + (int)threadIdx.x);
     return;
   }
-  // Branch-free by construction: the tree walks are dependent chains, and on this machine
-  // a taken scalar branch costs more than the handful of instructions it would skip, so
-  // every loop body is straight-line code (lane selects / scalar selects) and whatever can
-  // be done by all lanes at once (child lists, sorting, the macro entries) is.
-  using Arr = NodeArray<NB>;
-  const int t = blockIdx.x;
-  const int lane = threadIdx.x;
-  const int n = a.n, N = 2 * n - 1;
-  const int nodes_in = a.rooted ? N : N - 1;
-  const int root_in = nodes_in - 1;
-  const int32_t* par_in = a.parent_ids + (size_t)t * (nodes_in - 1);
-  SchedEntry* sched = a.sched + (size_t)t * (n - 1);
-  double* ble = a.bl_eff + (size_t)t * N;
-  auto own = [&](int nb) { return lane + 64 * nb; };
-
-  Arr par, maxleaf;
-  int status = kOk;
-  bool bad_parent = false;
-#pragma unroll
-  for (int nb = 0; nb < NB; nb++) {
-    const int v = own(nb);
-    par.r[nb] = v < nodes_in - 1 ? par_in[v] : -1;
-    maxleaf.r[nb] = v < n ? v : -1;
-    bad_parent |= v < nodes_in - 1 && (par.r[nb] <= v || par.r[nb] >= nodes_in || par.r[nb] < n);
-  }
-  if (__any(bad_parent)) status = kBadParentIds;
-
-  // One pass over the nodes in id order (a post-order: a node's largest leaf id is final when
-  // the node comes up): the parent's largest leaf id, and the parent's list of children in
-  // order of arrival; the (at most three) children are sorted by largest leaf id afterwards,
-  // all nodes at once.  (Until round 3 the pass kept every list sorted as it went -- a
-  // 25-instruction insert per node on the one dependent chain of this kernel: 13 k of its 25 k
-  // cycles for a DS1 tree.)
-  Arr cnt, k0, k1, k2;
-  cnt.fill(0); k0.fill(0); k1.fill(0); k2.fill(0);
-  if (status == kOk) {
-    for (int v = 0; v < nodes_in - 1; v++) {
-      const int p = par.rd(v), mv = maxleaf.rd(v);
-#pragma unroll
-      for (int nb = 0; nb < NB; nb++) {
-        const bool mine = own(nb) == p;
-        const int c = cnt.r[nb];
-        maxleaf.r[nb] = (mine && mv > maxleaf.r[nb]) ? mv : maxleaf.r[nb];
-        k0.r[nb] = (mine && c == 0) ? v : k0.r[nb];
-        k1.r[nb] = (mine && c == 1) ? v : k1.r[nb];
-        k2.r[nb] = (mine && c == 2) ? v : k2.r[nb];
-        cnt.r[nb] += mine ? 1 : 0;
-      }
-    }
-    // ascending largest leaf id (keys of siblings differ: disjoint leaf sets); absent children
-    // sort last
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-      const int c = cnt.r[nb];
-      int a = k0.r[nb], b = k1.r[nb], d = k2.r[nb];
-      int ma = maxleaf.gather(a), mb = maxleaf.gather(b), md = maxleaf.gather(d);
-      ma = c >= 1 ? ma : 0x7fffffff;
-      mb = c >= 2 ? mb : 0x7fffffff;
-      md = c >= 3 ? md : 0x7fffffff;
-      auto order2 = [](int& x, int& mx, int& y, int& my) {
-        const bool swap = mx > my;
-        const int tx = x, tm = mx;
-        x = swap ? y : x;
-        mx = swap ? my : mx;
-        y = swap ? tx : y;
-        my = swap ? tm : my;
-      };
-      order2(a, ma, b, mb);
-      order2(b, mb, d, md);
-      order2(a, ma, b, mb);
-      k0.r[nb] = a;
-      k1.r[nb] = b;
-      k2.r[nb] = d;
-    }
-  }
-  if (status == kOk) {
-    bool wrong = false;
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-      const int v = own(nb);
-      const int want = (!a.rooted && v == root_in) ? 3 : 2;
-      wrong |= v >= n && v < nodes_in && cnt.r[nb] != want;
-    }
-    if (__any(wrong)) status = a.rooted ? kNotBifurcating : kNotTrifurcatingRoot;
-  }
-  Arr c0, c1;
-  c0.fill(0);
-  c1.fill(0);
-  // schedule, entry i in lane i % 64 of register i / 64
-  Arr s_node, s_c0, s_c1, s_sl;
-  s_node.fill(0); s_c0.fill(0); s_c1.fill(0); s_sl.fill(0);
-  int macro_total = 0, stored_total = 0;
-  MacroEntry me[NB];
-  bool is_macro[NB];
-  int macro_rank[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; nb++) {
-    me[nb] = MacroEntry{};
-    is_macro[nb] = false;
-    macro_rank[nb] = 0;
-  }
-  if (status == kOk) {
-    const int kr0 = a.rooted ? 0 : k0.rd(root_in);
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-      const int v = own(nb);
-      if (v >= n && v < nodes_in) {
-        c0.r[nb] = k0.r[nb];
-        c1.r[nb] = k1.r[nb];
-      }
-      if (!a.rooted) {
-        // (k0,k1,k2) at root r  ->  r = (k1,k2), r+1 = (k0, r)
-        if (v == root_in) {
-          c0.r[nb] = k1.r[nb];
-          c1.r[nb] = k2.r[nb];
-        }
-        if (v == root_in + 1) {
-          c0.r[nb] = kr0;
-          c1.r[nb] = root_in;
-        }
-      }
-    }
-    if (!a.need_slots) {
-      // only the matrix-core gradient kernel and finalize will read this tree: the
-      // node-id order (already a post-order) with no slot assignment is enough
-#pragma unroll
-      for (int nb = 0; nb < NB; nb++) {
-        const int node = n + own(nb);
-        s_node.r[nb] = node;
-        s_c0.r[nb] = c0.gather(node < N ? node : 0);
-        s_c1.r[nb] = c1.gather(node < N ? node : 0);
-      }
-    } else {
-      // Sethi-Ullman labels and internal-subtree sizes, bottom-up (tips cost nothing)
-      Arr label, size;
-      label.fill(0);
-      size.fill(0);
-      for (int v = n; v < N; v++) {
-        const int a0 = c0.rd(v), a1 = c1.rd(v);
-        const int l0 = label.rd(a0), l1 = label.rd(a1);
-        const int sz = 1 + size.rd(a0) + size.rd(a1);
-        const int lb = l0 == l1 ? l0 + 1 : (l0 > l1 ? l0 : l1);
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-          label.r[nb] = own(nb) == v ? lb : label.r[nb];
-          size.r[nb] = own(nb) == v ? sz : size.r[nb];
-        }
-      }
-      // position in the post-order that visits the heavier child first: top-down, a
-      // node's subtree occupies [start, start + size), the node itself comes last
-      Arr first, second, size_first, start;
-      start.fill(0);
-#pragma unroll
-      for (int nb = 0; nb < NB; nb++) {
-        const int lab0 = label.gather(c0.r[nb]), lab1 = label.gather(c1.r[nb]);
-        const bool first0 = lab0 >= lab1;
-        first.r[nb] = first0 ? c0.r[nb] : c1.r[nb];
-        second.r[nb] = first0 ? c1.r[nb] : c0.r[nb];
-      }
-#pragma unroll
-      for (int nb = 0; nb < NB; nb++) size_first.r[nb] = size.gather(first.r[nb]);
-      // (the same loop fills node_at[position] = node)
-      Arr node_at;
-      node_at.fill(0);
-      for (int v = N - 1; v >= n; v--) {
-        const int st = start.rd(v), f = first.rd(v), sc = second.rd(v), sf = size_first.rd(v);
-        const int pos = st + size.rd(v) - 1;
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-          start.r[nb] = own(nb) == f ? st : (own(nb) == sc ? st + sf : start.r[nb]);
-          node_at.r[nb] = own(nb) == pos ? v : node_at.r[nb];
-        }
-      }
-      // LDS slots in schedule order from a free bitmask
-      Arr slot;
-      slot.fill(0);
-      uint32_t free_mask = 0xffffffffu;
-      int used_max = 0;
-      for (int out = 0; out < n - 1; out++) {
-        const int v = node_at.rd(out);
-        const int a0 = c0.rd(v), a1 = c1.rd(v);
-        const int sa0 = slot.rd(a0), sa1 = slot.rd(a1);
-        free_mask |= (a0 >= n ? 1u << sa0 : 0u) | (a1 >= n ? 1u << sa1 : 0u);
-        const int sl = __ffs(free_mask) - 1;
-        free_mask &= ~(1u << sl);
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) slot.r[nb] = own(nb) == v ? sl : slot.r[nb];
-        used_max = sl + 1 > used_max ? sl + 1 : used_max;
-      }
-      if (used_max > a.max_slots) status = kTooManySlots;
-#pragma unroll
-      for (int nb = 0; nb < NB; nb++) {
-        const int node = node_at.r[nb];
-        const int ch0 = c0.gather(node), ch1 = c1.gather(node);
-        s_node.r[nb] = node;
-        s_c0.r[nb] = ch0;
-        s_c1.r[nb] = ch1;
-        s_sl.r[nb] = slot.gather(node) | (slot.gather(ch0) << 8) | (slot.gather(ch1) << 16) |
-                     ((ch0 < n ? 1 : 0) << 24) | ((ch1 < n ? 1 : 0) << 25);
-      }
-    }
-    // ---- schedule of the on-chip gradient kernel (see tree_setup_kernel) ----
-    if (a.macros) {
-      // stored (1) / unstored (2) classes, bottom-up
-      Arr cls;
-      cls.fill(0);
-      for (int v = n; v < N - 1; v++) {
-        const int a0 = c0.rd(v), a1 = c1.rd(v);
-        const int k0c = cls.rd(a0), k1c = cls.rd(a1);
-        const bool unstored = (a0 < n || k0c == 1) && (a1 < n || k1c == 1);
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) cls.r[nb] = own(nb) == v ? (unstored ? 2 : 1) : cls.r[nb];
-      }
-      Arr sslot;
-      int stored_before = 0, macros_before = 0;
-#pragma unroll
-      for (int nb = 0; nb < NB; nb++) {
-        const int v = own(nb);
-        cls.r[nb] = v == N - 1 ? 1 : cls.r[nb];
-        const bool internal = v >= n && v < N;
-        const bool stored = internal && cls.r[nb] == 1 && v != N - 1;
-        const uint64_t stored_mask = __ballot(stored);
-        const uint64_t macro_mask = __ballot(internal && cls.r[nb] == 1);
-        const uint64_t below = (1ull << lane) - 1;
-        // slots and macro indices in node-id order
-        sslot.r[nb] = v == N - 1 ? -1 : stored_before + __popcll(stored_mask & below);
-        is_macro[nb] = internal && cls.r[nb] == 1;
-        macro_rank[nb] = macros_before + __popcll(macro_mask & below);
-        stored_before += __popcll(stored_mask);
-        macros_before += __popcll(macro_mask);
-      }
-      stored_total = stored_before;
-      macro_total = macros_before;
-      // every lane that owns a macro assembles it from its children's lanes (cross-lane
-      // reads stay outside lane-dependent conditions: an inactive source lane reads as 0)
-#pragma unroll
-      for (int nb = 0; nb < NB; nb++) {
-        int kind[2];
-        me[nb].node = own(nb);
-        me[nb].pad = 0;
-        me[nb].qslot = sslot.r[nb];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          const int ch = j ? c1.r[nb] : c0.r[nb];
-          const int cls_ch = cls.gather(ch), chs = sslot.gather(ch);
-          const int ga_ = c0.gather(ch), gb_ = c1.gather(ch);
-          const int cc = ch >= n ? cls_ch : 0;
-          me[nb].child[j] = ch;
-          kind[j] = cc;
-          me[nb].cslot[j] = cc == 1 ? chs : 0;
-          const bool expand = cc == 2;
-          const int ga = expand ? ga_ : 0, gb = expand ? gb_ : 0;
-          const int gas = sslot.gather(ga), gbs = sslot.gather(gb);
-          me[nb].grand[2 * j] = ga;
-          me[nb].grand[2 * j + 1] = gb;
-          me[nb].gslot[2 * j] = ga >= n ? gas : 0;
-          me[nb].gslot[2 * j + 1] = gb >= n ? gbs : 0;
-        }
-        me[nb].shape =
-            macro_shape(kind[0], kind[1], own(nb) == N - 1, me[nb].child, me[nb].grand, n);
-      }
-      if (stored_total > max_stored(n)) status = kTooManySlots;
-    }
-  }
-  if (status != kOk && lane == 0) set_status(a.status, status, t);
-  const bool ok = status == kOk || status == kTooManySlots;
-  if (!ok) {
-    if (lane == 0 && a.macro_count) a.macro_count[t] = 0;
-    for (int i = lane; i < n - 1; i += 64) sched[i] = {n + i, 0, 1, 0};
-    for (int v = lane; v < N; v += 64) ble[v] = 0.0;
-    return;
-  }
-#pragma unroll
-  for (int nb = 0; nb < NB; nb++)
-    if (own(nb) < n - 1) sched[own(nb)] = {s_node.r[nb], s_c0.r[nb], s_c1.r[nb], s_sl.r[nb]};
-  if (a.macros) {
-    MacroEntry* mac = a.macros + (size_t)t * max_macros(n);
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++)
-      if (is_macro[nb]) mac[macro_rank[nb]] = me[nb];
-    if (lane == 0) a.macro_count[t] = macro_total;
-  }
-  if (!a.rooted) {
-    const double* bl = a.bl + (size_t)t * (N - 1);
-    for (int v = lane; v < N; v += 64) ble[v] = v < N - 2 ? bl[v] : 0.0;
-  } else {
-    const double* bl = a.bl + (size_t)t * N;
-    const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
-    for (int v = lane; v < N; v += 64) ble[v] = (rates && v < N - 1) ? bl[v] * rates[v] : bl[v];
-  }
-}
-#undef RDL
-#undef WRL
-
-// ------------------------------------------------------------------------
-// Model setup (one thread per model instance).
-// ------------------------------------------------------------------------
-__device__ void jacobi4(const double* A_in, double* evals, double* U) {
-  double A[16];
-  for (int i = 0; i < 4; i++)
-    for (int j = 0; j < 4; j++) A[i * 4 + j] = i >= j ? A_in[i * 4 + j] : A_in[j * 4 + i];
-  for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; sweep++) {
-    double off = 0, diag = 0;
-    for (int i = 0; i < 4; i++)
-      for (int j = 0; j < 4; j++) {
-        const double x = A[i * 4 + j] * A[i * 4 + j];
-        if (i != j) off += x; else diag += x;
-      }
-    if (off <= 1e-40 * diag || off == 0.) break;
-    for (int p = 0; p < 3; p++)
-      for (int q = p + 1; q < 4; q++) {
-        const double apq = A[p * 4 + q];
-        if (apq == 0.) continue;
-        const double theta = (A[q * 4 + q] - A[p * 4 + p]) / (2. * apq);
-        const double tt = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
-        const double c = 1. / sqrt(tt * tt + 1.), sn = tt * c;
-        for (int k = 0; k < 4; k++) {
-          const double akp = A[k * 4 + p], akq = A[k * 4 + q];
-          A[k * 4 + p] = c * akp - sn * akq;
-          A[k * 4 + q] = sn * akp + c * akq;
-        }
-        for (int k = 0; k < 4; k++) {
-          const double apk = A[p * 4 + k], aqk = A[q * 4 + k];
-          A[p * 4 + k] = c * apk - sn * aqk;
-          A[q * 4 + k] = sn * apk + c * aqk;
-        }
-        for (int k = 0; k < 4; k++) {
-          const double ukp = U[k * 4 + p], ukq = U[k * 4 + q];
-          U[k * 4 + p] = c * ukp - sn * ukq;
-          U[k * 4 + q] = sn * ukp + c * ukq;
-        }
-      }
-  }
-  for (int i = 0; i < 4; i++) evals[i] = A[i * 4 + i];
-  for (int i = 0; i < 3; i++) {
-    int m = i;
-    for (int j = i + 1; j < 4; j++)
-      if (evals[j] < evals[m]) m = j;
-    if (m != i) {
-      const double tmp = evals[i]; evals[i] = evals[m]; evals[m] = tmp;
-      for (int k = 0; k < 4; k++) {
-        const double u = U[k * 4 + i]; U[k * 4 + i] = U[k * 4 + m]; U[k * 4 + m] = u;
-      }
-    }
-  }
-}
-
-// stick_breaking_transform.cpp:20-43
-__device__ void stick_breaking(int K, const double* y, double* x) {
-  double stick = 1.0;
-  for (int k = 0; k < K - 1; k++) {
-    const double z = 1.0 / (1 + exp(-(y[k] - log((double)(K - k - 1)))));
-    x[k] = stick * z;
-    stick -= x[k];
-  }
-  x[K - 1] = stick;
-}
-__device__ void stick_breaking_inverse(int K, const double* x, double* y) {
-  double sum = 0;
-  for (int k = 0; k < K - 1; k++) {
-    const double z = x[k] / (1.0 - sum);
-    y[k] = log(z / (1.0 - z)) + log((double)(K - k - 1));
-    sum += x[k];
-  }
-}
-
-__device__ void model_setup_thread(const ModelSetupArgs& a, int idx) {
-  if (idx >= a.T * a.models_per_tree) return;
-  const int t = idx / a.models_per_tree, j = idx % a.models_per_tree;
-  const double* row = a.params + (size_t)t * a.param_count;
-  DevModel& m = a.models[idx];
-  if (a.subst == 0) {
-    // substitution_model.hpp:59-74 (JC69 eigensystem as hard-coded there)
-    const double V[16] = {1.0, 2.0, 0.0, 0.5, 1.0, -2.0, 0.5, 0.0,
-                          1.0, 2.0, 0.0, -0.5, 1.0, -2.0, -0.5, 0.0};
-    const double Vi[16] = {0.25, 0.25, 0.25, 0.25, 0.125, -0.125, 0.125, -0.125,
-                           0.0,  1.0,  0.0,  -1.0, 1.0,   0.0,    -1.0,  0.0};
-    for (int i = 0; i < 4; i++) {
-      m.pi[i] = 0.25;
-      m.lambda[i] = i == 0 ? 0.0 : -1.3333333333333333;
-      for (int k = 0; k < 4; k++) m.Q[i * 4 + k] = i == k ? -1.0 : 1.0 / 3.0;
-    }
-    for (int i = 0; i < 16; i++) {
-      m.V[i] = V[i];
-      m.Vinv[i] = Vi[i];
-    }
-  } else {
-    // substitution_model.cpp:17-80, with the finite-difference perturbation of
-    // fat_beagle.cpp:400-438 applied for j > 0: coordinate c of the
-    // stick-breaking image of (frequencies | rates), sign +/-.
-    double rates[6], freqs[4];
-    for (int i = 0; i < 6; i++) rates[i] = row[a.rates_off + i];
-    for (int i = 0; i < 4; i++) freqs[i] = row[a.freqs_off + i];
-    double fsum = 0, rsum = 0;
-    for (int i = 0; i < 4; i++) fsum += freqs[i];
-    for (int i = 0; i < 6; i++) rsum += rates[i];
-    if (j == 0) {
-      if (fabs(fsum - 1.) >= 0.001) set_status(a.status, kGtrFrequencies, t);
-      if (fabs(rsum - 1.) >= 0.001) set_status(a.status, kGtrRates, t);
-    }
-    if (j > 0) {
-      const int coord = (j - 1) >> 1;
-      const double delta = ((j - 1) & 1) ? -1.e-6 : 1.e-6;
-      double y[5];
-      if (coord < 3) {
-        stick_breaking_inverse(4, freqs, y);
-        y[coord] += delta;
-        stick_breaking(4, y, freqs);
-      } else {
-        stick_breaking_inverse(6, rates, y);
-        y[coord - 3] += delta;
-        stick_breaking(6, y, rates);
-      }
-    }
-    double Q[16];
-    int ri = 0;
-    for (int i = 0; i < 4; i++)
-      for (int k = i + 1; k < 4; k++) {
-        const double r = rates[ri++];
-        Q[i * 4 + k] = r * freqs[k];
-        Q[k * 4 + i] = r * freqs[i];
-      }
-    double total = 0;
-    for (int i = 0; i < 4; i++) {
-      double row_sum = 0;
-      for (int k = 0; k < 4; k++)
-        if (i != k) row_sum += Q[i * 4 + k];
-      Q[i * 4 + i] = -row_sum;
-      total += row_sum * freqs[i];
-    }
-    for (int i = 0; i < 16; i++) Q[i] /= total;
-    double sq[4], S[16], U[16], ev[4];
-    for (int i = 0; i < 4; i++) sq[i] = sqrt(freqs[i]);
-    for (int i = 0; i < 4; i++)
-      for (int k = 0; k < 4; k++) S[i * 4 + k] = sq[i] * Q[i * 4 + k] * (1.0 / sq[k]);
-    jacobi4(S, ev, U);
-    for (int i = 0; i < 4; i++) {
-      m.pi[i] = freqs[i];
-      m.lambda[i] = ev[i];
-      for (int k = 0; k < 4; k++) {
-        m.Q[i * 4 + k] = Q[i * 4 + k];
-        m.V[i * 4 + k] = (1.0 / sq[i]) * U[i * 4 + k];
-        m.Vinv[i * 4 + k] = U[k * 4 + i] * sq[k];
-      }
-    }
-  }
-  if (a.site == 0) {
-    m.cat_rate[0] = 1.0;
-    m.cat_weight[0] = 1.0;
-    m.cat_drate[0] = 0.0;
-  } else {
-    // site_model.cpp:37-62
-    const int K = a.K;
-    const double shape = row[a.shape_off];
-    double mean_rate = 0, mean_deriv = 0;
-    for (int i = 0; i < K; i++) {
-      const double quantile = (2.0 * i + 1.0) / (2.0 * K);
-      const double r = pow(-log(1.0 - quantile), 1.0 / shape);
-      m.cat_rate[i] = r;
-      mean_rate += r;
-      const double du = -r * log(-log(1.0 - quantile)) / (shape * shape);
-      m.cat_drate[i] = du;
-      mean_deriv += du;
-    }
-    mean_rate /= K;
-    mean_deriv /= K;
-    for (int i = 0; i < K; i++) {
-      m.cat_drate[i] =
-          (m.cat_drate[i] * mean_rate - m.cat_rate[i] * mean_deriv) / (mean_rate * mean_rate);
-      m.cat_rate[i] /= mean_rate;
-      m.cat_weight[i] = 1.0 / K;
-    }
-  }
+  __shared__ int tree_lds[kSmallTreeLdsInts * NB];
+  SmallTree<NB> tree;
+  small_tree_build<NB>(a, blockIdx.x, threadIdx.x, tree, tree_lds);
+  small_tree_store<NB>(a, blockIdx.x, threadIdx.x, tree);
 }
 
 // ------------------------------------------------------------------------

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kTile, 2) void gradient_walk_kernel(LikArgs a) {
   const int gtiles = a.g_tiles;  // pattern tiles x category groups
   const int groups = a.cat_groups, tiles_per_group = gtiles / groups;
   const int Mmax = max_macros(n);
-  const MacroEntry* __restrict__ macros = a.macros + (size_t)t * Mmax;
+  const MacroEntry* __restrict__ macros = a.macros + (size_t)t * macro_stride(n);
   const cint_ptr mw = as_const(reinterpret_cast<const int*>(macros));  // scalar loads
   // Tip staging starts here, before anything else of the prologue: this lane's (macro,
   // position) pairs j = lane, lane + 64 -- their node ids are the first link of the chain
@@ -867,7 +867,7 @@ __global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMa
   const int ge = blockIdx.x;  // gradient evaluation of this launch (grid.x: no 65535 limit)
   int t, mi;
   a.map.decode(a.eval_begin + ge, t, mi);
-  const MacroEntry* mac = a.macros + (size_t)t * Mmax;
+  const MacroEntry* mac = a.macros + (size_t)t * macro_stride(a.n);
   const int M = a.macro_count[t];
   for (int j = threadIdx.x; j < M * 6; j += kTmBlock) {
     const int m = j / 6, pos = j - m * 6;

@@ -40,6 +40,7 @@
 
 #include "mi_phylo_device_utils.h"
 #include "mi_phylo_kernels.h"
+#include "mi_phylo_setup_device.h"
 
 namespace miphylo {
 namespace {
@@ -100,27 +101,71 @@ struct Ops {
   double x[PRE ? 14 : 7];
 };
 
-template <bool RESCALE>
-// (R = 2 -- 8 patterns per wave, 14 KB of LDS -- is built with three waves per SIMD:
-// `make EXTRA_LLVM=-DMI_LLR=2`, an experiment of round 4, DESIGN.md 4.1)
-__global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_kernel(LikArgs a) {
+// Hand-off word of the one-launch small call (round 5), one per tree: the set-up waves of a
+// tree add kReadyQuarter each when their share of the tree's operand records (wave 0 also the
+// macro list and the model instance) has been written through to memory, wave 0 adds the macro
+// count in the low byte; the walk waves of the tree wait for kSetupQuarters of them.
+constexpr int kSetupQuarters = 4, kReadyQuarter = 1 << 8;
+// polls before a walk wave gives up (0.2 us apart: a fifth of a second): a set-up wave that
+// never ran is an error (status kFusedTimeout), not a hang
+constexpr int kReadySpins = 1 << 20;
+
+// block: this wave's number among the walk waves of the launch.  FUSED: `ready` is the
+// hand-off word array (above), the launch's first workgroups are set-up waves.
+template <bool RESCALE, bool FUSED>
+__device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, const int block,
+                                              const int32_t* ready) {
   static_assert(R == 2 || R == 3, "tip bytes of a (macro, position) pair come as R words");
-  extern __shared__ double wlds[];
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
   // one tile per wave (several tiles per wave, as the second generation has them, were
   // measured here: what must live from tile to tile pushes the 216 registers of this kernel
   // past 256 -- 176 B of scratch per lane, 0.78 -> 0.95 ms)
-  const TileEval te = xcd_map(blockIdx.x, a.g_tiles, a.walk_evals);
+  const TileEval te = xcd_map(block, a.g_tiles, a.walk_evals);
   const int job_eval = te.eval, tile = te.tile;
   const int e = a.eval_offset + job_eval;
-  const int gi = a.grad_offset + job_eval;
+  int gi = a.grad_offset + job_eval;
   int t, mi;
   a.map.decode(e, t, mi);
+  int M_ready = 0;
+#ifdef XP_STAMPS
+  const long long w_in = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (FUSED) {
+    // Wait for this tree's set-up waves.  Everything they hand over (macro list, operand
+    // records, model instance) lies in cache lines of its own per tree (macro_stride, kVisit,
+    // alignas(128) DevModel) that no wave of this launch reads before the word says so, and was
+    // stored write-through (sc1) and waited for (vmcnt(0)) before the word was added to: the
+    // first touch of such a line after the poll misses every cache of this CU and XCD (they
+    // were invalidated when the kernel started) and is served with the stored bytes.
+    int v = 0, spins = 0;
+#ifdef XP_WALK_ONLY
+    v = (kSetupQuarters << 8) | __builtin_amdgcn_readfirstlane(a.macro_count[t]);
+#else
+    for (;;) {
+      v = __builtin_amdgcn_readfirstlane(
+          __hip_atomic_load(ready + (size_t)t * kReadyStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if ((v >> 8) >= kSetupQuarters || ++spins >= kReadySpins) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+    // (-1: waited in vain.  The wave leaves through the one exit below -- a second `return`
+    // up here, with its status store, changed how the WHOLE walk is compiled: 224 registers
+    // instead of 214 and a wait in front of single operand loads, +34 % time per 1000 trees)
+    M_ready = (v >> 8) < kSetupQuarters ? -1 : (v & 0xff);
+    // No load of the handed-over data may move above the poll -- the scalar loads of the
+    // macro list are loads from the constant address space, which the compiler may hoist over
+    // anything: the indices every such address is formed from are redefined HERE.
+    asm volatile("" : "+s"(t), "+s"(mi), "+s"(gi) : : "memory");
+  }
+#ifdef XP_STAMPS
+  if (lane == 0 && (block % 1499) == 0)
+    printf("walk block %d (tree %d tile %d): in %lld polled %lld\n", block, t, tile, w_in, (long long)__builtin_amdgcn_s_memrealtime());
+#endif
   const DevModel* __restrict__ model = a.models + mi;
   const int K = a.K, n = a.n;
   const int Mmax = max_macros(n);
-  const MacroEntry* __restrict__ macros = a.macros + (size_t)t * Mmax;
+  const MacroEntry* __restrict__ macros = a.macros + (size_t)t * macro_stride(n);
   const cint_ptr mw = as_const(reinterpret_cast<const int*>(macros));  // scalar loads
   // tip staging starts here (node ids of this lane's (macro, position) pairs): the first link
   // of the chain node id -> tip bytes -> LDS, the longest latency of a wave's life
@@ -132,8 +177,11 @@ __global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_kerne
     const int j = lane + 64 * u;
     if (j < jmax) node_j[u] = mwv[(j / 6) * 16 + 1 + (j % 6)];
   }
-  const int M = __builtin_amdgcn_readfirstlane(a.macro_count[t]);
-  if (M <= 0) return;
+  const int M = FUSED ? M_ready : __builtin_amdgcn_readfirstlane(a.macro_count[t]);
+  if (M <= 0) {
+    if (FUSED && M < 0 && lane == 0) set_status(a.status, kFusedTimeout, t);
+    return;
+  }
   constexpr int ppr = 4, TP = ppr * R;
   struct __attribute__((packed)) Bytes12 {  // (4 R bytes: the pair's codes of this tile)
     uint32_t d[R];
@@ -776,6 +824,14 @@ __global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_kerne
   }
 }
 
+template <bool RESCALE>
+// (R = 2 -- 8 patterns per wave, 14 KB of LDS -- is built with three waves per SIMD:
+// `make EXTRA_LLVM=-DMI_LLR=2`, an experiment of round 4, DESIGN.md 4.1)
+__global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_kernel(LikArgs a) {
+  extern __shared__ double wlds[];
+  walk_lut_body<RESCALE, false>(a, wlds, blockIdx.x, nullptr);
+}
+
 // ------------------------------------------------------------------------
 // The operand records of the third-generation walk.  One thread per (node, category) of ONE
 // gradient evaluation (blockIdx.x), as transition_macro_kernel: P = I + V expm1(L r t) V^-1
@@ -783,6 +839,42 @@ __global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_kerne
 // generation's ({f, tr} per (lo, hi) slot), a tip's is the table [row][state 0..3, gap]{P, P Q}.
 // Staged through LDS (row stride 41) so that a block writes runs of whole records.
 // ------------------------------------------------------------------------
+// One (node, category) of a record: P = I + V expm1(L tau) V^-1 (negative entries clamped), as
+// the {f, tr} slots of an internal position (32 doubles) or the table of a tip position (40).
+__device__ __forceinline__ void lut_record(const DevModel& md, const double tau, const bool tip, double* st) {
+  double ex[4], W[16], Pm[16];
+  for (int x = 0; x < 4; x++) ex[x] = expm1(md.lambda[x] * tau);
+  for (int x = 0; x < 4; x++)
+    for (int j = 0; j < 4; j++) W[x * 4 + j] = ex[x] * md.Vinv[x * 4 + j];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double sum = i == j ? 1.0 : 0.0;
+      for (int x = 0; x < 4; x++) sum += md.V[i * 4 + x] * W[x * 4 + j];
+      Pm[i * 4 + j] = sum > 0 ? sum : 0;
+    }
+  if (tip) {
+    for (int i = 0; i < 4; i++) {
+      double ps = 0, qs = 0;
+      for (int j = 0; j < 4; j++) {
+        double pq = 0;
+        for (int x = 0; x < 4; x++) pq += Pm[i * 4 + x] * md.Q[x * 4 + j];
+        st[(i * 5 + j) * 2] = Pm[i * 4 + j];
+        st[(i * 5 + j) * 2 + 1] = pq;
+        ps += Pm[i * 4 + j];
+        qs += pq;
+      }
+      st[(i * 5 + 4) * 2] = ps;
+      st[(i * 5 + 4) * 2 + 1] = qs;
+    }
+  } else {
+    for (int l = 0; l < 4; l++)  // slot (lo = l, hi = h): f = P[lo][hi], tr = P[hi][lo]
+      for (int h = 0; h < 4; h++) {
+        st[(l * 4 + h) * 2] = Pm[l * 4 + h];
+        st[(l * 4 + h) * 2 + 1] = Pm[h * 4 + l];
+      }
+  }
+}
+
 constexpr int kTlBlock = 128;
 __global__ __launch_bounds__(kTlBlock) void transition_lut_kernel(TransitionMacroArgs a) {
   __shared__ double stage[kTlBlock * 41];
@@ -793,7 +885,7 @@ __global__ __launch_bounds__(kTlBlock) void transition_lut_kernel(TransitionMacr
   const int ge = blockIdx.x;
   int t, mi;
   a.map.decode(a.eval_begin + ge, t, mi);
-  const MacroEntry* mac = a.macros + (size_t)t * Mmax;
+  const MacroEntry* mac = a.macros + (size_t)t * macro_stride(a.n);
   const int M = a.macro_count[t];
   for (int j = threadIdx.x; j < M * 6; j += kTlBlock) {
     const int m = j / 6, pos = j - m * 6;
@@ -810,43 +902,11 @@ __global__ __launch_bounds__(kTlBlock) void transition_lut_kernel(TransitionMacr
   if (live) {
     const bool tip = node < a.n;
     const double tau = md.cat_rate[k] * a.bl_eff[(size_t)t * a.N + node];
-    double ex[4], W[16], Pm[16];
-    for (int x = 0; x < 4; x++) ex[x] = expm1(md.lambda[x] * tau);
-    for (int x = 0; x < 4; x++)
-      for (int j = 0; j < 4; j++) W[x * 4 + j] = ex[x] * md.Vinv[x * 4 + j];
-    for (int i = 0; i < 4; i++)
-      for (int j = 0; j < 4; j++) {
-        double sum = i == j ? 1.0 : 0.0;
-        for (int x = 0; x < 4; x++) sum += md.V[i * 4 + x] * W[x * 4 + j];
-        Pm[i * 4 + j] = sum > 0 ? sum : 0;
-      }
+    lut_record(md, tau, tip, st);
     const int slot = slot_of[node], m = slot / 6, pos = slot - m * 6;
     const int rec8 = (int)((((size_t)ge * Mmax + m) * 6 + pos) * (kPos / 8));
-    if (tip) {
-      for (int i = 0; i < 4; i++) {
-        double ps = 0, qs = 0;
-        for (int j = 0; j < 4; j++) {
-          double pq = 0;
-          for (int x = 0; x < 4; x++) pq += Pm[i * 4 + x] * md.Q[x * 4 + j];
-          st[(i * 5 + j) * 2] = Pm[i * 4 + j];
-          st[(i * 5 + j) * 2 + 1] = pq;
-          ps += Pm[i * 4 + j];
-          qs += pq;
-        }
-        st[(i * 5 + 4) * 2] = ps;
-        st[(i * 5 + 4) * 2 + 1] = qs;
-      }
-      rec_of[threadIdx.x] = rec8 + k * (int)(kTipCat / 8);
-      len_of[threadIdx.x] = 40;
-    } else {
-      for (int l = 0; l < 4; l++)      // slot (lo = l, hi = h): f = P[lo][hi], tr = P[hi][lo]
-        for (int h = 0; h < 4; h++) {
-          st[(l * 4 + h) * 2] = Pm[l * 4 + h];
-          st[(l * 4 + h) * 2 + 1] = Pm[h * 4 + l];
-        }
-      rec_of[threadIdx.x] = rec8 + k * 32;
-      len_of[threadIdx.x] = 32;
-    }
+    rec_of[threadIdx.x] = rec8 + k * (tip ? (int)(kTipCat / 8) : 32);
+    len_of[threadIdx.x] = tip ? 40 : 32;
   } else {
     rec_of[threadIdx.x] = -1;
     len_of[threadIdx.x] = 0;
@@ -865,9 +925,230 @@ __global__ __launch_bounds__(kTlBlock) void transition_lut_kernel(TransitionMacr
   }
 }
 
+// ------------------------------------------------------------------------
+// The one-launch small call (round 5).  A `phylo_gradients` call of a
+// JC69-type engine used to be four dependent launches: tree set-up (+ model instances) ->
+// operand records -> walk -> reduce/finalize; on a batch of 125 trees -- the share of one GPU
+// of eight under strong scaling -- the two set-up kernels and their launch boundaries were
+// 20 of the step's 145 microseconds, with most of the chip idle.  Here they are the FIRST
+// 4 T one-wave workgroups of the walk's own launch:
+//   * set-up wave (tree t, quarter q): builds the tree's schedule in its registers
+//     (small_tree_build -- all four quarters do, redundantly: it costs no memory traffic and no
+//     hand-off between them), the model instance in LDS, then writes its quarter of the tree's
+//     (node, category) operand records; quarter 0 also writes the macro list, the model, the
+//     log-likelihood schedule and the effective branch lengths.  What walk waves read is stored
+//     write-through (sc1); then s_waitcnt vmcnt(0) and ONE agent-scope add to ready[t].
+//   * walk waves (walk_lut_body<.., true>) poll ready[t] (sc1 load, s_sleep in between, bounded).
+// Deadlock-freedom rests on workgroups being dispatched in id order (observed, not promised by
+// HIP): the set-up waves are resident (or done) before any walk wave is, and they wait for
+// nothing.  Should a walk wave ever wait in vain, it gives up after kReadySpins polls with
+// the sticky status kFusedTimeout -- the call fails with a message instead of hanging.
+// ------------------------------------------------------------------------
+// Write-through (sc1) stores of 16 bytes.  Inline assembly: the compiler has no 16-byte store
+// with a scope, and does not count these -- the role ends with an explicit s_waitcnt vmcnt(0).
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_sc1(void* p, const v4i32 v) {
+  // (s_nop: a store of more than 64 bits reads its data registers a cycle or two after it
+  // issues, and the compiler's hazard recogniser, which pads its own stores, does not see this
+  // one -- without the wait states the next instruction overwrote a data register of the macro
+  // list's stores now and then: garbage macros, wild tip reads in the walk waves)
+  // (no "memory" clobber: volatile asm statements keep their order among themselves -- the
+  // role's final wait is one --, and the LDS reads of the staged records may be batched across
+  // these stores)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v));
+}
+__device__ __forceinline__ void store16_sc1(double* p, const double x, const double y) {
+  store16_sc1(p, v4i32{__double2loint(x), __double2hiint(x), __double2loint(y), __double2hiint(y)});
+}
+
+// LDS of a set-up wave: staged records [per_q][41] | model instance | rec_of, len_of [64] | slot_of [N - 1]
+__host__ __device__ inline unsigned fused_setup_lds(int n, int K) {
+  const unsigned per_q = (unsigned)(((2 * n - 2) * K + kSetupQuarters - 1) / kSetupQuarters);
+  return per_q * 41u * 8u + (unsigned)sizeof(DevModel) + 2u * 64u * 4u + (unsigned)(2 * n - 2) * 4u;
+}
+
+__device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const int bid, char* lds) {
+  const TreeSetupArgs& a = f.ts;
+  const int t = bid / kSetupQuarters, q = bid - t * kSetupQuarters;
+  const int lane = threadIdx.x;
+  const int n = a.n, N = 2 * n - 1, K = f.ms.K;
+  const int per_q = ((N - 1) * K + kSetupQuarters - 1) / kSetupQuarters;
+  double* stage = reinterpret_cast<double*>(lds);
+  DevModel* md = reinterpret_cast<DevModel*>(lds + (unsigned)per_q * 41u * 8u);
+  int* rec_of = reinterpret_cast<int*>(reinterpret_cast<char*>(md) + sizeof(DevModel));
+  int* len_of = rec_of + 64;
+  int* slot_of = len_of + 64;
+
+#ifdef XP_STAMPS
+  long long st0 = __builtin_amdgcn_s_memrealtime(), st1, st2, st3, st4, st5;
+#define XSTAMP(x) x = __builtin_amdgcn_s_memrealtime()
+#else
+#define XSTAMP(x)
+#endif
+  // the model instance of the tree (one per tree in these calls)
+  model_setup_wave(f.ms, t, lane, *md);
+  XSTAMP(st1);
+  SmallTree<1> tree;
+  small_tree_build<1>(a, t, lane, tree, reinterpret_cast<int*>(lds));  // (the staging area is not in use yet)
+  const bool ok = tree.status == kOk;
+  const int M = ok ? tree.macro_total : 0;
+  XSTAMP(st2);
+  if (q == 0) small_tree_store<1>(a, t, lane, tree);  // (plain stores: later kernels read these)
+  if (ok) {
+    // node -> macro * 6 + position (the lane that owns a macro knows its children)
+    if (tree.is_macro[0]) {
+      const MacroEntry& me = tree.me[0];
+      const int base = tree.macro_rank[0] * 6;
+      slot_of[me.child[0]] = base;
+      slot_of[me.child[1]] = base + 1;
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        if (((me.shape >> (2 * j)) & 3) == 2) {
+          slot_of[me.grand[2 * j]] = base + 2 + 2 * j;
+          slot_of[me.grand[2 * j + 1]] = base + 3 + 2 * j;
+        }
+    }
+    if (q == 0) {
+      // the macro list, write-through: 16 words per entry
+      MacroEntry* mac = a.macros + (size_t)t * macro_stride(n);
+      if (tree.is_macro[0]) {
+        char* dst = reinterpret_cast<char*>(mac + tree.macro_rank[0]);
+        const MacroEntry& me = tree.me[0];
+        static_assert(sizeof(MacroEntry) == 64, "sixteen words, in this order");
+        store16_sc1(dst, v4i32{me.shape, me.child[0], me.child[1], me.grand[0]});
+        store16_sc1(dst + 16, v4i32{me.grand[1], me.grand[2], me.grand[3], me.node});
+        store16_sc1(dst + 32, v4i32{me.qslot, me.cslot[0], me.cslot[1], me.gslot[0]});
+        store16_sc1(dst + 48, v4i32{me.gslot[1], me.gslot[2], me.gslot[3], me.pad});
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations are in order)
+  if (ok) {
+    if (q == 0) {  // the model instance, write-through (the walk reads frequencies, rates, weights)
+      double* dst = reinterpret_cast<double*>(f.ms.models + t);
+      const double* src = reinterpret_cast<const double*>(md);
+      static_assert(sizeof(DevModel) % 16 == 0, "whole 16-byte pieces");
+      for (int i = lane; i < (int)(sizeof(DevModel) / 16); i += 64) store16_sc1(dst + 2 * i, src[2 * i], src[2 * i + 1]);
+    }
+    const int idx = q * per_q + lane;  // node * K + category
+    const int node = idx / K, k = idx - node * K;
+    const bool live = lane < per_q && node < N - 1;
+    if (live) {
+      // effective branch length as small_tree_store forms it
+      double bl;
+      if (!a.rooted) {
+        bl = node < N - 2 ? a.bl[(size_t)t * (N - 1) + node] : 0.0;
+      } else {
+        bl = a.bl[(size_t)t * N + node];
+        if (a.rates) bl *= a.rates[(size_t)t * (N - 1) + node];
+      }
+      const bool tip = node < n;
+      lut_record(*md, md->cat_rate[k] * bl, tip, stage + lane * 41);
+      const int slot = slot_of[node], m = slot / 6, pos = slot - m * 6;
+      const int rec8 = (int)((((size_t)t * max_macros(n) + m) * 6 + pos) * (kPos / 8));
+      rec_of[lane] = rec8 + k * (tip ? (int)(kTipCat / 8) : 32);
+      len_of[lane] = tip ? 40 : 32;
+    } else {
+      rec_of[lane] = -1;
+      len_of[lane] = 0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    XSTAMP(st3);
+    // eight lanes per record, up to three 16-byte pieces each: consecutive lanes write
+    // consecutive bytes.  Every LDS read first, unconditionally (rows clamped), then the
+    // stores under their conditions: with a read and its wait inside each condition the 24
+    // stores went out one LDS round trip apart (1.9 of the role's 11 microseconds).
+    {
+      int rec[8], len[8];
+      double va[24], vb[24];
+      const int part = lane & 7;
+#pragma unroll
+      for (int x8 = 0; x8 < 8; x8++) {
+        const int th = (lane >> 3) + 8 * x8;
+        rec[x8] = rec_of[th];
+        len[x8] = len_of[th];
+        const int row = min(th, per_q - 1) * 41;
+#pragma unroll
+        for (int p3 = 0; p3 < 3; p3++) {
+          const int d = 2 * (p3 * 8 + part);
+          va[3 * x8 + p3] = stage[row + min(d, 38)];
+          vb[3 * x8 + p3] = stage[row + min(d, 38) + 1];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 24; i++) asm volatile("" : "+v"(va[i]), "+v"(vb[i]));
+#pragma unroll
+      for (int x8 = 0; x8 < 8; x8++)
+#pragma unroll
+        for (int p3 = 0; p3 < 3; p3++) {
+          const int d = 2 * (p3 * 8 + part);
+          if (rec[x8] >= 0 && d < len[x8])
+            store16_sc1(f.mmats + (size_t)rec[x8] + d, va[3 * x8 + p3], vb[3 * x8 + p3]);
+        }
+    }
+  }
+  XSTAMP(st4);
+  // everything above has reached memory before the word says so
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  XSTAMP(st5);
+#ifdef XP_STAMPS
+  if (lane == 0 && (t == 0 || t == 60 || t == 124) && q < 2)
+    printf("setup role t %d q %d: start %lld end %lld model %lld tree %lld records %lld stores issued %lld landed %lld (10 ns ticks)\n", t, q, st0, (long long)__builtin_amdgcn_s_memrealtime(),
+           st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4);
+#endif
+  if (lane == 0)
+    __hip_atomic_fetch_add(f.ready + (size_t)t * kReadyStride, kReadyQuarter + (q == 0 ? M : 0), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool RESCALE>
+__global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_fused_kernel(LikArgs a, FusedSetupArgs f) {
+  extern __shared__ double wlds[];
+  if ((int)blockIdx.x < f.setup_blocks) {
+    fused_setup_role(f, blockIdx.x, reinterpret_cast<char*>(wlds));
+    return;
+  }
+  walk_lut_body<RESCALE, true>(a, wlds, (int)blockIdx.x - f.setup_blocks, f.ready);
+#ifdef XP_STAMPS
+  if (threadIdx.x == 0 && (((int)blockIdx.x - f.setup_blocks) % 1499) == 0)
+    printf("walk block %d: out %lld\n", (int)blockIdx.x - f.setup_blocks, (long long)__builtin_amdgcn_s_memrealtime());
+#endif
+}
+
 }  // namespace
 
 size_t gradient_walk_lut_mats_bytes_per_eval(int n) { return (size_t)max_macros(n) * kVisit; }
+
+// trees whose arrays fit one register per lane (64 nodes), a quarter of the (node, category)
+// pairs per set-up wave
+bool gradient_walk_lut_fused_applies(int n, int K) {
+  return gradient_walk_lut_applies(K) && 2 * n - 1 <= 64 && ((2 * n - 2) * K + 3) / 4 <= 64;
+}
+
+void launch_gradient_walk_lut_fused(const LikArgs& a_in, const FusedSetupArgs& f_in, int count, bool rescale,
+                                    hipStream_t s) {
+  if (count <= 0) return;
+  LikArgs a = a_in;
+  FusedSetupArgs f = f_in;
+  a.kp = 4;
+  a.cat_groups = 1;
+  a.walk_evals = count;
+  f.setup_blocks = kSetupQuarters * count;
+#ifdef XP_WALK_ONLY
+  f.setup_blocks = 0;
+#endif
+  const int gtiles = gradient_mfma_tiles(a.P, a.K);
+  dim3 grid((unsigned)((size_t)count * gtiles + f.setup_blocks));
+  if (getenv("MI_PHYLO_XP_SETUP_ONLY")) grid.x = f.setup_blocks;  // (timing experiment)
+  const size_t lds = std::max<size_t>(gradient_walk_lds_bytes(a.n, a.K, rescale, false), fused_setup_lds(a.n, a.K));
+  if (rescale) {
+    allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_fused_kernel<true>), lds);
+    hipLaunchKernelGGL(gradient_walk_lut_fused_kernel<true>, grid, dim3(kTile), lds, s, a, f);
+  } else {
+    allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_fused_kernel<false>), lds);
+    hipLaunchKernelGGL(gradient_walk_lut_fused_kernel<false>, grid, dim3(kTile), lds, s, a, f);
+  }
+}
 
 void launch_transition_lut(const TransitionMacroArgs& a, hipStream_t s) {
   if (a.count <= 0) return;
@@ -898,5 +1179,6 @@ void launch_gradient_walk_lut(const LikArgs& a_in, int count, bool rescale, hipS
   }
 }
 const char* gradient_walk_lut_kernel_name() { return "gradient_walk_lut_kernel"; }
+const char* gradient_walk_lut_fused_kernel_name() { return "gradient_walk_lut_fused_kernel"; }
 
 }  // namespace miphylo

@@ -18,7 +18,9 @@ constexpr int kFdModels = 17;    // base model + 2*(3 frequency + 5 rate) pertur
 
 // One substitution+site model instance (what FatBeagle::SetParameters pushes to
 // BEAGLE per tree: fat_beagle.cpp:273-300).
-struct DevModel {
+// (128-byte aligned, hence a multiple of 128 bytes: no cache line holds two instances -- see
+// macro_stride)
+struct alignas(128) DevModel {
   double pi[kStates];
   double Q[kStates * kStates];     // row-major
   double V[kStates * kStates];     // eigenvectors
@@ -69,6 +71,11 @@ __host__ __device__ inline int macro_shape(int kind0, int kind1, bool root, cons
 }
 
 inline __host__ __device__ int max_macros(int n) { return (n - 2) / 2 + 1; }
+// Stride of a tree's macro list in HBM: whole 128-byte lines per tree (an even number of the
+// 64-byte entries), so that no cache line holds macros of two trees -- the one-launch small
+// call hands each tree's list from its set-up wave to its walk waves INSIDE a kernel, and a
+// line first touched after the hand-off cannot be stale (kernels_walk3.hip).
+inline __host__ __device__ int macro_stride(int n) { return (max_macros(n) + 1) & ~1; }
 inline __host__ __device__ int max_stored(int n) { return (n - 2) / 2 > 1 ? (n - 2) / 2 : 1; }
 
 enum StatusCode : int32_t {
@@ -80,6 +87,7 @@ enum StatusCode : int32_t {
   kGtrRates = 5,
   kBadRateCount = 6,
   kTooManySlots = 7,
+  kFusedTimeout = 8,
 };
 
 }  // namespace miphylo

@@ -44,6 +44,9 @@ struct CallShape {
 // analytic: the opt-in analytic substitution gradient replaces the 16 finite-difference
 // evaluations (and with them the perturbed-model site pass): one gradient evaluation per
 // tree, as for JC69.
+// (also for a GTR gradient call that asks for neither the substitution nor the site gradient
+// -- `light`, run_device: the finite-difference passes and the perturbed-model site pass would
+// be computed for nobody)
 CallShape call_shape(const mi_engine* e, int T, bool gradient, bool analytic = false) {
   CallShape c{};
   c.T = T;
@@ -105,12 +108,12 @@ size_t plv_bytes_per_eval(const mi_engine* e) {
 }
 
 int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
-            bool analytic = false) {
-  const CallShape c = call_shape(e, T, gradient, analytic);
+            bool analytic = false, bool light = false) {
+  const CallShape c = call_shape(e, T, gradient, analytic || light);
   const int n = e->n, N = e->N;
   if (e->tree_scratch.ensure(sizeof(int32_t) * (size_t)T * 13 * N)) return 1;
   if (e->sched.ensure(sizeof(SchedEntry) * (size_t)T * (n - 1))) return 1;
-  if (e->macros.ensure(sizeof(MacroEntry) * (size_t)T * max_macros(n))) return 1;
+  if (e->macros.ensure(sizeof(MacroEntry) * (size_t)T * macro_stride(n))) return 1;
   if (e->macro_count.ensure(sizeof(int32_t) * (size_t)T)) return 1;
   if (e->bl_eff.ensure(sizeof(double) * (size_t)T * N)) return 1;
   if (e->models.ensure(sizeof(DevModel) * (size_t)c.M)) return 1;
@@ -129,6 +132,12 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
   if (e->ll_part.ensure(sizeof(double) * (size_t)c.E * e->ll_stride)) return 1;
   if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
   if (e->status.ensure(sizeof(int32_t) * 2)) return 1;
+  if (gradient && e->fused_setup && walk3_possible(e) && e->ready.bytes < sizeof(int32_t) * kReadyStride * (size_t)T) {
+    // hand-off words of the one-launch small call: zero whenever no such call is running
+    if (e->ready.ensure(sizeof(int32_t) * kReadyStride * (size_t)T)) return 1;
+    HIP_TRY(hipMemset(e->ready.ptr, 0, e->ready.bytes));
+    HIP_TRY(hipDeviceSynchronize());
+  }
   if (e->ll_sum.ensure(sizeof(double) * (size_t)c.E)) return 1;
   if (gradient && e->g_sum.ensure(sizeof(double) * (size_t)c.Eg * 2 * N)) return 1;
   if (gradient) {
@@ -142,7 +151,7 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
       const size_t aper = gradient_arena_bytes_per_eval(n, e->P, e->K);
       const size_t achunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / aper));
       if (e->plv.ensure(aper * achunk)) return 1;
-      if (e->arena_macros.ensure(sizeof(MacroEntry) * (size_t)T * max_macros(n))) return 1;
+      if (e->arena_macros.ensure(sizeof(MacroEntry) * (size_t)T * macro_stride(n))) return 1;
       if (e->slot_need.ensure(sizeof(int32_t) * (size_t)T)) return 1;
     }
     const size_t g_width = std::max<size_t>(2 * (size_t)N, (size_t)gradient_mfma_width(n, true));
@@ -172,8 +181,15 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const int groups = mfma ? gradient_mfma_groups(e->K) : 1;
   const int g_tiles = mfma ? gradient_mfma_tiles(e->P, e->K) * groups : e->tiles;
   const bool analytic = e->analytic_subst && mfma && e->spec.subst_model == MI_SUBST_GTR;
-  if (reserve(e, d.T, d.gradient, !onchip, analytic)) return 1;
-  const CallShape c = call_shape(e, d.T, d.gradient, analytic);
+  // A GTR gradient call whose caller wants neither the substitution-model nor the site-model
+  // gradient (BASELINE configs[2] as worded: log-likelihood + branch-length gradient) is ONE
+  // evaluation per tree with the tree's own model, exactly like a JC69 call: no perturbed
+  // model instances, no finite-difference passes -- and it can take the one-launch path.
+  // What it delivers is bit-identical to the full call's.
+  const bool light = d.gradient && mfma && !analytic && e->spec.subst_model == MI_SUBST_GTR &&
+                     !d.out_subst && !d.out_site;
+  if (reserve(e, d.T, d.gradient, !onchip, analytic, light)) return 1;
+  const CallShape c = call_shape(e, d.T, d.gradient, analytic || light);
   const int n = e->n, N = e->N, T = d.T;
   // (the status word is sticky: cleared when it is read, check_status -- not per call: one
   // dispatch less on the small-batch path)
@@ -196,7 +212,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ts.status = e->status.as<int32_t>();
   ts.max_slots = e->max_slots;
   // the Sethi-Ullman schedule with LDS slots is what the log-likelihood kernels walk
-  ts.need_slots = !(d.gradient && mfma && groups == 1 && (!c.gtr || analytic));
+  ts.need_slots = !(d.gradient && mfma && groups == 1 && (!c.gtr || analytic || light));
   ModelSetupArgs ms{};
   ms.T = T;
   ms.models_per_tree = c.models_per_tree;
@@ -213,11 +229,22 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool prof = e->prof_used < e->prof_capacity;
   const bool marks = prof && e->prof_phases;
   PROF_MARK(e, marks, 0, s);
-  launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
   // (a call of a few trees keeps its stored vectors in LDS however large the tree)
   const bool arena = mfma && use_arena(e, d.rescaling, analytic, (size_t)T * (size_t)g_tiles);
   const bool walk2 = mfma && e->walk2;
   const bool walk3 = walk2 && walk3_possible(e) && !arena && !analytic && groups == 1;
+  constexpr int kMaxEvals = 32768;
+  // The one-launch call (kernels_walk3.hip): tree set-up, model instances and operand records
+  // ride in the walk's launch.  One evaluation and one model instance per tree (JC69-type
+  // calls), trees of at most 64 nodes, one walk launch, nobody else reads the schedule's LDS
+  // slots.
+  static const bool fuse_allowed =
+      !(getenv("MI_PHYLO_FUSE_FINALIZE") && std::string(getenv("MI_PHYLO_FUSE_FINALIZE")) == "0");
+  const bool fuse_setup = walk3 && e->fused_setup && fuse_allowed && c.E == T && c.models_per_tree == 1 &&
+                          !ts.need_slots && T <= kMaxEvals && e->ready.ptr &&
+                          gradient_walk_lut_fused_applies(n, e->K);
+  static const bool xp_walk_only = getenv("MI_PHYLO_XP_WALK_ONLY") != nullptr;
+  if (!fuse_setup || xp_walk_only) launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
   if (arena)
     launch_macro_slots(e->macros.as<MacroEntry>(), e->arena_macros.as<MacroEntry>(),
                        e->macro_count.as<int32_t>(), n, T, e->slot_need.as<int32_t>(),
@@ -252,7 +279,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   tr.tr_skip_end = c.E > T ? std::min(17 * T, c.E) : c.E;
   // evaluations nobody walks need no matrices at all
   tr.ev_skip_begin = tr.ev_skip_end = 0;
-  if (d.gradient && c.gtr && !analytic && !fd_pass) {
+  if (d.gradient && c.gtr && !analytic && !light && !fd_pass) {
     tr.ev_skip_begin = T;
     tr.ev_skip_end = site_pass ? 17 * T : c.E;
   }
@@ -293,7 +320,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     tm.mphi = analytic ? e->mphi.as<double>() + (size_t)grad_begin * (per / 2) : nullptr;
     launch_transition_macro(tm, s);
   };
-  if (walk2) {
+  if (walk2 && (!fuse_setup || xp_walk_only)) {
     macro_matrices(0, 0, T);
     if (site_pass) macro_matrices(17 * T, T, T);
   }
@@ -332,7 +359,6 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.store = mfma ? (arena ? 2 : 1) : 0;  // (the launchers follow the choice the schedules were made for)
   // one launch covers at most kMaxEvals evaluations (grid y dimension: 65535; a multiple
   // of 8 keeps whole evaluations per XCD)
-  constexpr int kMaxEvals = 32768;
   int walk_launches = 0;
   auto loglik_range = [&](int eval_begin, int count) {
     for (int done = 0; done < count; done += kMaxEvals) {
@@ -362,7 +388,14 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
           g.site_exp = e->site_exp.as<int32_t>();
           launch_loglik(g, part, d.rescaling, e->max_slots, s);
         }
-        if (walk3) launch_gradient_walk_lut(g, part, d.rescaling, s);
+        if (fuse_setup) {
+          FusedSetupArgs fs{};
+          fs.ts = ts;
+          fs.ms = ms;
+          fs.mmats = e->mmats.as<double>();
+          fs.ready = e->ready.as<int32_t>();
+          launch_gradient_walk_lut_fused(g, fs, part, d.rescaling, s);
+        } else if (walk3) launch_gradient_walk_lut(g, part, d.rescaling, s);
         else if (walk2) launch_gradient_walk(g, part, d.rescaling, analytic, s);
         else launch_gradient_mfma(g, part, d.rescaling, analytic, s);
       }
@@ -394,7 +427,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     PROF_MARK(e, marks, 3, s);
     if (fd_pass) loglik_range(T, 16 * T);
     if (site_pass) grad_range(17 * T, T, T);
-    e->dominant = walk3 ? gradient_walk_lut_kernel_name()
+    e->dominant = fuse_setup ? gradient_walk_lut_fused_kernel_name()
+                  : walk3 ? gradient_walk_lut_kernel_name()
                   : walk2 ? gradient_walk_kernel_name()
                         : (mfma ? gradient_mfma_kernel_name() : gradient_kernel_name());
   }
@@ -421,13 +455,11 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const int grad_kernel_count =
       mfma ? (groups > 1 ? ll_kernel_count : gradient_mfma_tiles(e->P, e->K)) : e->tiles;
   LlCounts ll_used{d.gradient ? grad_kernel_count : ll_kernel_count, ll_kernel_count, 0, 0};
-  if (d.gradient && c.gtr && !analytic) {
+  if (d.gradient && c.gtr && !analytic && !light) {
     ll_used.mid_lo = T;
     ll_used.mid_hi = 17 * T;
   }
   fa.ll_used = ll_used;
-  static const bool fuse_allowed =
-      !(getenv("MI_PHYLO_FUSE_FINALIZE") && std::string(getenv("MI_PHYLO_FUSE_FINALIZE")) == "0");
   bool fused = false;
   ReduceArgs fused_ra{};
   if (reduce_tiles_fits(N)) {
@@ -464,7 +496,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   fa.gradient = d.gradient;
   fa.rooted = d.rooted;
   fa.with_jacobian = d.with_jacobian;
-  fa.gtr = c.gtr && !analytic;  // finite-difference assembly of the substitution gradient
+  fa.gtr = c.gtr && !analytic && !light;  // finite-difference assembly of the substitution gradient
   fa.site_fused = c.site_fused;
   fa.site_separate = c.site_separate;
   fa.bl_eff = e->bl_eff.as<double>();
@@ -483,6 +515,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   fa.out_site = d.out_site;
   fa.out_subst = d.out_subst;
   fa.status = e->status.as<int32_t>();
+  fa.clear_ready = fuse_setup ? e->ready.as<int32_t>() : nullptr;
+  if (fuse_setup && !fused) return fail("internal error: the one-launch call needs the fused reduction");
   if (fused) launch_reduce_finalize(fused_ra, fa, s);
   else launch_finalize(fa, s);
   if (analytic && d.out_subst) {
@@ -720,6 +754,7 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
     e->walk2 = std::string(env) != "v1";
     e->walk3 = std::string(env) != "v1" && std::string(env) != "v2";
   }
+  if (const char* env = getenv("MI_PHYLO_FUSED_SETUP")) e->fused_setup = std::string(env) != "0";
   if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH")) {  // force one gradient kernel
     const std::string v(env);
     e->gradient_path = v == "hbm" ? 2 : v == "mfma" ? 3 : 0;
@@ -905,7 +940,7 @@ void mi_engine_destroy(mi_engine* e) {
         &e->arena_macros, &e->slot_need,
         &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->mmats, &e->mphi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,
-        &e->ll_sum, &e->g_sum, &e->status, &e->aa_model, &e->aa_matP, &e->aa_matPT,
+        &e->ll_sum, &e->g_sum, &e->status, &e->ready, &e->aa_model, &e->aa_matP, &e->aa_matPT,
         &e->aa_tipP, &e->aa_tipPQ, &e->aa_exp_cum, &e->aa_exp_loc, &e->aa_root_val,
         &e->aa_root_exp, &e->aa_root_scale, &e->in_index, &e->in_weights, &e->out_reduced,
         &e->red_ll, &e->red_g, &e->red_site, &e->red_sort,

@@ -116,6 +116,9 @@ inline const char* status_message(int code) {
       return "The number of rates should be equal to 1 (i.e. strict clock) or equal to the "
              "number of branches.";
     case kTooManySlots: return "internal error: evaluation schedule needs too many LDS slots";
+    case kFusedTimeout:
+      return "internal error: the walk waves of the one-launch call waited in vain for their "
+             "tree's set-up waves (MI_PHYLO_FUSED_SETUP=0 selects the four-launch sequence)";
     default: return "unknown device status";
   }
 }
@@ -134,6 +137,8 @@ struct mi_engine {
   // per-call workspace
   Buffer arena_macros, slot_need, tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, mmats, mphi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
       ll_sum, g_sum, status;
+  Buffer ready;  // [T] hand-off words of the one-launch small call (zero between calls)
+  bool fused_setup = true;  // MI_PHYLO_FUSED_SETUP=0: always the four-launch sequence
   // 20-state path: the engine's eigensystem and the streamed workspace (the arena is `plv`)
   Buffer aa_model, aa_matP, aa_matPT, aa_tipP, aa_tipPQ, aa_exp_cum, aa_exp_loc,
       aa_root_val, aa_root_exp, aa_root_scale;

@@ -160,6 +160,7 @@ struct FinalizeArgs {
   double* out_subst;           // [T][8] or nullptr
   int32_t* status;
   int use_lds;  // set by the launcher
+  int32_t* clear_ready;  // reduce_finalize: the one-launch call's hand-off words, zeroed per tree (or nullptr)
 };
 
 // tree schedules (one wave per tree) and model instances (one thread each) in one launch
@@ -211,7 +212,26 @@ size_t gradient_walk_lut_mats_bytes_per_eval(int n);
 void launch_transition_lut(const TransitionMacroArgs& a, hipStream_t s);
 bool gradient_walk_lut_applies(int K);
 void launch_gradient_walk_lut(const LikArgs& a, int count, bool rescale, hipStream_t s);
+// The one-launch small call (round 5): tree set-up, model instances and operand records as the
+// FIRST workgroups of the walk's launch (four waves per tree), the walk waves wait for their
+// tree's hand-off word `ready[t]` (zero before the launch; reduce_finalize clears it again).
+// One model instance per tree, one evaluation per tree, trees of at most 64 nodes.
+// (a word per 128-byte line: the 78 walk waves of a tree poll their tree's word, and all the
+// words of a batch in a handful of lines made ONE memory channel serve every poll of the chip --
+// the set-up waves' adds then queued behind them for 6 microseconds)
+constexpr int kReadyStride = 32;
+struct FusedSetupArgs {
+  TreeSetupArgs ts;
+  ModelSetupArgs ms;
+  double* mmats;     // operand records of gradient evaluation 0 of the launch
+  int32_t* ready;    // [T][kReadyStride]
+  int setup_blocks;  // 4 T
+};
+bool gradient_walk_lut_fused_applies(int n, int K);
+void launch_gradient_walk_lut_fused(const LikArgs& a, const FusedSetupArgs& f, int count, bool rescale,
+                                    hipStream_t s);
 const char* gradient_walk_lut_kernel_name();
+const char* gradient_walk_lut_fused_kernel_name();
 // waves per CU each generation's LDS footprint allows for this tree size and category count
 int gradient_walk_waves_per_cu(int n, int K);
 int gradient_mfma_waves_per_cu(int n, int K);
@@ -234,6 +254,7 @@ struct ReduceArgs {
   // gradient: 64 + 4), reduced into x_sum[Eg][extra]
   int extra;
   double* x_sum;
+  int keep_offset;  // reduce_finalize_kernel (set by its launcher): where in LDS the reduced sums stay, in doubles
 };
 
 // Analytic substitution-model gradient (opt-in): one thread per tree turns the reduced

@@ -22,21 +22,21 @@ int main(int argc, char** argv) {
   int32_t *d_pid, *d_scratch, *d_mc, *d_status; double *d_bl, *d_ble; SchedEntry* d_sched; MacroEntry* d_mac;
   hipMalloc(&d_pid, pid.size() * 4); hipMalloc(&d_bl, bl.size() * 8); hipMalloc(&d_scratch, (size_t)T * 13 * N * 4);
   hipMalloc(&d_mc, T * 4); hipMalloc(&d_status, 8); hipMalloc(&d_ble, (size_t)T * N * 8);
-  hipMalloc(&d_sched, sizeof(SchedEntry) * (size_t)T * (n - 1)); hipMalloc(&d_mac, sizeof(MacroEntry) * (size_t)T * max_macros(n));
+  hipMalloc(&d_sched, sizeof(SchedEntry) * (size_t)T * (n - 1)); hipMalloc(&d_mac, sizeof(MacroEntry) * (size_t)T * macro_stride(n));
   hipMemcpy(d_pid, pid.data(), pid.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_bl, bl.data(), bl.size() * 8, hipMemcpyHostToDevice);
-  hipMemset(d_status, 0, 8); hipMemset(d_mac, 0, sizeof(MacroEntry) * (size_t)T * max_macros(n));
+  hipMemset(d_status, 0, 8); hipMemset(d_mac, 0, sizeof(MacroEntry) * (size_t)T * macro_stride(n));
   TreeSetupArgs a{}; a.n = n; a.T = T; a.rooted = rooted; a.parent_ids = d_pid; a.bl = d_bl; a.rates = nullptr; a.scratch = d_scratch;
   a.sched = d_sched; a.macros = d_mac; a.macro_count = d_mc; a.bl_eff = d_ble; a.status = d_status; a.max_slots = 32; a.need_slots = 1;
   launch_tree_setup(a, nullptr); hipDeviceSynchronize();
-  std::vector<SchedEntry> sc((size_t)T * (n - 1)); std::vector<MacroEntry> mac((size_t)T * max_macros(n)); std::vector<int32_t> mc(T); int32_t st[2];
+  std::vector<SchedEntry> sc((size_t)T * (n - 1)); std::vector<MacroEntry> mac((size_t)T * macro_stride(n)); std::vector<int32_t> mc(T); int32_t st[2];
   hipMemcpy(sc.data(), d_sched, sc.size() * sizeof(SchedEntry), hipMemcpyDeviceToHost);
   hipMemcpy(mac.data(), d_mac, mac.size() * sizeof(MacroEntry), hipMemcpyDeviceToHost);
   hipMemcpy(mc.data(), d_mc, T * 4, hipMemcpyDeviceToHost); hipMemcpy(st, d_status, 8, hipMemcpyDeviceToHost);
   // the arena variant's macro order / LDS slots / arena indices (macro_slots kernels)
   MacroEntry* d_mac2; int32_t* d_need;
-  hipMalloc(&d_mac2, sizeof(MacroEntry) * (size_t)T * max_macros(n)); hipMalloc(&d_need, T * 4);
-  hipMemset(d_mac2, 0, sizeof(MacroEntry) * (size_t)T * max_macros(n)); hipMemset(d_need, 0, T * 4);
-  std::vector<MacroEntry> mac2((size_t)T * max_macros(n)); std::vector<int32_t> need(T);
+  hipMalloc(&d_mac2, sizeof(MacroEntry) * (size_t)T * macro_stride(n)); hipMalloc(&d_need, T * 4);
+  hipMemset(d_mac2, 0, sizeof(MacroEntry) * (size_t)T * macro_stride(n)); hipMemset(d_need, 0, T * 4);
+  std::vector<MacroEntry> mac2((size_t)T * macro_stride(n)); std::vector<int32_t> need(T);
   if (st[0] == 0) {
     launch_macro_slots(d_mac, d_mac2, d_mc, n, T, d_need, d_status, nullptr); hipDeviceSynchronize();
     hipMemcpy(mac2.data(), d_mac2, mac2.size() * sizeof(MacroEntry), hipMemcpyDeviceToHost);

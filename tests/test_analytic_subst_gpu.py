@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 _FORCED = os.environ.get("MI_PHYLO_GRADIENT_WALK")
 WALK_KERNEL = (("gradient_mfma_kernel",) if _FORCED == "v1" else ("gradient_walk_kernel",)
                if _FORCED == "v2" else ("gradient_mfma_kernel", "gradient_walk_kernel",
-                                        "gradient_walk_lut_kernel"))
+                                        "gradient_walk_lut_kernel", "gradient_walk_lut_fused_kernel"))
 
 
 @pytest.fixture

@@ -240,8 +240,12 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // slots.
   static const bool fuse_allowed =
       !(getenv("MI_PHYLO_FUSE_FINALIZE") && std::string(getenv("MI_PHYLO_FUSE_FINALIZE")) == "0");
+  // Up to about a thousand trees: beyond, the set-up waves' share of the wave slots (four waves
+  // of ~10 microseconds per tree, a GTR eigensystem on one lane of each) costs the walk more
+  // than two launch boundaries -- measured cross-overs, DS1 (scratch notes in DESIGN.md 4.7).
+  const int fuse_max_trees = c.gtr ? 512 : 1024;
   const bool fuse_setup = walk3 && e->fused_setup && fuse_allowed && c.E == T && c.models_per_tree == 1 &&
-                          !ts.need_slots && T <= kMaxEvals && e->ready.ptr &&
+                          !ts.need_slots && T <= fuse_max_trees && e->ready.ptr &&
                           gradient_walk_lut_fused_applies(n, e->K);
   static const bool xp_walk_only = getenv("MI_PHYLO_XP_WALK_ONLY") != nullptr;
   if (!fuse_setup || xp_walk_only) launch_setup(ts, ms, s);  // tree schedules and model instances, one launch

@@ -434,7 +434,12 @@ __device__ inline void jacobi4(const double* A_in, double* evals, double* U) {
         const double x = A[i * 4 + j] * A[i * 4 + j];
         if (i != j) off += x; else diag += x;
       }
-    if (off <= 1e-40 * diag || off == 0.) break;
+    // (off, diag: SQUARED norms.  Until round 5 the bound was 1e-40 -- an off-diagonal norm of
+    // 1e-20 of the diagonal's, which double precision reaches only by accident: the loop ran
+    // 40 to 60 sweeps of ~3.4 microseconds on its one lane, 110-140 microseconds of EVERY GTR
+    // call's set-up.  1e-31 is an off-diagonal norm of 3e-16 of the diagonal's -- the rounding
+    // level; cyclic Jacobi converges quadratically and gets there in 5 or 6 sweeps.)
+    if (off <= 1e-31 * diag || off == 0.) break;
     for (int p = 0; p < 3; p++)
       for (int q = p + 1; q < 4; q++) {
         const double apq = A[p * 4 + q];

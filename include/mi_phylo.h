@@ -122,6 +122,10 @@ int32_t mi_engine_create_sharded(const mi_engine_spec* spec, int32_t shard_count
                                  const int32_t* tip_states, const double* tip_partials,
                                  const double* pattern_weights, mi_engine** out_engine);
 int32_t mi_engine_shard_count(const mi_engine* engine);
+/* The HIP device ordinal shard `shard` was placed on (a single-device engine: shard 0, its
+ * device); -1 for an invalid argument.  What the -1 - k / NULL forms of `devices` resolved to:
+ * the reference's counterpart is the thread a FatBeagle is pinned to, engine.cpp:23-27. */
+int32_t mi_engine_shard_device(const mi_engine* engine, int32_t shard);
 /* Contiguous block of shard `shard` of `shard_count` over `total` units: block sizes differ
  * by at most one, the larger blocks first. */
 int32_t mi_shard_range(int32_t total, int32_t shard_count, int32_t shard, int32_t* begin,

@@ -30,6 +30,7 @@ SYMBOLS = {
         (C.c_int32, [C.POINTER(EngineSpec), C.c_int32, I32P, C.c_int32, _V, _V, _V, _V, _V,
                      C.POINTER(_V)]),
     "mi_engine_shard_count": (C.c_int32, [_V]),
+    "mi_engine_shard_device": (C.c_int32, [_V, C.c_int32]),
     "mi_shard_range": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, I32P, I32P]),
     "mi_engine_gradients_unrooted_reduced":
         (C.c_int32, [_V, C.c_int32, _V, _V, _V, C.c_int32, _V, _V, C.c_int32, _V, _V, _V]),

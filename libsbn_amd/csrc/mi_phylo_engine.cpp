@@ -1341,6 +1341,13 @@ int32_t mi_engine_shard_count(const mi_engine* e) {
   return e ? std::max<int32_t>(1, (int32_t)e->shards.size()) : -1;
 }
 
+int32_t mi_engine_shard_device(const mi_engine* e, int32_t shard) {
+  if (!e) return -1;
+  if (e->shards.empty()) return shard == 0 ? e->spec.device : -1;
+  if (shard < 0 || shard >= (int32_t)e->shards.size()) return -1;
+  return e->shards[shard]->spec.device;
+}
+
 /* ---- host-pointer entry points ------------------------------------------ */
 
 }  // extern "C"

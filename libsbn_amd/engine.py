@@ -370,6 +370,11 @@ class Engine:
         return ([out[i] for i in range(cnt.value)],
                 [[ph[4 * i + k] for k in range(4)] for i in range(cnt.value)], first.value)
 
+    def shard_devices(self):
+        """HIP device ordinal of every shard (a single-device engine: its one device)."""
+        k = self._lib.mi_engine_shard_count(self._h)
+        return [self._lib.mi_engine_shard_device(self._h, i) for i in range(k)]
+
     def last_call_info(self):
         name, ev, gev = C.c_char_p(), C.c_int64(), C.c_int64()
         self._check(self._lib.mi_engine_last_call_info(self._h, C.byref(name), C.byref(ev),

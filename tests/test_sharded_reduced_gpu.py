@@ -48,6 +48,38 @@ def test_tree_shards_are_bit_identical_to_one_engine(shards, T):
         many.log_likelihoods_device(None, T, 0, 0, 0, 0)
 
 
+def test_relative_device_ordinals_wrap_around():
+    """devices = {-1, -2, -3} means "the current device, the next one, the one after", wrapping
+    around the visible devices (what a one-process-per-GPU launch relies on to stay on the
+    device it selected; engine.cpp:23-27 is the reference's thread_count counterpart).  On a
+    box with one GPU every shard lands on device 0 -- and on any box the placement is
+    (current + k) mod count and the results are a single engine's, bit for bit."""
+    import libsbn_amd as L
+    from libsbn_amd import _capi
+    T = 9
+    tips, w, pids, bls, rng = _ds1(T)
+    spec = L.PhyloModelSpecification("JC69", "weibull+4", "strict")
+    pr = np.ones((T, 2)); pr[:, 0] = rng.uniform(0.4, 1.6, T)
+    count = _capi.load().mi_device_count()
+    assert count >= 1
+    one = L.Engine(spec, tips, w)
+    current = one.shard_devices()[0]
+    for devs in ([-1, -2, -3], None):
+        many = (L.Engine(spec, tips, w, shard_devices=devs) if devs is not None
+                else L.Engine(spec, tips, w, shard_devices=[-1 - k for k in range(2)]))
+        k = len(many.shard_devices())
+        assert many.shard_devices() == [(current + i) % count for i in range(k)]
+        assert np.array_equal(many.log_likelihoods(pids, bls, pr), one.log_likelihoods(pids, bls, pr))
+        for a, b in zip(one.gradients(pids, bls, pr), many.gradients(pids, bls, pr)):
+            assert a.log_likelihood == b.log_likelihood
+            for key in a.gradient:
+                assert np.array_equal(a.gradient[key], b.gradient[key]), key
+        many.close()
+    with pytest.raises(RuntimeError, match="out of range"):
+        L.Engine(spec, tips, w, shard_devices=[count])
+    one.close()
+
+
 def test_rooted_tree_shards():
     import libsbn_amd as L
     rng = np.random.default_rng(2)

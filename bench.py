@@ -449,7 +449,7 @@ def emit(full):
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
     for key in ("roofline", "step_ms_device", "small_batch", "weak", "gathered", "reduced",
-                "host_pointer", "adapter", "cpu_baseline", "config"):
+                "host_pointer", "adapter", "cpu_baseline", "config", "rank_devices"):
         if full.get(key) is not None:
             print("BENCH_ALSO", key, json.dumps(_sig(full[key], 8)), flush=True)
     for leg in full.get("also") or []:
@@ -1096,12 +1096,34 @@ def main():
     # the RCCL branch on a 1-GPU box)
     distributed = world > 1 or os.environ.get("MI_BENCH_FORCE_DIST") == "1"
     if distributed:
-        if "MASTER_ADDR" not in os.environ:
+        if world > 1 and ("MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ):
+            # (a free port picked here would be a DIFFERENT port in every rank --
+            # the ranks of a launcher that sets WORLD_SIZE / RANK only would never meet;
+            # spawn_ranks and torch.distributed.run both set the pair)
+            sys.exit("bench.py: WORLD_SIZE > 1 needs MASTER_ADDR and MASTER_PORT from the "
+                     "launcher (torch.distributed.run sets them; `python bench.py --gpus N` "
+                     "without a launcher starts the ranks itself)")
+        if "MASTER_ADDR" not in os.environ:  # one rank, forced collective path
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     rccl_ranks = dist.get_world_size() if distributed else 1
     assert rccl_ranks == world
+    # Which physical GPU each rank drives: ordinal, PCI address and UUID
+    # as torch reports them, gathered on rank 0 -- N ranks on fewer than N devices would make
+    # every scaling figure meaningless, so that is an error, not a note.
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+          "name": props.name,
+          "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xff,
+                                     getattr(props, "pci_device_id", -1) & 0xff),
+          "uuid": str(getattr(props, "uuid", ""))}
+    rank_devices = [me]
+    if distributed and world > 1:
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, me)
+        ids = {(d["pci"], d["uuid"]) for d in rank_devices}
+        assert len(ids) == world, f"{world} ranks on {len(ids)} distinct devices: {rank_devices}"
 
     if args.workload == "swag":
         out = swag_pattern_sharded(args, torch, dist, L, sharding, dev, rank, world, distributed)
@@ -1176,7 +1198,8 @@ def main():
         # the one collective of the call -- every rank's per-tree results, tree order.
         # "stream" (default): enqueued on the calls' own stream right behind the kernels (an
         # all-gather of <= 54 KB per rank is latency, not bandwidth: there is nothing to
-        # overlap, and no cross-stream event dependency is paid); "overlap": asynchronously
+        # overlap; torch still runs a synchronous collective on RCCL's stream between two event
+        # waits, but it issues both itself, back to back with the launches); "overlap": asynchronously
         # on RCCL's stream under the next step's kernels, which write the other buffer set
         # (round 2-3 form: two cross-stream dependencies per step, 18.5 us on one rank).
         overlap = os.environ.get("MI_BENCH_COLLECTIVE", "stream") == "overlap"
@@ -1324,7 +1347,8 @@ def main():
                    "collective": f"one all_reduce over {rccl_ranks} rank(s)" if distributed
                                  else "none (one GPU)",
                    "max_rel_err": r_err,
-                   "note": "mi_engine_gradients_unrooted_reduced_device (vi_reduce_kernel after "
+                   "note": "mi_engine_gradients_unrooted_reduced_device (stable sort of the "
+                           "(tree, node) entries by index + one ordered sum per run, after "
                            "the gradient kernels) + ONE all-reduce of [sum logL | sum site "
                            "gradient | branch gradients scatter-added by a 4096-entry index]; "
                            "checked against the host scatter-add (np.add.at) of the headline "
@@ -1507,6 +1531,7 @@ def main():
                                  "profiles/traffic.json (PMC, 1000-tree launch), not this run"),
             "parity_checked": parity_n, "parity_max_rel_err": parity_err,
             "parity_note": "first trees of the last timed step vs the CPU oracle, tolerance 1e-10",
+            "rank_devices": rank_devices,
         }
         if args.no_parity:
             out["parity"] = "skipped"

@@ -1317,7 +1317,7 @@ def main():
         d_bi = torch.from_numpy(bi_all[lo:hi]).to(dev)
         packed = torch.zeros(2 + index_count, dtype=torch.float64, device=dev)
         r_ll = torch.empty(T_local, dtype=torch.float64, device=dev)
-        eng.reserve(T_local, True)
+        eng.reserve_reduced(T_local, index_count)
 
         def reduced_step():
             rc = eng._lib.mi_engine_gradients_unrooted_reduced_device(

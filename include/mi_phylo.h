@@ -268,6 +268,11 @@ int32_t mi_engine_gradients_unrooted_reduced_device(
  * reports a new back-off.  The fused-reduction entry points additionally need a sort
  * workspace that depends on index_count; it is allocated by their first call. */
 int32_t mi_engine_reserve(mi_engine* engine, int32_t tree_count, int32_t for_gradients);
+/* The same, plus the per-tree buffers and the index sort's workspace of
+ * mi_engine_gradients_unrooted_reduced[_device] for up to `index_count` indices: a reduced
+ * *_device call of at most that size then allocates nothing either (it used to
+ * size and allocate its sort workspace inside the call). */
+int32_t mi_engine_reserve_reduced(mi_engine* engine, int32_t tree_count, int32_t index_count);
 /* Synchronise `stream` and report the first per-tree error since the last check (the status
  * word is sticky and cleared when an error is reported: calls themselves never clear it). */
 int32_t mi_engine_check_status(mi_engine* engine, void* stream);

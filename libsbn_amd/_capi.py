@@ -62,6 +62,7 @@ SYMBOLS = {
         (C.c_int32, [_V, _V, C.c_int32, _V, _V, _V, _V, _V, _V, _V, _V, C.c_int32, _V, _V, _V,
                      _V, _V]),
     "mi_engine_reserve": (C.c_int32, [_V, C.c_int32, C.c_int32]),
+    "mi_engine_reserve_reduced": (C.c_int32, [_V, C.c_int32, C.c_int32]),
     "mi_engine_check_status": (C.c_int32, [_V, _V]),
     "mi_engine_profile_begin": (C.c_int32, [_V, C.c_int32]),
     "mi_engine_profile_collect": (C.c_int32, [_V, F64P, C.c_int32, I32P]),

@@ -1213,6 +1213,31 @@ int32_t mi_engine_gradients_rooted_device(mi_engine* e, void* stream, int32_t T,
   return run_device(e, pick_stream(e, stream), d);
 }
 
+// rocPRIM is asked for its temporary-storage size once per (entries, key bits), not per call
+static size_t reduce_workspace_bytes(mi_engine* e, int32_t T, int32_t index_count) {
+  const long entries = (long)T * e->N;
+  int bits = 1;
+  while (bits < 32 && (1u << bits) <= (uint32_t)index_count) bits++;
+  if (e->red_ws_entries != entries || e->red_ws_bits != bits) {
+    e->red_ws_bytes = vi_reduce_workspace_bytes(entries, index_count);
+    e->red_ws_entries = entries;
+    e->red_ws_bits = bits;
+  }
+  return e->red_ws_bytes;
+}
+
+int32_t mi_engine_reserve_reduced(mi_engine* e, int32_t tree_count, int32_t index_count) {
+  if (!e) return fail("null engine");
+  if (!e->shards.empty()) return mi_engine_reserve(e, tree_count, 1);  // (host-pointer calls only)
+  if (index_count < 0) return fail("index_count must be >= 0");
+  if (mi_engine_reserve(e, tree_count, 1)) return 1;
+  HIP_TRY(hipSetDevice(e->spec.device));
+  if ((uint64_t)tree_count * (uint64_t)e->N > 0xffffffffull)
+    return fail("the fused reductions number their (tree, node) entries in 32 bits: tree_count x "
+                "(2 taxa - 1) must stay below 2^32");
+  return e->red_sort.ensure(reduce_workspace_bytes(e, tree_count, index_count));
+}
+
 /* Engine::Gradients followed by the caller-side reductions of one variational-inference
  * step (vip/burrito.py:143-166, vip/branch_model.py:104-133,
  * src/unrooted_sbn_instance.cpp:176-198), fused behind the call: see include/mi_phylo.h. */
@@ -1257,7 +1282,10 @@ int32_t mi_engine_gradients_unrooted_reduced_device(
   ra.tree_weights = tree_weights;
   ra.out_sums = out_sums;
   ra.out_index_gradient = out_index_gradient;
-  const size_t ws = vi_reduce_workspace_bytes((long)T * e->N, index_count);
+  if ((uint64_t)T * (uint64_t)e->N > 0xffffffffull)
+    return fail("the fused reductions number their (tree, node) entries in 32 bits: tree_count x "
+                "(2 taxa - 1) must stay below 2^32");
+  const size_t ws = reduce_workspace_bytes(e, T, index_count);
   if (e->red_sort.ensure(ws)) return 1;
   if (launch_vi_reduce(ra, e->red_sort.ptr, ws, s)) return fail("the index sort of the reduction could not be launched");
   HIP_TRY(hipGetLastError());

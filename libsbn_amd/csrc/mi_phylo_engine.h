@@ -156,6 +156,9 @@ struct mi_engine {
   std::vector<double> shard_sums;  // per-shard partial results (pattern shards, fused sums)
   // fused reductions (mi_engine_gradients_unrooted_reduced*)
   Buffer in_index, in_weights, out_reduced, red_ll, red_g, red_site, red_sort;
+  long red_ws_entries = -1;  // what red_ws_bytes (the sort's workspace size) was computed for
+  int red_ws_bits = 0;
+  size_t red_ws_bytes = 0;
   // staging for the host-pointer entry points
   Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
       in_ratios, out_ll, out_a, out_b, out_site, out_subst;

@@ -344,6 +344,10 @@ class Engine:
             self._h, stream, T, parent_ids, branch_lengths, params, int(rescaling), out_ll,
             out_branch, out_site, out_subst))
 
+    def reserve_reduced(self, tree_count, index_count):
+        """mi_engine_reserve_reduced: workspace of a fused-reduction call (graph capture)."""
+        self._check(self._lib.mi_engine_reserve_reduced(self._h, int(tree_count), int(index_count)))
+
     def check_status(self, stream=None):
         self._check(self._lib.mi_engine_check_status(self._h, stream))
 

@@ -254,3 +254,60 @@ def test_device_call_replays_from_a_hip_graph():
         want = eng.gradients(pids, bl2, pr)
         assert np.array_equal(got_ll, np.array([x.log_likelihood for x in want]))
         assert np.array_equal(got_g, np.stack([x.gradient["branch_lengths"] for x in want]))
+
+
+def test_reduced_device_call_allocates_nothing_after_reserve_reduced():
+    """mi_engine_reserve_reduced: the per-tree buffers and the index sort's
+    workspace of the fused-reduction call are reserved up front, so the *_device call that
+    follows changes the free device memory by nothing and replays from a hipGraph; its sums
+    equal the host scatter-add of the per-tree results bit for bit."""
+    torch = pytest.importorskip("torch")
+    import libsbn_amd as L
+    from libsbn_amd import _capi
+    T, index_count = 40, 300
+    tips, w, pids, bls, rng = _ds1(T)
+    N = 53
+    spec = L.PhyloModelSpecification("JC69", "weibull+4", "strict")
+    pr = np.ones((T, 2)); pr[:, 0] = rng.uniform(0.4, 1.6, T)
+    bi = rng.integers(-1, index_count, size=(T, N)).astype(np.int32)
+    eng = L.Engine(spec, tips, w)
+    dev = torch.device("cuda", 0)
+    d_pid, d_bl, d_par, d_bi = (torch.from_numpy(x).to(dev) for x in (pids, bls, pr, bi))
+    packed = torch.zeros(2 + index_count, dtype=torch.float64, device=dev)
+    d_ll = torch.zeros(T, dtype=torch.float64, device=dev)
+    eng.reserve_reduced(T, index_count)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    gs = torch.cuda.Stream()
+
+    def call(stream):
+        rc = eng._lib.mi_engine_gradients_unrooted_reduced_device(
+            eng._h, stream, T, d_pid.data_ptr(), d_bl.data_ptr(), d_par.data_ptr(), 0,
+            d_bi.data_ptr(), None, index_count, packed.data_ptr(), packed.data_ptr() + 16,
+            d_ll.data_ptr())
+        assert rc == 0, _capi.last_error()
+
+    with torch.cuda.stream(gs):
+        call(gs.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=gs):
+        call(torch.cuda.current_stream().cuda_stream)
+    packed.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    eng.check_status()
+    g = eng.gradients(pids, bls, pr)
+    want = np.zeros(2 + index_count)
+    want[0] = sum(x.log_likelihood for x in g)   # (tree order)
+    want[1] = sum(np.atleast_1d(x.gradient["site_model"])[0] for x in g)
+    gb = np.stack([x.gradient["branch_lengths"] for x in g])
+    keep = bi >= 0
+    np.add.at(want[2:], bi[keep], gb[keep])
+    got = packed.cpu().numpy()
+    assert np.array_equal(got[2:], want[2:])
+    assert np.allclose(got[:2], want[:2], rtol=1e-13, atol=0)
+    with pytest.raises(RuntimeError, match="index_count"):
+        eng.reserve_reduced(T, -1)
+    eng.close()

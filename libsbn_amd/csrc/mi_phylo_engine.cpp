@@ -807,6 +807,17 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
     return cleanup_fail(fail("status word allocation failed"));
   const size_t np = (size_t)e->n * e->P;
   if (device_tips) {
+    // (the two arrays must be device memory of THIS engine's device: a host pointer or another
+    // device's memory would fault inside the preparation kernel, or worse, not fault)
+    for (const void* p : {static_cast<const void*>(device_tips), static_cast<const void*>(device_weights)}) {
+      hipPointerAttribute_t at{};
+      if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeDevice ||
+          at.device != e->spec.device) {
+        (void)hipGetLastError();
+        return cleanup_fail(fail("device_tip_states / device_pattern_weights must be device memory of "
+                                 "the engine's device"));
+      }
+    }
     // the tips are on the device already: one kernel derives what the host loops below derive
     const int stride = states == kAa ? e->tiles * kAaTile : e->P;
     const bool dna = states == kStates;

@@ -100,7 +100,19 @@ class Engine:
         states = 20 if SUBST[model_specification.substitution] == 2 else 4
         self.state_count = states
         if device_tips is not None:
+            # (this branch used to return before any validation and silently ignored
+            # what does not combine with device-resident tips)
+            for name, val in (("patterns", patterns), ("weights", weights), ("tip_partials", tip_partials),
+                              ("reversible_model", reversible_model), ("shard_devices", shard_devices)):
+                if val is not None:
+                    raise RuntimeError(f"device_tips does not combine with {name}: the tips and weights "
+                                       "are the device arrays, a 20-state engine made this way uses "
+                                       "the built-in WAG table, and a sharded handle uploads its tips "
+                                       "from host arrays")
             d_states, d_weights, n, P = device_tips
+            if not d_states or not d_weights or int(n) < 3 or int(P) < 1:
+                raise RuntimeError("device_tips = (states pointer, weights pointer, taxon count >= 3, "
+                                   "pattern count >= 1)")
             self.taxon_count, self.pattern_count, self.category_count = n, P, K
             self.node_count = 2 * n - 1
             self.spec = _capi.EngineSpec(n, P, states, K, SUBST[model_specification.substitution],

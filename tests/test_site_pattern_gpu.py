@@ -97,3 +97,29 @@ def test_device_resident_patterns_feed_an_engine_without_the_round_trip():
     assert np.array_equal(a.log_likelihoods(p2, b2, np.ones((2, 2))),
                           b.log_likelihoods(p2, b2, np.ones((2, 2))))
     dp.release()
+
+
+def test_device_tips_arguments_are_validated():
+    """the device-resident door validates what it is given -- host arrays beside
+    device_tips, a 20-state model table, a sharded handle and a HOST pointer passed as a device
+    pointer are errors with a message, not silently ignored (or a fault in a kernel)."""
+    torch = pytest.importorskip("torch")
+    import libsbn_amd as L
+    rng = np.random.default_rng(4)
+    n, P = 6, 50
+    tips = rng.integers(0, 5, size=(n, P)).astype(np.int32)
+    w = np.ones(P)
+    dev = torch.device("cuda", 0)
+    d_t, d_w = torch.from_numpy(tips).to(dev), torch.from_numpy(w).to(dev)
+    spec = L.PhyloModelSpecification("JC69", "weibull+4", "strict")
+    ok = L.Engine(spec, None, None, device_tips=(d_t.data_ptr(), d_w.data_ptr(), n, P))
+    ok.close()
+    for kw in ({"tip_partials": np.zeros((n, P, 4))}, {"shard_devices": [0, 0]},
+               {"reversible_model": (np.ones(190), np.full(20, 0.05))}):
+        with pytest.raises(RuntimeError, match="does not combine"):
+            L.Engine(spec, None, None, device_tips=(d_t.data_ptr(), d_w.data_ptr(), n, P), **kw)
+    with pytest.raises(RuntimeError, match="does not combine"):
+        L.Engine(spec, tips, w, device_tips=(d_t.data_ptr(), d_w.data_ptr(), n, P))
+    host = np.ascontiguousarray(tips)
+    with pytest.raises(RuntimeError, match="device memory"):
+        L.Engine(spec, None, None, device_tips=(host.ctypes.data, d_w.data_ptr(), n, P))

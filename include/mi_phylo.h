@@ -282,6 +282,12 @@ int32_t mi_engine_check_status(mi_engine* engine, void* stream);
  * (DESIGN.md "Measurement"). */
 int32_t mi_engine_last_call_info(const mi_engine* engine, const char** dominant_kernel,
                                  int64_t* evaluations, int64_t* gradient_evaluations);
+/* One line saying which path the last call took: the dominant kernel, where the partial
+ * vectors were kept (store=lds | arena | hbm), whether the tree set-up rode in the walk's launch
+ * (setup=in-walk) or had its own, and the call's flavour (fd=16, site-pass, light, analytic,
+ * rescaled, rooted, K=...).  Diagnostics for the randomised sweeps (tools/stress_*.py print a
+ * histogram of it); the string is the engine's and lives until the next call. */
+const char* mi_engine_last_call_path(const mi_engine* engine);
 
 /* How the last call was cut up: the number of launches of the walk kernel(s) over chunks of
  * evaluations (the partial-vector arena of large trees holds only as many evaluations as

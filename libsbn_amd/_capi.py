@@ -70,6 +70,7 @@ SYMBOLS = {
     "mi_engine_profile_collect_phases": (C.c_int32, [_V, F64P, F64P, C.c_int32, I32P, I32P]),
     "mi_engine_last_call_info":
         (C.c_int32, [_V, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mi_engine_last_call_path": (C.c_char_p, [_V]),
     "mi_engine_last_call_launches": (C.c_int32, [_V, I32P, I32P]),
     "mi_site_pattern_compress":
         (C.c_int32, [C.c_int32, C.c_int32, C.c_int64, _V, I32P, _V, _V, F64P]),

@@ -436,6 +436,20 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
                   : walk2 ? gradient_walk_kernel_name()
                         : (mfma ? gradient_mfma_kernel_name() : gradient_kernel_name());
   }
+  {  // which path the call took, for diagnostics (mi_engine_last_call_path)
+    std::string path = e->dominant;
+    if (d.gradient)
+      path += !mfma ? " store=hbm" : (arena ? " store=arena" : " store=lds");
+    path += fuse_setup ? " setup=in-walk" : " setup=own-launch";
+    if (d.gradient && fd_pass) path += " fd=16";
+    if (d.gradient && site_pass) path += " site-pass";
+    if (light) path += " light";
+    if (analytic) path += " analytic";
+    if (d.rescaling) path += " rescaled";
+    if (d.rooted) path += " rooted";
+    path += " K=" + std::to_string(e->K);
+    e->last_path = path;
+  }
   e->prof_first_launch_evals = T;
   e->last_evals = c.E;
   e->last_grad_evals = c.Eg;
@@ -1109,6 +1123,12 @@ int32_t mi_engine_last_call_info(const mi_engine* e, const char** dominant_kerne
   if (evaluations) *evaluations = e->last_evals;
   if (gradient_evaluations) *gradient_evaluations = e->last_grad_evals;
   return 0;
+}
+
+const char* mi_engine_last_call_path(const mi_engine* e) {
+  if (!e) return "";
+  if (!e->shards.empty()) return mi_engine_last_call_path(e->shards[0]);
+  return e->last_path.c_str();
 }
 
 int32_t mi_engine_last_call_launches(const mi_engine* e, int32_t* walk_launches,

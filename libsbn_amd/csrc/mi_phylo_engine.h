@@ -170,6 +170,7 @@ struct mi_engine {
   int prof_first_launch_evals = 0;  // evaluations in the first walk launch of the last call
   // last-call info
   const char* dominant = "";
+  std::string last_path;  // mi_engine_last_call_path
   int64_t last_evals = 0, last_grad_evals = 0;
   int status_tree_offset = 0;  // a shard's first tree in the caller's batch (error messages)
   int last_walk_launches = 1;  // chunks of evaluations the last call's walk kernels ran over

@@ -225,6 +225,7 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   }
   if (prof) HIP_TRY(hipEventRecord(prof_event(e, 1), s));
   e->dominant = d.gradient ? aa_pre_kernel_name() : aa_post_kernel_name();
+  e->last_path = std::string(e->dominant) + " store=hbm-arena states=20 K=" + std::to_string(e->K);
   e->last_evals = T;
   e->last_grad_evals = d.gradient ? T : 0;
   e->last_walk_launches = (T + chunk - 1) / chunk;

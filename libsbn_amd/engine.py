@@ -397,6 +397,10 @@ class Engine:
                                                        C.byref(gev)))
         return name.value.decode(), ev.value, gev.value
 
+    def last_call_path(self):
+        """mi_engine_last_call_path: one line saying which kernels / stores the last call used."""
+        return self._lib.mi_engine_last_call_path(self._h).decode()
+
     def last_call_launches(self):
         """(walk-kernel launches of the last call, arena-budget back-offs since creation)"""
         a, b = C.c_int32(), C.c_int32()

@@ -17,6 +17,8 @@ import tree_utils as TU  # noqa: E402
 rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "2025")))
 trials = int(os.environ.get("STRESS_TRIALS", "60"))
 bad = total = 0
+import collections  # noqa: E402
+seen = collections.Counter()  # which kernels the trials exercised
 wag = E.wag_model()
 for trial in range(trials):
     n = int(rng.choice([3, 4, 5, 6, 9, 16, 17, 31, 32, 33, 64, 100, 129, 200, 257, 300]))
@@ -50,7 +52,9 @@ for trial in range(trials):
                 pids[0] = TU.balanced_topology(n)
             og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, True, 4)
             g = eng.gradients(pids, bls, pr)
+            seen[eng.last_call_path()] += 1
             ll = eng.log_likelihoods(pids, bls, pr)
+            seen[eng.last_call_path()] += 1
             keys = ["branch_lengths"]
         else:
             trees = [TU.clocklike_rooted_tree(n, rng) for _ in range(T)]
@@ -62,6 +66,7 @@ for trial in range(trials):
             counts = np.ones(T, np.int32)
             og = O.rooted_gradients(spec, tips, w, pids, bls, pr, rates, counts, h, bd, ra, True, 4)
             g = eng.rooted_gradients(pids, bls, pr, rates, counts, h, bd, ra)
+            seen[eng.last_call_path() + " rooted"] += 1
             ll = np.array([x.log_likelihood for x in g])
             keys = ["ratios_root_height", "clock_model"]
     finally:
@@ -91,3 +96,6 @@ for trial in range(trials):
                                mode=kw.get("shard_mode")))
     eng.close()
 print("trials", total, "bad", bad)
+print("kernels seen:")
+for path, count in sorted(seen.items(), key=lambda kv: -kv[1]):
+    print("  %5d  %s" % (count, path))

@@ -1,7 +1,7 @@
 """Randomised parity sweep of the GPU engine against the CPU oracle (not part of the test
 suite: run on an MI355X box, optionally with MI_PHYLO_SUBST_GRADIENT=analytic).
 Random taxa / pattern / category counts, models, rescaling, branch-length scales, gaps."""
-import sys, os, itertools
+import sys, os, itertools, collections
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np
@@ -10,14 +10,19 @@ import test_gpu_parity as TG
 RTOL = 1e-10
 rng = np.random.default_rng(int(os.environ.get('STRESS_SEED', '2024')))
 bad = 0; total = 0
+seen = collections.Counter()  # which kernels / stores the trials exercised
 for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
-    n = int(rng.choice([3, 4, 5, 6, 7, 9, 12, 17, 26, 27, 28, 29, 30, 31, 32, 33, 45, 64, 80, 100, 130, 257]))
+    n = int(rng.choice([3, 4, 5, 6, 7, 9, 12, 17, 26, 27, 28, 29, 30, 31, 32, 33, 36, 45, 50, 64, 69, 80, 100, 130, 257]))
     P = int(rng.choice([1, 2, 3, 11, 12, 13, 16, 47, 48, 49, 64, 100, 257]))
-    K = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 11, 16, 23, 64]))
+    # (one and two categories -- the first-generation walk's engines -- and three / four -- the
+    # third's -- weighted up: every generation x store appears a hundred times per 1 000 trials)
+    K = int(rng.choice([1, 1, 2, 2, 3, 3, 4, 4, 4, 5, 6, 8, 11, 16, 23, 64]))
     subst = str(rng.choice(["JC69", "GTR"]))
     site = "constant" if K == 1 else f"weibull+{K}"
     resc = bool(rng.integers(0, 2))
-    T = int(rng.choice([1, 2, 9]))
+    # (mostly a few trees; now and then a batch large enough that 32-100-taxon trees take the
+    # arena variant of the walk and small ones fill the machine)
+    T = int(rng.choice([1, 2, 9, 9, 150])) if n <= 100 and P <= 100 and K <= 8 else int(rng.choice([1, 2, 9]))
     tips, w = TU.random_alignment(n, P, rng, gap_fraction=float(rng.choice([0.0, 0.05, 0.5])))
     pids, bls = TU.random_trees(n, T, rng, mean_bl=float(rng.choice([0.001, 0.1, 1.0])))
     if rng.integers(0, 3) == 0: pids[0] = TU.ladder_topology(n)
@@ -32,6 +37,7 @@ for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
     pr = TG._params(spec, T, **blocks)
     g = eng.gradients(pids, bls, pr, resc)
     kern = eng.last_call_info()[0]
+    seen[eng.last_call_path()] += 1
     O.set_transition_mode(1)
     og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, resc, 4)
     O.set_transition_mode(0)
@@ -67,6 +73,7 @@ for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
             ok &= okk
     # the log-likelihood-only call (its own kernel and traversal order)
     ll = np.asarray(eng.log_likelihoods(pids, bls, pr, resc))
+    seen[eng.last_call_path()] += 1
     okl = np.all(np.abs(ll - og["log_likelihood"]) <= RTOL * np.abs(og["log_likelihood"]) + 1e-13)
     if not okl: print("  logL call", ll, og["log_likelihood"])
     ok &= bool(okl)
@@ -75,3 +82,6 @@ for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
         bad += 1
         print("MISMATCH", dict(n=n, P=P, K=K, subst=subst, resc=resc, T=T, kern=kern))
 print("trials", total, "bad", bad, "analytic" if os.environ.get("MI_PHYLO_SUBST_GRADIENT") else "fd")
+print("kernels seen:")
+for path, count in sorted(seen.items(), key=lambda kv: -kv[1]):
+    print("  %5d  %s" % (count, path))

@@ -11,7 +11,9 @@ import oracle_lib as O, libsbn_amd as L, tree_utils as TU
 import test_gpu_parity as TG
 
 rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "99")))
+import collections
 bad = 0
+seen = collections.Counter()  # which kernels / stores the trials exercised
 trials = int(os.environ.get("STRESS_TRIALS", "30"))
 for trial in range(trials):
     # (STRESS_N="257,258,300": sizes on both sides of the 257-taxon limit of the register
@@ -47,8 +49,10 @@ for trial in range(trials):
     pr = TG._params(spec, T, **blocks)
     resc = n > 100
     ll = eng.rooted_log_likelihoods(pids, bls, pr, rates, hs, bds, resc)
+    seen[eng.last_call_path()] += 1
     oll = O.rooted_log_likelihoods(spec, tips, w, pids, bls, pr, rates, hs, bds, rescaling=resc)
     g = eng.rooted_gradients(pids, bls, pr, rates, rcounts, hs, bds, ras, resc)
+    seen[eng.last_call_path()] += 1
     O.set_transition_mode(1)
     og = O.rooted_gradients(spec, tips, w, pids, bls, pr, rates, rcounts, hs, bds, ras, resc)
     O.set_transition_mode(0)
@@ -73,3 +77,6 @@ for trial in range(trials):
         bad += 1
         print("MISMATCH", dict(n=n, P=P, K=K, subst=subst, T=T, resc=resc, kern=eng.last_call_info()[0]))
 print("rooted trials", trials, "bad", bad)
+print("kernels seen:")
+for path, count in sorted(seen.items(), key=lambda kv: -kv[1]):
+    print("  %5d  %s" % (count, path))

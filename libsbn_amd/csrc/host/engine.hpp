@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 #include "../../../include/mi_phylo.h"
@@ -155,19 +157,30 @@ class Engine {
   std::vector<PhyloGradient> Gradients(const UnrootedTreeCollection& trees,
                                        const ParamMatrix& params, const bool rescaling) const {
     const size_t T = trees.size(), N = 2 * site_pattern_.SequenceCount() - 1;
-    std::vector<int32_t> parents;
-    std::vector<double> bl;
+    // (the flat arrays are the engine's own, re-used from call to call: no allocation, no
+    // zero-filling of a megabyte of outputs per call)
+    std::vector<int32_t>& parents = scratch_parents_;
+    std::vector<double>& bl = scratch_bl_;
     Flatten(trees, params, false, &parents, &bl);
     if (trees.empty()) return {};
-    std::vector<double> ll(T), g(T * N), site(T), subst(T * 8);
+    Grow(&scratch_ll_, T);
+    Grow(&scratch_a_, T * N);
+    Grow(&scratch_site_, T);
+    Grow(&scratch_subst_, T * 8);
+    const double *ll = scratch_ll_.data(), *g = scratch_a_.data(), *site = scratch_site_.data(),
+                 *subst = scratch_subst_.data();
     Check(mi_engine_gradients_unrooted(handle_, static_cast<int32_t>(T), parents.data(),
-                                       bl.data(), params.data.data(), rescaling, ll.data(),
-                                       g.data(), site.data(), subst.data()));
+                                       bl.data(), params.data.data(), rescaling, scratch_ll_.data(),
+                                       scratch_a_.data(), category_count_ > 1 ? scratch_site_.data() : nullptr,
+                                       is_gtr_ ? scratch_subst_.data() : nullptr));
     std::vector<PhyloGradient> out(T);
     for (size_t t = 0; t < T; t++) {
       out[t].log_likelihood_ = ll[t];
-      out[t].gradient_["branch_lengths"].assign(g.begin() + t * N, g.begin() + (t + 1) * N);
-      AddModelGradients(&out[t], site[t], &subst[8 * t]);
+      // (keys in map order, each placed at the end with its vector built in place)
+      GradientMap& m = out[t].gradient_;
+      m.emplace_hint(m.end(), std::piecewise_construct, std::forward_as_tuple("branch_lengths"),
+                     std::forward_as_tuple(g + t * N, g + (t + 1) * N));
+      AddModelGradients(&out[t], site[t], subst + 8 * t);
     }
     return out;
   }
@@ -216,6 +229,10 @@ class Engine {
   int category_count_ = 1;
   bool is_gtr_ = false;
   size_t taxon_count_ = 0;
+  // flat arrays of the last call (an Engine is not used from two threads at once: neither is
+  // the C handle behind it)
+  mutable std::vector<int32_t> scratch_parents_;
+  mutable std::vector<double> scratch_bl_, scratch_ll_, scratch_a_, scratch_site_, scratch_subst_;
 
   static void Check(int rc) {
     if (rc != 0) Failwith(mi_last_error());
@@ -235,9 +252,13 @@ class Engine {
         Failwith("Tree does not have the taxon count of the site pattern (expected " +
                  std::to_string(want_parents) + " parent ids and " + std::to_string(want_bl) +
                  " branch lengths).");
+    parents->resize(trees.size() * want_parents);
+    bl->resize(trees.size() * want_bl);
+    int32_t* pp = parents->data();
+    double* pb = bl->data();
     for (const auto& tree : trees) {
-      parents->insert(parents->end(), tree.parent_ids.begin(), tree.parent_ids.end());
-      bl->insert(bl->end(), tree.branch_lengths.begin(), tree.branch_lengths.end());
+      pp = std::copy(tree.parent_ids.begin(), tree.parent_ids.end(), pp);
+      pb = std::copy(tree.branch_lengths.begin(), tree.branch_lengths.end(), pb);
     }
   }
 
@@ -267,9 +288,18 @@ class Engine {
     return out;
   }
 
+  // ("site_model" < "substitution_model", both after the other keys: hinted at the end)
   void AddModelGradients(PhyloGradient* g, double site, const double* subst) const {
-    if (category_count_ > 1) g->gradient_["site_model"] = {site};
-    if (is_gtr_) g->gradient_["substitution_model"].assign(subst, subst + 8);
+    GradientMap& m = g->gradient_;
+    if (category_count_ > 1)
+      m.emplace_hint(m.end(), std::piecewise_construct, std::forward_as_tuple("site_model"),
+                     std::forward_as_tuple(size_t{1}, site));
+    if (is_gtr_)
+      m.emplace_hint(m.end(), std::piecewise_construct, std::forward_as_tuple("substitution_model"),
+                     std::forward_as_tuple(subst, subst + 8));
+  }
+  static void Grow(std::vector<double>* v, size_t count) {
+    if (v->size() < count) v->resize(count);
   }
 };
 

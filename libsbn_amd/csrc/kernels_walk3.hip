@@ -115,7 +115,7 @@ constexpr int kReadySpins = 1 << 20;
 template <bool RESCALE, bool FUSED>
 __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, const int block,
                                               const int32_t* ready) {
-  static_assert(R == 2 || R == 3, "tip bytes of a (macro, position) pair come as R words");
+  static_assert(R >= 1 && R <= 3, "tip bytes of a (macro, position) pair come as R words");
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
   // one tile per wave (several tiles per wave, as the second generation has them, were
@@ -375,7 +375,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
 #pragma unroll
           for (int c = 0; c < 4; c++)
             *reinterpret_cast<uint32_t*>(dst + c * kTwCol) =
-                ((w.d[0] >> (8 * c)) & 0xffu) | (((w.d[1] >> (8 * c)) & 0xffu) << 8) |
+                ((w.d[0] >> (8 * c)) & 0xffu) | (R > 1 ? ((w.d[R > 1 ? 1 : 0] >> (8 * c)) & 0xffu) << 8 : 0u) |
                 (R > 2 ? ((w.d[R - 1] >> (8 * c)) & 0xffu) << 16 : 0u);
         }
       }
@@ -1159,7 +1159,9 @@ void launch_transition_lut(const TransitionMacroArgs& a, hipStream_t s) {
 
 // the third generation takes calls the second would run with its stored vectors in LDS, one
 // category group of three or four categories
-bool gradient_walk_lut_applies(int K) { return K == 3 || K == 4; }
+// (R = 1 -- four patterns per wave -- is not worth the look-up walk's per-visit cost: the
+// engine's tile-width choice never pairs them)
+bool gradient_walk_lut_applies(int K) { return (K == 3 || K == 4) && R >= 2; }
 
 void launch_gradient_walk_lut(const LikArgs& a_in, int count, bool rescale, hipStream_t s) {
   if (count <= 0) return;

@@ -162,6 +162,7 @@ struct mi_engine {
   // staging for the host-pointer entry points
   Buffer in_parent, in_bl, in_params, in_rates, in_rate_counts, in_heights, in_bounds,
       in_ratios, out_ll, out_a, out_b, out_site, out_subst;
+  Buffer in_pack, out_pack;  // one block each way per host-pointer call (begin_host_call)
   size_t plv_budget = (size_t)8 << 30;
   // kernel timing (bench.py)
   std::vector<hipEvent_t> prof_events;  // kProfEvents per call: [begin, end, mark 0..4]

@@ -409,6 +409,9 @@ def final_line(full):
     if full.get("small_batch"):
         out["small_batch"] = _pick(full["small_batch"],
                                    ("trees", "ms_per_step", "graph_ms_per_step", "kernel_ms",
+                                    "graph_with_event_per_replay_ms_per_step",
+                                    "graph_speedup_vs_full_batch", "graph_full_batch_ms_per_step",
+                                    "graph_full_over_small",
                                     "graph_with_collective_ms_per_step"))
     if full.get("weak"):
         out["weak"] = _pick(full["weak"], ("value", "ms_per_step", "trees_per_gpu"))
@@ -1389,6 +1392,22 @@ def main():
             for _ in range(5):
                 graph.replay()
             torch.cuda.synchronize()
+            # 100 replays back to back between TWO events (what a rank does step after step);
+            # three such passes, the median.  Until round 5 an event was recorded after every
+            # replay inside this pass: each record is a marker packet the next graph launch
+            # queues behind -- it added ~10 us to every step (0.1424 against 0.1326 ms on one
+            # box, same binary).  The per-replay spread is a second pass, marked as such.
+            passes = []
+            for _ in range(3):
+                g0, g1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+                g0.record()
+                for k in range(100):
+                    graph.replay()
+                g1.record()
+                torch.cuda.synchronize()
+                passes.append(g0.elapsed_time(g1) / 100)
+            small["graph_ms_per_step"] = float(np.median(passes))
+            small["graph_passes_ms_per_step"] = [float(x) for x in passes]
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(101)]
             evs[0].record()
             for k in range(100):
@@ -1396,11 +1415,45 @@ def main():
                 evs[k + 1].record()
             torch.cuda.synchronize()
             reps = [evs[k].elapsed_time(evs[k + 1]) for k in range(100)]
-            small["graph_ms_per_step"] = evs[0].elapsed_time(evs[100]) / 100
+            small["graph_with_event_per_replay_ms_per_step"] = evs[0].elapsed_time(evs[100]) / 100
             small["graph_step_ms"] = {"min": float(np.min(reps)), "median": float(np.median(reps)),
                                       "max": float(np.max(reps))}
             small["graph_speedup_vs_full_batch"] = ms_per_step / small["graph_ms_per_step"]
             assert bool(torch.isfinite(blk.log_likelihoods).all())
+            # like against like: the FULL batch replayed from a hipGraph the same way -- the
+            # one-GPU step of a strong-scaling curve whose 8-GPU step is the figure above
+            if grad:
+                f_pid = torch.from_numpy(pids_all[:T_total]).to(dev)
+                f_bl = torch.from_numpy(bls_all[:T_total]).to(dev)
+                f_par = torch.from_numpy(params_all[:T_total]).to(dev)
+                fblk = sharding.ResultBlocks(T_total, N, extra=1, device=dev)
+                eng.reserve(T_total, True)
+                fgraph = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(fgraph, stream=gstream):
+                    eng.gradients_device(torch.cuda.current_stream().cuda_stream, T_total,
+                                         f_pid.data_ptr(), f_bl.data_ptr(), f_par.data_ptr(),
+                                         fblk.log_likelihoods.data_ptr(),
+                                         fblk.branch_gradients.data_ptr(),
+                                         fblk.extras[0].data_ptr(), None)
+                for _ in range(3):
+                    fgraph.replay()
+                torch.cuda.synchronize()
+                fpasses = []
+                for _ in range(3):
+                    g0, g1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+                    g0.record()
+                    for k in range(20):
+                        fgraph.replay()
+                    g1.record()
+                    torch.cuda.synchronize()
+                    fpasses.append(g0.elapsed_time(g1) / 20)
+                small["graph_full_batch_ms_per_step"] = float(np.median(fpasses))
+                small["graph_full_over_small"] = (small["graph_full_batch_ms_per_step"]
+                                                  / small["graph_ms_per_step"])
+                # the reserve above may have re-allocated workspace the 125-tree graph points
+                # at: capture that one again before anything below replays it
+                eng.reserve(Ts, True)
         except Exception as exc:  # capture support varies; the eager figure stands
             small["graph_error"] = repr(exc)[:200]
         if grad and "graph_error" not in small:

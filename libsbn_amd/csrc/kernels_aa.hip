@@ -675,6 +675,19 @@ template <int M, bool GRAD>
 __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkArgs a) {
   __shared__ SchedEntry sched_lds[kSchedWindow];
   __shared__ double ops_lds[2][2][kAaPack];  // [buffer][child][640]: pack, or tip table (420)
+  // Log-likelihood form (round 5): the TOP of the wave's stack of kept
+  // vectors lives in LDS.  A post-order walk keeps vectors in stack order -- the schedule's slot
+  // number of a kept vector IS its stack position (tree set-up hands out the lowest free slot,
+  // and the two children of a visit are the two topmost entries) -- and most kept vectors are
+  // consumed a few visits later: of the ~171 vectors a random 512-taxon tree keeps (the rest
+  // pass from a visit to the next in registers), 90 % never have more than one other vector
+  // pushed on top of them, 97 % never more than two (the stack is never deeper than 5 there).
+  // Until round 5 every one of them went to the HBM arena and back: 42 + 42 GB of the
+  // kernel's ~100 GB per eight 512 x 50 000 x 4 trees.  Now the slots [lo, lo + S) of the wave
+  // are a ring in LDS (S = a.ring_slots entries; vector and exponents); a push that finds the ring full
+  // spills the ring's OLDEST entry to its arena slot first (lo++), a pop below lo reads the
+  // arena as before.  Same loads, products and stores in the same order: bit-identical.
+  extern __shared__ double ring_lds[];  // [wave][S][M tiles x (320 doubles + 16 ints)]
   const int blocks = a.tiles / M;
   const int wgs = (blocks + kPostWaves - 1) / kPostWaves;  // workgroups per (evaluation, category)
   const AaUnit un = aa_unit(wgs, a.evals * a.K);
@@ -762,6 +775,12 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
   int eloc[M];
 #pragma unroll
   for (int u = 0; u < M; u++) eloc[u] = 0;
+  // the ring of this wave; lo: first slot that lives in it (slots below are in the arena)
+  constexpr int kRingEntry = M * (kAaTileDoubles + 8);  // doubles per entry (16 ints = 8 doubles per tile)
+  const int RS = GRAD ? 0 : sgpr(a.ring_slots);
+  double* const ring = ring_lds + (size_t)sgpr(wave) * RS * kRingEntry;
+  int lo = RS > 0 ? 0 : 0x7fffffff;
+  auto ring_entry = [&](int slot) { return ring + (slot % max(RS, 1)) * kRingEntry; };
   for (int i = 0; i < count; i++) {
     const int buf = i & 1;
     int nv = -1, next_c0 = -1, next_c1 = -1, nslots = 0;
@@ -800,9 +819,17 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
           }
         } else {
           const int idx = GRAD ? ch - n : ((slots >> (8 + 8 * c)) & 0xff);
-          load_tiles<M>(arena + idx * arena_stride, lane, L);
+          if (!GRAD && idx >= lo) {  // (wave-uniform) in the ring
+            const double* src = ring_entry(idx);
+            load_tiles<M>(src, lane, L);
+            const int* ex = reinterpret_cast<const int*>(src + M * kAaTileDoubles);
 #pragma unroll
-          for (int u = 0; u < M; u++) Ec[c][u] = exp_cum[idx * exp_stride + u * 16 + j];
+            for (int u = 0; u < M; u++) Ec[c][u] = ex[u * 16 + j];
+          } else {
+            load_tiles<M>(arena + idx * arena_stride, lane, L);
+#pragma unroll
+            for (int u = 0; u < M; u++) Ec[c][u] = exp_cum[idx * exp_stride + u * 16 + j];
+          }
         }
 #pragma unroll
         for (int r = 0; r < 10; r++) A[r] = shared[r * 64 + lane];
@@ -847,10 +874,42 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
         }
       } else if (prev != ch0 && prev != ch1) {
         const int dst = prev_slots & 0xff;
-        store_tiles_async<M>(arena + dst * arena_stride, lane, R);
-        if (g == 0) {
+        if (RS > 0) {
+          if (dst < lo) lo = dst;  // (the stack has unwound below the ring: it starts anew here)
+          if (dst - lo >= RS) {
+            // the ring is full: its oldest entry goes to its arena slot
+            const double* old = ring_entry(lo);
+            double Lo[M][5];
+            load_tiles<M>(old, lane, Lo);
+            const int* ex = reinterpret_cast<const int*>(old + M * kAaTileDoubles);
+            int eo[M];
 #pragma unroll
-          for (int u = 0; u < M; u++) store_async(exp_cum + dst * exp_stride, u * 16 + j, E[u]);
+            for (int u = 0; u < M; u++) eo[u] = ex[u * 16 + j];
+            const int lo_s = sgpr(lo);
+            store_tiles_async<M>(sgpr_ptr(arena + lo_s * arena_stride), lane, Lo);
+            if (g == 0) {
+              int32_t* eb = sgpr_ptr(exp_cum + lo_s * exp_stride);
+#pragma unroll
+              for (int u = 0; u < M; u++) store_async(eb, u * 16 + j, eo[u]);
+            }
+            lo = lo_s + 1;
+          }
+          double* dstp = ring_entry(dst);
+#pragma unroll
+          for (int u = 0; u < M; u++)
+#pragma unroll
+            for (int t = 0; t < 5; t++) dstp[u * kAaTileDoubles + t * 64 + lane] = R[u][t];
+          if (g == 0) {
+            int* ex = reinterpret_cast<int*>(dstp + M * kAaTileDoubles);
+#pragma unroll
+            for (int u = 0; u < M; u++) ex[u * 16 + j] = E[u];
+          }
+        } else {
+          store_tiles_async<M>(arena + dst * arena_stride, lane, R);
+          if (g == 0) {
+#pragma unroll
+            for (int u = 0; u < M; u++) store_async(exp_cum + dst * exp_stride, u * 16 + j, E[u]);
+          }
         }
       }
     }
@@ -1492,17 +1551,42 @@ static bool aa_post_wg() {
   static const bool wg = !(getenv("MI_PHYLO_AA_POST") && std::string(getenv("MI_PHYLO_AA_POST")) == "wave");
   return wg;
 }
-void launch_aa_post(const AaWalkArgs& a, hipStream_t s) {
+// Entries of the LDS ring a log-likelihood wave keeps the top of its vector stack in
+// (aa_post_wg_kernel); MI_PHYLO_AA_RING=0..4 overrides (0: every kept vector through the arena,
+// the form until round 4).  Measured, eight 512 x 50 000 x 4 trees per launch (tools/bench_aa.py
+// --mode loglik): 18.6 / 18.5 / 21.3 / 32.1 ms with 0 / 1 / 2 / 3 entries -- an entry is 5 KB
+// per wave, 21 KB per workgroup, and every entry costs a workgroup per CU (4 / 3 / 2 / 1 fit):
+// the kernel is bound by issue and latency at these occupancies, not by the 42 + 42 GB of
+// arena traffic the ring removes (67 % of it with one entry, 90 % with two).  ONE entry is the
+// default for launches of three rounds of workgroups and more: the same time with less than
+// half of the HBM traffic; smaller launches (one tree: 1.5 rounds at four per CU, two at
+// three) keep four workgroups per CU and the arena.
+static int aa_ring_slots(size_t workgroups) {
+  static const int forced = getenv("MI_PHYLO_AA_RING") ? atoi(getenv("MI_PHYLO_AA_RING")) : -1;
+  if (forced >= 0 && forced <= 4) return forced;
+  return workgroups >= 3 * 4 * (size_t)device_compute_units() ? 1 : 0;
+}
+void launch_aa_post(const AaWalkArgs& a_in, hipStream_t s) {
+  AaWalkArgs a = a_in;
   const int m = aa_post_tiles(a);
   if (aa_post_wg()) {
     const int blocks = a.tiles / m;
     const dim3 grid(aa_grid((blocks + kPostWaves - 1) / kPostWaves, a.evals * a.K)), block(kPostThreads);
+    a.ring_slots = a.gradient ? 0 : aa_ring_slots((size_t)grid.x * grid.y * grid.z);
+    const size_t ring = sizeof(double) * (size_t)kPostWaves * a.ring_slots * m * (kAaTileDoubles + 8);
+    const size_t lds = ring + aa_lds_pad();
     if (m == 4) {
-      if (a.gradient) hipLaunchKernelGGL((aa_post_wg_kernel<4, true>), grid, block, aa_lds_pad(), s, a);
-      else hipLaunchKernelGGL((aa_post_wg_kernel<4, false>), grid, block, aa_lds_pad(), s, a);
+      if (a.gradient) hipLaunchKernelGGL((aa_post_wg_kernel<4, true>), grid, block, lds, s, a);
+      else {
+        allow_large_lds(reinterpret_cast<const void*>(aa_post_wg_kernel<4, false>), lds + 32 * 1024);
+        hipLaunchKernelGGL((aa_post_wg_kernel<4, false>), grid, block, lds, s, a);
+      }
     } else {
-      if (a.gradient) hipLaunchKernelGGL((aa_post_wg_kernel<2, true>), grid, block, aa_lds_pad(), s, a);
-      else hipLaunchKernelGGL((aa_post_wg_kernel<2, false>), grid, block, aa_lds_pad(), s, a);
+      if (a.gradient) hipLaunchKernelGGL((aa_post_wg_kernel<2, true>), grid, block, lds, s, a);
+      else {
+        allow_large_lds(reinterpret_cast<const void*>(aa_post_wg_kernel<2, false>), lds + 32 * 1024);
+        hipLaunchKernelGGL((aa_post_wg_kernel<2, false>), grid, block, lds, s, a);
+      }
     }
     return;
   }

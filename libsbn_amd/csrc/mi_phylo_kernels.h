@@ -335,6 +335,7 @@ struct AaWalkArgs {
   int eval_offset, evals;  // this chunk
   int gradient;            // post-order: every internal vector is kept, indexed by node
   int slots;               // log-likelihood only: vectors are kept by schedule slot
+  int ring_slots;          // log-likelihood only (set by the launcher): stack entries a wave keeps in LDS
   int ll_stride;           // stride of ll_part per evaluation
   const SchedEntry* sched; // [T][n-1]
   const AaModel* model;

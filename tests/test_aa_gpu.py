@@ -282,6 +282,7 @@ def test_kernel_forms_agree_bitwise(tmp_path):
         "rng = np.random.default_rng(5)\n"
         "tips, w = A.random_aa_alignment(41, 700, rng)\n"
         "pids, bls = TU.random_trees(41, 3, rng)\n"
+        "pids[0] = TU.balanced_topology(41)\n"  # (the deepest stack a tree of this size can have)
         "pr = A.params_for('weibull+4', 3, rng)\n"
         "eng = L.Engine(L.PhyloModelSpecification('WAG', 'weibull+4', 'strict'), tips, w)\n"
         "g = eng.gradients(pids, bls, pr)\n"
@@ -290,15 +291,22 @@ def test_kernel_forms_agree_bitwise(tmp_path):
         " + [np.atleast_1d(x.gradient['site_model']) for x in g])\n"
         "np.save(sys.argv[1], out)\n")
     outs = []
-    for post, pre in (("", ""), ("wave", ""), ("", "wave"), ("wave", "wave")):
+    # (round 5: the log-likelihood walk keeps the top 0 / 1 / 2 / 3 entries of its vector stack
+    # in an LDS ring -- MI_PHYLO_AA_RING; a 41-taxon tree's stack reaches three or four entries,
+    # so the smaller rings spill to the arena and read it back: same loads, products and stores)
+    for post, pre, ring in (("", "", ""), ("wave", "", ""), ("", "wave", ""), ("wave", "wave", ""),
+                            ("", "", "0"), ("", "", "1"), ("", "", "2"), ("", "", "3")):
         env = dict(os.environ)
         env.pop("MI_PHYLO_AA_POST", None)
         env.pop("MI_PHYLO_AA_PRE", None)
+        env.pop("MI_PHYLO_AA_RING", None)
         if post:
             env["MI_PHYLO_AA_POST"] = post
         if pre:
             env["MI_PHYLO_AA_PRE"] = pre
-        out = tmp_path / f"out_{post}_{pre}.npy"
+        if ring:
+            env["MI_PHYLO_AA_RING"] = ring
+        out = tmp_path / f"out_{post}_{pre}_{ring}.npy"
         r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True,
                            text=True)
         assert r.returncode == 0, r.stdout + r.stderr

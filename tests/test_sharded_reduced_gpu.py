@@ -270,15 +270,23 @@ def test_reduced_device_call_allocates_nothing_after_reserve_reduced():
     spec = L.PhyloModelSpecification("JC69", "weibull+4", "strict")
     pr = np.ones((T, 2)); pr[:, 0] = rng.uniform(0.4, 1.6, T)
     bi = rng.integers(-1, index_count, size=(T, N)).astype(np.int32)
-    eng = L.Engine(spec, tips, w)
     dev = torch.device("cuda", 0)
     d_pid, d_bl, d_par, d_bi = (torch.from_numpy(x).to(dev) for x in (pids, bls, pr, bi))
     packed = torch.zeros(2 + index_count, dtype=torch.float64, device=dev)
     d_ll = torch.zeros(T, dtype=torch.float64, device=dev)
+    gs = torch.cuda.Stream()
+    # (another engine runs the same call first: the kernels' code objects are loaded -- into
+    # device memory -- at their first launch, which is not the engine's allocation)
+    warm = L.Engine(spec, tips, w)
+    rc = warm._lib.mi_engine_gradients_unrooted_reduced_device(
+        warm._h, gs.cuda_stream, T, d_pid.data_ptr(), d_bl.data_ptr(), d_par.data_ptr(), 0,
+        d_bi.data_ptr(), None, index_count, packed.data_ptr(), packed.data_ptr() + 16, d_ll.data_ptr())
+    assert rc == 0, _capi.last_error()
+    torch.cuda.synchronize()
+    eng = L.Engine(spec, tips, w)
     eng.reserve_reduced(T, index_count)
     torch.cuda.synchronize()
     free_before = torch.cuda.mem_get_info()[0]
-    gs = torch.cuda.Stream()
 
     def call(stream):
         rc = eng._lib.mi_engine_gradients_unrooted_reduced_device(
@@ -310,4 +318,4 @@ def test_reduced_device_call_allocates_nothing_after_reserve_reduced():
     assert np.allclose(got[:2], want[:2], rtol=1e-13, atol=0)
     with pytest.raises(RuntimeError, match="index_count"):
         eng.reserve_reduced(T, -1)
-    eng.close()
+    eng.close(); warm.close()

@@ -94,6 +94,10 @@ constexpr bool kStoreS = W3_STORE_S != 0;
 #define W3_EARLY_LDS 0
 #endif
 constexpr bool kEarlyLds = W3_EARLY_LDS != 0;
+// W3_SCHED_REGS: see load_shape / load_slots
+#ifndef W3_SCHED_REGS
+#define W3_SCHED_REGS 0
+#endif
 
 // operands of one child of a visit (see fetch_child)
 template <bool PRE>
@@ -215,11 +219,35 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   struct Slots {  // scalars (s_load_dwordx8)
     int q, c[2], g[4], dst;
   };
+#if W3_SCHED_REGS
+  // (experiment, round 5: the schedule words of the whole tree in nine vector registers --
+  // lane m holds macro m's shape and its eight slot words -- read with v_readlane when a visit
+  // needs them: no scalar-memory instruction inside the walk, so a wait for LDS data is no
+  // longer a wait for scalar loads that return out of order)
+  int sched_w[9];
+  {
+    const int ml = lane < Mmax ? lane : 0;
+    sched_w[0] = mwv[ml * 16];
+    const int4 lo4 = *reinterpret_cast<const int4*>(mwv + ml * 16 + 8);
+    const int4 hi4 = *reinterpret_cast<const int4*>(mwv + ml * 16 + 12);
+    sched_w[1] = lo4.x; sched_w[2] = lo4.y; sched_w[3] = lo4.z; sched_w[4] = lo4.w;
+    sched_w[5] = hi4.x; sched_w[6] = hi4.y; sched_w[7] = hi4.z; sched_w[8] = hi4.w;
+  }
+  auto load_shape = [&](int m) { return __builtin_amdgcn_readlane(sched_w[0], m); };
+  auto load_slots = [&](int m) {
+    return Slots{__builtin_amdgcn_readlane(sched_w[1], m),
+                 {__builtin_amdgcn_readlane(sched_w[2], m), __builtin_amdgcn_readlane(sched_w[3], m)},
+                 {__builtin_amdgcn_readlane(sched_w[4], m), __builtin_amdgcn_readlane(sched_w[5], m),
+                  __builtin_amdgcn_readlane(sched_w[6], m), __builtin_amdgcn_readlane(sched_w[7], m)},
+                 __builtin_amdgcn_readlane(sched_w[8], m)};
+  };
+#else
   auto load_shape = [&](int m) { return mw[m * 16]; };
   auto load_slots = [&](int m) {
     const cint_ptr p = mw + m * 16 + 8;
     return Slots{p[0], {p[1], p[2]}, {p[3], p[4], p[5], p[6]}, p[7]};
   };
+#endif
   // LDS: [macro][column][8 words: tip codes of positions 0..5, one byte per register r] --
   // re-used, macro by macro, for that macro's edge sums once its tip words were consumed --
   // | vectors [slot][r][lane] | RESCALE: exponents

@@ -18,11 +18,24 @@ for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
     # third's -- weighted up: every generation x store appears a hundred times per 1 000 trials)
     K = int(rng.choice([1, 1, 2, 2, 3, 3, 4, 4, 4, 5, 6, 8, 11, 16, 23, 64]))
     subst = str(rng.choice(["JC69", "GTR"]))
-    site = "constant" if K == 1 else f"weibull+{K}"
     resc = bool(rng.integers(0, 2))
     # (mostly a few trees; now and then a batch large enough that 32-100-taxon trees take the
     # arena variant of the walk and small ones fill the machine)
     T = int(rng.choice([1, 2, 9, 9, 150])) if n <= 100 and P <= 100 and K <= 8 else int(rng.choice([1, 2, 9]))
+    # STRESS_FOCUS=arena: batches of 150 trees of 32-100 taxa (the arena variants of the walk
+    # kernels); =fused: small trees, three or four categories, 1-300 trees (the one-launch call,
+    # half of the GTR trials asking for the branch-length gradient only)
+    focus = os.environ.get("STRESS_FOCUS", "")
+    if focus == "arena":
+        n = int(rng.choice([32, 33, 36, 41, 45, 50, 59, 64, 69, 80, 100]))
+        P = int(rng.choice([11, 13, 47, 49, 64, 100]))
+        K = int(rng.choice([1, 2, 3, 4, 4, 8]))
+        T = 150
+    elif focus == "fused":
+        n = int(rng.choice([3, 4, 5, 7, 9, 12, 17, 26, 27, 28, 30, 31]))
+        K = int(rng.choice([3, 4]))
+        T = int(rng.choice([1, 2, 9, 64, 300]))
+    site = "constant" if K == 1 else f"weibull+{K}"
     tips, w = TU.random_alignment(n, P, rng, gap_fraction=float(rng.choice([0.0, 0.05, 0.5])))
     pids, bls = TU.random_trees(n, T, rng, mean_bl=float(rng.choice([0.001, 0.1, 1.0])))
     if rng.integers(0, 3) == 0: pids[0] = TU.ladder_topology(n)
@@ -35,7 +48,9 @@ for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
         r, f = TU.random_gtr_params(T, rng); blocks["GTR rates"] = r; blocks["frequencies"] = f
     if K > 1: blocks["Weibull shape"] = rng.uniform(0.2, 3.0, size=(T, 1))
     pr = TG._params(spec, T, **blocks)
-    g = eng.gradients(pids, bls, pr, resc)
+    # (a GTR call that asks for the branch-length gradient only: one evaluation per tree)
+    only_branch = subst == "GTR" and bool(rng.integers(0, 2)) and focus == "fused"
+    g = eng.gradients(pids, bls, pr, resc, gradient_blocks=("branch_lengths",) if only_branch else None)
     kern = eng.last_call_info()[0]
     seen[eng.last_call_path()] += 1
     O.set_transition_mode(1)
@@ -58,12 +73,12 @@ for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
         okb = np.max(np.abs(g[t].gradient["branch_lengths"] - og["branch_lengths"][t])) <= 1e-9 * scale
         if not okb: print("  bl", g[t].gradient["branch_lengths"], og["branch_lengths"][t])
         ok &= okl and okb
-        if K > 1:
+        if K > 1 and not only_branch:
             tol_site = 1e-4 if (subst == "GTR" and os.environ.get("MI_PHYLO_SUBST_GRADIENT")) else 1e-8
             okk = abs(g[t].gradient["site_model"][0] - og["site_model"][t]) <= tol_site * max(1.0, abs(og["site_model"][t]))
             if not okk: print("  site", g[t].gradient["site_model"][0], og["site_model"][t])
             ok &= okk
-        if subst == "GTR":
+        if subst == "GTR" and not only_branch:
             a = g[t].gradient["substitution_model"]; f_ = og["substitution_model"][t]
             # (finite differences of logL with a 1e-6 step: rounding noise ~ 1e-16 |logL| / 2e-6
             # per ulp of difference in the summation order)

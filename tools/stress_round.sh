@@ -1,0 +1,31 @@
+#!/bin/bash
+# The randomised parity sweeps of a round, run in parallel on the GPU box's cores (the CPU oracle
+# is most of their time); summaries -- trial counts, mismatches, the histogram of the paths the
+# trials took (mi_engine_last_call_path) -- land in gpurun_out/<tag>_stress_*.txt, from where
+# they are copied to profiles/.
+#   bash tools/stress_round.sh r05
+tag=${1:-rXX}
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+run() {  # name, tool, seed, trials, [ENV=value ...]
+  local name=$1 tool=$2 seed=$3 trials=$4; shift 4
+  env STRESS_SEED=$seed STRESS_TRIALS=$trials "$@" timeout 3000 python3 tools/stress_$tool.py > gpurun_out/stress_$name.log 2>&1
+  {
+    echo "stress_$tool ($name) seed $seed trials $trials $* rc=$?"
+    grep -c "MISMATCH" gpurun_out/stress_$name.log | sed 's/^/mismatch lines: /'
+    sed -n '/^trials\|^rooted trials/,$p' gpurun_out/stress_$name.log
+  } > gpurun_out/${tag}_stress_$name.txt
+}
+run parity_a parity 3001 1500 &
+run parity_b parity 3002 1500 &
+run parity_fused parity 3003 600 STRESS_FOCUS=fused &
+run parity_arena parity 3004 300 STRESS_FOCUS=arena &
+run parity_arena_v1 parity 3010 150 STRESS_FOCUS=arena MI_PHYLO_GRADIENT_WALK=v1 &
+run parity_v2 parity 3005 600 MI_PHYLO_GRADIENT_WALK=v2 &
+run parity_v1 parity 3006 600 MI_PHYLO_GRADIENT_WALK=v1 &
+run parity_unfused parity 3007 400 MI_PHYLO_FUSED_SETUP=0 STRESS_FOCUS=fused &
+run parity_analytic parity 3008 400 MI_PHYLO_SUBST_GRADIENT=analytic &
+run rooted rooted 3009 800 &
+run aa aa 3011 500 &
+wait
+cat gpurun_out/${tag}_stress_*.txt

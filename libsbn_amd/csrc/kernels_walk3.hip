@@ -132,7 +132,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   int t, mi;
   a.map.decode(e, t, mi);
   int M_ready = 0;
-#ifdef XP_STAMPS
+#ifdef W3_SETUP_STAMPS
   const long long w_in = __builtin_amdgcn_s_memrealtime();
 #endif
   if (FUSED) {
@@ -143,16 +143,12 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     // first touch of such a line after the poll misses every cache of this CU and XCD (they
     // were invalidated when the kernel started) and is served with the stored bytes.
     int v = 0, spins = 0;
-#ifdef XP_WALK_ONLY
-    v = (kSetupQuarters << 8) | __builtin_amdgcn_readfirstlane(a.macro_count[t]);
-#else
     for (;;) {
       v = __builtin_amdgcn_readfirstlane(
           __hip_atomic_load(ready + (size_t)t * kReadyStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       if ((v >> 8) >= kSetupQuarters || ++spins >= kReadySpins) break;
       __builtin_amdgcn_s_sleep(8);
     }
-#endif
     // (-1: waited in vain.  The wave leaves through the one exit below -- a second `return`
     // up here, with its status store, changed how the WHOLE walk is compiled: 224 registers
     // instead of 214 and a wait in front of single operand loads, +34 % time per 1000 trees)
@@ -162,7 +158,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     // anything: the indices every such address is formed from are redefined HERE.
     asm volatile("" : "+s"(t), "+s"(mi), "+s"(gi) : : "memory");
   }
-#ifdef XP_STAMPS
+#ifdef W3_SETUP_STAMPS
   if (lane == 0 && (block % 1499) == 0)
     printf("walk block %d (tree %d tile %d): in %lld polled %lld\n", block, t, tile, w_in, (long long)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -1007,7 +1003,7 @@ __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const 
   int* len_of = rec_of + 64;
   int* slot_of = len_of + 64;
 
-#ifdef XP_STAMPS
+#ifdef W3_SETUP_STAMPS
   long long st0 = __builtin_amdgcn_s_memrealtime(), st1, st2, st3, st4, st5;
 #define XSTAMP(x) x = __builtin_amdgcn_s_memrealtime()
 #else
@@ -1119,7 +1115,7 @@ __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const 
   // everything above has reached memory before the word says so
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   XSTAMP(st5);
-#ifdef XP_STAMPS
+#ifdef W3_SETUP_STAMPS
   if (lane == 0 && (t == 0 || t == 60 || t == 124) && q < 2)
     printf("setup role t %d q %d: start %lld end %lld model %lld tree %lld records %lld stores issued %lld landed %lld (10 ns ticks)\n", t, q, st0, (long long)__builtin_amdgcn_s_memrealtime(),
            st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4);
@@ -1137,7 +1133,7 @@ __global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_fused
     return;
   }
   walk_lut_body<RESCALE, true>(a, wlds, (int)blockIdx.x - f.setup_blocks, f.ready);
-#ifdef XP_STAMPS
+#ifdef W3_SETUP_STAMPS
   if (threadIdx.x == 0 && (((int)blockIdx.x - f.setup_blocks) % 1499) == 0)
     printf("walk block %d: out %lld\n", (int)blockIdx.x - f.setup_blocks, (long long)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -1162,12 +1158,8 @@ void launch_gradient_walk_lut_fused(const LikArgs& a_in, const FusedSetupArgs& f
   a.cat_groups = 1;
   a.walk_evals = count;
   f.setup_blocks = kSetupQuarters * count;
-#ifdef XP_WALK_ONLY
-  f.setup_blocks = 0;
-#endif
   const int gtiles = gradient_mfma_tiles(a.P, a.K);
-  dim3 grid((unsigned)((size_t)count * gtiles + f.setup_blocks));
-  if (getenv("MI_PHYLO_XP_SETUP_ONLY")) grid.x = f.setup_blocks;  // (timing experiment)
+  const dim3 grid((unsigned)((size_t)count * gtiles + f.setup_blocks));
   const size_t lds = std::max<size_t>(gradient_walk_lds_bytes(a.n, a.K, rescale, false), fused_setup_lds(a.n, a.K));
   if (rescale) {
     allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_fused_kernel<true>), lds);

@@ -247,8 +247,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool fuse_setup = walk3 && e->fused_setup && fuse_allowed && c.E == T && c.models_per_tree == 1 &&
                           !ts.need_slots && T <= fuse_max_trees && e->ready.ptr &&
                           gradient_walk_lut_fused_applies(n, e->K);
-  static const bool xp_walk_only = getenv("MI_PHYLO_XP_WALK_ONLY") != nullptr;
-  if (!fuse_setup || xp_walk_only) launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
+  if (!fuse_setup) launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
   if (arena)
     launch_macro_slots(e->macros.as<MacroEntry>(), e->arena_macros.as<MacroEntry>(),
                        e->macro_count.as<int32_t>(), n, T, e->slot_need.as<int32_t>(),
@@ -324,7 +323,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     tm.mphi = analytic ? e->mphi.as<double>() + (size_t)grad_begin * (per / 2) : nullptr;
     launch_transition_macro(tm, s);
   };
-  if (walk2 && (!fuse_setup || xp_walk_only)) {
+  if (walk2 && !fuse_setup) {
     macro_matrices(0, 0, T);
     if (site_pass) macro_matrices(17 * T, T, T);
   }

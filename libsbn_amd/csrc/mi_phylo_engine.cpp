@@ -240,10 +240,13 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // slots.
   static const bool fuse_allowed =
       !(getenv("MI_PHYLO_FUSE_FINALIZE") && std::string(getenv("MI_PHYLO_FUSE_FINALIZE")) == "0");
-  // Up to about a thousand trees: beyond, the set-up waves' share of the wave slots (four waves
-  // of ~10 microseconds per tree, a GTR eigensystem on one lane of each) costs the walk more
-  // than two launch boundaries -- measured cross-overs, DS1 (scratch notes in DESIGN.md 4.7).
-  const int fuse_max_trees = c.gtr ? 512 : 1024;
+  // Up to 512 trees: the set-up waves take wave slots the walk would use (four waves of ~10
+  // microseconds per tree, a GTR eigensystem on one lane of each) -- measured, DS1
+  // (tools/bench_fused_scan.py): one launch / four launches 0.91 at 1-8 trees,
+  // 0.98 at 250-500, 0.99 at 1000 (JC69; GTR 1.00), 1.01 beyond.  MI_PHYLO_FUSED_MAX_TREES
+  // moves the cross-over (testing).
+  static const int fuse_max_trees =
+      getenv("MI_PHYLO_FUSED_MAX_TREES") ? atoi(getenv("MI_PHYLO_FUSED_MAX_TREES")) : 512;
   const bool fuse_setup = walk3 && e->fused_setup && fuse_allowed && c.E == T && c.models_per_tree == 1 &&
                           !ts.need_slots && T <= fuse_max_trees && e->ready.ptr &&
                           gradient_walk_lut_fused_applies(n, e->K);

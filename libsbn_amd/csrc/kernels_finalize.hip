@@ -26,22 +26,38 @@ __device__ __forceinline__ void reduce_tiles_body(const ReduceArgs& a, const int
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int N2 = 2 * a.N;
   const int W = a.g_width ? a.g_width : N2;  // doubles per (evaluation, tile)
+  const int t = b < a.T ? b : b - a.T;  // gradient evaluations: [0,T) main, [T,2T) site pass
+  // Everything that does not depend on anything is requested FIRST (round 5): the macro
+  // count, the log-likelihood terms, and the schedule words that say which node a column of
+  // positional sums belongs to -- their round trips then pass under the tile loop's instead of
+  // standing in front of it and behind it (two of the ~five this kernel's time is made of on a
+  // small batch).
+  const bool positional = b < a.Eg && a.g_width;
+  const int mcount = positional ? a.macro_count[t] : 0;
   double llp = 0;
   for (int i = threadIdx.x; i < a.ll_used.of(b); i += 256) llp += a.ll_part[(size_t)b * a.ll_tiles + i];
-  llp = wave_sum(llp);
-  if (lane == 0) llw[wv] = llp;
-  const int t = b < a.T ? b : b - a.T;  // gradient evaluations: [0,T) main, [T,2T) site pass
-  int used = W;
-  if (b < a.Eg && a.g_width) used = a.macro_count[t] * kMacroPositions * 2;
+  const MacroEntry* mac = a.macros + (size_t)t * macro_stride(a.n);
+  int my_shape = 0, my_node = 0;  // of column threadIdx.x (the first of this thread's columns)
+  if (positional && (int)threadIdx.x < W - a.extra) {
+    const int m = threadIdx.x / (kMacroPositions * 2), pos = (threadIdx.x % (kMacroPositions * 2)) >> 1;
+    const int32_t* mw = reinterpret_cast<const int32_t*>(mac + m);
+    my_shape = mw[0];
+    my_node = mw[1 + pos];  // child[0..1], grand[0..3] follow the shape word
+  }
   if (b < a.Eg) {
     const double* src = a.g_part + (size_t)b * a.g_tiles * W;
     const int tail = a.g_width ? W - a.extra : W;  // plain sums after the positional part
+    // which columns: without trailing plain sums (every call but the analytic substitution
+    // gradient's) all W of them -- columns past the tree's last macro hold nothing anyone
+    // wrote, are summed for nothing and dropped below --, so that the loads do not wait for
+    // the macro count; with trailing sums the positional ones, then those
+    const int used_cols = a.extra ? mcount * kMacroPositions * 2 : W;
     // Four columns per lane side by side and the tile loop unrolled: 32 loads in flight per
     // lane (round 5; a column at a time with 16 in flight, the 156 columns of a DS1 tree were
     // six memory round trips one after the other -- most of this kernel's time on a small
     // batch).  Per (wave, column) the additions are the same in the same order.
     constexpr int VU = 4;
-    const int total = used + a.extra;
+    const int total = used_cols + a.extra;
     for (int v0 = lane; v0 < total; v0 += 64 * VU) {
       int col[VU];
       bool on[VU];
@@ -50,7 +66,7 @@ __device__ __forceinline__ void reduce_tiles_body(const ReduceArgs& a, const int
       for (int j = 0; j < VU; j++) {
         const int v = v0 + 64 * j;
         on[j] = v < total;
-        col[j] = !on[j] ? 0 : (v < used ? v : tail + (v - used));
+        col[j] = !on[j] ? 0 : (v < used_cols ? v : tail + (v - used_cols));
         s0[j] = s1[j] = 0;
       }
       int i = wv;
@@ -73,6 +89,10 @@ __device__ __forceinline__ void reduce_tiles_body(const ReduceArgs& a, const int
         if (on[j]) red_lds[wv * W + col[j]] = s0[j] + s1[j];
     }
   }
+  llp = wave_sum(llp);
+  if (lane == 0) llw[wv] = llp;
+  int used = W;
+  if (positional) used = mcount * kMacroPositions * 2;
   __syncthreads();
   if (threadIdx.x == 0) (keep ? keep[N2] : a.ll_sum[b]) = (llw[0] + llw[1]) + (llw[2] + llw[3]);
   if (b >= a.Eg) return;
@@ -83,7 +103,6 @@ __device__ __forceinline__ void reduce_tiles_body(const ReduceArgs& a, const int
     return;
   }
   // positional: entry (m, pos, q) belongs to the edge above child/grandchild `pos` of macro m
-  const MacroEntry* mac = a.macros + (size_t)t * macro_stride(a.n);
   if (a.extra)
     for (int v = threadIdx.x; v < a.extra; v += 256) {
       const int c = W - a.extra + v;
@@ -94,10 +113,14 @@ __device__ __forceinline__ void reduce_tiles_body(const ReduceArgs& a, const int
   for (int v = threadIdx.x; v < used; v += 256) {
     const int m = v / (kMacroPositions * 2), r = v - m * (kMacroPositions * 2);
     const int pos = r >> 1, q = r & 1;
-    const MacroEntry& me = mac[m];
-    const bool exists = pos < 2 || ((me.shape >> (2 * ((pos - 2) >> 1))) & 3) == 2;
+    int shape = my_shape, node = my_node;
+    if (v >= 256) {  // (larger trees: this thread's further columns)
+      const MacroEntry& me = mac[m];
+      shape = me.shape;
+      node = pos < 2 ? me.child[pos] : me.grand[pos - 2];
+    }
+    const bool exists = pos < 2 || ((shape >> (2 * ((pos - 2) >> 1))) & 3) == 2;
     if (!exists) continue;
-    const int node = pos < 2 ? me.child[pos] : me.grand[pos - 2];
     out[q * a.N + node] =
         (red_lds[v] + red_lds[W + v]) + (red_lds[2 * W + v] + red_lds[3 * W + v]);
   }

@@ -709,6 +709,19 @@ void launch_setup(const TreeSetupArgs& a_in, const ModelSetupArgs& ms, hipStream
   const dim3 grid(a.T + (ms.T * ms.models_per_tree + 63) / 64), block(64);
   hipLaunchKernelGGL(tree_setup_kernel, grid, block, a.use_lds ? lds : 0, s, a, ms);
 }
+namespace {
+__global__ void weibull_table_kernel(int K, double* table) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K) return;
+  const double quantile = (2.0 * i + 1.0) / (2.0 * K);  // (the expressions of weibull_category)
+  const double x = -log(1.0 - quantile);
+  table[2 * i] = x;
+  table[2 * i + 1] = log(x);
+}
+}  // namespace
+void launch_weibull_table(int K, double* table, hipStream_t s) {
+  hipLaunchKernelGGL(weibull_table_kernel, dim3(1), dim3(64), 0, s, K, table);
+}
 void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s) {  // trees only
   ModelSetupArgs none{};
   launch_setup(a, none, s);

@@ -226,6 +226,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ms.params = d.params;
   ms.models = e->models.as<DevModel>();
   ms.status = e->status.as<int32_t>();
+  ms.weibull_x = e->weibull_x.as<double>();
   const bool prof = e->prof_used < e->prof_capacity;
   const bool marks = prof && e->prof_phases;
   PROF_MARK(e, marks, 0, s);
@@ -821,6 +822,11 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   if (e->status.ensure(sizeof(int32_t) * 2) ||
       hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, e->stream) != hipSuccess)
     return cleanup_fail(fail("status word allocation failed"));
+  if (spec->site_model == MI_SITE_WEIBULL) {
+    // what the Weibull site model needs of its quantiles, once per engine (kernels_setup.hip)
+    if (e->weibull_x.ensure(sizeof(double) * 2 * (size_t)e->K)) return cleanup_fail(1);
+    launch_weibull_table(e->K, e->weibull_x.as<double>(), e->stream);
+  }
   const size_t np = (size_t)e->n * e->P;
   if (device_tips) {
     // (the two arrays must be device memory of THIS engine's device: a host pointer or another
@@ -971,7 +977,7 @@ void mi_engine_destroy(mi_engine* e) {
         &e->arena_macros, &e->slot_need,
         &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->mmats, &e->mphi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,
-        &e->ll_sum, &e->g_sum, &e->status, &e->ready, &e->aa_model, &e->aa_matP, &e->aa_matPT,
+        &e->ll_sum, &e->g_sum, &e->status, &e->ready, &e->weibull_x, &e->aa_model, &e->aa_matP, &e->aa_matPT,
         &e->aa_tipP, &e->aa_tipPQ, &e->aa_exp_cum, &e->aa_exp_loc, &e->aa_root_val,
         &e->aa_root_exp, &e->aa_root_scale, &e->in_index, &e->in_weights, &e->out_reduced,
         &e->red_ll, &e->red_g, &e->red_site, &e->red_sort,

@@ -137,6 +137,7 @@ struct mi_engine {
   // per-call workspace
   Buffer arena_macros, slot_need, tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, mmats, mphi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
       ll_sum, g_sum, status;
+  Buffer weibull_x;  // [K][2] {x_k, log x_k} of the Weibull quantiles (once per engine)
   Buffer ready;  // [T] hand-off words of the one-launch small call (zero between calls)
   bool fused_setup = true;  // MI_PHYLO_FUSED_SETUP=0: always the four-launch sequence
   // 20-state path: the engine's eigensystem and the streamed workspace (the arena is `plv`)

@@ -159,6 +159,7 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   ms.params = d.params;
   ms.models = e->models.as<DevModel>();
   ms.status = e->status.as<int32_t>();
+  ms.weibull_x = e->weibull_x.as<double>();
   const bool prof = e->prof_used < e->prof_capacity;
   const bool marks = prof && e->prof_phases;
   PROF_MARK(e, marks, 0, s);

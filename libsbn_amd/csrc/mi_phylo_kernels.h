@@ -54,6 +54,7 @@ struct ModelSetupArgs {
   const double* params;  // [T][param_count]
   DevModel* models;      // [T * models_per_tree]
   int32_t* status;
+  const double* weibull_x;  // [K][2]: {x_k, log x_k} of the Weibull quantiles (launch_weibull_table), or nullptr
 };
 
 struct TransitionArgs {
@@ -166,6 +167,7 @@ struct FinalizeArgs {
 // tree schedules (one wave per tree) and model instances (one thread each) in one launch
 void launch_setup(const TreeSetupArgs& a, const ModelSetupArgs& ms, hipStream_t s);
 void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s);  // trees only
+void launch_weibull_table(int K, double* table, hipStream_t s);  // once per engine: ModelSetupArgs::weibull_x
 void launch_transition(const TransitionArgs& a, hipStream_t s);
 // On-chip (LDS-resident) log-likelihood: evaluations [eval_offset, eval_offset+count)
 void launch_loglik(const LikArgs& a, int count, bool rescale, int max_slots, hipStream_t s);

@@ -581,12 +581,22 @@ __device__ inline void subst_model_into(const ModelSetupArgs& a, const int t, co
 // site_model.cpp:37-62 in two steps shared by the one-thread and the one-wave form below (explicitly
 // rounded operations: both forms must produce the same bits whatever the compiler would
 // contract around them): rate and d rate / d shape of category i before the normalisation ...
+// (table: {x_i, log x_i} per category, x_i = -log(1 - quantile_i) -- they depend on the
+// category count only and are computed once per engine by weibull_table_kernel with these very
+// expressions, which leaves the power as the one transcendental of a category; null: inline)
 __device__ __forceinline__ void weibull_category(const int K, const double shape, const int i, double& r,
-                                                 double& du) {
-  const double quantile = (2.0 * i + 1.0) / (2.0 * K);
-  const double x = -log(1.0 - quantile);
+                                                 double& du, const double* table = nullptr) {
+  double x, lx;
+  if (table) {
+    x = table[2 * i];
+    lx = table[2 * i + 1];
+  } else {
+    const double quantile = (2.0 * i + 1.0) / (2.0 * K);
+    x = -log(1.0 - quantile);
+    lx = log(x);
+  }
   r = pow(x, 1.0 / shape);
-  du = __ddiv_rn(__dmul_rn(-r, log(x)), __dmul_rn(shape, shape));
+  du = __ddiv_rn(__dmul_rn(-r, lx), __dmul_rn(shape, shape));
 }
 // ... and the normalisation by the mean rate
 __device__ __forceinline__ void weibull_normalise(const double mean_rate, const double mean_deriv, double& r,
@@ -607,7 +617,7 @@ __device__ inline void site_model_into(const ModelSetupArgs& a, const double* ro
   double mean_rate = 0, mean_deriv = 0;
   for (int i = 0; i < K; i++) {
     double r, du;
-    weibull_category(K, shape, i, r, du);
+    weibull_category(K, shape, i, r, du, a.weibull_x);
     m.cat_rate[i] = r;
     m.cat_drate[i] = du;
     mean_rate = __dadd_rn(mean_rate, r);
@@ -667,7 +677,7 @@ __device__ __forceinline__ void model_setup_wave(const ModelSetupArgs& a, const 
   const int K = a.K;
   const double shape = row[a.shape_off];
   double r = 0, du = 0;
-  if (lane < K) weibull_category(K, shape, lane, r, du);
+  if (lane < K) weibull_category(K, shape, lane, r, du, a.weibull_x);
   auto lane_value = [](double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
                             __builtin_amdgcn_readlane(__double2loint(x), l));

@@ -119,7 +119,7 @@ constexpr int kReadySpins = 1 << 20;
 template <bool RESCALE, bool FUSED>
 __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, const int block,
                                               const int32_t* ready) {
-  static_assert(R >= 1 && R <= 3, "tip bytes of a (macro, position) pair come as R words");
+  static_assert(R >= 1 && R <= 4, "a tip word holds one byte per register");
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
   // one tile per wave (several tiles per wave, as the second generation has them, were
@@ -397,10 +397,12 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
           const int m = j / 6, pos = j - m * 6;
           char* dst = lds0 + (unsigned)m * kTStride + (unsigned)pos * 4u;
 #pragma unroll
-          for (int c = 0; c < 4; c++)
-            *reinterpret_cast<uint32_t*>(dst + c * kTwCol) =
-                ((w.d[0] >> (8 * c)) & 0xffu) | (R > 1 ? ((w.d[R > 1 ? 1 : 0] >> (8 * c)) & 0xffu) << 8 : 0u) |
-                (R > 2 ? ((w.d[R - 1] >> (8 * c)) & 0xffu) << 16 : 0u);
+          for (int c = 0; c < 4; c++) {
+            uint32_t word = 0;  // byte r: the code of column c in register r
+#pragma unroll
+            for (int r = 0; r < R; r++) word |= ((w.d[r] >> (8 * c)) & 0xffu) << (8 * r);
+            *reinterpret_cast<uint32_t*>(dst + c * kTwCol) = word;
+          }
         }
       }
     } else {

@@ -769,7 +769,12 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   // generation no longer loses waves per CU at K < 3, and was measured again: fluA x 1000
   // 0.344 ms against the first generation's 0.327, one fluA tree 0.100 against 0.103.  The
   // batch is what counts: K < 3 stays with the first generation.)
-  e->walk2 = e->K >= 3 &&
+  // Round 5: that comparison was made on fluA (69 taxa: the arena variants).  With the stored
+  // vectors in LDS the second generation wins for one and two categories as well -- DS1 x 1000,
+  // constant site model: 0.270 against 0.331 ms, two categories 0.467 against 0.585 -- so K < 3
+  // engines whose trees keep their vectors in LDS on a large batch take it too; the arena
+  // shapes (more than ~31 taxa) stay with the first generation.
+  e->walk2 = (e->K >= 3 || !gradient_walk_use_arena(e->n, e->K, false, false)) &&
              gradient_walk_waves_per_cu(e->n, e->K) >= gradient_mfma_waves_per_cu(e->n, e->K);
   if (const char* env = getenv("MI_PHYLO_GRADIENT_WALK")) {
     e->walk2 = std::string(env) != "v1";

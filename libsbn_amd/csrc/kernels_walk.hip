@@ -1054,7 +1054,8 @@ void launch_gradient_walk(const LikArgs& a_in, int count, bool rescale, bool sub
 }
 
 bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves) {
-  static const int forced = [] {
+  // (read at every call: tools/audit_paths.py switches it between engines of one process)
+  const int forced = [] {
     const char* env = getenv("MI_PHYLO_GRADIENT_STORE");
     if (!env) return 0;
     return std::string(env) == "arena" ? 2 : (std::string(env) == "lds" ? 1 : 0);
@@ -1064,7 +1065,11 @@ bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t wave
   if (forced == 1 && lds_fits) return false;
   if (forced == 2) return true;
   if (lds_fits && arena_single_launch(lds_all, waves)) return false;  // a call of a few trees
-  return !lds_fits || (160 * 1024) / lds_all < 7;
+  // (round 5, tools/audit_paths.py with the store forced either way: with five and six waves per
+  // CU the LDS store still wins -- 31 taxa x 1000 patterns x 4 categories 1.29 against 1.54 ms per
+  // 1000 trees, 36 x 200: 0.41 / 0.46, one category 0.36 / 0.41 -- and from four waves down the
+  // arena does; the round-1 cross-over "fewer than seven" dated from the first generation)
+  return !lds_fits || (160 * 1024) / lds_all < 5;
 }
 bool gradient_walk_fits(int n, int K, bool rescale) {
   if (n < 3 || K > kMaxCategories) return false;

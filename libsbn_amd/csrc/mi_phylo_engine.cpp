@@ -774,8 +774,16 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   // constant site model: 0.270 against 0.331 ms, two categories 0.467 against 0.585 -- so K < 3
   // engines whose trees keep their vectors in LDS on a large batch take it too; the arena
   // shapes (more than ~31 taxa) stay with the first generation.
-  e->walk2 = (e->K >= 3 || !gradient_walk_use_arena(e->n, e->K, false, false)) &&
-             gradient_walk_waves_per_cu(e->n, e->K) >= gradient_mfma_waves_per_cu(e->n, e->K);
+  // ... and so do the arena shapes with eight pattern tiles per tree and more (tools/audit_paths.py,
+  // 1000 trees x 1000 patterns: 31 taxa 0.474 -> 0.409 ms, 45: 0.661 -> 0.577, 64: 0.918 -> 0.800,
+  // 100: 1.558 -> 1.280 with one category; 9-42 % with two): its waves take several tiles of a tree
+  // in a row.  With a handful of tiles per tree the first generation keeps a 0-5 % edge (fluA:
+  // five tiles, 0.321 against 0.335 ms per 1000 trees).
+  // (The waves-per-CU comparison of the two generations that used to gate this is gone: at 31
+  // taxa and two categories the second generation fits fewer waves and still takes 0.646
+  // against 0.917 ms.)
+  e->walk2 = e->K >= 3 || !gradient_walk_use_arena(e->n, e->K, false, false) ||
+             gradient_mfma_tiles(e->P, e->K) >= 8;
   if (const char* env = getenv("MI_PHYLO_GRADIENT_WALK")) {
     e->walk2 = std::string(env) != "v1";
     e->walk3 = std::string(env) != "v1" && std::string(env) != "v2";

@@ -491,7 +491,7 @@ int loglik_mfma_tiles(int P, int K) {
 bool loglik_mfma_supported(const LikArgs& a, bool rescale) {
   // The matrix-core log-likelihood kernel needs tips in state-mask form (K > 4: the
   // categories are walked four at a time).  MI_PHYLO_LOGLIK_PATH=valu|mfma forces one of the two kernels.
-  static const int forced = [] {
+  const int forced = [] {  // (read per call: tools/audit_paths.py switches it between engines)
     const char* env = getenv("MI_PHYLO_LOGLIK_PATH");
     if (!env) return 0;
     return std::string(env) == "mfma" ? 2 : (std::string(env) == "valu" ? 1 : 0);

@@ -563,6 +563,13 @@ int check_status(mi_engine* e, hipStream_t s) {
   int32_t st[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(st, e->status.ptr, sizeof st, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (st[0] == kFusedTimeout) {
+    // the one-launch call's walk waves waited in vain (workgroups not dispatched in id order?):
+    // this engine takes the four-launch sequence from now on, so that a retry succeeds; its
+    // hand-off words are cleared (waves that gave up left them set)
+    e->fused_setup = false;
+    if (e->ready.ptr) HIP_TRY(hipMemsetAsync(e->ready.ptr, 0, e->ready.bytes, s));
+  }
   if (st[0] != 0) {  // reported once: the first error since the last check
     HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, s));
     HIP_TRY(hipStreamSynchronize(s));

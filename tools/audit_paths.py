@@ -14,7 +14,7 @@ dev = torch.device("cuda", 0)
 rng = np.random.default_rng(11)
 
 def time_cfg(n, P, K, T, env):
-    for k in ("MI_PHYLO_GRADIENT_WALK", "MI_PHYLO_GRADIENT_STORE"):
+    for k in ("MI_PHYLO_GRADIENT_WALK", "MI_PHYLO_GRADIENT_STORE", "MI_PHYLO_LOGLIK_PATH"):
         os.environ.pop(k, None)
     os.environ.update(env)
     site = "constant" if K == 1 else f"weibull+{K}"
@@ -38,8 +38,11 @@ def time_cfg(n, P, K, T, env):
     torch.cuda.set_stream(cs)
     st = cs.cuda_stream
     def step():
-        eng.gradients_device(st, T, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d_ll.data_ptr(), d_g.data_ptr(),
-                             d_s.data_ptr() if K > 1 else None, None)
+        if os.environ.get("AUDIT_MODE") == "loglik":
+            eng.log_likelihoods_device(st, T, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d_ll.data_ptr())
+        else:
+            eng.gradients_device(st, T, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d_ll.data_ptr(), d_g.data_ptr(),
+                                 d_s.data_ptr() if K > 1 else None, None)
     try:
         for _ in range(2): step()
         eng.check_status(st); torch.cuda.synchronize()
@@ -62,11 +65,15 @@ grid = list(itertools.product(sizes, [200, 1000] if not quick else [300], [1, 2,
 for n, P, K, T in grid:
     base, bpath = time_cfg(n, P, K, T, {})
     best, bestname, bestpath = base, "default", bpath
-    for walk, store in itertools.product(("v1", "v2", "v3"), ("lds", "arena")):
-        env = {"MI_PHYLO_GRADIENT_WALK": walk, "MI_PHYLO_GRADIENT_STORE": store}
+    if os.environ.get("AUDIT_MODE") == "loglik":
+        variants = [("valu", {"MI_PHYLO_LOGLIK_PATH": "valu"}), ("mfma", {"MI_PHYLO_LOGLIK_PATH": "mfma"})]
+    else:
+        variants = [(f"{walk}/{store}", {"MI_PHYLO_GRADIENT_WALK": walk, "MI_PHYLO_GRADIENT_STORE": store})
+                    for walk, store in itertools.product(("v1", "v2", "v3"), ("lds", "arena"))]
+    for vname, env in variants:
         ms, path = time_cfg(n, P, K, T, env)
         if ms is not None and ms < best:
-            best, bestname, bestpath = ms, f"{walk}/{store}", path
+            best, bestname, bestpath = ms, vname, path
     flag = "  <== default loses %.0f %%" % (100 * (base / best - 1)) if best < base * 0.97 else ""
     print("n=%3d P=%4d K=%d T=%4d default %.4f ms [%s] best %.4f ms (%s: %s)%s" % (
         n, P, K, T, base, bpath.split(" ll0")[0], best, bestname, bestpath.split(" ll0")[0], flag), flush=True)

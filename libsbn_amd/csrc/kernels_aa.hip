@@ -918,7 +918,11 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
     // columns of transition matrices is far from underflow, powers of two are exact, so the
     // result is bit-identical; a third of the nodes of a random tree, -2.3 % kernel time.  The
     // gradient form is bound by its stores and keeps every node's exponent.)
+#ifdef AA_ABL_NO_RESCALE  // (timing experiment: wrong results for deep trees)
+    if (true) {
+#else
     if (!GRAD && ch0 < n && ch1 < n) {
+#endif
 #pragma unroll
       for (int u = 0; u < M; u++) {
 #pragma unroll

@@ -672,7 +672,7 @@ __device__ __forceinline__ void wait_all_vm() { asm volatile("s_waitcnt vmcnt(0)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int kPreWaves = 4, kPreThreads = 64 * kPreWaves;
 template <int M, bool GRAD>
-__global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkArgs a) {
+__global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_kernel(AaWalkArgs a) {
   __shared__ SchedEntry sched_lds[kSchedWindow];
   __shared__ double ops_lds[2][2][kAaPack];  // [buffer][child][640]: pack, or tip table (420)
   // Log-likelihood form (round 5): the TOP of the wave's stack of kept
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
   const int wgs = (blocks + kPostWaves - 1) / kPostWaves;  // workgroups per (evaluation, category)
   const AaUnit un = aa_unit(wgs, a.evals * a.K);
   if (!un.valid) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, wave = sgpr(tid >> 6), lane = tid & 63, g = lane >> 4, j = lane & 15;
   const int el = un.ec / a.K, cat = un.ec - el * a.K;
   const int blk_raw = un.blk * kPostWaves + wave;
   const bool active = blk_raw < blocks;         // (a padding wave joins the staging and barriers only)
@@ -760,6 +760,14 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
   }
   stage0(ch0, ch1, xc);
   stage(ch0, ch1, 0);
+  // (the compiler must see the first visit's tip states consumed HERE: it does not know what
+  // wait_all_vm waits for, and with these loads still pending in its books at the loop's head
+  // it puts a vmcnt(0) in front of the first use of xc in the loop -- behind the requests for
+  // the next visit's operands, i.e. a full memory round trip at the start of every visit)
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int u = 0; u < M; u++) asm volatile("" : "+v"(xc[c][u]));
   wait_all_vm();
   lds_barrier();
 
@@ -780,7 +788,20 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
   const int RS = GRAD ? 0 : sgpr(a.ring_slots);
   double* const ring = ring_lds + (size_t)sgpr(wave) * RS * kRingEntry;
   int lo = RS > 0 ? 0 : 0x7fffffff;
-  auto ring_entry = [&](int slot) { return ring + (slot % max(RS, 1)) * kRingEntry; };
+  // (ring sizes are powers of two: launch_aa_post)
+  auto ring_entry = [&](int slot) { return ring + (slot & (RS - 1)) * kRingEntry; };
+#ifdef AA_STAMPS  // (timing experiment: where a wave's visit goes, in shader clocks)
+  unsigned long long stamp_acc[5] = {0, 0, 0, 0, 0};
+  unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#define AA_STAMP(k)                                                  \
+  {                                                                  \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+    stamp_acc[k] += now_ - stamp_t;                                  \
+    stamp_t = now_;                                                  \
+  }
+#else
+#define AA_STAMP(k)
+#endif
   for (int i = 0; i < count; i++) {
     const int buf = i & 1;
     int nv = -1, next_c0 = -1, next_c1 = -1, nslots = 0;
@@ -794,73 +815,60 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
       stage(next_c0, next_c1, buf ^ 1);  // the next visit's shared operands: global -> LDS
       stage0(next_c0, next_c1, xn);
     }
-    double S[2][M][5];
-    int Ec[2][M];
+    AA_STAMP(0);  // requests for the next visit issued
+    if constexpr (GRAD) {
+      // Gradient form: every internal vector goes to the arena, by node, for the pre-order
+      // kernel (P L of the child taken from registers, L of a node consumed later: see
+      // aa_post_kernel), and every node keeps its own exponent.
+      double S[2][M][5];
+      int Ec[2][M];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-      const int ch = c ? ch1 : ch0;
-      const double* shared = ops_lds[buf][c];
-      if (ch < n) {
-#pragma unroll
-        for (int u = 0; u < M; u++) {
-          Ec[c][u] = 0;
-          const double* col = shared + xc[c][u] * kAa + g;
-#pragma unroll
-          for (int t = 0; t < 5; t++) S[c][u][t] = col[4 * t];
-        }
-      } else {
-        double A[10], L[M][5];
-        if (ch == prev) {
+      for (int c = 0; c < 2; c++) {
+        const int ch = c ? ch1 : ch0;
+        const double* shared = ops_lds[buf][c];
+        if (ch < n) {
 #pragma unroll
           for (int u = 0; u < M; u++) {
-            Ec[c][u] = E[u];
+            Ec[c][u] = 0;
+            const double* col = shared + xc[c][u] * kAa + g;
 #pragma unroll
-            for (int t = 0; t < 5; t++) L[u][t] = R[u][t];
+            for (int t = 0; t < 5; t++) S[c][u][t] = col[4 * t];
           }
         } else {
-          const int idx = GRAD ? ch - n : ((slots >> (8 + 8 * c)) & 0xff);
-          if (!GRAD && idx >= lo) {  // (wave-uniform) in the ring
-            const double* src = ring_entry(idx);
-            load_tiles<M>(src, lane, L);
-            const int* ex = reinterpret_cast<const int*>(src + M * kAaTileDoubles);
+          double A[10], L[M][5];
+          if (ch == prev) {
 #pragma unroll
-            for (int u = 0; u < M; u++) Ec[c][u] = ex[u * 16 + j];
+            for (int u = 0; u < M; u++) {
+              Ec[c][u] = E[u];
+#pragma unroll
+              for (int t = 0; t < 5; t++) L[u][t] = R[u][t];
+            }
           } else {
+            const int idx = ch - n;
             load_tiles<M>(arena + idx * arena_stride, lane, L);
 #pragma unroll
             for (int u = 0; u < M; u++) Ec[c][u] = exp_cum[idx * exp_stride + u * 16 + j];
           }
+#pragma unroll
+          for (int r = 0; r < 10; r++) A[r] = shared[r * 64 + lane];
+          mat_apply<M>(A, L, S[c]);
         }
-#pragma unroll
-        for (int r = 0; r < 10; r++) A[r] = shared[r * 64 + lane];
-        mat_apply<M>(A, L, S[c]);
       }
-    }
-    // (log-likelihood form: the product first -- it consumes, i.e. waits for, everything this
-    // visit loaded; gradient form: after the stores, which may read S, to save registers)
-    double Tn[M][5];
-    auto product = [&]() {
+      AA_STAMP(1);
+      // the deferred stores of the previous visit (its vector is still in R); before them the
+      // visit's one wait for the DMA of the next visit's operands (the children's exponents are
+      // consumed here so that no later use makes the compiler wait after the stores)
+      int Es[M];
 #pragma unroll
-      for (int u = 0; u < M; u++)
-#pragma unroll
-        for (int t = 0; t < 5; t++) Tn[u][t] = S[0][u][t] * S[1][u][t];
-    };
-    if (!GRAD) product();
-    // the deferred stores of the previous visit (its vector is still in R); before them the
-    // visit's one wait for the DMA of the next visit's operands (the children's exponents are
-    // consumed here so that no later use makes the compiler wait after the stores)
-    int Es[M];
-#pragma unroll
-    for (int u = 0; u < M; u++) {
-      Es[u] = Ec[0][u] + Ec[1][u];
-      asm volatile("" : "+v"(Es[u]));
-      asm volatile("" : "+v"(xn[0][u]));  // (likewise the next visit's tip states)
-      asm volatile("" : "+v"(xn[1][u]));
-    }
-    wait_all_vm();
-    if (prev >= 0 && active) {
-      if (GRAD) {
-        // (P L of the child taken from registers, L of a node consumed later: see aa_post_kernel)
+      for (int u = 0; u < M; u++) {
+        Es[u] = Ec[0][u] + Ec[1][u];
+        asm volatile("" : "+v"(Es[u]));
+        asm volatile("" : "+v"(xn[0][u]));  // (likewise the next visit's tip states)
+        asm volatile("" : "+v"(xn[1][u]));
+      }
+      wait_all_vm();
+      AA_STAMP(2);
+      if (prev >= 0 && active) {
         double* dstp = arena + (size_t)(prev - n) * arena_stride;
         if (prev == ch0) store_tiles_async<M>(dstp, lane, S[0]);
         else if (prev == ch1) store_tiles_async<M>(dstp, lane, S[1]);
@@ -872,81 +880,202 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
             store_async(exp_cum + (size_t)(prev - n) * exp_stride, u * 16 + j, E[u]);
           }
         }
-      } else if (prev != ch0 && prev != ch1) {
-        const int dst = prev_slots & 0xff;
-        if (RS > 0) {
-          if (dst < lo) lo = dst;  // (the stack has unwound below the ring: it starts anew here)
-          if (dst - lo >= RS) {
-            // the ring is full: its oldest entry goes to its arena slot
-            const double* old = ring_entry(lo);
-            double Lo[M][5];
-            load_tiles<M>(old, lane, Lo);
-            const int* ex = reinterpret_cast<const int*>(old + M * kAaTileDoubles);
-            int eo[M];
-#pragma unroll
-            for (int u = 0; u < M; u++) eo[u] = ex[u * 16 + j];
-            const int lo_s = sgpr(lo);
-            store_tiles_async<M>(sgpr_ptr(arena + lo_s * arena_stride), lane, Lo);
-            if (g == 0) {
-              int32_t* eb = sgpr_ptr(exp_cum + lo_s * exp_stride);
-#pragma unroll
-              for (int u = 0; u < M; u++) store_async(eb, u * 16 + j, eo[u]);
-            }
-            lo = lo_s + 1;
-          }
-          double* dstp = ring_entry(dst);
-#pragma unroll
-          for (int u = 0; u < M; u++)
-#pragma unroll
-            for (int t = 0; t < 5; t++) dstp[u * kAaTileDoubles + t * 64 + lane] = R[u][t];
-          if (g == 0) {
-            int* ex = reinterpret_cast<int*>(dstp + M * kAaTileDoubles);
-#pragma unroll
-            for (int u = 0; u < M; u++) ex[u * 16 + j] = E[u];
-          }
-        } else {
-          store_tiles_async<M>(arena + dst * arena_stride, lane, R);
-          if (g == 0) {
-#pragma unroll
-            for (int u = 0; u < M; u++) store_async(exp_cum + dst * exp_stride, u * 16 + j, E[u]);
-          }
-        }
       }
-    }
-    if (GRAD) product();
-    // (log-likelihood form: a node with two tip children is not rescaled -- the product of two
-    // columns of transition matrices is far from underflow, powers of two are exact, so the
-    // result is bit-identical; a third of the nodes of a random tree, -2.3 % kernel time.  The
-    // gradient form is bound by its stores and keeps every node's exponent.)
-#ifdef AA_ABL_NO_RESCALE  // (timing experiment: wrong results for deep trees)
-    if (true) {
-#else
-    if (!GRAD && ch0 < n && ch1 < n) {
-#endif
+      // (the product after the stores, which may read S: fewer registers)
 #pragma unroll
       for (int u = 0; u < M; u++) {
+        double Tn[5];
 #pragma unroll
-        for (int t = 0; t < 5; t++) R[u][t] = Tn[u][t];
-        eloc[u] = 0;
-        E[u] = Es[u];
+        for (int t = 0; t < 5; t++) Tn[t] = S[0][u][t] * S[1][u][t];
+        // column sum over the 20 states: this lane's five rows with vector adds, then ONE product
+        // with a ones matrix for the four row groups (only the exponent of the sum is used)
+        const double part = ((Tn[0] + Tn[1]) + (Tn[2] + Tn[3])) + Tn[4];
+        const double cs = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, part, 0.0, 0, 0, 0);
+        const int e = cs > 0.0 ? __builtin_amdgcn_frexp_exp(cs) - 1 : 0;
+#pragma unroll
+        for (int t = 0; t < 5; t++) R[u][t] = ldexp(Tn[t], -e);
+        eloc[u] = e;
+        E[u] = Es[u] + e;
       }
-    } else
+    } else {
+      // Log-likelihood form (round 5).  In a post-order over the internal nodes the node visited
+      // just before v is a child of v unless both children of v are tips (the last node a
+      // depth-first walk leaves before v is the root of the subtree it finished last).  A visit
+      // is therefore one of two kinds, told apart by a scalar compare:
+      //   (T) two tips: the previous visit's vector, still in R, is not consumed here and is
+      //       PUSHED first (to the ring, or to its arena slot); the new vector is the product of
+      //       two table columns, written over it, and is not rescaled (far from underflow; powers
+      //       of two are exact, so the result is bit-identical -- a third of the nodes of a
+      //       random tree);
+      //   (P) one child is the previous visit's node and is multiplied where it lies, in R; the
+      //       other child is a tip or the top of the stack (ring, else arena).
+      // The element-wise product of the two children's vectors commutes bit for bit, so the
+      // code is written for "the previous node" and "the other child" instead of child 0 and
+      // child 1: no source of a vector has to be merged into common registers (the merged form
+      // copied R for every visit: 12 64-bit moves, on the one pipe the FP64 MFMAs also occupy).
+      const bool two_tips = ch0 < n && ch1 < n;
+      if (two_tips) {
+        if (prev >= 0 && active) {
+          const int dst = prev_slots & 0xff;
+          if (RS > 0) {
+            if (dst < lo) lo = dst;  // (the stack has unwound below the ring: it starts anew here)
+            if (dst - lo >= RS) {
+              // the ring is full: its oldest entry goes to its arena slot
+              const double* old = ring_entry(lo);
+              double Lo[M][5];
+              load_tiles<M>(old, lane, Lo);
+              const int* ex = reinterpret_cast<const int*>(old + M * kAaTileDoubles);
+              int eo[M];
 #pragma unroll
-    for (int u = 0; u < M; u++) {
-      // column sum over the 20 states: this lane's five rows with vector adds, then ONE product
-      // with a ones matrix for the four row groups (only the exponent of the sum is used)
-      const double part = ((Tn[u][0] + Tn[u][1]) + (Tn[u][2] + Tn[u][3])) + Tn[u][4];
-      const double cs = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, part, 0.0, 0, 0, 0);
-      const int e = cs > 0.0 ? __builtin_amdgcn_frexp_exp(cs) - 1 : 0;
+              for (int u = 0; u < M; u++) eo[u] = ex[u * 16 + j];
+              store_tiles_async<M>(sgpr_ptr(arena + lo * arena_stride), lane, Lo);
+              if (g == 0) {
+                int32_t* eb = sgpr_ptr(exp_cum + lo * exp_stride);
 #pragma unroll
-      for (int t = 0; t < 5; t++) R[u][t] = ldexp(Tn[u][t], -e);
-      eloc[u] = e;
-      E[u] = Es[u] + e;
+                for (int u = 0; u < M; u++) store_async(eb, u * 16 + j, eo[u]);
+              }
+              lo = lo + 1;
+            }
+            double* dstp = ring_entry(dst);
+#pragma unroll
+            for (int u = 0; u < M; u++)
+#pragma unroll
+              for (int t = 0; t < 5; t++) dstp[u * kAaTileDoubles + t * 64 + lane] = R[u][t];
+            if (g == 0) {
+              int* ex = reinterpret_cast<int*>(dstp + M * kAaTileDoubles);
+#pragma unroll
+              for (int u = 0; u < M; u++) ex[u * 16 + j] = E[u];
+            }
+          }
+        }
+        double Tn[M][5];
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+          const double* col0 = ops_lds[buf][0] + xc[0][u] * kAa + g;
+          const double* col1 = ops_lds[buf][1] + xc[1][u] * kAa + g;
+#pragma unroll
+          for (int t = 0; t < 5; t++) Tn[u][t] = col0[4 * t] * col1[4 * t];
+        }
+        if (RS == 0) {
+          // no ring (small launches): the push is a store to the arena, issued AFTER the visit's
+          // wait so that it has the whole next visit to be acknowledged
+#pragma unroll
+          for (int u = 0; u < M; u++) {
+            asm volatile("" : "+v"(xn[0][u]));
+            asm volatile("" : "+v"(xn[1][u]));
+          }
+          wait_all_vm();
+          if (prev >= 0 && active) {
+            const int dst = prev_slots & 0xff;
+            store_tiles_async<M>(arena + dst * arena_stride, lane, R);
+            if (g == 0) {
+#pragma unroll
+              for (int u = 0; u < M; u++) store_async(exp_cum + dst * exp_stride, u * 16 + j, E[u]);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+#pragma unroll
+          for (int t = 0; t < 5; t++) R[u][t] = Tn[u][t];
+          E[u] = 0;
+        }
+      } else {
+        const int cb = ch1 == prev ? 0 : 1;  // the child that is NOT the previous visit's node
+        const int chb = cb ? ch1 : ch0;
+        const double* ops_a = ops_lds[buf][cb ^ 1];
+        const double* ops_b = ops_lds[buf][cb];
+        double SA[M][5], SB[M][5];
+        int Es[M];
+        {
+          double A[10];
+#pragma unroll
+          for (int r = 0; r < 10; r++) A[r] = ops_a[r * 64 + lane];
+          mat_apply<M>(A, R, SA);
+        }
+        if (chb < n) {
+#pragma unroll
+          for (int u = 0; u < M; u++) {
+            const int x = cb ? xc[1][u] : xc[0][u];
+            const double* col = ops_b + x * kAa + g;
+#pragma unroll
+            for (int t = 0; t < 5; t++) SB[u][t] = col[4 * t];
+            Es[u] = E[u];
+          }
+        } else {
+          const int idx = (slots >> (8 + 8 * cb)) & 0xff;
+          double A[10], L[M][5];
+          int Eb[M];
+          if (idx >= lo) {  // in the ring
+            const double* src = ring_entry(idx);
+            load_tiles<M>(src, lane, L);
+            const int* ex = reinterpret_cast<const int*>(src + M * kAaTileDoubles);
+#pragma unroll
+            for (int u = 0; u < M; u++) Eb[u] = ex[u * 16 + j];
+          } else {
+            load_tiles<M>(arena + idx * arena_stride, lane, L);
+#pragma unroll
+            for (int u = 0; u < M; u++) Eb[u] = exp_cum[idx * exp_stride + u * 16 + j];
+            // (the compiler's wait for these loads belongs in THIS branch: placed after the merge
+            // with the ring source it would also wait -- vmcnt counts in order -- for the next
+            // visit's operands, requested above, on every visit)
+#pragma unroll
+            for (int u = 0; u < M; u++) {
+              asm volatile("" : "+v"(Eb[u]));
+#pragma unroll
+              for (int t = 0; t < 5; t++) asm volatile("" : "+v"(L[u][t]));
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 10; r++) A[r] = ops_b[r * 64 + lane];
+          mat_apply<M>(A, L, SB);
+#pragma unroll
+          for (int u = 0; u < M; u++) Es[u] = E[u] + Eb[u];
+        }
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+          double Tn[5];
+#pragma unroll
+          for (int t = 0; t < 5; t++) Tn[t] = SA[u][t] * SB[u][t];
+          // column sum over the 20 states: this lane's five rows with vector adds, then ONE
+          // product with a ones matrix for the four row groups (only the exponent of the sum is used)
+          const double part = ((Tn[0] + Tn[1]) + (Tn[2] + Tn[3])) + Tn[4];
+          const double cs = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, part, 0.0, 0, 0, 0);
+          const int e = cs > 0.0 ? __builtin_amdgcn_frexp_exp(cs) - 1 : 0;
+#pragma unroll
+          for (int t = 0; t < 5; t++) R[u][t] = ldexp(Tn[t], -e);
+          E[u] = Es[u] + e;
+        }
+      }
+#ifdef AA_STAMPS
+#pragma unroll
+      for (int u = 0; u < M; u++)
+#pragma unroll
+        for (int t = 0; t < 5; t++) asm volatile("" : "+v"(R[u][t]));
+#endif
+      AA_STAMP(1);  // the visit's work: push or products, rescaling
+      // the visit's one wait, for the next visit's operands (its tip states are consumed here:
+      // the compiler's own wait for them then sits here too)
+#pragma unroll
+      for (int u = 0; u < M; u++) {
+        asm volatile("" : "+v"(xn[0][u]));
+        asm volatile("" : "+v"(xn[1][u]));
+      }
+      if (!(two_tips && RS == 0)) wait_all_vm();
+      AA_STAMP(2);  // waited for the next visit's operands
     }
     prev_slots = slots;
+#ifdef AA_STAMPS
+#pragma unroll
+    for (int u = 0; u < M; u++)
+#pragma unroll
+      for (int t = 0; t < 5; t++) asm volatile("" : "+v"(R[u][t]));
+#endif
+    AA_STAMP(3);  // pushes (ring or arena) and rescaling
     // the barrier publishes the other buffer (its DMA was waited for above) and tells
     // everyone this visit's buffer has been read
     lds_barrier();
+    AA_STAMP(4);  // barrier
     prev = v;
     v = nv;
     ch0 = next_c0;
@@ -957,6 +1086,12 @@ __global__ __launch_bounds__(64 * kPostWaves, 4) void aa_post_wg_kernel(AaWalkAr
 #pragma unroll
       for (int u = 0; u < M; u++) xc[c][u] = xn[c][u];
   }
+#ifdef AA_STAMPS
+  if (!GRAD && lane == 0 && (blockIdx.x % 4001) == 7)
+    printf("aa_post_wg block %d wave %d visits %d: issue %llu compute %llu wait %llu store+rescale %llu barrier %llu (clocks per visit)\n",
+           (int)blockIdx.x, wave, count, stamp_acc[0] / count, stamp_acc[1] / count, stamp_acc[2] / count,
+           stamp_acc[3] / count, stamp_acc[4] / count);
+#endif
   if (!active) return;
   if (GRAD && g == 0) {  // (the root's vector itself is not needed)
 #pragma unroll
@@ -1544,8 +1679,9 @@ static size_t aa_lds_pad() {
   static const size_t pad = getenv("MI_PHYLO_AA_LDS_PAD") ? strtoul(getenv("MI_PHYLO_AA_LDS_PAD"), nullptr, 10) : 0;
   return pad;
 }
-// tiles a wave of the post-order kernel takes: two (measured, workgroup form: 20.8 ms per 8
-// trees against 24.5 with four); MI_PHYLO_AA_POST_TILES=2|4 overrides.
+// tiles a wave of the post-order kernel takes: two (measured, workgroup form, log-likelihoods
+// of 8 trees: 17.1-17.3 ms against 17.7-17.8 with four at three waves per SIMD; gradients 20.8
+// against 24.5 in round 3); MI_PHYLO_AA_POST_TILES=2|4 overrides.
 static int aa_post_tiles(const AaWalkArgs&) {
   static const int forced = getenv("MI_PHYLO_AA_POST_TILES") ? atoi(getenv("MI_PHYLO_AA_POST_TILES")) : 0;
   return forced == 4 ? 4 : 2;
@@ -1556,18 +1692,18 @@ static bool aa_post_wg() {
   return wg;
 }
 // Entries of the LDS ring a log-likelihood wave keeps the top of its vector stack in
-// (aa_post_wg_kernel); MI_PHYLO_AA_RING=0..4 overrides (0: every kept vector through the arena,
-// the form until round 4).  Measured, eight 512 x 50 000 x 4 trees per launch (tools/bench_aa.py
-// --mode loglik): 18.6 / 18.5 / 21.3 / 32.1 ms with 0 / 1 / 2 / 3 entries -- an entry is 5 KB
-// per wave, 21 KB per workgroup, and every entry costs a workgroup per CU (4 / 3 / 2 / 1 fit):
-// the kernel is bound by issue and latency at these occupancies, not by the 42 + 42 GB of
-// arena traffic the ring removes (67 % of it with one entry, 90 % with two).  ONE entry is the
-// default for launches of three rounds of workgroups and more: the same time with less than
-// half of the HBM traffic; smaller launches (one tree: 1.5 rounds at four per CU, two at
+// (aa_post_wg_kernel); MI_PHYLO_AA_RING=0|1|2|4 overrides (0: every kept vector through the
+// arena, the form until round 4).  Measured, eight 512 x 50 000 x 4 trees per launch
+// (tools/bench_aa.py --mode loglik): 17.7 / 17.1-17.3 / 19.3 ms with 0 / 1 / 2 entries -- an
+// entry is 5 KB per wave, 21 KB per workgroup, and every entry costs a workgroup per CU (4 / 3 /
+// 2 fit): the kernel is bound by the vector pipe, not by the 42 + 42 GB of arena
+// traffic the ring removes (67 % of it with one entry, 90 % with two).  ONE entry is the
+// default for launches of three rounds of workgroups and more: less than a third of the HBM
+// traffic and 2-3 % less time; smaller launches (one tree: 1.5 rounds at four per CU, two at
 // three) keep four workgroups per CU and the arena.
 static int aa_ring_slots(size_t workgroups) {
   static const int forced = getenv("MI_PHYLO_AA_RING") ? atoi(getenv("MI_PHYLO_AA_RING")) : -1;
-  if (forced >= 0 && forced <= 4) return forced;
+  if (forced == 0 || forced == 1 || forced == 2 || forced == 4) return forced;  // (powers of two)
   return workgroups >= 3 * 4 * (size_t)device_compute_units() ? 1 : 0;
 }
 void launch_aa_post(const AaWalkArgs& a_in, hipStream_t s) {

@@ -291,11 +291,11 @@ def test_kernel_forms_agree_bitwise(tmp_path):
         " + [np.atleast_1d(x.gradient['site_model']) for x in g])\n"
         "np.save(sys.argv[1], out)\n")
     outs = []
-    # (round 5: the log-likelihood walk keeps the top 0 / 1 / 2 / 3 entries of its vector stack
+    # (round 5: the log-likelihood walk keeps the top 0 / 1 / 2 / 4 entries of its vector stack
     # in an LDS ring -- MI_PHYLO_AA_RING; a 41-taxon tree's stack reaches three or four entries,
     # so the smaller rings spill to the arena and read it back: same loads, products and stores)
     for post, pre, ring in (("", "", ""), ("wave", "", ""), ("", "wave", ""), ("wave", "wave", ""),
-                            ("", "", "0"), ("", "", "1"), ("", "", "2"), ("", "", "3")):
+                            ("", "", "0"), ("", "", "1"), ("", "", "2"), ("", "", "4")):
         env = dict(os.environ)
         env.pop("MI_PHYLO_AA_POST", None)
         env.pop("MI_PHYLO_AA_PRE", None)

@@ -1347,19 +1347,37 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
 // Pre-order + derivatives, workgroup form (see aa_post_wg_kernel): the three matrices of
 // an internal child (P, P Q, P^T: 15 KB) or the two column tables of a tip child are staged
 // in LDS once per workgroup of four pattern blocks, one visit ahead.
+//
+// Round 5: the top of the stack of pending pre-order vectors in LDS.  A visit hands the
+// pre-order vector of ONE child to the next visit in registers (the child the walk descends
+// into); the other internal child's vector waits until the walk comes back for it -- until
+// round 5 in the arena, by node: written once, read once.  The walk is the post-order
+// schedule backwards, so these pending vectors are a stack with the SAME positions the
+// schedule's slot numbers give the post-order vectors (a push here is a pop there): the
+// child's slot in its parent's entry on the push, the node's own slot on the pop.  Slots
+// [lo, lo + S) of a wave are a ring in LDS (S = a.pre_ring_slots, a power of two; 20 KB per
+// workgroup and entry: one fits beside the operand buffers at the two workgroups per CU the
+// registers allow); a push that finds the ring full spills its oldest entry to the arena, a
+// pop below lo reads the arena as before.  Same values in the same registers: bit-identical.
+// Of the ~171 vectors a random 512-taxon tree parks, 67 % are taken back before another is
+// parked on top: one entry keeps them on the CU.
 // ------------------------------------------------------------------------
+#ifndef AA_PRE_MIN_WGS
+#define AA_PRE_MIN_WGS 2
+#endif
 constexpr int kPreOps = 2 * kAaPack;  // doubles per child in LDS: P | P^T  (tip: tipP | tipPQ)
 template <int M>
-__global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a) {
-  extern __shared__ double pre_lds[];  // [2][2][kPreOps] doubles, Q, then the schedule window
+__global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kernel(AaWalkArgs a) {
+  extern __shared__ double pre_lds[];  // [2][2][kPreOps] doubles, Q, the schedule window, the ring
   double (*ops_lds)[2][kPreOps] = reinterpret_cast<double (*)[2][kPreOps]>(pre_lds);
   double* q_lds = pre_lds + 2 * 2 * kPreOps;
   SchedEntry* sched_lds = reinterpret_cast<SchedEntry*>(q_lds + kAaPack);
+  double* ring_lds = reinterpret_cast<double*>(sched_lds + kSchedWindow);  // [wave][S][M tiles x 320]
   const int blocks = a.tiles / M;
   const int wgs = (blocks + kPreWaves - 1) / kPreWaves;
   const AaUnit un = aa_unit(wgs, a.evals * a.K);
   if (!un.valid) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, wave = sgpr(tid >> 6), lane = tid & 63, g = lane >> 4, j = lane & 15;
   const int el = un.ec / a.K, cat = un.ec - el * a.K;
   const int blk_raw = un.blk * kPreWaves + wave;
   const bool active = blk_raw < blocks;
@@ -1426,13 +1444,22 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
   for (int c = 0; c < 2; c++)
 #pragma unroll
     for (int u = 0; u < M; u++) xc[c][u] = xn[c][u] = kAa;
-  int v, ch[2];
+  int v, ch[2], vslots;
   {
     const SchedEntry e0 = win.at(count - 1);
     v = sgpr(e0.node);
     ch[0] = sgpr(e0.child0);
     ch[1] = sgpr(e0.child1);
+    vslots = sgpr(e0.slots);
   }
+  // the ring of this wave: entries by slot & (RS - 1), the node each entry belongs to (its
+  // arena address, should it be spilled), lo: the first slot that lives in it
+  const int RS = sgpr(a.pre_ring_slots);
+  constexpr int kPreRingEntry = M * kAaTileDoubles;
+  double* const ring = ring_lds + (size_t)wave * RS * kPreRingEntry;
+  int lo = RS > 0 ? 0 : 0x7fffffff;
+  int ring_node[2] = {-1, -1};
+  auto ring_entry = [&](int slot) { return ring + (slot & (RS - 1)) * kPreRingEntry; };
   // Everything a visit reads from global memory -- its children's post-order vectors, its own
   // pre-order vector unless the previous visit hands it over in registers, its exponents, the
   // tip states, the LDS operands -- is requested during the visit BEFORE it, each into the
@@ -1452,14 +1479,20 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
     if (c0 >= n) load_tiles<M>(arena + (size_t)(c0 - n) * arena_stride, lane, L[0]);
     if (c1 >= n) load_tiles<M>(arena + (size_t)(c1 - n) * arena_stride, lane, L[1]);
   };
-  auto fetch_node = [&](int node, bool load_q) {
-    if (load_q) load_tiles<M>(arena + (size_t)(node - n) * arena_stride, lane, q);
+  // (own_slot: the node's stack position; a parked vector that is still in the ring is read
+  // from LDS -- this is called in a visit without pushes: one that parks a vector descends into
+  // the other child, whose vector it keeps in registers)
+  auto fetch_node = [&](int node, bool load_q, int own_slot) {
+    if (load_q) {
+      if (own_slot >= lo) load_tiles<M>(ring_entry(own_slot), lane, q);
+      else load_tiles<M>(arena + (size_t)(node - n) * arena_stride, lane, q);
+    }
 #pragma unroll
     for (int u = 0; u < M; u++) ev[u] = exp_loc[(size_t)(node - n) * exp_stride + u * 16 + j];
   };
   stage(ch[0], ch[1], (count - 1) & 1);
   fetch_children(v, ch[0], ch[1], xc);
-  fetch_node(v, false);
+  fetch_node(v, false, 0);
   {
     const size_t rbase = ((size_t)el * K + cat) * tiles * 16 + p0;
 #pragma unroll
@@ -1474,13 +1507,14 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
 
   for (int i = count - 1; i >= 0; i--) {
     const int buf = i & 1;
-    int next = -1, nc0 = -1, nc1 = -1;
+    int next = -1, nc0 = -1, nc1 = -1, nslots = 0;
     if (i > 0) {
       if (i - 1 < win.base) fill_upto(i - 1);
       const SchedEntry s1 = win.at(i - 1);
       next = sgpr(s1.node);
       nc0 = sgpr(s1.child0);
       nc1 = sgpr(s1.child1);
+      nslots = sgpr(s1.slots);
       stage(nc0, nc1, buf ^ 1);
     }
 #pragma unroll
@@ -1548,7 +1582,7 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
     // q is done with: the next node's (unless this visit computes it below) and its exponents
     const bool keep = i > 0 && (next == ch[0] || next == ch[1]);
     asm volatile("" ::: "memory");
-    if (i > 0) fetch_node(next, !keep);
+    if (i > 0) fetch_node(next, !keep, nslots & 0xff);
     // The visit's one wait: the DMA and the loads for the next visit.  What they loaded is
     // consumed HERE as far as the compiler is concerned, so that it puts its own waits before
     // the stores below and none after them (the stores stay in flight).
@@ -1576,7 +1610,28 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
       double A[10], qc[M][5];
       lds_pack(ops_lds[buf][c] + kAaPack, A);
       mat_apply<M>(A, S[1 - c], qc);
-      if (active) store_tiles_async<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, qc);
+      if (RS > 0) {
+        // parked in the ring, at the child's stack position
+        const int dst = (vslots >> (8 + 8 * c)) & 0xff;
+        if (dst < lo) lo = dst;  // (the stack has unwound below the ring: it starts anew here)
+        if (dst - lo >= RS) {
+          // the ring is full: its oldest entry goes to its node's place in the arena
+          double old[M][5];
+          load_tiles<M>(ring_entry(lo), lane, old);
+          const int old_node = (lo & (RS - 1)) ? ring_node[1] : ring_node[0];
+          if (active) store_tiles_async<M>(sgpr_ptr(arena + (size_t)(old_node - n) * arena_stride), lane, old);
+          lo = lo + 1;
+        }
+        double* dstp = ring_entry(dst);
+#pragma unroll
+        for (int u = 0; u < M; u++)
+#pragma unroll
+          for (int t = 0; t < 5; t++) dstp[u * kAaTileDoubles + t * 64 + lane] = qc[u][t];
+        if (dst & (RS - 1)) ring_node[1] = ch[c];
+        else ring_node[0] = ch[c];
+      } else if (active) {
+        store_tiles_async<M>(arena + (size_t)(ch[c] - n) * arena_stride, lane, qc);
+      }
     }
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -1589,6 +1644,7 @@ __global__ __launch_bounds__(64 * kPreWaves) void aa_pre_wg_kernel(AaWalkArgs a)
     v = next;
     ch[0] = nc0;
     ch[1] = nc1;
+    vslots = nslots;
 #pragma unroll
     for (int u = 0; u < M; u++) {
       xc[0][u] = xn[0][u];
@@ -1751,9 +1807,16 @@ void launch_aa_pre(const AaWalkArgs& a, hipStream_t s) {
   if (wg) {
     const int blocks = a.tiles / kAaPreTiles;
     const dim3 grid(aa_grid((blocks + kPreWaves - 1) / kPreWaves, a.evals * a.K)), block(kPreThreads);
-    const size_t lds = sizeof(double) * (2 * 2 * kPreOps + kAaPack) + sizeof(SchedEntry) * kSchedWindow + aa_lds_pad();
+    // entries of the LDS ring of parked pre-order vectors (aa_pre_wg_kernel): one -- 20 KB per
+    // workgroup beside 49 KB of operand buffers, two workgroups per CU by registers either way;
+    // MI_PHYLO_AA_PRE_RING=0|1|2 overrides (2 costs a workgroup per CU)
+    static const int forced = getenv("MI_PHYLO_AA_PRE_RING") ? atoi(getenv("MI_PHYLO_AA_PRE_RING")) : -1;
+    AaWalkArgs b = a;
+    b.pre_ring_slots = forced == 0 || forced == 1 || forced == 2 ? forced : 1;
+    const size_t lds = sizeof(double) * (2 * 2 * kPreOps + kAaPack) + sizeof(SchedEntry) * kSchedWindow +
+                       sizeof(double) * (size_t)kPreWaves * b.pre_ring_slots * kAaPreTiles * kAaTileDoubles + aa_lds_pad();
     allow_large_lds(reinterpret_cast<const void*>(aa_pre_wg_kernel<kAaPreTiles>), lds);
-    hipLaunchKernelGGL((aa_pre_wg_kernel<kAaPreTiles>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((aa_pre_wg_kernel<kAaPreTiles>), grid, block, lds, s, b);
     return;
   }
   const dim3 grid(aa_grid(a.tiles / kAaPreTiles, a.evals * a.K));

@@ -338,6 +338,7 @@ struct AaWalkArgs {
   int gradient;            // post-order: every internal vector is kept, indexed by node
   int slots;               // log-likelihood only: vectors are kept by schedule slot
   int ring_slots;          // log-likelihood only (set by the launcher): stack entries a wave keeps in LDS
+  int pre_ring_slots;      // pre-order kernel (set by the launcher): parked vectors a wave keeps in LDS
   int ll_stride;           // stride of ll_part per evaluation
   const SchedEntry* sched; // [T][n-1]
   const AaModel* model;

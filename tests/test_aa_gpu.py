@@ -294,19 +294,26 @@ def test_kernel_forms_agree_bitwise(tmp_path):
     # (round 5: the log-likelihood walk keeps the top 0 / 1 / 2 / 4 entries of its vector stack
     # in an LDS ring -- MI_PHYLO_AA_RING; a 41-taxon tree's stack reaches three or four entries,
     # so the smaller rings spill to the arena and read it back: same loads, products and stores)
-    for post, pre, ring in (("", "", ""), ("wave", "", ""), ("", "wave", ""), ("wave", "wave", ""),
-                            ("", "", "0"), ("", "", "1"), ("", "", "2"), ("", "", "4")):
+    # (likewise MI_PHYLO_AA_PRE_RING: the pre-order walk parks the vectors it comes back for in
+    # a ring of 0 / 1 / 2 entries)
+    for post, pre, ring, pre_ring in (("", "", "", ""), ("wave", "", "", ""), ("", "wave", "", ""),
+                                      ("wave", "wave", "", ""), ("", "", "0", ""), ("", "", "1", ""),
+                                      ("", "", "2", ""), ("", "", "4", ""), ("", "", "", "0"),
+                                      ("", "", "", "1"), ("", "", "", "2")):
         env = dict(os.environ)
         env.pop("MI_PHYLO_AA_POST", None)
         env.pop("MI_PHYLO_AA_PRE", None)
         env.pop("MI_PHYLO_AA_RING", None)
+        env.pop("MI_PHYLO_AA_PRE_RING", None)
         if post:
             env["MI_PHYLO_AA_POST"] = post
         if pre:
             env["MI_PHYLO_AA_PRE"] = pre
         if ring:
             env["MI_PHYLO_AA_RING"] = ring
-        out = tmp_path / f"out_{post}_{pre}_{ring}.npy"
+        if pre_ring:
+            env["MI_PHYLO_AA_PRE_RING"] = pre_ring
+        out = tmp_path / f"out_{post}_{pre}_{ring}_{pre_ring}.npy"
         r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True,
                            text=True)
         assert r.returncode == 0, r.stdout + r.stderr

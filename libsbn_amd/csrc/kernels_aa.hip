@@ -1762,13 +1762,19 @@ static int aa_ring_slots(size_t workgroups) {
   if (forced == 0 || forced == 1 || forced == 2 || forced == 4) return forced;  // (powers of two)
   return workgroups >= 3 * 4 * (size_t)device_compute_units() ? 1 : 0;
 }
+// (what launch_aa_post / launch_aa_pre will choose: for the engine's description of a call)
+int aa_post_ring_entries(const AaWalkArgs& a) {
+  if (a.gradient || !aa_post_wg()) return 0;
+  const int blocks = a.tiles / aa_post_tiles(a);
+  return aa_ring_slots(aa_grid((blocks + kPostWaves - 1) / kPostWaves, a.evals * a.K));
+}
 void launch_aa_post(const AaWalkArgs& a_in, hipStream_t s) {
   AaWalkArgs a = a_in;
   const int m = aa_post_tiles(a);
   if (aa_post_wg()) {
     const int blocks = a.tiles / m;
     const dim3 grid(aa_grid((blocks + kPostWaves - 1) / kPostWaves, a.evals * a.K)), block(kPostThreads);
-    a.ring_slots = a.gradient ? 0 : aa_ring_slots((size_t)grid.x * grid.y * grid.z);
+    a.ring_slots = aa_post_ring_entries(a);
     const size_t ring = sizeof(double) * (size_t)kPostWaves * a.ring_slots * m * (kAaTileDoubles + 8);
     const size_t lds = ring + aa_lds_pad();
     if (m == 4) {
@@ -1802,17 +1808,24 @@ void launch_aa_post(const AaWalkArgs& a_in, hipStream_t s) {
 void launch_aa_root(const AaWalkArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(aa_root_kernel, dim3(aa_ll_blocks(a.P), a.evals), dim3(256), 0, s, a);
 }
-void launch_aa_pre(const AaWalkArgs& a, hipStream_t s) {
+static bool aa_pre_wg() {
   static const bool wg = !(getenv("MI_PHYLO_AA_PRE") && std::string(getenv("MI_PHYLO_AA_PRE")) == "wave");
-  if (wg) {
+  return wg;
+}
+// entries of the LDS ring of parked pre-order vectors (aa_pre_wg_kernel): one -- 20 KB per
+// workgroup beside 49 KB of operand buffers, two workgroups per CU by registers either way;
+// MI_PHYLO_AA_PRE_RING=0|1|2 overrides (2 costs a workgroup per CU)
+int aa_pre_ring_entries() {
+  static const int forced = getenv("MI_PHYLO_AA_PRE_RING") ? atoi(getenv("MI_PHYLO_AA_PRE_RING")) : -1;
+  if (!aa_pre_wg()) return 0;
+  return forced == 0 || forced == 1 || forced == 2 ? forced : 1;
+}
+void launch_aa_pre(const AaWalkArgs& a, hipStream_t s) {
+  if (aa_pre_wg()) {
     const int blocks = a.tiles / kAaPreTiles;
     const dim3 grid(aa_grid((blocks + kPreWaves - 1) / kPreWaves, a.evals * a.K)), block(kPreThreads);
-    // entries of the LDS ring of parked pre-order vectors (aa_pre_wg_kernel): one -- 20 KB per
-    // workgroup beside 49 KB of operand buffers, two workgroups per CU by registers either way;
-    // MI_PHYLO_AA_PRE_RING=0|1|2 overrides (2 costs a workgroup per CU)
-    static const int forced = getenv("MI_PHYLO_AA_PRE_RING") ? atoi(getenv("MI_PHYLO_AA_PRE_RING")) : -1;
     AaWalkArgs b = a;
-    b.pre_ring_slots = forced == 0 || forced == 1 || forced == 2 ? forced : 1;
+    b.pre_ring_slots = aa_pre_ring_entries();
     const size_t lds = sizeof(double) * (2 * 2 * kPreOps + kAaPack) + sizeof(SchedEntry) * kSchedWindow +
                        sizeof(double) * (size_t)kPreWaves * b.pre_ring_slots * kAaPreTiles * kAaTileDoubles + aa_lds_pad();
     allow_large_lds(reinterpret_cast<const void*>(aa_pre_wg_kernel<kAaPreTiles>), lds);

@@ -167,6 +167,7 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
 
   if (prof) HIP_TRY(hipEventRecord(prof_event(e, 0), s));
   const int chunk = aa_chunk(e, T, d.gradient);
+  int post_ring = 0;
   e->prof_first_launch_evals = std::min(chunk, T);
   for (int off = 0; off < T; off += chunk) {
     const int evals = std::min(chunk, T - off);
@@ -217,6 +218,7 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     w.ll_sum = e->ll_sum.as<double>();
     w.g_sum = e->g_sum.as<double>();
     PROF_MARK(e, marks && off == 0, 1, s);
+    post_ring = aa_post_ring_entries(w);
     launch_aa_post(w, s);
     launch_aa_root(w, s);
     PROF_MARK(e, marks && off == 0, 2, s);
@@ -226,7 +228,11 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   }
   if (prof) HIP_TRY(hipEventRecord(prof_event(e, 1), s));
   e->dominant = d.gradient ? aa_pre_kernel_name() : aa_post_kernel_name();
-  e->last_path = std::string(e->dominant) + " store=hbm-arena states=20 K=" + std::to_string(e->K);
+  // (the stack tops of the walks live in LDS rings: kernels_aa.hip)
+  e->last_path = std::string(e->dominant) + " store=hbm-arena" +
+                 (d.gradient ? " pre-ring=" + std::to_string(aa_pre_ring_entries())
+                             : " post-ring=" + std::to_string(post_ring)) +
+                 " states=20 K=" + std::to_string(e->K);
   e->last_evals = T;
   e->last_grad_evals = d.gradient ? T : 0;
   e->last_walk_launches = (T + chunk - 1) / chunk;

@@ -369,6 +369,9 @@ int aa_ll_blocks(int P);             // partial log-likelihood sums per evaluati
 void launch_aa_post(const AaWalkArgs& a, hipStream_t s);
 void launch_aa_root(const AaWalkArgs& a, hipStream_t s);
 void launch_aa_pre(const AaWalkArgs& a, hipStream_t s);
+// entries of the LDS rings the two launchers above will use for these arguments
+int aa_post_ring_entries(const AaWalkArgs& a);
+int aa_pre_ring_entries();
 void launch_aa_reduce(const AaWalkArgs& a, hipStream_t s);
 const char* aa_post_kernel_name();
 const char* aa_pre_kernel_name();

@@ -257,7 +257,17 @@ __device__ __forceinline__ void mat_apply(const double (&A)[10], const double (&
 #pragma unroll
     for (int t = 0; t < 5; t++) {
       c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t], L[u][t], c, 0, 0, 0);
+#ifdef AA_MFMA_NOPS  // (experiment, DESIGN 4.6 finding 2: the wave stays silent while its MFMA runs)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop %0" ::"n"(AA_MFMA_NOPS));
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       d = __builtin_amdgcn_mfma_f64_4x4x4f64(A[5 + t], L[u][t], d, 0, 0, 0);
+#ifdef AA_MFMA_NOPS
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 2");
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     S[u][0] = c.x; S[u][1] = c.y; S[u][2] = c.z; S[u][3] = c.w;
     S[u][4] = d;
@@ -1463,15 +1473,19 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
   // Everything a visit reads from global memory -- its children's post-order vectors, its own
   // pre-order vector unless the previous visit hands it over in registers, its exponents, the
   // tip states, the LDS operands -- is requested during the visit BEFORE it, each into the
-  // registers that visit has just finished with (no second register set, no copies), and
-  // retired by that visit's one vmcnt(0): a visit's own arithmetic never waits for memory.
-  double q[M][5], L[2][M][5];
+  // registers that visit has just finished with, and retired by that visit's one vmcnt(0): a
+  // visit's own arithmetic never waits for memory.  (Round 5: the node's own vector and
+  // exponents are requested at the TOP of the visit before, the vector into registers of its
+  // own -- until then they were the last thing requested before the wait, which every visit
+  // then paid in full: 1 400-1 500 of a visit's 9 000 clocks in the stamps.  The registers are
+  // there: the operand buffers in LDS allow two waves per SIMD whatever the kernel uses.)
+  double q[M][5], qn[M][5], L[2][M][5];
   int ev[M];
 #pragma unroll
   for (int u = 0; u < M; u++) {
     ev[u] = 0;
 #pragma unroll
-    for (int t = 0; t < 5; t++) q[u][t] = L[0][u][t] = L[1][u][t] = 0;
+    for (int t = 0; t < 5; t++) q[u][t] = qn[u][t] = L[0][u][t] = L[1][u][t] = 0;
   }
   auto fetch_children = [&](int node, int c0, int c1, int (&x)[2][M]) {
     if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
@@ -1484,8 +1498,8 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
   // the other child, whose vector it keeps in registers)
   auto fetch_node = [&](int node, bool load_q, int own_slot) {
     if (load_q) {
-      if (own_slot >= lo) load_tiles<M>(ring_entry(own_slot), lane, q);
-      else load_tiles<M>(arena + (size_t)(node - n) * arena_stride, lane, q);
+      if (own_slot >= lo) load_tiles<M>(ring_entry(own_slot), lane, qn);
+      else load_tiles<M>(arena + (size_t)(node - n) * arena_stride, lane, qn);
     }
 #pragma unroll
     for (int u = 0; u < M; u++) ev[u] = exp_loc[(size_t)(node - n) * exp_stride + u * 16 + j];
@@ -1505,6 +1519,21 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
   wait_all_vm();
   lds_barrier();
 
+#ifdef AA_STAMPS  // (timing experiment: where a wave's visit goes, in shader clocks)
+  unsigned long long pstamp_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pstamp_t = __builtin_amdgcn_s_memtime();
+#define AA_PSTAMP(k)                                                 \
+  {                                                                  \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+    pstamp_acc[k] += now_ - pstamp_t;                                \
+    pstamp_t = now_;                                                 \
+  }
+#define AA_PIN(arr)                                                  \
+  _Pragma("unroll") for (int u_ = 0; u_ < M; u_++) _Pragma("unroll") for (int t_ = 0; t_ < 5; t_++) asm volatile("" : "+v"(arr[u_][t_]));
+#else
+#define AA_PSTAMP(k)
+#define AA_PIN(arr)
+#endif
   for (int i = count - 1; i >= 0; i--) {
     const int buf = i & 1;
     int next = -1, nc0 = -1, nc1 = -1, nslots = 0;
@@ -1517,10 +1546,16 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
       nslots = sgpr(s1.slots);
       stage(nc0, nc1, buf ^ 1);
     }
+    AA_PSTAMP(0);  // schedule entry, operand DMA of the next visit issued
 #pragma unroll
     for (int u = 0; u < M; u++)
 #pragma unroll
       for (int t = 0; t < 5; t++) q[u][t] = ldexp(q[u][t], -ev[u]);
+    // ev is done with: the next node's exponents, and its vector unless this visit computes it
+    const bool keep = i > 0 && (next == ch[0] || next == ch[1]);
+#pragma unroll
+    for (int u = 0; u < M; u++) asm volatile("" : "+v"(ev[u]));
+    if (i > 0) fetch_node(next, !keep, nslots & 0xff);
     // S[c] = P_c L_c (tip: column of P)
     double S[2][M][5];
 #pragma unroll
@@ -1542,8 +1577,12 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
     }
     // L is done with: the next visit's vectors go into it (and its tip states into xn); the
     // compiler may not move these loads up: they follow a memory barrier
+    AA_PIN(S[0]);
+    AA_PIN(S[1]);
+    AA_PSTAMP(1);  // S_c = P_c L_c
     asm volatile("" ::: "memory");
     if (i > 0) fetch_children(next, nc0, nc1, xn);
+    AA_PSTAMP(2);  // the next visit's vectors requested
     // X_c = sum (q o S[sibling]) . Q S_c (tip: the column of P Q), tile by tile
     double X[2];
 #pragma unroll
@@ -1579,10 +1618,12 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
         S[1][u][t] = u0;
         S[0][u][t] = u1;
       }
-    // q is done with: the next node's (unless this visit computes it below) and its exponents
-    const bool keep = i > 0 && (next == ch[0] || next == ch[1]);
-    asm volatile("" ::: "memory");
-    if (i > 0) fetch_node(next, !keep, nslots & 0xff);
+    AA_PIN(S[0]);
+    AA_PIN(S[1]);
+#ifdef AA_STAMPS
+    asm volatile("" : "+v"(X[0]), "+v"(X[1]));
+#endif
+    AA_PSTAMP(3);  // edge derivatives (Q S, two wave sums), messages u_c
     // The visit's one wait: the DMA and the loads for the next visit.  What they loaded is
     // consumed HERE as far as the compiler is concerned, so that it puts its own waits before
     // the stores below and none after them (the stores stay in flight).
@@ -1596,9 +1637,16 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
       for (int t = 0; t < 5; t++) {
         asm volatile("" : "+v"(L[0][u][t]));
         asm volatile("" : "+v"(L[1][u][t]));
-        asm volatile("" : "+v"(q[u][t]));
+        asm volatile("" : "+v"(qn[u][t]));
       }
     }
+    if (i > 0 && !keep) {
+#pragma unroll
+      for (int u = 0; u < M; u++)
+#pragma unroll
+        for (int t = 0; t < 5; t++) q[u][t] = qn[u][t];
+    }
+    AA_PSTAMP(4);  // the visit's wait
     if (lane == 0 && active) {
       store_async(gp + ch[0], 0, X[0]);
       store_async(gp + ch[1], 0, X[1]);
@@ -1640,7 +1688,10 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
       lds_pack(ops_lds[buf][c] + kAaPack, A);
       mat_apply<M>(A, S[1 - c], q);
     }
+    AA_PIN(q);
+    AA_PSTAMP(5);  // q_c = P_c^T u_c, parked or handed over
     lds_barrier();
+    AA_PSTAMP(6);  // barrier
     v = next;
     ch[0] = nc0;
     ch[1] = nc1;
@@ -1651,6 +1702,12 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
       xc[1][u] = xn[1][u];
     }
   }
+#ifdef AA_STAMPS
+  if (lane == 0 && (blockIdx.x % 4001) == 7)
+    printf("aa_pre_wg block %d wave %d visits %d: issue %llu S %llu fetch %llu derivatives %llu wait %llu q_c %llu barrier %llu (clocks per visit)\n",
+           (int)blockIdx.x, wave, count, pstamp_acc[0] / count, pstamp_acc[1] / count, pstamp_acc[2] / count,
+           pstamp_acc[3] / count, pstamp_acc[4] / count, pstamp_acc[5] / count, pstamp_acc[6] / count);
+#endif
 }
 
 // ------------------------------------------------------------------------

@@ -45,6 +45,7 @@ namespace {
 using namespace dev;
 
 typedef double double4v __attribute__((ext_vector_type(4)));
+typedef double double2v __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------
 // Model set-up: Q from (exchangeabilities, frequencies) by the reference's GTR recipe
@@ -300,13 +301,26 @@ __device__ __forceinline__ void tip_gather(const double* __restrict__ table, con
   }
 }
 
+// A tile in memory (arena, LDS rings): 320 doubles = registers (0, 1) of the 64 lanes
+// interleaved (lane l: doubles 2l, 2l + 1), registers (2, 3) likewise from double 128, register
+// 4 from double 256 -- two 16-byte and one 8-byte access per lane and tile instead of five
+// 8-byte ones (round 5: a vector-memory instruction of these walks costs 40-50 clocks of issue
+// whatever its width; the stamps of aa_pre_wg_kernel).  Every access goes through the three
+// functions below.
 template <int M>
 __device__ __forceinline__ void load_tiles(const double* __restrict__ src, int lane,
                                            double (&L)[M][5]) {
 #pragma unroll
-  for (int u = 0; u < M; u++)
-#pragma unroll
-    for (int t = 0; t < 5; t++) L[u][t] = src[u * kAaTileDoubles + t * 64 + lane];
+  for (int u = 0; u < M; u++) {
+    const double* p = src + u * kAaTileDoubles;
+    const double2v a = *reinterpret_cast<const double2v*>(p + 2 * lane);
+    const double2v b = *reinterpret_cast<const double2v*>(p + 128 + 2 * lane);
+    L[u][0] = a.x;
+    L[u][1] = a.y;
+    L[u][2] = b.x;
+    L[u][3] = b.y;
+    L[u][4] = p[256 + lane];
+  }
 }
 // Sum of one double per lane over the wave without LDS round trips: a product with a ones
 // matrix adds the four 16-lane rows (v_mfma_f64_4x4x4: D[i][j] = sum_k B[k][j], k = lane >>
@@ -333,9 +347,12 @@ template <int M>
 __device__ __forceinline__ void store_tiles(double* __restrict__ dst, int lane,
                                             const double (&L)[M][5]) {
 #pragma unroll
-  for (int u = 0; u < M; u++)
-#pragma unroll
-    for (int t = 0; t < 5; t++) dst[u * kAaTileDoubles + t * 64 + lane] = L[u][t];
+  for (int u = 0; u < M; u++) {
+    double* p = dst + u * kAaTileDoubles;
+    *reinterpret_cast<double2v*>(p + 2 * lane) = double2v{L[u][0], L[u][1]};
+    *reinterpret_cast<double2v*>(p + 128 + 2 * lane) = double2v{L[u][2], L[u][3]};
+    p[256 + lane] = L[u][4];
+  }
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs by linear id.  The walk kernels give each
@@ -661,13 +678,14 @@ __device__ __forceinline__ void dma_table(const double* __restrict__ src, double
 // one vmcnt(0) per visit retires them a visit later.
 template <int M>
 __device__ __forceinline__ void store_tiles_async(double* dst, int lane, const double (&L)[M][5]) {
-  const uint32_t lane8 = (uint32_t)lane * 8;
+  const uint32_t lane8 = (uint32_t)lane * 8, lane16 = (uint32_t)lane * 16;
 #pragma unroll
   for (int u = 0; u < M; u++) {
     const double* p = dst + u * kAaTileDoubles;
-#pragma unroll
-    for (int t = 0; t < 5; t++)
-      asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(lane8), "v"(L[u][t]), "s"(p), "n"(t * 512) : "memory");
+    const double2v a = {L[u][0], L[u][1]}, b = {L[u][2], L[u][3]};
+    asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(lane16), "v"(a), "s"(p) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024" ::"v"(lane16), "v"(b), "s"(p) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, %2 offset:2048" ::"v"(lane8), "v"(L[u][4]), "s"(p) : "memory");
   }
 }
 // (base: wave-uniform; index: this lane's element)
@@ -697,7 +715,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
   // are a ring in LDS (S = a.ring_slots entries; vector and exponents); a push that finds the ring full
   // spills the ring's OLDEST entry to its arena slot first (lo++), a pop below lo reads the
   // arena as before.  Same loads, products and stores in the same order: bit-identical.
-  extern __shared__ double ring_lds[];  // [wave][S][M tiles x (320 doubles + 16 ints)]
+  extern __shared__ __align__(16) double ring_lds[];  // [wave][S][M tiles x (320 doubles + 16 ints)]
   const int blocks = a.tiles / M;
   const int wgs = (blocks + kPostWaves - 1) / kPostWaves;  // workgroups per (evaluation, category)
   const AaUnit un = aa_unit(wgs, a.evals * a.K);
@@ -947,10 +965,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
               lo = lo + 1;
             }
             double* dstp = ring_entry(dst);
-#pragma unroll
-            for (int u = 0; u < M; u++)
-#pragma unroll
-              for (int t = 0; t < 5; t++) dstp[u * kAaTileDoubles + t * 64 + lane] = R[u][t];
+            store_tiles<M>(dstp, lane, R);
             if (g == 0) {
               int* ex = reinterpret_cast<int*>(dstp + M * kAaTileDoubles);
 #pragma unroll
@@ -1378,7 +1393,7 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
 constexpr int kPreOps = 2 * kAaPack;  // doubles per child in LDS: P | P^T  (tip: tipP | tipPQ)
 template <int M>
 __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kernel(AaWalkArgs a) {
-  extern __shared__ double pre_lds[];  // [2][2][kPreOps] doubles, Q, the schedule window, the ring
+  extern __shared__ __align__(16) double pre_lds[];  // [2][2][kPreOps] doubles, Q, the schedule window, the ring
   double (*ops_lds)[2][kPreOps] = reinterpret_cast<double (*)[2][kPreOps]>(pre_lds);
   double* q_lds = pre_lds + 2 * 2 * kPreOps;
   SchedEntry* sched_lds = reinterpret_cast<SchedEntry*>(q_lds + kAaPack);
@@ -1670,11 +1685,7 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
           if (active) store_tiles_async<M>(sgpr_ptr(arena + (size_t)(old_node - n) * arena_stride), lane, old);
           lo = lo + 1;
         }
-        double* dstp = ring_entry(dst);
-#pragma unroll
-        for (int u = 0; u < M; u++)
-#pragma unroll
-          for (int t = 0; t < 5; t++) dstp[u * kAaTileDoubles + t * 64 + lane] = qc[u][t];
+        store_tiles<M>(ring_entry(dst), lane, qc);
         if (dst & (RS - 1)) ring_node[1] = ch[c];
         else ring_node[0] = ch[c];
       } else if (active) {

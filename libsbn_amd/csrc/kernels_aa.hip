@@ -1833,8 +1833,13 @@ static int aa_ring_slots(size_t workgroups) {
 // (what launch_aa_post / launch_aa_pre will choose: for the engine's description of a call)
 int aa_post_ring_entries(const AaWalkArgs& a) {
   if (a.gradient || !aa_post_wg()) return 0;
-  const int blocks = a.tiles / aa_post_tiles(a);
-  return aa_ring_slots(aa_grid((blocks + kPostWaves - 1) / kPostWaves, a.evals * a.K));
+  const int m = aa_post_tiles(a), blocks = a.tiles / m;
+  int entries = aa_ring_slots(aa_grid((blocks + kPostWaves - 1) / kPostWaves, a.evals * a.K));
+  // (a forced size must still fit a CU beside the 24.5 KB of operand buffers and schedule)
+  while (entries > 0 && sizeof(double) * (size_t)kPostWaves * entries * m * (kAaTileDoubles + 8) + aa_lds_pad() >
+                            160 * 1024 - 25 * 1024)
+    entries >>= 1;
+  return entries;
 }
 void launch_aa_post(const AaWalkArgs& a_in, hipStream_t s) {
   AaWalkArgs a = a_in;

@@ -80,15 +80,21 @@ def lib():
     so = os.path.join(ORACLE_DIR, name)
     stamp_path = os.path.join(ORACLE_DIR, "." + name + ".stamp")
     stamp = _host_stamp()
-    have = open(stamp_path).read() if os.path.exists(stamp_path) else ""
-    src_newer = (not os.path.exists(so) or os.path.getmtime(so) < max(
-        os.path.getmtime(os.path.join(ORACLE_DIR, f))
-        for f in ("phylo_oracle.c", "phylo_oracle.h")))
-    if src_newer or have != stamp:
-        subprocess.run(["make", "-B", "-C", ORACLE_DIR, name], check=True, capture_output=True)
-        with open(stamp_path, "w") as fh:
-            fh.write(stamp)
-    L = C.CDLL(so)
+    # (several processes may come here at once -- the stress sweeps run in parallel on a fresh
+    # box: the check and the rebuild happen under a file lock, so that nobody loads a library
+    # that another process is still writing)
+    import fcntl
+    with open(os.path.join(ORACLE_DIR, "." + name + ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        have = open(stamp_path).read() if os.path.exists(stamp_path) else ""
+        src_newer = (not os.path.exists(so) or os.path.getmtime(so) < max(
+            os.path.getmtime(os.path.join(ORACLE_DIR, f))
+            for f in ("phylo_oracle.c", "phylo_oracle.h")))
+        if src_newer or have != stamp:
+            subprocess.run(["make", "-B", "-C", ORACLE_DIR, name], check=True, capture_output=True)
+            with open(stamp_path, "w") as fh:
+                fh.write(stamp)
+        L = C.CDLL(so)
     L.orc_last_error.restype = C.c_char_p
     L.orc_core_log_likelihood.restype = C.c_double
     L.orc_core_branch_gradient.restype = C.c_double

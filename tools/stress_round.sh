@@ -27,5 +27,10 @@ run parity_unfused parity 3007 400 MI_PHYLO_FUSED_SETUP=0 STRESS_FOCUS=fused &
 run parity_analytic parity 3008 400 MI_PHYLO_SUBST_GRADIENT=analytic &
 run rooted rooted 3009 800 &
 run aa aa 3011 500 &
+run aa_b aa 5012 500 &
+# (the sweeps' problems are small: the launchers would never choose a ring for them)
+run aa_ring1 aa 6001 400 MI_PHYLO_AA_RING=1 MI_PHYLO_AA_PRE_RING=2 &
+run aa_ring2 aa 6002 400 MI_PHYLO_AA_RING=2 MI_PHYLO_AA_PRE_RING=0 &
+run aa_ring4 aa 6003 400 MI_PHYLO_AA_RING=4 MI_PHYLO_AA_POST_TILES=4 &
 wait
 cat gpurun_out/${tag}_stress_*.txt

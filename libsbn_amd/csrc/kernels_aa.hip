@@ -728,6 +728,8 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
   const int tree = a.eval_offset + el;
   const int n = a.n, K = a.K;
   const int p0 = sgpr(blk * M * 16);
+  constexpr int kTipBytes = kPostWaves * M * 16;  // tip states of the workgroup's patterns
+  const size_t p0_wg = (size_t)un.blk * kTipBytes;
   const size_t tiles = a.tiles, tip_stride = tiles * 16;
   const int nodes = GRAD ? n - 1 : a.slots;
   double* arena = sgpr_ptr(a.arena + (((size_t)el * nodes * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles);
@@ -762,6 +764,15 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
     if (ch < n) {
       const double* src = tipP + (size_t)ch * K * kAaTipTable + (second ? 2 * 128 : 0);
       dma_run<2>(src, lane16, ops_lds[buf][c] + (second ? 2 * 128 : 0));
+      // the tip's states for the workgroup's patterns (kTipBytes of them) behind the table, in
+      // the fifth piece of the slot that only a matrix pack uses: ONE 4-byte LDS-DMA by the
+      // table's second wave instead of M byte loads by every wave (round 5: a vector-memory
+      // instruction costs these walks 50-150 clocks of issue whatever it moves)
+      if (second && lane < kTipBytes / 4) {
+        const int8_t* ts = a.tip_states + (size_t)ch * tip_stride + p0_wg;
+        const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)(ops_lds[buf][c] + 4 * 128);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"((uint32_t)lane * 4), "s"(ts), "s"(m0) : "memory");
+      }
     } else {
       const double* src = matP + (size_t)(ch - n) * K * kAaPack + (second ? 3 * 128 : 0);
       double* dst = ops_lds[buf][c] + (second ? 3 * 128 : 0);
@@ -769,15 +780,18 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
       else dma_run<3>(src, lane16, dst);
     }
   };
-  auto stage0 = [&](int c0, int c1, int (&x)[2][M]) {
-    if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
-    if (c1 < n) load_tip_states<M>(a.tip_states + (size_t)c1 * tip_stride, p0, lane, x[1]);
+  // the states of a tip child, this lane's M patterns: from the bytes stage() put behind the
+  // child's table (read first thing in the visit, used after the next visit's requests)
+  auto tip_states_of = [&](int buf, int c, int (&x)[M]) {
+    const int8_t* ts = reinterpret_cast<const int8_t*>(ops_lds[buf][c] + 4 * 128) + wave * (M * 16) + j;
+#pragma unroll
+    for (int u = 0; u < M; u++) x[u] = ts[u * 16];
   };
-  int xc[2][M], xn[2][M];
+  int xc[2][M];
 #pragma unroll
   for (int c = 0; c < 2; c++)
 #pragma unroll
-    for (int u = 0; u < M; u++) xc[c][u] = xn[c][u] = kAa;
+    for (int u = 0; u < M; u++) xc[c][u] = kAa;
   int v, ch0, ch1, slots;
   {
     const SchedEntry e0 = win.at(0);
@@ -786,16 +800,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
     ch1 = sgpr(e0.child1);
     slots = sgpr(e0.slots);
   }
-  stage0(ch0, ch1, xc);
   stage(ch0, ch1, 0);
-  // (the compiler must see the first visit's tip states consumed HERE: it does not know what
-  // wait_all_vm waits for, and with these loads still pending in its books at the loop's head
-  // it puts a vmcnt(0) in front of the first use of xc in the loop -- behind the requests for
-  // the next visit's operands, i.e. a full memory round trip at the start of every visit)
-#pragma unroll
-  for (int c = 0; c < 2; c++)
-#pragma unroll
-    for (int u = 0; u < M; u++) asm volatile("" : "+v"(xc[c][u]));
   wait_all_vm();
   lds_barrier();
 
@@ -830,18 +835,25 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
 #else
 #define AA_STAMP(k)
 #endif
+  // (the schedule entry of visit i + 1 is read from the LDS window during visit i - 1: the
+  // top of a visit then goes straight from the barrier to its requests, without an LDS round
+  // trip in front of them)
+  SchedEntry ahead = count > 1 ? win.at(1) : SchedEntry{-1, -1, -1, 0};
   for (int i = 0; i < count; i++) {
     const int buf = i & 1;
+    if (ch0 < n) tip_states_of(buf, 0, xc[0]);
+    if (ch1 < n) tip_states_of(buf, 1, xc[1]);
     int nv = -1, next_c0 = -1, next_c1 = -1, nslots = 0;
     if (i + 1 < count) {
-      if (i + 1 >= win.base + kSchedWindow) fill(i + 1);
-      const SchedEntry s1 = win.at(i + 1);
-      nv = sgpr(s1.node);
-      next_c0 = sgpr(s1.child0);
-      next_c1 = sgpr(s1.child1);
-      nslots = sgpr(s1.slots);
+      nv = sgpr(ahead.node);
+      next_c0 = sgpr(ahead.child0);
+      next_c1 = sgpr(ahead.child1);
+      nslots = sgpr(ahead.slots);
       stage(next_c0, next_c1, buf ^ 1);  // the next visit's shared operands: global -> LDS
-      stage0(next_c0, next_c1, xn);
+      if (i + 2 < count) {
+        if (i + 2 >= win.base + kSchedWindow) fill(i + 2);
+        ahead = win.at(i + 2);
+      }
     }
     AA_STAMP(0);  // requests for the next visit issued
     if constexpr (GRAD) {
@@ -891,8 +903,6 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
       for (int u = 0; u < M; u++) {
         Es[u] = Ec[0][u] + Ec[1][u];
         asm volatile("" : "+v"(Es[u]));
-        asm volatile("" : "+v"(xn[0][u]));  // (likewise the next visit's tip states)
-        asm volatile("" : "+v"(xn[1][u]));
       }
       wait_all_vm();
       AA_STAMP(2);
@@ -984,11 +994,6 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
         if (RS == 0) {
           // no ring (small launches): the push is a store to the arena, issued AFTER the visit's
           // wait so that it has the whole next visit to be acknowledged
-#pragma unroll
-          for (int u = 0; u < M; u++) {
-            asm volatile("" : "+v"(xn[0][u]));
-            asm volatile("" : "+v"(xn[1][u]));
-          }
           wait_all_vm();
           if (prev >= 0 && active) {
             const int dst = prev_slots & 0xff;
@@ -1079,13 +1084,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
         for (int t = 0; t < 5; t++) asm volatile("" : "+v"(R[u][t]));
 #endif
       AA_STAMP(1);  // the visit's work: push or products, rescaling
-      // the visit's one wait, for the next visit's operands (its tip states are consumed here:
-      // the compiler's own wait for them then sits here too)
-#pragma unroll
-      for (int u = 0; u < M; u++) {
-        asm volatile("" : "+v"(xn[0][u]));
-        asm volatile("" : "+v"(xn[1][u]));
-      }
+      // the visit's one wait, for the next visit's operands
       if (!(two_tips && RS == 0)) wait_all_vm();
       AA_STAMP(2);  // waited for the next visit's operands
     }
@@ -1106,10 +1105,6 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
     ch0 = next_c0;
     ch1 = next_c1;
     slots = nslots;
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int u = 0; u < M; u++) xc[c][u] = xn[c][u];
   }
 #ifdef AA_STAMPS
   if (!GRAD && lane == 0 && (blockIdx.x % 4001) == 7)

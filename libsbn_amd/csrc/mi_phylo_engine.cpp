@@ -863,7 +863,10 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
     // the tips are on the device already: one kernel derives what the host loops below derive
     const int stride = states == kAa ? e->tiles * kAaTile : e->P;
     const bool dna = states == kStates;
-    if (e->tip_states.ensure((size_t)e->n * stride)) return cleanup_fail(1);
+    if (e->tip_states.ensure((size_t)e->n * stride + (states == kAa ? kAaTipSlack : 0))) return cleanup_fail(1);
+    if (states == kAa &&
+        hipMemsetAsync(e->tip_states.as<int8_t>() + (size_t)e->n * stride, states, kAaTipSlack, e->stream) != hipSuccess)
+      return cleanup_fail(fail("hipMemset failed"));
     if (dna && (e->tip_masks.ensure(np) || e->tip_codes.ensure(np + 16))) return cleanup_fail(1);
     if (dna && !spec->use_tip_states && e->tip_partials.ensure(sizeof(double) * np * kStates))
       return cleanup_fail(1);
@@ -913,7 +916,9 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
     }
     {  // rows padded with gaps to whole 16-pattern tiles: the walk kernels read them unmasked
       const size_t stride = (size_t)e->tiles * kAaTile;
-      std::vector<int8_t> padded((size_t)e->n * stride, (int8_t)states);
+      // (+ a tile group of slack behind the last row: the workgroup kernels fetch the states of
+      // their whole pattern range, padding waves included, with one LDS-DMA)
+      std::vector<int8_t> padded((size_t)e->n * stride + kAaTipSlack, (int8_t)states);
       for (int x = 0; x < e->n; x++)
         std::copy(st8.begin() + (size_t)x * e->P, st8.begin() + (size_t)(x + 1) * e->P,
                   padded.begin() + (size_t)x * stride);

@@ -301,6 +301,7 @@ void launch_reduce_finalize(const ReduceArgs& ra, const FinalizeArgs& fa, hipStr
 // ------------------------------------------------------------------------
 constexpr int kAa = 20;              // states
 constexpr int kAaTile = 16;          // site patterns per matrix-core tile
+constexpr int kAaTipSlack = 512;     // bytes behind the tip-state rows (a workgroup fetches its whole pattern range)
 constexpr int kAaTileDoubles = 320;  // one tile of one category: 5 registers x 64 lanes
 constexpr int kAaPack = 640;         // one 20x20 matrix as matrix-core A operands: 10 registers x 64 lanes
 constexpr int kAaTipTable = 21 * 20; // per tip edge and category: column of the matrix per state, 20 = gap

@@ -1405,6 +1405,8 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
   const int tree = a.eval_offset + el;
   const int n = a.n, N = a.N, K = a.K;
   const int p0 = sgpr(blk * M * 16);
+  constexpr int kTipBytes = kPreWaves * M * 16;  // tip states of the workgroup's patterns
+  const size_t p0_wg = (size_t)un.blk * kTipBytes;
   const size_t tiles = a.tiles, tip_stride = tiles * 16;
   double* arena = sgpr_ptr(a.arena + (((size_t)el * (n - 1) * K + cat) * tiles + (size_t)blk * M) * kAaTileDoubles);
   const size_t arena_stride = (size_t)K * tiles * kAaTileDoubles;
@@ -1442,6 +1444,12 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
     if (ch < n) {
       const double* src = (second ? tipPQ : tipP) + (size_t)ch * K * kAaTipTable;
       dma_whole<4>(src, lane16, dst);
+      // (the tip's states for the workgroup's patterns behind its first table: see aa_post_wg_kernel)
+      if (second && lane < kTipBytes / 4) {
+        const int8_t* ts = a.tip_states + (size_t)ch * tip_stride + p0_wg;
+        const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)(ops_lds[buf][c] + 4 * 128);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"((uint32_t)lane * 4), "s"(ts), "s"(m0) : "memory");
+      }
     } else {
       const double* src = (second ? matPT : matP) + (size_t)(ch - n) * K * kAaPack;
       dma_whole<5>(src, lane16, dst);
@@ -1459,11 +1467,16 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
       for (int t = 0; t < 5; t++) S[u][t] = col[4 * t];
     }
   };
-  int xc[2][M], xn[2][M];
+  auto tip_states_of = [&](int buf, int c, int (&x)[M]) {
+    const int8_t* ts = reinterpret_cast<const int8_t*>(ops_lds[buf][c] + 4 * 128) + wave * (M * 16) + j;
+#pragma unroll
+    for (int u = 0; u < M; u++) x[u] = ts[u * 16];
+  };
+  int xc[2][M];
 #pragma unroll
   for (int c = 0; c < 2; c++)
 #pragma unroll
-    for (int u = 0; u < M; u++) xc[c][u] = xn[c][u] = kAa;
+    for (int u = 0; u < M; u++) xc[c][u] = kAa;
   int v, ch[2], vslots;
   {
     const SchedEntry e0 = win.at(count - 1);
@@ -1497,9 +1510,7 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
 #pragma unroll
     for (int t = 0; t < 5; t++) q[u][t] = qn[u][t] = L[0][u][t] = L[1][u][t] = 0;
   }
-  auto fetch_children = [&](int node, int c0, int c1, int (&x)[2][M]) {
-    if (c0 < n) load_tip_states<M>(a.tip_states + (size_t)c0 * tip_stride, p0, lane, x[0]);
-    if (c1 < n) load_tip_states<M>(a.tip_states + (size_t)c1 * tip_stride, p0, lane, x[1]);
+  auto fetch_children = [&](int node, int c0, int c1) {
     if (c0 >= n) load_tiles<M>(arena + (size_t)(c0 - n) * arena_stride, lane, L[0]);
     if (c1 >= n) load_tiles<M>(arena + (size_t)(c1 - n) * arena_stride, lane, L[1]);
   };
@@ -1515,7 +1526,7 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
     for (int u = 0; u < M; u++) ev[u] = exp_loc[(size_t)(node - n) * exp_stride + u * 16 + j];
   };
   stage(ch[0], ch[1], (count - 1) & 1);
-  fetch_children(v, ch[0], ch[1], xc);
+  fetch_children(v, ch[0], ch[1]);
   fetch_node(v, false, 0);
   {
     const size_t rbase = ((size_t)el * K + cat) * tiles * 16 + p0;
@@ -1546,6 +1557,8 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
 #endif
   for (int i = count - 1; i >= 0; i--) {
     const int buf = i & 1;
+    if (ch[0] < n) tip_states_of(buf, 0, xc[0]);
+    if (ch[1] < n) tip_states_of(buf, 1, xc[1]);
     int next = -1, nc0 = -1, nc1 = -1, nslots = 0;
     if (i > 0) {
       if (i - 1 < win.base) fill_upto(i - 1);
@@ -1591,7 +1604,7 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
     AA_PIN(S[1]);
     AA_PSTAMP(1);  // S_c = P_c L_c
     asm volatile("" ::: "memory");
-    if (i > 0) fetch_children(next, nc0, nc1, xn);
+    if (i > 0) fetch_children(next, nc0, nc1);
     AA_PSTAMP(2);  // the next visit's vectors requested
     // X_c = sum (q o S[sibling]) . Q S_c (tip: the column of P Q), tile by tile
     double X[2];
@@ -1640,8 +1653,6 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
     wait_all_vm();
 #pragma unroll
     for (int u = 0; u < M; u++) {
-      asm volatile("" : "+v"(xn[0][u]));
-      asm volatile("" : "+v"(xn[1][u]));
       asm volatile("" : "+v"(ev[u]));
 #pragma unroll
       for (int t = 0; t < 5; t++) {
@@ -1702,11 +1713,6 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
     ch[0] = nc0;
     ch[1] = nc1;
     vslots = nslots;
-#pragma unroll
-    for (int u = 0; u < M; u++) {
-      xc[0][u] = xn[0][u];
-      xc[1][u] = xn[1][u];
-    }
   }
 #ifdef AA_STAMPS
   if (lane == 0 && (blockIdx.x % 4001) == 7)

@@ -331,13 +331,23 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   using J1 = std::integral_constant<int, 1>;
   using Post = std::false_type;
   using Pre = std::true_type;
+#ifdef W3_STAMPS
+  long long stamp_fetch = 0, stamp_visits = 0;
+#endif
   auto fetch = [&](auto pre_tag, int m, int sh, const Tw& tw, auto& o0, auto& o1) {
+#ifdef W3_STAMPS
+    const long long f0 = __builtin_amdgcn_s_memtime();
+#endif
     const char* sb = mm_g + (size_t)((unsigned)m * kVisit);
     unsigned off4 = 4 * kPos;
     asm volatile("" : "+s"(off4));
     const char* sb4 = sb + off4;
     fetch_child(pre_tag, J0{}, sh, tw, sb, sb4, o0);
     fetch_child(pre_tag, J1{}, sh, tw, sb, sb4, o1);
+#ifdef W3_STAMPS
+    stamp_fetch += __builtin_amdgcn_s_memtime() - f0;
+    stamp_visits++;
+#endif
   };
 
   // ONE wait per visit for operands.  How many loads a fetch issues depends on the visit's
@@ -837,8 +847,8 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   }
 #ifdef W3_STAMPS
   if (lane == 0 && (job_eval % 250) == 3 && (tile % 39) == 5)
-    printf("walk3 stamps eval %d tile %d: operand waits %lld of %lld ticks (100 MHz)\n", job_eval, tile,
-           stamp_wait, (long long)__builtin_amdgcn_s_memtime() - stamp_t0);
+    printf("walk3 stamps eval %d tile %d: operand waits %lld, operand requests %lld (%lld visits) of %lld shader clocks\n", job_eval, tile,
+           stamp_wait, stamp_fetch, stamp_visits, (long long)__builtin_amdgcn_s_memtime() - stamp_t0);
 #endif
   __syncthreads();
   // positions that do not exist in a macro are never written nor read downstream

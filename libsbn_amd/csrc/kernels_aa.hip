@@ -355,6 +355,42 @@ __device__ __forceinline__ void store_tiles(double* __restrict__ dst, int lane,
   }
 }
 
+// The same for a tile in an LDS ring, through pointers that SAY they are LDS pointers: a ring
+// read and an arena read under the two arms of one branch are otherwise merged into ONE load
+// through a generic pointer -- a flat instruction, which reaches LDS by way of the vector
+// memory path (round 5: the pre-order kernel's ring reads were such loads).
+typedef __attribute__((address_space(3))) double* lds_f64_ptr;
+typedef __attribute__((address_space(3))) const double* lds_cf64_ptr;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+template <int M>
+__device__ __forceinline__ void load_tiles_lds(const double* src_generic, int lane, double (&L)[M][5]) {
+  const lds_cf64_ptr src = (lds_cf64_ptr)(lds_void_ptr)const_cast<double*>(src_generic);
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    const lds_cf64_ptr p = src + u * kAaTileDoubles;
+    typedef __attribute__((address_space(3))) const double2v* lds_pair_ptr;
+    const double2v a = *(lds_pair_ptr)(p + 2 * lane);
+    const double2v b = *(lds_pair_ptr)(p + 128 + 2 * lane);
+    L[u][0] = a.x;
+    L[u][1] = a.y;
+    L[u][2] = b.x;
+    L[u][3] = b.y;
+    L[u][4] = p[256 + lane];
+  }
+}
+template <int M>
+__device__ __forceinline__ void store_tiles_lds(double* dst_generic, int lane, const double (&L)[M][5]) {
+  const lds_f64_ptr dst = (lds_f64_ptr)(lds_void_ptr)dst_generic;
+#pragma unroll
+  for (int u = 0; u < M; u++) {
+    const lds_f64_ptr p = dst + u * kAaTileDoubles;
+    typedef __attribute__((address_space(3))) double2v* lds_pair_ptr;
+    *(lds_pair_ptr)(p + 2 * lane) = double2v{L[u][0], L[u][1]};
+    *(lds_pair_ptr)(p + 128 + 2 * lane) = double2v{L[u][2], L[u][3]};
+    p[256 + lane] = L[u][4];
+  }
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs by linear id.  The walk kernels give each
 // XCD a CONTIGUOUS range of the (evaluation x category)-major work list, so that an XCD's
 // L2 holds the transition matrices of one or two (evaluation, category) units instead of all.
@@ -627,6 +663,7 @@ constexpr int kPostWaves = 4, kPostThreads = 64 * kPostWaves;
 // the top of the visit, the previous visit's stores) has had most of a visit to finish -- so
 // the stores themselves stay in flight across the barrier.
 typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(3))) int8_t* lds_i8_ptr;
 // All of them address memory as (wave-uniform base in scalar registers) + (lane offset in
 // one vector register) + immediate: no 64-bit vector address arithmetic.
 __device__ __forceinline__ void dma_1k(const double* src, uint32_t lane16, double* dst_lds) {
@@ -769,7 +806,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
       // table's second wave instead of M byte loads by every wave (round 5: a vector-memory
       // instruction costs these walks 50-150 clocks of issue whatever it moves)
       if (second && lane < kTipBytes / 4) {
-        const int8_t* ts = a.tip_states + (size_t)ch * tip_stride + p0_wg;
+        const int8_t* ts = sgpr_ptr(a.tip_states + (size_t)ch * tip_stride + p0_wg);
         const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)(ops_lds[buf][c] + 4 * 128);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"((uint32_t)lane * 4), "s"(ts), "s"(m0) : "memory");
       }
@@ -783,7 +820,8 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
   // the states of a tip child, this lane's M patterns: from the bytes stage() put behind the
   // child's table (read first thing in the visit, used after the next visit's requests)
   auto tip_states_of = [&](int buf, int c, int (&x)[M]) {
-    const int8_t* ts = reinterpret_cast<const int8_t*>(ops_lds[buf][c] + 4 * 128) + wave * (M * 16) + j;
+    // (an explicit LDS pointer: left generic, the byte reads become flat loads in some builds)
+    const lds_i8_ptr ts = (lds_i8_ptr)(lds_ptr)(ops_lds[buf][c] + 4 * 128) + wave * (M * 16) + j;
 #pragma unroll
     for (int u = 0; u < M; u++) x[u] = ts[u * 16];
   };
@@ -961,7 +999,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
               // the ring is full: its oldest entry goes to its arena slot
               const double* old = ring_entry(lo);
               double Lo[M][5];
-              load_tiles<M>(old, lane, Lo);
+              load_tiles_lds<M>(old, lane, Lo);
               const int* ex = reinterpret_cast<const int*>(old + M * kAaTileDoubles);
               int eo[M];
 #pragma unroll
@@ -975,7 +1013,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
               lo = lo + 1;
             }
             double* dstp = ring_entry(dst);
-            store_tiles<M>(dstp, lane, R);
+            store_tiles_lds<M>(dstp, lane, R);
             if (g == 0) {
               int* ex = reinterpret_cast<int*>(dstp + M * kAaTileDoubles);
 #pragma unroll
@@ -1038,7 +1076,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
           int Eb[M];
           if (idx >= lo) {  // in the ring
             const double* src = ring_entry(idx);
-            load_tiles<M>(src, lane, L);
+            load_tiles_lds<M>(src, lane, L);
             const int* ex = reinterpret_cast<const int*>(src + M * kAaTileDoubles);
 #pragma unroll
             for (int u = 0; u < M; u++) Eb[u] = ex[u * 16 + j];
@@ -1446,7 +1484,7 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
       dma_whole<4>(src, lane16, dst);
       // (the tip's states for the workgroup's patterns behind its first table: see aa_post_wg_kernel)
       if (second && lane < kTipBytes / 4) {
-        const int8_t* ts = a.tip_states + (size_t)ch * tip_stride + p0_wg;
+        const int8_t* ts = sgpr_ptr(a.tip_states + (size_t)ch * tip_stride + p0_wg);
         const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)(ops_lds[buf][c] + 4 * 128);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"((uint32_t)lane * 4), "s"(ts), "s"(m0) : "memory");
       }
@@ -1468,7 +1506,8 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
     }
   };
   auto tip_states_of = [&](int buf, int c, int (&x)[M]) {
-    const int8_t* ts = reinterpret_cast<const int8_t*>(ops_lds[buf][c] + 4 * 128) + wave * (M * 16) + j;
+    // (an explicit LDS pointer: left generic, the byte reads become flat loads in some builds)
+    const lds_i8_ptr ts = (lds_i8_ptr)(lds_ptr)(ops_lds[buf][c] + 4 * 128) + wave * (M * 16) + j;
 #pragma unroll
     for (int u = 0; u < M; u++) x[u] = ts[u * 16];
   };
@@ -1519,7 +1558,7 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
   // the other child, whose vector it keeps in registers)
   auto fetch_node = [&](int node, bool load_q, int own_slot) {
     if (load_q) {
-      if (own_slot >= lo) load_tiles<M>(ring_entry(own_slot), lane, qn);
+      if (own_slot >= lo) load_tiles_lds<M>(ring_entry(own_slot), lane, qn);
       else load_tiles<M>(arena + (size_t)(node - n) * arena_stride, lane, qn);
     }
 #pragma unroll
@@ -1686,12 +1725,12 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
         if (dst - lo >= RS) {
           // the ring is full: its oldest entry goes to its node's place in the arena
           double old[M][5];
-          load_tiles<M>(ring_entry(lo), lane, old);
+          load_tiles_lds<M>(ring_entry(lo), lane, old);
           const int old_node = (lo & (RS - 1)) ? ring_node[1] : ring_node[0];
           if (active) store_tiles_async<M>(sgpr_ptr(arena + (size_t)(old_node - n) * arena_stride), lane, old);
           lo = lo + 1;
         }
-        store_tiles<M>(ring_entry(dst), lane, qc);
+        store_tiles_lds<M>(ring_entry(dst), lane, qc);
         if (dst & (RS - 1)) ring_node[1] = ch[c];
         else ring_node[0] = ch[c];
       } else if (active) {

@@ -382,8 +382,12 @@ __device__ __forceinline__ void rooted_recurrences_wave(int n, int lane, const i
 }
 
 // keep: see reduce_tiles_body (the reduced sums in LDS instead of a.ll_part / a.g_part)
-__device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t, double* fin_lds,
-                                              const double* keep = nullptr) {
+// (LDS, ROOTED: LDS and ROOTED as compile-time constants -- with either left a run-time
+// value the working-set pointers are "LDS or global" selects, and every access through them a
+// flat instruction on the dependent chains of this kernel: 156 of them until round 5)
+template <bool LDS, bool ROOTED>
+__device__ __forceinline__ void finalize_body_t(const FinalizeArgs& a, const int t, double* fin_lds,
+                                                const double* keep) {
   // One wave per tree: lanes run over nodes / tiles for the reductions, lane 0
   // walks the O(n) recurrences of the rooted chain rule.  Working set (6n doubles, for
   // rooted trees also the tree's heights, bounds, ratios, rates and the ratio gradient
@@ -391,12 +395,12 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t
   // load there costs ten LDS reads) in LDS unless the tree is too large.
   const int lane = threadIdx.x;
   const int n = a.n, N = a.N, T = a.T;
-  double* base = a.use_lds ? fin_lds : a.scratch + (size_t)t * 6 * n;
+  double* base = LDS ? fin_lds : a.scratch + (size_t)t * 6 * n;
   int32_t* c0 = reinterpret_cast<int32_t*>(base);
   int32_t* c1 = c0 + n;
   double* work = base + n;  // 5n doubles
   const SchedEntry* sched = a.sched + (size_t)t * (n - 1);
-  if (a.rooted)  // (only the rooted chain rule and log-det-Jacobian look at the tree)
+  if (ROOTED)  // (only the rooted chain rule and log-det-Jacobian look at the tree)
     for (int i = lane; i < n - 1; i += 64) {
       const SchedEntry se = sched[i];
       c0[se.node - n] = se.child0;
@@ -407,7 +411,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t
   const double* ratios = a.height_ratios ? a.height_ratios + (size_t)t * (n - 1) : nullptr;
   const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
   double* outr_stage = nullptr;
-  if (a.rooted && a.use_lds) {
+  if (ROOTED && LDS) {
     double* stage = fin_lds + 6 * n;  // h[N] | bd[N] | rates[N] | ratios[n] | out[n]
     for (int v = lane; v < N; v += 64) {
       if (h) stage[v] = h[v];
@@ -431,7 +435,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t
     // a logarithm per step: 20 of the 44 microseconds of a one-tree fluA call.  The order of
     // the additions differs from the reference's in the last bits only.)
     double jac = 0.0;
-    if (a.rooted && (a.with_jacobian || (a.gradient && a.gtr))) {
+    if (ROOTED && (a.with_jacobian || (a.gradient && a.gtr))) {
       for (int i = lane; i < n - 1; i += 64) {
         const int v = n + i, a0 = c0[i], a1 = c1[i];
         if (a0 >= n) jac += log(h[v] - bd[a0]);
@@ -487,14 +491,14 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t
     const size_t ep = (size_t)T + (size_t)t * 16 + 2 * coord;
     double lp = sum_tiles(a.ll_part + ep * a.ll_tiles, a.ll_used.of((long)ep));
     double lm = sum_tiles(a.ll_part + (ep + 1) * a.ll_tiles, a.ll_used.of((long)ep + 1));
-    if (a.rooted) {
+    if (ROOTED) {
       lp += jac;
       lm += jac;
     }
     a.out_subst[(size_t)t * 8 + lane] = (lp - lm) / (2. * 1.e-6);
   }
   __syncthreads();
-  if (!a.rooted) {
+  if (!ROOTED) {
     double* ob = a.out_branch + (size_t)t * N;
     // fixed node = second child of the root (fat_beagle.cpp:499); root entry is 0
     for (int v = lane; v < N; v += 64) ob[v] = v < N - 2 ? bg[v] : 0.0;
@@ -608,6 +612,16 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t
   ratio_transform(n, c0, c1, h, ratios, bd, aux, mult, jacg);
   for (int i = 0; i < n - 2; i++) outr[i] += jacg[i] - 1.0 / ratios[i];
   outr[n - 2] += jacg[n - 2];
+  }
+}
+__device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int t, double* fin_lds,
+                                              const double* keep = nullptr) {
+  if (a.use_lds) {
+    if (a.rooted) finalize_body_t<true, true>(a, t, fin_lds, keep);
+    else finalize_body_t<true, false>(a, t, fin_lds, keep);
+  } else {
+    if (a.rooted) finalize_body_t<false, true>(a, t, fin_lds, keep);
+    else finalize_body_t<false, false>(a, t, fin_lds, keep);
   }
 }
 

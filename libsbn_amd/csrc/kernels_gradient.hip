@@ -1005,11 +1005,16 @@ __global__ __launch_bounds__(1024) void macro_slots_wg_kernel(const MacroEntry* 
   const int t = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
   const int Mmax = max_macros(n), S = max_stored(n);
   MacroEntry* ent = reinterpret_cast<MacroEntry*>(slot_scratch);
-  volatile uint64_t* Lw = reinterpret_cast<volatile uint64_t*>(slot_scratch + (size_t)Mmax * 16);
-  volatile uint64_t* Dw = Lw + Mmax;  // ready << 63 | expanded << 62 | slot << 32 | start
-  volatile int32_t* mac_of = reinterpret_cast<volatile int32_t*>(Dw + Mmax);  // stored id -> macro
-  volatile int32_t* order = mac_of + S;
-  volatile int32_t* base = order + Mmax;  // arena index of a position's first input
+  // (typed as LDS pointers: volatile accesses through generic pointers stay flat instructions)
+#define MS_LDS(T) volatile __attribute__((address_space(3))) T*
+  typedef __attribute__((address_space(3))) int32_t* ms_lds_base;
+  const ms_lds_base ms3 = (ms_lds_base)slot_scratch;
+  MS_LDS(uint64_t) Lw = (MS_LDS(uint64_t))(ms3 + (size_t)Mmax * 16);
+  MS_LDS(uint64_t) Dw = Lw + Mmax;  // ready << 63 | expanded << 62 | slot << 32 | start
+  MS_LDS(int32_t) mac_of = (MS_LDS(int32_t))(Dw + Mmax);  // stored id -> macro
+  MS_LDS(int32_t) order = mac_of + S;
+  MS_LDS(int32_t) base = order + Mmax;  // arena index of a position's first input
+#undef MS_LDS
   const int M = macro_count[t];
   if (M <= 0) {
     if (tid == 0) need[t] = 0;

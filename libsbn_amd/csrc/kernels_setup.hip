@@ -251,14 +251,20 @@ __global__ __launch_bounds__(kSetupMaxThreads) void tree_setup_wg_kernel(TreeSet
   const int n = a.n, N = 2 * n - 1;
   const int nodes_in = a.rooted ? N : N - 1, root_in = nodes_in - 1;
   const int32_t* par_in = a.parent_ids + (size_t)t * (nodes_in - 1);
-  // (64-bit and 128-bit arrays first: alignment)
-  volatile int4* kid = reinterpret_cast<volatile int4*>(ts_lds);                 // {k0, k1, k2, count}
-  volatile uint64_t* W = reinterpret_cast<volatile uint64_t*>(ts_lds + 4 * N);  // bottom-up word
-  volatile uint64_t* D = W + N;                                                  // top-down word
-  volatile int2* cc = reinterpret_cast<volatile int2*>(D + N);   // {c0, c1 | first0 << 30}
-  volatile int2* up = cc + N;                                    // {parent, offsets} of the reshaped tree
-  volatile int32_t* par = reinterpret_cast<volatile int32_t*>(up + N);
-  volatile int32_t* sslot = par + N;
+  // (64-bit and 128-bit arrays first: alignment.  The pointers are TYPED as LDS pointers: a
+  // volatile access through a generic pointer stays a flat instruction -- 105 of them in this
+  // kernel until round 5, each on the dependent chain of a round)
+#define TS_LDS(T) volatile __attribute__((address_space(3))) T*
+  typedef __attribute__((address_space(3))) int32_t* ts_lds_base;
+  const ts_lds_base ts3 = (ts_lds_base)ts_lds;
+  TS_LDS(int4) kid = (TS_LDS(int4))ts3;                 // {k0, k1, k2, count}
+  TS_LDS(uint64_t) W = (TS_LDS(uint64_t))(ts3 + 4 * N);  // bottom-up word
+  TS_LDS(uint64_t) D = W + N;                            // top-down word
+  TS_LDS(int2) cc = (TS_LDS(int2))(D + N);               // {c0, c1 | first0 << 30}
+  TS_LDS(int2) up = cc + N;                              // {parent, offsets} of the reshaped tree
+  TS_LDS(int32_t) par = (TS_LDS(int32_t))(up + N);
+  TS_LDS(int32_t) sslot = par + N;
+#undef TS_LDS
   int32_t* kid_i = ts_lds;
   SchedEntry* sched = a.sched + (size_t)t * (n - 1);
   double* ble = a.bl_eff + (size_t)t * N;

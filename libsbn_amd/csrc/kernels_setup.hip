@@ -239,6 +239,10 @@ __device__ __forceinline__ int up_cls(uint64_t w) { return (int)(w >> 56) & 3; }
 __device__ __forceinline__ int up_label(uint64_t w) { return (int)(w >> 48) & 0xff; }
 __device__ __forceinline__ int up_isz(uint64_t w) { return (int)(w >> 20) & 0xfffff; }
 __device__ __forceinline__ int up_mxl(uint64_t w) { return (int)w & 0xfffff; }
+// (the 1024-thread bound leaves 128 registers per lane and 52 values spill; an instance bounded
+// at 256 threads for trees of up to 256 taxa -- 228 registers, no scratch -- measured SLOWER:
+// fluA one tree 0.0928 against 0.0896 ms, x 1000 0.315 against 0.310: the spills are not on
+// the rounds' dependent chains, the occupancy is)
 __global__ __launch_bounds__(kSetupMaxThreads) void tree_setup_wg_kernel(TreeSetupArgs a, ModelSetupArgs ms) {
   const int tid = threadIdx.x, nthreads = blockDim.x;
   if ((int)blockIdx.x >= a.T) {

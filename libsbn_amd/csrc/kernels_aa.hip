@@ -1594,19 +1594,23 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
 #define AA_PSTAMP(k)
 #define AA_PIN(arr)
 #endif
+  SchedEntry ahead = count > 1 ? win.at(count - 2) : SchedEntry{-1, -1, -1, 0};
   for (int i = count - 1; i >= 0; i--) {
     const int buf = i & 1;
     if (ch[0] < n) tip_states_of(buf, 0, xc[0]);
     if (ch[1] < n) tip_states_of(buf, 1, xc[1]);
     int next = -1, nc0 = -1, nc1 = -1, nslots = 0;
     if (i > 0) {
-      if (i - 1 < win.base) fill_upto(i - 1);
-      const SchedEntry s1 = win.at(i - 1);
-      next = sgpr(s1.node);
-      nc0 = sgpr(s1.child0);
-      nc1 = sgpr(s1.child1);
-      nslots = sgpr(s1.slots);
+      // (the entry of visit i - 1 was read from the LDS window during visit i + 1)
+      next = sgpr(ahead.node);
+      nc0 = sgpr(ahead.child0);
+      nc1 = sgpr(ahead.child1);
+      nslots = sgpr(ahead.slots);
       stage(nc0, nc1, buf ^ 1);
+      if (i > 1) {
+        if (i - 2 < win.base) fill_upto(i - 2);
+        ahead = win.at(i - 2);
+      }
     }
     AA_PSTAMP(0);  // schedule entry, operand DMA of the next visit issued
 #pragma unroll

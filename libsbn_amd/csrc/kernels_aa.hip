@@ -25,8 +25,8 @@
 // Measured (tools/fp64_peak_probe.hip, profiles/r02_fp64_peak_probe.txt): this 16+4 mix
 // sustains 69-71 TFLOP/s device-wide at >= 2 waves per SIMD, the same as 4x4x4 alone, with
 // 2.5x fewer instructions; 16x16x4 alone (rows padded to 32) reaches 34-49.
-// Transition matrices are pre-packed by aa_transition_kernel as A operands (10 registers
-// per matrix), tips are compact states: a tip child's product is a gather of a COLUMN of P.
+// Transition matrices are pre-packed by aa_transition_kernel as A operands (kAaPack: five
+// registers of 64 lanes + five blocks of 16 values per matrix), tips are compact states: a tip child's product is a gather of a COLUMN of P.
 // Rescaling is by exact powers of two per (pattern, category) column at every internal
 // node (the column sum's exponent, obtained in all four lanes of the column by one more
 // 4x4x4 product with a ones matrix).
@@ -46,6 +46,32 @@ using namespace dev;
 
 typedef double double4v __attribute__((ext_vector_type(4)));
 typedef double double2v __attribute__((ext_vector_type(2)));
+
+// Which matrix entry a pack's element `idx` holds (kAaPack, mi_phylo_kernels.h): elements
+// 0..319 are register t = idx >> 6 of lane l = idx & 63 for the 16x16x4 steps -- A[i = l & 15]
+// [k = l >> 4] = entry (row l & 15, column 4 t + (l >> 4)); elements 320..399 are the 4x4x4
+// steps' 16 values per step t -- value (g, i) at 320 + 16 t + 4 g + i = entry (row 16 + i,
+// column 4 t + g), which lane l of that instruction reads with g = l >> 4, i = l & 3.
+struct AaPackEntry {
+  int row, col;
+  bool used;
+};
+__device__ __forceinline__ AaPackEntry aa_pack_entry(int idx) {
+  if (idx < kAaPackRows16) {
+    const int t = idx >> 6, l = idx & 63;
+    return {l & 15, 4 * t + (l >> 4), true};
+  }
+  const int e = idx - kAaPackRows16, t = e >> 4, g = (e >> 2) & 3, i = e & 3;
+  return {16 + i, 4 * t + g, e < 80};
+}
+// the ten A-operand registers of this lane from a pack (global memory or LDS)
+__device__ __forceinline__ void pack_operands(const double* __restrict__ pack, int lane, double (&A)[10]) {
+  const int tail = kAaPackRows16 + 4 * (lane >> 4) + (lane & 3);
+#pragma unroll
+  for (int r = 0; r < 5; r++) A[r] = pack[r * 64 + lane];
+#pragma unroll
+  for (int t = 0; t < 5; t++) A[5 + t] = pack[tail + 16 * t];
+}
 
 // ------------------------------------------------------------------------
 // Model set-up: Q from (exchangeabilities, frequencies) by the reference's GTR recipe
@@ -168,10 +194,8 @@ __global__ __launch_bounds__(64) void aa_model_setup_kernel(const double* exch,
     m->Vinv[idx] = U[j * kAa + i] * sq[j];
   }
   for (int idx = lane; idx < kAaPack; idx += 64) {  // Q in the A-operand layout (below)
-    const int r = idx >> 6, l = idx & 63, g = l >> 4;
-    const int t = r < 5 ? r : r - 5;
-    const int row = r < 5 ? (l & 15) : 16 + (l & 3), col = 4 * t + g;
-    m->Qpack[idx] = Q[row * kAa + col];
+    const AaPackEntry pe = aa_pack_entry(idx);
+    m->Qpack[idx] = pe.used ? Q[pe.row * kAa + pe.col] : 0.0;
   }
 }
 
@@ -222,11 +246,9 @@ __global__ __launch_bounds__(256) void aa_transition_kernel(AaTransitionArgs a) 
   } else {
     const size_t base = (((size_t)el * (a.n - 1) + (edge - a.n)) * a.K + k) * kAaPack;
     for (int idx = tid; idx < kAaPack; idx += 256) {
-      const int r = idx >> 6, l = idx & 63, g = l >> 4;
-      const int t = r < 5 ? r : r - 5;
-      const int row = r < 5 ? (l & 15) : 16 + (l & 3), col = 4 * t + g;
-      a.matP[base + idx] = Pm[row * kAa + col];
-      if (a.gradient) a.matPT[base + idx] = Pm[col * kAa + row];
+      const AaPackEntry pe = aa_pack_entry(idx);
+      a.matP[base + idx] = pe.used ? Pm[pe.row * kAa + pe.col] : 0.0;
+      if (a.gradient) a.matPT[base + idx] = pe.used ? Pm[pe.col * kAa + pe.row] : 0.0;
     }
   }
 }
@@ -277,8 +299,7 @@ __device__ __forceinline__ void mat_apply(const double (&A)[10], const double (&
 
 __device__ __forceinline__ void load_pack(const double* __restrict__ pack, int lane,
                                           double (&A)[10]) {
-#pragma unroll
-  for (int r = 0; r < 10; r++) A[r] = pack[r * 64 + lane];
+  pack_operands(pack, lane, A);
 }
 
 // compact states of a tip for this lane's pattern column of each tile (20 = gap / padding)
@@ -412,7 +433,7 @@ __device__ __forceinline__ AaUnit aa_unit(int blocks, int units) {
 
 // The schedule of a tree in LDS, a window of kSchedWindow entries at a time (a wave looks
 // two visits ahead); one wave per workgroup, so the window is private to the wave.
-constexpr int kSchedWindow = 256;
+constexpr int kSchedWindow = 128;  // (2 KB: with the ring's 21 KB four log-likelihood workgroups fit a CU)
 struct SchedWindow {
   const SchedEntry* sched;  // the tree's n-1 entries in HBM
   SchedEntry* lds;
@@ -739,7 +760,8 @@ constexpr int kPreWaves = 4, kPreThreads = 64 * kPreWaves;
 template <int M, bool GRAD>
 __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_kernel(AaWalkArgs a) {
   __shared__ SchedEntry sched_lds[kSchedWindow];
-  __shared__ double ops_lds[2][2][kAaPack];  // [buffer][child][640]: pack, or tip table (420)
+  __shared__ double ops_lds[2][2][kAaPack];  // [buffer][child][512]: pack (400), or tip table (420)
+  __shared__ int8_t tips_lds[2][2][kPostWaves * M * 16];  // [buffer][child]: a tip child's states
   // Log-likelihood form (round 5): the TOP of the wave's stack of kept
   // vectors lives in LDS.  A post-order walk keeps vectors in stack order -- the schedule's slot
   // number of a kept vector IS its stack position (tree set-up hands out the lowest free slot,
@@ -788,7 +810,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
   fill(0);
 
   // staging of one visit's shared operands into LDS buffer `buf` by LDS-DMA: a child's pack
-  // (5 pieces of 1 KB) or, for a tip, its column table (3 360 B: 4 pieces, the tail of the
+  // (4 pieces of 1 KB) or, for a tip, its column table (3 360 B: 4 pieces, the tail of the
   // last one is the next table's head -- the arrays are padded by one piece)
   const int wave_s = sgpr(wave);
   auto stage = [&](int c0, int c1, int buf) {
@@ -801,27 +823,24 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
     if (ch < n) {
       const double* src = tipP + (size_t)ch * K * kAaTipTable + (second ? 2 * 128 : 0);
       dma_run<2>(src, lane16, ops_lds[buf][c] + (second ? 2 * 128 : 0));
-      // the tip's states for the workgroup's patterns (kTipBytes of them) behind the table, in
-      // the fifth piece of the slot that only a matrix pack uses: ONE 4-byte LDS-DMA by the
-      // table's second wave instead of M byte loads by every wave (round 5: a vector-memory
+      // the tip's states for the workgroup's patterns (kTipBytes of them): ONE 4-byte LDS-DMA by
+      // the table's second wave instead of M byte loads by every wave (round 5: a vector-memory
       // instruction costs these walks 50-150 clocks of issue whatever it moves)
       if (second && lane < kTipBytes / 4) {
         const int8_t* ts = sgpr_ptr(a.tip_states + (size_t)ch * tip_stride + p0_wg);
-        const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)(ops_lds[buf][c] + 4 * 128);
+        const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)(tips_lds[buf][c]);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"((uint32_t)lane * 4), "s"(ts), "s"(m0) : "memory");
       }
     } else {
-      const double* src = matP + (size_t)(ch - n) * K * kAaPack + (second ? 3 * 128 : 0);
-      double* dst = ops_lds[buf][c] + (second ? 3 * 128 : 0);
-      if (second) dma_run<2>(src, lane16, dst);
-      else dma_run<3>(src, lane16, dst);
+      const double* src = matP + (size_t)(ch - n) * K * kAaPack + (second ? 2 * 128 : 0);
+      dma_run<2>(src, lane16, ops_lds[buf][c] + (second ? 2 * 128 : 0));
     }
   };
   // the states of a tip child, this lane's M patterns: from the bytes stage() put behind the
   // child's table (read first thing in the visit, used after the next visit's requests)
   auto tip_states_of = [&](int buf, int c, int (&x)[M]) {
     // (an explicit LDS pointer: left generic, the byte reads become flat loads in some builds)
-    const lds_i8_ptr ts = (lds_i8_ptr)(lds_ptr)(ops_lds[buf][c] + 4 * 128) + wave * (M * 16) + j;
+    const lds_i8_ptr ts = (lds_i8_ptr)(lds_ptr)(tips_lds[buf][c]) + wave * (M * 16) + j;
 #pragma unroll
     for (int u = 0; u < M; u++) x[u] = ts[u * 16];
   };
@@ -927,8 +946,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
 #pragma unroll
             for (int u = 0; u < M; u++) Ec[c][u] = exp_cum[idx * exp_stride + u * 16 + j];
           }
-#pragma unroll
-          for (int r = 0; r < 10; r++) A[r] = shared[r * 64 + lane];
+          pack_operands(shared, lane, A);
           mat_apply<M>(A, L, S[c]);
         }
       }
@@ -1057,8 +1075,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
         int Es[M];
         {
           double A[10];
-#pragma unroll
-          for (int r = 0; r < 10; r++) A[r] = ops_a[r * 64 + lane];
+          pack_operands(ops_a, lane, A);
           mat_apply<M>(A, R, SA);
         }
         if (chb < n) {
@@ -1094,8 +1111,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
               for (int t = 0; t < 5; t++) asm volatile("" : "+v"(L[u][t]));
             }
           }
-#pragma unroll
-          for (int r = 0; r < 10; r++) A[r] = ops_b[r * 64 + lane];
+          pack_operands(ops_b, lane, A);
           mat_apply<M>(A, L, SB);
 #pragma unroll
           for (int u = 0; u < M; u++) Es[u] = E[u] + Eb[u];
@@ -1403,7 +1419,7 @@ __global__ __launch_bounds__(64) void aa_pre_kernel(AaWalkArgs a) {
 
 // ------------------------------------------------------------------------
 // Pre-order + derivatives, workgroup form (see aa_post_wg_kernel): the three matrices of
-// an internal child (P, P Q, P^T: 15 KB) or the two column tables of a tip child are staged
+// an internal child (P, P^T: 8 KB) or the two column tables of a tip child are staged
 // in LDS once per workgroup of four pattern blocks, one visit ahead.
 //
 // Round 5: the top of the stack of pending pre-order vectors in LDS.  A visit hands the
@@ -1431,6 +1447,7 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
   double* q_lds = pre_lds + 2 * 2 * kPreOps;
   SchedEntry* sched_lds = reinterpret_cast<SchedEntry*>(q_lds + kAaPack);
   double* ring_lds = reinterpret_cast<double*>(sched_lds + kSchedWindow);  // [wave][S][M tiles x 320]
+  __shared__ int8_t tips_lds[2][2][kPreWaves * M * 16];  // [buffer][child]: a tip child's states
   const int blocks = a.tiles / M;
   const int wgs = (blocks + kPreWaves - 1) / kPreWaves;
   const AaUnit un = aa_unit(wgs, a.evals * a.K);
@@ -1468,7 +1485,7 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
   };
   fill_upto(count - 1);
 
-  // staging by LDS-DMA into buffer `buf`: internal child P | P^T (2 x 5 pieces), tip child
+  // staging by LDS-DMA into buffer `buf`: internal child P | P^T (2 x 4 pieces), tip child
   // its two column tables (2 x 4 pieces) at offsets 0 and kAaPack
   const int wave_s = sgpr(wave);
   const uint32_t lane16 = (uint32_t)lane * 16;
@@ -1482,21 +1499,18 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
     if (ch < n) {
       const double* src = (second ? tipPQ : tipP) + (size_t)ch * K * kAaTipTable;
       dma_whole<4>(src, lane16, dst);
-      // (the tip's states for the workgroup's patterns behind its first table: see aa_post_wg_kernel)
+      // (the tip's states for the workgroup's patterns: see aa_post_wg_kernel)
       if (second && lane < kTipBytes / 4) {
         const int8_t* ts = sgpr_ptr(a.tip_states + (size_t)ch * tip_stride + p0_wg);
-        const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)(ops_lds[buf][c] + 4 * 128);
+        const uint32_t m0 = (uint32_t)(uintptr_t)(lds_ptr)(tips_lds[buf][c]);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"((uint32_t)lane * 4), "s"(ts), "s"(m0) : "memory");
       }
     } else {
       const double* src = (second ? matPT : matP) + (size_t)(ch - n) * K * kAaPack;
-      dma_whole<5>(src, lane16, dst);
+      dma_whole<4>(src, lane16, dst);
     }
   };
-  auto lds_pack = [&](const double* base, double (&A)[10]) {
-#pragma unroll
-    for (int r = 0; r < 10; r++) A[r] = base[r * 64 + lane];
-  };
+  auto lds_pack = [&](const double* base, double (&A)[10]) { pack_operands(base, lane, A); };
   auto lds_cols = [&](const double* table, const int (&x)[M], double (&S)[M][5]) {
 #pragma unroll
     for (int u = 0; u < M; u++) {
@@ -1507,7 +1521,7 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
   };
   auto tip_states_of = [&](int buf, int c, int (&x)[M]) {
     // (an explicit LDS pointer: left generic, the byte reads become flat loads in some builds)
-    const lds_i8_ptr ts = (lds_i8_ptr)(lds_ptr)(ops_lds[buf][c] + 4 * 128) + wave * (M * 16) + j;
+    const lds_i8_ptr ts = (lds_i8_ptr)(lds_ptr)(tips_lds[buf][c]) + wave * (M * 16) + j;
 #pragma unroll
     for (int u = 0; u < M; u++) x[u] = ts[u * 16];
   };
@@ -1861,18 +1875,17 @@ static bool aa_post_wg() {
 }
 // Entries of the LDS ring a log-likelihood wave keeps the top of its vector stack in
 // (aa_post_wg_kernel); MI_PHYLO_AA_RING=0|1|2|4 overrides (0: every kept vector through the
-// arena, the form until round 4).  Measured, eight 512 x 50 000 x 4 trees per launch
-// (tools/bench_aa.py --mode loglik): 17.7 / 17.1-17.3 / 19.3 ms with 0 / 1 / 2 entries -- an
-// entry is 5 KB per wave, 21 KB per workgroup, and every entry costs a workgroup per CU (4 / 3 /
-// 2 fit): the kernel is bound by the vector pipe, not by the 42 + 42 GB of arena
-// traffic the ring removes (67 % of it with one entry, 90 % with two).  ONE entry is the
-// default for launches of three rounds of workgroups and more: less than a third of the HBM
-// traffic and 2-3 % less time; smaller launches (one tree: 1.5 rounds at four per CU, two at
-// three) keep four workgroups per CU and the arena.
+// arena, the form until round 4).  An entry is 5 KB per wave, 21 KB per workgroup; since the
+// operand packs are four pieces instead of five and the schedule window 2 KB, ONE entry fits
+// beside them at the four workgroups per CU the registers allow (39.9 KB each), so one entry
+// is the default for every launch: less than a third of the arena's HBM traffic (67 % of the
+// kept vectors never have another pushed on top of them) and 2-3 % less time; two entries
+// cost a workgroup per CU and lose.
 static int aa_ring_slots(size_t workgroups) {
   static const int forced = getenv("MI_PHYLO_AA_RING") ? atoi(getenv("MI_PHYLO_AA_RING")) : -1;
   if (forced == 0 || forced == 1 || forced == 2 || forced == 4) return forced;  // (powers of two)
-  return workgroups >= 3 * 4 * (size_t)device_compute_units() ? 1 : 0;
+  (void)workgroups;
+  return 1;
 }
 // (what launch_aa_post / launch_aa_pre will choose: for the engine's description of a call)
 int aa_post_ring_entries(const AaWalkArgs& a) {

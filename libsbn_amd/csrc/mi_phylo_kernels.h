@@ -303,7 +303,12 @@ constexpr int kAa = 20;              // states
 constexpr int kAaTile = 16;          // site patterns per matrix-core tile
 constexpr int kAaTipSlack = 512;     // bytes behind the tip-state rows (a workgroup fetches its whole pattern range)
 constexpr int kAaTileDoubles = 320;  // one tile of one category: 5 registers x 64 lanes
-constexpr int kAaPack = 640;         // one 20x20 matrix as matrix-core A operands: 10 registers x 64 lanes
+// one 20x20 matrix as matrix-core A operands: rows 0..15 as five registers x 64 lanes (320
+// doubles), rows 16..19 as five blocks of 16 values (a 4x4x4 A operand repeats its 16 values
+// in each of the instruction's four blocks: round 5 stores them once) -- 400 doubles, in a
+// stride of 512 = four 1 KB pieces of LDS-DMA (until round 5: 10 x 64 = 640, five pieces)
+constexpr int kAaPack = 512;
+constexpr int kAaPackRows16 = 320;   // offset of the rows-16..19 part
 constexpr int kAaTipTable = 21 * 20; // per tip edge and category: column of the matrix per state, 20 = gap
 constexpr int kAaPreTiles = 2;       // tiles a wave of the pre-order kernel takes (post-order: 2 or 4)
 
@@ -315,7 +320,7 @@ struct AaModel {
   double Q[kAa * kAa];     // row-major, normalised to one expected substitution per unit time
   double V[kAa * kAa];     // eigenvectors
   double Vinv[kAa * kAa];  // inverse eigenvectors
-  double Qpack[kAaPack];   // Q as a matrix-instruction A operand (10 registers x 64 lanes)
+  double Qpack[kAaPack];   // Q as matrix-instruction A operands (the pack layout above)
 };
 
 struct AaTransitionArgs {

@@ -875,7 +875,7 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
   for (int u = 0; u < M; u++) eloc[u] = 0;
   // the ring of this wave; lo: first slot that lives in it (slots below are in the arena)
   constexpr int kRingEntry = M * (kAaTileDoubles + 8);  // doubles per entry (16 ints = 8 doubles per tile)
-  const int RS = GRAD ? 0 : sgpr(a.ring_slots);
+  const int RS = sgpr(a.ring_slots);
   double* const ring = ring_lds + (size_t)sgpr(wave) * RS * kRingEntry;
   int lo = RS > 0 ? 0 : 0x7fffffff;
   // (ring sizes are powers of two: launch_aa_post)
@@ -941,10 +941,21 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
               for (int t = 0; t < 5; t++) L[u][t] = R[u][t];
             }
           } else {
-            const int idx = ch - n;
-            load_tiles<M>(arena + idx * arena_stride, lane, L);
+            // (round 5: a vector that was left on the stack is ALSO in the LDS ring while it is
+            // near the top -- the arena copy is for the pre-order kernel, this read need not
+            // fetch it back: 44 of the launch's 200 GB)
+            const int idx = ch - n, slot = (slots >> (8 + 8 * c)) & 0xff;
+            if (slot >= lo) {
+              const double* src = ring_entry(slot);
+              load_tiles_lds<M>(src, lane, L);
+              const int* ex = reinterpret_cast<const int*>(src + M * kAaTileDoubles);
 #pragma unroll
-            for (int u = 0; u < M; u++) Ec[c][u] = exp_cum[idx * exp_stride + u * 16 + j];
+              for (int u = 0; u < M; u++) Ec[c][u] = ex[u * 16 + j];
+            } else {
+              load_tiles<M>(arena + idx * arena_stride, lane, L);
+#pragma unroll
+              for (int u = 0; u < M; u++) Ec[c][u] = exp_cum[idx * exp_stride + u * 16 + j];
+            }
           }
           pack_operands(shared, lane, A);
           mat_apply<M>(A, L, S[c]);
@@ -966,7 +977,21 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
         double* dstp = arena + (size_t)(prev - n) * arena_stride;
         if (prev == ch0) store_tiles_async<M>(dstp, lane, S[0]);
         else if (prev == ch1) store_tiles_async<M>(dstp, lane, S[1]);
-        else store_tiles_async<M>(dstp, lane, R);
+        else {
+          store_tiles_async<M>(dstp, lane, R);
+          if (RS > 0) {  // left on the stack: into the ring as well (an entry pushed out is simply dropped)
+            const int dst = prev_slots & 0xff;
+            if (dst < lo) lo = dst;
+            if (dst - lo >= RS) lo = lo + 1;
+            double* rp = ring_entry(dst);
+            store_tiles_lds<M>(rp, lane, R);
+            if (g == 0) {
+              int* ex = reinterpret_cast<int*>(rp + M * kAaTileDoubles);
+#pragma unroll
+              for (int u = 0; u < M; u++) ex[u * 16 + j] = E[u];
+            }
+          }
+        }
         if (g == 0) {
 #pragma unroll
           for (int u = 0; u < M; u++) {
@@ -1889,7 +1914,7 @@ static int aa_ring_slots(size_t workgroups) {
 }
 // (what launch_aa_post / launch_aa_pre will choose: for the engine's description of a call)
 int aa_post_ring_entries(const AaWalkArgs& a) {
-  if (a.gradient || !aa_post_wg()) return 0;
+  if (!aa_post_wg()) return 0;
   const int m = aa_post_tiles(a), blocks = a.tiles / m;
   int entries = aa_ring_slots(aa_grid((blocks + kPostWaves - 1) / kPostWaves, a.evals * a.K));
   // (a forced size must still fit a CU beside the 24.5 KB of operand buffers and schedule)

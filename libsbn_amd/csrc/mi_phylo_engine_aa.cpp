@@ -230,8 +230,8 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   e->dominant = d.gradient ? aa_pre_kernel_name() : aa_post_kernel_name();
   // (the stack tops of the walks live in LDS rings: kernels_aa.hip)
   e->last_path = std::string(e->dominant) + " store=hbm-arena" +
-                 (d.gradient ? " pre-ring=" + std::to_string(aa_pre_ring_entries())
-                             : " post-ring=" + std::to_string(post_ring)) +
+                 " post-ring=" + std::to_string(post_ring) +
+                 (d.gradient ? " pre-ring=" + std::to_string(aa_pre_ring_entries()) : std::string()) +
                  " states=20 K=" + std::to_string(e->K);
   e->last_evals = T;
   e->last_grad_evals = d.gradient ? T : 0;

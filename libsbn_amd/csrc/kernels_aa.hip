@@ -993,10 +993,12 @@ __global__ __launch_bounds__(64 * kPostWaves, M == 4 ? 3 : 4) void aa_post_wg_ke
           }
         }
         if (g == 0) {
+          // (the cumulative exponent is read back only for a node that was left on the stack)
+          const bool stacked = prev != ch0 && prev != ch1;
 #pragma unroll
           for (int u = 0; u < M; u++) {
             store_async(exp_loc + (size_t)(prev - n) * exp_stride, u * 16 + j, eloc[u]);
-            store_async(exp_cum + (size_t)(prev - n) * exp_stride, u * 16 + j, E[u]);
+            if (stacked) store_async(exp_cum + (size_t)(prev - n) * exp_stride, u * 16 + j, E[u]);
           }
         }
       }
@@ -1750,10 +1752,8 @@ __global__ __launch_bounds__(64 * kPreWaves, AA_PRE_MIN_WGS) void aa_pre_wg_kern
         for (int t = 0; t < 5; t++) q[u][t] = qn[u][t];
     }
     AA_PSTAMP(4);  // the visit's wait
-    if (lane == 0 && active) {
-      store_async(gp + ch[0], 0, X[0]);
-      store_async(gp + ch[1], 0, X[1]);
-    }
+    // (both edge sums with ONE store instruction: lane 0 child 0's, lane 1 child 1's)
+    if (lane < 2 && active) store_async(gp, lane ? ch[1] : ch[0], lane ? X[1] : X[0]);
     // q_c = P_c^T u_c for internal children: into the arena, or handed to the next visit
 #pragma unroll
     for (int c = 0; c < 2; c++) {

@@ -350,6 +350,21 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
 #endif
   };
 
+  // W3_SPLIT_FETCH: child 0's operands are requested at the top of the visit before, child 1's
+  // from that visit's middle (behind its LDS reads): two shorter bursts of loads instead of one
+  // (a wave stalls in the issue of a load while the CU's address path is full: DESIGN.md 4.1)
+#ifndef W3_SPLIT_FETCH
+#define W3_SPLIT_FETCH 0
+#endif
+  constexpr bool kSplitFetch = W3_SPLIT_FETCH != 0;
+  auto fetch_j = [&](auto pre_tag, auto jtag, int m, int sh, const Tw& tw, auto& o) {
+    const char* sb = mm_g + (size_t)((unsigned)m * kVisit);
+    unsigned off4 = 4 * kPos;
+    asm volatile("" : "+s"(off4));
+    const char* sb4 = sb + off4;
+    fetch_child(pre_tag, jtag, sh, tw, sb, sb4, o);
+  };
+
   // ONE wait per visit for operands.  How many loads a fetch issues depends on the visit's
   // shape, so the compiler cannot count them: left alone it waits with vmcnt(0) at the first
   // use of a visit's operands -- i.e. also for the NEXT visit's operands requested just before,
@@ -625,7 +640,9 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       Early ea;
       if (kEarlyLds) early_loads(false, s0, la, ea);
       settle(a0, a1);
-      fetch(Post{}, min(m + 1, M1), s1, tw, b0, b1);
+      const Tw tw_a = tw;
+      if (kSplitFetch) fetch_j(Post{}, J0{}, min(m + 1, M1), s1, tw_a, b0);
+      else fetch(Post{}, min(m + 1, M1), s1, tw, b0, b1);
       tw = fetch_tw(min(m + 2, M1));
       int s3;
       auto req = [&]() {
@@ -635,6 +652,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       if (kScalars == 1) req();
       post_visit(Inner{}, s0, la, a0, a1, 0, ea, [&]() {
         if (kScalars == 2) req();
+        if (kSplitFetch) fetch_j(Post{}, J1{}, min(m + 1, M1), s1, tw_a, b1);
       });
       if (kScalars == 0) req();
       s0 = s1;
@@ -645,7 +663,9 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
         Early eb;
         if (kEarlyLds) early_loads(false, s0, lb, eb);
         settle(b0, b1);
-        fetch(Post{}, min(m + 2, M1), s1, tw, a0, a1);
+        const Tw tw_b = tw;
+        if (kSplitFetch) fetch_j(Post{}, J0{}, min(m + 2, M1), s1, tw_b, a0);
+        else fetch(Post{}, min(m + 2, M1), s1, tw, a0, a1);
         tw = fetch_tw(min(m + 3, M1));
         int s4;
         auto req = [&]() {
@@ -655,6 +675,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
         if (kScalars == 1) req();
         post_visit(Inner{}, s0, lb, b0, b1, 0, eb, [&]() {
           if (kScalars == 2) req();
+          if (kSplitFetch) fetch_j(Post{}, J1{}, min(m + 2, M1), s1, tw_b, a1);
         });
         if (kScalars == 0) req();
         s0 = s1;
@@ -807,7 +828,9 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       Early eb;
       if (kEarlyLds) early_loads(true, s0, lb, eb);
       settle(b0, b1);
-      fetch(Pre{}, dn(m - 1), s1, tw, a0, a1);
+      const Tw tw_b = tw;
+      if (kSplitFetch) fetch_j(Pre{}, J0{}, dn(m - 1), s1, tw_b, a0);
+      else fetch(Pre{}, dn(m - 1), s1, tw, a0, a1);
       tw = fetch_tw(dn(m - 2));
       int s3;
       auto req = [&]() {
@@ -817,6 +840,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       if (kScalars == 1) req();
       pre_visit(Inner{}, s0, lb, b0, b1, m, eb, [&]() {
         if (kScalars == 2) req();
+        if (kSplitFetch) fetch_j(Pre{}, J1{}, dn(m - 1), s1, tw_b, a1);
       });
       if (kScalars == 0) req();
       s0 = s1;
@@ -827,7 +851,9 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
         Early ea;
         if (kEarlyLds) early_loads(true, s0, la, ea);
         settle(a0, a1);
-        fetch(Pre{}, dn(m - 2), s1, tw, b0, b1);
+        const Tw tw_a = tw;
+        if (kSplitFetch) fetch_j(Pre{}, J0{}, dn(m - 2), s1, tw_a, b0);
+        else fetch(Pre{}, dn(m - 2), s1, tw, b0, b1);
         tw = fetch_tw(dn(m - 3));
         int s4;
         auto req = [&]() {
@@ -837,6 +863,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
         if (kScalars == 1) req();
         pre_visit(Inner{}, s0, la, a0, a1, m - 1, ea, [&]() {
           if (kScalars == 2) req();
+          if (kSplitFetch) fetch_j(Pre{}, J1{}, dn(m - 2), s1, tw_a, b1);
         });
         if (kScalars == 0) req();
         s0 = s1;

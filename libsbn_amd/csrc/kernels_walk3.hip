@@ -62,42 +62,17 @@ __device__ __forceinline__ double row_ror_add(double v) {
 }
 
 constexpr int R = kLlR;                  // registers (16 columns each) per vector
-constexpr unsigned kTwCol = 32;          // LDS bytes per (macro, column): six words, padded
-constexpr unsigned kTStride = 4 * kTwCol;  // per macro: four pattern columns per register
+// Tip codes in LDS, by (macro, column).  Four categories per instruction (KP = 4: three or four
+// rate categories, four pattern columns per register): six words per column -- one per position,
+// one byte per register: the byte offset of the state's table entry -- padded to 32 bytes.
+// Fewer (KP = 1, 2: a register then holds 16 / 8 pattern columns, and 32 bytes per column and
+// macro would cost waves per CU -- fluA, K = 1: 17 KB of them): the COMPACT form of the second
+// generation, six 16-bit fields per column with a 4-bit state number (0..3, 4 = gap) per register;
+// the byte offset is then one v_bfe + one v_lshl_add instead of one SDWA add.
+constexpr unsigned kTwCol = 32, kTwColCompact = 12;
 constexpr unsigned kPos = 1280u, kVisit = 6u * kPos;
 constexpr unsigned kTipCat = 320u, kTipRow = 80u;
-// where a visit issues its scalar loads (slots of the next visit, shape three ahead): at its
-// top, right behind the operand requests and the LDS read of the tip words, or at its end
-// (W3_SCALARS: 0 at the visit's end, 1 at its top, 2 in its middle -- behind the visit's last
-// LDS read, so that no LDS wait of the visit waits for them and they have the rest of the
-// visit to arrive: scalar loads return out of order, any wait for LDS data with one of them
-// in flight is a wait for everything)
-#ifndef W3_SCALARS
-#define W3_SCALARS 0
-#endif
-constexpr int kScalars = W3_SCALARS;
-// W3_STORE_S: the post-order walk overwrites a stored node's vector L, once its parent's visit
-// has consumed it, with the product S = P L it has just formed; the pre-order walk then reads
-// S instead of recomputing it, and takes the edge's derivative as sum qs . Q S instead of
-// sum (P^T qs) . Q L -- the same number because P and Q commute (what the 20-state kernels
-// do).  36 matrix instructions of a DS1 tile job less and one dependent stage
-// off the visit's chain, for 36 more LDS stores; results then differ from the second
-// generation's in the last bits (P Q against Q P).
-#ifndef W3_STORE_S
-#define W3_STORE_S 0
-#endif
-constexpr bool kStoreS = W3_STORE_S != 0;
-// when a visit reads the stored vectors of its node and of its stored children from LDS: first
-// thing at its top, BEFORE the operand wait and the next visit's requests (their LDS latency
-// then passes under those), or where the visit's arithmetic needs them
-#ifndef W3_EARLY_LDS
-#define W3_EARLY_LDS 0
-#endif
-constexpr bool kEarlyLds = W3_EARLY_LDS != 0;
-// W3_SCHED_REGS: see load_shape / load_slots
-#ifndef W3_SCHED_REGS
-#define W3_SCHED_REGS 0
-#endif
+constexpr unsigned kVecBytes = R * kTile * 8;  // one stored vector of a wave (LDS slot, arena entry)
 
 // operands of one child of a visit (see fetch_child)
 template <bool PRE>
@@ -110,16 +85,31 @@ struct Ops {
 // macro list and the model instance) has been written through to memory, wave 0 adds the macro
 // count in the low byte; the walk waves of the tree wait for kSetupQuarters of them.
 constexpr int kSetupQuarters = 4, kReadyQuarter = 1 << 8;
-// polls before a walk wave gives up (0.2 us apart: a fifth of a second): a set-up wave that
-// never ran is an error (status kFusedTimeout), not a hang
-constexpr int kReadySpins = 1 << 20;
 
-// block: this wave's number among the walk waves of the launch.  FUSED: `ready` is the
-// hand-off word array (above), the launch's first workgroups are set-up waves.
-template <bool RESCALE, bool FUSED>
+// block: this wave's number among the walk waves of the launch.
+//   FUSED: `ready` is the hand-off word array (above), the launch's first workgroups are set-up
+//          waves; `spin_ticks`: how long a walk wave polls (100 MHz ticks) before it gives up.
+//   ARENA (round 6): trees of more than ~45 taxa -- the stored post-order vectors go to a per-wave
+//          HBM arena as well as to a handful of recycled LDS slots (schedule of macro_slots_kernel:
+//          Sethi-Ullman order, the arena index of a node in its `pad` word, of a macro's first
+//          stored input in the upper half of its shape word); the pre-order walk takes them back
+//          from the arena, requested a visit ahead WITH the visit's operands and INTO the operand
+//          group of the child they belong to (a stored input's group has room: see fetch_child),
+//          and recycles the LDS slots for its own vectors.  Same products in the same order as
+//          with every vector in LDS: bit-identical.
+//   KP:    rate categories per matrix instruction (4: K = 3, 4; 2: K = 2; 1: K = 1); a register
+//          holds 16 / KP pattern columns.
+template <bool RESCALE, bool FUSED, bool ARENA, int KP>
 __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, const int block,
-                                              const int32_t* ready) {
-  static_assert(R >= 1 && R <= 4, "a tip word holds one byte per register");
+                                              const int32_t* ready, const int spin_ticks) {
+  static_assert(R >= 1 && R <= 4, "a tip word holds one byte / one 4-bit field per register");
+  static_assert(KP == 1 || KP == 2 || KP == 4, "categories per matrix instruction");
+  static_assert(!(FUSED && ARENA), "the one-launch call keeps its stored vectors in LDS");
+  constexpr bool COMPACT = KP < 4;
+  constexpr int ppr = 16 / KP, TP = ppr * R;
+  constexpr unsigned kCol = COMPACT ? kTwColCompact : kTwCol;
+  constexpr unsigned kTStride = (unsigned)ppr * kCol;  // per macro (>= 96: it also takes the macro's edge sums)
+  static_assert(kTStride >= 96, "a macro's edge sums go where its tip words were");
   const int lane = threadIdx.x;
   const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
   // one tile per wave (several tiles per wave, as the second generation has them, were
@@ -136,19 +126,24 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   const long long w_in = __builtin_amdgcn_s_memrealtime();
 #endif
   if (FUSED) {
-    // Wait for this tree's set-up waves.  Everything they hand over (macro list, operand
-    // records, model instance) lies in cache lines of its own per tree (macro_stride, kVisit,
-    // alignas(128) DevModel) that no wave of this launch reads before the word says so, and was
-    // stored write-through (sc1) and waited for (vmcnt(0)) before the word was added to: the
-    // first touch of such a line after the poll misses every cache of this CU and XCD (they
-    // were invalidated when the kernel started) and is served with the stored bytes.
-    int v = 0, spins = 0;
+    // Wait for this tree's set-up waves: poll the tree's word (relaxed, agent scope), then an
+    // ACQUIRE fence at agent scope (round 6, ADVICE r5: buffer_inv sc1 -- this CU's vector L1 and
+    // whatever of the L2 is not coherent hold nothing older than the word) and an invalidate of
+    // the scalar cache (the macro list is read with scalar loads, which a fence does not cover).
+    // The set-up waves stored everything write-through, waited for it (vmcnt(0)) and passed a
+    // RELEASE fence before they added to the word.  The poll is bounded by WALL-CLOCK time
+    // (s_memrealtime, 100 MHz: a count of polls would shrink under a profiler or pre-emption).
+    int v = 0;
+    const long long t_in = __builtin_amdgcn_s_memrealtime();
     for (;;) {
       v = __builtin_amdgcn_readfirstlane(
           __hip_atomic_load(ready + (size_t)t * kReadyStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if ((v >> 8) >= kSetupQuarters || ++spins >= kReadySpins) break;
+      if ((v >> 8) >= kSetupQuarters) break;
+      if ((long long)__builtin_amdgcn_s_memrealtime() - t_in > (long long)spin_ticks) break;
       __builtin_amdgcn_s_sleep(8);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_dcache_inv" ::: "memory");
     // (-1: waited in vain.  The wave leaves through the one exit below -- a second `return`
     // up here, with its status store, changed how the WHOLE walk is compiled: 224 registers
     // instead of 214 and a wait in front of single operand loads, +34 % time per 1000 trees)
@@ -178,92 +173,97 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     if (j < jmax) node_j[u] = mwv[(j / 6) * 16 + 1 + (j % 6)];
   }
   const int M = FUSED ? M_ready : __builtin_amdgcn_readfirstlane(a.macro_count[t]);
+  if (ARENA) {  // (two launches over one grid: this one takes the trees whose schedule fits its LDS slots)
+    const int need = __builtin_amdgcn_readfirstlane(a.slot_need[t]);
+    if (need <= a.lds_lo || need > a.lds_slots) return;
+  }
   if (M <= 0) {
-    if (FUSED && M < 0 && lane == 0) set_status(a.status, kFusedTimeout, t);
+    // (the time-out has a word of its own, status[2]: an input error of another tree, which
+    // keeps the FIRST code in status[0], must not hide it from the host's fallback)
+    if (FUSED && M < 0 && lane == 0) a.status[2] = 1 + t;
     return;
   }
-  constexpr int ppr = 4, TP = ppr * R;
-  struct __attribute__((packed)) Bytes12 {  // (4 R bytes: the pair's codes of this tile)
-    uint32_t d[R];
+  struct __attribute__((packed)) BytesTP {  // (the pair's codes of this tile)
+    uint32_t d[TP / 4];
   };
+  static_assert(TP % 4 == 0, "whole words of tip codes per tile");
   const int tile_start = tile * TP;
   const bool whole = tile_start + TP <= a.P;
-  Bytes12 bytes_now[2] = {};
-  if (whole) {
+  BytesTP bytes_now[2] = {};
+  if (whole && !COMPACT) {
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int j = lane + 64 * u, node = node_j[u];
       if (j < jmax && (unsigned)node < (unsigned)n)
-        bytes_now[u] = *reinterpret_cast<const Bytes12*>(a.tip_codes + (size_t)node * a.P + tile_start);
+        bytes_now[u] = *reinterpret_cast<const BytesTP*>(a.tip_codes + (size_t)node * a.P + tile_start);
     }
   }
-  const int cat = b, catc = cat < K ? cat : K - 1;
+  const int cat = b % KP, pgrp = b / KP;
+  const int catc = cat < K ? cat : K - 1;
   // this lane's constant offsets into a position's record: internal (16-byte {f, tr} slot of
   // (category, lo, hi)) and tip (row hi of the category's table; the state's offset is added)
   const unsigned lane_moff = 16u * (unsigned)(catc * 16 + lo * 4 + hi);
   const unsigned lane_tip = (unsigned)catc * kTipCat + (unsigned)hi * kTipRow;
   const char* __restrict__ mm_g = reinterpret_cast<const char*>(a.mmats) + (size_t)gi * Mmax * kVisit;
-  const int col = lo;  // this lane's pattern column; register r adds r * ppr
+  const int col = pgrp * 4 + lo;  // this lane's pattern column; register r adds r * ppr
   const double pi_l = model->pi[hi];
   const double cw_l = cat < K ? model->cat_weight[cat] : 0.0;
   const double rate_l = model->cat_rate[catc], drate_l = model->cat_drate[catc];
   const double AQ = model->Q[lo * 4 + hi];  // A operand for Q L (same in every block)
 
   struct Tw {
-    uint32_t w[6];
+    uint32_t w[COMPACT ? 3 : 6];  // (COMPACT: two positions per word)
   };
   struct Slots {  // scalars (s_load_dwordx8)
     int q, c[2], g[4], dst;
   };
-#if W3_SCHED_REGS
-  // (experiment, round 5: the schedule words of the whole tree in nine vector registers --
-  // lane m holds macro m's shape and its eight slot words -- read with v_readlane when a visit
-  // needs them: no scalar-memory instruction inside the walk, so a wait for LDS data is no
-  // longer a wait for scalar loads that return out of order)
-  int sched_w[9];
-  {
-    const int ml = lane < Mmax ? lane : 0;
-    sched_w[0] = mwv[ml * 16];
-    const int4 lo4 = *reinterpret_cast<const int4*>(mwv + ml * 16 + 8);
-    const int4 hi4 = *reinterpret_cast<const int4*>(mwv + ml * 16 + 12);
-    sched_w[1] = lo4.x; sched_w[2] = lo4.y; sched_w[3] = lo4.z; sched_w[4] = lo4.w;
-    sched_w[5] = hi4.x; sched_w[6] = hi4.y; sched_w[7] = hi4.z; sched_w[8] = hi4.w;
-  }
-  auto load_shape = [&](int m) { return __builtin_amdgcn_readlane(sched_w[0], m); };
-  auto load_slots = [&](int m) {
-    return Slots{__builtin_amdgcn_readlane(sched_w[1], m),
-                 {__builtin_amdgcn_readlane(sched_w[2], m), __builtin_amdgcn_readlane(sched_w[3], m)},
-                 {__builtin_amdgcn_readlane(sched_w[4], m), __builtin_amdgcn_readlane(sched_w[5], m),
-                  __builtin_amdgcn_readlane(sched_w[6], m), __builtin_amdgcn_readlane(sched_w[7], m)},
-                 __builtin_amdgcn_readlane(sched_w[8], m)};
-  };
-#else
   auto load_shape = [&](int m) { return mw[m * 16]; };
   auto load_slots = [&](int m) {
     const cint_ptr p = mw + m * 16 + 8;
     return Slots{p[0], {p[1], p[2]}, {p[3], p[4], p[5], p[6]}, p[7]};
   };
-#endif
-  // LDS: [macro][column][8 words: tip codes of positions 0..5, one byte per register r] --
-  // re-used, macro by macro, for that macro's edge sums once its tip words were consumed --
-  // | vectors [slot][r][lane] | RESCALE: exponents
+  // LDS: [macro][column][tip codes of positions 0..5] -- re-used, macro by macro, for that
+  // macro's edge sums once its tip words were consumed -- | vectors [slot][r][lane] |
+  // RESCALE: exponents
   char* const lds0 = reinterpret_cast<char*>(wlds);
   char* const plv = lds0 + (unsigned)Mmax * kTStride;
-  int16_t* exps = reinterpret_cast<int16_t*>(plv + (size_t)max_stored(n) * R * kTile * 8);
-  const unsigned tw_lane = (unsigned)col * kTwCol;
-  auto fetch_tw = [&](int m) {  // the six tip words of visit m (LDS)
+  int16_t* exps = reinterpret_cast<int16_t*>(plv + (size_t)(ARENA ? a.lds_slots : max_stored(n)) * kVecBytes);
+  const unsigned tw_lane = (unsigned)col * kCol;
+  auto fetch_tw = [&](int m) {  // the tip words of visit m (LDS)
     Tw t;
     const char* twp = lds0 + ((unsigned)m * kTStride + tw_lane);
-    const uint4 w4 = *reinterpret_cast<const uint4*>(twp);
-    const uint2 w2 = *reinterpret_cast<const uint2*>(twp + 16);
-    t.w[0] = w4.x;
-    t.w[1] = w4.y;
-    t.w[2] = w4.z;
-    t.w[3] = w4.w;
-    t.w[4] = w2.x;
-    t.w[5] = w2.y;
+    if constexpr (COMPACT) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) t.w[j] = *reinterpret_cast<const uint32_t*>(twp + 4 * j);
+    } else {
+      const uint4 w4 = *reinterpret_cast<const uint4*>(twp);
+      const uint2 w2 = *reinterpret_cast<const uint2*>(twp + 16);
+      t.w[0] = w4.x;
+      t.w[1] = w4.y;
+      t.w[2] = w4.z;
+      t.w[3] = w4.w;
+      t.w[4] = w2.x;
+      t.w[5] = w2.y;
+    }
     return t;
   };
+  // byte offset of the table entry of register r's pattern at tip position POS
+  auto tip_offset = [&](const Tw& tw, auto pos_tag, int r) {
+    constexpr int POS = decltype(pos_tag)::value;
+    if constexpr (COMPACT)
+      return lane_tip + (__builtin_amdgcn_ubfe(tw.w[POS >> 1], (uint32_t)(16 * (POS & 1) + 4 * r), 3u) << 4);
+    else
+      return lane_tip + ((tw.w[POS] >> (8 * r)) & 0xffu);
+  };
+
+  // ARENA: this wave's arena, [stored node in order of consumption] x kVecBytes; a vector lies
+  // there as register pairs interleaved by lane (16-byte accesses: one instruction moves two
+  // registers -- every vector-memory instruction costs a wave ~45 clocks of issue)
+  // followed by the odd register
+  char* const arena =
+      ARENA ? reinterpret_cast<char*>(a.plv + ((size_t)job_eval * a.g_tiles + tile) * max_stored(n) * (R * kTile))
+            : nullptr;
+  const unsigned lane16 = 16u * lane, lane8 = 8u * lane;
 
   // ---- operands of one child (J = 0, 1) of a visit, requested a visit ahead ----
   // W doubles per internal position ({f} post-order, {f, tr} pre-order), 3 W per tip position
@@ -271,6 +271,10 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   //   tip:      x[0 .. 3W)                      stored: x[0 .. W)
   //   unstored: x[0 .. W), first grandchild at x[W ..), second at x[4W ..) (tip: 3W, else W)
   // (destinations are compile-time indices into the group: the groups live in registers)
+  // ARENA, pre-order: a stored input's post-order vector comes from the arena into the SAME
+  // group, behind the input's W doubles -- R more, and a stored input leaves at least 2 W of
+  // its place unused: stored child x[W .. W + R), grandchildren x[2W ..) and x[5W ..)
+  static_assert(R <= 4, "an arena vector fits the unused part of its operand group (2 W = 4 doubles)");
   auto load_internal = [&](auto pre_tag, const char* at, auto& o, auto off_tag) {
     constexpr bool PRE = decltype(pre_tag)::value;
     constexpr int OFF = decltype(off_tag)::value;
@@ -284,16 +288,12 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       o.x[OFF] = *reinterpret_cast<const double*>(at + (size_t)voff);
     }
   };
-  auto load_tip = [&](auto pre_tag, const char* at, uint32_t word, auto& o, auto off_tag) {
+  auto load_tip = [&](auto pre_tag, const char* at, const Tw& tw, auto pos_tag, auto& o, auto off_tag) {
     constexpr bool PRE = decltype(pre_tag)::value;
     constexpr int OFF = decltype(off_tag)::value;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-#ifdef W3_ABL_COALESCED_TIPS  // (timing experiment, wrong results: every lane its row's entry 0)
-      unsigned voff = lane_tip + ((word >> (8 * r)) & 0x0u);
-#else
-      unsigned voff = lane_tip + ((word >> (8 * r)) & 0xffu);
-#endif
+      unsigned voff = tip_offset(tw, pos_tag, r);
       asm volatile("" : "+v"(voff));
       if (PRE) {
         const double2 v = *reinterpret_cast<const double2*>(at + (size_t)voff);
@@ -304,28 +304,56 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       }
     }
   };
+  auto load_arena = [&](int k, auto& o, auto off_tag) {  // k: scalar
+    constexpr int OFF = decltype(off_tag)::value;
+    const char* at = arena + (size_t)((unsigned)k * kVecBytes);
+    unsigned v16 = lane16, v8 = lane8;
+    asm volatile("" : "+v"(v16), "+v"(v8));
+#pragma unroll
+    for (int p = 0; p < R / 2; p++) {
+      const double2 v = *reinterpret_cast<const double2*>(at + p * (kTile * 16) + (size_t)v16);
+      o.x[OFF + 2 * p] = v.x;
+      o.x[OFF + 2 * p + 1] = v.y;
+    }
+    if (R & 1) o.x[OFF + R - 1] = *reinterpret_cast<const double*>(at + (R / 2) * (kTile * 16) + (size_t)v8);
+  };
   auto fetch_child = [&](auto pre_tag, auto jtag, int sh, const Tw& tw, const char* sb, const char* sb4,
-                         auto& o) {
+                         auto& o, int& ak) {
     constexpr bool PRE = decltype(pre_tag)::value;
     constexpr int J = decltype(jtag)::value;
     constexpr int W = PRE ? 2 : 1;
+    constexpr bool AR = ARENA && PRE;
     using O0 = std::integral_constant<int, 0>;
     using OA = std::integral_constant<int, W>;
     using OB = std::integral_constant<int, 4 * W>;
+    using P0 = std::integral_constant<int, J>;
+    using PA = std::integral_constant<int, 2 + 2 * J>;
+    using PB = std::integral_constant<int, 3 + 2 * J>;
     const int kind = (sh >> (2 * J)) & 3;
     if (kind == 0) {
-      load_tip(pre_tag, sb + J * kPos, tw.w[J], o, O0{});
+      load_tip(pre_tag, sb + J * kPos, tw, P0{}, o, O0{});
       return;
     }
     load_internal(pre_tag, sb + J * kPos, o, O0{});
-    if (kind != 2) return;
+    if (kind != 2) {
+      if constexpr (AR) load_arena(ak++, o, std::integral_constant<int, W>{});
+      return;
+    }
     // positions 2, 3 (J = 0) lie below the 4095-byte immediate, 4, 5 (J = 1) beyond it
     const char* ga = J == 0 ? sb + 2 * kPos : sb4;
     const char* gb = J == 0 ? sb + 3 * kPos : sb4 + kPos;
-    if (sh & (1 << (10 + 2 * J))) load_tip(pre_tag, ga, tw.w[2 + 2 * J], o, OA{});
-    else load_internal(pre_tag, ga, o, OA{});
-    if (sh & (1 << (11 + 2 * J))) load_tip(pre_tag, gb, tw.w[3 + 2 * J], o, OB{});
-    else load_internal(pre_tag, gb, o, OB{});
+    if (sh & (1 << (10 + 2 * J))) {
+      load_tip(pre_tag, ga, tw, PA{}, o, OA{});
+    } else {
+      load_internal(pre_tag, ga, o, OA{});
+      if constexpr (AR) load_arena(ak++, o, std::integral_constant<int, 2 * W>{});
+    }
+    if (sh & (1 << (11 + 2 * J))) {
+      load_tip(pre_tag, gb, tw, PB{}, o, OB{});
+    } else {
+      load_internal(pre_tag, gb, o, OB{});
+      if constexpr (AR) load_arena(ak++, o, std::integral_constant<int, 5 * W>{});
+    }
   };
   using J0 = std::integral_constant<int, 0>;
   using J1 = std::integral_constant<int, 1>;
@@ -342,27 +370,13 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     unsigned off4 = 4 * kPos;
     asm volatile("" : "+s"(off4));
     const char* sb4 = sb + off4;
-    fetch_child(pre_tag, J0{}, sh, tw, sb, sb4, o0);
-    fetch_child(pre_tag, J1{}, sh, tw, sb, sb4, o1);
+    int ak = (int)((unsigned)sh >> 16);  // ARENA: arena index of the visit's first stored input
+    fetch_child(pre_tag, J0{}, sh, tw, sb, sb4, o0, ak);
+    fetch_child(pre_tag, J1{}, sh, tw, sb, sb4, o1, ak);
 #ifdef W3_STAMPS
     stamp_fetch += __builtin_amdgcn_s_memtime() - f0;
     stamp_visits++;
 #endif
-  };
-
-  // W3_SPLIT_FETCH: child 0's operands are requested at the top of the visit before, child 1's
-  // from that visit's middle (behind its LDS reads): two shorter bursts of loads instead of one
-  // (a wave stalls in the issue of a load while the CU's address path is full: DESIGN.md 4.1)
-#ifndef W3_SPLIT_FETCH
-#define W3_SPLIT_FETCH 0
-#endif
-  constexpr bool kSplitFetch = W3_SPLIT_FETCH != 0;
-  auto fetch_j = [&](auto pre_tag, auto jtag, int m, int sh, const Tw& tw, auto& o) {
-    const char* sb = mm_g + (size_t)((unsigned)m * kVisit);
-    unsigned off4 = 4 * kPos;
-    asm volatile("" : "+s"(off4));
-    const char* sb4 = sb + off4;
-    fetch_child(pre_tag, jtag, sh, tw, sb, sb4, o);
   };
 
   // ONE wait per visit for operands.  How many loads a fetch issues depends on the visit's
@@ -407,18 +421,48 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     auto stage_bytes = [&](int j, int node) {  // columns clamped to the last pattern
       const int m = j / 6, pos = j - m * 6;
       const uint8_t* src = a.tip_codes + (size_t)node * a.P;
-      char* dst = lds0 + (unsigned)m * kTStride + (unsigned)pos * 4u;
-      for (int q = 0; q < TP; q++) {
-        const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
-        dst[(q & (ppr - 1)) * kTwCol + (q >> 2)] = (char)src[pp];
+      if constexpr (COMPACT) {
+        // one 16-bit field per column: the state numbers (code / 16) of its R patterns (ppr apart)
+        char* dst = lds0 + (unsigned)m * kTStride + (unsigned)pos * 2u;
+        if (whole) {  // the tile's TP bytes as whole words
+          uint32_t d[TP / 4];
+#pragma unroll
+          for (int i = 0; i < TP / 4; i++) d[i] = *reinterpret_cast<const uint32_t*>(src + tile_start + 4 * i);
+#pragma unroll
+          for (int c = 0; c < ppr; c++) {
+            uint32_t f = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+              const int q = r * ppr + c;
+              f |= ((d[q >> 2] >> (8 * (q & 3) + 4)) & 0x7u) << (4 * r);
+            }
+            *reinterpret_cast<uint16_t*>(dst + c * kCol) = (uint16_t)f;
+          }
+          return;
+        }
+        for (int c = 0; c < ppr; c++) {
+          uint32_t f = 0;
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            const int q = tile_start + r * ppr + c;
+            f |= (((uint32_t)src[q < a.P ? q : a.P - 1] >> 4) & 0x7u) << (4 * r);
+          }
+          *reinterpret_cast<uint16_t*>(dst + c * kCol) = (uint16_t)f;
+        }
+      } else {
+        char* dst = lds0 + (unsigned)m * kTStride + (unsigned)pos * 4u;
+        for (int q = 0; q < TP; q++) {
+          const int pp = tile_start + q < a.P ? tile_start + q : a.P - 1;
+          dst[(q & (ppr - 1)) * kTwCol + (q >> 2)] = (char)src[pp];
+        }
       }
     };
-    if (whole) {
+    if (whole && !COMPACT) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int j = lane + 64 * u, node = node_j[u];
         if (j < jmax && (unsigned)node < (unsigned)n) {
-          const Bytes12 w = bytes_now[u];
+          const BytesTP w = bytes_now[u];
           const int m = j / 6, pos = j - m * 6;
           char* dst = lds0 + (unsigned)m * kTStride + (unsigned)pos * 4u;
 #pragma unroll
@@ -447,8 +491,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   struct V {
     double v[R];
   };
-  const unsigned lane8 = 8u * lane;
-  unsigned slot_stride = R * kTile * 8;
+  unsigned slot_stride = kVecBytes;
   asm volatile("" : "+v"(slot_stride));
   const unsigned plv_lane = (unsigned)(plv - lds0) + lane8;
   auto slot_ptr = [&](int slot) {  // slot: scalar
@@ -465,6 +508,15 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     double* c = slot_ptr(slot);
 #pragma unroll
     for (int r = 0; r < R; r++) c[r * kTile] = x.v[r];
+  };
+  auto store_arena = [&](int k, const V& x) {  // (the layout load_arena reads)
+    char* at = arena + (size_t)((unsigned)k * kVecBytes);
+    unsigned v16 = lane16, v8 = lane8;
+    asm volatile("" : "+v"(v16), "+v"(v8));
+#pragma unroll
+    for (int p = 0; p < R / 2; p++)
+      *reinterpret_cast<double2*>(at + p * (kTile * 16) + (size_t)v16) = double2{x.v[2 * p], x.v[2 * p + 1]};
+    if (R & 1) *reinterpret_cast<double*>(at + (R / 2) * (kTile * 16) + (size_t)v8) = x.v[R - 1];
   };
   auto mm = [&](double A, const V& x) {
     V y;
@@ -494,6 +546,14 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     for (int r = 0; r < R; r++) y.v[r] = o.x[OFF + 2 * r + 1];
     return y;
   };
+  // ARENA, pre-order: the post-order vector of a stored input, as load_arena left it in the group
+  auto arena_vec = [&](const auto& o, auto off_tag) {
+    constexpr int OFF = decltype(off_tag)::value;
+    V y;
+#pragma unroll
+    for (int r = 0; r < R; r++) y.v[r] = o.x[OFF + r];
+    return y;
+  };
 
   double qroot[R];  // root pre-order vector: pi * category weight * w_p / site likelihood
   int esum[R];      // RESCALE: exponents removed so far, per pattern
@@ -501,25 +561,17 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   for (int r = 0; r < R; r++) esum[r] = 0;
 
   // What a visit knows of one child: S = P_c L_c (the message to the parent / the sibling),
-  // and for an internal child its vector L (stored: from its slot; unstored: Ap o Bp, the
-  // products of its two children, whose vectors xa / xb are read only where they are stored
-  // nodes).
+  // and for an internal child its vector L (stored: from its slot -- ARENA, pre-order: from the
+  // arena --; unstored: Ap o Bp, the products of its two children, whose vectors xa / xb are
+  // read only where they are stored nodes).
   struct Child {
     V S, L, xa, xb, Ap, Bp;
   };
-  struct Early {  // a visit's early LDS reads: q of its node (pre-order), its stored children
-    V q, l0, l1;
-  };
-  auto early_loads = [&](bool with_q, int sh, const Slots& sl, Early& ea) {
-    if (with_q) ea.q = load_slot(sl.q);
-    if ((sh & 3) == 1) ea.l0 = load_slot(sl.c[0]);
-    if (((sh >> 2) & 3) == 1) ea.l1 = load_slot(sl.c[1]);
-  };
-  auto child_S = [&](auto pre_tag, auto jtag, int sh, const auto& o, const Slots& sl, Child& c,
-                     const Early& ea) {
+  auto child_S = [&](auto pre_tag, auto jtag, int sh, const auto& o, const Slots& sl, Child& c) {
     constexpr bool PRE = decltype(pre_tag)::value;
     constexpr int J = decltype(jtag)::value;
     constexpr int W = PRE ? 2 : 1;
+    constexpr bool AR = ARENA && PRE;
     using O0 = std::integral_constant<int, 0>;
     using OA = std::integral_constant<int, W>;
     using OB = std::integral_constant<int, 4 * W>;
@@ -529,48 +581,48 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       return;
     }
     if (kind == 1) {
-      c.L = kEarlyLds ? (J == 0 ? ea.l0 : ea.l1) : load_slot(sl.c[J]);
-      if (kStoreS && PRE) {  // (the slot holds S since the post-order walk)
-        c.S = c.L;
-        return;
-      }
+      if constexpr (AR) c.L = arena_vec(o, std::integral_constant<int, W>{});
+      else c.L = load_slot(sl.c[J]);
     } else {
       if (sh & (1 << (10 + 2 * J))) {
         c.Ap = tip_p(pre_tag, o, OA{});
       } else {
-        c.xa = load_slot(sl.g[2 * J]);
-        if (kStoreS && PRE) {
-          c.Ap = c.xa;
-        } else {
-          c.Ap = mm(o.x[W], c.xa);
-          if (kStoreS) store_slot(sl.g[2 * J], c.Ap);
-        }
+        if constexpr (AR) c.xa = arena_vec(o, std::integral_constant<int, 2 * W>{});
+        else c.xa = load_slot(sl.g[2 * J]);
+        c.Ap = mm(o.x[W], c.xa);
       }
       if (sh & (1 << (11 + 2 * J))) {
         c.Bp = tip_p(pre_tag, o, OB{});
       } else {
-        c.xb = load_slot(sl.g[2 * J + 1]);
-        if (kStoreS && PRE) {
-          c.Bp = c.xb;
-        } else {
-          c.Bp = mm(o.x[4 * W], c.xb);
-          if (kStoreS) store_slot(sl.g[2 * J + 1], c.Bp);
-        }
+        if constexpr (AR) c.xb = arena_vec(o, std::integral_constant<int, 5 * W>{});
+        else c.xb = load_slot(sl.g[2 * J + 1]);
+        c.Bp = mm(o.x[4 * W], c.xb);
       }
       c.L = mul(c.Ap, c.Bp);
     }
     c.S = mm(o.x[0], c.L);
-    if (kStoreS && !PRE && kind == 1) store_slot(sl.c[J], c.S);
+  };
+
+  // ARENA: the last stored vector, on its way to the arena -- stored at the top of the NEXT
+  // visit, behind that visit's operand wait and requests, so that the store has a whole visit
+  // before the next wait (stores count on vmcnt like loads)
+  V pend_L;
+  int pend_dst = 0;
+  bool pend = false;
+  auto flush_arena = [&]() {
+    if (ARENA && pend) {
+      store_arena(pend_dst, pend_L);
+      pend = false;
+    }
   };
 
   // ================= post-order over the stored nodes, then the root (site likelihood) ====
   auto post_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<false>& o0, const Ops<false>& o1,
-                        int tile_for_ll, const Early& ea, auto&& mid) {
+                        int tile_for_ll) {
     constexpr bool ROOT = decltype(root_tag)::value;
     Child c0, c1;
-    child_S(Post{}, J0{}, sh, o0, sl, c0, ea);
-    child_S(Post{}, J1{}, sh, o1, sl, c1, ea);
-    mid();  // (the visit's LDS reads are behind it)
+    child_S(Post{}, J0{}, sh, o0, sl, c0);
+    child_S(Post{}, J1{}, sh, o1, sl, c1);
     V Lv = mul(c0.S, c1.S);
     if (!ROOT) {
       if (RESCALE) {
@@ -578,15 +630,20 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
         for (int r = 0; r < R; r++) {
           const double colsum = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, Lv.v[r], 0.0, 0, 0, 0);
           int ex = colsum > 0.0 ? __builtin_amdgcn_frexp_exp(colsum) : -4096;
-          ex = max(ex, __shfl_xor(ex, 4, 64));
-          ex = max(ex, __shfl_xor(ex, 8, 64));
+          if (KP >= 2) ex = max(ex, __shfl_xor(ex, 4, 64));
+          if (KP >= 4) ex = max(ex, __shfl_xor(ex, 8, 64));
           ex = ex == -4096 ? 0 : ex;
           Lv.v[r] = ldexp(Lv.v[r], -ex);
           esum[r] += ex;
-          exps[(unsigned)sl.q * (unsigned)TP + (unsigned)(r * ppr + col)] = (int16_t)ex;
+          exps[(unsigned)(ARENA ? sl.dst : sl.q) * (unsigned)TP + (unsigned)(r * ppr + col)] = (int16_t)ex;
         }
       }
       store_slot(sl.q, Lv);
+      if (ARENA) {
+        pend_L = Lv;
+        pend_dst = sl.dst;
+        pend = true;
+      }
     } else {
       // root: site likelihood per pattern, log-likelihood partial, derivative weights
       double sitev[R];
@@ -594,8 +651,12 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       for (int r = 0; r < R; r++) {
         double v = cw_l * pi_l * Lv.v[r];
         v = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, v, 0.0, 0, 0, 0);  // states
-        v = row_ror_add<8>(v);                                           // categories
-        v = row_ror_add<4>(v);
+        if (KP == 4) {                                                   // categories
+          v = row_ror_add<8>(v);
+          v = row_ror_add<4>(v);
+        } else if (KP == 2) {
+          v += __shfl_xor(v, 4, 64);
+        }
         sitev[r] = v;
       }
       double sv = sitev[0], wv = pw[0];
@@ -612,7 +673,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       for (int r = 0; r < R; r++)
         qroot[r] = pi_l * cw_l * __builtin_amdgcn_mfma_f64_4x4x4f64(hi == r ? 1.0 : 0.0, quot, 0.0, 0, 0, 0);
       double ll = 0.0;
-      if (hi < R && b == 0 && pv < a.P)
+      if (hi < R && (b % KP) == 0 && pv < a.P)
         ll = wv * (RESCALE ? log(sv) + ev * 0.69314718055994530942 : log(sv));
       ll = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, ll, 0.0, 0, 0, 0);  // rows
       ll = row_ror_add<8>(ll);
@@ -628,7 +689,9 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     // Two visits per iteration, two operand sets (A, B), nothing copied.  At the top of visit
     // m: shape (s0), slots and operands of m are there; shape (s1) and tip words of m + 1 too,
     // so its operands are requested into the other set; then the tip words of m + 2 are read
-    // (LDS).  The visit ends with the scalar loads: slots of m + 1, shape of m + 3.
+    // (LDS).  The visit ends with the scalar loads: slots of m + 1, shape of m + 3 (scalar
+    // loads return out of order: any wait for LDS data with one of them in flight is a wait
+    // for everything -- at the visit's top or in its middle they cost 12-14 %, round 4).
     Ops<false> a0, a1, b0, b1;
     int s0 = sh_a, s1 = sh_b, s2 = sh_c;
     Slots la = sl_a, lb;
@@ -637,47 +700,25 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     tw = fetch_tw(min(1, M1));
     for (int m = 0; m < M1; m += 2) {
       // ---- visit m (set A) ----
-      Early ea;
-      if (kEarlyLds) early_loads(false, s0, la, ea);
       settle(a0, a1);
-      const Tw tw_a = tw;
-      if (kSplitFetch) fetch_j(Post{}, J0{}, min(m + 1, M1), s1, tw_a, b0);
-      else fetch(Post{}, min(m + 1, M1), s1, tw, b0, b1);
+      fetch(Post{}, min(m + 1, M1), s1, tw, b0, b1);
       tw = fetch_tw(min(m + 2, M1));
-      int s3;
-      auto req = [&]() {
-        lb = load_slots(min(m + 1, M1));
-        s3 = load_shape(min(m + 3, M1));
-      };
-      if (kScalars == 1) req();
-      post_visit(Inner{}, s0, la, a0, a1, 0, ea, [&]() {
-        if (kScalars == 2) req();
-        if (kSplitFetch) fetch_j(Post{}, J1{}, min(m + 1, M1), s1, tw_a, b1);
-      });
-      if (kScalars == 0) req();
+      flush_arena();
+      post_visit(Inner{}, s0, la, a0, a1, 0);
+      lb = load_slots(min(m + 1, M1));
+      const int s3 = load_shape(min(m + 3, M1));
       s0 = s1;
       s1 = s2;
       s2 = s3;
       if (m + 1 < M1) {
         // ---- visit m + 1 (set B) ----
-        Early eb;
-        if (kEarlyLds) early_loads(false, s0, lb, eb);
         settle(b0, b1);
-        const Tw tw_b = tw;
-        if (kSplitFetch) fetch_j(Post{}, J0{}, min(m + 2, M1), s1, tw_b, a0);
-        else fetch(Post{}, min(m + 2, M1), s1, tw, a0, a1);
+        fetch(Post{}, min(m + 2, M1), s1, tw, a0, a1);
         tw = fetch_tw(min(m + 3, M1));
-        int s4;
-        auto req = [&]() {
-          la = load_slots(min(m + 2, M1));
-          s4 = load_shape(min(m + 4, M1));
-        };
-        if (kScalars == 1) req();
-        post_visit(Inner{}, s0, lb, b0, b1, 0, eb, [&]() {
-          if (kScalars == 2) req();
-          if (kSplitFetch) fetch_j(Post{}, J1{}, min(m + 2, M1), s1, tw_b, a1);
-        });
-        if (kScalars == 0) req();
+        flush_arena();
+        post_visit(Inner{}, s0, lb, b0, b1, 0);
+        la = load_slots(min(m + 2, M1));
+        const int s4 = load_shape(min(m + 4, M1));
         s0 = s1;
         s1 = s2;
         s2 = s4;
@@ -687,12 +728,9 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
         la = lb;
       }
     }
-    {
-      Early ea;
-      if (kEarlyLds) early_loads(false, s0, la, ea);
-      settle(a0, a1);
-      post_visit(Root{}, s0, la, a0, a1, tile, ea, [] {});
-    }
+    settle(a0, a1);
+    flush_arena();
+    post_visit(Root{}, s0, la, a0, a1, tile);
   }
 
   // ================= pre-order + edge derivatives =================
@@ -731,12 +769,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       return;
     }
     V qc;
-    if (kStoreS && kind == 1) {  // sum qs . Q S = sum (P^T qs) . Q L
-      qc = mm(o.x[1], qs);
-      nout = mul(qs, mm(AQ, c.S));
-    } else {
-      nout = inner_edge(o.x[1], qs, c.L, qc);
-    }
+    nout = inner_edge(o.x[1], qs, c.L, qc);
     if (kind == 1) {
       store_slot(sl.c[J], qc);
       return;
@@ -746,46 +779,35 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     if (sh & (1 << (10 + 2 * J))) {
       na = mul(qsa, tip_pq(o, std::integral_constant<int, 2>{}));
     } else {
-      if (kStoreS) {
-        qa = mm(o.x[3], qsa);
-        na = mul(qsa, mm(AQ, c.Ap));
-      } else {
-        na = inner_edge(o.x[3], qsa, c.xa, qa);
-      }
+      na = inner_edge(o.x[3], qsa, c.xa, qa);
       store_slot(sl.g[2 * J], qa);
     }
     if (sh & (1 << (11 + 2 * J))) {
       nb = mul(qsb, tip_pq(o, std::integral_constant<int, 8>{}));
     } else {
-      if (kStoreS) {
-        qb = mm(o.x[9], qsb);
-        nb = mul(qsb, mm(AQ, c.Bp));
-      } else {
-        nb = inner_edge(o.x[9], qsb, c.xb, qb);
-      }
+      nb = inner_edge(o.x[9], qsb, c.xb, qb);
       store_slot(sl.g[2 * J + 1], qb);
     }
     edge_sums(na, nb, m, 2 + 2 * J);
   };
-  auto pre_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<true>& o0, const Ops<true>& o1, int m,
-                       const Early& ea, auto&& mid) {
+  auto pre_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<true>& o0, const Ops<true>& o1, int m) {
     constexpr bool ROOT = decltype(root_tag)::value;
     V qv;
     if (ROOT) {
 #pragma unroll
       for (int r = 0; r < R; r++) qv.v[r] = qroot[r];
     } else {
-      qv = kEarlyLds ? ea.q : load_slot(sl.q);
+      qv = load_slot(sl.q);
       if (RESCALE) {
 #pragma unroll
         for (int r = 0; r < R; r++)
-          qv.v[r] = ldexp(qv.v[r], -(int)exps[(unsigned)sl.q * (unsigned)TP + (unsigned)(r * ppr + col)]);
+          qv.v[r] = ldexp(qv.v[r], -(int)exps[(unsigned)(ARENA ? sl.dst : sl.q) * (unsigned)TP +
+                                              (unsigned)(r * ppr + col)]);
       }
     }
     Child c0, c1;
-    child_S(Pre{}, J0{}, sh, o0, sl, c0, ea);
-    child_S(Pre{}, J1{}, sh, o1, sl, c1, ea);
-    mid();  // (the visit's LDS reads are behind it)
+    child_S(Pre{}, J0{}, sh, o0, sl, c0);
+    child_S(Pre{}, J1{}, sh, o1, sl, c1);
     V n0, n1;
     child_edges(J0{}, sh, o0, sl, c0, mul(qv, c1.S), m, n0);
     child_edges(J1{}, sh, o1, sl, c1, mul(qv, c0.S), m, n1);
@@ -804,68 +826,35 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     fetch(Pre{}, M1, s0, tw, a0, a1);
     tw = fetch_tw(dn(M1 - 1));
     {  // ---- visit M1 (the root, set A) ----
-      Early ea;
-      if (kEarlyLds) early_loads(false, s0, la, ea);
       settle(a0, a1);
       fetch(Pre{}, dn(M1 - 1), s1, tw, b0, b1);
       tw = fetch_tw(dn(M1 - 2));
-      int s3;
-      auto req = [&]() {
-        lb = load_slots(dn(M1 - 1));
-        s3 = load_shape(dn(M1 - 3));
-      };
-      if (kScalars == 1) req();
-      pre_visit(Root{}, s0, la, a0, a1, M1, ea, [&]() {
-        if (kScalars == 2) req();
-      });
-      if (kScalars == 0) req();
+      pre_visit(Root{}, s0, la, a0, a1, M1);
+      lb = load_slots(dn(M1 - 1));
+      const int s3 = load_shape(dn(M1 - 3));
       s0 = s1;
       s1 = s2;
       s2 = s3;
     }
     for (int m = M1 - 1; m >= 0; m -= 2) {
       // ---- visit m (set B) ----
-      Early eb;
-      if (kEarlyLds) early_loads(true, s0, lb, eb);
       settle(b0, b1);
-      const Tw tw_b = tw;
-      if (kSplitFetch) fetch_j(Pre{}, J0{}, dn(m - 1), s1, tw_b, a0);
-      else fetch(Pre{}, dn(m - 1), s1, tw, a0, a1);
+      fetch(Pre{}, dn(m - 1), s1, tw, a0, a1);
       tw = fetch_tw(dn(m - 2));
-      int s3;
-      auto req = [&]() {
-        la = load_slots(dn(m - 1));
-        s3 = load_shape(dn(m - 3));
-      };
-      if (kScalars == 1) req();
-      pre_visit(Inner{}, s0, lb, b0, b1, m, eb, [&]() {
-        if (kScalars == 2) req();
-        if (kSplitFetch) fetch_j(Pre{}, J1{}, dn(m - 1), s1, tw_b, a1);
-      });
-      if (kScalars == 0) req();
+      pre_visit(Inner{}, s0, lb, b0, b1, m);
+      la = load_slots(dn(m - 1));
+      const int s3 = load_shape(dn(m - 3));
       s0 = s1;
       s1 = s2;
       s2 = s3;
       if (m >= 1) {
         // ---- visit m - 1 (set A) ----
-        Early ea;
-        if (kEarlyLds) early_loads(true, s0, la, ea);
         settle(a0, a1);
-        const Tw tw_a = tw;
-        if (kSplitFetch) fetch_j(Pre{}, J0{}, dn(m - 2), s1, tw_a, b0);
-        else fetch(Pre{}, dn(m - 2), s1, tw, b0, b1);
+        fetch(Pre{}, dn(m - 2), s1, tw, b0, b1);
         tw = fetch_tw(dn(m - 3));
-        int s4;
-        auto req = [&]() {
-          lb = load_slots(dn(m - 2));
-          s4 = load_shape(dn(m - 4));
-        };
-        if (kScalars == 1) req();
-        pre_visit(Inner{}, s0, la, a0, a1, m - 1, ea, [&]() {
-          if (kScalars == 2) req();
-          if (kSplitFetch) fetch_j(Pre{}, J1{}, dn(m - 2), s1, tw_a, b1);
-        });
-        if (kScalars == 0) req();
+        pre_visit(Inner{}, s0, la, a0, a1, m - 1);
+        lb = load_slots(dn(m - 2));
+        const int s4 = load_shape(dn(m - 4));
         s0 = s1;
         s1 = s2;
         s2 = s4;
@@ -887,12 +876,12 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   }
 }
 
-template <bool RESCALE>
 // (R = 2 -- 8 patterns per wave, 14 KB of LDS -- is built with three waves per SIMD:
 // `make EXTRA_LLVM=-DMI_LLR=2`, an experiment of round 4)
+template <bool RESCALE, bool ARENA, int KP>
 __global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_kernel(LikArgs a) {
   extern __shared__ double wlds[];
-  walk_lut_body<RESCALE, false>(a, wlds, blockIdx.x, nullptr);
+  walk_lut_body<RESCALE, false, ARENA, KP>(a, wlds, blockIdx.x, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------
@@ -1004,8 +993,13 @@ __global__ __launch_bounds__(kTlBlock) void transition_lut_kernel(TransitionMacr
 //   * walk waves (walk_lut_body<.., true>) poll ready[t] (sc1 load, s_sleep in between, bounded).
 // Deadlock-freedom rests on workgroups being dispatched in id order (observed, not promised by
 // HIP): the set-up waves are resident (or done) before any walk wave is, and they wait for
-// nothing.  Should a walk wave ever wait in vain, it gives up after kReadySpins polls with
-// the sticky status kFusedTimeout -- the call fails with a message instead of hanging.
+// nothing.  Should a walk wave ever wait in vain, it gives up after `spin_ticks` of wall-clock
+// time and raises the time-out word status[2]: a host-pointer entry point then runs the call
+// again through the four-launch sequence and returns ITS results (round 6: a time-out never
+// reaches such a caller); a *_device caller finds the sticky status kFusedTimeout.
+// The hand-off is a release / acquire pair at agent scope (round 6): the set-up wave
+// passes a RELEASE fence between its (write-through, waited-for) stores and the add, the walk
+// wave an ACQUIRE fence and a scalar-cache invalidate between its poll and its first read.
 // ------------------------------------------------------------------------
 // Write-through (sc1) stores of 16 bytes.  Inline assembly: the compiler has no 16-byte store
 // with a scope, and does not count these -- the role ends with an explicit s_waitcnt vmcnt(0).
@@ -1159,19 +1153,22 @@ __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const 
     printf("setup role t %d q %d: start %lld end %lld model %lld tree %lld records %lld stores issued %lld landed %lld (10 ns ticks)\n", t, q, st0, (long long)__builtin_amdgcn_s_memrealtime(),
            st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4);
 #endif
-  if (lane == 0)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  // (f.debug_skip: testing only -- quarter 1 of tree debug_skip - 1 never reports, its walk waves
+  // time out: tests/test_fused_setup_gpu.py forces the host's fallback with it)
+  if (lane == 0 && !(f.debug_skip == t + 1 && q == 1))
     __hip_atomic_fetch_add(f.ready + (size_t)t * kReadyStride, kReadyQuarter + (q == 0 ? M : 0), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool RESCALE>
+template <bool RESCALE, int KP>
 __global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_fused_kernel(LikArgs a, FusedSetupArgs f) {
   extern __shared__ double wlds[];
   if ((int)blockIdx.x < f.setup_blocks) {
     fused_setup_role(f, blockIdx.x, reinterpret_cast<char*>(wlds));
     return;
   }
-  walk_lut_body<RESCALE, true>(a, wlds, (int)blockIdx.x - f.setup_blocks, f.ready);
+  walk_lut_body<RESCALE, true, false, KP>(a, wlds, (int)blockIdx.x - f.setup_blocks, f.ready, f.spin_ticks);
 #ifdef W3_SETUP_STAMPS
   if (threadIdx.x == 0 && (((int)blockIdx.x - f.setup_blocks) % 1499) == 0)
     printf("walk block %d: out %lld\n", (int)blockIdx.x - f.setup_blocks, (long long)__builtin_amdgcn_s_memrealtime());
@@ -1182,30 +1179,41 @@ __global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_fused
 
 size_t gradient_walk_lut_mats_bytes_per_eval(int n) { return (size_t)max_macros(n) * kVisit; }
 
+// categories per matrix instruction for K rate categories
+static int lut_kp(int K) { return K == 1 ? 1 : (K == 2 ? 2 : 4); }
+
 // trees whose arrays fit one register per lane (64 nodes), a quarter of the (node, category)
 // pairs per set-up wave
 bool gradient_walk_lut_fused_applies(int n, int K) {
   return gradient_walk_lut_applies(K) && 2 * n - 1 <= 64 && ((2 * n - 2) * K + 3) / 4 <= 64;
 }
 
+template <bool RESCALE, int KP>
+static void launch_fused_variant(const LikArgs& a, const FusedSetupArgs& f, dim3 grid, size_t lds, hipStream_t s) {
+  allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_fused_kernel<RESCALE, KP>), lds);
+  hipLaunchKernelGGL((gradient_walk_lut_fused_kernel<RESCALE, KP>), grid, dim3(kTile), lds, s, a, f);
+}
 void launch_gradient_walk_lut_fused(const LikArgs& a_in, const FusedSetupArgs& f_in, int count, bool rescale,
                                     hipStream_t s) {
   if (count <= 0) return;
   LikArgs a = a_in;
   FusedSetupArgs f = f_in;
-  a.kp = 4;
+  a.kp = lut_kp(a.K);
   a.cat_groups = 1;
   a.walk_evals = count;
   f.setup_blocks = kSetupQuarters * count;
+  // how long a walk wave polls before it gives up: one second of the 100 MHz clock by default
+  if (f.spin_ticks <= 0) f.spin_ticks = 100 * 1000 * 1000;
   const int gtiles = gradient_mfma_tiles(a.P, a.K);
   const dim3 grid((unsigned)((size_t)count * gtiles + f.setup_blocks));
   const size_t lds = std::max<size_t>(gradient_walk_lds_bytes(a.n, a.K, rescale, false), fused_setup_lds(a.n, a.K));
-  if (rescale) {
-    allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_fused_kernel<true>), lds);
-    hipLaunchKernelGGL(gradient_walk_lut_fused_kernel<true>, grid, dim3(kTile), lds, s, a, f);
-  } else {
-    allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_fused_kernel<false>), lds);
-    hipLaunchKernelGGL(gradient_walk_lut_fused_kernel<false>, grid, dim3(kTile), lds, s, a, f);
+  switch ((rescale ? 8 : 0) | a.kp) {
+    case 1: launch_fused_variant<false, 1>(a, f, grid, lds, s); break;
+    case 2: launch_fused_variant<false, 2>(a, f, grid, lds, s); break;
+    case 4: launch_fused_variant<false, 4>(a, f, grid, lds, s); break;
+    case 9: launch_fused_variant<true, 1>(a, f, grid, lds, s); break;
+    case 10: launch_fused_variant<true, 2>(a, f, grid, lds, s); break;
+    default: launch_fused_variant<true, 4>(a, f, grid, lds, s); break;
   }
 }
 
@@ -1216,28 +1224,60 @@ void launch_transition_lut(const TransitionMacroArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(transition_lut_kernel, grid, dim3(kTlBlock), sizeof(int) * (size_t)(a.N - 1), s, a);
 }
 
-// the third generation takes calls the second would run with its stored vectors in LDS, one
-// category group of three or four categories
+// The third generation takes every call of an engine whose tips are one-hot / all ones with one
+// category group (K <= 4) and no analytic substitution gradient: stored vectors in LDS or, for
+// the larger trees, in the arena (round 6; until then K = 3, 4 with the vectors in LDS only).
 // (R = 1 -- four patterns per wave -- is not worth the look-up walk's per-visit cost: the
 // engine's tile-width choice never pairs them)
-bool gradient_walk_lut_applies(int K) { return (K == 3 || K == 4) && R >= 2; }
+bool gradient_walk_lut_applies(int K) { return K >= 1 && K <= 4 && R >= 2; }
+
+template <bool RESCALE, bool ARENA, int KP>
+static void launch_lut_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_kernel<RESCALE, ARENA, KP>), lds);
+  hipLaunchKernelGGL((gradient_walk_lut_kernel<RESCALE, ARENA, KP>), grid, dim3(kTile), lds, s, a);
+}
+template <bool ARENA>
+static void launch_lut_store(const LikArgs& a, dim3 grid, size_t lds, bool rescale, hipStream_t s) {
+  switch ((rescale ? 8 : 0) | a.kp) {
+    case 1: launch_lut_variant<false, ARENA, 1>(a, grid, lds, s); break;
+    case 2: launch_lut_variant<false, ARENA, 2>(a, grid, lds, s); break;
+    case 4: launch_lut_variant<false, ARENA, 4>(a, grid, lds, s); break;
+    case 9: launch_lut_variant<true, ARENA, 1>(a, grid, lds, s); break;
+    case 10: launch_lut_variant<true, ARENA, 2>(a, grid, lds, s); break;
+    default: launch_lut_variant<true, ARENA, 4>(a, grid, lds, s); break;
+  }
+}
 
 void launch_gradient_walk_lut(const LikArgs& a_in, int count, bool rescale, hipStream_t s) {
   if (count <= 0) return;
   LikArgs a = a_in;
-  a.kp = 4;
+  a.kp = lut_kp(a.K);
   a.cat_groups = 1;
   a.walk_evals = count;
   const int gtiles = gradient_mfma_tiles(a.P, a.K);
   const dim3 grid((unsigned)((size_t)count * gtiles));
-  const size_t lds = gradient_walk_lds_bytes(a.n, a.K, rescale, false);
-  if (rescale) {
-    allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_kernel<true>), lds);
-    hipLaunchKernelGGL(gradient_walk_lut_kernel<true>, grid, dim3(kTile), lds, s, a);
-  } else {
-    allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_kernel<false>), lds);
-    hipLaunchKernelGGL(gradient_walk_lut_kernel<false>, grid, dim3(kTile), lds, s, a);
+  const bool arena_variant =
+      a.store ? a.store == 2 : gradient_walk_use_arena(a.n, a.K, rescale, false, (size_t)gtiles * (size_t)count);
+  if (arena_variant) {
+    // two launches over one grid, as the second generation's arena variant: the trees whose
+    // schedule fits the usual number of LDS slots, then (more LDS per wave) the rest
+    const int usual = gradient_arena_slots_usual(a.n), sure = gradient_arena_slots_sure(a.n);
+    a.lds_lo = -1;
+    if (arena_single_launch(gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), grid.x)) {
+      a.lds_slots = sure;
+      launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), rescale, s);
+      return;
+    }
+    a.lds_slots = usual;
+    launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, usual), rescale, s);
+    if (sure > usual) {
+      a.lds_lo = usual;
+      a.lds_slots = sure;
+      launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), rescale, s);
+    }
+    return;
   }
+  launch_lut_store<false>(a, grid, gradient_walk_lds_bytes(a.n, a.K, rescale, false), rescale, s);
 }
 const char* gradient_walk_lut_kernel_name() { return "gradient_walk_lut_kernel"; }
 const char* gradient_walk_lut_fused_kernel_name() { return "gradient_walk_lut_fused_kernel"; }

@@ -97,6 +97,15 @@ bool matrix_core_gradient(const mi_engine* e, bool rescaling) {
          (gradient_mfma_groups(e->K) == 1 || !loglik_kernel_is_valu(e, rescaling));
 }
 
+// Round 6: the third generation runs every shape the first two did for engines with one-hot /
+// all-ones tips and at most four rate categories (arena variant, one and two categories), so
+// such an engine never needs the first generation: the K < 3 rule of engine creation (first
+// generation on arena shapes with few tiles) is overridden once the tips are known.
+void choose_walk_generation(mi_engine* e) {
+  if (e->walk_forced || e->s != kStates) return;
+  if (e->walk3 && e->walk3_arena && e->have_tip_codes && gradient_walk_lut_applies(e->K)) e->walk2 = true;
+}
+
 // Can calls of this engine take the third-generation walk (kernels_walk3.hip)?  (Per call it
 // also needs the stored vectors in LDS and no analytic substitution gradient.)
 bool walk3_possible(const mi_engine* e) {
@@ -131,7 +140,7 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
   if (analytic && e->x_sum.ensure(sizeof(double) * (size_t)c.Eg * kSubstExtra)) return 1;
   if (e->ll_part.ensure(sizeof(double) * (size_t)c.E * e->ll_stride)) return 1;
   if (e->fin_scratch.ensure(sizeof(double) * (size_t)T * 6 * n)) return 1;
-  if (e->status.ensure(sizeof(int32_t) * 2)) return 1;
+  if (e->status.ensure(sizeof(int32_t) * kStatusWords)) return 1;
   if (gradient && e->fused_setup && walk3_possible(e) && e->ready.bytes < sizeof(int32_t) * kReadyStride * (size_t)T) {
     // hand-off words of the one-launch small call: zero whenever no such call is running
     if (e->ready.ensure(sizeof(int32_t) * kReadyStride * (size_t)T)) return 1;
@@ -233,7 +242,9 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // (a call of a few trees keeps its stored vectors in LDS however large the tree)
   const bool arena = mfma && use_arena(e, d.rescaling, analytic, (size_t)T * (size_t)g_tiles);
   const bool walk2 = mfma && e->walk2;
-  const bool walk3 = walk2 && walk3_possible(e) && !arena && !analytic && groups == 1;
+  // the third-generation (look-up) walk: stored vectors in LDS or, since round 6, in the arena
+  const bool walk3 = walk2 && walk3_possible(e) && !analytic && groups == 1 &&
+                     (!arena || e->walk3_arena);
   constexpr int kMaxEvals = 32768;
   // The one-launch call (kernels_walk3.hip): tree set-up, model instances and operand records
   // ride in the walk's launch.  One evaluation and one model instance per tree (JC69-type
@@ -248,7 +259,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // moves the cross-over (testing).
   static const int fuse_max_trees =
       getenv("MI_PHYLO_FUSED_MAX_TREES") ? atoi(getenv("MI_PHYLO_FUSED_MAX_TREES")) : 512;
-  const bool fuse_setup = walk3 && e->fused_setup && fuse_allowed && c.E == T && c.models_per_tree == 1 &&
+  const bool fuse_setup = walk3 && !arena && e->fused_setup && fuse_allowed && c.E == T && c.models_per_tree == 1 &&
                           !ts.need_slots && T <= fuse_max_trees && e->ready.ptr &&
                           gradient_walk_lut_fused_applies(n, e->K);
   if (!fuse_setup) launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
@@ -401,6 +412,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
           fs.ms = ms;
           fs.mmats = e->mmats.as<double>();
           fs.ready = e->ready.as<int32_t>();
+          fs.debug_skip = e->fused_debug_skip;
+          fs.spin_ticks = e->fused_spin_ticks;
           launch_gradient_walk_lut_fused(g, fs, part, d.rescaling, s);
         } else if (walk3) launch_gradient_walk_lut(g, part, d.rescaling, s);
         else if (walk2) launch_gradient_walk(g, part, d.rescaling, analytic, s);
@@ -560,18 +573,29 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
 
 int check_status(mi_engine* e, hipStream_t s) {
   HIP_TRY(hipSetDevice(e->spec.device));
-  int32_t st[2] = {0, 0};
+  int32_t st[kStatusWords] = {};
   HIP_TRY(hipMemcpyAsync(st, e->status.ptr, sizeof st, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (st[0] == kFusedTimeout) {
-    // the one-launch call's walk waves waited in vain (workgroups not dispatched in id order?):
-    // this engine takes the four-launch sequence from now on, so that a retry succeeds; its
-    // hand-off words are cleared (waves that gave up left them set)
+  if (st[2] != 0) {
+    // A walk wave of the one-launch call waited in vain for its tree's set-up waves (workgroups
+    // not dispatched in id order? the device held by another process's kernels for longer than
+    // the poll's budget?).  The time-out has a status word of its own, so that an input error
+    // in the same batch -- status[0] keeps the FIRST code -- cannot hide it.  This engine takes
+    // the four-launch sequence from now on (a hipGraph captured BEFORE this point still replays
+    // the one-launch kernel: re-capture it); a host-pointer entry point runs the call again at
+    // once and returns its results (finish_host_call), a *_device caller gets the message
+    // below.  (reduce_finalize has cleared every tree's hand-off word already; the memset makes
+    // the "zero between calls" invariant independent of that.)
     e->fused_setup = false;
+    e->fused_timed_out = true;
     if (e->ready.ptr) HIP_TRY(hipMemsetAsync(e->ready.ptr, 0, e->ready.bytes, s));
+    if (st[0] == 0) {
+      st[0] = kFusedTimeout;
+      st[1] = st[2] - 1;
+    }
   }
   if (st[0] != 0) {  // reported once: the first error since the last check
-    HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, s));
+    HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * kStatusWords, s));
     HIP_TRY(hipStreamSynchronize(s));
     // (a shard of a sharded handle reports the caller's tree index, not its own)
     return fail(std::string(status_message(st[0])) + " (tree " +
@@ -605,15 +629,6 @@ int download(mi_engine* e, double* host, const Buffer& b, size_t count) {
   HIP_TRY(hipMemcpyAsync(p, b.ptr, sizeof(double) * count, hipMemcpyDeviceToHost, e->stream));
   e->pinned.pending.push_back({host, p, sizeof(double) * count});
   return 0;
-}
-
-// End of a host-pointer call: one synchronisation (inside check_status), then the staged
-// outputs are copied to the caller's buffers.
-int finish_host_call(mi_engine* e) {
-  const int rc = check_status(e, e->stream);
-  if (rc == 0) e->pinned.flush();
-  e->pinned.reset();
-  return rc;
 }
 
 void add_block(std::map<std::string, std::pair<int, int>>& m, const std::string& k, int start,
@@ -794,8 +809,15 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   if (const char* env = getenv("MI_PHYLO_GRADIENT_WALK")) {
     e->walk2 = std::string(env) != "v1";
     e->walk3 = std::string(env) != "v1" && std::string(env) != "v2";
+    e->walk_forced = true;
   }
   if (const char* env = getenv("MI_PHYLO_FUSED_SETUP")) e->fused_setup = std::string(env) != "0";
+  if (const char* env = getenv("MI_PHYLO_DEBUG_FUSED_SKIP")) e->fused_debug_skip = atoi(env);
+  // how long a walk wave of the one-launch call polls before it gives up (testing; default 1 s)
+  if (const char* env = getenv("MI_PHYLO_FUSED_SPIN_MS"))
+    e->fused_spin_ticks = (int)std::min(2.0e9, std::max(0.01, atof(env)) * 1.0e5);
+  // MI_PHYLO_WALK3_ARENA=0: arena-variant calls stay with the second / first generation (A/B)
+  if (const char* env = getenv("MI_PHYLO_WALK3_ARENA")) e->walk3_arena = std::string(env) != "0";
   if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH")) {  // force one gradient kernel
     const std::string v(env);
     e->gradient_path = v == "hbm" ? 2 : v == "mfma" ? 3 : 0;
@@ -839,8 +861,8 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   };
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     return cleanup_fail(fail("hipStreamCreate failed"));
-  if (e->status.ensure(sizeof(int32_t) * 2) ||
-      hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, e->stream) != hipSuccess)
+  if (e->status.ensure(sizeof(int32_t) * kStatusWords) ||
+      hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * kStatusWords, e->stream) != hipSuccess)
     return cleanup_fail(fail("status word allocation failed"));
   if (spec->site_model == MI_SITE_WEIBULL) {
     // what the Weibull site model needs of its quantiles, once per engine (kernels_setup.hip)
@@ -886,6 +908,7 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
       return cleanup_fail(fail("copy of the pattern weights failed"));
     if (hipStreamSynchronize(e->stream) != hipSuccess || hipGetLastError() != hipSuccess)
       return cleanup_fail(fail("preparation of the device-resident tips failed"));
+    choose_walk_generation(e);
     *out_engine = e;
     return 0;
   }
@@ -985,6 +1008,7 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   if (upload(e->weights, pattern_weights, (size_t)e->P, e->stream)) return cleanup_fail(1);
   if (hipStreamSynchronize(e->stream) != hipSuccess)
     return cleanup_fail(fail("upload of tips failed"));
+  choose_walk_generation(e);
   *out_engine = e;
   return 0;
 }
@@ -1550,7 +1574,7 @@ int begin_host_call(mi_engine* e, const HostCall& h) {
   // The status word is sticky (the *_device calls never clear it).  A host-pointer call
   // reports ITS OWN errors only: whatever an earlier device-pointer call left unread on this
   // engine's stream is dropped here, not blamed on this batch.
-  HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * 2, e->stream));
+  HIP_TRY(hipMemsetAsync(e->status.ptr, 0, sizeof(int32_t) * kStatusWords, e->stream));
   const size_t np = h.rooted ? 2 * n - 2 : 2 * n - 3, nb = np + 1;
   const bool tt = h.rooted && h.rates && h.heights && h.bounds;
   const bool gtr = e->spec.subst_model == MI_SUBST_GTR;
@@ -1627,6 +1651,27 @@ int begin_host_call(mi_engine* e, const HostCall& h) {
   return download_pack(e, outs);
 }
 
+// End of a host-pointer call: one synchronisation (inside check_status), then the staged
+// outputs are copied to the caller's buffers.  A time-out of the one-launch call (see
+// check_status) does not reach the caller: the call is run again, now through the four-launch
+// sequence -- fresh launches in the same process, nothing else is restarted -- and ITS results
+// and errors are what the caller gets (the reference never fails spuriously:
+// src/engine.cpp:54-92).
+int finish_host_call(mi_engine* e, const HostCall& h) {
+  int rc = check_status(e, e->stream);
+  if (e->fused_timed_out) {
+    e->fused_timed_out = false;
+    e->fused_fallbacks++;
+    e->pinned.reset();
+    rc = begin_host_call(e, h);
+    if (rc == 0) rc = check_status(e, e->stream);
+    e->fused_timed_out = false;
+  }
+  if (rc == 0) e->pinned.flush();
+  e->pinned.reset();
+  return rc;
+}
+
 // A sharded handle: trees dealt to the shards in contiguous blocks (what
 // FatBeagleParallelize's work queue does with thread_count FatBeagles,
 // fat_beagle.hpp:119-149), or -- few trees, very long alignments -- every shard evaluates
@@ -1638,6 +1683,7 @@ int run_sharded(mi_engine* e, const HostCall& h) {
   if (T <= 0) return fail("tree_count must be positive");
   if (e->shard_mode == MI_SHARD_TREES) {
     std::vector<int> started;
+    std::vector<HostCall> calls(D);
     int rc = 0;
     for (int i = 0; i < D && !rc; i++) {
       int32_t b = 0, c = 0;
@@ -1667,10 +1713,11 @@ int run_sharded(mi_engine* e, const HostCall& h) {
         s.out_index_grad = s.out_sum + 2;
       }
       e->shards[i]->status_tree_offset = b;
+      calls[i] = s;
       rc = begin_host_call(e->shards[i], s);
       started.push_back(i);
     }
-    for (int i : started) rc |= finish_host_call(e->shards[i]);
+    for (int i : started) rc |= finish_host_call(e->shards[i], calls[i]);
     if (rc) return 1;
     if (h.reduced) {  // partial sums added in shard order: deterministic
       h.out_sum[0] = h.out_sum[1] = 0;
@@ -1691,6 +1738,7 @@ int run_sharded(mi_engine* e, const HostCall& h) {
   const size_t per = (size_t)T * (1 + (h.gradient ? N + 1 + 8 : 0)) + 2 + h.index_count;
   e->shard_sums.assign((size_t)D * per, 0.0);
   int rc = 0, started = 0;
+  std::vector<HostCall> calls(D);
   for (int i = 0; i < D && !rc; i++, started++) {
     double* base = e->shard_sums.data() + (size_t)i * per;
     HostCall s = h;
@@ -1704,9 +1752,10 @@ int run_sharded(mi_engine* e, const HostCall& h) {
       s.out_sum = base + (size_t)T * (1 + (h.gradient ? N + 1 + 8 : 0));
       s.out_index_grad = s.out_sum + 2;
     }
+    calls[i] = s;
     rc = begin_host_call(e->shards[i], s);
   }
-  for (int i = 0; i < started; i++) rc |= finish_host_call(e->shards[i]);
+  for (int i = 0; i < started; i++) rc |= finish_host_call(e->shards[i], calls[i]);
   if (rc) return 1;
   auto add = [&](double* out, size_t off, size_t count) {
     if (!out) return;
@@ -1737,7 +1786,7 @@ int run_host(mi_engine* e, const HostCall& h) {
     e->pinned.reset();
     return 1;
   }
-  return finish_host_call(e);
+  return finish_host_call(e, h);
 }
 
 }  // namespace

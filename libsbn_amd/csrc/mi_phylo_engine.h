@@ -123,6 +123,8 @@ inline const char* status_message(int code) {
   }
 }
 
+constexpr int kStatusWords = 4;  // code, tree, 1 + tree of a one-launch time-out, spare
+
 struct mi_engine {
   mi_engine_spec spec;
   int n, N, P, K, tiles, max_slots, ll_stride;
@@ -140,6 +142,10 @@ struct mi_engine {
   Buffer weibull_x;  // [K][2] {x_k, log x_k} of the Weibull quantiles (once per engine)
   Buffer ready;  // [T] hand-off words of the one-launch small call (zero between calls)
   bool fused_setup = true;  // MI_PHYLO_FUSED_SETUP=0: always the four-launch sequence
+  bool fused_timed_out = false;  // check_status found the one-launch call's time-out word set
+  int fused_fallbacks = 0;       // host-pointer calls that were run again through four launches
+  int fused_spin_ticks = 0;      // MI_PHYLO_FUSED_SPIN_MS (testing): the walk waves' poll budget, 100 MHz ticks
+  int fused_debug_skip = 0;      // MI_PHYLO_DEBUG_FUSED_SKIP=t+1: tree t's set-up never reports (testing)
   // 20-state path: the engine's eigensystem and the streamed workspace (the arena is `plv`)
   Buffer aa_model, aa_matP, aa_matPT, aa_tipP, aa_tipPQ, aa_exp_cum, aa_exp_loc,
       aa_root_val, aa_root_exp, aa_root_scale;
@@ -150,6 +156,8 @@ struct mi_engine {
   int gradient_path = 0;  // 0 auto, 2 hbm, 3 mfma (MI_PHYLO_GRADIENT_PATH)
   bool walk2 = true;      // second-generation matrix-core gradient walk (MI_PHYLO_GRADIENT_WALK=v1: first)
   bool walk3 = true;      // third generation where it applies (tip children looked up; MI_PHYLO_GRADIENT_WALK=v2: off)
+  bool walk_forced = false;  // MI_PHYLO_GRADIENT_WALK given: engine creation keeps that choice
+  bool walk3_arena = true;  // ... for arena-variant calls too (MI_PHYLO_WALK3_ARENA=0: off)
   // a sharded handle (mi_engine_create_sharded): the per-device / per-shard engines it
   // drives; such a handle owns no device memory itself
   std::vector<mi_engine*> shards;

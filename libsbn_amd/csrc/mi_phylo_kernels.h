@@ -122,7 +122,7 @@ struct LikArgs {
   double* g_part;              // [Eg][tiles][2][N]
   double* site_lik;            // [Eg][tiles*64] per-pattern site likelihood (K > 4 gradient: from the logL pass)
   int32_t* site_exp;           // [Eg][tiles*64] its power of two when rescaling
-  int32_t* status;             // [2]: code, tree (schedule does not fit the kernel's LDS slots)
+  int32_t* status;             // [4]: code, tree (schedule does not fit the kernel's LDS slots), [2]: 1 + tree of a walk wave of the one-launch call that waited in vain
   const int32_t* slot_need;    // [T] arena gradient kernel: LDS slots each tree's schedule uses
   int lds_lo;                  // arena gradient kernel: this launch takes trees with lds_lo < need <= lds_slots
 };
@@ -228,6 +228,8 @@ struct FusedSetupArgs {
   double* mmats;     // operand records of gradient evaluation 0 of the launch
   int32_t* ready;    // [T][kReadyStride]
   int setup_blocks;  // 4 T
+  int spin_ticks;    // how long a walk wave polls its tree's word (100 MHz ticks; 0: the launcher's default, one second)
+  int debug_skip;    // testing: tree debug_skip - 1 never becomes ready (0: off)
 };
 bool gradient_walk_lut_fused_applies(int n, int K);
 void launch_gradient_walk_lut_fused(const LikArgs& a, const FusedSetupArgs& f, int count, bool rescale,

@@ -108,15 +108,22 @@ def test_gtr_branch_gradient_only_takes_one_launch_and_equals_the_full_call():
     fused.close(); plain.close()
 
 
-@pytest.mark.parametrize("site", ["weibull+3", "weibull+4"])
+def _site_params(spec, T, site, rng):
+    return _params(spec, T) if site == "constant" else \
+        _params(spec, T, **{"Weibull shape": rng.uniform(0.4, 1.5, size=(T, 1))})
+
+
+@pytest.mark.parametrize("site", ["constant", "weibull+2", "weibull+3", "weibull+4"])
 def test_small_and_rooted_trees(site):
+    """(round 6: one and two rate categories take the look-up walk, and with it the one-launch
+    call, as well)"""
     rng = np.random.default_rng(77)
     # 5 taxa x 7 patterns (one partial tile), 300 trees: more set-up waves than some CUs hold
     n, P, T = 5, 7, 300
     tips, w = TU.random_alignment(n, P, rng)
     pids, bls = TU.random_trees(n, T, rng, mean_bl=0.07)
     spec = O.make_spec(n, P, "JC69", site, "strict")
-    pr = _params(spec, T, **{"Weibull shape": rng.uniform(0.4, 1.5, size=(T, 1))})
+    pr = _site_params(spec, T, site, rng)
     fused, plain = _engines("JC69", site, tips, w)
     a, b = fused.gradients(pids, bls, pr), plain.gradients(pids, bls, pr)
     assert fused.last_call_info()[0] == FUSED and plain.last_call_info()[0] == PLAIN
@@ -131,7 +138,7 @@ def test_small_and_rooted_trees(site):
     h = np.stack([s[0] for s in state]); bd = np.stack([s[1] for s in state]); ra = np.stack([s[2] for s in state])
     rates = np.full((T, 2 * n - 2), 0.7)
     spec = O.make_spec(n, P, "JC69", site, "strict")
-    pr = _params(spec, T, **{"Weibull shape": rng.uniform(0.4, 1.5, size=(T, 1))})
+    pr = _site_params(spec, T, site, rng)
     fused, plain = _engines("JC69", site, tips, w)
     a = fused.rooted_gradients(pids, bls, pr, rates, np.ones(T, np.int32), h, bd, ra)
     assert fused.last_call_info()[0] == FUSED
@@ -215,3 +222,65 @@ def test_replayed_from_a_graph_under_load():
     fused.check_status(); plain.check_status()
     assert np.array_equal(d_ll.cpu().numpy(), ref_ll) and np.array_equal(d_g.cpu().numpy(), ref_g)
     fused.close(); plain.close()
+
+
+def test_a_time_out_does_not_reach_a_host_pointer_caller(monkeypatch):
+    """VERDICT r5 item 6 / ADVICE r5: the walk waves of the one-launch call poll their tree's
+    hand-off word for a bounded (wall-clock) time.  Should they ever wait in vain, a caller of
+    a host-pointer entry point must not see it -- the reference never fails spuriously
+    (/root/reference/src/engine.cpp:54-92): the engine runs the call again through the four-launch
+    sequence and returns ITS results.  Forced here with a debug switch that makes one set-up
+    wave of tree 2 never report (and a 20 ms budget instead of one second): results equal the
+    four-launch engine's bit for bit, the path string says `setup=own-launch`, later calls of
+    the engine keep four launches; an input error in the same batch is still reported as such.
+    A *_device caller finds the sticky status with its message."""
+    torch = pytest.importorskip("torch")
+    import libsbn_amd as L
+    T = 64
+    tips, w, pids, bls, rng = _ds1(T, seed=21)
+    spec = O.make_spec(27, tips.shape[1], "JC69", "weibull+4", "strict")
+    pr = _params(spec, T, **{"Weibull shape": rng.uniform(0.3, 2.0, size=(T, 1))})
+    _, plain = _engines("JC69", "weibull+4", tips, w)
+    ref = _flat(plain.gradients(pids, bls, pr))
+    monkeypatch.setenv("MI_PHYLO_FUSED_SPIN_MS", "20")  # (read at engine creation)
+    monkeypatch.setenv("MI_PHYLO_DEBUG_FUSED_SKIP", "3")
+    monkeypatch.setenv("MI_PHYLO_FUSED_SETUP", "1")
+    broken = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w)
+    other = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w)
+    third = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w)
+    monkeypatch.delenv("MI_PHYLO_DEBUG_FUSED_SKIP")
+    a = broken.gradients(pids, bls, pr)
+    assert np.array_equal(_flat(a), ref)
+    assert "setup=own-launch" in broken.last_call_path() and broken.last_call_info()[0] == PLAIN
+    a = broken.gradients(pids, bls, pr)  # ... and stays with four launches
+    assert np.array_equal(_flat(a), ref) and broken.last_call_info()[0] == PLAIN
+    # an input error beside the time-out is reported as the input error it is
+    bad = pids.copy()
+    bad[40, 5] = 2
+    with pytest.raises(RuntimeError) as err:
+        other.gradients(bad, bls, pr)
+    assert "(tree 40)" in str(err.value) and "waited in vain" not in str(err.value)
+    a = other.gradients(pids, bls, pr)
+    assert np.array_equal(_flat(a), ref) and other.last_call_info()[0] == PLAIN
+    # device-pointer caller: sticky status, reported once, with the message
+    dev = torch.device("cuda", 0)
+    N = 2 * 27 - 1
+    d = [torch.from_numpy(x).to(dev) for x in (pids, bls, pr)]
+    o_ll = torch.zeros(T, dtype=torch.float64, device=dev)
+    o_g = torch.zeros((T, N), dtype=torch.float64, device=dev)
+    o_s = torch.zeros(T, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    third.gradients_device(st, T, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), o_ll.data_ptr(),
+                           o_g.data_ptr(), o_s.data_ptr(), None)
+    assert third.last_call_info()[0] == FUSED
+    with pytest.raises(RuntimeError) as err:
+        third.check_status(st)
+    assert "waited in vain" in str(err.value) and "(tree 2)" in str(err.value)
+    third.check_status(st)  # reported once
+    third.gradients_device(st, T, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), o_ll.data_ptr(),
+                           o_g.data_ptr(), o_s.data_ptr(), None)
+    third.check_status(st)
+    assert third.last_call_info()[0] == PLAIN
+    assert np.array_equal(o_ll.cpu().numpy(), ref[:T])
+    for e in (plain, broken, other, third):
+        e.close()

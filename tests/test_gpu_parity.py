@@ -989,7 +989,7 @@ np.save(sys.argv[1], np.concatenate(out))
         for walk in ("v1", "v2", "v3"):
             for store in ("", "arena"):
                 for subst_mode in ("", "analytic"):
-                    if walk == "v3" and (store or subst_mode):
+                    if walk == "v3" and subst_mode:
                         continue  # (the third generation leaves those calls to the second)
                     env = dict(os.environ, MI_PHYLO_GRADIENT_WALK=walk)
                     env.pop("MI_PHYLO_GRADIENT_STORE", None)
@@ -1018,9 +1018,12 @@ np.save(sys.argv[1], np.concatenate(out))
     # list; the others fall back to the second) looks tip products up instead of multiplying.
     # P e_s IS column s of P, and the all-ones vector's row sum is added in index order by the
     # table builder exactly as the matrix instruction adds its four terms: BIT-IDENTICAL.
-    a, b = results[("v3", "", "")], results[("v2", "", "")]
-    assert a.shape == b.shape and np.isfinite(a).all()
-    assert np.array_equal(a, b), np.max(np.abs(a - b))
+    # Round 6: so do its arena variant (stored vectors of the larger trees through HBM) and its
+    # one- and two-category forms -- every engine of the list with at most four categories.
+    for store in ("", "arena"):
+        a, b = results[("v3", store, "")], results[("v2", store, "")]
+        assert a.shape == b.shape and np.isfinite(a).all()
+        assert np.array_equal(a, b), (store, np.max(np.abs(a - b)))
 
 
 def test_waves_taking_several_tiles_are_bit_identical_and_match_oracle():
@@ -1123,7 +1126,7 @@ np.save(sys.argv[1], np.concatenate(out))
 """
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as tmp:
-        for walk in ("v1", "v2"):
+        for walk in ("v1", "v2", "v3"):
             got = {}
             for store in ("lds", "arena", ""):
                 env = dict(os.environ, MI_PHYLO_GRADIENT_WALK=walk)

@@ -250,31 +250,114 @@ def cpu_baseline(tips, w, pids, bls, params, mode, budget_s=15.0, reps=10):
                              "not BEAGLE (dlopen probe for libhmsbeagle in beagle_probe)"}
 
 
-def roofline(kname, k_ms, units, flops_per_unit, bytes_per_unit, traffic=None,
-             traffic_source=None):
-    """The dominant kernel against the roofline that binds it.  The 4-state walk kernels keep
-    partial vectors in LDS: what binds them is the FP64 matrix/vector datapath, so `frac` is
-    SURVEY 8(d)'s algorithmic flops x units per launch / kernel time against the MEASURED FP64
-    peak.  The 8(d) PLV-streaming byte model is kept beside it as `hbm_model_*` (it exceeds the
-    HBM peak for an on-chip kernel and is therefore NOT a roofline fraction), and the real
-    HBM-side bytes per launch (PMC, profiles/traffic.json) as `traffic` / `hbm_frac`."""
-    tflops = flops_per_unit * units / (k_ms * 1e-3) / 1e12
-    gbps = bytes_per_unit * units / (k_ms * 1e-3) / 1e9
-    out = {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": tflops / FP64_PEAK_TFLOPS, "fp64_peak_source": FP64_PEAK_SOURCE,
-           "traffic": traffic, "traffic_source": traffic_source,
-           "kernel": kname, "kernel_ms": k_ms, "units_per_launch": units,
-           "algorithmic_flops_per_tree": flops_per_unit,
-           "hbm_model_GBps": gbps, "hbm_model_over_peak": gbps / HBM_PEAK_GBPS,
-           "hbm_model_bytes_per_tree": bytes_per_unit,
-           "note": "achieved = SURVEY 8(d) algorithmic flops x trees per launch / kernel time "
-                   "(HIP events on the call's stream); hbm_model_* = the 8(d) PLV-streaming "
-                   "byte model over the same time, kept for reference only (partial vectors "
-                   "stay in LDS, so it is not a bound); hbm_frac = real HBM-side bytes (PMC) "
-                   "/ kernel time / 8 TB/s"}
-    if traffic:
-        out["hbm_frac"] = traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+FP64_PEAK_DATASHEET_TFLOPS = 78.6
+
+
+def executed_flops_per_tree(kname, n, P, K, R=3):
+    """Flops of the FP64 matrix instructions a 4-state walk kernel EXECUTES for one tree, from
+    the launch geometry (pattern tiles per tree) x the matrix instructions of a tile job, which
+    follow from the tree size alone (checked against SQ_INSTS_MFMA of the committed counter
+    tables: 385 / 628 / 208 per job for a 27-taxon tree) x 512 flops per v_mfma_f64_4x4x4_4b.
+      look-up walk (gradient_walk_lut*):   4 (n-2) R + 2 R + 1 + 3 (n-1)   (tip children: none)
+      mask-tip walks (gradient_walk / gradient_mfma):  (7 n - 8) R + 2 R + 1 + 3 (n-1)
+      loglik_mfma (R = 4):                 2 (n-1) R + R + 1
+    None for kernels that do not run on the matrix cores or for more than four categories."""
+    if K > 4:
+        return None
+    kp = 1 if K == 1 else (2 if K == 2 else 4)
+    if kname.startswith("gradient_walk_lut"):
+        per_job = 4 * (n - 2) * R + 2 * R + 1 + 3 * (n - 1)
+    elif kname.startswith(("gradient_walk_kernel", "gradient_mfma_kernel")):
+        per_job = (7 * n - 8) * R + 2 * R + 1 + 3 * (n - 1)
+    elif kname.startswith("loglik_mfma"):
+        R = 4
+        per_job = 2 * (n - 1) * R + R + 1
+    else:
+        return None
+    per_tile = R * (16 // kp)
+    return ((P + per_tile - 1) // per_tile) * per_job * 512.0
+
+
+def pipe_entry(kname, launch_trees=None):
+    """profiles/pipe.json (tools/pipe_table.py, from the committed SQ-counter tables): how busy
+    the vector pipe was during a launch of this kernel -- static, not measured in this run."""
+    try:
+        table = json.load(open(os.path.join(REPO, "profiles", "pipe.json")))
+    except (OSError, ValueError):
+        return None
+    base = kname.split("<")[0].split(" ")[0]
+    want_grad = "true" in kname
+    hits = []
+    for key, ent in table.items():
+        if not key.startswith(base):
+            continue
+        if base.startswith("aa_post") and (("true" in key.split(" ")[0]) != want_grad):
+            continue
+        if launch_trees is not None and " tree(s) per launch" in key and \
+                f"-- {launch_trees} tree(s) per launch" not in key:
+            continue
+        hits.append((ent.get("round", ""), key, ent))
+    if not hits:
+        return None
+    hits.sort(reverse=True)
+    return hits[0][2]
+
+
+def unified_roofline(kname, k_ms, units, alg_flops_per_unit, exec_flops_per_unit, traffic=None,
+                     traffic_source=None, model_bytes_per_unit=None, pipe_trees=None):
+    """ONE convention for every leg, 4-state and 20-state.  Per launch of the
+    dominant kernel, `kernel_ms` from HIP events on the call's stream:
+      frac_algorithmic  SURVEY 8(d) algorithmic flops x units / time / MEASURED FP64 matrix peak
+                        (71.1 TFLOP/s; `_datasheet`: against 78.6).  Can exceed 1 where the kernel
+                        does not execute what the model counts (tip children are table look-ups);
+      frac_executed     flops of the matrix instructions really executed / time / measured peak;
+      pipe_busy         (16|64 x MFMA + 4 x other vector instructions) / SIMD cycles of the launch,
+                        STATIC: from the committed SQ-counter tables (profiles/pipe.json);
+      hbm_frac          HBM-side bytes per launch (PMC; STATIC: profiles/traffic.json) / time / 8 TB/s.
+    `bound` names the resource that binds -- "hbm" when hbm_frac exceeds the executed matrix
+    fraction, else "mfma" (the SIMD's FP64 pipe) -- and `achieved` / `peak` / `unit` / `frac` are
+    the task contract's fields for it: algorithmic flops (or real bytes) per launch / time."""
+    sec = k_ms * 1e-3
+    alg = alg_flops_per_unit * units / sec / 1e12
+    exe = exec_flops_per_unit * units / sec / 1e12 if exec_flops_per_unit else None
+    hbm_frac = traffic / sec / 1e9 / HBM_PEAK_GBPS if traffic else None
+    pipe = pipe_entry(kname, pipe_trees)
+    out = {"kernel": kname, "kernel_ms": k_ms, "units_per_launch": units,
+           "frac_algorithmic": alg / FP64_PEAK_TFLOPS,
+           "frac_executed": exe / FP64_PEAK_TFLOPS if exe is not None else None,
+           "pipe_busy": pipe["pipe_busy"] if pipe else None,
+           "hbm_frac": hbm_frac,
+           "algorithmic_TFLOPs": alg, "executed_TFLOPs": exe,
+           "peak_measured": FP64_PEAK_TFLOPS, "peak_datasheet": FP64_PEAK_DATASHEET_TFLOPS,
+           "frac_algorithmic_datasheet": alg / FP64_PEAK_DATASHEET_TFLOPS,
+           "frac_executed_datasheet": exe / FP64_PEAK_DATASHEET_TFLOPS if exe is not None else None,
+           "fp64_peak_source": FP64_PEAK_SOURCE,
+           "pipe_busy_source": ("static: " + pipe["source"] + " via profiles/pipe.json") if pipe else None,
+           "traffic": traffic,
+           "traffic_source": ("static: " + traffic_source) if traffic_source else None,
+           "algorithmic_flops_per_unit": alg_flops_per_unit,
+           "executed_flops_per_unit": exec_flops_per_unit}
+    if model_bytes_per_unit:
+        out["hbm_model_bytes_per_unit"] = model_bytes_per_unit
+        out["hbm_model_over_peak"] = model_bytes_per_unit * units / sec / 1e9 / HBM_PEAK_GBPS
+    pipe_frac = out["frac_executed"] if out["frac_executed"] is not None else out["frac_algorithmic"]
+    if hbm_frac is not None and hbm_frac >= pipe_frac:
+        out.update(bound="hbm", achieved=traffic / sec / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s", frac=hbm_frac)
+    else:
+        out.update(bound="mfma", achieved=alg, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                   frac=out["frac_algorithmic"])
     return out
+
+
+def roofline(kname, k_ms, units, flops_per_unit, bytes_per_unit, traffic=None,
+             traffic_source=None, shape=None, exec_flops_per_unit=None):
+    """A 4-state leg.  The walk kernels keep partial vectors in LDS: what binds them is the
+    SIMD's FP64 pipe.  shape = (n, P, K): the executed matrix flops follow from the kernel that
+    ran and the launch geometry (executed_flops_per_tree); whole-call legs pass their own sum."""
+    if exec_flops_per_unit is None and shape is not None:
+        exec_flops_per_unit = executed_flops_per_tree(kname, *shape)
+    return unified_roofline(kname, k_ms, units, flops_per_unit, exec_flops_per_unit, traffic,
+                            traffic_source, bytes_per_unit)
 
 
 def traffic_entry(name):
@@ -297,12 +380,12 @@ def traffic_entry(name):
     return table[hits[0]] if hits else None
 
 
-def streamed_roofline(kname, k_ms, evals, traffic_key, mfma_flops_per_eval, model_bytes_per_eval):
-    """A kernel that streams partial vectors through HBM (the 20-state walk kernels): both
-    candidate bounds, per launch -- real HBM-side bytes (PMC; per-evaluation figure x the
-    evaluations of THIS launch when no measurement of this launch size exists, said so in
-    traffic_source) over kernel time against 8 TB/s, and the 20x20 products really executed
-    against the measured FP64 matrix peak.  `bound` names the larger one; `frac` is it."""
+def streamed_roofline(kname, k_ms, evals, traffic_key, mfma_flops_per_eval, model_bytes_per_eval,
+                      alg_flops_per_eval, traffic_scale=1.0):
+    """A 20-state leg (partial vectors stream through HBM): the same fields as every other leg
+    (unified_roofline).  HBM-side bytes: the PMC figure of a launch of this size where one was
+    profiled, else the one-tree figure x the evaluations of this launch (said so in
+    traffic_source); traffic_scale: this run's share of the profiled alignment (pattern shards)."""
     ent = traffic_entry(f"{traffic_key}|T={evals}")
     if ent:
         traffic, src = ent["hbm_bytes_per_launch"], f"profiles/traffic.json [{traffic_key}|T={evals}] ({ent.get('round', '')}), measured at this launch size"
@@ -311,28 +394,11 @@ def streamed_roofline(kname, k_ms, evals, traffic_key, mfma_flops_per_eval, mode
         traffic = ent["hbm_bytes_per_launch"] * evals if ent else None
         src = (f"profiles/traffic.json [{traffic_key}] one-tree launch x {evals} evaluations "
                f"({ent.get('round', '')})" if ent else None)
-    sec = k_ms * 1e-3
-    mfma = mfma_flops_per_eval * evals / sec / 1e12
-    out = {"kernel": kname, "kernel_ms": k_ms, "units_per_launch": evals,
-           "traffic": traffic, "traffic_source": src,
-           "mfma_TFLOPs": mfma, "mfma_frac": mfma / FP64_PEAK_TFLOPS,
-           "fp64_peak_source": FP64_PEAK_SOURCE,
-           "hbm_model_bytes_per_tree": model_bytes_per_eval,
-           "hbm_model_over_peak": model_bytes_per_eval * evals / sec / 1e9 / HBM_PEAK_GBPS,
-           "note": "hbm_frac = real HBM-side bytes of the launch (PMC) / kernel time (HIP events "
-                   "around this kernel) / 8 TB/s; mfma_frac = executed 20x20 products (tip "
-                   "children are table look-ups) / measured FP64 matrix peak; hbm_model_* = "
-                   "SURVEY 8(d) PLV-streaming model (every vector read and written; the kernels "
-                   "keep the chained child in registers), for reference only"}
-    hbm_frac = traffic / sec / 1e9 / HBM_PEAK_GBPS if traffic else None
-    out["hbm_frac"] = hbm_frac
-    if hbm_frac is not None and hbm_frac >= out["mfma_frac"]:
-        out.update(bound="hbm", achieved=traffic / sec / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
-                   frac=hbm_frac)
-    else:
-        out.update(bound="mfma", achieved=mfma, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-                   frac=out["mfma_frac"])
-    return out
+    if traffic is not None and traffic_scale != 1.0:
+        traffic *= traffic_scale
+        src += f", x {traffic_scale:.4f} (this run's share of the profiled alignment)"
+    return unified_roofline(kname, k_ms, evals, alg_flops_per_eval, mfma_flops_per_eval, traffic, src,
+                            model_bytes_per_eval, pipe_trees=evals if traffic_scale == 1.0 else None)
 
 
 def rel_err(a, b):
@@ -379,7 +445,9 @@ def _pick(d, keys):
 
 
 ROOFLINE_KEYS = ("kernel", "kernel_ms", "units_per_launch", "bound", "achieved", "peak", "unit",
-                 "frac", "traffic", "hbm_frac")
+                 "frac", "frac_algorithmic", "frac_executed", "pipe_busy", "hbm_frac", "traffic",
+                 "peak_measured", "peak_datasheet")
+ALSO_ROOFLINE_KEYS = ("bound", "frac", "frac_algorithmic", "frac_executed", "pipe_busy", "hbm_frac")
 
 
 def final_line(full):
@@ -421,10 +489,18 @@ def final_line(full):
     if full.get("gathered"):
         out["gathered"] = _pick(full["gathered"], ("trees_per_s", "ms_per_step", "collective"))
     if full.get("also"):
-        out["also"] = [dict(_pick(a, ("trees_per_s", "parity_max_rel_err")),
-                            workload=a.get("short", a.get("workload", ""))[:48],
-                            **_pick(a.get("roofline") or {}, ("bound", "frac")))
-                       for a in full["also"]]
+        # one row per other leg, the SAME columns for every leg (4-state and 20-state alike; the
+        # column names once: fifteen legs as objects would not fit the line); null = not applicable
+        keys = ("workload", "trees_per_s", "parity_max_rel_err") + ALSO_ROOFLINE_KEYS + ("full_over_shard",)
+        rows = []
+        for a in full["also"]:
+            r = a.get("roofline") or {}
+            row = [a.get("short", a.get("workload", ""))[:40], _sig(a.get("trees_per_s"), 4),
+                   _sig(a.get("parity_max_rel_err"), 2)]
+            row += [r.get("bound")] + [_sig(r.get(k), 3) for k in ALSO_ROOFLINE_KEYS[1:]]
+            row.append(_sig(a.get("full_over_shard"), 3))
+            rows.append(row)
+        out["also"] = {"keys": list(keys), "rows": rows}
     out["detail"] = "bench_also.json"
     line = json.dumps(_sig(out), separators=(",", ":"))
     if len(line) >= LINE_LIMIT:
@@ -561,8 +637,11 @@ def also_workloads(torch, dev, L, steps):
                        og["substitution_model"], 1e-6)]
         err = parity(pairs)
         # the whole call against the FP64 roofline: every pass of the call is a walk kernel
-        r = roofline(kname, ms, T, flops, bytes_)
-        r["note"] = ("whole call (all its walk passes) over the step time; " + r["note"])
+        # the whole call against the FP64 pipe: every pass of the call is a walk kernel
+        x_g, x_ll = executed_flops_per_tree(kname, n, P, K), executed_flops_per_tree("loglik_mfma", n, P, K)
+        r = roofline(kname, ms, T, flops, bytes_,
+                     exec_flops_per_unit=(2 * x_g + 16 * x_ll) if full else x_g)
+        r["note"] = "whole call (all its walk passes) over the step time"
         out.append({"workload": f"DS1 27 taxa x {P} patterns x {T} trees, GTR+weibull+4, " + label,
                     "short": short, "trees_per_s": T / (ms * 1e-3), "ms_per_step": ms,
                     "kernel": kname,
@@ -593,7 +672,8 @@ def also_workloads(torch, dev, L, steps):
                 "kernel_ms": k_ms,
                 "roofline": roofline(kname, k_ms, T, f_ll, b_ll,
                                      ent["hbm_bytes_per_launch"] if ent else None,
-                                     "profiles/traffic.json (PMC, 1000-tree launch), not this run"),
+                                     "profiles/traffic.json (PMC, 1000-tree launch), not this run",
+                                     shape=(n, P, K)),
                 "parity_checked": S, "parity_max_rel_err": err})
     eng.close()
     # S-DS1, 1949 patterns (every column of a DS1-sized alignment its own pattern)
@@ -620,7 +700,7 @@ def also_workloads(torch, dev, L, steps):
                             "trees, JC69+weibull+4, phylo_gradients",
                 "short": "S-DS1 1949 patterns x1000 gradients", "trees_per_s": T / (ms * 1e-3),
                 "ms_per_step": ms, "kernel": kname,
-                "kernel_ms": k_ms, "roofline": roofline(kname, k_ms, T, f2_g, b2_g),
+                "kernel_ms": k_ms, "roofline": roofline(kname, k_ms, T, f2_g, b2_g, shape=(n, 1949, K)),
                 "parity_checked": S, "parity_max_rel_err": err})
     eng.close()
 
@@ -666,7 +746,7 @@ def also_workloads(torch, dev, L, steps):
                     "trees_per_s": Tf / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
                     "kernel_ms": k_ms, "logL0": float(ll[0]),
                     "phase_ms": {"setup": phase_ms[0], "walk": phase_ms[2], "rest": phase_ms[3]},
-                    "roofline": roofline(kname, k_ms, Tf, ff_g, bf_g),
+                    "roofline": roofline(kname, k_ms, Tf, ff_g, bf_g, shape=(n, P, 1)),
                     "parity_checked": S, "parity_max_rel_err": err})
         eng.close()
 
@@ -696,7 +776,11 @@ def also_workloads(torch, dev, L, steps):
         oracle_s = time.perf_counter() - t0
     finally:
         O.set_transition_mode(0)
-    for Tw in (1, 8):
+    def swag_legs(eng, Pe, Tw, og, oracle_note, scale, what):
+        """log_likelihoods and phylo_gradients of Tw trees on an engine of Pe site patterns (scale =
+        Pe / P: its share of the full alignment), tree 0 against the oracle results `og`."""
+        legs = []
+        plv = K * Pe * 20 * 8
         pids, bls = pids8[:Tw], bls8[:Tw]
         d_pid, d_bl, d_par = dev_arrays(pids, bls, np.ones((Tw, 2)))
         ll = torch.empty(Tw, dtype=torch.float64, device=dev)
@@ -712,7 +796,7 @@ def also_workloads(torch, dev, L, steps):
             else:
                 fn = lambda: eng.log_likelihoods_device(  # noqa: E731
                     stream, Tw, d_pid.data_ptr(), d_bl.data_ptr(), d_par.data_ptr(), ll.data_ptr())
-            ms, k_ms = tm.run(fn, 3 if Tw == 1 else 2, 1)
+            ms, k_ms = tm.run(fn, (3 if Tw == 1 else 2) if scale == 1.0 else 10, 1)
             phase_ms, first = tm.phases(fn, 2)
             launches = eng.last_call_launches()[0]
             assert bool(torch.isfinite(ll).all())
@@ -721,45 +805,91 @@ def also_workloads(torch, dev, L, steps):
                 pairs += [("branch gradient of tree 0", host(g, 1), og["branch_lengths"]),
                           ("site gradient of tree 0", host(site, 1), og["site_model"])]
             err = parity(pairs)
-            b_model = ((10 * n - 14) if grad else 2 * (n - 1)) * plv + (12 if grad else 4) * n * P
+            b_model = ((10 * n - 14) if grad else 2 * (n - 1)) * plv + (12 if grad else 4) * n * Pe
+            f_ll_aa, f_g_aa = algorithmic_flops(n, Pe, K, s=20)
             # what the kernels really have to do: a tip child's product is a table look-up,
             # so only the n-2 internal edges cost 20x20 products: one each in the post-order
             # pass; in the pre-order pass two each, plus P L once per node with two internal
             # children (the child the post-order pass did NOT take from registers)
-            prod = K * P * 800.0
+            prod = K * Pe * 800.0
             post = streamed_roofline(
                 "aa_post_wg_kernel<2," + ("true" if grad else "false") + "> (+ aa_root_kernel)",
                 phase_ms[1], first,
                 "aa_post_wg_kernel<2, true>" if grad else "aa_post_wg_kernel<2, false>",
-                (n - 2) * prod, (2 * (n - 1)) * plv + 4 * n * P)
-            entry = {"workload": f"S-WAG 20 states, {n} taxa x {P} patterns x {K} categories "
-                                 f"x {Tw} tree(s), " + ("phylo_gradients" if grad else
-                                                        "log_likelihoods"),
-                     "short": f"S-WAG 512x50000x4 T={Tw} " + ("gradients" if grad else "logL"),
+                (n - 2) * prod, (2 * (n - 1)) * plv + 4 * n * Pe, f_ll_aa, traffic_scale=scale)
+            entry = {"workload": f"S-WAG 20 states, {n} taxa x {Pe} patterns x {K} categories "
+                                 f"x {Tw} tree(s){what}, " + ("phylo_gradients" if grad else
+                                                              "log_likelihoods"),
+                     "short": f"S-WAG 512x{Pe}x4 T={Tw} " + ("gradients" if grad else "logL"),
                      "trees_per_s": Tw / (ms * 1e-3), "ms_per_step": ms,
                      "kernel": eng.last_call_info()[0], "kernel_ms": k_ms,
+                     "path": eng.last_call_path(),
                      "walk_launches": launches, "evaluations_in_first_launch": first,
                      "logL0": float(ll[0]),
                      "phase_ms": {"setup": phase_ms[0], "post_order": phase_ms[1],
                                   "pre_order": phase_ms[2], "rest": phase_ms[3]},
-                     "hbm_model_bytes_per_tree": b_model,
-                     "hbm_model_over_peak": b_model * Tw / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "parity_checked": 1, "parity_max_rel_err": err,
                      "parity_note": "tree 0 vs the CPU oracle evaluated on pattern blocks "
-                                    f"({oracle_s:.0f} s on {cores} threads): "
+                                    f"({oracle_note}): "
                                     + ("logL, branch and site gradients" if grad and
                                        "branch_lengths" in og else "logL")}
             if grad:
                 pre = streamed_roofline(
                     "aa_pre_wg_kernel<2>", phase_ms[2], first, "aa_pre_wg_kernel<2>",
                     (2 * (n - 2) + two_internal_children(pids[0], n)) * prod,
-                    (8 * n - 12) * plv + 8 * n * P)
+                    (8 * n - 12) * plv + 8 * n * Pe, f_g_aa - f_ll_aa, traffic_scale=scale)
                 entry["roofline"] = pre  # the dominant kernel of a gradient call
                 entry["roofline_post_order"] = post
             else:
                 entry["roofline"] = post
-            out.append(entry)
+            legs.append(entry)
+        return legs
+
+    full = {}
+    for Tw in (1, 8):
+        legs = swag_legs(eng, P, Tw, og, f"{oracle_s:.0f} s on {cores} threads", 1.0, "")
+        full[Tw] = legs
+        out += legs
     eng.close()
+    # --- configs[4] is worded "8 x MI355X": a rank's share of it on ONE GPU (VERDICT r5 item 2;
+    # what `small_batch` is for DS1).  Two ways to deal it to 8 ranks (SURVEY 8(e);
+    # /root/reference/src/fat_beagle.hpp:134-147): (i) 8 trees, tree-sharded -- a rank runs ONE tree on
+    # the whole alignment (the T = 1 legs above); (ii) few trees, pattern-sharded -- a rank runs
+    # every tree on 50 000 / 8 = 6 250 patterns (engine built from a rank's block, as
+    # libsbn_amd/sharding.py deals them) and ONE all-reduce adds the per-tree results.
+    # full_over_shard = time of the whole job on one GPU / time of a rank's share: the speed-up 8
+    # GPUs would give before the collective.
+    Ps = P // 8
+    tips_s, w_s = np.ascontiguousarray(tips[:, :Ps]), np.ascontiguousarray(w[:Ps])
+    O.set_reversible_model(ex, fr)
+    O.set_transition_mode(1)
+    try:
+        t0 = time.perf_counter()
+        og_s = O.unrooted_by_pattern_blocks(O.make_spec(n, Ps, "reversible", f"weibull+{K}", s=20),
+                                            tips_s, w_s, pids8[:1], bls8[:1], np.ones((1, 2)),
+                                            rescaling=True, gradient=cores >= 8, threads=cores)
+        oracle_shard_s = time.perf_counter() - t0
+    finally:
+        O.set_transition_mode(0)
+    eng = L.Engine(L.PhyloModelSpecification("WAG", f"weibull+{K}", "strict"), tips_s, w_s,
+                   device=dev.index)
+    shard = {}
+    for Tw in (1, 8):
+        legs = swag_legs(eng, Ps, Tw, og_s, f"{oracle_shard_s:.1f} s on {cores} threads", Ps / P,
+                         " -- one rank's pattern block of eight")
+        shard[Tw] = legs
+        out += legs
+    eng.close()
+    for Tw in (1, 8):
+        for i, what in ((0, "logL"), (1, "gradients")):
+            shard[Tw][i]["full_over_shard"] = full[Tw][i]["ms_per_step"] / shard[Tw][i]["ms_per_step"]
+            shard[Tw][i]["full_over_shard_note"] = (
+                f"T = {Tw} on 50 000 patterns / T = {Tw} on a rank's 6 250: 8-way PATTERN sharding "
+                "before the all-reduce")
+    for i in (0, 1):
+        full[1][i]["full_over_shard"] = full[8][i]["ms_per_step"] / full[1][i]["ms_per_step"]
+        full[1][i]["full_over_shard_note"] = ("T = 8 / T = 1 on the whole alignment: 8-way TREE "
+                                              "sharding of an 8-tree batch before the all-gather")
     return out
 
 
@@ -839,24 +969,19 @@ def swag_pattern_sharded(args, torch, dist, L, sharding, dev, rank, world, distr
     b_model = ((10 * n - 14) if grad else 2 * (n - 1)) * plv + (12 if grad else 4) * n * P
     ms = 1e3 * elapsed / steps
     prod = K * P * 800.0 * share
+    f_ll_aa, f_g_aa = algorithmic_flops(n, P, K, s=20)
     post = streamed_roofline(
         "aa_post_wg_kernel<2," + ("true" if grad else "false") + "> (+ aa_root_kernel)",
         phase_ms[1], first,
         "aa_post_wg_kernel<2, true>" if grad else "aa_post_wg_kernel<2, false>",
-        (n - 2) * prod, ((2 * (n - 1)) * plv + 4 * n * P) * share)
+        (n - 2) * prod, ((2 * (n - 1)) * plv + 4 * n * P) * share, f_ll_aa * share,
+        traffic_scale=share)
     rl = post
     if grad:
         rl = streamed_roofline("aa_pre_wg_kernel<2>", phase_ms[2], first, "aa_pre_wg_kernel<2>",
                                (2 * (n - 2) + two_internal_children(pids[0], n)) * prod,
-                               ((8 * n - 12) * plv + 8 * n * P) * share)
-    for r in (rl, post):  # the PMC figures are for the whole alignment: scale to the block
-        if r.get("traffic") and share != 1.0:
-            for key in ("traffic", "hbm_frac"):
-                r[key] *= share
-            if r["bound"] == "hbm":
-                r["achieved"] *= share
-                r["frac"] *= share
-            r["traffic_source"] += f", x {share:.4f} (this rank's pattern block)"
+                               ((8 * n - 12) * plv + 8 * n * P) * share,
+                               (f_g_aa - f_ll_aa) * share, traffic_scale=share)
     return {
         "metric": "tree log-likelihoods+gradients/sec (batched)" if grad
                   else "tree log-likelihoods/sec (batched)",
@@ -1581,7 +1706,8 @@ def main():
                                  "product's FASTA / Newick ingest"},
             "roofline": roofline(kname, k_ms, T_local, f_g if grad else f_ll,
                                  b_g if grad else b_ll, traffic,
-                                 "profiles/traffic.json (PMC, 1000-tree launch), not this run"),
+                                 "profiles/traffic.json (PMC, 1000-tree launch), not this run",
+                                 shape=(n, P, K)),
             "parity_checked": parity_n, "parity_max_rel_err": parity_err,
             "parity_note": "first trees of the last timed step vs the CPU oracle, tolerance 1e-10",
             "rank_devices": rank_devices,

@@ -73,6 +73,12 @@ __device__ __forceinline__ void pack_operands(const double* __restrict__ pack, i
   for (int t = 0; t < 5; t++) A[5 + t] = pack[tail + 16 * t];
 }
 
+__device__ __forceinline__ double wave_sum_aa(double v) {  // every lane gets the sum
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 // ------------------------------------------------------------------------
 // Model set-up: Q from (exchangeabilities, frequencies) by the reference's GTR recipe
 // (substitution_model.cpp:39-80) and its symmetric eigendecomposition (cyclic Jacobi,
@@ -192,6 +198,165 @@ __global__ __launch_bounds__(64) void aa_model_setup_kernel(const double* exch,
     m->Q[idx] = Q[idx];
     m->V[idx] = (1.0 / sq[i]) * U[idx];
     m->Vinv[idx] = U[j * kAa + i] * sq[j];
+  }
+  for (int idx = lane; idx < kAaPack; idx += 64) {  // Q in the A-operand layout (below)
+    const AaPackEntry pe = aa_pack_entry(idx);
+    m->Qpack[idx] = pe.used ? Q[pe.row * kAa + pe.col] : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------
+// The same, wave-parallel (round 6): the kernel above applies its 190
+// rotations per sweep one after the other, the rotation's cosine and sine computed by ONE lane
+// between two barriers, and its stopping bound (off <= 1e-45 diag on squared norms) is
+// unreachable in double precision -- it always runs its 100 sweeps: 10.1 ms for ONE 20 x 20
+// eigensystem at every 20-state engine creation.  Here
+//   * a sweep is 19 steps of TEN disjoint rotations (round-robin pairing: player 19 stays, the
+//     other 19 rotate -- every pair (p, q) exactly once per sweep); ten lanes compute the
+//     cosines / sines, then all 64 lanes apply the ten column rotations to A and U (200 + 200
+//     element pairs), then the ten row rotations to A: disjoint rotations commute, so the step
+//     is J^T A J with J their product;
+//   * the off-diagonal / diagonal norms are summed by the wave, and the loop stops at the
+//     rounding level (off <= 1e-30 diag) or when a sweep no longer reduces the off-diagonal
+//     norm (at most 30 sweeps; 7-9 for WAG-like matrices);
+//   * Q is built by all lanes (each entry and each row sum by the same expression in the same
+//     order as above: bit-identical Q), the eigenvalues are ranked in parallel.
+// Another rotation order: eigenvalues and P(t) agree with the kernel above to ~1e-15, not
+// bit for bit (eigenvectors may come out with the other sign; V and V^-1 change together).
+// MI_PHYLO_AA_JACOBI=seq selects the kernel above (tests/test_aa_gpu.py compares the two).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void aa_model_setup_wave_kernel(const double* exch,
+                                                                  const double* freqs, AaModel* m,
+                                                                  int32_t* status) {
+  __shared__ double A[kAa * kAa], U[kAa * kAa], U2[kAa * kAa], Q[kAa * kAa], pi[kAa], sq[kAa], ev[kAa], rowsum[kAa];
+  __shared__ double rc[10], rs[10];
+  __shared__ int rank_of[kAa];
+  const int lane = threadIdx.x;
+  if (lane < kAa) {
+    pi[lane] = freqs[lane];
+    sq[lane] = sqrt(freqs[lane]);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double fsum = 0;
+    for (int i = 0; i < kAa; i++) fsum += pi[i];
+    if (fabs(fsum - 1.) >= 0.001) set_status(status, kGtrFrequencies, 0);
+  }
+  for (int idx = lane; idx < kAa * kAa; idx += 64) {
+    const int i = idx / kAa, j = idx % kAa;
+    if (i != j) {
+      const int a = i < j ? i : j, b = i < j ? j : i;
+      const double r = exch[a * (2 * kAa - a - 1) / 2 + (b - a - 1)];
+      Q[idx] = r * pi[j];
+    }
+  }
+  __syncthreads();
+  if (lane < kAa) {
+    double row = 0;
+    for (int j = 0; j < kAa; j++)
+      if (lane != j) row += Q[lane * kAa + j];
+    Q[lane * kAa + lane] = -row;
+    rowsum[lane] = row;
+  }
+  __syncthreads();
+  double total = 0;
+  for (int i = 0; i < kAa; i++) total += rowsum[i] * pi[i];
+  for (int idx = lane; idx < kAa * kAa; idx += 64) Q[idx] /= total;
+  __syncthreads();
+  for (int idx = lane; idx < kAa * kAa; idx += 64) {
+    const int i = idx / kAa, j = idx % kAa;
+    // S = Pi^1/2 Q Pi^-1/2; the lower triangle is authoritative
+    const int a = i >= j ? i : j, b = i >= j ? j : i;
+    A[idx] = sq[a] * Q[a * kAa + b] * (1.0 / sq[b]);
+    U[idx] = i == j ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  double prev_off = 1e300;
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = 0, diag = 0;
+    for (int idx = lane; idx < kAa * kAa; idx += 64) {
+      const double x = A[idx];
+      if (idx / kAa != idx % kAa) off += x * x;
+      else diag += x * x;
+    }
+    off = wave_sum_aa(off);
+    diag = wave_sum_aa(diag);
+    if (off <= 1e-30 * diag || off == 0. || off >= prev_off) break;  // (wave-uniform: every lane holds the sums)
+    prev_off = off;
+    for (int step = 0; step < kAa - 1; step++) {
+      // this lane's pair of the step (lanes 0..9 compute it; every lane needs one for the updates)
+      auto pair_of = [&](int i, int& p, int& q) {
+        const int x = i == 0 ? kAa - 1 : (step + i) % (kAa - 1);
+        const int y = i == 0 ? step : (step - i + (kAa - 1)) % (kAa - 1);
+        p = x < y ? x : y;
+        q = x < y ? y : x;
+      };
+      if (lane < 10) {
+        int p, q;
+        pair_of(lane, p, q);
+        const double apq = A[p * kAa + q];
+        double c = 1.0, sn = 0.0;
+        if (apq != 0.) {
+          const double theta = (A[q * kAa + q] - A[p * kAa + p]) / (2. * apq);
+          const double t = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+          c = 1. / sqrt(t * t + 1.);
+          sn = t * c;
+        }
+        rc[lane] = c;
+        rs[lane] = sn;
+      }
+      __syncthreads();
+      for (int idx = lane; idx < 10 * kAa; idx += 64) {  // columns p, q of A and U, row k
+        const int i = idx / kAa, k = idx - i * kAa;
+        int p, q;
+        pair_of(i, p, q);
+        const double c = rc[i], sn = rs[i];
+        const double akp = A[k * kAa + p], akq = A[k * kAa + q];
+        A[k * kAa + p] = c * akp - sn * akq;
+        A[k * kAa + q] = sn * akp + c * akq;
+        const double ukp = U[k * kAa + p], ukq = U[k * kAa + q];
+        U[k * kAa + p] = c * ukp - sn * ukq;
+        U[k * kAa + q] = sn * ukp + c * ukq;
+      }
+      __syncthreads();
+      for (int idx = lane; idx < 10 * kAa; idx += 64) {  // rows p, q of A, column k
+        const int i = idx / kAa, k = idx - i * kAa;
+        int p, q;
+        pair_of(i, p, q);
+        const double c = rc[i], sn = rs[i];
+        const double apk = A[p * kAa + k], aqk = A[q * kAa + k];
+        A[p * kAa + k] = c * apk - sn * aqk;
+        A[q * kAa + k] = sn * apk + c * aqk;
+      }
+      __syncthreads();
+    }
+  }
+  // ascending eigenvalues: rank = how many are smaller (ties by index); columns of U permuted
+  if (lane < kAa) {
+    const double x = A[lane * kAa + lane];
+    int r = 0;
+    for (int j = 0; j < kAa; j++) {
+      const double y = A[j * kAa + j];
+      r += (y < x || (y == x && j < lane)) ? 1 : 0;
+    }
+    rank_of[lane] = r;
+    ev[r] = x;
+  }
+  __syncthreads();
+  for (int idx = lane; idx < kAa * kAa; idx += 64) {
+    const int k = idx / kAa, j = idx % kAa;
+    U2[k * kAa + rank_of[j]] = U[idx];
+  }
+  __syncthreads();
+  if (lane < kAa) {
+    m->pi[lane] = pi[lane];
+    m->lambda[lane] = ev[lane];
+  }
+  for (int idx = lane; idx < kAa * kAa; idx += 64) {
+    const int i = idx / kAa, j = idx % kAa;
+    m->Q[idx] = Q[idx];
+    m->V[idx] = (1.0 / sq[i]) * U2[idx];
+    m->Vinv[idx] = U2[j * kAa + i] * sq[j];
   }
   for (int idx = lane; idx < kAaPack; idx += 64) {  // Q in the A-operand layout (below)
     const AaPackEntry pe = aa_pack_entry(idx);
@@ -1865,7 +2030,9 @@ __global__ __launch_bounds__(256) void aa_reduce_kernel(AaWalkArgs a, int ll_blo
 // ------------------------------------------------------------------------
 void launch_aa_model_setup(const double* exch, const double* freqs, AaModel* model,
                            int32_t* status, hipStream_t s) {
-  hipLaunchKernelGGL(aa_model_setup_kernel, dim3(1), dim3(64), 0, s, exch, freqs, model, status);
+  const bool seq = getenv("MI_PHYLO_AA_JACOBI") && std::string(getenv("MI_PHYLO_AA_JACOBI")) == "seq";  // (read per engine)
+  if (seq) hipLaunchKernelGGL(aa_model_setup_kernel, dim3(1), dim3(64), 0, s, exch, freqs, model, status);
+  else hipLaunchKernelGGL(aa_model_setup_wave_kernel, dim3(1), dim3(64), 0, s, exch, freqs, model, status);
 }
 void launch_aa_transition(const AaTransitionArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(aa_transition_kernel, dim3(a.N - 1, a.K, a.evals), dim3(256), 0, s, a);
@@ -1888,10 +2055,20 @@ static size_t aa_lds_pad() {
 }
 // tiles a wave of the post-order kernel takes: two (measured, workgroup form, log-likelihoods
 // of 8 trees: 17.1-17.3 ms against 17.7-17.8 with four at three waves per SIMD; gradients 20.8
-// against 24.5 in round 3); MI_PHYLO_AA_POST_TILES=2|4 overrides.
-static int aa_post_tiles(const AaWalkArgs&) {
+// against 24.5 in round 3) -- or ONE when the launch would otherwise leave the chip short of
+// work (round 6): a rank's share of BASELINE configs[4] under 8-way pattern
+// sharding is 6 250 patterns of one tree = 196 two-tile workgroups on 256 CUs, each of its waves
+// alone on a SIMD and the visit's dependent chain all there is to hide latency with; one tile
+// per wave is twice the workgroups with half the matrix instructions per visit each.
+// aa_post_tiles_threshold: workgroups (at two tiles) below which a launch takes one tile.
+// MI_PHYLO_AA_POST_TILES=1|2|4 overrides (workgroup form only: the wave form has 2 and 4).
+static int aa_post_tiles(const AaWalkArgs& a) {
   static const int forced = getenv("MI_PHYLO_AA_POST_TILES") ? atoi(getenv("MI_PHYLO_AA_POST_TILES")) : 0;
-  return forced == 4 ? 4 : 2;
+  if (forced == 4 || forced == 2 || forced == 1) return forced;
+  static const long threshold =
+      getenv("MI_PHYLO_AA_POST_ONE_TILE_BELOW") ? atol(getenv("MI_PHYLO_AA_POST_ONE_TILE_BELOW")) : 2L * device_compute_units();
+  const long wgs2 = (long)((a.tiles / 2 + 4 - 1) / 4) * a.evals * a.K;
+  return wgs2 < threshold ? 1 : 2;
 }
 // MI_PHYLO_AA_POST=wave selects the wave-per-block form of the post-order kernel
 static bool aa_post_wg() {
@@ -1913,6 +2090,7 @@ static int aa_ring_slots(size_t workgroups) {
   return 1;
 }
 // (what launch_aa_post / launch_aa_pre will choose: for the engine's description of a call)
+int aa_post_tiles_per_wave(const AaWalkArgs& a) { return aa_post_wg() ? aa_post_tiles(a) : std::max(2, aa_post_tiles(a)); }
 int aa_post_ring_entries(const AaWalkArgs& a) {
   if (!aa_post_wg()) return 0;
   const int m = aa_post_tiles(a), blocks = a.tiles / m;
@@ -1923,9 +2101,16 @@ int aa_post_ring_entries(const AaWalkArgs& a) {
     entries >>= 1;
   return entries;
 }
+template <int M, bool GRAD>
+static void launch_aa_post_wg(const AaWalkArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+  // (static LDS of the kernel: operand buffers, schedule window, tip bytes -- about 25 KB; the
+  // opt-in covers static + dynamic.  Both forms use the ring since round 5: ADVICE r5)
+  allow_large_lds(reinterpret_cast<const void*>(aa_post_wg_kernel<M, GRAD>), lds + 32 * 1024);
+  hipLaunchKernelGGL((aa_post_wg_kernel<M, GRAD>), grid, block, lds, s, a);
+}
 void launch_aa_post(const AaWalkArgs& a_in, hipStream_t s) {
   AaWalkArgs a = a_in;
-  const int m = aa_post_tiles(a);
+  int m = aa_post_tiles(a);
   if (aa_post_wg()) {
     const int blocks = a.tiles / m;
     const dim3 grid(aa_grid((blocks + kPostWaves - 1) / kPostWaves, a.evals * a.K)), block(kPostThreads);
@@ -1933,20 +2118,18 @@ void launch_aa_post(const AaWalkArgs& a_in, hipStream_t s) {
     const size_t ring = sizeof(double) * (size_t)kPostWaves * a.ring_slots * m * (kAaTileDoubles + 8);
     const size_t lds = ring + aa_lds_pad();
     if (m == 4) {
-      if (a.gradient) hipLaunchKernelGGL((aa_post_wg_kernel<4, true>), grid, block, lds, s, a);
-      else {
-        allow_large_lds(reinterpret_cast<const void*>(aa_post_wg_kernel<4, false>), lds + 32 * 1024);
-        hipLaunchKernelGGL((aa_post_wg_kernel<4, false>), grid, block, lds, s, a);
-      }
+      if (a.gradient) launch_aa_post_wg<4, true>(a, grid, block, lds, s);
+      else launch_aa_post_wg<4, false>(a, grid, block, lds, s);
+    } else if (m == 1) {
+      if (a.gradient) launch_aa_post_wg<1, true>(a, grid, block, lds, s);
+      else launch_aa_post_wg<1, false>(a, grid, block, lds, s);
     } else {
-      if (a.gradient) hipLaunchKernelGGL((aa_post_wg_kernel<2, true>), grid, block, lds, s, a);
-      else {
-        allow_large_lds(reinterpret_cast<const void*>(aa_post_wg_kernel<2, false>), lds + 32 * 1024);
-        hipLaunchKernelGGL((aa_post_wg_kernel<2, false>), grid, block, lds, s, a);
-      }
+      if (a.gradient) launch_aa_post_wg<2, true>(a, grid, block, lds, s);
+      else launch_aa_post_wg<2, false>(a, grid, block, lds, s);
     }
     return;
   }
+  if (m == 1) m = 2;  // (the wave-per-block form has two and four tiles)
   const dim3 grid(aa_grid(a.tiles / m, a.evals * a.K));
   if (m == 4) {
     if (a.gradient)
@@ -1994,7 +2177,8 @@ void launch_aa_reduce(const AaWalkArgs& a, hipStream_t s) {
   const int gx = a.gradient ? 1 + (a.N + 63) / 64 : 1;
   hipLaunchKernelGGL(aa_reduce_kernel, dim3(gx, a.evals), dim3(256), 0, s, a, aa_ll_blocks(a.P));
 }
-const char* aa_post_kernel_name() { return "aa_post_kernel"; }
-const char* aa_pre_kernel_name() { return "aa_pre_kernel"; }
+// (the names rocprofv3 prints: the workgroup forms unless MI_PHYLO_AA_POST / _PRE = wave)
+const char* aa_post_kernel_name() { return aa_post_wg() ? "aa_post_wg_kernel" : "aa_post_kernel"; }
+const char* aa_pre_kernel_name() { return aa_pre_wg() ? "aa_pre_wg_kernel" : "aa_pre_kernel"; }
 
 }  // namespace miphylo

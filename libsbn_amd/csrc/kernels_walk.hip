@@ -1053,7 +1053,7 @@ void launch_gradient_walk(const LikArgs& a_in, int count, bool rescale, bool sub
                            subst, s);
 }
 
-bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves) {
+bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves, bool lut) {
   // (read at every call: tools/audit_paths.py switches it between engines of one process)
   const int forced = [] {
     const char* env = getenv("MI_PHYLO_GRADIENT_STORE");
@@ -1069,7 +1069,11 @@ bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t wave
   // CU the LDS store still wins -- 31 taxa x 1000 patterns x 4 categories 1.29 against 1.54 ms per
   // 1000 trees, 36 x 200: 0.41 / 0.46, one category 0.36 / 0.41 -- and from four waves down the
   // arena does; the round-1 cross-over "fewer than seven" dated from the first generation)
-  return !lds_fits || (160 * 1024) / lds_all < 5;
+  // (round 6: the look-up walk's arena variant -- stored vectors back from the arena in 16-byte
+  // accesses, requested with the operands -- wins one step earlier: at five waves per CU the
+  // arena's eight take 36 taxa x 1812 patterns in 2.68 against 2.87 ms per 1000 trees, 41 x 1137
+  // in 1.96 against 2.07; at six -- 29 to 35 taxa -- the LDS store keeps 1.21 against 1.38)
+  return !lds_fits || (160 * 1024) / lds_all < (lut ? 6 : 5);
 }
 bool gradient_walk_fits(int n, int K, bool rescale) {
   if (n < 3 || K > kMaxCategories) return false;
@@ -1078,7 +1082,7 @@ bool gradient_walk_fits(int n, int K, bool rescale) {
 }
 // waves per CU the kernel's LDS footprint allows (the registers allow 8)
 int gradient_walk_waves_per_cu(int n, int K) {
-  const size_t lds = gradient_walk_use_arena(n, K, false, false)
+  const size_t lds = gradient_walk_use_arena(n, K, false, false, (size_t)-1, false)
                          ? gradient_walk_lds_bytes_for(n, K, false, false, gradient_arena_slots_usual(n))
                          : gradient_walk_lds_bytes(n, K, false, false);
   return (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));

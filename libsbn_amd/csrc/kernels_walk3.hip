@@ -101,7 +101,7 @@ constexpr int kSetupQuarters = 4, kReadyQuarter = 1 << 8;
 //          holds 16 / KP pattern columns.
 template <bool RESCALE, bool FUSED, bool ARENA, int KP>
 __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, const int block,
-                                              const int32_t* ready, const int spin_ticks) {
+                                              const int32_t* ready, const int spin_ticks, const int fence) {
   static_assert(R >= 1 && R <= 4, "a tip word holds one byte / one 4-bit field per register");
   static_assert(KP == 1 || KP == 2 || KP == 4, "categories per matrix instruction");
   static_assert(!(FUSED && ARENA), "the one-launch call keeps its stored vectors in LDS");
@@ -126,13 +126,26 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   const long long w_in = __builtin_amdgcn_s_memrealtime();
 #endif
   if (FUSED) {
-    // Wait for this tree's set-up waves: poll the tree's word (relaxed, agent scope), then an
-    // ACQUIRE fence at agent scope (round 6, ADVICE r5: buffer_inv sc1 -- this CU's vector L1 and
-    // whatever of the L2 is not coherent hold nothing older than the word) and an invalidate of
-    // the scalar cache (the macro list is read with scalar loads, which a fence does not cover).
-    // The set-up waves stored everything write-through, waited for it (vmcnt(0)) and passed a
-    // RELEASE fence before they added to the word.  The poll is bounded by WALL-CLOCK time
-    // (s_memrealtime, 100 MHz: a count of polls would shrink under a profiler or pre-emption).
+    // Wait for this tree's set-up waves: poll the tree's word (relaxed load at agent scope: served
+    // by the memory side, never by this CU's L1), bounded by WALL-CLOCK time (s_memrealtime,
+    // 100 MHz: a count of polls would shrink under a profiler or pre-emption).  What makes the
+    // plain loads behind the poll see the handed-over bytes -- `fence` (FusedSetupArgs::fence):
+    //   1 (default): everything handed over lies in cache lines of its own per tree
+    //      (macro_stride, kVisit, alignas(128) DevModel) that no wave of this launch reads before
+    //      the word says so (control dependency on the polled value + the redefinition of the
+    //      indices below), was stored write-through (sc1) and waited for (vmcnt(0)) before the
+    //      word was added to, and the caches held nothing of these lines when the kernel started
+    //      (the dispatch packet's acquire); on top of that this wave invalidates its CU's vector
+    //      L1 (buffer_inv sc0) and the scalar cache (s_dcache_inv) behind the poll, so that a
+    //      line touched early by a wave that timed out cannot be served stale from them, and the
+    //      set-up waves of a tree run on the XCD of its walk waves (fused_setup_role), whose L2
+    //      is the one coherence point of both;
+    //   2 (MI_PHYLO_FUSED_FENCE=agent): a formal release / acquire pair at agent scope
+    //       -- on gfx950 that is buffer_wbl2 sc1 in every set-up wave and buffer_inv sc1
+    //      in every walk wave: a write-back / invalidate of the XCD's WHOLE L2 per wave (the
+    //      eight L2s of the chip are not coherent with each other), measured +42 % on the
+    //      125-tree step (0.1326 -> 0.188 ms, round 6) -- which is why it is not the default;
+    //   0 (MI_PHYLO_FUSED_FENCE=none): the round-5 form, the argument of (1) alone.
     int v = 0;
     const long long t_in = __builtin_amdgcn_s_memrealtime();
     for (;;) {
@@ -142,8 +155,12 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       if ((long long)__builtin_amdgcn_s_memrealtime() - t_in > (long long)spin_ticks) break;
       __builtin_amdgcn_s_sleep(8);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_dcache_inv" ::: "memory");
+    if (fence == 2) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_dcache_inv" ::: "memory");
+    } else if (fence == 1) {
+      asm volatile("buffer_inv sc0\n\ts_dcache_inv" ::: "memory");
+    }
     // (-1: waited in vain.  The wave leaves through the one exit below -- a second `return`
     // up here, with its status store, changed how the WHOLE walk is compiled: 224 registers
     // instead of 214 and a wait in front of single operand loads, +34 % time per 1000 trees)
@@ -293,6 +310,15 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     constexpr int OFF = decltype(off_tag)::value;
 #pragma unroll
     for (int r = 0; r < R; r++) {
+#ifdef W3_ABL_FEWER_LOADS
+      // (timing experiment, WRONG results, never the product: what tables by state PAIR could
+      // save at best -- a post-order tip position issues two gathers instead of three; register 1
+      // takes register 0's value.  DESIGN.md 4.1)
+      if (!PRE && r == 1) {
+        o.x[OFF + 1] = o.x[OFF];
+        continue;
+      }
+#endif
       unsigned voff = tip_offset(tw, pos_tag, r);
       asm volatile("" : "+v"(voff));
       if (PRE) {
@@ -349,6 +375,15 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       if constexpr (AR) load_arena(ak++, o, std::integral_constant<int, 2 * W>{});
     }
     if (sh & (1 << (11 + 2 * J))) {
+#if defined(W3_ABL_FEWER_LOADS) && W3_ABL_FEWER_LOADS >= 2
+      // (timing experiment, WRONG results: what CHERRY tables could save at best -- the second
+      // tip of an unstored child with two tip children costs no gather in the post-order walk)
+      if (!PRE && (sh & (1 << (10 + 2 * J)))) {
+#pragma unroll
+        for (int r = 0; r < R; r++) o.x[4 * W + r] = o.x[W + r];
+        return;
+      }
+#endif
       load_tip(pre_tag, gb, tw, PB{}, o, OB{});
     } else {
       load_internal(pre_tag, gb, o, OB{});
@@ -881,7 +916,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
 template <bool RESCALE, bool ARENA, int KP>
 __global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_kernel(LikArgs a) {
   extern __shared__ double wlds[];
-  walk_lut_body<RESCALE, false, ARENA, KP>(a, wlds, blockIdx.x, nullptr, 0);
+  walk_lut_body<RESCALE, false, ARENA, KP>(a, wlds, blockIdx.x, nullptr, 0, 0);
 }
 
 // ------------------------------------------------------------------------
@@ -1026,7 +1061,24 @@ __host__ __device__ inline unsigned fused_setup_lds(int n, int K) {
 
 __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const int bid, char* lds) {
   const TreeSetupArgs& a = f.ts;
-  const int t = bid / kSetupQuarters, q = bid - t * kSetupQuarters;
+  // Which (tree, quarter): workgroups are dealt to the eight XCDs round-robin by id, and the walk
+  // waves of tree t (t in a whole group of eight: xcd_map) all run on XCD (setup_blocks + t) & 7 --
+  // its set-up waves are placed there too (round 6): what they write passes through the ONE L2
+  // both sides use (no reliance on another XCD's L2 having never seen the lines), and the walk
+  // waves find the records in that L2 instead of fetching them from the memory side.
+  // f.colocate == 0: bid / 4, bid % 4 as in round 5 (A/B).
+  int t, q;
+  {
+    const int T = f.setup_blocks / kSetupQuarters, full = T & ~7;
+    if (f.colocate && bid < kSetupQuarters * full) {
+      const int j = bid >> 3, x = bid & 7;
+      t = 8 * (j / kSetupQuarters) + ((x - f.setup_blocks) & 7);
+      q = j % kSetupQuarters;
+    } else {
+      t = bid / kSetupQuarters;
+      q = bid - t * kSetupQuarters;
+    }
+  }
   const int lane = threadIdx.x;
   const int n = a.n, N = 2 * n - 1, K = f.ms.K;
   const int per_q = ((N - 1) * K + kSetupQuarters - 1) / kSetupQuarters;
@@ -1153,7 +1205,7 @@ __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const 
     printf("setup role t %d q %d: start %lld end %lld model %lld tree %lld records %lld stores issued %lld landed %lld (10 ns ticks)\n", t, q, st0, (long long)__builtin_amdgcn_s_memrealtime(),
            st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4);
 #endif
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (f.fence == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   // (f.debug_skip: testing only -- quarter 1 of tree debug_skip - 1 never reports, its walk waves
   // time out: tests/test_fused_setup_gpu.py forces the host's fallback with it)
   if (lane == 0 && !(f.debug_skip == t + 1 && q == 1))
@@ -1168,7 +1220,7 @@ __global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_fused
     fused_setup_role(f, blockIdx.x, reinterpret_cast<char*>(wlds));
     return;
   }
-  walk_lut_body<RESCALE, true, false, KP>(a, wlds, (int)blockIdx.x - f.setup_blocks, f.ready, f.spin_ticks);
+  walk_lut_body<RESCALE, true, false, KP>(a, wlds, (int)blockIdx.x - f.setup_blocks, f.ready, f.spin_ticks, f.fence);
 #ifdef W3_SETUP_STAMPS
   if (threadIdx.x == 0 && (((int)blockIdx.x - f.setup_blocks) % 1499) == 0)
     printf("walk block %d: out %lld\n", (int)blockIdx.x - f.setup_blocks, (long long)__builtin_amdgcn_s_memrealtime());
@@ -1257,7 +1309,7 @@ void launch_gradient_walk_lut(const LikArgs& a_in, int count, bool rescale, hipS
   const int gtiles = gradient_mfma_tiles(a.P, a.K);
   const dim3 grid((unsigned)((size_t)count * gtiles));
   const bool arena_variant =
-      a.store ? a.store == 2 : gradient_walk_use_arena(a.n, a.K, rescale, false, (size_t)gtiles * (size_t)count);
+      a.store ? a.store == 2 : gradient_walk_use_arena(a.n, a.K, rescale, false, (size_t)gtiles * (size_t)count, true);
   if (arena_variant) {
     // two launches over one grid, as the second generation's arena variant: the trees whose
     // schedule fits the usual number of LDS slots, then (more LDS per wave) the rest

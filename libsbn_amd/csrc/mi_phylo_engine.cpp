@@ -70,8 +70,11 @@ CallShape call_shape(const mi_engine* e, int T, bool gradient, bool analytic = f
 // the two generations of the matrix-core gradient walk (kernels_gradient.hip /
 // kernels_walk.hip) size their LDS slightly differently
 // (waves: one-wave workgroups of a gradient launch; default: a large batch)
+bool walk3_possible(const mi_engine* e);
 bool use_arena(const mi_engine* e, bool rescale, bool subst, size_t waves = (size_t)-1) {
-  return e->walk2 ? gradient_walk_use_arena(e->n, e->K, rescale, subst, waves)
+  // (the look-up walk's arena variant starts one step earlier: gradient_walk_use_arena)
+  const bool lut = walk3_possible(e) && e->walk3_arena && !subst && gradient_mfma_groups(e->K) == 1;
+  return e->walk2 ? gradient_walk_use_arena(e->n, e->K, rescale, subst, waves, lut)
                   : gradient_mfma_use_arena(e->n, e->K, rescale, subst, waves);
 }
 bool walk_fits(const mi_engine* e, bool rescale) {
@@ -156,7 +159,8 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / per));
     if (need_hbm_path && e->plv.ensure(per * chunk)) return 1;
     // the arena variant of the matrix-core kernel keeps its stored vectors in the same buffer
-    if (!need_hbm_path && (use_arena(e, false, true) || use_arena(e, true, true))) {
+    if (!need_hbm_path && (use_arena(e, false, true) || use_arena(e, true, true) || use_arena(e, false, false) ||
+                           use_arena(e, true, false))) {
       const size_t aper = gradient_arena_bytes_per_eval(n, e->P, e->K);
       const size_t achunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / aper));
       if (e->plv.ensure(aper * achunk)) return 1;
@@ -414,6 +418,8 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
           fs.ready = e->ready.as<int32_t>();
           fs.debug_skip = e->fused_debug_skip;
           fs.spin_ticks = e->fused_spin_ticks;
+          fs.fence = e->fused_fence;
+          fs.colocate = e->fused_colocate;
           launch_gradient_walk_lut_fused(g, fs, part, d.rescaling, s);
         } else if (walk3) launch_gradient_walk_lut(g, part, d.rescaling, s);
         else if (walk2) launch_gradient_walk(g, part, d.rescaling, analytic, s);
@@ -813,6 +819,10 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   }
   if (const char* env = getenv("MI_PHYLO_FUSED_SETUP")) e->fused_setup = std::string(env) != "0";
   if (const char* env = getenv("MI_PHYLO_DEBUG_FUSED_SKIP")) e->fused_debug_skip = atoi(env);
+  // the one-launch call's hand-off (kernels_walk3.hip, walk_lut_body): none | l1 (default) | agent
+  if (const char* env = getenv("MI_PHYLO_FUSED_FENCE"))
+    e->fused_fence = std::string(env) == "none" ? 0 : (std::string(env) == "agent" ? 2 : 1);
+  if (const char* env = getenv("MI_PHYLO_FUSED_COLOCATE")) e->fused_colocate = std::string(env) != "0";
   // how long a walk wave of the one-launch call polls before it gives up (testing; default 1 s)
   if (const char* env = getenv("MI_PHYLO_FUSED_SPIN_MS"))
     e->fused_spin_ticks = (int)std::min(2.0e9, std::max(0.01, atof(env)) * 1.0e5);

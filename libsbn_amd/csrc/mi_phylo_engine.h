@@ -144,6 +144,8 @@ struct mi_engine {
   bool fused_setup = true;  // MI_PHYLO_FUSED_SETUP=0: always the four-launch sequence
   bool fused_timed_out = false;  // check_status found the one-launch call's time-out word set
   int fused_fallbacks = 0;       // host-pointer calls that were run again through four launches
+  int fused_fence = 1;           // MI_PHYLO_FUSED_FENCE=none|l1|agent: 0 | 1 | 2 (FusedSetupArgs::fence)
+  bool fused_colocate = true;    // MI_PHYLO_FUSED_COLOCATE=0: set-up waves in id order (round 5)
   int fused_spin_ticks = 0;      // MI_PHYLO_FUSED_SPIN_MS (testing): the walk waves' poll budget, 100 MHz ticks
   int fused_debug_skip = 0;      // MI_PHYLO_DEBUG_FUSED_SKIP=t+1: tree t's set-up never reports (testing)
   // 20-state path: the engine's eigensystem and the streamed workspace (the arena is `plv`)

@@ -167,7 +167,8 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
 
   if (prof) HIP_TRY(hipEventRecord(prof_event(e, 0), s));
   const int chunk = aa_chunk(e, T, d.gradient);
-  int post_ring = 0;
+  int post_ring = 0, post_tiles = 0;
+  bool first_chunk = true;
   e->prof_first_launch_evals = std::min(chunk, T);
   for (int off = 0; off < T; off += chunk) {
     const int evals = std::min(chunk, T - off);
@@ -218,7 +219,11 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     w.ll_sum = e->ll_sum.as<double>();
     w.g_sum = e->g_sum.as<double>();
     PROF_MARK(e, marks && off == 0, 1, s);
-    post_ring = aa_post_ring_entries(w);
+    if (first_chunk) {  // (the path string describes the first -- largest -- launch of the call)
+      post_ring = aa_post_ring_entries(w);
+      post_tiles = aa_post_tiles_per_wave(w);
+      first_chunk = false;
+    }
     launch_aa_post(w, s);
     launch_aa_root(w, s);
     PROF_MARK(e, marks && off == 0, 2, s);
@@ -230,7 +235,7 @@ int aa_run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   e->dominant = d.gradient ? aa_pre_kernel_name() : aa_post_kernel_name();
   // (the stack tops of the walks live in LDS rings: kernels_aa.hip)
   e->last_path = std::string(e->dominant) + " store=hbm-arena" +
-                 " post-ring=" + std::to_string(post_ring) +
+                 " post-tiles=" + std::to_string(post_tiles) + " post-ring=" + std::to_string(post_ring) +
                  (d.gradient ? " pre-ring=" + std::to_string(aa_pre_ring_entries()) : std::string()) +
                  " states=20 K=" + std::to_string(e->K);
   e->last_evals = T;

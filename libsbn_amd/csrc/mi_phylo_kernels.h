@@ -204,7 +204,8 @@ int gradient_arena_slots_usual(int n);
 void launch_transition_macro(const TransitionMacroArgs& a, hipStream_t s);
 void launch_gradient_walk(const LikArgs& a, int count, bool rescale, bool subst, hipStream_t s);
 bool gradient_walk_fits(int n, int K, bool rescale);
-bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves = (size_t)-1);
+// lut: the call runs the third-generation (look-up) walk, whose arena variant pays one step earlier
+bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves = (size_t)-1, bool lut = false);
 size_t gradient_walk_lds_bytes(int n, int K, bool rescale, bool subst);
 size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots);
 size_t gradient_walk_mats_bytes_per_eval(int n, int K);
@@ -230,6 +231,8 @@ struct FusedSetupArgs {
   int setup_blocks;  // 4 T
   int spin_ticks;    // how long a walk wave polls its tree's word (100 MHz ticks; 0: the launcher's default, one second)
   int debug_skip;    // testing: tree debug_skip - 1 never becomes ready (0: off)
+  int fence;         // hand-off: 0 none (round 5), 1 L1 + scalar-cache invalidate (default), 2 agent-scope release / acquire
+  int colocate;      // set-up waves of a tree on the XCD of its walk waves
 };
 bool gradient_walk_lut_fused_applies(int n, int K);
 void launch_gradient_walk_lut_fused(const LikArgs& a, const FusedSetupArgs& f, int count, bool rescale,
@@ -345,7 +348,7 @@ struct AaWalkArgs {
   int eval_offset, evals;  // this chunk
   int gradient;            // post-order: every internal vector is kept, indexed by node
   int slots;               // log-likelihood only: vectors are kept by schedule slot
-  int ring_slots;          // log-likelihood only (set by the launcher): stack entries a wave keeps in LDS
+  int ring_slots;          // post-order kernel, both forms (set by the launcher): stack entries a wave keeps in LDS
   int pre_ring_slots;      // pre-order kernel (set by the launcher): parked vectors a wave keeps in LDS
   int ll_stride;           // stride of ll_part per evaluation
   const SchedEntry* sched; // [T][n-1]
@@ -379,6 +382,7 @@ void launch_aa_root(const AaWalkArgs& a, hipStream_t s);
 void launch_aa_pre(const AaWalkArgs& a, hipStream_t s);
 // entries of the LDS rings the two launchers above will use for these arguments
 int aa_post_ring_entries(const AaWalkArgs& a);
+int aa_post_tiles_per_wave(const AaWalkArgs& a);  // 16-pattern tiles a wave of the post-order kernel takes (1, 2 or 4)
 int aa_pre_ring_entries();
 void launch_aa_reduce(const AaWalkArgs& a, hipStream_t s);
 const char* aa_post_kernel_name();

@@ -80,7 +80,7 @@ def swag_engine_results(swag):
 def test_full_size_log_likelihood_and_gradients_match_oracle(swag, swag_engine_results):
     tips, w, pids, bls, pr = swag
     ll, g, info, ll_launches, launches = swag_engine_results
-    assert info[0] == "aa_pre_kernel" and ll_launches[0] == 1 and launches[0] == 1
+    assert info[0].startswith("aa_pre") and ll_launches[0] == 1 and launches[0] == 1
     ex, fr = _wag()
     O.set_reversible_model(ex, fr)
     O.set_transition_mode(1)

@@ -103,8 +103,11 @@ def test_line_is_small():
     assert d["value"] == pytest.approx(full["value"], rel=1e-5)
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
-    assert d["config"]["workload"] and len(d["also"]) == len(full["also"])
-    assert all(set(a) >= {"workload", "trees_per_s"} for a in d["also"])
+    # the other legs: one table, the same columns for every leg (round 6)
+    assert d["config"]["workload"] and len(d["also"]["rows"]) == len(full["also"])
+    assert {"workload", "trees_per_s", "bound", "frac", "frac_algorithmic", "frac_executed", "pipe_busy",
+            "hbm_frac"} <= set(d["also"]["keys"])
+    assert all(len(r) == len(d["also"]["keys"]) for r in d["also"]["rows"])
     # and a line that cannot be made small is refused, not printed
     full["config"]["workload"] = "w" * 5000
     with pytest.raises(AssertionError, match="bytes"):

@@ -314,8 +314,8 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       // (timing experiment, WRONG results, never the product: what tables by state PAIR could
       // save at best -- a post-order tip position issues two gathers instead of three; register 1
       // takes register 0's value.  DESIGN.md 4.1)
-      if (!PRE && r == 1) {  // (a constant, not a copy: a copy would wait for the load right here)
-        o.x[OFF + 1] = 0.25;
+      if (!PRE && r == 1) {
+        o.x[OFF + 1] = o.x[OFF];
         continue;
       }
 #endif
@@ -380,7 +380,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       // tip of an unstored child with two tip children costs no gather in the post-order walk)
       if (!PRE && (sh & (1 << (10 + 2 * J)))) {
 #pragma unroll
-        for (int r = 0; r < R; r++) o.x[4 * W + r] = 0.25;
+        for (int r = 0; r < R; r++) o.x[4 * W + r] = o.x[W + r];
         return;
       }
 #endif
@@ -1054,18 +1054,11 @@ __device__ __forceinline__ void store16_sc1(double* p, const double x, const dou
 }
 
 // LDS of a set-up wave: staged records [per_q][41] | model instance | rec_of, len_of [64] | slot_of [N - 1]
-// registers per node array the set-up role is built with for trees of n taxa (instantiated: 1, 3)
-__host__ __device__ inline int fused_setup_nb(int n) { return 2 * n - 1 <= 64 ? 1 : 3; }
 __host__ __device__ inline unsigned fused_setup_lds(int n, int K) {
   const unsigned per_q = (unsigned)(((2 * n - 2) * K + kSetupQuarters - 1) / kSetupQuarters);
-  // (the tree build borrows the staging area: 256 ints per 64 nodes)
-  const unsigned stage = per_q * 41u * 8u, build = (unsigned)kSmallTreeLdsInts * 4u * (unsigned)fused_setup_nb(n);
-  return (stage > build ? stage : build) + (unsigned)sizeof(DevModel) + 2u * 64u * 4u + (unsigned)(2 * n - 2) * 4u;
+  return per_q * 41u * 8u + (unsigned)sizeof(DevModel) + 2u * 64u * 4u + (unsigned)(2 * n - 2) * 4u;
 }
 
-// NB: registers per node array of the tree build (64 nodes each): 1 for trees of up to 32 taxa,
-// 3 up to 96 (round 6: one fluA tree -- 69 taxa -- takes the one-launch call)
-template <int NB>
 __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const int bid, char* lds) {
   const TreeSetupArgs& a = f.ts;
   // Which (tree, quarter): workgroups are dealt to the eight XCDs round-robin by id, and the walk
@@ -1090,9 +1083,7 @@ __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const 
   const int n = a.n, N = 2 * n - 1, K = f.ms.K;
   const int per_q = ((N - 1) * K + kSetupQuarters - 1) / kSetupQuarters;
   double* stage = reinterpret_cast<double*>(lds);
-  // (behind the staging area -- or the tree build's scratch, whichever is larger: fused_setup_lds)
-  const unsigned stage_bytes = (unsigned)per_q * 41u * 8u, build_bytes = (unsigned)kSmallTreeLdsInts * 4u * NB;
-  DevModel* md = reinterpret_cast<DevModel*>(lds + (stage_bytes > build_bytes ? stage_bytes : build_bytes));
+  DevModel* md = reinterpret_cast<DevModel*>(lds + (unsigned)per_q * 41u * 8u);
   int* rec_of = reinterpret_cast<int*>(reinterpret_cast<char*>(md) + sizeof(DevModel));
   int* len_of = rec_of + 64;
   int* slot_of = len_of + 64;
@@ -1106,19 +1097,17 @@ __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const 
   // the model instance of the tree (one per tree in these calls)
   model_setup_wave(f.ms, t, lane, *md);
   XSTAMP(st1);
-  SmallTree<NB> tree;
-  small_tree_build<NB>(a, t, lane, tree, reinterpret_cast<int*>(lds));  // (the staging area is not in use yet)
+  SmallTree<1> tree;
+  small_tree_build<1>(a, t, lane, tree, reinterpret_cast<int*>(lds));  // (the staging area is not in use yet)
   const bool ok = tree.status == kOk;
   const int M = ok ? tree.macro_total : 0;
   XSTAMP(st2);
-  if (q == 0) small_tree_store<NB>(a, t, lane, tree);  // (plain stores: later kernels read these)
+  if (q == 0) small_tree_store<1>(a, t, lane, tree);  // (plain stores: later kernels read these)
   if (ok) {
     // node -> macro * 6 + position (the lane that owns a macro knows its children)
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-      if (!tree.is_macro[nb]) continue;
-      const MacroEntry& me = tree.me[nb];
-      const int base = tree.macro_rank[nb] * 6;
+    if (tree.is_macro[0]) {
+      const MacroEntry& me = tree.me[0];
+      const int base = tree.macro_rank[0] * 6;
       slot_of[me.child[0]] = base;
       slot_of[me.child[1]] = base + 1;
 #pragma unroll
@@ -1131,11 +1120,9 @@ __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const 
     if (q == 0) {
       // the macro list, write-through: 16 words per entry
       MacroEntry* mac = a.macros + (size_t)t * macro_stride(n);
-#pragma unroll
-      for (int nb = 0; nb < NB; nb++) {
-        if (!tree.is_macro[nb]) continue;
-        char* dst = reinterpret_cast<char*>(mac + tree.macro_rank[nb]);
-        const MacroEntry& me = tree.me[nb];
+      if (tree.is_macro[0]) {
+        char* dst = reinterpret_cast<char*>(mac + tree.macro_rank[0]);
+        const MacroEntry& me = tree.me[0];
         static_assert(sizeof(MacroEntry) == 64, "sixteen words, in this order");
         store16_sc1(dst, v4i32{me.shape, me.child[0], me.child[1], me.grand[0]});
         store16_sc1(dst + 16, v4i32{me.grand[1], me.grand[2], me.grand[3], me.node});
@@ -1226,11 +1213,11 @@ __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const 
                            __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool RESCALE, int KP, int NB>
+template <bool RESCALE, int KP>
 __global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_fused_kernel(LikArgs a, FusedSetupArgs f) {
   extern __shared__ double wlds[];
   if ((int)blockIdx.x < f.setup_blocks) {
-    fused_setup_role<NB>(f, blockIdx.x, reinterpret_cast<char*>(wlds));
+    fused_setup_role(f, blockIdx.x, reinterpret_cast<char*>(wlds));
     return;
   }
   walk_lut_body<RESCALE, true, false, KP>(a, wlds, (int)blockIdx.x - f.setup_blocks, f.ready, f.spin_ticks, f.fence);
@@ -1247,22 +1234,16 @@ size_t gradient_walk_lut_mats_bytes_per_eval(int n) { return (size_t)max_macros(
 // categories per matrix instruction for K rate categories
 static int lut_kp(int K) { return K == 1 ? 1 : (K == 2 ? 2 : 4); }
 
-// trees whose arrays fit one (up to 64 nodes) or three (up to 192) registers per lane, a quarter
-// of the (node, category) pairs -- at most 64 -- per set-up wave: up to 32 taxa with four rate
-// categories, 64 with two, 96 with one (round 6: a fluA tree)
+// trees whose arrays fit one register per lane (64 nodes), a quarter of the (node, category)
+// pairs per set-up wave
 bool gradient_walk_lut_fused_applies(int n, int K) {
-  return gradient_walk_lut_applies(K) && 2 * n - 1 <= 192 && ((2 * n - 2) * K + 3) / 4 <= 64;
+  return gradient_walk_lut_applies(K) && 2 * n - 1 <= 64 && ((2 * n - 2) * K + 3) / 4 <= 64;
 }
 
 template <bool RESCALE, int KP>
 static void launch_fused_variant(const LikArgs& a, const FusedSetupArgs& f, dim3 grid, size_t lds, hipStream_t s) {
-  if (fused_setup_nb(a.n) == 1) {
-    allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_fused_kernel<RESCALE, KP, 1>), lds);
-    hipLaunchKernelGGL((gradient_walk_lut_fused_kernel<RESCALE, KP, 1>), grid, dim3(kTile), lds, s, a, f);
-  } else {
-    allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_fused_kernel<RESCALE, KP, 3>), lds);
-    hipLaunchKernelGGL((gradient_walk_lut_fused_kernel<RESCALE, KP, 3>), grid, dim3(kTile), lds, s, a, f);
-  }
+  allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_fused_kernel<RESCALE, KP>), lds);
+  hipLaunchKernelGGL((gradient_walk_lut_fused_kernel<RESCALE, KP>), grid, dim3(kTile), lds, s, a, f);
 }
 void launch_gradient_walk_lut_fused(const LikArgs& a_in, const FusedSetupArgs& f_in, int count, bool rescale,
                                     hipStream_t s) {

@@ -148,47 +148,6 @@ def test_small_and_rooted_trees(site):
     fused.close(); plain.close()
 
 
-@pytest.mark.parametrize("n,P,site,rooted", [(69, 238, "constant", True), (69, 238, "constant", False),
-                                               (60, 100, "weibull+2", False), (43, 64, "weibull+3", False),
-                                               (96, 50, "constant", False)])
-def test_trees_of_more_than_64_nodes_take_the_one_launch_call(n, P, site, rooted):
-    """Round 6: the set-up role builds trees of up to 192 nodes (three registers per node array)
-    wherever a quarter of the tree's (node, category) pairs fits a wave -- 96 taxa with one rate
-    category (one fluA tree: BASELINE configs[3]), 64 with two, 43 with three.  Bit-identical to
-    the four-launch sequence, for 1 and 9 trees, rescaled or not, and equal to the oracle."""
-    rng = np.random.default_rng(1000 * n + P)
-    tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.05)
-    spec = O.make_spec(n, P, "JC69", site, "strict")
-    fused, plain = _engines("JC69", site, tips, w)
-    for T in (1, 9):
-        pr = _site_params(spec, T, site, rng)
-        if rooted:
-            trees = [TU.clocklike_rooted_tree(n, rng) for _ in range(T)]
-            pids = np.stack([t[0] for t in trees]); bls = np.stack([t[1] for t in trees])
-            state = [O.time_tree_init(n, t[0], t[1], t[2]) for t in trees]
-            h = np.stack([s[0] for s in state]); bd = np.stack([s[1] for s in state]); ra = np.stack([s[2] for s in state])
-            rates = np.full((T, 2 * n - 2), 0.7)
-            args = (pids, bls, pr, rates, np.ones(T, np.int32), h, bd, ra)
-            a, b = fused.rooted_gradients(*args), plain.rooted_gradients(*args)
-            assert fused.last_call_info()[0] == FUSED and plain.last_call_info()[0] == PLAIN, fused.last_call_path()
-            assert np.array_equal(_flat(a), _flat(b))
-            og = O.rooted_gradients(spec, tips, w, *args, False, 4)
-            assert np.allclose([x.log_likelihood for x in a], og["log_likelihood"], rtol=1e-10, atol=0)
-        else:
-            pids, bls = TU.random_trees(n, T, rng, mean_bl=0.06)
-            if T > 2:
-                pids[0] = TU.balanced_topology(n); pids[1] = TU.ladder_topology(n)
-            for resc in (False, True):
-                a, b = fused.gradients(pids, bls, pr, resc), plain.gradients(pids, bls, pr, resc)
-                assert fused.last_call_info()[0] == FUSED and plain.last_call_info()[0] == PLAIN, fused.last_call_path()
-                assert np.array_equal(_flat(a), _flat(b))
-            og = O.unrooted_gradients(spec, tips, w, pids, bls, pr, True, 4)
-            assert np.allclose([x.log_likelihood for x in a], og["log_likelihood"], rtol=1e-10, atol=0)
-            gb = np.stack([x.gradient["branch_lengths"] for x in a])
-            assert np.allclose(gb, og["branch_lengths"], rtol=1e-10, atol=1e-10 * np.max(np.abs(gb)))
-    fused.close(); plain.close()
-
-
 def test_hand_off_words_survive_errors_and_changing_batch_sizes():
     """The per-tree words are zero between calls (reduce_finalize clears them).  A malformed
     tree is an error of the call, as in the four-launch sequence (same message), and leaves

@@ -2086,8 +2086,11 @@ static bool aa_post_wg() {
 static int aa_ring_slots(size_t workgroups) {
   static const int forced = getenv("MI_PHYLO_AA_RING") ? atoi(getenv("MI_PHYLO_AA_RING")) : -1;
   if (forced == 0 || forced == 1 || forced == 2 || forced == 4) return forced;  // (powers of two)
-  (void)workgroups;
-  return 1;
+  // (round 6: a launch that leaves the chip short of work -- fewer than two workgroups per CU: a
+  // rank's pattern block of one tree -- is bound by its visits' latencies, not by workgroups per
+  // CU: four entries keep 97 % of the kept vectors out of the arena; 512 x 6 250 x 4, one tree:
+  // 0.581 / 0.566 / 0.564 ms with 1 / 2 / 4 entries)
+  return workgroups < 2 * (size_t)device_compute_units() ? 4 : 1;
 }
 // (what launch_aa_post / launch_aa_pre will choose: for the engine's description of a call)
 int aa_post_tiles_per_wave(const AaWalkArgs& a) { return aa_post_wg() ? aa_post_tiles(a) : std::max(2, aa_post_tiles(a)); }

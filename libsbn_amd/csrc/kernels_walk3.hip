@@ -314,8 +314,8 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       // (timing experiment, WRONG results, never the product: what tables by state PAIR could
       // save at best -- a post-order tip position issues two gathers instead of three; register 1
       // takes register 0's value.  DESIGN.md 4.1)
-      if (!PRE && r == 1) {
-        o.x[OFF + 1] = o.x[OFF];
+      if (!PRE && r == 1) {  // (a constant, not a copy: a copy would wait for the load right here)
+        o.x[OFF + 1] = 0.25;
         continue;
       }
 #endif
@@ -380,7 +380,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       // tip of an unstored child with two tip children costs no gather in the post-order walk)
       if (!PRE && (sh & (1 << (10 + 2 * J)))) {
 #pragma unroll
-        for (int r = 0; r < R; r++) o.x[4 * W + r] = o.x[W + r];
+        for (int r = 0; r < R; r++) o.x[4 * W + r] = 0.25;
         return;
       }
 #endif

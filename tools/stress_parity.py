@@ -32,8 +32,9 @@ for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
         K = int(rng.choice([1, 2, 3, 4, 4, 8]))
         T = 150
     elif focus == "fused":
-        n = int(rng.choice([3, 4, 5, 7, 9, 12, 17, 26, 27, 28, 30, 31]))
-        K = int(rng.choice([3, 4]))
+        # (round 6: one and two categories take the look-up walk and its one-launch call as well)
+        n = int(rng.choice([3, 4, 5, 7, 9, 12, 17, 26, 27, 28, 30, 31, 32, 33]))
+        K = int(rng.choice([1, 2, 3, 4, 4]))
         T = int(rng.choice([1, 2, 9, 64, 300]))
     site = "constant" if K == 1 else f"weibull+{K}"
     tips, w = TU.random_alignment(n, P, rng, gap_fraction=float(rng.choice([0.0, 0.05, 0.5])))

@@ -19,7 +19,8 @@ run() {  # name, tool, seed, trials, [ENV=value ...]
 run parity_a parity 3001 1500 &
 run parity_b parity 3002 1500 &
 run parity_fused parity 3003 600 STRESS_FOCUS=fused &
-run parity_arena parity 3004 300 STRESS_FOCUS=arena &
+run parity_arena parity 3004 400 STRESS_FOCUS=arena &
+run parity_arena_v2 parity 3012 200 STRESS_FOCUS=arena MI_PHYLO_WALK3_ARENA=0 &
 run parity_arena_v1 parity 3010 150 STRESS_FOCUS=arena MI_PHYLO_GRADIENT_WALK=v1 &
 run parity_v2 parity 3005 600 MI_PHYLO_GRADIENT_WALK=v2 &
 run parity_v1 parity 3006 600 MI_PHYLO_GRADIENT_WALK=v1 &
@@ -32,5 +33,6 @@ run aa_b aa 5012 500 &
 run aa_ring1 aa 6001 400 MI_PHYLO_AA_RING=1 MI_PHYLO_AA_PRE_RING=2 &
 run aa_ring2 aa 6002 400 MI_PHYLO_AA_RING=2 MI_PHYLO_AA_PRE_RING=0 &
 run aa_ring4 aa 6003 400 MI_PHYLO_AA_RING=4 MI_PHYLO_AA_POST_TILES=4 &
+run aa_tiles1 aa 6004 400 MI_PHYLO_AA_POST_TILES=1 MI_PHYLO_AA_RING=2 &
 wait
 cat gpurun_out/${tag}_stress_*.txt

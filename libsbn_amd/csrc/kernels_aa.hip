@@ -377,26 +377,36 @@ __global__ __launch_bounds__(64) void aa_model_setup_wave_kernel(const double* e
 // tip edges as per-state columns (state 20 = gap: P 1 = 1, (P Q) 1 = 0).
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void aa_transition_kernel(AaTransitionArgs a) {
-  __shared__ double ex[kAa], Pm[kAa * kAa], PQm[kAa * kAa];
+  // (round 6: the eigenvectors -- and, for a tip edge of a gradient call, Q -- are staged in LDS:
+  // read from global memory inside the 20-term sums they were 8 000 dependent-latency loads per
+  // workgroup, 36 us per call for one 512-taxon tree -- 6 % of a rank's 6 250-pattern share of
+  // BASELINE configs[4].  Same products in the same order.)
+  __shared__ double ex[kAa], Pm[kAa * kAa], PQm[kAa * kAa], Vs[kAa * kAa], Vis[kAa * kAa];
   const int edge = blockIdx.x, k = blockIdx.y, el = blockIdx.z;
   const int tree = a.eval_offset + el;
   const int tid = threadIdx.x;
   const AaModel& m = *a.model;
   const double rt = a.models[tree].cat_rate[k] * a.bl_eff[(size_t)tree * a.N + edge];
   if (tid < kAa) ex[tid] = expm1(m.lambda[tid] * rt);
+  for (int idx = tid; idx < kAa * kAa; idx += 256) {
+    Vs[idx] = m.V[idx];
+    Vis[idx] = m.Vinv[idx];
+  }
   __syncthreads();
   for (int idx = tid; idx < kAa * kAa; idx += 256) {
     const int i = idx / kAa, j = idx % kAa;
     double sum = i == j ? 1.0 : 0.0;
-    for (int x = 0; x < kAa; x++) sum += m.V[i * kAa + x] * ex[x] * m.Vinv[x * kAa + j];
+    for (int x = 0; x < kAa; x++) sum += Vs[i * kAa + x] * ex[x] * Vis[x * kAa + j];
     Pm[idx] = sum > 0 ? sum : 0;
   }
   __syncthreads();
   if (a.gradient && edge < a.n) {  // (tip edges only: columns of P Q; internal edges use Q (P L))
+    for (int idx = tid; idx < kAa * kAa; idx += 256) Vs[idx] = m.Q[idx];  // (V is no longer needed)
+    __syncthreads();
     for (int idx = tid; idx < kAa * kAa; idx += 256) {
       const int i = idx / kAa, j = idx % kAa;
       double sum = 0;
-      for (int x = 0; x < kAa; x++) sum += Pm[i * kAa + x] * m.Q[x * kAa + j];
+      for (int x = 0; x < kAa; x++) sum += Pm[i * kAa + x] * Vs[x * kAa + j];
       PQm[idx] = sum;
     }
     __syncthreads();

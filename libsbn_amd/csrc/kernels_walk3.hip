@@ -73,6 +73,7 @@ constexpr unsigned kTwCol = 32, kTwColCompact = 12;
 constexpr unsigned kPos = 1280u, kVisit = 6u * kPos;
 constexpr unsigned kTipCat = 320u, kTipRow = 80u;
 constexpr unsigned kVecBytes = R * kTile * 8;  // one stored vector of a wave (LDS slot, arena entry)
+typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 // operands of one child of a visit (see fetch_child)
 template <bool PRE>
@@ -99,7 +100,17 @@ constexpr int kSetupQuarters = 4, kReadyQuarter = 1 << 8;
 //          with every vector in LDS: bit-identical.
 //   KP:    rate categories per matrix instruction (4: K = 3, 4; 2: K = 2; 1: K = 1); a register
 //          holds 16 / KP pattern columns.
-template <bool RESCALE, bool FUSED, bool ARENA, int KP>
+//   NT:    ARENA only -- the arena is written and read with non-temporal accesses.  A vector is
+//          written once and read once; whether it should stay in the XCD's L2 in between depends
+//          on what else wants that L2 (measured, round 6, ms per 1000 trees, plain / non-temporal):
+//          with few pattern tiles per tree many trees are in flight per XCD and their operand
+//          records -- shared by all waves of a tree -- are what the L2 should hold: 50 taxa x 378
+//          patterns (32 tiles) 0.983 / 0.937, fluA-sized 69 x 238 x 1 category (5 tiles) 0.271 /
+//          0.258; with many tiles per tree the records fit anyway and the pre-order walk finds
+//          the vectors written last still in the L2 (it reads them in reverse order): 36 x 1812
+//          (151 tiles) 2.72 / 2.82, 59 x 1824 4.50 / 4.71, 64 x 1008 (84) 2.81 / 2.89; 100 x 500
+//          (42) 2.40 / 2.40.  The launcher takes NT up to 48 tiles per tree.
+template <bool RESCALE, bool FUSED, bool ARENA, int KP, bool NT = false>
 __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, const int block,
                                               const int32_t* ready, const int spin_ticks, const int fence) {
   static_assert(R >= 1 && R <= 4, "a tip word holds one byte / one 4-bit field per register");
@@ -337,11 +348,15 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     asm volatile("" : "+v"(v16), "+v"(v8));
 #pragma unroll
     for (int p = 0; p < R / 2; p++) {
-      const double2 v = *reinterpret_cast<const double2*>(at + p * (kTile * 16) + (size_t)v16);
+      const dbl2* src = reinterpret_cast<const dbl2*>(at + p * (kTile * 16) + (size_t)v16);
+      const dbl2 v = NT ? __builtin_nontemporal_load(src) : *src;
       o.x[OFF + 2 * p] = v.x;
       o.x[OFF + 2 * p + 1] = v.y;
     }
-    if (R & 1) o.x[OFF + R - 1] = *reinterpret_cast<const double*>(at + (R / 2) * (kTile * 16) + (size_t)v8);
+    if (R & 1) {
+      const double* src = reinterpret_cast<const double*>(at + (R / 2) * (kTile * 16) + (size_t)v8);
+      o.x[OFF + R - 1] = NT ? __builtin_nontemporal_load(src) : *src;
+    }
   };
   auto fetch_child = [&](auto pre_tag, auto jtag, int sh, const Tw& tw, const char* sb, const char* sb4,
                          auto& o, int& ak) {
@@ -549,9 +564,17 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     unsigned v16 = lane16, v8 = lane8;
     asm volatile("" : "+v"(v16), "+v"(v8));
 #pragma unroll
-    for (int p = 0; p < R / 2; p++)
-      *reinterpret_cast<double2*>(at + p * (kTile * 16) + (size_t)v16) = double2{x.v[2 * p], x.v[2 * p + 1]};
-    if (R & 1) *reinterpret_cast<double*>(at + (R / 2) * (kTile * 16) + (size_t)v8) = x.v[R - 1];
+    for (int p = 0; p < R / 2; p++) {
+      dbl2* dst = reinterpret_cast<dbl2*>(at + p * (kTile * 16) + (size_t)v16);
+      const dbl2 v = {x.v[2 * p], x.v[2 * p + 1]};
+      if (NT) __builtin_nontemporal_store(v, dst);
+      else *dst = v;
+    }
+    if (R & 1) {
+      double* dst = reinterpret_cast<double*>(at + (R / 2) * (kTile * 16) + (size_t)v8);
+      if (NT) __builtin_nontemporal_store(x.v[R - 1], dst);
+      else *dst = x.v[R - 1];
+    }
   };
   auto mm = [&](double A, const V& x) {
     V y;
@@ -913,10 +936,10 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
 
 // (R = 2 -- 8 patterns per wave, 14 KB of LDS -- is built with three waves per SIMD:
 // `make EXTRA_LLVM=-DMI_LLR=2`, an experiment of round 4)
-template <bool RESCALE, bool ARENA, int KP>
+template <bool RESCALE, bool ARENA, int KP, bool NT = false>
 __global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_kernel(LikArgs a) {
   extern __shared__ double wlds[];
-  walk_lut_body<RESCALE, false, ARENA, KP>(a, wlds, blockIdx.x, nullptr, 0, 0);
+  walk_lut_body<RESCALE, false, ARENA, KP, NT>(a, wlds, blockIdx.x, nullptr, 0, 0);
 }
 
 // ------------------------------------------------------------------------
@@ -1285,6 +1308,14 @@ bool gradient_walk_lut_applies(int K) { return K >= 1 && K <= 4 && R >= 2; }
 
 template <bool RESCALE, bool ARENA, int KP>
 static void launch_lut_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  // (non-temporal arena accesses up to 48 pattern tiles per tree: walk_lut_body;
+  // MI_PHYLO_ARENA_NT=0|1 forces plain / non-temporal)
+  static const int forced = getenv("MI_PHYLO_ARENA_NT") ? atoi(getenv("MI_PHYLO_ARENA_NT")) : -1;
+  if (ARENA && (forced < 0 ? a.g_tiles <= 48 : forced != 0)) {
+    allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_kernel<RESCALE, ARENA, KP, ARENA>), lds);
+    hipLaunchKernelGGL((gradient_walk_lut_kernel<RESCALE, ARENA, KP, ARENA>), grid, dim3(kTile), lds, s, a);
+    return;
+  }
   allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_kernel<RESCALE, ARENA, KP>), lds);
   hipLaunchKernelGGL((gradient_walk_lut_kernel<RESCALE, ARENA, KP>), grid, dim3(kTile), lds, s, a);
 }

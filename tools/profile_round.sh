@@ -35,6 +35,14 @@ stats flua_1 python3 tools/bench_flua.py 1
 stats flua_1000 python3 tools/bench_flua.py 1000
 stats aa_T1 python3 tools/bench_aa.py --trees 1 --steps 3
 stats aa_T8 python3 tools/bench_aa.py --trees 8 --steps 3
+# round 6: a rank's pattern block of BASELINE configs[4] under 8-way sharding; the arena shapes
+stats aa_shard_T1 python3 tools/bench_aa.py --trees 1 --steps 10 --patterns 6250
+stats ts_64x1008 python3 tools/bench_tree_size.py 64 1008
+stats ts_36x1812 python3 tools/bench_tree_size.py 36 1812
+stats ts_50x378 python3 tools/bench_tree_size.py 50 378
+python3 tools/bench_shapes_ab.py default 2>&1 | grep -v amdgpu.ids > $S/${tag}_tree_size.txt
+python3 tools/bench_shapes_ab.py --shapes 36x1812x4,41x1137x4,50x378x4,50x1133x4,59x1824x4,64x1008x4,100x500x4,69x238x1,45x1000x1,45x1000x2 default gen2=MI_PHYLO_WALK3_ARENA=0 v1=MI_PHYLO_GRADIENT_WALK=v1 lds=MI_PHYLO_GRADIENT_STORE=lds 2>&1 | grep -v amdgpu.ids > $S/${tag}_arena_ab.txt
+python3 tools/bench_small_step.py --rounds 2 default=MI_PHYLO_FUSED_FENCE=l1 none=MI_PHYLO_FUSED_FENCE=none none_id_order=MI_PHYLO_FUSED_FENCE=none,MI_PHYLO_FUSED_COLOCATE=0 agent=MI_PHYLO_FUSED_FENCE=agent four_launches=MI_PHYLO_FUSED_SETUP=0 2>&1 | grep -v amdgpu.ids > $S/${tag}_small_step_handoff.txt
 
 pmc pmc_fetch_gradient FETCH_SIZE python3 bench.py --steps 3 --warmup 1 --headline-only
 pmc pmc_write_gradient WRITE_SIZE python3 bench.py --steps 3 --warmup 1 --headline-only
@@ -46,6 +54,7 @@ for T in 1 8; do
 done
 
 SQ_JOBS=78000 bash tools/sq_counters.sh $S/${tag}_sq_counters_gradient_walk.txt > /dev/null 2>&1
+SQ_JOBS=59000 bash tools/sq_counters.sh $S/${tag}_sq_counters_loglik.txt --mode loglik > /dev/null 2>&1
 
 # SQ counters of the 20-state walk kernels (one tree and eight trees per launch)
 for T in 1 8; do

@@ -259,7 +259,7 @@ def executed_flops_per_tree(kname, n, P, K, R=3):
     follow from the tree size alone (checked against SQ_INSTS_MFMA of the committed counter
     tables: 385 / 628 / 208 per job for a 27-taxon tree) x 512 flops per v_mfma_f64_4x4x4_4b.
       look-up walk (gradient_walk_lut*):   4 (n-2) R + 2 R + 1 + 3 (n-1)   (tip children: none)
-      mask-tip walks (gradient_walk / gradient_mfma):  (7 n - 8) R + 2 R + 1 + 3 (n-1)
+      mask-tip walk (gradient_walk_kernel):  (7 n - 8) R + 2 R + 1 + 3 (n-1)
       loglik_mfma (R = 4):                 2 (n-1) R + R + 1
     None for kernels that do not run on the matrix cores or for more than four categories."""
     if K > 4:
@@ -267,7 +267,7 @@ def executed_flops_per_tree(kname, n, P, K, R=3):
     kp = 1 if K == 1 else (2 if K == 2 else 4)
     if kname.startswith("gradient_walk_lut"):
         per_job = 4 * (n - 2) * R + 2 * R + 1 + 3 * (n - 1)
-    elif kname.startswith(("gradient_walk_kernel", "gradient_mfma_kernel")):
+    elif kname.startswith("gradient_walk_kernel"):
         per_job = (7 * n - 8) * R + 2 * R + 1 + 3 * (n - 1)
     elif kname.startswith("loglik_mfma"):
         R = 4

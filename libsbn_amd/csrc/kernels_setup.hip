@@ -579,9 +579,6 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
     const long last = (first + kTransitionBlock - 1 < total ? first + kTransitionBlock - 1 : total - 1);
     if (first / per >= a.ev_skip_begin && last / per < a.ev_skip_end) return;
   }
-  double Pm[16];
-  bool tip_edge = false;
-  int mi_keep = 0;
   if (idx < total) {
     const int k = idx % a.K;
     const int edge = (idx / a.K) % (a.N - 1);
@@ -599,11 +596,8 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
       for (int j = 0; j < 4; j++) {
         double sum = i == j ? 1.0 : 0.0;
         for (int x = 0; x < 4; x++) sum += m.V[i * 4 + x] * W[x * 4 + j];
-        Pm[i * 4 + j] = sum > 0 ? sum : 0;  // BEAGLE clamps negative probabilities to 0
-        stage[threadIdx.x * 17 + i * 4 + j] = Pm[i * 4 + j];
+        stage[threadIdx.x * 17 + i * 4 + j] = sum > 0 ? sum : 0;  // BEAGLE clamps negative probabilities to 0
       }
-    tip_edge = edge < a.n;
-    mi_keep = mi;
   }
   __syncthreads();
   const long left = total - first;
@@ -626,54 +620,6 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
         a.tip_tables[(((size_t)e * a.n + edge) * a.K + k) * 20 + j] =
             j < 16 ? stage[m * 17 + (j & 3) * 4 + (j >> 2)] : 1.0;
     }
-  }
-  // blocks whose matrices all belong to log-likelihood-only evaluations (the finite-difference
-  // passes of a GTR gradient call) have no pre-order step to prepare
-  const long per_eval = (long)a.K * (a.N - 1);
-  const bool tr_needed = first / per_eval < a.tr_skip_begin ||
-                         (first + (count >> 4) - 1) / per_eval >= a.tr_skip_end;
-  if (a.tr_mats != nullptr && tr_needed) {
-    // Matrix of the matrix-core kernel's pre-order step, per edge: P again for an
-    // internal edge (the kernel reads it transposed), and for a tip edge -- whose
-    // derivative is (q_parent o sibling) . (P Q) e_state, one product instead of two --
-    // (P Q) stored transposed so that the same transposed read yields it in forward layout.
-    __syncthreads();
-    if (tip_edge) {
-      const DevModel& m = a.models[mi_keep];
-      for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-          double pq = 0;
-          for (int x = 0; x < 4; x++) pq += Pm[i * 4 + x] * m.Q[x * 4 + j];
-          stage[threadIdx.x * 17 + j * 4 + i] = pq;
-        }
-    }
-    __syncthreads();
-    double* out2 = a.tr_mats + first * 16;
-    for (int x = threadIdx.x; x < count; x += kTransitionBlock)
-      out2[x] = stage[(x >> 4) * 17 + (x & 15)];
-  }
-  if (a.phi != nullptr) {
-    // Analytic substitution gradient: d exp(Q tau) = V ((V^-1 dQ V) o Phi) V^-1 with the
-    // divided differences Phi_ij = (e^{l_i tau} - e^{l_j tau}) / (l_i - l_j), Phi_ii =
-    // tau e^{l_i tau}, tau = r_k t.  Evaluated as tau e^{l_j tau} expm1(x)/x, x = (l_i -
-    // l_j) tau, which is stable for close and for equal eigenvalues.
-    __syncthreads();
-    if (idx < total) {
-      const int k = idx % a.K;
-      const int edge = (idx / a.K) % (a.N - 1);
-      const int e = idx / ((long)a.K * (a.N - 1));
-      int t, mi;
-      a.map.decode(e, t, mi);
-      const DevModel& m = a.models[mi];
-      const double tau = m.cat_rate[k] * a.bl_eff[(size_t)t * a.N + edge];
-      for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++)
-          stage[threadIdx.x * 17 + i * 4 + j] = phi_divided_difference(m.lambda[i], m.lambda[j], tau);
-    }
-    __syncthreads();
-    double* out3 = a.phi + first * 16;
-    for (int x = threadIdx.x; x < count; x += kTransitionBlock)
-      out3[x] = stage[(x >> 4) * 17 + (x & 15)];
   }
 }
 

@@ -1075,6 +1075,7 @@ bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t wave
   // in 1.96 against 2.07; at six -- 29 to 35 taxa -- the LDS store keeps 1.21 against 1.38)
   return !lds_fits || (160 * 1024) / lds_all < (lut ? 6 : 5);
 }
+int gradient_walk_waves_per_cu(int n, int K);
 bool gradient_walk_fits(int n, int K, bool rescale) {
   if (n < 3 || K > kMaxCategories) return false;
   if (gradient_walk_lds_bytes(n, K, rescale, true) <= 160 * 1024) return true;

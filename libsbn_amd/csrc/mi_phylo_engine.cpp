@@ -67,19 +67,14 @@ CallShape call_shape(const mi_engine* e, int T, bool gradient, bool analytic = f
   return c;
 }
 
-// the two generations of the matrix-core gradient walk (kernels_gradient.hip /
-// kernels_walk.hip) size their LDS slightly differently
 // (waves: one-wave workgroups of a gradient launch; default: a large batch)
 bool walk3_possible(const mi_engine* e);
 bool use_arena(const mi_engine* e, bool rescale, bool subst, size_t waves = (size_t)-1) {
   // (the look-up walk's arena variant starts one step earlier: gradient_walk_use_arena)
   const bool lut = walk3_possible(e) && e->walk3_arena && !subst && gradient_mfma_groups(e->K) == 1;
-  return e->walk2 ? gradient_walk_use_arena(e->n, e->K, rescale, subst, waves, lut)
-                  : gradient_mfma_use_arena(e->n, e->K, rescale, subst, waves);
+  return gradient_walk_use_arena(e->n, e->K, rescale, subst, waves, lut);
 }
-bool walk_fits(const mi_engine* e, bool rescale) {
-  return e->walk2 ? gradient_walk_fits(e->n, e->K, rescale) : gradient_mfma_fits(e->n, e->K, rescale);
-}
+bool walk_fits(const mi_engine* e, bool rescale) { return gradient_walk_fits(e->n, e->K, rescale); }
 
 // which log-likelihood kernel a call uses (also decides who fills the tip tables)
 bool loglik_kernel_is_valu(const mi_engine* e, bool rescaling) {
@@ -100,19 +95,10 @@ bool matrix_core_gradient(const mi_engine* e, bool rescaling) {
          (gradient_mfma_groups(e->K) == 1 || !loglik_kernel_is_valu(e, rescaling));
 }
 
-// Round 6: the third generation runs every shape the first two did for engines with one-hot /
-// all-ones tips and at most four rate categories (arena variant, one and two categories), so
-// such an engine never needs the first generation: the K < 3 rule of engine creation (first
-// generation on arena shapes with few tiles) is overridden once the tips are known.
-void choose_walk_generation(mi_engine* e) {
-  if (e->walk_forced || e->s != kStates) return;
-  if (e->walk3 && e->walk3_arena && e->have_tip_codes && gradient_walk_lut_applies(e->K)) e->walk2 = true;
-}
-
 // Can calls of this engine take the third-generation walk (kernels_walk3.hip)?  (Per call it
 // also needs the stored vectors in LDS and no analytic substitution gradient.)
 bool walk3_possible(const mi_engine* e) {
-  return e->walk2 && e->walk3 && e->have_tip_codes && gradient_walk_lut_applies(e->K);
+  return e->walk3 && e->have_tip_codes && gradient_walk_lut_applies(e->K);
 }
 
 size_t plv_bytes_per_eval(const mi_engine* e) {
@@ -131,9 +117,7 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
   if (e->models.ensure(sizeof(DevModel) * (size_t)c.M)) return 1;
   if (e->mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
   if (e->tip_tables.ensure(sizeof(double) * (size_t)c.E * n * e->K * 20)) return 1;
-  if (gradient && e->tr_mats.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
-  if (analytic && e->phi.ensure(sizeof(double) * (size_t)c.E * (N - 1) * e->K * 16)) return 1;
-  if (gradient && e->walk2) {
+  if (gradient) {
     // matrices in the walk's order, per gradient evaluation (kernels_walk.hip)
     const size_t per = std::max(gradient_walk_mats_bytes_per_eval(n, e->K),
                                 walk3_possible(e) ? gradient_walk_lut_mats_bytes_per_eval(n) : 0);
@@ -245,7 +229,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   PROF_MARK(e, marks, 0, s);
   // (a call of a few trees keeps its stored vectors in LDS however large the tree)
   const bool arena = mfma && use_arena(e, d.rescaling, analytic, (size_t)T * (size_t)g_tiles);
-  const bool walk2 = mfma && e->walk2;
+  const bool walk2 = mfma;  // (every matrix-core call: the first generation was retired in round 6)
   // the third-generation (look-up) walk: stored vectors in LDS or, since round 6, in the arena
   const bool walk3 = walk2 && walk3_possible(e) && !analytic && groups == 1 &&
                      (!arena || e->walk3_arena);
@@ -293,12 +277,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool loglik_runs = !d.gradient || fd_pass || (mfma && groups > 1);
   const bool need_tip_tables = loglik_runs && loglik_is_valu;
   tr.tip_tables = need_tip_tables ? e->tip_tables.as<double>() : nullptr;
-  tr.tr_mats = (mfma && !walk2) ? e->tr_mats.as<double>() : nullptr;
-  tr.phi = (analytic && !walk2) ? e->phi.as<double>() : nullptr;
   tr.n = n;
-  // evaluations [T, 17 T) of a finite-difference GTR call never run the gradient kernel
-  tr.tr_skip_begin = c.E > T ? T : c.E;
-  tr.tr_skip_end = c.E > T ? std::min(17 * T, c.E) : c.E;
   // evaluations nobody walks need no matrices at all
   tr.ev_skip_begin = tr.ev_skip_end = 0;
   if (d.gradient && c.gtr && !analytic && !light && !fd_pass) {
@@ -362,8 +341,6 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.macro_count = e->macro_count.as<int32_t>();
   la.mats = e->mats.as<double>();
   la.tip_tables = e->tip_tables.as<double>();
-  la.tr_mats = e->tr_mats.as<double>();
-  la.phi = e->phi.as<double>();
   la.mmats = e->mmats.as<double>();
   la.mphi = e->mphi.as<double>();
   la.tip_states = e->tip_states.as<int8_t>();
@@ -422,8 +399,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
           fs.colocate = e->fused_colocate;
           launch_gradient_walk_lut_fused(g, fs, part, d.rescaling, s);
         } else if (walk3) launch_gradient_walk_lut(g, part, d.rescaling, s);
-        else if (walk2) launch_gradient_walk(g, part, d.rescaling, analytic, s);
-        else launch_gradient_mfma(g, part, d.rescaling, analytic, s);
+        else launch_gradient_walk(g, part, d.rescaling, analytic, s);
       }
       return;
     }
@@ -456,7 +432,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     e->dominant = fuse_setup ? gradient_walk_lut_fused_kernel_name()
                   : walk3 ? gradient_walk_lut_kernel_name()
                   : walk2 ? gradient_walk_kernel_name()
-                        : (mfma ? gradient_mfma_kernel_name() : gradient_kernel_name());
+                        : gradient_kernel_name();
   }
   {  // which path the call took, for diagnostics (mi_engine_last_call_path)
     std::string path = e->dominant;
@@ -786,37 +762,15 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   if (const char* env = getenv("MI_PHYLO_PLV_BYTES")) e->plv_budget = strtoull(env, nullptr, 10);
   if (const char* env = getenv("MI_PHYLO_SUBST_GRADIENT"))
     e->analytic_subst = std::string(env) == "analytic";
-  // MI_PHYLO_GRADIENT_WALK=v1: the first-generation matrix-core gradient kernel (node-ordered
-  // matrices; kept selectable, results are bit-identical)
-  // Which generation of the matrix-core gradient walk: the second (macro-ordered operand
-  // streams) keeps its tip words by (macro, position, column), 32 bytes per column -- with
-  // fewer than three rate categories a wave has 8 or 16 columns, and that table can cost
-  // waves per CU (fluA, K = 1: 5 instead of 8); then the first generation stays.
-  // MI_PHYLO_GRADIENT_WALK=v1|v2 forces one.
-  // (Round 4: with compact tip words -- 12 instead of 32 bytes per column and macro -- the second
-  // generation no longer loses waves per CU at K < 3, and was measured again: fluA x 1000
-  // 0.344 ms against the first generation's 0.327, one fluA tree 0.100 against 0.103.  The
-  // batch is what counts: K < 3 stays with the first generation.)
-  // Round 5: that comparison was made on fluA (69 taxa: the arena variants).  With the stored
-  // vectors in LDS the second generation wins for one and two categories as well -- DS1 x 1000,
-  // constant site model: 0.270 against 0.331 ms, two categories 0.467 against 0.585 -- so K < 3
-  // engines whose trees keep their vectors in LDS on a large batch take it too; the arena
-  // shapes (more than ~31 taxa) stay with the first generation.
-  // ... and so do the arena shapes with eight pattern tiles per tree and more (tools/audit_paths.py,
-  // 1000 trees x 1000 patterns: 31 taxa 0.474 -> 0.409 ms, 45: 0.661 -> 0.577, 64: 0.918 -> 0.800,
-  // 100: 1.558 -> 1.280 with one category; 9-42 % with two): its waves take several tiles of a tree
-  // in a row.  With a handful of tiles per tree the first generation keeps a 0-5 % edge (fluA:
-  // five tiles, 0.321 against 0.335 ms per 1000 trees).
-  // (The waves-per-CU comparison of the two generations that used to gate this is gone: at 31
-  // taxa and two categories the second generation fits fewer waves and still takes 0.646
-  // against 0.917 ms.)
-  e->walk2 = e->K >= 3 || !gradient_walk_use_arena(e->n, e->K, false, false) ||
-             gradient_mfma_tiles(e->P, e->K) >= 8;
-  if (const char* env = getenv("MI_PHYLO_GRADIENT_WALK")) {
-    e->walk2 = std::string(env) != "v1";
-    e->walk3 = std::string(env) != "v1" && std::string(env) != "v2";
-    e->walk_forced = true;
-  }
+  // Which generation of the matrix-core gradient walk a call takes: the third (kernels_walk3.hip:
+  // tip children looked up; one-hot / all-ones tips, at most four rate categories, no analytic
+  // substitution gradient -- everything the reference produces) wherever it applies, else the
+  // second (kernels_walk.hip: mask tips, any category count, analytic gradient).
+  // MI_PHYLO_GRADIENT_WALK=v2 keeps every call on the second.  (The first generation,
+  // gradient_mfma_kernel, was retired in round 6: the second had been ahead of it on every shape
+  // but the arena shapes with fewer than three categories and a handful of tiles -- fluA: 0.321
+  // against 0.335 ms per 1000 trees -- and those now take the third: 0.305 -> 0.29.)
+  if (const char* env = getenv("MI_PHYLO_GRADIENT_WALK")) e->walk3 = std::string(env) != "v2";
   if (const char* env = getenv("MI_PHYLO_FUSED_SETUP")) e->fused_setup = std::string(env) != "0";
   if (const char* env = getenv("MI_PHYLO_DEBUG_FUSED_SKIP")) e->fused_debug_skip = atoi(env);
   // the one-launch call's hand-off (kernels_walk3.hip, walk_lut_body): none | l1 (default) | agent
@@ -918,7 +872,6 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
       return cleanup_fail(fail("copy of the pattern weights failed"));
     if (hipStreamSynchronize(e->stream) != hipSuccess || hipGetLastError() != hipSuccess)
       return cleanup_fail(fail("preparation of the device-resident tips failed"));
-    choose_walk_generation(e);
     *out_engine = e;
     return 0;
   }
@@ -1018,7 +971,6 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
   if (upload(e->weights, pattern_weights, (size_t)e->P, e->stream)) return cleanup_fail(1);
   if (hipStreamSynchronize(e->stream) != hipSuccess)
     return cleanup_fail(fail("upload of tips failed"));
-  choose_walk_generation(e);
   *out_engine = e;
   return 0;
 }
@@ -1034,7 +986,7 @@ void mi_engine_destroy(mi_engine* e) {
   for (Buffer* b :
        {&e->tip_states, &e->tip_partials, &e->tip_masks, &e->tip_codes, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
         &e->arena_macros, &e->slot_need,
-        &e->macro_count, &e->tip_tables, &e->tr_mats, &e->phi, &e->mmats, &e->mphi, &e->x_sum, &e->bl_eff,
+        &e->macro_count, &e->tip_tables, &e->mmats, &e->mphi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,
         &e->ll_sum, &e->g_sum, &e->status, &e->ready, &e->weibull_x, &e->aa_model, &e->aa_matP, &e->aa_matPT,
         &e->aa_tipP, &e->aa_tipPQ, &e->aa_exp_cum, &e->aa_exp_loc, &e->aa_root_val,

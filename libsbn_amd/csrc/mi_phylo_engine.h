@@ -137,7 +137,7 @@ struct mi_engine {
   bool have_tip_masks = false;  // every tip vector is 0/1: the matrix-core kernel can run
   bool have_tip_codes = false;  // ... and one-hot or all ones: the third-generation walk can run
   // per-call workspace
-  Buffer arena_macros, slot_need, tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, tr_mats, phi, mmats, mphi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
+  Buffer arena_macros, slot_need, tree_scratch, sched, macros, macro_count, bl_eff, models, mats, tip_tables, mmats, mphi, x_sum, ll_part, plv, g_part, site_lik, site_exp, fin_scratch,
       ll_sum, g_sum, status;
   Buffer weibull_x;  // [K][2] {x_k, log x_k} of the Weibull quantiles (once per engine)
   Buffer ready;  // [T] hand-off words of the one-launch small call (zero between calls)
@@ -156,9 +156,7 @@ struct mi_engine {
   bool allow_onchip_gradient = true;
   bool analytic_subst = false;       // MI_PHYLO_SUBST_GRADIENT=analytic (opt-in)
   int gradient_path = 0;  // 0 auto, 2 hbm, 3 mfma (MI_PHYLO_GRADIENT_PATH)
-  bool walk2 = true;      // second-generation matrix-core gradient walk (MI_PHYLO_GRADIENT_WALK=v1: first)
   bool walk3 = true;      // third generation where it applies (tip children looked up; MI_PHYLO_GRADIENT_WALK=v2: off)
-  bool walk_forced = false;  // MI_PHYLO_GRADIENT_WALK given: engine creation keeps that choice
   bool walk3_arena = true;  // ... for arena-variant calls too (MI_PHYLO_WALK3_ARENA=0: off)
   // a sharded handle (mi_engine_create_sharded): the per-device / per-shard engines it
   // drives; such a handle owns no device memory itself

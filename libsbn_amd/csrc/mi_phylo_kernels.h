@@ -64,10 +64,7 @@ struct TransitionArgs {
   const double* bl_eff;  // [T][N]
   double* mats;          // [E][N-1][K][16]
   double* tip_tables;    // [E][n][K][5][4]: per tip edge and state (4 = gap), the column of P; may be nullptr
-  double* tr_mats;       // [E][N-1][K][4][4]: matrix of the matrix-core pre-order step (P, or (P Q)^T for tips); may be nullptr
-  double* phi;           // [E][N-1][K][4][4]: divided differences of exp(lambda r t) (analytic substitution gradient); may be nullptr
   int n;
-  int tr_skip_begin, tr_skip_end;  // evaluations [begin, end) are log-likelihood only: no tr_mats for them
   int ev_skip_begin, ev_skip_end;  // evaluations [begin, end) are not walked at all: no matrices
   int eval_base;                   // this launch covers evaluations [eval_base, eval_base + E)
 };
@@ -108,8 +105,6 @@ struct LikArgs {
   const int32_t* macro_count;  // [T]
   const double* mats;
   const double* tip_tables;    // see TransitionArgs
-  const double* tr_mats;       // see TransitionArgs
-  const double* phi;           // see TransitionArgs
   const double* mmats;         // see TransitionMacroArgs (indexed by gradient evaluation)
   const double* mphi;
   const int8_t* tip_states;    // [n][P]
@@ -175,23 +170,15 @@ int loglik_mfma_tiles(int P, int K);
 int gradient_mfma_tiles(int P, int K);
 // Gradient, partial-likelihood vectors streamed through HBM (any tree size, rescaling)
 void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t s);
-// Gradient with all partial-likelihood vectors resident in LDS (no rescaling;
-// needs the per-pattern site likelihoods written by launch_loglik with
-// a.site_lik set).  Returns false when the tree does not fit in LDS.
-// Same walk on the FP64 matrix cores, all categories per instruction (K <= 4); also
-// writes the log-likelihood partial sums, so no separate logL pass is needed.
-bool gradient_mfma_fits(int n, int K, bool rescale);
+// The matrix-core gradient walks (kernels_walk.hip: second generation, kernels_walk3.hip: third;
+// the first, gradient_mfma_kernel, was retired in round 6): all categories of a group of four
+// per instruction; they also write the log-likelihood partial sums, so no separate logL pass is
+// needed (K > 4: the site likelihoods come from a pass of the log-likelihood kernel).
 int gradient_mfma_groups(int K);  // waves per pattern tile (category groups of four)
 // subst: analytic substitution gradient statistics appended (kSubstExtra doubles)
 int gradient_mfma_width(int n, bool subst = false);  // doubles per (gradient evaluation, tile) of its partial sums
-void launch_gradient_mfma(const LikArgs& a, int count, bool rescale, bool subst, hipStream_t s);
-// arena variant of the matrix-core gradient kernel (stored post-order vectors in HBM, LDS
-// slots reused): when it runs, its slot assignment pass, and its HBM need per evaluation
-// waves: one-wave workgroups of the launch (default: a large batch).  A call whose waves are
-// all resident at once with the LDS footprint of the all-in-LDS store keeps that store however
-// large the tree: occupancy is not what bounds a call of a few trees, and the arena's second
-// launch, macro-slot kernel and HBM round trips are.
-bool gradient_mfma_use_arena(int n, int K, bool rescale, bool subst, size_t waves = (size_t)-1);
+// arena variant of the walks (stored post-order vectors in HBM, LDS slots reused): its slot
+// assignment pass, and its HBM need per evaluation
 void launch_macro_slots(const MacroEntry* macros_in, MacroEntry* macros_out,
                         const int32_t* macro_count, int n, int T, int32_t* need, int32_t* status,
                         hipStream_t s);
@@ -239,9 +226,8 @@ void launch_gradient_walk_lut_fused(const LikArgs& a, const FusedSetupArgs& f, i
                                     hipStream_t s);
 const char* gradient_walk_lut_kernel_name();
 const char* gradient_walk_lut_fused_kernel_name();
-// waves per CU each generation's LDS footprint allows for this tree size and category count
+// waves per CU the walks' LDS footprint allows for this tree size and category count
 int gradient_walk_waves_per_cu(int n, int K);
-int gradient_mfma_waves_per_cu(int n, int K);
 // Sum of the per-tile partials: ll_sum[e] = sum_i ll_part[e][i] for e < E,
 // g_sum[gi][2N] = sum_i g_part[gi][i][2N] for gi < Eg (fixed order: deterministic).
 struct ReduceArgs {
@@ -390,6 +376,5 @@ const char* aa_pre_kernel_name();
 
 const char* loglik_kernel_name(const LikArgs& a, bool rescale, int max_slots);
 const char* gradient_kernel_name();
-const char* gradient_mfma_kernel_name();
 
 }  // namespace miphylo

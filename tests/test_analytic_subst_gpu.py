@@ -15,14 +15,9 @@ import tree_utils as TU
 
 pytestmark = pytest.mark.gpu
 
-# The matrix-core gradient walk: first generation (kernels_gradient.hip) or second
-# (kernels_walk.hip).  MI_PHYLO_GRADIENT_WALK=v1|v2 forces one; by default the engine takes
-# the second unless its LDS footprint would cost waves per CU (fewer than three rate
-# categories).  Either name means "the matrix-core path ran, not the HBM-streamed fallback".
-_FORCED = os.environ.get("MI_PHYLO_GRADIENT_WALK")
-WALK_KERNEL = (("gradient_mfma_kernel",) if _FORCED == "v1" else ("gradient_walk_kernel",)
-               if _FORCED == "v2" else ("gradient_mfma_kernel", "gradient_walk_kernel",
-                                        "gradient_walk_lut_kernel", "gradient_walk_lut_fused_kernel"))
+# The analytic gradient runs on the second-generation matrix-core walk (kernels_walk.hip); the
+# name means "the matrix-core path ran, not the HBM-streamed fallback".
+WALK_KERNEL = ("gradient_walk_kernel",)
 
 
 @pytest.fixture

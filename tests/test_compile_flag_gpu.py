@@ -35,7 +35,7 @@ def grads(tag, eng, pr, **kw):
     for k in g[0].gradient:
         out[tag + "." + k] = np.stack([x.gradient[k] for x in g])
 jc = np.ones((T, 2)); jc[:, 0] = rng.uniform(0.4, 1.6, T)
-for walk in ("v3", "v2", "v1"):
+for walk in ("v3", "v2"):
     os.environ["MI_PHYLO_GRADIENT_WALK"] = walk
     for store in ("", "arena"):
         if store: os.environ["MI_PHYLO_GRADIENT_STORE"] = store

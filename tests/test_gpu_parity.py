@@ -26,17 +26,15 @@ import tree_utils as TU
 
 pytestmark = pytest.mark.gpu
 
-# The matrix-core gradient walk: first generation (kernels_gradient.hip), second
-# (kernels_walk.hip) or third (kernels_walk3.hip: tip children looked up).
-# MI_PHYLO_GRADIENT_WALK=v1|v2 forces one of the first two; by default the engine takes the
-# third where it applies (three or four rate categories, one-hot / all-ones tips, stored
-# vectors in LDS), else the second unless its LDS footprint would cost waves per CU (fewer
-# than three rate categories).  Any name means "the matrix-core path ran, not the HBM-streamed
-# fallback".
+# The matrix-core gradient walk: second generation (kernels_walk.hip: mask tips, any category
+# count, analytic substitution gradient) or third (kernels_walk3.hip: tip children looked up --
+# one-hot / all-ones tips, at most four rate categories; stored vectors in LDS or, for the larger
+# trees, in the arena).  The engine takes the third wherever it applies; MI_PHYLO_GRADIENT_WALK=v2
+# keeps every call on the second.  (The first generation, gradient_mfma_kernel, was retired in
+# round 6.)  Any name means "the matrix-core path ran, not the HBM-streamed fallback".
 _FORCED = os.environ.get("MI_PHYLO_GRADIENT_WALK")
-WALK_KERNEL = (("gradient_mfma_kernel",) if _FORCED == "v1" else ("gradient_walk_kernel",)
-               if _FORCED == "v2" else ("gradient_mfma_kernel", "gradient_walk_kernel",
-                                        "gradient_walk_lut_kernel", "gradient_walk_lut_fused_kernel"))
+WALK_KERNEL = (("gradient_walk_kernel",) if _FORCED == "v2" else
+               ("gradient_walk_kernel", "gradient_walk_lut_kernel", "gradient_walk_lut_fused_kernel"))
 
 RTOL = 1e-10
 
@@ -920,14 +918,14 @@ def test_full_size_gtr_weibull_1000_trees():
 
 
 def test_walk_kernels_agree():
-    """The two generations of the matrix-core gradient walk -- gradient_mfma_kernel
-    (node-ordered matrices, schedule entries in vector registers) and gradient_walk_kernel
-    (macro-ordered operand streams, scalar descriptors, one switch per child configuration) --
-    do the same products in the same order (only two root reductions are ordered differently):
-    log-likelihoods and gradients equal to the last bits, over rate-category counts 1 / 2 / 3 / 4 / 8, with and without rescaling, finite-difference
-    and analytic GTR, stored vectors in LDS and in the arena, unrooted and rooted.  (The
-    switches are read at engine creation / once per process: each form runs in its own
-    interpreter.)"""
+    """The generations of the matrix-core gradient walk -- gradient_walk_kernel (macro-ordered
+    operand streams, mask tips) and gradient_walk_lut_kernel (tip children looked up; round 6:
+    with an arena variant and one- and two-category forms) -- do the same products in the same
+    order: log-likelihoods and gradients BIT-IDENTICAL wherever both apply, over rate-category
+    counts 1 / 2 / 3 / 4 / 8, with and without rescaling, finite-difference GTR, stored vectors
+    in LDS and in the arena, unrooted and rooted; the second generation's analytic-GTR form gives
+    the same bits with either store.  (The switches are read at engine creation / once per
+    process: each form runs in its own interpreter.)"""
     import subprocess
     import sys
     import tempfile
@@ -986,7 +984,7 @@ np.save(sys.argv[1], np.concatenate(out))
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     results = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for walk in ("v1", "v2", "v3"):
+        for walk in ("v2", "v3"):
             for store in ("", "arena"):
                 for subst_mode in ("", "analytic"):
                     if walk == "v3" and subst_mode:
@@ -1003,19 +1001,12 @@ np.save(sys.argv[1], np.concatenate(out))
                                        capture_output=True, text=True)
                     assert r.returncode == 0, (walk, store, subst_mode, r.stdout + r.stderr)
                     results[(walk, store, subst_mode)] = np.load(path)
-    for store in ("", "arena"):
-        for subst_mode in ("", "analytic"):
-            a, b = results[("v1", store, subst_mode)], results[("v2", store, subst_mode)]
-            assert a.shape == b.shape and np.isfinite(a).all()
-            # Same products in the same order; what differs is the ORDER of two reductions at
-            # the root (states and categories of the site likelihood, the log-likelihood
-            # partial: matrix-core / row-rotation sums in the second generation, a cross-lane
-            # butterfly in the first), i.e. last-bit differences that the rest of the walk
-            # carries along.  Until that change the two were bit-identical (round 3 history).
-            assert np.allclose(a, b, rtol=1e-12, atol=1e-13 * np.max(np.abs(b))), (
-                store, subst_mode, np.max(np.abs(a - b)))
-    # the third generation (where it applies: the three- and four-category engines of this
-    # list; the others fall back to the second) looks tip products up instead of multiplying.
+    for subst_mode in ("", "analytic"):
+        a, b = results[("v2", "", subst_mode)], results[("v2", "arena", subst_mode)]
+        assert a.shape == b.shape and np.isfinite(a).all()
+        assert np.array_equal(a, b), (subst_mode, np.max(np.abs(a - b)))
+    # the third generation (where it applies: the engines of this list with at most four
+    # categories; the others fall back to the second) looks tip products up instead of multiplying.
     # P e_s IS column s of P, and the all-ones vector's row sum is added in index order by the
     # table builder exactly as the matrix instruction adds its four terms: BIT-IDENTICAL.
     # Round 6: so do its arena variant (stored vectors of the larger trees through HBM) and its
@@ -1086,7 +1077,7 @@ def test_stored_vectors_in_lds_or_arena_are_bit_identical():
     """Where the matrix-core gradient kernels keep the stored vectors of trees of 32 taxa and
     more -- all in LDS (calls of a few trees) or in the HBM arena with a few LDS slots
     (batches) -- is decided per call; the walk generation is fixed per engine.  With the
-    generation held (v1, v2) the two stores give bit-identical results: unrooted and rooted,
+    generation held (v2, v3) the two stores give bit-identical results: unrooted and rooted,
     with and without rescaling, 1 / 3 / 4 rate categories -- so a tree's outputs do not
     depend on the size of the batch it came in.  (The switches are read once per process.)"""
     import subprocess
@@ -1126,7 +1117,7 @@ np.save(sys.argv[1], np.concatenate(out))
 """
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as tmp:
-        for walk in ("v1", "v2", "v3"):
+        for walk in ("v2", "v3"):
             got = {}
             for store in ("lds", "arena", ""):
                 env = dict(os.environ, MI_PHYLO_GRADIENT_WALK=walk)

@@ -69,7 +69,7 @@ for n, P, K, T in grid:
         variants = [("valu", {"MI_PHYLO_LOGLIK_PATH": "valu"}), ("mfma", {"MI_PHYLO_LOGLIK_PATH": "mfma"})]
     else:
         variants = [(f"{walk}/{store}", {"MI_PHYLO_GRADIENT_WALK": walk, "MI_PHYLO_GRADIENT_STORE": store})
-                    for walk, store in itertools.product(("v1", "v2", "v3"), ("lds", "arena"))]
+                    for walk, store in itertools.product(("v2", "v3"), ("lds", "arena"))]
     for vname, env in variants:
         ms, path = time_cfg(n, P, K, T, env)
         if ms is not None and ms < best:

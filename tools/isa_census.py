@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction census of one kernel in an AMDGPU assembly listing (`make asm`).
 
-  python tools/isa_census.py libsbn_amd/csrc/kernels_gradient.s 'gradient_mfma_kernelILi3ELi0ELb0ELb0ELb0E'
+  python tools/isa_census.py libsbn_amd/csrc/kernels_walk3.s 'gradient_walk_lut_kernelILb0ELb0ELi4ELb0E'
 
 Per basic block (label to label) and in total: instructions by class -- matrix (v_mfma),
 f64 vector arithmetic, other vector ALU (32-bit / moves / conversions), cross-lane

@@ -21,9 +21,7 @@ run parity_b parity 3002 1500 &
 run parity_fused parity 3003 600 STRESS_FOCUS=fused &
 run parity_arena parity 3004 400 STRESS_FOCUS=arena &
 run parity_arena_v2 parity 3012 200 STRESS_FOCUS=arena MI_PHYLO_WALK3_ARENA=0 &
-run parity_arena_v1 parity 3010 150 STRESS_FOCUS=arena MI_PHYLO_GRADIENT_WALK=v1 &
 run parity_v2 parity 3005 600 MI_PHYLO_GRADIENT_WALK=v2 &
-run parity_v1 parity 3006 600 MI_PHYLO_GRADIENT_WALK=v1 &
 run parity_unfused parity 3007 400 MI_PHYLO_FUSED_SETUP=0 STRESS_FOCUS=fused &
 run parity_analytic parity 3008 400 MI_PHYLO_SUBST_GRADIENT=analytic &
 run rooted rooted 3009 800 &

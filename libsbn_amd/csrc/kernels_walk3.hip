@@ -1346,6 +1346,10 @@ void launch_gradient_walk_lut(const LikArgs& a_in, int count, bool rescale, hipS
     // schedule fits the usual number of LDS slots, then (more LDS per wave) the rest
     const int usual = gradient_arena_slots_usual(a.n), sure = gradient_arena_slots_sure(a.n);
     a.lds_lo = -1;
+    // (ONE launch with the larger footprint only when all waves are resident at once anyway -- a
+    // call of a few trees.  Round 6 tried it wherever the larger footprint costs no wave per CU,
+    // up to ~60 taxa, to save the second launch's 35-50 us of waves that exit at once: no gain --
+    // 59 x 1824: 4.51 against 4.34-4.40 ms, the others level)
     if (arena_single_launch(gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), grid.x)) {
       a.lds_slots = sure;
       launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), rescale, s);

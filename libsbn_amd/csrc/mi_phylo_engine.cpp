@@ -231,8 +231,12 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool arena = mfma && use_arena(e, d.rescaling, analytic, (size_t)T * (size_t)g_tiles);
   const bool walk2 = mfma;  // (every matrix-core call: the first generation was retired in round 6)
   // the third-generation (look-up) walk: stored vectors in LDS or, since round 6, in the arena
+  // (one rate category with the stored vectors in LDS stays with the second generation, whose
+  // waves take several tiles of a tree in a row: DS1 x 1000 with the constant site model 0.281
+  // against 0.297 ms, 29 taxa x 1195: 0.358 / 0.383; two and three categories: third generation
+  // 0.462 / 0.490 and 0.831 / 0.868; one category in the arena: 0.261 / 0.294 on fluA's shape)
   const bool walk3 = walk2 && walk3_possible(e) && !analytic && groups == 1 &&
-                     (!arena || e->walk3_arena);
+                     (arena ? e->walk3_arena : (e->K > 1 || e->walk3_k1_lds));
   constexpr int kMaxEvals = 32768;
   // The one-launch call (kernels_walk3.hip): tree set-up, model instances and operand records
   // ride in the walk's launch.  One evaluation and one model instance per tree (JC69-type
@@ -782,6 +786,8 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
     e->fused_spin_ticks = (int)std::min(2.0e9, std::max(0.01, atof(env)) * 1.0e5);
   // MI_PHYLO_WALK3_ARENA=0: arena-variant calls stay with the second / first generation (A/B)
   if (const char* env = getenv("MI_PHYLO_WALK3_ARENA")) e->walk3_arena = std::string(env) != "0";
+  // MI_PHYLO_WALK3_K1=1: one-category calls with the vectors in LDS take the third generation too (A/B)
+  if (const char* env = getenv("MI_PHYLO_WALK3_K1")) e->walk3_k1_lds = std::string(env) != "0";
   if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH")) {  // force one gradient kernel
     const std::string v(env);
     e->gradient_path = v == "hbm" ? 2 : v == "mfma" ? 3 : 0;

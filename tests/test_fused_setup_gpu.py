@@ -115,8 +115,18 @@ def _site_params(spec, T, site, rng):
 
 @pytest.mark.parametrize("site", ["constant", "weibull+2", "weibull+3", "weibull+4"])
 def test_small_and_rooted_trees(site):
-    """(round 6: one and two rate categories take the look-up walk, and with it the one-launch
-    call, as well)"""
+    """(round 6: two rate categories take the look-up walk, and with it the one-launch call, as
+    well; one category with the vectors in LDS stays with the second generation, whose waves take
+    several tiles in a row -- MI_PHYLO_WALK3_K1=1 sends it through the look-up walk too)"""
+    if site == "constant":
+        os.environ["MI_PHYLO_WALK3_K1"] = "1"
+    try:
+        _small_and_rooted(site)
+    finally:
+        os.environ.pop("MI_PHYLO_WALK3_K1", None)
+
+
+def _small_and_rooted(site):
     rng = np.random.default_rng(77)
     # 5 taxa x 7 patterns (one partial tile), 300 trees: more set-up waves than some CUs hold
     n, P, T = 5, 7, 300

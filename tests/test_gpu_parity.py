@@ -923,8 +923,8 @@ def test_walk_kernels_agree():
     with an arena variant and one- and two-category forms) -- do the same products in the same
     order: log-likelihoods and gradients BIT-IDENTICAL wherever both apply, over rate-category
     counts 1 / 2 / 3 / 4 / 8, with and without rescaling, finite-difference GTR, stored vectors
-    in LDS and in the arena, unrooted and rooted; the second generation's analytic-GTR form gives
-    the same bits with either store.  (The switches are read at engine creation / once per
+    in LDS and in the arena, unrooted and rooted; the second generation's analytic-GTR form agrees
+    between the two stores to the last bits.  (The switches are read at engine creation / once per
     process: each form runs in its own interpreter.)"""
     import subprocess
     import sys
@@ -1004,7 +1004,12 @@ np.save(sys.argv[1], np.concatenate(out))
     for subst_mode in ("", "analytic"):
         a, b = results[("v2", "", subst_mode)], results[("v2", "arena", subst_mode)]
         assert a.shape == b.shape and np.isfinite(a).all()
-        assert np.array_equal(a, b), (subst_mode, np.max(np.abs(a - b)))
+        if subst_mode:
+            # (the analytic form adds one 4 x 4 statistic per edge into a running sum in VISIT order,
+            # and the arena schedule visits the macros in Sethi-Ullman order: last-bit differences)
+            assert np.allclose(a, b, rtol=1e-11, atol=1e-12 * np.max(np.abs(b))), np.max(np.abs(a - b))
+        else:
+            assert np.array_equal(a, b), np.max(np.abs(a - b))
     # the third generation (where it applies: the engines of this list with at most four
     # categories; the others fall back to the second) looks tip products up instead of multiplying.
     # P e_s IS column s of P, and the all-ones vector's row sum is added in index order by the

@@ -41,7 +41,7 @@ stats ts_64x1008 python3 tools/bench_tree_size.py 64 1008
 stats ts_36x1812 python3 tools/bench_tree_size.py 36 1812
 stats ts_50x378 python3 tools/bench_tree_size.py 50 378
 python3 tools/bench_shapes_ab.py default 2>&1 | grep -v amdgpu.ids > $S/${tag}_tree_size.txt
-python3 tools/bench_shapes_ab.py --shapes 36x1812x4,41x1137x4,50x378x4,50x1133x4,59x1824x4,64x1008x4,100x500x4,69x238x1,45x1000x1,45x1000x2 default gen2=MI_PHYLO_WALK3_ARENA=0 v1=MI_PHYLO_GRADIENT_WALK=v1 lds=MI_PHYLO_GRADIENT_STORE=lds 2>&1 | grep -v amdgpu.ids > $S/${tag}_arena_ab.txt
+python3 tools/bench_shapes_ab.py --shapes 36x1812x4,41x1137x4,50x378x4,50x1133x4,59x1824x4,64x1008x4,100x500x4,69x238x1,45x1000x1,45x1000x2 default gen2=MI_PHYLO_GRADIENT_WALK=v2 lds=MI_PHYLO_GRADIENT_STORE=lds 2>&1 | grep -v amdgpu.ids > $S/${tag}_arena_ab.txt
 python3 tools/bench_small_step.py --rounds 2 default=MI_PHYLO_FUSED_FENCE=l1 none=MI_PHYLO_FUSED_FENCE=none none_id_order=MI_PHYLO_FUSED_FENCE=none,MI_PHYLO_FUSED_COLOCATE=0 agent=MI_PHYLO_FUSED_FENCE=agent four_launches=MI_PHYLO_FUSED_SETUP=0 2>&1 | grep -v amdgpu.ids > $S/${tag}_small_step_handoff.txt
 
 pmc pmc_fetch_gradient FETCH_SIZE python3 bench.py --steps 3 --warmup 1 --headline-only

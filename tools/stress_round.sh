@@ -21,6 +21,10 @@ run parity_b parity 3002 1500 &
 run parity_fused parity 3003 600 STRESS_FOCUS=fused &
 run parity_arena parity 3004 400 STRESS_FOCUS=arena &
 run parity_arena_v2 parity 3012 200 STRESS_FOCUS=arena MI_PHYLO_WALK3_ARENA=0 &
+# (a batch of 150 small-pattern trees often fits the chip at once and keeps its vectors in LDS:
+# the arena variants forced, so that every gradient call of the sweep takes them)
+run parity_arena_forced parity 3013 300 STRESS_FOCUS=arena MI_PHYLO_GRADIENT_STORE=arena &
+run rooted_arena_forced rooted 3014 300 MI_PHYLO_GRADIENT_STORE=arena &
 run parity_v2 parity 3005 600 MI_PHYLO_GRADIENT_WALK=v2 &
 run parity_unfused parity 3007 400 MI_PHYLO_FUSED_SETUP=0 STRESS_FOCUS=fused &
 run parity_analytic parity 3008 400 MI_PHYLO_SUBST_GRADIENT=analytic &

@@ -1501,7 +1501,10 @@ def main():
             d_bl = torch.from_numpy(bls_all[:Ts]).to(dev)
             d_par = torch.from_numpy(params_all[:Ts]).to(dev)
             blk = sharding.ResultBlocks(Ts, N, extra=1, device=dev)
-            eng.reserve(Ts, grad)
+            # every workspace the graphs below point at is reserved BEFORE the first capture: a
+            # later reserve that grew a buffer would leave a captured graph replaying freed
+            # device pointers (buffers only grow)
+            eng.reserve(max(Ts, T_total) if grad else Ts, grad)
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with torch.cuda.graph(graph, stream=gstream):
@@ -1552,7 +1555,6 @@ def main():
                 f_bl = torch.from_numpy(bls_all[:T_total]).to(dev)
                 f_par = torch.from_numpy(params_all[:T_total]).to(dev)
                 fblk = sharding.ResultBlocks(T_total, N, extra=1, device=dev)
-                eng.reserve(T_total, True)
                 fgraph = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
                 with torch.cuda.graph(fgraph, stream=gstream):
@@ -1576,9 +1578,6 @@ def main():
                 small["graph_full_batch_ms_per_step"] = float(np.median(fpasses))
                 small["graph_full_over_small"] = (small["graph_full_batch_ms_per_step"]
                                                   / small["graph_ms_per_step"])
-                # the reserve above may have re-allocated workspace the 125-tree graph points
-                # at: capture that one again before anything below replays it
-                eng.reserve(Ts, True)
         except Exception as exc:  # capture support varies; the eager figure stands
             small["graph_error"] = repr(exc)[:200]
         if grad and "graph_error" not in small:

@@ -304,7 +304,7 @@ def pipe_entry(kname, launch_trees=None):
 
 
 def unified_roofline(kname, k_ms, units, alg_flops_per_unit, exec_flops_per_unit, traffic=None,
-                     traffic_source=None, model_bytes_per_unit=None, pipe_trees=None):
+                     traffic_source=None, model_bytes_per_unit=None, pipe_trees=None, pipe=True):
     """ONE convention for every leg, 4-state and 20-state.  Per launch of the
     dominant kernel, `kernel_ms` from HIP events on the call's stream:
       frac_algorithmic  SURVEY 8(d) algorithmic flops x units / time / MEASURED FP64 matrix peak
@@ -321,7 +321,9 @@ def unified_roofline(kname, k_ms, units, alg_flops_per_unit, exec_flops_per_unit
     alg = alg_flops_per_unit * units / sec / 1e12
     exe = exec_flops_per_unit * units / sec / 1e12 if exec_flops_per_unit else None
     hbm_frac = traffic / sec / 1e9 / HBM_PEAK_GBPS if traffic else None
-    pipe = pipe_entry(kname, pipe_trees)
+    # (pipe=False: this leg runs another instantiation of the kernel than the one whose SQ
+    # counters are committed -- no figure rather than a borrowed one)
+    pipe = pipe_entry(kname, pipe_trees) if pipe else None
     out = {"kernel": kname, "kernel_ms": k_ms, "units_per_launch": units,
            "frac_algorithmic": alg / FP64_PEAK_TFLOPS,
            "frac_executed": exe / FP64_PEAK_TFLOPS if exe is not None else None,
@@ -350,14 +352,14 @@ def unified_roofline(kname, k_ms, units, alg_flops_per_unit, exec_flops_per_unit
 
 
 def roofline(kname, k_ms, units, flops_per_unit, bytes_per_unit, traffic=None,
-             traffic_source=None, shape=None, exec_flops_per_unit=None):
+             traffic_source=None, shape=None, exec_flops_per_unit=None, pipe=True):
     """A 4-state leg.  The walk kernels keep partial vectors in LDS: what binds them is the
     SIMD's FP64 pipe.  shape = (n, P, K): the executed matrix flops follow from the kernel that
     ran and the launch geometry (executed_flops_per_tree); whole-call legs pass their own sum."""
     if exec_flops_per_unit is None and shape is not None:
         exec_flops_per_unit = executed_flops_per_tree(kname, *shape)
     return unified_roofline(kname, k_ms, units, flops_per_unit, exec_flops_per_unit, traffic,
-                            traffic_source, bytes_per_unit)
+                            traffic_source, bytes_per_unit, pipe=pipe)
 
 
 def traffic_entry(name):
@@ -398,7 +400,7 @@ def streamed_roofline(kname, k_ms, evals, traffic_key, mfma_flops_per_eval, mode
         traffic *= traffic_scale
         src += f", x {traffic_scale:.4f} (this run's share of the profiled alignment)"
     return unified_roofline(kname, k_ms, evals, alg_flops_per_eval, mfma_flops_per_eval, traffic, src,
-                            model_bytes_per_eval, pipe_trees=evals if traffic_scale == 1.0 else None)
+                            model_bytes_per_eval, pipe_trees=evals, pipe=traffic_scale == 1.0)
 
 
 def rel_err(a, b):
@@ -746,7 +748,7 @@ def also_workloads(torch, dev, L, steps):
                     "trees_per_s": Tf / (ms * 1e-3), "ms_per_step": ms, "kernel": kname,
                     "kernel_ms": k_ms, "logL0": float(ll[0]),
                     "phase_ms": {"setup": phase_ms[0], "walk": phase_ms[2], "rest": phase_ms[3]},
-                    "roofline": roofline(kname, k_ms, Tf, ff_g, bf_g, shape=(n, P, 1)),
+                    "roofline": roofline(kname, k_ms, Tf, ff_g, bf_g, shape=(n, P, 1), pipe=False),
                     "parity_checked": S, "parity_max_rel_err": err})
         eng.close()
 

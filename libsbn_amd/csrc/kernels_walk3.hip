@@ -674,14 +674,49 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     }
   };
 
+  // Post-order (round 6): the message S = P_c L_c of child J is handed to its consumer `use`
+  // INSIDE the arm that knows where it lives -- a tip's S is the registers its gathers filled, an
+  // internal child's the matrix instruction's result -- and an unstored child's vector is formed
+  // at the four leaves of ONE decision tree on its grandchildren's tip flags.  Written as
+  // "compute S under the child's branches, then multiply" (as the pre-order walk's child_S still
+  // is), the compiler joined S into common registers behind the branches and every tip arm
+  // paid R 64-bit moves on the visit's dependent chain (found by a census of the kernel's
+  // instructions, profiles/r06_walk_isa_census.txt: 17 % of the visit code's vector
+  // instructions were moves): kernel 0.794 -> 0.774 ms per 1000 DS1 trees (-2.5 %), bit-identical
+  // (the same products in the same order).  The consumer's code is inlined into both arms of
+  // child 0 (child 1's code twice): 3 047 -> 3 411 static instructions, 214 registers as before.
+  auto post_child = [&](auto jtag, int sh, const Ops<false>& o, const Slots& sl, auto&& use) {
+    constexpr int J = decltype(jtag)::value;
+    using O0 = std::integral_constant<int, 0>;
+    using OA = std::integral_constant<int, 1>;
+    using OB = std::integral_constant<int, 4>;
+    const int kind = (sh >> (2 * J)) & 3;
+    if (kind == 0) {
+      use(tip_p(Post{}, o, O0{}));
+      return;
+    }
+    V L;
+    if (kind == 1) {
+      L = load_slot(sl.c[J]);
+    } else if (sh & (1 << (10 + 2 * J))) {
+      if (sh & (1 << (11 + 2 * J))) L = mul(tip_p(Post{}, o, OA{}), tip_p(Post{}, o, OB{}));
+      else L = mul(tip_p(Post{}, o, OA{}), mm(o.x[4], load_slot(sl.g[2 * J + 1])));
+    } else {
+      const V Ap = mm(o.x[1], load_slot(sl.g[2 * J]));
+      if (sh & (1 << (11 + 2 * J))) L = mul(Ap, tip_p(Post{}, o, OB{}));
+      else L = mul(Ap, mm(o.x[4], load_slot(sl.g[2 * J + 1])));
+    }
+    use(mm(o.x[0], L));
+  };
+
   // ================= post-order over the stored nodes, then the root (site likelihood) ====
   auto post_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<false>& o0, const Ops<false>& o1,
                         int tile_for_ll) {
     constexpr bool ROOT = decltype(root_tag)::value;
-    Child c0, c1;
-    child_S(Post{}, J0{}, sh, o0, sl, c0);
-    child_S(Post{}, J1{}, sh, o1, sl, c1);
-    V Lv = mul(c0.S, c1.S);
+    V Lv;
+    post_child(J0{}, sh, o0, sl, [&](const V& S0) {
+      post_child(J1{}, sh, o1, sl, [&](const V& S1) { Lv = mul(S0, S1); });
+    });
     if (!ROOT) {
       if (RESCALE) {
 #pragma unroll
@@ -864,9 +899,14 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       }
     }
     Child c0, c1;
+    V n0, n1;
+    // (two treatments of the pre-order walk in the same spirit were built and measured in round 6
+    // and not kept: every use of a child's S, Ap, Bp branching on the shape bit again and reading
+    // a tip's values in place -- +0.5 % alone, and it took back 1 % of the post-order form's
+    // gain: more branches than moves saved --; and q o S formed inside the arm that produced S,
+    // no new branch -- level, 0.7716 against 0.7743 ms.  profiles/r06_ab_post_cps.txt, r06_ab_pre_qs.txt)
     child_S(Pre{}, J0{}, sh, o0, sl, c0);
     child_S(Pre{}, J1{}, sh, o1, sl, c1);
-    V n0, n1;
     child_edges(J0{}, sh, o0, sl, c0, mul(qv, c1.S), m, n0);
     child_edges(J1{}, sh, o1, sl, c1, mul(qv, c0.S), m, n1);
     edge_sums(n0, n1, m, 0);

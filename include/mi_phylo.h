@@ -220,7 +220,17 @@ int32_t mi_engine_gradients_rooted(mi_engine* engine, int32_t tree_count,
  * the engine's device and nothing is synchronised: the work is enqueued on
  * `stream`.  Per-tree input errors (malformed parent ids, GTR sums off by
  * >= 1e-3, bad rate_count) set a device-side status word that
- * mi_engine_check_status() reads back (it synchronises the stream). */
+ * mi_engine_check_status() reads back (it synchronises the stream).
+ *
+ * A call never fails spuriously (the reference's Engine does not: src/engine.cpp:54-92).  A
+ * gradient call of up to 512 small trees runs tree set-up and walk as ONE launch whose walk
+ * waves wait -- bounded: one second of wall clock -- for their tree's set-up waves.  Should
+ * that wait ever run out, the HOST-pointer entry points above run the call again at once
+ * through the four-launch sequence and return those results (mi_engine_last_call_path then
+ * says "setup=own-launch", and the engine keeps four launches from then on); a caller of the
+ * *_device entry points finds the message at mi_engine_check_status and repeats the call --
+ * a hipGraph captured before that still holds the one-launch kernel and must be captured
+ * again.  (MI_PHYLO_FUSED_SETUP=0 selects four launches from the start.) */
 
 int32_t mi_engine_log_likelihoods_unrooted_device(mi_engine* engine, void* stream,
                                                   int32_t tree_count, const int32_t* parent_ids,

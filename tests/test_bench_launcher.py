@@ -112,3 +112,47 @@ def test_line_is_small():
     full["config"]["workload"] = "w" * 5000
     with pytest.raises(AssertionError, match="bytes"):
         bench.final_line(full)
+
+
+def test_one_roofline_convention_on_every_leg():
+    """4-state and 20-state legs carry the same roofline keys.  The executed
+    matrix-instruction counts follow from the tree size alone and are pinned to the SQ_INSTS_MFMA
+    figures of the committed counter tables (385 / 628 per tile job of a 27-taxon tree; the
+    log-likelihood kernel's 208 + its root reductions); `bound` names the larger of the HBM
+    fraction and the executed matrix fraction, `frac` is the contract's figure for it; a leg whose
+    kernel instantiation has no committed counters gets no borrowed `pipe_busy`."""
+    bench = _bench_module()
+    n, P, K = 27, 934, 4
+    per_tile = 512.0 * 78
+    assert bench.executed_flops_per_tree("gradient_walk_lut_kernel", n, P, K) == 385 * per_tile
+    assert bench.executed_flops_per_tree("gradient_walk_lut_fused_kernel", n, P, K) == 385 * per_tile
+    assert bench.executed_flops_per_tree("gradient_walk_kernel", n, P, K) == 628 * per_tile
+    assert bench.executed_flops_per_tree("loglik_mfma_kernel", n, P, K) == (208 + 5) * 512.0 * 59
+    assert bench.executed_flops_per_tree("gradient_hbm_kernel", n, P, K) is None
+    assert bench.executed_flops_per_tree("gradient_walk_kernel", n, P, 8) is None
+    keys = {"kernel", "kernel_ms", "units_per_launch", "bound", "achieved", "peak", "unit", "frac",
+            "frac_algorithmic", "frac_executed", "pipe_busy", "hbm_frac", "traffic", "peak_measured",
+            "peak_datasheet"}
+    f_ll, f_g = bench.algorithmic_flops(n, P, K)
+    b_ll, b_g = bench.algorithmic_bytes(n, P, K)
+    r4 = bench.roofline("gradient_walk_lut_kernel", 0.77, 1000, f_g, b_g, 153.7e6, "x", shape=(n, P, K))
+    assert keys <= set(r4) and r4["bound"] == "mfma" and r4["frac"] == r4["frac_algorithmic"]
+    assert abs(r4["frac_algorithmic"] - 0.511) < 0.002 and abs(r4["frac_executed"] - 0.281) < 0.002
+    assert 0.0 < r4["hbm_frac"] < 0.05 and r4["traffic_source"].startswith("static: ")
+    assert r4["pipe_busy"] is None or 0.3 < r4["pipe_busy"] < 1.0
+    none = bench.roofline("gradient_walk_lut_kernel", 0.26, 1000, 1e6, 1e6, shape=(69, 238, 1), pipe=False)
+    assert none["pipe_busy"] is None and none["hbm_frac"] is None and keys - {"traffic"} <= set(none) | {"traffic"}
+    # a streamed (20-state) leg: the same keys; HBM binds when its fraction exceeds the executed one
+    f_ll20, f_g20 = bench.algorithmic_flops(512, 50000, 4, s=20)
+    pre = bench.streamed_roofline("aa_pre_wg_kernel<2>", 42.1, 8, "aa_pre_wg_kernel<2>",
+                                  1.0e11, 1.0e10, f_g20 - f_ll20)
+    assert keys <= set(pre)
+    if pre["traffic"]:
+        assert pre["bound"] in ("hbm", "mfma")
+        assert pre["frac"] == (pre["hbm_frac"] if pre["bound"] == "hbm" else pre["frac_algorithmic"])
+    shard = bench.streamed_roofline("aa_post_wg_kernel<2,false> (+ aa_root_kernel)", 0.5, 1,
+                                    "aa_post_wg_kernel<2, false>", 1.0e10, 1.0e9, f_ll20 / 8,
+                                    traffic_scale=0.125)
+    assert shard["pipe_busy"] is None  # (another instantiation than the profiled one)
+    if shard["traffic"]:
+        assert "share of the profiled alignment" in shard["traffic_source"]

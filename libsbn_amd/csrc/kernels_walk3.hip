@@ -194,10 +194,16 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   // of the chain node id -> tip bytes -> LDS, the longest latency of a wave's life
   const int* mwv = reinterpret_cast<const int*>(macros);
   const int jmax = Mmax * 6;
-  int node_j[2] = {-1, -1};
+  // (pairs per lane whose node id and tip bytes are requested up front: two cover 42 taxa; the
+  // arena variant -- larger trees -- takes four, 86 taxa: round 6, until then a lane's third
+  // pair went through two more dependent round trips and byte-by-byte copies; +0.2-0.5 % on
+  // the 50-64-taxon shapes)
+  constexpr int U = ARENA ? 4 : 2;
+  int node_j[U];
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
+  for (int u = 0; u < U; u++) {
     const int j = lane + 64 * u;
+    node_j[u] = -1;
     if (j < jmax) node_j[u] = mwv[(j / 6) * 16 + 1 + (j % 6)];
   }
   const int M = FUSED ? M_ready : __builtin_amdgcn_readfirstlane(a.macro_count[t]);
@@ -217,10 +223,10 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   static_assert(TP % 4 == 0, "whole words of tip codes per tile");
   const int tile_start = tile * TP;
   const bool whole = tile_start + TP <= a.P;
-  BytesTP bytes_now[2] = {};
+  BytesTP bytes_now[U] = {};
   if (whole && !COMPACT) {
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
       const int j = lane + 64 * u, node = node_j[u];
       if (j < jmax && (unsigned)node < (unsigned)n)
         bytes_now[u] = *reinterpret_cast<const BytesTP*>(a.tip_codes + (size_t)node * a.P + tile_start);
@@ -507,33 +513,39 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
         }
       }
     };
+    // the packed form: a pair's TP bytes as whole words, regrouped into the four columns' words
+    auto stage_packed = [&](int j, const BytesTP& w) {
+      const int m = j / 6, pos = j - m * 6;
+      char* dst = lds0 + (unsigned)m * kTStride + (unsigned)pos * 4u;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        uint32_t word = 0;  // byte r: the code of column c in register r
+#pragma unroll
+        for (int r = 0; r < R; r++) word |= ((w.d[r] >> (8 * c)) & 0xffu) << (8 * r);
+        *reinterpret_cast<uint32_t*>(dst + c * kTwCol) = word;
+      }
+    };
     if (whole && !COMPACT) {
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < U; u++) {
         const int j = lane + 64 * u, node = node_j[u];
-        if (j < jmax && (unsigned)node < (unsigned)n) {
-          const BytesTP w = bytes_now[u];
-          const int m = j / 6, pos = j - m * 6;
-          char* dst = lds0 + (unsigned)m * kTStride + (unsigned)pos * 4u;
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            uint32_t word = 0;  // byte r: the code of column c in register r
-#pragma unroll
-            for (int r = 0; r < R; r++) word |= ((w.d[r] >> (8 * c)) & 0xffu) << (8 * r);
-            *reinterpret_cast<uint32_t*>(dst + c * kTwCol) = word;
-          }
-        }
+        if (j < jmax && (unsigned)node < (unsigned)n) stage_packed(j, bytes_now[u]);
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < U; u++) {
         const int j = lane + 64 * u, node = node_j[u];
         if (j < jmax && (unsigned)node < (unsigned)n) stage_bytes(j, node);
       }
     }
-    for (int j = lane + 128; j < jmax; j += kTile) {  // larger trees: the rest
+    for (int j = lane + 64 * U; j < jmax; j += kTile) {  // larger trees: the rest
       const int node = mwv[(j / 6) * 16 + 1 + (j % 6)];
-      if ((unsigned)node < (unsigned)n) stage_bytes(j, node);
+      if ((unsigned)node < (unsigned)n) {
+        if (whole && !COMPACT)
+          stage_packed(j, *reinterpret_cast<const BytesTP*>(a.tip_codes + (size_t)node * a.P + tile_start));
+        else
+          stage_bytes(j, node);
+      }
     }
   }
   __syncthreads();

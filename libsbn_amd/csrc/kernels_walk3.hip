@@ -26,10 +26,14 @@
 // sum is added in index order by the table builder as by the instruction): results are
 // BIT-IDENTICAL to the second generation's (tests/test_gpu_parity.py::test_walk_kernels_agree).
 //
-// Scope: engines whose tip vectors are the five of SitePattern (one-hot / all ones:
-// src/site_pattern.cpp:117-131 -- everything the reference produces), three or four rate
-// categories (one category group), stored vectors in LDS, no analytic substitution gradient;
-// everything else keeps the second generation.
+// Scope (round 6: widened from "three or four categories, stored vectors in LDS"): engines
+// whose tip vectors are the five of SitePattern (one-hot / all ones: src/site_pattern.cpp:117-131
+// -- everything the reference produces), one to four rate categories (one category group; KP =
+// categories per matrix instruction), stored vectors in LDS or -- batches of trees of 36 taxa and
+// more -- in a per-wave HBM arena (ARENA), no analytic substitution gradient.  The second
+// generation keeps: more than four categories, the analytic gradient, 0/1 tip vectors that are
+// not one-hot, and one-category engines whose vectors fit LDS (its waves take several tiles in a
+// row there).  The first generation (gradient_mfma_kernel) was retired in round 6.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1366,7 +1366,9 @@ template <bool RESCALE, bool ARENA, int KP>
 static void launch_lut_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   // (non-temporal arena accesses up to 48 pattern tiles per tree: walk_lut_body;
   // MI_PHYLO_ARENA_NT=0|1 forces plain / non-temporal)
-  static const int forced = getenv("MI_PHYLO_ARENA_NT") ? atoi(getenv("MI_PHYLO_ARENA_NT")) : -1;
+  // (read per launch: tests switch it between calls of one process)
+  const char* nt_env = getenv("MI_PHYLO_ARENA_NT");
+  const int forced = nt_env ? atoi(nt_env) : -1;
   if (ARENA && (forced < 0 ? a.g_tiles <= 48 : forced != 0)) {
     allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_kernel<RESCALE, ARENA, KP, ARENA>), lds);
     hipLaunchKernelGGL((gradient_walk_lut_kernel<RESCALE, ARENA, KP, ARENA>), grid, dim3(kTile), lds, s, a);

@@ -294,3 +294,53 @@ def test_a_time_out_does_not_reach_a_host_pointer_caller(monkeypatch):
     assert np.array_equal(o_ll.cpu().numpy(), ref[:T])
     for e in (plain, broken, other, third):
         e.close()
+
+
+def test_hand_off_modes_and_arena_access_forms_are_bit_identical(monkeypatch):
+    """The one-launch call's three hand-off modes (MI_PHYLO_FUSED_FENCE=none|l1|agent: DESIGN.md
+    4.7), its set-up waves placed on their tree's XCD or in id order, and the arena variant's
+    plain / non-temporal accesses (MI_PHYLO_ARENA_NT) change how data travels, never what is
+    computed: every form gives the bits of the four-launch sequence / of the other form."""
+    import libsbn_amd as L
+    T = 125
+    tips, w, pids, bls, rng = _ds1(T, seed=31)
+    spec = O.make_spec(27, tips.shape[1], "JC69", "weibull+4", "strict")
+    pr = _params(spec, T, **{"Weibull shape": rng.uniform(0.3, 2.0, size=(T, 1))})
+    _, plain = _engines("JC69", "weibull+4", tips, w)
+    ref = _flat(plain.gradients(pids, bls, pr))
+    plain.close()
+    monkeypatch.setenv("MI_PHYLO_FUSED_SETUP", "1")
+    for fence in ("none", "l1", "agent"):
+        for colocate in ("1", "0"):
+            monkeypatch.setenv("MI_PHYLO_FUSED_FENCE", fence)
+            monkeypatch.setenv("MI_PHYLO_FUSED_COLOCATE", colocate)
+            eng = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w)
+            for _ in range(3):
+                got = _flat(eng.gradients(pids, bls, pr))
+                assert eng.last_call_info()[0] == FUSED
+                assert np.array_equal(got, ref), (fence, colocate)
+            eng.close()
+    monkeypatch.delenv("MI_PHYLO_FUSED_FENCE")
+    monkeypatch.delenv("MI_PHYLO_FUSED_COLOCATE")
+    # the arena variant, plain and non-temporal accesses (the launcher chooses by tiles per tree)
+    rng = np.random.default_rng(64)
+    n, P, T = 50, 60, 300
+    tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.05)
+    pids, bls = TU.random_trees(n, T, rng, mean_bl=0.06)
+    spec = O.make_spec(n, P, "JC69", "weibull+4", "strict")
+    pr = _params(spec, T, **{"Weibull shape": rng.uniform(0.4, 1.5, size=(T, 1))})
+    monkeypatch.setenv("MI_PHYLO_GRADIENT_STORE", "arena")
+    eng = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w)
+    got = {}
+    for nt in ("0", "1"):
+        monkeypatch.setenv("MI_PHYLO_ARENA_NT", nt)  # (read by the launcher at every launch)
+        got[nt] = _flat(eng.gradients(pids, bls, pr))
+        assert "store=arena" in eng.last_call_path()
+    monkeypatch.delenv("MI_PHYLO_ARENA_NT")
+    eng.close()
+    monkeypatch.setenv("MI_PHYLO_GRADIENT_STORE", "lds")
+    eng = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w)
+    lds = _flat(eng.gradients(pids, bls, pr))
+    assert "store=lds" in eng.last_call_path()
+    eng.close()
+    assert np.array_equal(got["0"], lds) and np.array_equal(got["1"], lds)

@@ -1071,11 +1071,16 @@ int32_t mi_engine_reserve(mi_engine* e, int32_t tree_count, int32_t for_gradient
 int32_t mi_engine_check_status(mi_engine* e, void* stream) {
   if (!e) return fail("null engine");
   if (!e->shards.empty()) {
-    for (mi_engine* shard : e->shards)
-      if (check_status(shard, shard->stream)) return 1;
+    for (mi_engine* shard : e->shards) {
+      const int rc = check_status(shard, shard->stream);
+      shard->fused_timed_out = false;  // (reported to the caller: not a host-pointer call's to repeat)
+      if (rc) return 1;
+    }
     return 0;
   }
-  return check_status(e, pick_stream(e, stream));
+  const int rc = check_status(e, pick_stream(e, stream));
+  e->fused_timed_out = false;  // (a device-pointer caller repeats the call itself)
+  return rc;
 }
 
 static int32_t profile_begin(mi_engine* e, int32_t max_calls, bool phases) {
@@ -1538,6 +1543,7 @@ int begin_host_call(mi_engine* e, const HostCall& h) {
   if (!h.parent_ids || !h.bl) return fail("null tree arrays");
   if (e->param_count > 0 && !h.params) return fail("null parameter matrix");
   HIP_TRY(hipSetDevice(e->spec.device));
+  e->fused_timed_out = false;  // (what an earlier device-pointer call left unread is not this call's)
   e->pinned.reset();  // nothing of an earlier (possibly failed) call is delivered late
   // The status word is sticky (the *_device calls never clear it).  A host-pointer call
   // reports ITS OWN errors only: whatever an earlier device-pointer call left unread on this

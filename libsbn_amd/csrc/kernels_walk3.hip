@@ -1363,13 +1363,14 @@ void launch_transition_lut(const TransitionMacroArgs& a, hipStream_t s) {
 bool gradient_walk_lut_applies(int K) { return K >= 1 && K <= 4 && R >= 2; }
 
 template <bool RESCALE, bool ARENA, int KP>
-static void launch_lut_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  // (non-temporal arena accesses up to 48 pattern tiles per tree: walk_lut_body;
-  // MI_PHYLO_ARENA_NT=0|1 forces plain / non-temporal)
+static void launch_lut_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s, bool resident) {
+  // (non-temporal arena accesses up to 48 pattern tiles per tree, and for a call whose waves are
+  // all resident at once -- 64 taxa x 1000 x 4 categories, 16 trees: 0.0990 against 0.1025 ms,
+  // tools/audit_paths.py: walk_lut_body; MI_PHYLO_ARENA_NT=0|1 forces plain / non-temporal)
   // (read per launch: tests switch it between calls of one process)
   const char* nt_env = getenv("MI_PHYLO_ARENA_NT");
   const int forced = nt_env ? atoi(nt_env) : -1;
-  if (ARENA && (forced < 0 ? a.g_tiles <= 48 : forced != 0)) {
+  if (ARENA && (forced < 0 ? (a.g_tiles <= 48 || resident) : forced != 0)) {
     allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_kernel<RESCALE, ARENA, KP, ARENA>), lds);
     hipLaunchKernelGGL((gradient_walk_lut_kernel<RESCALE, ARENA, KP, ARENA>), grid, dim3(kTile), lds, s, a);
     return;
@@ -1378,14 +1379,15 @@ static void launch_lut_variant(const LikArgs& a, dim3 grid, size_t lds, hipStrea
   hipLaunchKernelGGL((gradient_walk_lut_kernel<RESCALE, ARENA, KP>), grid, dim3(kTile), lds, s, a);
 }
 template <bool ARENA>
-static void launch_lut_store(const LikArgs& a, dim3 grid, size_t lds, bool rescale, hipStream_t s) {
+static void launch_lut_store(const LikArgs& a, dim3 grid, size_t lds, bool rescale, hipStream_t s,
+                             bool resident = false) {
   switch ((rescale ? 8 : 0) | a.kp) {
-    case 1: launch_lut_variant<false, ARENA, 1>(a, grid, lds, s); break;
-    case 2: launch_lut_variant<false, ARENA, 2>(a, grid, lds, s); break;
-    case 4: launch_lut_variant<false, ARENA, 4>(a, grid, lds, s); break;
-    case 9: launch_lut_variant<true, ARENA, 1>(a, grid, lds, s); break;
-    case 10: launch_lut_variant<true, ARENA, 2>(a, grid, lds, s); break;
-    default: launch_lut_variant<true, ARENA, 4>(a, grid, lds, s); break;
+    case 1: launch_lut_variant<false, ARENA, 1>(a, grid, lds, s, resident); break;
+    case 2: launch_lut_variant<false, ARENA, 2>(a, grid, lds, s, resident); break;
+    case 4: launch_lut_variant<false, ARENA, 4>(a, grid, lds, s, resident); break;
+    case 9: launch_lut_variant<true, ARENA, 1>(a, grid, lds, s, resident); break;
+    case 10: launch_lut_variant<true, ARENA, 2>(a, grid, lds, s, resident); break;
+    default: launch_lut_variant<true, ARENA, 4>(a, grid, lds, s, resident); break;
   }
 }
 
@@ -1410,15 +1412,16 @@ void launch_gradient_walk_lut(const LikArgs& a_in, int count, bool rescale, hipS
     // 59 x 1824: 4.51 against 4.34-4.40 ms, the others level)
     if (arena_single_launch(gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), grid.x)) {
       a.lds_slots = sure;
-      launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), rescale, s);
+      launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), rescale, s, true);
       return;
     }
     a.lds_slots = usual;
-    launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, usual), rescale, s);
+    const bool resident = arena_single_launch(gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, usual), grid.x);
+    launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, usual), rescale, s, resident);
     if (sure > usual) {
       a.lds_lo = usual;
       a.lds_slots = sure;
-      launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), rescale, s);
+      launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), rescale, s, resident);
     }
     return;
   }

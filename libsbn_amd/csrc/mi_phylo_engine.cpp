@@ -231,12 +231,6 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool arena = mfma && use_arena(e, d.rescaling, analytic, (size_t)T * (size_t)g_tiles);
   const bool walk2 = mfma;  // (every matrix-core call: the first generation was retired in round 6)
   // the third-generation (look-up) walk: stored vectors in LDS or, since round 6, in the arena
-  // (one rate category with the stored vectors in LDS stays with the second generation, whose
-  // waves take several tiles of a tree in a row: DS1 x 1000 with the constant site model 0.281
-  // against 0.297 ms, 29 taxa x 1195: 0.358 / 0.383; two and three categories: third generation
-  // 0.462 / 0.490 and 0.831 / 0.868; one category in the arena: 0.261 / 0.294 on fluA's shape)
-  const bool walk3 = walk2 && walk3_possible(e) && !analytic && groups == 1 &&
-                     (arena ? e->walk3_arena : (e->K > 1 || e->walk3_k1_lds));
   constexpr int kMaxEvals = 32768;
   // The one-launch call (kernels_walk3.hip): tree set-up, model instances and operand records
   // ride in the walk's launch.  One evaluation and one model instance per tree (JC69-type
@@ -251,9 +245,20 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // moves the cross-over (testing).
   static const int fuse_max_trees =
       getenv("MI_PHYLO_FUSED_MAX_TREES") ? atoi(getenv("MI_PHYLO_FUSED_MAX_TREES")) : 512;
-  const bool fuse_setup = walk3 && !arena && e->fused_setup && fuse_allowed && c.E == T && c.models_per_tree == 1 &&
-                          !ts.need_slots && T <= fuse_max_trees && e->ready.ptr &&
-                          gradient_walk_lut_fused_applies(n, e->K);
+  const bool fuse_possible = mfma && walk3_possible(e) && !analytic && groups == 1 && !arena && e->fused_setup &&
+                             fuse_allowed && c.E == T && c.models_per_tree == 1 && !ts.need_slots &&
+                             T <= fuse_max_trees && e->ready.ptr && gradient_walk_lut_fused_applies(n, e->K);
+  // One rate category with the stored vectors in LDS: the second generation, whose waves take
+  // several tiles of a tree in a row, is 5-7 % ahead on a large batch (DS1 x 1000 with the
+  // constant site model 0.281 against 0.297 ms, 29 taxa x 1195: 0.358 / 0.383) -- but the
+  // look-up walk has the one-launch call: 0.0336 against 0.0390 ms at 32 trees, 0.0617 / 0.0671
+  // at 125, 0.0905 / 0.0965 at 250, level at 500 (profiles/r06_k1_small_batches.txt).  So one
+  // category in LDS takes the look-up walk exactly where the one-launch call applies.  (Two and
+  // three categories: look-up walk 0.462 / 0.490 and 0.831 / 0.868 ms per 1000 DS1 trees; one
+  // category in the arena 0.261 / 0.294 on fluA's shape.)
+  const bool walk3 = walk2 && walk3_possible(e) && !analytic && groups == 1 &&
+                     (arena ? e->walk3_arena : (e->K > 1 || e->walk3_k1_lds || fuse_possible));
+  const bool fuse_setup = walk3 && fuse_possible;
   if (!fuse_setup) launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
   if (arena)
     launch_macro_slots(e->macros.as<MacroEntry>(), e->arena_macros.as<MacroEntry>(),

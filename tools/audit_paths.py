@@ -14,7 +14,8 @@ dev = torch.device("cuda", 0)
 rng = np.random.default_rng(11)
 
 def time_cfg(n, P, K, T, env):
-    for k in ("MI_PHYLO_GRADIENT_WALK", "MI_PHYLO_GRADIENT_STORE", "MI_PHYLO_LOGLIK_PATH"):
+    for k in ("MI_PHYLO_GRADIENT_WALK", "MI_PHYLO_GRADIENT_STORE", "MI_PHYLO_LOGLIK_PATH", "MI_PHYLO_WALK3_K1",
+              "MI_PHYLO_ARENA_NT"):
         os.environ.pop(k, None)
     os.environ.update(env)
     site = "constant" if K == 1 else f"weibull+{K}"
@@ -70,6 +71,12 @@ for n, P, K, T in grid:
     else:
         variants = [(f"{walk}/{store}", {"MI_PHYLO_GRADIENT_WALK": walk, "MI_PHYLO_GRADIENT_STORE": store})
                     for walk, store in itertools.product(("v2", "v3"), ("lds", "arena"))]
+        # (round 6: one category in LDS keeps the second generation unless told otherwise; the
+        # arena's non-temporal accesses are chosen by tiles per tree)
+        if K == 1:
+            variants.append(("v3k1/lds", {"MI_PHYLO_GRADIENT_WALK": "v3", "MI_PHYLO_GRADIENT_STORE": "lds", "MI_PHYLO_WALK3_K1": "1"}))
+        variants += [("v3/arena/nt%s" % nt, {"MI_PHYLO_GRADIENT_WALK": "v3", "MI_PHYLO_GRADIENT_STORE": "arena", "MI_PHYLO_ARENA_NT": nt})
+                     for nt in ("0", "1")]
     for vname, env in variants:
         ms, path = time_cfg(n, P, K, T, env)
         if ms is not None and ms < best:

@@ -179,9 +179,29 @@ int gradient_mfma_width(int n, bool subst) {
   return max_macros(n) * kMacroPositions * 2 + (subst ? kSubstExtra : 0);
 }
 int gradient_mfma_groups(int K) { return K <= 4 ? 1 : (K + 3) / 4; }
-int gradient_mfma_tiles(int P, int K) {
-  const int per_wave = kLlR * (16 / (K == 1 ? 1 : (K == 2 ? 2 : 4)));
+int gradient_mfma_tiles(int P, int K, int regs) {
+  const int per_wave = (regs > 0 ? regs : kLlR) * (16 / (K == 1 ? 1 : (K == 2 ? 2 : 4)));
   return (P + per_wave - 1) / per_wave;
+}
+// Tile width of the look-up walk for an engine whose batches take the arena: four registers per
+// vector where that leaves enough fewer tiles, else the default.  A wide tile costs 1.14-1.25
+// default tiles of two to four categories (a visit's fixed costs are spread over a third more
+// columns) and 1.2-1.45 of one category -- 29 shapes both ways, profiles/r06_wide_tiles.txt: 36
+// taxa x 1812 patterns x 4 categories 151 -> 114 tiles, 2.72 -> 2.34 ms per 1000 trees; fluA's
+// 69 x 238 x 1, five tiles filled to 99 % against four filled to 93 %, 0.255 -> 0.293.  Wide
+// where the tile count falls by more than a fifth.  The width is the ENGINE's (all its look-up
+// calls take it, and with it the arena): sums over patterns are formed tile by tile, and a
+// tree's outputs must not depend on the size of the batch it came in.
+// MI_PHYLO_WALK_TILE_REGS=3|4 forces a width (read at engine creation).
+int gradient_walk_tile_regs(int P, int K) {
+  if (kLlR >= 4) return kLlR;
+  if (const char* env = getenv("MI_PHYLO_WALK_TILE_REGS")) {
+    const int r = atoi(env);
+    if (r == 4 || r == kLlR) return r;
+  }
+  const int t3 = gradient_mfma_tiles(P, K, kLlR), t4 = gradient_mfma_tiles(P, K, 4);
+  const bool wide = 5 * t4 < 4 * t3;
+  return wide ? 4 : kLlR;
 }
 // ---- arena variant: LDS slots of the two launches ----
 // Live vectors of the macro walk: each is either live in the node-level Sethi-Ullman walk
@@ -197,8 +217,9 @@ static int floor_log2(int n) {
 int gradient_arena_slots_sure(int n) { return std::max(1, std::min(max_stored(n), 2 * floor_log2(n))); }
 int gradient_arena_slots_usual(int n) { return std::min(gradient_arena_slots_sure(n), floor_log2(n) + 2); }
 size_t gradient_arena_bytes_per_eval(int n, int P, int K) {
-  return (size_t)gradient_mfma_tiles(P, K) * gradient_mfma_groups(K) * max_stored(n) * kLlR * kTile *
-         sizeof(double);
+  // (the larger of the two tile widths: the choice is made per call)
+  const size_t cols = std::max((size_t)gradient_mfma_tiles(P, K) * kLlR, (size_t)gradient_mfma_tiles(P, K, 4) * 4);
+  return cols * gradient_mfma_groups(K) * max_stored(n) * kTile * sizeof(double);
 }
 // One thread per tree: the macro schedule re-ordered and given reusable LDS slots.
 // tree_setup lists the macros by node id -- a post-order, but one that can keep many

@@ -9,6 +9,14 @@
 #include "mi_phylo_device_utils.h"
 #include "mi_phylo_kernels.h"
 
+// (timing builds of the matrix-core kernel: see its visit)
+#ifndef LL_ABL_TIPS
+#define LL_ABL_TIPS 0
+#endif
+#ifndef LL_WAVES
+#define LL_WAVES 5
+#endif
+
 namespace miphylo {
 
 namespace {
@@ -186,7 +194,7 @@ template <int R, bool RESCALE, bool MULTI>
 // (kTile, 5): LDS allows ~20 waves per CU for typical trees; and with at most 256 registers per lane the compiler keeps the products in
 // ordinary vector registers; without the bound it places them in accumulation registers
 // and spends two v_accvgpr_read per product to get them back
-__global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
+__global__ __launch_bounds__(kTile, LL_WAVES) void loglik_mfma_kernel(LikArgs a) {
   static_assert(R <= 8, "tip masks of one column group are packed in one 32- or 64-bit word");
   using TipWord = std::conditional_t<(R > 4), uint64_t, uint32_t>;
   constexpr unsigned TB = sizeof(TipWord);  // bytes of tip masks per (taxon, column)
@@ -257,6 +265,13 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
     }
     sched_l[i] = v;
   }
+#if LL_ABL_TIPS == 5
+  // (timing build 5: the tip bytes arrive as one 8-byte copy per lane -- what a pre-tiled
+  // array would cost; contents are garbage)
+  for (int q = lane; q < (n * ppr * (int)TB + 7) / 8; q += kTile)
+    reinterpret_cast<uint64_t*>(tips)[q] = reinterpret_cast<const uint64_t*>(a.tip_masks)[(size_t)te.tile * 64 + q];
+  if (false)
+#endif
   {
     const int tp_shift = TP <= 16 ? 4 : (TP <= 32 ? 5 : 6);
     const int group = 64 >> tp_shift;
@@ -280,11 +295,53 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
   // registers, the two tip words, and the entry itself.  Child ids stay vector
   // registers (multiplicands of per-lane addresses); the `slots` word, which also
   // carries the two is-a-tip flags, is the only scalar.
+#if LL_ABL_TIPS == 3
+  // TIMING build 3: a tip child's products are gathered from its matrix block when the visit
+  // is requested (kAhead visits early), in place of the matrix register; no tip bits, no
+  // matrix instruction (the state index is made up from the mask byte: wrong results)
+  constexpr int kAhead = 3;
+  struct Ahead {
+    double G0[R], G1[R];  // tip child: its products; internal child: [0] = the matrix register
+    int slots;
+  };
+  const unsigned lane8 = 8u * lane, col4 = TB * col;
+  const unsigned row_off = 8u * ((lane >> 2 & 3) * 16 + hi * 4);
+  auto request = [&](int i) {
+    const SchedEntry sv = sched_l[i < n - 1 ? i : n - 2];
+    int c0 = sv.child0, c1 = sv.child1;
+    asm volatile("" : "+v"(c0), "+v"(c1));
+    const int slots = __builtin_amdgcn_readfirstlane(sv.slots);
+    Ahead h;
+    h.slots = slots;
+    if (slots & (1 << 24)) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(tips + (__umul24((unsigned)c0, (unsigned)ppr * TB) + col4));
+      const unsigned g = __umul24((unsigned)c0, node_bytes) + row_off;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        h.G0[r] = *reinterpret_cast<const double*>(mats_e + (g + ((w >> (8 * r)) & 3u) * 8u));
+    } else {
+      h.G0[0] = *reinterpret_cast<const double*>(mats_e + (__umul24((unsigned)c0, node_bytes) + a_off));
+    }
+    if (slots & (1 << 25)) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(tips + (__umul24((unsigned)c1, (unsigned)ppr * TB) + col4));
+      const unsigned g = __umul24((unsigned)c1, node_bytes) + row_off;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        h.G1[r] = *reinterpret_cast<const double*>(mats_e + (g + ((w >> (8 * r)) & 3u) * 8u));
+    } else {
+      h.G1[0] = *reinterpret_cast<const double*>(mats_e + (__umul24((unsigned)c1, node_bytes) + a_off));
+    }
+    return h;
+  };
+#else
   constexpr int kAhead = 4;
   struct Ahead {
     double A0, A1;
     TipWord w0, w1;
     int slots;
+#if LL_ABL_TIPS == 2
+    unsigned g0, g1;  // (timing build: byte offsets of the children's matrix blocks)
+#endif
   };
   const unsigned lane8 = 8u * lane, col4 = TB * col;
   auto request = [&](int i) {
@@ -297,8 +354,13 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
     h.w0 = *reinterpret_cast<const TipWord*>(tips + (__umul24((unsigned)c0, (unsigned)ppr * TB) + col4));
     h.w1 = *reinterpret_cast<const TipWord*>(tips + (__umul24((unsigned)c1, (unsigned)ppr * TB) + col4));
     h.slots = sv.slots;
+#if LL_ABL_TIPS == 2
+    h.g0 = __umul24((unsigned)c0, node_bytes) + 8u * ((lane >> 2 & 3) * 16 + hi * 4);
+    h.g1 = __umul24((unsigned)c1, node_bytes) + 8u * ((lane >> 2 & 3) * 16 + hi * 4);
+#endif
     return h;
   };
+#endif
   auto slot_ptr = [&](int slot) {
     return reinterpret_cast<double*>(reinterpret_cast<char*>(plv) +
                                      ((unsigned)slot * (unsigned)(R * kTile * 8) + lane8));
@@ -314,6 +376,103 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
     const uint32_t half = r < 4 ? (uint32_t)w : (uint32_t)((uint64_t)w >> 32);
     return (double)__builtin_amdgcn_ubfe(half, (uint32_t)(8 * (r & 3) + hi), 1u);
   };
+#if LL_ABL_TIPS == 3
+  auto visit = [&](int i, Ahead& h) {
+    const int slots = h.slots;
+    double D0[R];
+    if (slots & (1 << 24)) {
+#pragma unroll
+      for (int r = 0; r < R; r++) D0[r] = h.G0[r];
+    } else {
+      const double* src = slot_ptr((slots >> 8) & 0xff);
+      const double A0 = h.G0[0];
+#pragma unroll
+      for (int r = 0; r < R; r++) D0[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, src[r * kTile], 0.0, 0, 0, 0);
+    }
+    if ((slots & (1 << 25)) && !(slots & kFromPrev)) {
+#pragma unroll
+      for (int r = 0; r < R; r++) L[r] = h.G1[r];
+    } else {
+      if (!(slots & kFromPrev)) {
+        const double* src = slot_ptr((slots >> 16) & 0xff);
+#pragma unroll
+        for (int r = 0; r < R; r++) L[r] = src[r * kTile];
+      }
+      const double A1 = h.G1[0];
+#pragma unroll
+      for (int r = 0; r < R; r++) L[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, L[r], 0.0, 0, 0, 0);
+    }
+    h = request(i + kAhead);
+#pragma unroll
+    for (int r = 0; r < R; r++) L[r] = D0[r] * L[r];
+    if (slots & kStore) {
+      double* dst = slot_ptr(slots & 0xff);
+#pragma unroll
+      for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
+    }
+  };
+#elif LL_ABL_TIPS && LL_ABL_TIPS != 5
+  // TIMING builds only (wrong results): what a tip child costs.  1: its product is a constant
+  // (no matrix instruction, no tip bits); 2: its product is gathered from the node's matrix
+  // block at the moment of use (the look-up's memory pattern, latency exposed).
+  auto visit = [&](int i, Ahead& h) {
+    const int slots = __builtin_amdgcn_readfirstlane(h.slots);
+    double D0[R];
+    const double A0 = h.A0, A1 = h.A1;
+    if (slots & (1 << 24)) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+#if LL_ABL_TIPS == 1
+        D0[r] = 0.25;
+#elif LL_ABL_TIPS == 4
+        {  // (timing build 4: the product permuted out of the matrix register across lanes)
+          const int at = (int)(4u * lane + (((uint32_t)h.w0 >> (8 * r)) & 0xffu));
+          D0[r] = __hiloint2double(__builtin_amdgcn_ds_bpermute(at, __double2hiint(A0)),
+                                   __builtin_amdgcn_ds_bpermute(at, __double2loint(A0)));
+        }
+#else
+        D0[r] = *reinterpret_cast<const double*>(mats_e + (h.g0 + (((uint32_t)h.w0 >> (8 * r)) & 3u) * 8u));
+#endif
+      }
+    } else {
+      const double* src = slot_ptr((slots >> 8) & 0xff);
+#pragma unroll
+      for (int r = 0; r < R; r++) D0[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, src[r * kTile], 0.0, 0, 0, 0);
+    }
+    if ((slots & (1 << 25)) && !(slots & kFromPrev)) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+#if LL_ABL_TIPS == 1
+        L[r] = 0.25;
+#elif LL_ABL_TIPS == 4
+        {
+          const int at = (int)(4u * lane + (((uint32_t)h.w1 >> (8 * r)) & 0xffu));
+          L[r] = __hiloint2double(__builtin_amdgcn_ds_bpermute(at, __double2hiint(A1)),
+                                  __builtin_amdgcn_ds_bpermute(at, __double2loint(A1)));
+        }
+#else
+        L[r] = *reinterpret_cast<const double*>(mats_e + (h.g1 + (((uint32_t)h.w1 >> (8 * r)) & 3u) * 8u));
+#endif
+      }
+    } else {
+      if (!(slots & kFromPrev)) {
+        const double* src = slot_ptr((slots >> 16) & 0xff);
+#pragma unroll
+        for (int r = 0; r < R; r++) L[r] = src[r * kTile];
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) L[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, L[r], 0.0, 0, 0, 0);
+    }
+    h = request(i + kAhead);
+#pragma unroll
+    for (int r = 0; r < R; r++) L[r] = D0[r] * L[r];
+    if (slots & kStore) {
+      double* dst = slot_ptr(slots & 0xff);
+#pragma unroll
+      for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
+    }
+  };
+#else
   auto visit = [&](int i, Ahead& h) {
     const int slots = __builtin_amdgcn_readfirstlane(h.slots);
     double B0[R];
@@ -361,6 +520,7 @@ __global__ __launch_bounds__(kTile, 5) void loglik_mfma_kernel(LikArgs a) {
       for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
     }
   };
+#endif
   for (int ev = 0; ev < epw; ev++) {
   const int e = e0 + ev;
   int t_ev, mi;

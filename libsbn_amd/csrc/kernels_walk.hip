@@ -944,17 +944,18 @@ __global__ __launch_bounds__(kTmBlock) void transition_macro_kernel(TransitionMa
 
 }  // namespace
 
-size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots) {
+size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots, int regs) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);
+  const int R = regs > 0 ? regs : kLlR;
   // (compact tip words for fewer than three categories -- not in the analytic variant)
   const unsigned col = (kp < 4 && !subst) ? kTwColCompact : kTwCol;
   size_t bytes = (size_t)max_macros(n) * (16 / kp) * col + (subst ? 32 : 0) +
-                 sizeof(double) * (size_t)slots * kLlR * kTile;
-  if (rescale) bytes += ((sizeof(int16_t) * (size_t)max_stored(n) * kLlR * (16 / kp) + 7) / 8) * 8;
+                 sizeof(double) * (size_t)slots * R * kTile;
+  if (rescale) bytes += ((sizeof(int16_t) * (size_t)max_stored(n) * R * (16 / kp) + 7) / 8) * 8;
   return bytes;
 }
-size_t gradient_walk_lds_bytes(int n, int K, bool rescale, bool subst) {
-  return gradient_walk_lds_bytes_for(n, K, rescale, subst, max_stored(n));
+size_t gradient_walk_lds_bytes(int n, int K, bool rescale, bool subst, int regs) {
+  return gradient_walk_lds_bytes_for(n, K, rescale, subst, max_stored(n), regs);
 }
 size_t gradient_walk_mats_bytes_per_eval(int n, int K) {
   return (size_t)max_macros(n) * ((K + 3) / 4) * 24 * 32 * sizeof(double);
@@ -1074,6 +1075,11 @@ bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t wave
   // arena's eight take 36 taxa x 1812 patterns in 2.68 against 2.87 ms per 1000 trees, 41 x 1137
   // in 1.96 against 2.07; at six -- 29 to 35 taxa -- the LDS store keeps 1.21 against 1.38)
   return !lds_fits || (160 * 1024) / lds_all < (lut ? 6 : 5);
+}
+// the same rule for a large batch with no store forced: does this engine's tree size take the arena?
+bool gradient_walk_batches_take_arena(int n, int K, bool lut) {
+  const size_t lds_all = gradient_walk_lds_bytes(n, K, false, false);
+  return lds_all > 160 * 1024 || (160 * 1024) / lds_all < (size_t)(lut ? 6 : 5);
 }
 int gradient_walk_waves_per_cu(int n, int K);
 bool gradient_walk_fits(int n, int K, bool rescale) {

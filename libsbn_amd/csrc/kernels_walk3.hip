@@ -65,7 +65,8 @@ __device__ __forceinline__ double row_ror_add(double v) {
   return v + __hiloint2double(shi, slo);
 }
 
-constexpr int R = kLlR;                  // registers (16 columns each) per vector
+constexpr int kRegs = kLlR;              // registers (16 columns each) per vector: the default tile width
+constexpr int kRegsWide = 4;             // the arena variant's wide tile (round 6: walk_lut_body, RR)
 // Tip codes in LDS, by (macro, column).  Four categories per instruction (KP = 4: three or four
 // rate categories, four pattern columns per register): six words per column -- one per position,
 // one byte per register: the byte offset of the state's table entry -- padded to 32 bytes.
@@ -76,13 +77,14 @@ constexpr int R = kLlR;                  // registers (16 columns each) per vect
 constexpr unsigned kTwCol = 32, kTwColCompact = 12;
 constexpr unsigned kPos = 1280u, kVisit = 6u * kPos;
 constexpr unsigned kTipCat = 320u, kTipRow = 80u;
-constexpr unsigned kVecBytes = R * kTile * 8;  // one stored vector of a wave (LDS slot, arena entry)
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 // operands of one child of a visit (see fetch_child)
-template <bool PRE>
+// (RR registers per vector: a tip position takes RR W doubles, W = 1 post-order / 2 pre-order;
+// the child itself, or its first grandchild, and its second grandchild: (2 RR + 1) W)
+template <bool PRE, int RR>
 struct Ops {
-  double x[PRE ? 14 : 7];
+  double x[(2 * RR + 1) * (PRE ? 2 : 1)];
 };
 
 // Hand-off word of the one-launch small call (round 5), one per tree: the set-up waves of a
@@ -114,9 +116,22 @@ constexpr int kSetupQuarters = 4, kReadyQuarter = 1 << 8;
 //          the vectors written last still in the L2 (it reads them in reverse order): 36 x 1812
 //          (151 tiles) 2.72 / 2.82, 59 x 1824 4.50 / 4.71, 64 x 1008 (84) 2.81 / 2.89; 100 x 500
 //          (42) 2.40 / 2.40.  The launcher takes NT up to 48 tiles per tree.
-template <bool RESCALE, bool FUSED, bool ARENA, int KP, bool NT = false>
+//   RR:    registers per vector = the tile width, 16 / KP pattern columns each.  Three by default
+//          (MI_LLR); FOUR (ARENA only) for engines whose tile counts say so (round 6).  With
+//          the vectors in LDS a wider tile costs waves per CU (DS1: 0.81 -> 0.84 ms); the arena
+//          variant's LDS holds a handful of recycled slots only, and a visit's fixed costs -- the
+//          operand requests, the arena round trip, the schedule words -- are spread over a third
+//          more columns: 36 taxa x 1812 patterns x 4 categories 2.72 -> 2.34 ms per 1000 trees,
+//          64 x 1008 2.74 -> 2.44, 59 x 1824 4.37 -> 3.85, 50 x 378 0.922 -> 0.819, two categories
+//          64 x 1008 1.42 -> 1.29, one 36 x 1812 0.776 -> 0.702 (profiles/r06_wide_tiles.txt; the
+//          rule: gradient_walk_tile_regs).  248 registers, no scratch; with every vector in LDS
+//          the wide kernel would need more than 256, so wide tiles exist in the arena variant
+//          only and a wide-tile engine takes the arena for every call.
+template <bool RESCALE, bool FUSED, bool ARENA, int KP, bool NT = false, int RR = kRegs>
 __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, const int block,
                                               const int32_t* ready, const int spin_ticks, const int fence) {
+  constexpr int R = RR;
+  constexpr unsigned kVecBytes = R * kTile * 8;  // one stored vector of a wave (LDS slot, arena entry)
   static_assert(R >= 1 && R <= 4, "a tip word holds one byte / one 4-bit field per register");
   static_assert(KP == 1 || KP == 2 || KP == 4, "categories per matrix instruction");
   static_assert(!(FUSED && ARENA), "the one-launch call keeps its stored vectors in LDS");
@@ -304,15 +319,15 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   const unsigned lane16 = 16u * lane, lane8 = 8u * lane;
 
   // ---- operands of one child (J = 0, 1) of a visit, requested a visit ahead ----
-  // W doubles per internal position ({f} post-order, {f, tr} pre-order), 3 W per tip position
+  // W doubles per internal position ({f} post-order, {f, tr} pre-order), R W per tip position
   // ({P} / {P, P Q} per register).  One register group per child, laid out by its kind:
-  //   tip:      x[0 .. 3W)                      stored: x[0 .. W)
-  //   unstored: x[0 .. W), first grandchild at x[W ..), second at x[4W ..) (tip: 3W, else W)
+  //   tip:      x[0 .. RW)                      stored: x[0 .. W)
+  //   unstored: x[0 .. W), first grandchild at x[W ..), second at x[(R+1)W ..) (tip: RW, else W)
   // (destinations are compile-time indices into the group: the groups live in registers)
   // ARENA, pre-order: a stored input's post-order vector comes from the arena into the SAME
-  // group, behind the input's W doubles -- R more, and a stored input leaves at least 2 W of
-  // its place unused: stored child x[W .. W + R), grandchildren x[2W ..) and x[5W ..)
-  static_assert(R <= 4, "an arena vector fits the unused part of its operand group (2 W = 4 doubles)");
+  // group, behind the input's W doubles -- R more, and a stored input leaves (R - 1) W >= R of
+  // its place unused: stored child x[W .. W + R), grandchildren x[2W ..) and x[(R+2)W ..)
+  static_assert(R >= 2 && R <= 4, "an arena vector fits the unused part of its operand group ((R - 1) W >= R doubles)");
   auto load_internal = [&](auto pre_tag, const char* at, auto& o, auto off_tag) {
     constexpr bool PRE = decltype(pre_tag)::value;
     constexpr int OFF = decltype(off_tag)::value;
@@ -376,7 +391,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     constexpr bool AR = ARENA && PRE;
     using O0 = std::integral_constant<int, 0>;
     using OA = std::integral_constant<int, W>;
-    using OB = std::integral_constant<int, 4 * W>;
+    using OB = std::integral_constant<int, (R + 1) * W>;
     using P0 = std::integral_constant<int, J>;
     using PA = std::integral_constant<int, 2 + 2 * J>;
     using PB = std::integral_constant<int, 3 + 2 * J>;
@@ -405,14 +420,14 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       // tip of an unstored child with two tip children costs no gather in the post-order walk)
       if (!PRE && (sh & (1 << (10 + 2 * J)))) {
 #pragma unroll
-        for (int r = 0; r < R; r++) o.x[4 * W + r] = 0.25;
+        for (int r = 0; r < R; r++) o.x[(R + 1) * W + r] = 0.25;
         return;
       }
 #endif
       load_tip(pre_tag, gb, tw, PB{}, o, OB{});
     } else {
       load_internal(pre_tag, gb, o, OB{});
-      if constexpr (AR) load_arena(ak++, o, std::integral_constant<int, 5 * W>{});
+      if constexpr (AR) load_arena(ak++, o, std::integral_constant<int, (R + 2) * W>{});
     }
   };
   using J0 = std::integral_constant<int, 0>;
@@ -613,7 +628,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     for (int r = 0; r < R; r++) y.v[r] = o.x[OFF + W * r];
     return y;
   };
-  auto tip_pq = [&](const Ops<true>& o, auto off_tag) {
+  auto tip_pq = [&](const Ops<true, R>& o, auto off_tag) {
     constexpr int OFF = decltype(off_tag)::value;
     V y;
 #pragma unroll
@@ -648,7 +663,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     constexpr bool AR = ARENA && PRE;
     using O0 = std::integral_constant<int, 0>;
     using OA = std::integral_constant<int, W>;
-    using OB = std::integral_constant<int, 4 * W>;
+    using OB = std::integral_constant<int, (R + 1) * W>;
     const int kind = (sh >> (2 * J)) & 3;
     if (kind == 0) {
       c.S = tip_p(pre_tag, o, O0{});
@@ -668,9 +683,9 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       if (sh & (1 << (11 + 2 * J))) {
         c.Bp = tip_p(pre_tag, o, OB{});
       } else {
-        if constexpr (AR) c.xb = arena_vec(o, std::integral_constant<int, 5 * W>{});
+        if constexpr (AR) c.xb = arena_vec(o, std::integral_constant<int, (R + 2) * W>{});
         else c.xb = load_slot(sl.g[2 * J + 1]);
-        c.Bp = mm(o.x[4 * W], c.xb);
+        c.Bp = mm(o.x[(R + 1) * W], c.xb);
       }
       c.L = mul(c.Ap, c.Bp);
     }
@@ -701,11 +716,11 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   // instructions were moves): kernel 0.794 -> 0.774 ms per 1000 DS1 trees (-2.5 %), bit-identical
   // (the same products in the same order).  The consumer's code is inlined into both arms of
   // child 0 (child 1's code twice): 3 047 -> 3 411 static instructions, 214 registers as before.
-  auto post_child = [&](auto jtag, int sh, const Ops<false>& o, const Slots& sl, auto&& use) {
+  auto post_child = [&](auto jtag, int sh, const Ops<false, R>& o, const Slots& sl, auto&& use) {
     constexpr int J = decltype(jtag)::value;
     using O0 = std::integral_constant<int, 0>;
     using OA = std::integral_constant<int, 1>;
-    using OB = std::integral_constant<int, 4>;
+    using OB = std::integral_constant<int, R + 1>;
     const int kind = (sh >> (2 * J)) & 3;
     if (kind == 0) {
       use(tip_p(Post{}, o, O0{}));
@@ -716,17 +731,17 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       L = load_slot(sl.c[J]);
     } else if (sh & (1 << (10 + 2 * J))) {
       if (sh & (1 << (11 + 2 * J))) L = mul(tip_p(Post{}, o, OA{}), tip_p(Post{}, o, OB{}));
-      else L = mul(tip_p(Post{}, o, OA{}), mm(o.x[4], load_slot(sl.g[2 * J + 1])));
+      else L = mul(tip_p(Post{}, o, OA{}), mm(o.x[R + 1], load_slot(sl.g[2 * J + 1])));
     } else {
       const V Ap = mm(o.x[1], load_slot(sl.g[2 * J]));
       if (sh & (1 << (11 + 2 * J))) L = mul(Ap, tip_p(Post{}, o, OB{}));
-      else L = mul(Ap, mm(o.x[4], load_slot(sl.g[2 * J + 1])));
+      else L = mul(Ap, mm(o.x[R + 1], load_slot(sl.g[2 * J + 1])));
     }
     use(mm(o.x[0], L));
   };
 
   // ================= post-order over the stored nodes, then the root (site likelihood) ====
-  auto post_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<false>& o0, const Ops<false>& o1,
+  auto post_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<false, R>& o0, const Ops<false, R>& o1,
                         int tile_for_ll) {
     constexpr bool ROOT = decltype(root_tag)::value;
     V Lv;
@@ -801,7 +816,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     // (LDS).  The visit ends with the scalar loads: slots of m + 1, shape of m + 3 (scalar
     // loads return out of order: any wait for LDS data with one of them in flight is a wait
     // for everything -- at the visit's top or in its middle they cost 12-14 %, round 4).
-    Ops<false> a0, a1, b0, b1;
+    Ops<false, R> a0, a1, b0, b1;
     int s0 = sh_a, s1 = sh_b, s2 = sh_c;
     Slots la = sl_a, lb;
     Tw tw = fetch_tw(0);
@@ -869,7 +884,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     qc = mm(trm, qs);
     return mul(qc, mm(AQ, Lc));
   };
-  auto child_edges = [&](auto jtag, int sh, const Ops<true>& o, const Slots& sl, const Child& c, const V& qs,
+  auto child_edges = [&](auto jtag, int sh, const Ops<true, R>& o, const Slots& sl, const Child& c, const V& qs,
                          int m, V& nout) {
     constexpr int J = decltype(jtag)::value;
     const int kind = (sh >> (2 * J)) & 3;
@@ -892,14 +907,14 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
       store_slot(sl.g[2 * J], qa);
     }
     if (sh & (1 << (11 + 2 * J))) {
-      nb = mul(qsb, tip_pq(o, std::integral_constant<int, 8>{}));
+      nb = mul(qsb, tip_pq(o, std::integral_constant<int, 2 * (R + 1)>{}));
     } else {
-      nb = inner_edge(o.x[9], qsb, c.xb, qb);
+      nb = inner_edge(o.x[2 * (R + 1) + 1], qsb, c.xb, qb);
       store_slot(sl.g[2 * J + 1], qb);
     }
     edge_sums(na, nb, m, 2 + 2 * J);
   };
-  auto pre_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<true>& o0, const Ops<true>& o1, int m) {
+  auto pre_visit = [&](auto root_tag, int sh, const Slots& sl, const Ops<true, R>& o0, const Ops<true, R>& o1, int m) {
     constexpr bool ROOT = decltype(root_tag)::value;
     V qv;
     if (ROOT) {
@@ -933,7 +948,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
     // then the tip words of m - 2 are read; the visit ends with the slots of m - 1 and the
     // shape of m - 3
     auto dn = [&](int m) { return max(m, 0); };
-    Ops<true> a0, a1, b0, b1;
+    Ops<true, R> a0, a1, b0, b1;
     int s0 = load_shape(M1), s1 = load_shape(dn(M1 - 1)), s2 = load_shape(dn(M1 - 2));
     Slots la = load_slots(M1), lb;
     Tw tw = fetch_tw(M1);
@@ -992,10 +1007,10 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
 
 // (R = 2 -- 8 patterns per wave, 14 KB of LDS -- is built with three waves per SIMD:
 // `make EXTRA_LLVM=-DMI_LLR=2`, an experiment of round 4)
-template <bool RESCALE, bool ARENA, int KP, bool NT = false>
-__global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_kernel(LikArgs a) {
+template <bool RESCALE, bool ARENA, int KP, bool NT = false, int RR = kRegs>
+__global__ __launch_bounds__(kTile, RR == 2 ? 3 : 2) void gradient_walk_lut_kernel(LikArgs a) {
   extern __shared__ double wlds[];
-  walk_lut_body<RESCALE, false, ARENA, KP, NT>(a, wlds, blockIdx.x, nullptr, 0, 0);
+  walk_lut_body<RESCALE, false, ARENA, KP, NT, RR>(a, wlds, blockIdx.x, nullptr, 0, 0);
 }
 
 // ------------------------------------------------------------------------
@@ -1293,7 +1308,7 @@ __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const 
 }
 
 template <bool RESCALE, int KP>
-__global__ __launch_bounds__(kTile, R == 2 ? 3 : 2) void gradient_walk_lut_fused_kernel(LikArgs a, FusedSetupArgs f) {
+__global__ __launch_bounds__(kTile, kRegs == 2 ? 3 : 2) void gradient_walk_lut_fused_kernel(LikArgs a, FusedSetupArgs f) {
   extern __shared__ double wlds[];
   if ((int)blockIdx.x < f.setup_blocks) {
     fused_setup_role(f, blockIdx.x, reinterpret_cast<char*>(wlds));
@@ -1360,34 +1375,35 @@ void launch_transition_lut(const TransitionMacroArgs& a, hipStream_t s) {
 // the larger trees, in the arena (round 6; until then K = 3, 4 with the vectors in LDS only).
 // (R = 1 -- four patterns per wave -- is not worth the look-up walk's per-visit cost: the
 // engine's tile-width choice never pairs them)
-bool gradient_walk_lut_applies(int K) { return K >= 1 && K <= 4 && R >= 2; }
+bool gradient_walk_lut_applies(int K) { return K >= 1 && K <= 4 && kRegs >= 2; }
 
-template <bool RESCALE, bool ARENA, int KP>
+template <bool RESCALE, bool ARENA, int KP, int RR>
 static void launch_lut_variant(const LikArgs& a, dim3 grid, size_t lds, hipStream_t s, bool resident) {
-  // (non-temporal arena accesses up to 48 pattern tiles per tree, and for a call whose waves are
-  // all resident at once -- 64 taxa x 1000 x 4 categories, 16 trees: 0.0990 against 0.1025 ms,
-  // tools/audit_paths.py: walk_lut_body; MI_PHYLO_ARENA_NT=0|1 forces plain / non-temporal)
+  // (non-temporal arena accesses up to 48 default-width pattern tiles per tree, and for a call
+  // whose waves are all resident at once -- 64 taxa x 1000 x 4 categories, 16 trees: 0.0990
+  // against 0.1025 ms, tools/audit_paths.py: walk_lut_body; MI_PHYLO_ARENA_NT=0|1 forces plain /
+  // non-temporal)
   // (read per launch: tests switch it between calls of one process)
   const char* nt_env = getenv("MI_PHYLO_ARENA_NT");
   const int forced = nt_env ? atoi(nt_env) : -1;
-  if (ARENA && (forced < 0 ? (a.g_tiles <= 48 || resident) : forced != 0)) {
-    allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_kernel<RESCALE, ARENA, KP, ARENA>), lds);
-    hipLaunchKernelGGL((gradient_walk_lut_kernel<RESCALE, ARENA, KP, ARENA>), grid, dim3(kTile), lds, s, a);
+  if (ARENA && (forced < 0 ? (a.g_tiles * RR <= 48 * kRegs || resident) : forced != 0)) {
+    allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_kernel<RESCALE, ARENA, KP, ARENA, RR>), lds);
+    hipLaunchKernelGGL((gradient_walk_lut_kernel<RESCALE, ARENA, KP, ARENA, RR>), grid, dim3(kTile), lds, s, a);
     return;
   }
-  allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_kernel<RESCALE, ARENA, KP>), lds);
-  hipLaunchKernelGGL((gradient_walk_lut_kernel<RESCALE, ARENA, KP>), grid, dim3(kTile), lds, s, a);
+  allow_large_lds(reinterpret_cast<const void*>(gradient_walk_lut_kernel<RESCALE, ARENA, KP, false, RR>), lds);
+  hipLaunchKernelGGL((gradient_walk_lut_kernel<RESCALE, ARENA, KP, false, RR>), grid, dim3(kTile), lds, s, a);
 }
-template <bool ARENA>
+template <bool ARENA, int RR = kRegs>
 static void launch_lut_store(const LikArgs& a, dim3 grid, size_t lds, bool rescale, hipStream_t s,
                              bool resident = false) {
   switch ((rescale ? 8 : 0) | a.kp) {
-    case 1: launch_lut_variant<false, ARENA, 1>(a, grid, lds, s, resident); break;
-    case 2: launch_lut_variant<false, ARENA, 2>(a, grid, lds, s, resident); break;
-    case 4: launch_lut_variant<false, ARENA, 4>(a, grid, lds, s, resident); break;
-    case 9: launch_lut_variant<true, ARENA, 1>(a, grid, lds, s, resident); break;
-    case 10: launch_lut_variant<true, ARENA, 2>(a, grid, lds, s, resident); break;
-    default: launch_lut_variant<true, ARENA, 4>(a, grid, lds, s, resident); break;
+    case 1: launch_lut_variant<false, ARENA, 1, RR>(a, grid, lds, s, resident); break;
+    case 2: launch_lut_variant<false, ARENA, 2, RR>(a, grid, lds, s, resident); break;
+    case 4: launch_lut_variant<false, ARENA, 4, RR>(a, grid, lds, s, resident); break;
+    case 9: launch_lut_variant<true, ARENA, 1, RR>(a, grid, lds, s, resident); break;
+    case 10: launch_lut_variant<true, ARENA, 2, RR>(a, grid, lds, s, resident); break;
+    default: launch_lut_variant<true, ARENA, 4, RR>(a, grid, lds, s, resident); break;
   }
 }
 
@@ -1397,31 +1413,41 @@ void launch_gradient_walk_lut(const LikArgs& a_in, int count, bool rescale, hipS
   a.kp = lut_kp(a.K);
   a.cat_groups = 1;
   a.walk_evals = count;
-  const int gtiles = gradient_mfma_tiles(a.P, a.K);
-  const dim3 grid((unsigned)((size_t)count * gtiles));
+  // (the engine chose the store and the tile width: a.g_tiles follows them; wide tiles exist in
+  // the arena variant only)
+  const bool wide = kRegs < kRegsWide && a.tile_regs == kRegsWide;
+  const int regs = wide ? kRegsWide : kRegs;
+  const int gtiles = gradient_mfma_tiles(a.P, a.K, regs);
   const bool arena_variant =
-      a.store ? a.store == 2 : gradient_walk_use_arena(a.n, a.K, rescale, false, (size_t)gtiles * (size_t)count, true);
+      wide || (a.store ? a.store == 2
+                       : gradient_walk_use_arena(a.n, a.K, rescale, false, (size_t)gtiles * (size_t)count, true));
+  const dim3 grid((unsigned)((size_t)count * gtiles));
   if (arena_variant) {
     // two launches over one grid, as the second generation's arena variant: the trees whose
     // schedule fits the usual number of LDS slots, then (more LDS per wave) the rest
     const int usual = gradient_arena_slots_usual(a.n), sure = gradient_arena_slots_sure(a.n);
+    auto lds_for = [&](int slots) { return gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, slots, regs); };
+    auto launch = [&](int slots, bool resident) {
+      if (wide) launch_lut_store<true, kRegsWide>(a, grid, lds_for(slots), rescale, s, resident);
+      else launch_lut_store<true>(a, grid, lds_for(slots), rescale, s, resident);
+    };
     a.lds_lo = -1;
     // (ONE launch with the larger footprint only when all waves are resident at once anyway -- a
     // call of a few trees.  Round 6 tried it wherever the larger footprint costs no wave per CU,
     // up to ~60 taxa, to save the second launch's 35-50 us of waves that exit at once: no gain --
     // 59 x 1824: 4.51 against 4.34-4.40 ms, the others level)
-    if (arena_single_launch(gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), grid.x)) {
+    if (arena_single_launch(lds_for(sure), grid.x)) {
       a.lds_slots = sure;
-      launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), rescale, s, true);
+      launch(sure, true);
       return;
     }
     a.lds_slots = usual;
-    const bool resident = arena_single_launch(gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, usual), grid.x);
-    launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, usual), rescale, s, resident);
+    const bool resident = arena_single_launch(lds_for(usual), grid.x);
+    launch(usual, resident);
     if (sure > usual) {
       a.lds_lo = usual;
       a.lds_slots = sure;
-      launch_lut_store<true>(a, grid, gradient_walk_lds_bytes_for(a.n, a.K, rescale, false, sure), rescale, s, resident);
+      launch(sure, resident);
     }
     return;
   }

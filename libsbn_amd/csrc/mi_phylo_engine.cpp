@@ -69,12 +69,32 @@ CallShape call_shape(const mi_engine* e, int T, bool gradient, bool analytic = f
 
 // (waves: one-wave workgroups of a gradient launch; default: a large batch)
 bool walk3_possible(const mi_engine* e);
-bool use_arena(const mi_engine* e, bool rescale, bool subst, size_t waves = (size_t)-1) {
+bool use_arena(const mi_engine* e, bool rescale, bool subst, size_t waves = (size_t)-1, int regs = 0) {
   // (the look-up walk's arena variant starts one step earlier: gradient_walk_use_arena)
   const bool lut = walk3_possible(e) && e->walk3_arena && !subst && gradient_mfma_groups(e->K) == 1;
+  // (a wide-tile engine keeps its stored vectors in the arena whatever the size of the call:
+  // with every vector in LDS the wide kernel needs more than 256 registers -- 90-110 bytes of
+  // scratch per lane, 16 trees of 64 taxa x 1008 patterns 0.146 against 0.093 ms)
+  if (regs > kLlR) return true;
   return gradient_walk_use_arena(e->n, e->K, rescale, subst, waves, lut);
 }
 bool walk_fits(const mi_engine* e, bool rescale) { return gradient_walk_fits(e->n, e->K, rescale); }
+// The look-up walk's tile width for this engine (kernels_walk3.hip, RR; gradient_walk_tile_regs):
+// wide tiles pay in the arena variant, so an engine gets them if its batches take the arena --
+// and then for every look-up-walk call, which all take the arena (use_arena): sums over patterns
+// are formed tile by tile, and a tree's outputs must not depend on the size of the batch it came
+// in.  (A call of a handful of large trees pays for that: four trees of 64 taxa x 1008 patterns
+// 0.086 against 0.069 ms with default tiles in LDS; from sixteen trees on the wide arena call
+// is ahead, 0.093 against 0.114.)
+int engine_tile_regs(mi_engine* e) {
+  if (e->tile_regs < 0) {
+    const bool lut = walk3_possible(e) && e->walk3_arena && gradient_mfma_groups(e->K) == 1;
+    const bool forced = getenv("MI_PHYLO_WALK_TILE_REGS") != nullptr;
+    const int r = lut && (forced || gradient_walk_batches_take_arena(e->n, e->K, true)) ? gradient_walk_tile_regs(e->P, e->K) : 0;
+    e->tile_regs = r > kLlR ? r : 0;
+  }
+  return e->tile_regs;
+}
 
 // which log-likelihood kernel a call uses (also decides who fills the tip tables)
 bool loglik_kernel_is_valu(const mi_engine* e, bool rescaling) {
@@ -143,8 +163,8 @@ int reserve(mi_engine* e, int T, bool gradient, bool need_hbm_path = true,
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / per));
     if (need_hbm_path && e->plv.ensure(per * chunk)) return 1;
     // the arena variant of the matrix-core kernel keeps its stored vectors in the same buffer
-    if (!need_hbm_path && (use_arena(e, false, true) || use_arena(e, true, true) || use_arena(e, false, false) ||
-                           use_arena(e, true, false))) {
+    if (!need_hbm_path && (engine_tile_regs(e) || use_arena(e, false, true) || use_arena(e, true, true) ||
+                           use_arena(e, false, false) || use_arena(e, true, false))) {
       const size_t aper = gradient_arena_bytes_per_eval(n, e->P, e->K);
       const size_t achunk = std::max<size_t>(1, std::min<size_t>(c.Eg, e->plv_budget / aper));
       if (e->plv.ensure(aper * achunk)) return 1;
@@ -176,8 +196,10 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool mfma = d.gradient && matrix_core_gradient(e, d.rescaling);
   const bool onchip = mfma;  // the only on-chip gradient kernel; everything else streams PLVs
   const int groups = mfma ? gradient_mfma_groups(e->K) : 1;
-  const int g_tiles = mfma ? gradient_mfma_tiles(e->P, e->K) * groups : e->tiles;
   const bool analytic = e->analytic_subst && mfma && e->spec.subst_model == MI_SUBST_GTR;
+  // (a wide-tile engine: every call the look-up walk can take runs it, with wide tiles)
+  const int tile_regs = mfma && !analytic && groups == 1 ? engine_tile_regs(e) : 0;
+  const int g_tiles = mfma ? gradient_mfma_tiles(e->P, e->K, tile_regs) * groups : e->tiles;
   // A GTR gradient call whose caller wants neither the substitution-model nor the site-model
   // gradient (BASELINE configs[2] as worded: log-likelihood + branch-length gradient) is ONE
   // evaluation per tree with the tree's own model, exactly like a JC69 call: no perturbed
@@ -228,7 +250,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool marks = prof && e->prof_phases;
   PROF_MARK(e, marks, 0, s);
   // (a call of a few trees keeps its stored vectors in LDS however large the tree)
-  const bool arena = mfma && use_arena(e, d.rescaling, analytic, (size_t)T * (size_t)g_tiles);
+  const bool arena = mfma && use_arena(e, d.rescaling, analytic, (size_t)T * (size_t)g_tiles, tile_regs);
   const bool walk2 = mfma;  // (every matrix-core call: the first generation was retired in round 6)
   // the third-generation (look-up) walk: stored vectors in LDS or, since round 6, in the arena
   constexpr int kMaxEvals = 32768;
@@ -245,7 +267,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // moves the cross-over (testing).
   static const int fuse_max_trees =
       getenv("MI_PHYLO_FUSED_MAX_TREES") ? atoi(getenv("MI_PHYLO_FUSED_MAX_TREES")) : 512;
-  const bool fuse_possible = mfma && walk3_possible(e) && !analytic && groups == 1 && !arena && e->fused_setup &&
+  const bool fuse_possible = mfma && walk3_possible(e) && !analytic && groups == 1 && !arena && !tile_regs && e->fused_setup &&
                              fuse_allowed && c.E == T && c.models_per_tree == 1 && !ts.need_slots &&
                              T <= fuse_max_trees && e->ready.ptr && gradient_walk_lut_fused_applies(n, e->K);
   // One rate category with the stored vectors in LDS: the second generation, whose waves take
@@ -257,7 +279,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // three categories: look-up walk 0.462 / 0.490 and 0.831 / 0.868 ms per 1000 DS1 trees; one
   // category in the arena 0.261 / 0.294 on fluA's shape.)
   const bool walk3 = walk2 && walk3_possible(e) && !analytic && groups == 1 &&
-                     (arena ? e->walk3_arena : (e->K > 1 || e->walk3_k1_lds || fuse_possible));
+                     (tile_regs || (arena ? e->walk3_arena : (e->K > 1 || e->walk3_k1_lds || fuse_possible)));
   const bool fuse_setup = walk3 && fuse_possible;
   if (!fuse_setup) launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
   if (arena)
@@ -365,6 +387,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.status = e->status.as<int32_t>();
   la.slot_need = e->slot_need.as<int32_t>();
   la.store = mfma ? (arena ? 2 : 1) : 0;  // (the launchers follow the choice the schedules were made for)
+  la.tile_regs = tile_regs;
   // one launch covers at most kMaxEvals evaluations (grid y dimension: 65535; a multiple
   // of 8 keeps whole evaluations per XCD)
   int walk_launches = 0;
@@ -448,6 +471,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     if (d.gradient)
       path += !mfma ? " store=hbm" : (arena ? " store=arena" : " store=lds");
     path += fuse_setup ? " setup=in-walk" : " setup=own-launch";
+    if (tile_regs > kLlR) path += " tile=wide";
     if (d.gradient && fd_pass) path += " fd=16";
     if (d.gradient && site_pass) path += " site-pass";
     if (light) path += " light";
@@ -478,7 +502,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   // log-likelihood pass
   const int ll_kernel_count = loglik_is_valu ? e->tiles : loglik_mfma_tiles(e->P, e->K);
   const int grad_kernel_count =
-      mfma ? (groups > 1 ? ll_kernel_count : gradient_mfma_tiles(e->P, e->K)) : e->tiles;
+      mfma ? (groups > 1 ? ll_kernel_count : g_tiles) : e->tiles;
   LlCounts ll_used{d.gradient ? grad_kernel_count : ll_kernel_count, ll_kernel_count, 0, 0};
   if (d.gradient && c.gtr && !analytic && !light) {
     ll_used.mid_lo = T;

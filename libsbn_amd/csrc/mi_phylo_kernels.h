@@ -91,6 +91,7 @@ struct LikArgs {
   // tiles each (tile g, g + walk_groups, ...); the others get a wave per tile
   int walk_evals, walk_big_evals, walk_groups;
   int store;           // matrix-core gradient kernels: 0 = the launcher decides, 1 = stored vectors in LDS, 2 = arena (the engine decides: its schedules must match)
+  int tile_regs;       // look-up walk: registers per vector = tile width (0: the default, kLlR; 4: wide tiles -- gradient_walk_tile_regs)
   int evals_per_wave;  // loglik_mfma_kernel: consecutive evaluations of one tree per wave (launcher)
   int kp;           // MFMA path: categories per instruction (1, 2 or 4; set by the launcher)
   int cat_groups;   // matrix-core gradient: groups of four categories (K > 4; set by the launcher)
@@ -167,7 +168,10 @@ void launch_transition(const TransitionArgs& a, hipStream_t s);
 // On-chip (LDS-resident) log-likelihood: evaluations [eval_offset, eval_offset+count)
 void launch_loglik(const LikArgs& a, int count, bool rescale, int max_slots, hipStream_t s);
 int loglik_mfma_tiles(int P, int K);
-int gradient_mfma_tiles(int P, int K);
+int gradient_mfma_tiles(int P, int K, int regs = 0);  // regs: registers per vector (0: kLlR)
+// tile width of the look-up walk for an engine whose batches take the arena (kLlR or 4:
+// kernels_walk3.hip, RR)
+int gradient_walk_tile_regs(int P, int K);
 // Gradient, partial-likelihood vectors streamed through HBM (any tree size, rescaling)
 void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t s);
 // The matrix-core gradient walks (kernels_walk.hip: second generation, kernels_walk3.hip: third;
@@ -193,8 +197,9 @@ void launch_gradient_walk(const LikArgs& a, int count, bool rescale, bool subst,
 bool gradient_walk_fits(int n, int K, bool rescale);
 // lut: the call runs the third-generation (look-up) walk, whose arena variant pays one step earlier
 bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves = (size_t)-1, bool lut = false);
-size_t gradient_walk_lds_bytes(int n, int K, bool rescale, bool subst);
-size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots);
+bool gradient_walk_batches_take_arena(int n, int K, bool lut);  // (large batch, no rescaling, whatever MI_PHYLO_GRADIENT_STORE says)
+size_t gradient_walk_lds_bytes(int n, int K, bool rescale, bool subst, int regs = 0);
+size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots, int regs = 0);
 size_t gradient_walk_mats_bytes_per_eval(int n, int K);
 const char* gradient_walk_kernel_name();
 // kernels_walk3.hip: the third-generation walk (tip children are table look-ups)

@@ -329,18 +329,26 @@ def test_hand_off_modes_and_arena_access_forms_are_bit_identical(monkeypatch):
     pids, bls = TU.random_trees(n, T, rng, mean_bl=0.06)
     spec = O.make_spec(n, P, "JC69", "weibull+4", "strict")
     pr = _params(spec, T, **{"Weibull shape": rng.uniform(0.4, 1.5, size=(T, 1))})
-    monkeypatch.setenv("MI_PHYLO_GRADIENT_STORE", "arena")
-    eng = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w)
+    # (default tile width: an engine of this shape gets wide tiles -- and then takes the arena for
+    # every call -- since round 6; both widths run both access forms)
     got = {}
-    for nt in ("0", "1"):
-        monkeypatch.setenv("MI_PHYLO_ARENA_NT", nt)  # (read by the launcher at every launch)
-        got[nt] = _flat(eng.gradients(pids, bls, pr))
-        assert "store=arena" in eng.last_call_path()
-    monkeypatch.delenv("MI_PHYLO_ARENA_NT")
-    eng.close()
+    for regs in ("3", "4"):
+        monkeypatch.setenv("MI_PHYLO_WALK_TILE_REGS", regs)
+        monkeypatch.setenv("MI_PHYLO_GRADIENT_STORE", "arena")
+        eng = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w)
+        for nt in ("0", "1"):
+            monkeypatch.setenv("MI_PHYLO_ARENA_NT", nt)  # (read by the launcher at every launch)
+            got[regs, nt] = _flat(eng.gradients(pids, bls, pr))
+            assert "store=arena" in eng.last_call_path()
+            assert ("tile=wide" in eng.last_call_path()) == (regs == "4")
+        monkeypatch.delenv("MI_PHYLO_ARENA_NT")
+        eng.close()
+    monkeypatch.setenv("MI_PHYLO_WALK_TILE_REGS", "3")
     monkeypatch.setenv("MI_PHYLO_GRADIENT_STORE", "lds")
     eng = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips, w)
     lds = _flat(eng.gradients(pids, bls, pr))
     assert "store=lds" in eng.last_call_path()
     eng.close()
-    assert np.array_equal(got["0"], lds) and np.array_equal(got["1"], lds)
+    assert np.array_equal(got["3", "0"], lds) and np.array_equal(got["3", "1"], lds)
+    assert np.array_equal(got["4", "0"], got["4", "1"])
+    assert np.allclose(got["4", "0"], lds, rtol=1e-11, atol=1e-12 * np.max(np.abs(lds)))

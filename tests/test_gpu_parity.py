@@ -984,23 +984,28 @@ np.save(sys.argv[1], np.concatenate(out))
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     results = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for walk in ("v2", "v3"):
+        # (third generation: with the default tile width -- three registers per vector, as the
+        # second generation -- and with the wide tiles that engines whose batches take the arena
+        # get since round 6, here forced on every engine of the list)
+        for walk, regs in (("v2", ""), ("v3", "3"), ("v3", "4")):
             for store in ("", "arena"):
                 for subst_mode in ("", "analytic"):
                     if walk == "v3" and subst_mode:
                         continue  # (the third generation leaves those calls to the second)
                     env = dict(os.environ, MI_PHYLO_GRADIENT_WALK=walk)
-                    env.pop("MI_PHYLO_GRADIENT_STORE", None)
-                    env.pop("MI_PHYLO_SUBST_GRADIENT", None)
+                    for k in ("MI_PHYLO_GRADIENT_STORE", "MI_PHYLO_SUBST_GRADIENT", "MI_PHYLO_WALK_TILE_REGS"):
+                        env.pop(k, None)
                     if store:
                         env["MI_PHYLO_GRADIENT_STORE"] = store
                     if subst_mode:
                         env["MI_PHYLO_SUBST_GRADIENT"] = subst_mode
-                    path = os.path.join(tmp, f"{walk}_{store}_{subst_mode}.npy")
+                    if regs:
+                        env["MI_PHYLO_WALK_TILE_REGS"] = regs
+                    path = os.path.join(tmp, f"{walk}{regs}_{store}_{subst_mode}.npy")
                     r = subprocess.run([sys.executable, "-c", code, path], env=env, cwd=repo,
                                        capture_output=True, text=True)
-                    assert r.returncode == 0, (walk, store, subst_mode, r.stdout + r.stderr)
-                    results[(walk, store, subst_mode)] = np.load(path)
+                    assert r.returncode == 0, (walk, regs, store, subst_mode, r.stdout + r.stderr)
+                    results[(walk + regs, store, subst_mode)] = np.load(path)
     for subst_mode in ("", "analytic"):
         a, b = results[("v2", "", subst_mode)], results[("v2", "arena", subst_mode)]
         assert a.shape == b.shape and np.isfinite(a).all()
@@ -1017,9 +1022,18 @@ np.save(sys.argv[1], np.concatenate(out))
     # Round 6: so do its arena variant (stored vectors of the larger trees through HBM) and its
     # one- and two-category forms -- every engine of the list with at most four categories.
     for store in ("", "arena"):
-        a, b = results[("v3", store, "")], results[("v2", store, "")]
+        a, b = results[("v33", store, "")], results[("v2", store, "")]
         assert a.shape == b.shape and np.isfinite(a).all()
         assert np.array_equal(a, b), (store, np.max(np.abs(a - b)))
+    # Wide tiles (four registers per vector): the same products per pattern column, but the sums
+    # over patterns are formed over other tiles -- last-bit differences from the default width,
+    # and bit-identical between the two stores (the width is the engine's, not the call's).
+    a, b = results[("v34", "", "")], results[("v34", "arena", "")]
+    assert a.shape == b.shape and np.isfinite(a).all()
+    assert np.array_equal(a, b), np.max(np.abs(a - b))
+    c = results[("v33", "", "")]
+    assert not np.array_equal(a, c), "the wide-tile kernels did not run"
+    assert np.allclose(a, c, rtol=1e-11, atol=1e-12 * np.max(np.abs(c))), np.max(np.abs(a - c))
 
 
 def test_waves_taking_several_tiles_are_bit_identical_and_match_oracle():

@@ -15,7 +15,7 @@ rng = np.random.default_rng(11)
 
 def time_cfg(n, P, K, T, env):
     for k in ("MI_PHYLO_GRADIENT_WALK", "MI_PHYLO_GRADIENT_STORE", "MI_PHYLO_LOGLIK_PATH", "MI_PHYLO_WALK3_K1",
-              "MI_PHYLO_ARENA_NT"):
+              "MI_PHYLO_ARENA_NT", "MI_PHYLO_WALK_TILE_REGS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     site = "constant" if K == 1 else f"weibull+{K}"
@@ -75,6 +75,10 @@ for n, P, K, T in grid:
         # arena's non-temporal accesses are chosen by tiles per tree)
         if K == 1:
             variants.append(("v3k1/lds", {"MI_PHYLO_GRADIENT_WALK": "v3", "MI_PHYLO_GRADIENT_STORE": "lds", "MI_PHYLO_WALK3_K1": "1"}))
+        # (and its tile width by the engine's tile counts)
+        variants += [("v3/%s/r%s" % (store, regs), {"MI_PHYLO_GRADIENT_WALK": "v3", "MI_PHYLO_GRADIENT_STORE": store,
+                                                   "MI_PHYLO_WALK_TILE_REGS": regs})
+                     for store in ("lds", "arena") for regs in ("3", "4")]
         variants += [("v3/arena/nt%s" % nt, {"MI_PHYLO_GRADIENT_WALK": "v3", "MI_PHYLO_GRADIENT_STORE": "arena", "MI_PHYLO_ARENA_NT": nt})
                      for nt in ("0", "1")]
     for vname, env in variants:

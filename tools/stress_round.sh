@@ -26,6 +26,11 @@ run parity_arena_v2 parity 3012 200 STRESS_FOCUS=arena MI_PHYLO_WALK3_ARENA=0 &
 run parity_arena_forced parity 3013 300 STRESS_FOCUS=arena MI_PHYLO_GRADIENT_STORE=arena &
 run rooted_arena_forced rooted 3014 300 MI_PHYLO_GRADIENT_STORE=arena &
 run parity_v2 parity 3005 600 MI_PHYLO_GRADIENT_WALK=v2 &
+# (wide pattern tiles -- engines whose batches take the arena get them by tile count -- on every
+# engine the look-up walk takes, and with the arena forced)
+run parity_wide parity 3015 600 MI_PHYLO_WALK_TILE_REGS=4 &
+run parity_wide_arena parity 3016 300 STRESS_FOCUS=arena MI_PHYLO_WALK_TILE_REGS=4 MI_PHYLO_GRADIENT_STORE=arena &
+run rooted_wide rooted 3017 300 MI_PHYLO_WALK_TILE_REGS=4 &
 run parity_unfused parity 3007 400 MI_PHYLO_FUSED_SETUP=0 STRESS_FOCUS=fused &
 run parity_analytic parity 3008 400 MI_PHYLO_SUBST_GRADIENT=analytic &
 run rooted rooted 3009 800 &

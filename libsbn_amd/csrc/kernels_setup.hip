@@ -2,12 +2,14 @@
 // (gfx950 / CDNA4, wave64; see DESIGN.md for the mapping and what bounds each kernel.)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 
 #include "mi_phylo_device_utils.h"
 #include "mi_phylo_kernels.h"
 #include "mi_phylo_setup_device.h"
+#include "mi_phylo_macro_slots_device.h"
 
 namespace miphylo {
 
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(kSetupMaxThreads) void tree_setup_wg_kernel(TreeSet
   }
   __syncthreads();
   int status = flag_bad ? kBadParentIds : kOk;
+  int macro_M = 0;  // (uniform) the tree's macro count, for the arena's slot assignment below
   if (status == kOk) {
     for (int v = tid; v < nodes_in - 1; v += nthreads) {
       const int p = par[v];
@@ -510,7 +513,8 @@ __global__ __launch_bounds__(kSetupMaxThreads) void tree_setup_wg_kernel(TreeSet
         me.shape = macro_shape(kind[0], kind[1], root, me.child, me.grand, n);
         if (sslot[v] < max_macros(n)) mac[sslot[v]] = me;
       }
-      if (tid == 0) a.macro_count[t] = stored + 1 < max_macros(n) ? stored + 1 : max_macros(n);
+      macro_M = stored + 1 < max_macros(n) ? stored + 1 : max_macros(n);
+      if (tid == 0) a.macro_count[t] = macro_M;
       if (stored > max_stored(n)) status = kTooManySlots;
     }
   }
@@ -520,12 +524,11 @@ __global__ __launch_bounds__(kSetupMaxThreads) void tree_setup_wg_kernel(TreeSet
   }
   __syncthreads();
   if (!ok_flag) {
+    macro_M = 0;
     if (tid == 0 && a.macro_count) a.macro_count[t] = 0;
     for (int i = tid; i < n - 1; i += nthreads) sched[i] = {n + i, 0, 1, 0};
     for (int v = tid; v < N; v += nthreads) ble[v] = 0.0;
-    return;
-  }
-  if (!a.rooted) {
+  } else if (!a.rooted) {
     const double* bl = a.bl + (size_t)t * (N - 1);
     for (int v = tid; v < N; v += nthreads) ble[v] = v < N - 2 ? bl[v] : 0.0;
   } else {
@@ -533,6 +536,13 @@ __global__ __launch_bounds__(kSetupMaxThreads) void tree_setup_wg_kernel(TreeSet
     const double* rates = a.rates ? a.rates + (size_t)t * (N - 1) : nullptr;
     for (int v = tid; v < N; v += nthreads)
       ble[v] = (rates && v < N - 1) ? bl[v] * rates[v] : bl[v];
+  }
+  // Arena calls (round 6): the slot assignment of the arena variant -- macro_slots_wg_kernel's
+  // work, the same workgroup-per-tree mapping -- on the macro list this workgroup has just
+  // written (visible to it after the barrier), in the LDS the tree arrays no longer need.
+  if (a.arena_macros) {
+    __syncthreads();
+    macro_slots_wg_body(ts_lds, a.macros, a.arena_macros, macro_M, n, t, a.slot_need, a.arena_sure, a.status);
   }
 }
 
@@ -628,8 +638,11 @@ __global__ __launch_bounds__(kTransitionBlock) void transition_kernel(Transition
 // ------------------------------------------------------------------------
 // Launch wrappers
 // ------------------------------------------------------------------------
-void launch_setup(const TreeSetupArgs& a_in, const ModelSetupArgs& ms, hipStream_t s) {
+bool launch_setup(const TreeSetupArgs& a_in, const ModelSetupArgs& ms, hipStream_t s) {
   TreeSetupArgs a = a_in;
+  // MI_PHYLO_MACRO_SLOTS=own|seq: the arena's slot assignment stays a launch of its own (A/B, tests)
+  const bool fold_slots = getenv("MI_PHYLO_MACRO_SLOTS") == nullptr;  // (read per call)
+  a.arena_sure = gradient_arena_slots_sure(a.n);
   const size_t lds = sizeof(int32_t) * 13 * (size_t)(2 * a.n - 1);
   a.use_lds = lds <= 64 * 1024;
   // Three kernels build the same schedule (tests/test_cpp_adapter_gpu.py compares them bit for
@@ -651,19 +664,28 @@ void launch_setup(const TreeSetupArgs& a_in, const ModelSetupArgs& ms, hipStream
     else if (N <= 128) hipLaunchKernelGGL(tree_setup_small_kernel<2>, grid, block, 0, s, a, ms);
     else if (N <= 192) hipLaunchKernelGGL(tree_setup_small_kernel<3>, grid, block, 0, s, a, ms);
     else hipLaunchKernelGGL(tree_setup_small_kernel<4>, grid, block, 0, s, a, ms);
-    return;
+    return false;
   }
   if (use_wg) {
     // (a thread per internal node, at most kSetupOwn of them per thread: the LDS bound keeps
     // N below 2 600)
     const int threads = a.n >= kSetupMaxThreads ? kSetupMaxThreads : (a.n + 63) / 64 * 64;
     const dim3 wgrid(a.T + (ms.T * ms.models_per_tree + threads - 1) / threads);
-    allow_large_lds(reinterpret_cast<const void*>(tree_setup_wg_kernel), wg_lds);
-    hipLaunchKernelGGL(tree_setup_wg_kernel, wgrid, dim3(threads), wg_lds, s, a, ms);
-    return;
+    // (the slot assignment takes two macros per thread at most, and its own LDS in place of the
+    // tree arrays)
+    const size_t slots_lds = macro_slots_wg_lds_bytes(a.n);
+    const bool fold = a.arena_macros && a.macros && fold_slots && max_macros(a.n) <= 2 * threads &&
+                      slots_lds <= 160 * 1024 - 1024;
+    if (!fold) a.arena_macros = nullptr;
+    const size_t lds_bytes = fold ? std::max(wg_lds, slots_lds) : wg_lds;
+    allow_large_lds(reinterpret_cast<const void*>(tree_setup_wg_kernel), lds_bytes);
+    hipLaunchKernelGGL(tree_setup_wg_kernel, wgrid, dim3(threads), lds_bytes, s, a, ms);
+    return fold;
   }
+  a.arena_macros = nullptr;
   const dim3 grid(a.T + (ms.T * ms.models_per_tree + 63) / 64), block(64);
   hipLaunchKernelGGL(tree_setup_kernel, grid, block, a.use_lds ? lds : 0, s, a, ms);
+  return false;
 }
 namespace {
 __global__ void weibull_table_kernel(int K, double* table) {
@@ -678,9 +700,9 @@ __global__ void weibull_table_kernel(int K, double* table) {
 void launch_weibull_table(int K, double* table, hipStream_t s) {
   hipLaunchKernelGGL(weibull_table_kernel, dim3(1), dim3(64), 0, s, K, table);
 }
-void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s) {  // trees only
+bool launch_tree_setup(const TreeSetupArgs& a, hipStream_t s) {  // trees only
   ModelSetupArgs none{};
-  launch_setup(a, none, s);
+  return launch_setup(a, none, s);
 }
 void launch_transition(const TransitionArgs& a, hipStream_t s) {
   const long total = (long)a.E * (a.N - 1) * a.K;

@@ -281,8 +281,11 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool walk3 = walk2 && walk3_possible(e) && !analytic && groups == 1 &&
                      (tile_regs || (arena ? e->walk3_arena : (e->K > 1 || e->walk3_k1_lds || fuse_possible)));
   const bool fuse_setup = walk3 && fuse_possible;
-  if (!fuse_setup) launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
-  if (arena)
+  // (arena calls: the slot assignment rides in the set-up launch where a workgroup builds the tree)
+  ts.arena_macros = arena ? e->arena_macros.as<MacroEntry>() : nullptr;
+  ts.slot_need = e->slot_need.as<int32_t>();
+  const bool slots_done = !fuse_setup && launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
+  if (arena && !slots_done)
     launch_macro_slots(e->macros.as<MacroEntry>(), e->arena_macros.as<MacroEntry>(),
                        e->macro_count.as<int32_t>(), n, T, e->slot_need.as<int32_t>(),
                        e->status.as<int32_t>(), s);

@@ -45,6 +45,11 @@ struct TreeSetupArgs {
   int max_slots;
   int use_lds;     // set by the launcher
   int need_slots;  // 0: no log-likelihood kernel will run on this batch (node-id order, no LDS slots)
+  // arena calls: the slot assignment of launch_macro_slots done by the tree's set-up workgroup
+  // (tree_setup_wg_kernel only; launch_setup says whether it was): outputs, or nullptr
+  MacroEntry* arena_macros;  // [T][max_macros(n)]
+  int32_t* slot_need;        // [T]
+  int arena_sure;            // set by the launcher
 };
 
 struct ModelSetupArgs {
@@ -161,8 +166,9 @@ struct FinalizeArgs {
 };
 
 // tree schedules (one wave per tree) and model instances (one thread each) in one launch
-void launch_setup(const TreeSetupArgs& a, const ModelSetupArgs& ms, hipStream_t s);
-void launch_tree_setup(const TreeSetupArgs& a, hipStream_t s);  // trees only
+// (returns true when the arena's slot assignment was done in the same launch: a.arena_macros)
+bool launch_setup(const TreeSetupArgs& a, const ModelSetupArgs& ms, hipStream_t s);
+bool launch_tree_setup(const TreeSetupArgs& a, hipStream_t s);  // (as launch_setup)  // trees only
 void launch_weibull_table(int K, double* table, hipStream_t s);  // once per engine: ModelSetupArgs::weibull_x
 void launch_transition(const TransitionArgs& a, hipStream_t s);
 // On-chip (LDS-resident) log-likelihood: evaluations [eval_offset, eval_offset+count)

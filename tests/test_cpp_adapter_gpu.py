@@ -47,9 +47,14 @@ def test_tree_setup_kernels_agree(tmp_path):
         if slots != "default":
             env["MI_PHYLO_MACRO_SLOTS"] = slots
         out = tmp_path / f"dump_{n}_{mode}_{rooted}_{slots}.bin"
-        r = subprocess.run([str(exe), str(n), str(T), str(trees), str(out), str(rooted)], env=env,
+        fold = slots == "fold"  # (round 6: the slot assignment in the set-up launch itself)
+        if fold:
+            env.pop("MI_PHYLO_MACRO_SLOTS")
+        r = subprocess.run([str(exe), str(n), str(T), str(trees), str(out), str(rooted), str(int(fold))], env=env,
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
+        if fold:
+            assert "folded=1" in r.stdout, r.stdout
         return np.fromfile(out, dtype=np.int32)
 
     # up to 64 nodes the register-array kernel is the default, above the workgroup kernel;
@@ -68,6 +73,8 @@ def test_tree_setup_kernels_agree(tmp_path):
             # workgroup-per-tree macro_slots kernel by default, the sequential one for `ref`)
             ref = dump(n, T, trees, "lds", rooted, slots="seq")
             assert np.array_equal(dump(n, T, trees, "default", rooted), ref), f"n = {n}"
+            if n >= 4:  # (the workgroup kernel, forced below 65 nodes, with the arena's slot assignment folded in)
+                assert np.array_equal(dump(n, T, trees, "wg", rooted, slots="fold"), ref), f"n = {n} (wg + slots)"
             if n <= 128:
                 assert np.array_equal(dump(n, T, trees, "wg", rooted), ref), f"n = {n} (wg)"
                 assert np.array_equal(dump(n, T, trees, "small", rooted), ref), f"n = {n} (small)"

@@ -265,14 +265,14 @@ __global__ __launch_bounds__(kTile, LL_WAVES) void loglik_mfma_kernel(LikArgs a)
     }
     sched_l[i] = v;
   }
-#if LL_ABL_TIPS == 5
-  // (timing build 5: the tip bytes arrive as one 8-byte copy per lane -- what a pre-tiled
-  // array would cost; contents are garbage)
-  for (int q = lane; q < (n * ppr * (int)TB + 7) / 8; q += kTile)
-    reinterpret_cast<uint64_t*>(tips)[q] = reinterpret_cast<const uint64_t*>(a.tip_masks)[(size_t)te.tile * 64 + q];
-  if (false)
-#endif
-  {
+  if (a.tip_tiles) {
+    // (round 6) the tile's tip bytes in exactly this layout, prepared once per engine
+    // (tip_tiles_kernel): 8-byte copies -- the general staging below is ~200 vector instructions
+    // of a tile job's ~950, 0.241 -> 0.231 ms per 1000 DS1 log-likelihoods
+    const int words = (n * ppr * (int)TB + 7) >> 3;
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(a.tip_tiles) + (size_t)te.tile * words;
+    for (int q = lane; q < words; q += kTile) reinterpret_cast<uint64_t*>(tips)[q] = src[q];
+  } else {
     const int tp_shift = TP <= 16 ? 4 : (TP <= 32 ? 5 : 6);
     const int group = 64 >> tp_shift;
     const int ppr_shift = Kp == 4 ? 2 : (Kp == 2 ? 3 : 4);
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kTile, LL_WAVES) void loglik_mfma_kernel(LikArgs a)
       for (int r = 0; r < R; r++) dst[r * kTile] = L[r];
     }
   };
-#elif LL_ABL_TIPS && LL_ABL_TIPS != 5
+#elif LL_ABL_TIPS
   // TIMING builds only (wrong results): what a tip child costs.  1: its product is a constant
   // (no matrix instruction, no tip bits); 2: its product is gathered from the node's matrix
   // block at the moment of use (the look-up's memory pattern, latency exposed).
@@ -642,6 +642,37 @@ static size_t loglik_mfma_lds_bytes(int n, int K, int max_slots) {
                        sizeof(double) * (size_t)loglik_mfma_slots(max_slots) * kLogR * kTile;
   const size_t reach = (size_t)(2 * n - 1) * tb * (16 / kp);  // mask fetches of internal ids
   return bytes > reach ? bytes : reach;
+}
+// The matrix-core kernel's tip bytes per pattern tile, in the layout its LDS wants
+// ([taxon][column][register], the block padded to 8 bytes): built once per engine.
+namespace {
+__global__ __launch_bounds__(256) void tip_tiles_kernel(const uint8_t* masks, uint8_t* tiles, int n, int P, int ppr,
+                                                        int tile_count, int block_bytes) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)tile_count * block_bytes;
+  if (id >= total) return;
+  const int tile = (int)(id / block_bytes), x = (int)(id - (long)tile * block_bytes);
+  const int r = x & 3, c = (x >> 2) % ppr, taxon = (x >> 2) / ppr;
+  uint8_t v = 0;
+  if (taxon < n && r < kLogR) {
+    const int p = tile * (kLogR * ppr) + r * ppr + c;
+    v = masks[(size_t)taxon * P + (p < P ? p : P - 1)];
+  }
+  tiles[id] = v;
+}
+}  // namespace
+size_t loglik_tip_tiles_bytes(int n, int P, int K) {
+  const int ppr = 16 / (K == 1 ? 1 : (K == 2 ? 2 : 4));
+  return (size_t)loglik_mfma_tiles(P, K) * (size_t)(((size_t)n * ppr * 4 + 7) / 8 * 8);
+}
+void launch_tip_tiles(const uint8_t* masks, uint8_t* tiles, int n, int P, int K, hipStream_t s) {
+  static_assert(kLogR <= 4, "four bytes per (taxon, column)");
+  const int ppr = 16 / (K == 1 ? 1 : (K == 2 ? 2 : 4));
+  const int block_bytes = (int)(((size_t)n * ppr * 4 + 7) / 8 * 8);
+  const int tile_count = loglik_mfma_tiles(P, K);
+  const long total = (long)tile_count * block_bytes;
+  hipLaunchKernelGGL(tip_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, masks, tiles, n, P, ppr,
+                     tile_count, block_bytes);
 }
 int loglik_mfma_tiles(int P, int K) {
   const int kp = K == 1 ? 1 : (K == 2 ? 2 : 4);

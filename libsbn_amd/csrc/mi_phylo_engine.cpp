@@ -79,6 +79,13 @@ bool use_arena(const mi_engine* e, bool rescale, bool subst, size_t waves = (siz
   return gradient_walk_use_arena(e->n, e->K, rescale, subst, waves, lut);
 }
 bool walk_fits(const mi_engine* e, bool rescale) { return gradient_walk_fits(e->n, e->K, rescale); }
+// (engine creation, tips in mask form on the device: the log-likelihood kernel's pre-tiled copy)
+int build_tip_tiles(mi_engine* e) {
+  if (!e->have_tip_masks || e->K > kMaxCategories) return 0;
+  if (e->tip_tiles.ensure(loglik_tip_tiles_bytes(e->n, e->P, e->K))) return 1;
+  launch_tip_tiles(e->tip_masks.as<uint8_t>(), e->tip_tiles.as<uint8_t>(), e->n, e->P, e->K, e->stream);
+  return 0;
+}
 // The look-up walk's tile width for this engine (kernels_walk3.hip, RR; gradient_walk_tile_regs):
 // wide tiles pay in the arena variant, so an engine gets them if its batches take the arena --
 // and then for every look-up-walk call, which all take the arena (use_arena): sums over patterns
@@ -379,6 +386,9 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.mphi = e->mphi.as<double>();
   la.tip_states = e->tip_states.as<int8_t>();
   la.tip_masks = e->have_tip_masks ? e->tip_masks.as<uint8_t>() : nullptr;
+  // (MI_PHYLO_TIP_TILES=0: the kernel stages its tip bytes from tip_masks itself -- A/B, tests)
+  la.tip_tiles = e->have_tip_masks && e->tip_tiles.ptr && !(getenv("MI_PHYLO_TIP_TILES") && getenv("MI_PHYLO_TIP_TILES")[0] == '0')
+                     ? e->tip_tiles.as<uint8_t>() : nullptr;
   la.tip_codes = e->have_tip_codes ? e->tip_codes.as<uint8_t>() : nullptr;
   la.tip_partials = e->spec.use_tip_states ? nullptr : e->tip_partials.as<double>();
   la.weights = e->weights.as<double>();
@@ -903,6 +913,7 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
                        dna ? e->tip_codes.as<uint8_t>() : nullptr,
                        dna && !spec->use_tip_states ? e->tip_partials.as<double>() : nullptr);
     e->have_tip_masks = e->have_tip_codes = dna;
+    if (build_tip_tiles(e)) return cleanup_fail(1);
     if (states == kAa && aa_engine_init(e, exchangeabilities, frequencies)) return cleanup_fail(1);
     if (e->weights.ensure(sizeof(double) * (size_t)e->P) ||
         hipMemcpyAsync(e->weights.ptr, device_weights, sizeof(double) * (size_t)e->P,
@@ -1006,6 +1017,7 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
     }
   }
   }
+  if (build_tip_tiles(e)) return cleanup_fail(1);
   if (upload(e->weights, pattern_weights, (size_t)e->P, e->stream)) return cleanup_fail(1);
   if (hipStreamSynchronize(e->stream) != hipSuccess)
     return cleanup_fail(fail("upload of tips failed"));
@@ -1022,7 +1034,7 @@ void mi_engine_destroy(mi_engine* e) {
     (void)hipStreamSynchronize(e->stream);
   }
   for (Buffer* b :
-       {&e->tip_states, &e->tip_partials, &e->tip_masks, &e->tip_codes, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
+       {&e->tip_states, &e->tip_partials, &e->tip_masks, &e->tip_tiles, &e->tip_codes, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
         &e->arena_macros, &e->slot_need,
         &e->macro_count, &e->tip_tables, &e->mmats, &e->mphi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,

@@ -96,6 +96,7 @@ struct LikArgs {
   // tiles each (tile g, g + walk_groups, ...); the others get a wave per tile
   int walk_evals, walk_big_evals, walk_groups;
   int store;           // matrix-core gradient kernels: 0 = the launcher decides, 1 = stored vectors in LDS, 2 = arena (the engine decides: its schedules must match)
+  const uint8_t* tip_tiles;  // loglik_mfma_kernel: tip_masks by pattern tile in the kernel's LDS layout, or nullptr
   int tile_regs;       // look-up walk: registers per vector = tile width (0: the default, kLlR; 4: wide tiles -- gradient_walk_tile_regs)
   int evals_per_wave;  // loglik_mfma_kernel: consecutive evaluations of one tree per wave (launcher)
   int kp;           // MFMA path: categories per instruction (1, 2 or 4; set by the launcher)
@@ -174,6 +175,9 @@ void launch_transition(const TransitionArgs& a, hipStream_t s);
 // On-chip (LDS-resident) log-likelihood: evaluations [eval_offset, eval_offset+count)
 void launch_loglik(const LikArgs& a, int count, bool rescale, int max_slots, hipStream_t s);
 int loglik_mfma_tiles(int P, int K);
+// the matrix-core log-likelihood kernel's tip bytes, pre-tiled once per engine (LikArgs::tip_tiles)
+size_t loglik_tip_tiles_bytes(int n, int P, int K);
+void launch_tip_tiles(const uint8_t* masks, uint8_t* tiles, int n, int P, int K, hipStream_t s);
 int gradient_mfma_tiles(int P, int K, int regs = 0);  // regs: registers per vector (0: kLlR)
 // tile width of the look-up walk for an engine whose batches take the arena (kLlR or 4:
 // kernels_walk3.hip, RR)

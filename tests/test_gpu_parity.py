@@ -1182,3 +1182,43 @@ def test_limits_are_refused_at_the_c_abi_with_a_message():
     assert rc != 0 and "state_count must be 4" in msg
     rc, msg = create(K=4, site=0)
     assert rc != 0 and "exactly one rate category" in msg
+
+
+def test_pretiled_tip_bytes_are_what_the_kernel_stages_itself(monkeypatch):
+    """loglik_mfma_kernel takes its tile's tip bytes from a copy laid out per tile at engine
+    creation (round 6: launch_tip_tiles) instead of gathering them from the [taxon][pattern]
+    masks in every wave; MI_PHYLO_TIP_TILES=0 (read per call) keeps the gather.  Same bytes, same
+    arithmetic: bit-identical log-likelihoods -- 1 / 2 / 4 / 8 categories, a partial last tile,
+    gaps, rescaling, tips handed over as states or as 0/1 partial vectors -- and the GTR
+    finite-difference gradient, whose sixteen passes run the same kernel."""
+    rng = np.random.default_rng(77)
+    for n, P, site, subst, as_partials in ((9, 70, "weibull+4", "JC69", False), (27, 131, "constant", "JC69", False),
+                                          (33, 50, "weibull+2", "GTR", True), (64, 17, "weibull+8", "JC69", False),
+                                          (130, 40, "weibull+4", "JC69", False)):
+        T = 6
+        tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.1)
+        pids, bls = TU.random_trees(n, T, rng, mean_bl=0.08)
+        eng = _engine(subst, site, "strict", tips, w, use_tip_states=not as_partials)
+        spec = O.make_spec(n, P, subst, site, "strict", use_tip_states=0 if as_partials else 1)
+        blocks = {}
+        if subst == "GTR":
+            r, f = TU.random_gtr_params(T, rng)
+            blocks["GTR rates"] = r
+            blocks["frequencies"] = f
+        if site != "constant":
+            blocks["Weibull shape"] = rng.uniform(0.4, 1.5, size=(T, 1))
+        pr = _params(spec, T, **blocks)
+        got = {}
+        for tiles in ("1", "0"):
+            monkeypatch.setenv("MI_PHYLO_TIP_TILES", tiles)
+            res = []
+            for resc in (False, True):
+                res.append(np.asarray(eng.log_likelihoods(pids, bls, pr, resc)))
+                assert eng.last_call_info()[0] == "loglik_mfma_kernel", eng.last_call_info()
+            if subst == "GTR":
+                res.append(np.stack([x.gradient["substitution_model"] for x in eng.gradients(pids, bls, pr)]).ravel())
+            got[tiles] = np.concatenate(res)
+        monkeypatch.delenv("MI_PHYLO_TIP_TILES")
+        eng.close()
+        assert np.isfinite(got["1"]).all()
+        assert np.array_equal(got["1"], got["0"]), (n, P, site, np.max(np.abs(got["1"] - got["0"])))

@@ -1054,13 +1054,26 @@ void launch_gradient_walk(const LikArgs& a_in, int count, bool rescale, bool sub
                            subst, s);
 }
 
-bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves, bool lut) {
+bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves, bool lut, int regs) {
   // (read at every call: tools/audit_paths.py switches it between engines of one process)
   const int forced = [] {
     const char* env = getenv("MI_PHYLO_GRADIENT_STORE");
     if (!env) return 0;
     return std::string(env) == "arena" ? 2 : (std::string(env) == "lds" ? 1 : 0);
   }();
+  if (regs > kLlR) {
+    // A wide-tile engine (look-up walk, kernels_walk3.hip): wide tiles pay in the arena; the form
+    // with every vector in LDS runs at one wave per SIMD (registers) and takes the calls whose
+    // waves are all resident at once at that occupancy -- 16 trees of 45 taxa x 200 patterns
+    // 0.052 (default tiles in LDS) / 0.068 ms (wide, arena) before it existed.  The tile width
+    // never depends on the call: a tree's outputs do not depend on the batch it came in.
+    const size_t lds_w = gradient_walk_lds_bytes(n, K, rescale, subst, regs);
+    const bool fits = lds_w <= 160 * 1024;
+    if (forced == 1 && fits) return false;
+    if (forced == 2 || !fits) return true;
+    const size_t per_cu = std::min<size_t>(4, (160 * 1024) / lds_w);
+    return waves > (size_t)device_compute_units() * per_cu;
+  }
   const size_t lds_all = gradient_walk_lds_bytes(n, K, rescale, subst);
   const bool lds_fits = lds_all <= 160 * 1024;
   if (forced == 1 && lds_fits) return false;

@@ -125,8 +125,9 @@ constexpr int kSetupQuarters = 4, kReadyQuarter = 1 << 8;
 //          64 x 1008 2.74 -> 2.44, 59 x 1824 4.37 -> 3.85, 50 x 378 0.922 -> 0.819, two categories
 //          64 x 1008 1.42 -> 1.29, one 36 x 1812 0.776 -> 0.702 (profiles/r06_wide_tiles.txt; the
 //          rule: gradient_walk_tile_regs).  248 registers, no scratch; with every vector in LDS
-//          the wide kernel would need more than 256, so wide tiles exist in the arena variant
-//          only and a wide-tile engine takes the arena for every call.
+//          the wide kernel needs ~280, so that form is built for one wave per SIMD and a
+//          wide-tile engine takes the arena unless the call's waves are all resident at that
+//          occupancy (gradient_walk_use_arena).
 template <bool RESCALE, bool FUSED, bool ARENA, int KP, bool NT = false, int RR = kRegs>
 __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, const int block,
                                               const int32_t* ready, const int spin_ticks, const int fence) {
@@ -1007,8 +1008,12 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
 
 // (R = 2 -- 8 patterns per wave, 14 KB of LDS -- is built with three waves per SIMD:
 // `make EXTRA_LLVM=-DMI_LLR=2`, an experiment of round 4)
-template <bool RESCALE, bool ARENA, int KP, bool NT = false, int RR = kRegs>
-__global__ __launch_bounds__(kTile, RR == 2 ? 3 : 2) void gradient_walk_lut_kernel(LikArgs a) {
+// (WAVES: waves per SIMD the registers are budgeted for.  Two -- 256 registers -- everywhere but in
+// the wide-tile form with every vector in LDS, which needs ~280: that one is built for ONE wave
+// per SIMD and serves the calls of a wide-tile engine whose waves are all resident at that
+// occupancy, a handful of trees; larger calls take the arena.)
+template <bool RESCALE, bool ARENA, int KP, bool NT = false, int RR = kRegs, int WAVES = (RR == 2 ? 3 : 2)>
+__global__ __launch_bounds__(kTile, WAVES) void gradient_walk_lut_kernel(LikArgs a) {
   extern __shared__ double wlds[];
   walk_lut_body<RESCALE, false, ARENA, KP, NT, RR>(a, wlds, blockIdx.x, nullptr, 0, 0);
 }
@@ -1413,14 +1418,13 @@ void launch_gradient_walk_lut(const LikArgs& a_in, int count, bool rescale, hipS
   a.kp = lut_kp(a.K);
   a.cat_groups = 1;
   a.walk_evals = count;
-  // (the engine chose the store and the tile width: a.g_tiles follows them; wide tiles exist in
-  // the arena variant only)
+  // (the engine chose the store and the tile width: a.g_tiles follows them)
   const bool wide = kRegs < kRegsWide && a.tile_regs == kRegsWide;
   const int regs = wide ? kRegsWide : kRegs;
   const int gtiles = gradient_mfma_tiles(a.P, a.K, regs);
   const bool arena_variant =
-      wide || (a.store ? a.store == 2
-                       : gradient_walk_use_arena(a.n, a.K, rescale, false, (size_t)gtiles * (size_t)count, true));
+      a.store ? a.store == 2
+              : gradient_walk_use_arena(a.n, a.K, rescale, false, (size_t)gtiles * (size_t)count, true, regs);
   const dim3 grid((unsigned)((size_t)count * gtiles));
   if (arena_variant) {
     // two launches over one grid, as the second generation's arena variant: the trees whose
@@ -1448,6 +1452,23 @@ void launch_gradient_walk_lut(const LikArgs& a_in, int count, bool rescale, hipS
       a.lds_lo = usual;
       a.lds_slots = sure;
       launch(sure, resident);
+    }
+    return;
+  }
+  if (wide) {
+    // (a wide-tile engine's call of a few trees: every vector in LDS, one wave per SIMD)
+    const size_t lds = gradient_walk_lds_bytes(a.n, a.K, rescale, false, regs);
+    auto go = [&](auto kernel) {
+      allow_large_lds(reinterpret_cast<const void*>(kernel), lds);
+      hipLaunchKernelGGL(kernel, grid, dim3(kTile), lds, s, a);
+    };
+    switch ((rescale ? 8 : 0) | a.kp) {
+      case 1: go(gradient_walk_lut_kernel<false, false, 1, false, kRegsWide, 1>); break;
+      case 2: go(gradient_walk_lut_kernel<false, false, 2, false, kRegsWide, 1>); break;
+      case 4: go(gradient_walk_lut_kernel<false, false, 4, false, kRegsWide, 1>); break;
+      case 9: go(gradient_walk_lut_kernel<true, false, 1, false, kRegsWide, 1>); break;
+      case 10: go(gradient_walk_lut_kernel<true, false, 2, false, kRegsWide, 1>); break;
+      default: go(gradient_walk_lut_kernel<true, false, 4, false, kRegsWide, 1>); break;
     }
     return;
   }

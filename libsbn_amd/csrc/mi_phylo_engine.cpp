@@ -72,11 +72,7 @@ bool walk3_possible(const mi_engine* e);
 bool use_arena(const mi_engine* e, bool rescale, bool subst, size_t waves = (size_t)-1, int regs = 0) {
   // (the look-up walk's arena variant starts one step earlier: gradient_walk_use_arena)
   const bool lut = walk3_possible(e) && e->walk3_arena && !subst && gradient_mfma_groups(e->K) == 1;
-  // (a wide-tile engine keeps its stored vectors in the arena whatever the size of the call:
-  // with every vector in LDS the wide kernel needs more than 256 registers -- 90-110 bytes of
-  // scratch per lane, 16 trees of 64 taxa x 1008 patterns 0.146 against 0.093 ms)
-  if (regs > kLlR) return true;
-  return gradient_walk_use_arena(e->n, e->K, rescale, subst, waves, lut);
+  return gradient_walk_use_arena(e->n, e->K, rescale, subst, waves, lut, regs);
 }
 bool walk_fits(const mi_engine* e, bool rescale) { return gradient_walk_fits(e->n, e->K, rescale); }
 // (engine creation, tips in mask form on the device: the log-likelihood kernel's pre-tiled copy)
@@ -88,11 +84,10 @@ int build_tip_tiles(mi_engine* e) {
 }
 // The look-up walk's tile width for this engine (kernels_walk3.hip, RR; gradient_walk_tile_regs):
 // wide tiles pay in the arena variant, so an engine gets them if its batches take the arena --
-// and then for every look-up-walk call, which all take the arena (use_arena): sums over patterns
-// are formed tile by tile, and a tree's outputs must not depend on the size of the batch it came
-// in.  (A call of a handful of large trees pays for that: four trees of 64 taxa x 1008 patterns
-// 0.086 against 0.069 ms with default tiles in LDS; from sixteen trees on the wide arena call
-// is ahead, 0.093 against 0.114.)
+// and then for every look-up-walk call: sums over patterns are formed tile by tile, and a
+// tree's outputs must not depend on the size of the batch it came in.  (Its calls of a few
+// trees keep every vector in LDS with the same wide tiles, one wave per SIMD:
+// gradient_walk_use_arena.)
 int engine_tile_regs(mi_engine* e) {
   if (e->tile_regs < 0) {
     const bool lut = walk3_possible(e) && e->walk3_arena && gradient_mfma_groups(e->K) == 1;

@@ -206,7 +206,8 @@ void launch_transition_macro(const TransitionMacroArgs& a, hipStream_t s);
 void launch_gradient_walk(const LikArgs& a, int count, bool rescale, bool subst, hipStream_t s);
 bool gradient_walk_fits(int n, int K, bool rescale);
 // lut: the call runs the third-generation (look-up) walk, whose arena variant pays one step earlier
-bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves = (size_t)-1, bool lut = false);
+bool gradient_walk_use_arena(int n, int K, bool rescale, bool subst, size_t waves = (size_t)-1, bool lut = false,
+                             int regs = 0);  // regs: the engine's tile width (0: default)
 bool gradient_walk_batches_take_arena(int n, int K, bool lut);  // (large batch, no rescaling, whatever MI_PHYLO_GRADIENT_STORE says)
 size_t gradient_walk_lds_bytes(int n, int K, bool rescale, bool subst, int regs = 0);
 size_t gradient_walk_lds_bytes_for(int n, int K, bool rescale, bool subst, int slots, int regs = 0);

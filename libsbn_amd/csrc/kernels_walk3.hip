@@ -243,8 +243,27 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
   static_assert(TP % 4 == 0, "whole words of tip codes per tile");
   const int tile_start = tile * TP;
   const bool whole = tile_start + TP <= a.P;
+  // (round 6) the tile's codes of a tip in exactly the form the LDS wants -- per column one word
+  // (byte r: register r's code) or, COMPACT, one 16-bit field (4 bits per register) -- laid out
+  // per tile at engine creation (launch_tip_code_tiles): a copy instead of TP bytes regrouped by
+  // every wave (one category: 16 columns x R fields, ~150 vector instructions per tip pair and
+  // round, a quarter of a fluA tile job's vector instructions)
+  struct TileCodes {
+    uint32_t d[ppr * (COMPACT ? 2 : 4) / 4];
+  };
+  const bool tiled = a.tip_code_tiles != nullptr;
+  const TileCodes* __restrict__ tile_codes =
+      reinterpret_cast<const TileCodes*>(a.tip_code_tiles) + (size_t)tile * (size_t)n;
+  TileCodes codes_now[U] = {};
+  if (tiled) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int j = lane + 64 * u, node = node_j[u];
+      if (j < jmax && (unsigned)node < (unsigned)n) codes_now[u] = tile_codes[node];
+    }
+  }
   BytesTP bytes_now[U] = {};
-  if (whole && !COMPACT) {
+  if (!tiled && whole && !COMPACT) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int j = lane + 64 * u, node = node_j[u];
@@ -545,7 +564,30 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
         *reinterpret_cast<uint32_t*>(dst + c * kTwCol) = word;
       }
     };
-    if (whole && !COMPACT) {
+    auto stage_tiled = [&](int j, const TileCodes& w) {
+      const int m = j / 6, pos = j - m * 6;
+      if constexpr (COMPACT) {
+        char* dst = lds0 + (unsigned)m * kTStride + (unsigned)pos * 2u;
+#pragma unroll
+        for (int c = 0; c < ppr; c++)
+          *reinterpret_cast<uint16_t*>(dst + c * kCol) = (uint16_t)(w.d[c >> 1] >> (16 * (c & 1)));
+      } else {
+        char* dst = lds0 + (unsigned)m * kTStride + (unsigned)pos * 4u;
+#pragma unroll
+        for (int c = 0; c < 4; c++) *reinterpret_cast<uint32_t*>(dst + c * kTwCol) = w.d[c];
+      }
+    };
+    if (tiled) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int j = lane + 64 * u, node = node_j[u];
+        if (j < jmax && (unsigned)node < (unsigned)n) stage_tiled(j, codes_now[u]);
+      }
+      for (int j = lane + 64 * U; j < jmax; j += kTile) {  // larger trees: the rest
+        const int node = mwv[(j / 6) * 16 + 1 + (j % 6)];
+        if ((unsigned)node < (unsigned)n) stage_tiled(j, tile_codes[node]);
+      }
+    } else if (whole && !COMPACT) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int j = lane + 64 * u, node = node_j[u];
@@ -558,7 +600,7 @@ __device__ __forceinline__ void walk_lut_body(const LikArgs& a, double* wlds, co
         if (j < jmax && (unsigned)node < (unsigned)n) stage_bytes(j, node);
       }
     }
-    for (int j = lane + 64 * U; j < jmax; j += kTile) {  // larger trees: the rest
+    for (int j = lane + 64 * U; !tiled && j < jmax; j += kTile) {  // larger trees: the rest
       const int node = mwv[(j / 6) * 16 + 1 + (j % 6)];
       if ((unsigned)node < (unsigned)n) {
         if (whole && !COMPACT)
@@ -1473,6 +1515,37 @@ void launch_gradient_walk_lut(const LikArgs& a_in, int count, bool rescale, hipS
     return;
   }
   launch_lut_store<false>(a, grid, gradient_walk_lds_bytes(a.n, a.K, rescale, false), rescale, s);
+}
+// The look-up walk's tip codes per pattern tile, in the form its LDS holds them (walk_lut_body,
+// TileCodes): per (tile, taxon) one word per column (byte r: the code of register r's pattern) for
+// three / four categories, one 16-bit field per column (4 bits per register: code / 16) for one /
+// two.  Built once per engine for its tile width; columns past the last pattern repeat it.
+namespace {
+__global__ __launch_bounds__(256) void tip_code_tiles_kernel(const uint8_t* codes, uint8_t* out, int n, int P, int ppr,
+                                                             int regs, int tile_count) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)tile_count * n * ppr) return;
+  const int c = (int)(id % ppr), taxon = (int)((id / ppr) % n), tile = (int)(id / ((long)ppr * n));
+  uint32_t word = 0, field = 0;
+  for (int r = 0; r < regs; r++) {
+    const int p = tile * (regs * ppr) + r * ppr + c;
+    const uint32_t code = codes[(size_t)taxon * P + (p < P ? p : P - 1)];
+    word |= code << (8 * r);
+    field |= ((code >> 4) & 0x7u) << (4 * r);
+  }
+  if (ppr == 4) reinterpret_cast<uint32_t*>(out)[id] = word;
+  else reinterpret_cast<uint16_t*>(out)[id] = (uint16_t)field;
+}
+}  // namespace
+size_t tip_code_tiles_bytes(int n, int P, int K, int regs) {
+  const int ppr = 16 / lut_kp(K);
+  return (size_t)gradient_mfma_tiles(P, K, regs) * (size_t)n * ppr * (ppr == 4 ? 4 : 2);
+}
+void launch_tip_code_tiles(const uint8_t* codes, uint8_t* out, int n, int P, int K, int regs, hipStream_t s) {
+  const int ppr = 16 / lut_kp(K), tiles = gradient_mfma_tiles(P, K, regs);
+  const long total = (long)tiles * n * ppr;
+  hipLaunchKernelGGL(tip_code_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, codes, out, n, P, ppr,
+                     regs > 0 ? regs : kRegs, tiles);
 }
 const char* gradient_walk_lut_kernel_name() { return "gradient_walk_lut_kernel"; }
 const char* gradient_walk_lut_fused_kernel_name() { return "gradient_walk_lut_fused_kernel"; }

@@ -76,10 +76,17 @@ bool use_arena(const mi_engine* e, bool rescale, bool subst, size_t waves = (siz
 }
 bool walk_fits(const mi_engine* e, bool rescale) { return gradient_walk_fits(e->n, e->K, rescale); }
 // (engine creation, tips in mask form on the device: the log-likelihood kernel's pre-tiled copy)
+int engine_tile_regs(mi_engine* e);
 int build_tip_tiles(mi_engine* e) {
   if (!e->have_tip_masks || e->K > kMaxCategories) return 0;
   if (e->tip_tiles.ensure(loglik_tip_tiles_bytes(e->n, e->P, e->K))) return 1;
   launch_tip_tiles(e->tip_masks.as<uint8_t>(), e->tip_tiles.as<uint8_t>(), e->n, e->P, e->K, e->stream);
+  // ... and the look-up walk's, for the engine's tile width
+  if (walk3_possible(e) && gradient_mfma_groups(e->K) == 1) {
+    const int regs = engine_tile_regs(e);
+    if (e->tip_code_tiles.ensure(tip_code_tiles_bytes(e->n, e->P, e->K, regs))) return 1;
+    launch_tip_code_tiles(e->tip_codes.as<uint8_t>(), e->tip_code_tiles.as<uint8_t>(), e->n, e->P, e->K, regs, e->stream);
+  }
   return 0;
 }
 // The look-up walk's tile width for this engine (kernels_walk3.hip, RR; gradient_walk_tile_regs):
@@ -381,7 +388,14 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   la.mphi = e->mphi.as<double>();
   la.tip_states = e->tip_states.as<int8_t>();
   la.tip_masks = e->have_tip_masks ? e->tip_masks.as<uint8_t>() : nullptr;
-  // (MI_PHYLO_TIP_TILES=0: the kernel stages its tip bytes from tip_masks itself -- A/B, tests)
+  {  // (the look-up walk's pre-tiled codes were made for the engine's tile width)
+    const char* off = getenv("MI_PHYLO_TIP_TILES");
+    la.tip_code_tiles = e->have_tip_codes && e->tip_code_tiles.ptr && !(off && off[0] == '0') &&
+                                engine_tile_regs(e) == tile_regs
+                            ? e->tip_code_tiles.as<uint8_t>()
+                            : nullptr;
+  }
+  // (MI_PHYLO_TIP_TILES=0: the kernels stage their tip bytes from tip_masks / tip_codes themselves -- A/B, tests)
   la.tip_tiles = e->have_tip_masks && e->tip_tiles.ptr && !(getenv("MI_PHYLO_TIP_TILES") && getenv("MI_PHYLO_TIP_TILES")[0] == '0')
                      ? e->tip_tiles.as<uint8_t>() : nullptr;
   la.tip_codes = e->have_tip_codes ? e->tip_codes.as<uint8_t>() : nullptr;
@@ -1029,7 +1043,7 @@ void mi_engine_destroy(mi_engine* e) {
     (void)hipStreamSynchronize(e->stream);
   }
   for (Buffer* b :
-       {&e->tip_states, &e->tip_partials, &e->tip_masks, &e->tip_tiles, &e->tip_codes, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
+       {&e->tip_states, &e->tip_partials, &e->tip_masks, &e->tip_tiles, &e->tip_code_tiles, &e->tip_codes, &e->weights, &e->tree_scratch, &e->sched, &e->macros,
         &e->arena_macros, &e->slot_need,
         &e->macro_count, &e->tip_tables, &e->mmats, &e->mphi, &e->x_sum, &e->bl_eff,
         &e->models, &e->mats, &e->ll_part, &e->plv, &e->g_part, &e->site_lik, &e->site_exp, &e->fin_scratch,

@@ -134,6 +134,7 @@ struct mi_engine {
   hipStream_t stream = nullptr;
   // static device data
   Buffer tip_states, tip_partials, tip_masks, tip_codes, weights;
+  Buffer tip_code_tiles;  // tip_codes by pattern tile of the look-up walk (launch_tip_code_tiles), if have_tip_codes and K <= 4
   Buffer tip_tiles;  // tip_masks by pattern tile of the matrix-core log-likelihood kernel (launch_tip_tiles), if have_tip_masks
   bool have_tip_masks = false;  // every tip vector is 0/1: the matrix-core kernel can run
   bool have_tip_codes = false;  // ... and one-hot or all ones: the third-generation walk can run

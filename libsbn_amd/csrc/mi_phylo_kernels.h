@@ -96,6 +96,7 @@ struct LikArgs {
   // tiles each (tile g, g + walk_groups, ...); the others get a wave per tile
   int walk_evals, walk_big_evals, walk_groups;
   int store;           // matrix-core gradient kernels: 0 = the launcher decides, 1 = stored vectors in LDS, 2 = arena (the engine decides: its schedules must match)
+  const uint8_t* tip_code_tiles;  // look-up walk: tip_codes by pattern tile in the form its LDS holds them (launch_tip_code_tiles), or nullptr
   const uint8_t* tip_tiles;  // loglik_mfma_kernel: tip_masks by pattern tile in the kernel's LDS layout, or nullptr
   int tile_regs;       // look-up walk: registers per vector = tile width (0: the default, kLlR; 4: wide tiles -- gradient_walk_tile_regs)
   int evals_per_wave;  // loglik_mfma_kernel: consecutive evaluations of one tree per wave (launcher)
@@ -179,6 +180,9 @@ int loglik_mfma_tiles(int P, int K);
 size_t loglik_tip_tiles_bytes(int n, int P, int K);
 void launch_tip_tiles(const uint8_t* masks, uint8_t* tiles, int n, int P, int K, hipStream_t s);
 int gradient_mfma_tiles(int P, int K, int regs = 0);  // regs: registers per vector (0: kLlR)
+// the look-up walk's tip codes pre-tiled once per engine for its tile width (LikArgs::tip_code_tiles)
+size_t tip_code_tiles_bytes(int n, int P, int K, int regs);
+void launch_tip_code_tiles(const uint8_t* codes, uint8_t* out, int n, int P, int K, int regs, hipStream_t s);
 // tile width of the look-up walk for an engine whose batches take the arena (kLlR or 4:
 // kernels_walk3.hip, RR)
 int gradient_walk_tile_regs(int P, int K);

@@ -1222,3 +1222,66 @@ def test_pretiled_tip_bytes_are_what_the_kernel_stages_itself(monkeypatch):
         eng.close()
         assert np.isfinite(got["1"]).all()
         assert np.array_equal(got["1"], got["0"]), (n, P, site, np.max(np.abs(got["1"] - got["0"])))
+
+
+def test_pretiled_tip_codes_are_what_the_walk_stages_itself(monkeypatch):
+    """The look-up gradient walk copies a tip's codes of its tile from a per-tile layout made at
+    engine creation (launch_tip_code_tiles: one word per column for three / four categories, one
+    16-bit field for one / two) instead of regrouping the tile's bytes in every wave;
+    MI_PHYLO_TIP_TILES=0 (read per call) keeps the regrouping.  Same LDS contents: bit-identical
+    gradients -- one to four categories, the one-launch call (small trees), every vector in LDS,
+    the arena with default and wide tiles, a partial last tile, gaps, rescaling, rooted."""
+    rng = np.random.default_rng(78)
+    cases = ((9, 70, "weibull+4", 5, ""), (27, 131, "constant", 5, ""), (12, 50, "weibull+2", 600, ""),
+             (33, 50, "weibull+3", 5, ""), (40, 90, "weibull+4", 300, ""), (69, 238, "constant", 200, ""),
+             (45, 100, "weibull+2", 300, ""), (90, 61, "weibull+4", 6, ""), (40, 90, "constant", 300, "4"))
+    for n, P, site, T, regs in cases:
+        if regs:
+            monkeypatch.setenv("MI_PHYLO_WALK_TILE_REGS", regs)
+        tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.1)
+        pids, bls = TU.random_trees(n, T, rng, mean_bl=0.08)
+        eng = _engine("JC69", site, "strict", tips, w)
+        spec = O.make_spec(n, P, "JC69", site, "strict")
+        blocks = {} if site == "constant" else {"Weibull shape": rng.uniform(0.4, 1.5, size=(T, 1))}
+        pr = _params(spec, T, **blocks)
+        got, paths = {}, set()
+        for tiles in ("1", "0"):
+            monkeypatch.setenv("MI_PHYLO_TIP_TILES", tiles)
+            res = []
+            for resc in (False, True):
+                for x in eng.gradients(pids, bls, pr, resc):
+                    res.append([x.log_likelihood])
+                    res += [np.atleast_1d(x.gradient[k]).ravel() for k in sorted(x.gradient)]
+                paths.add(eng.last_call_path())
+            got[tiles] = np.concatenate(res)
+        monkeypatch.delenv("MI_PHYLO_TIP_TILES")
+        if regs:
+            monkeypatch.delenv("MI_PHYLO_WALK_TILE_REGS")
+        eng.close()
+        assert np.isfinite(got["1"]).all()
+        assert np.array_equal(got["1"], got["0"]), (n, P, site, T, paths, np.max(np.abs(got["1"] - got["0"])))
+    # rooted (fluA-like: one category, arena)
+    n, P, T = 50, 80, 300
+    tips, w = TU.random_alignment(n, P, rng, gap_fraction=0.05)
+    trees = [TU.clocklike_rooted_tree(n, rng) for _ in range(T)]
+    pids = np.stack([t[0] for t in trees])
+    bls = np.stack([t[1] for t in trees])
+    state = [O.time_tree_init(n, t[0], t[1], t[2]) for t in trees]
+    h = np.stack([s[0] for s in state])
+    bd = np.stack([s[1] for s in state])
+    ra = np.stack([s[2] for s in state])
+    rates = np.full((T, 2 * n - 2), 0.7)
+    eng = _engine("JC69", "constant", "strict", tips, w)
+    spec = O.make_spec(n, P, "JC69", "constant", "strict")
+    pr = _params(spec, T)
+    got = {}
+    for tiles in ("1", "0"):
+        monkeypatch.setenv("MI_PHYLO_TIP_TILES", tiles)
+        res = []
+        for x in eng.rooted_gradients(pids, bls, pr, rates, np.ones(T, np.int32), h, bd, ra):
+            res.append([x.log_likelihood])
+            res += [np.atleast_1d(x.gradient[k]).ravel() for k in sorted(x.gradient)]
+        got[tiles] = np.concatenate(res)
+    monkeypatch.delenv("MI_PHYLO_TIP_TILES")
+    eng.close()
+    assert np.isfinite(got["1"]).all() and np.array_equal(got["1"], got["0"])

@@ -22,7 +22,7 @@ import tree_utils as TU
 
 DEFAULT_SHAPES = "27x934x4,29x1195x4,36x1812x4,41x1137x4,50x378x4,50x1133x4,59x1824x4,64x1008x4,100x500x4,69x238x1,45x1000x1,45x1000x2,31x1000x4"
 SWITCHES = ("MI_PHYLO_GRADIENT_WALK", "MI_PHYLO_GRADIENT_STORE", "MI_PHYLO_WALK3_ARENA", "MI_PHYLO_FUSED_SETUP",
-            "MI_PHYLO_WALK3_K1", "MI_PHYLO_ARENA_NT", "MI_PHYLO_WALK_TILE_REGS", "MI_PHYLO_MACRO_SLOTS", "MI_PHYLO_FUSED_FENCE", "MI_PHYLO_FUSED_COLOCATE")
+            "MI_PHYLO_WALK3_K1", "MI_PHYLO_ARENA_NT", "MI_PHYLO_WALK_TILE_REGS", "MI_PHYLO_MACRO_SLOTS", "MI_PHYLO_TIP_TILES", "MI_PHYLO_FUSED_FENCE", "MI_PHYLO_FUSED_COLOCATE")
 PEAK = 71.1e12
 dev = torch.device("cuda", 0)
 

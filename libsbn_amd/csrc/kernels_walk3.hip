@@ -1213,7 +1213,7 @@ __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const 
     const int T = f.setup_blocks / kSetupQuarters, full = T & ~7;
     if (f.colocate && bid < kSetupQuarters * full) {
       const int j = bid >> 3, x = bid & 7;
-      t = 8 * (j / kSetupQuarters) + ((x - f.setup_blocks) & 7);
+      t = 8 * (j / kSetupQuarters) + ((x - f.xcd_base) & 7);
       q = j % kSetupQuarters;
     } else {
       t = bid / kSetupQuarters;
@@ -1349,9 +1349,15 @@ __device__ __forceinline__ void fused_setup_role(const FusedSetupArgs& f, const 
   if (f.fence == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   // (f.debug_skip: testing only -- quarter 1 of tree debug_skip - 1 never reports, its walk waves
   // time out: tests/test_fused_setup_gpu.py forces the host's fallback with it)
-  if (lane == 0 && !(f.debug_skip == t + 1 && q == 1))
+  if (lane == 0 && f.ready && !(f.debug_skip == t + 1 && q == 1))
     __hip_atomic_fetch_add(f.ready + (size_t)t * kReadyStride, kReadyQuarter + (q == 0 ? M : 0), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The set-up waves alone (launch_setup_records).
+__global__ __launch_bounds__(kTile) void setup_records_kernel(FusedSetupArgs f) {
+  extern __shared__ double wlds[];
+  fused_setup_role(f, blockIdx.x, reinterpret_cast<char*>(wlds));
 }
 
 template <bool RESCALE, int KP>
@@ -1395,6 +1401,7 @@ void launch_gradient_walk_lut_fused(const LikArgs& a_in, const FusedSetupArgs& f
   a.cat_groups = 1;
   a.walk_evals = count;
   f.setup_blocks = kSetupQuarters * count;
+  f.xcd_base = f.setup_blocks & 7;  // (the walk workgroups follow the set-up waves in this launch)
   // how long a walk wave polls before it gives up: one second of the 100 MHz clock by default
   if (f.spin_ticks <= 0) f.spin_ticks = 100 * 1000 * 1000;
   const int gtiles = gradient_mfma_tiles(a.P, a.K);
@@ -1408,6 +1415,19 @@ void launch_gradient_walk_lut_fused(const LikArgs& a_in, const FusedSetupArgs& f
     case 10: launch_fused_variant<true, 2>(a, f, grid, lds, s); break;
     default: launch_fused_variant<true, 4>(a, f, grid, lds, s); break;
   }
+}
+
+void launch_setup_records(const FusedSetupArgs& f_in, int count, hipStream_t s) {
+  if (count <= 0) return;
+  FusedSetupArgs f = f_in;
+  f.setup_blocks = kSetupQuarters * count;
+  f.xcd_base = 0;  // (the walk's launch numbers its workgroups from zero)
+  f.ready = nullptr;
+  f.fence = 0;
+  f.debug_skip = 0;
+  const size_t lds = fused_setup_lds(f.ts.n, f.ms.K);
+  allow_large_lds(reinterpret_cast<const void*>(setup_records_kernel), lds);
+  hipLaunchKernelGGL(setup_records_kernel, dim3((unsigned)f.setup_blocks), dim3(kTile), lds, s, f);
 }
 
 void launch_transition_lut(const TransitionMacroArgs& a, hipStream_t s) {

@@ -290,10 +290,28 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool walk3 = walk2 && walk3_possible(e) && !analytic && groups == 1 &&
                      (tile_regs || (arena ? e->walk3_arena : (e->K > 1 || e->walk3_k1_lds || fuse_possible)));
   const bool fuse_setup = walk3 && fuse_possible;
+  // Beyond the one-launch call's size the same set-up waves CAN run as one launch in front of the
+  // walk's (round 6, MI_PHYLO_SETUP_RECORDS=1): trees, model instances and operand records --
+  // instead of the tree set-up launch and the record launch, 13 + 18 us of a 1000-tree DS1 step.
+  // Built, bit-identical (test), and not the default: the four quarter-waves of a tree each build
+  // the tree, and 4 000 of them take what the two launches take -- the replayed headline step
+  // 0.7826 against 0.7823 ms (tools/ab_kernels.py, four rounds), direct launches -1 %.
+  const bool setup_records = walk3 && !fuse_setup && !arena && !tile_regs && !analytic && groups == 1 && e->fused_setup &&
+                             c.E == T && c.models_per_tree == 1 && !ts.need_slots && T <= kMaxEvals &&
+                             gradient_walk_lut_fused_applies(n, e->K) &&
+                             getenv("MI_PHYLO_SETUP_RECORDS") && getenv("MI_PHYLO_SETUP_RECORDS")[0] == '1';
   // (arena calls: the slot assignment rides in the set-up launch where a workgroup builds the tree)
   ts.arena_macros = arena ? e->arena_macros.as<MacroEntry>() : nullptr;
   ts.slot_need = e->slot_need.as<int32_t>();
-  const bool slots_done = !fuse_setup && launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
+  if (setup_records) {
+    FusedSetupArgs fs{};
+    fs.ts = ts;
+    fs.ms = ms;
+    fs.mmats = e->mmats.as<double>();
+    fs.colocate = e->fused_colocate;
+    launch_setup_records(fs, T, s);
+  }
+  const bool slots_done = !fuse_setup && !setup_records && launch_setup(ts, ms, s);  // tree schedules and model instances, one launch
   if (arena && !slots_done)
     launch_macro_slots(e->macros.as<MacroEntry>(), e->arena_macros.as<MacroEntry>(),
                        e->macro_count.as<int32_t>(), n, T, e->slot_need.as<int32_t>(),
@@ -364,7 +382,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     tm.mphi = analytic ? e->mphi.as<double>() + (size_t)grad_begin * (per / 2) : nullptr;
     launch_transition_macro(tm, s);
   };
-  if (walk2 && !fuse_setup) {
+  if (walk2 && !fuse_setup && !setup_records) {
     macro_matrices(0, 0, T);
     if (site_pass) macro_matrices(17 * T, T, T);
   }
@@ -492,7 +510,7 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
     std::string path = e->dominant;
     if (d.gradient)
       path += !mfma ? " store=hbm" : (arena ? " store=arena" : " store=lds");
-    path += fuse_setup ? " setup=in-walk" : " setup=own-launch";
+    path += fuse_setup ? " setup=in-walk" : (setup_records ? " setup=with-records" : " setup=own-launch");
     if (tile_regs > kLlR) path += " tile=wide";
     if (d.gradient && fd_pass) path += " fd=16";
     if (d.gradient && site_pass) path += " site-pass";

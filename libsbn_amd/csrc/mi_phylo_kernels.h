@@ -240,10 +240,15 @@ struct FusedSetupArgs {
   int debug_skip;    // testing: tree debug_skip - 1 never becomes ready (0: off)
   int fence;         // hand-off: 0 none (round 5), 1 L1 + scalar-cache invalidate (default), 2 agent-scope release / acquire
   int colocate;      // set-up waves of a tree on the XCD of its walk waves
+  int xcd_base;      // id of the first walk workgroup of the launch that will walk these trees, mod 8 (set by the launchers)
 };
 bool gradient_walk_lut_fused_applies(int n, int K);
 void launch_gradient_walk_lut_fused(const LikArgs& a, const FusedSetupArgs& f, int count, bool rescale,
                                     hipStream_t s);
+// The same set-up waves as a launch of their own (round 6): trees, model instances and operand
+// records in ONE launch in front of the walk's, for batches beyond the one-launch call's size
+// (instead of launch_setup + launch_transition_lut).  f.ready may be nullptr.
+void launch_setup_records(const FusedSetupArgs& f, int count, hipStream_t s);
 const char* gradient_walk_lut_kernel_name();
 const char* gradient_walk_lut_fused_kernel_name();
 // waves per CU the walks' LDS footprint allows for this tree size and category count

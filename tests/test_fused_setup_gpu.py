@@ -352,3 +352,46 @@ def test_hand_off_modes_and_arena_access_forms_are_bit_identical(monkeypatch):
     assert np.array_equal(got["3", "0"], lds) and np.array_equal(got["3", "1"], lds)
     assert np.array_equal(got["4", "0"], got["4", "1"])
     assert np.allclose(got["4", "0"], lds, rtol=1e-11, atol=1e-12 * np.max(np.abs(lds)))
+
+
+def test_setup_and_records_in_one_launch_for_large_batches(monkeypatch):
+    """Beyond the one-launch call's 512 trees the same set-up waves can run as ONE launch in front
+    of the walk's (round 6: launch_setup_records, MI_PHYLO_SETUP_RECORDS=1, read per call; measured
+    level with the two launches it replaces and not the default) instead of the tree set-up and
+    the record launches.  Same trees, model instances and operand records: results bit-identical
+    to the four-launch sequence -- two to four categories,
+    rescaling, GTR with the branch-length gradient only, an input error reported with its tree."""
+    import libsbn_amd as L
+    T = 700
+    tips, w, pids, bls, rng = _ds1(T, seed=31)
+    for subst, site in (("JC69", "weibull+4"), ("JC69", "weibull+3"), ("JC69", "weibull+2"), ("GTR", "weibull+4")):
+        spec = O.make_spec(27, tips.shape[1], subst, site, "strict")
+        blocks = {"Weibull shape": rng.uniform(0.3, 2.0, size=(T, 1))}
+        if subst == "GTR":
+            r, f = TU.random_gtr_params(T, rng)
+            blocks["GTR rates"] = r
+            blocks["frequencies"] = f
+        pr = _params(spec, T, **blocks)
+        eng = L.Engine(L.PhyloModelSpecification(subst, site, "strict"), tips, w)
+        only = ("branch_lengths",) if subst == "GTR" else None
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MI_PHYLO_SETUP_RECORDS", mode)
+            res = []
+            for resc in (False, True):
+                res.append(_flat(eng.gradients(pids, bls, pr, resc, gradient_blocks=only)))
+                assert eng.last_call_info()[0] == PLAIN
+                assert ("setup=with-records" in eng.last_call_path()) == (mode == "1"), eng.last_call_path()
+            got[mode] = np.concatenate(res)
+        monkeypatch.delenv("MI_PHYLO_SETUP_RECORDS")
+        assert np.isfinite(got["1"]).all() and np.array_equal(got["1"], got["0"]), (subst, site)
+        if subst == "JC69" and site == "weibull+4":
+            monkeypatch.setenv("MI_PHYLO_SETUP_RECORDS", "1")
+            bad = pids.copy()
+            bad[640, 5] = 2
+            with pytest.raises(RuntimeError) as err:
+                eng.gradients(bad, bls, pr)
+            assert "(tree 640)" in str(err.value)
+            assert np.array_equal(_flat(eng.gradients(pids, bls, pr)), got["1"][:len(got["1"]) // 2])
+            monkeypatch.delenv("MI_PHYLO_SETUP_RECORDS")
+        eng.close()

@@ -279,14 +279,18 @@ int run_device(mi_engine* e, hipStream_t s, const DeviceCall& d) {
   const bool fuse_possible = mfma && walk3_possible(e) && !analytic && groups == 1 && !arena && !tile_regs && e->fused_setup &&
                              fuse_allowed && c.E == T && c.models_per_tree == 1 && !ts.need_slots &&
                              T <= fuse_max_trees && e->ready.ptr && gradient_walk_lut_fused_applies(n, e->K);
-  // One rate category with the stored vectors in LDS: the second generation, whose waves take
-  // several tiles of a tree in a row, is 5-7 % ahead on a large batch (DS1 x 1000 with the
-  // constant site model 0.281 against 0.297 ms, 29 taxa x 1195: 0.358 / 0.383) -- but the
-  // look-up walk has the one-launch call: 0.0336 against 0.0390 ms at 32 trees, 0.0617 / 0.0671
-  // at 125, 0.0905 / 0.0965 at 250, level at 500 (profiles/r06_k1_small_batches.txt).  So one
-  // category in LDS takes the look-up walk exactly where the one-launch call applies.  (Two and
-  // three categories: look-up walk 0.462 / 0.490 and 0.831 / 0.868 ms per 1000 DS1 trees; one
-  // category in the arena 0.261 / 0.294 on fluA's shape.)
+  // One rate category with the stored vectors in LDS.  The second generation, whose waves take
+  // several tiles of a tree in a row, was 5-7 % ahead on a large batch (DS1 x 1000 with the
+  // constant site model 0.281 against 0.297 ms) and the look-up walk, with its one-launch call,
+  // 6-20 % ahead up to 500 trees (profiles/r06_k1_small_batches.txt): so the rule was "look-up
+  // walk where the one-launch call applies".  With the tip codes pre-tiled (a one-category wave
+  // regrouped 16 columns of fields per tip: a quarter of its vector instructions) the look-up
+  // walk is level on large batches too -- 1000 / 4000 trees, second generation / look-up walk:
+  // DS1's shape 0.282 / 0.281 and 0.970 / 0.976 ms, 31 x 1000 0.360 / 0.365 and 1.26 / 1.31, 16 x
+  // 500 0.112 / 0.106 and 0.373 / 0.364, 29 x 1195 0.362 / 0.361 and 1.39 / 1.28
+  // (profiles/r06_k1_large_batches.txt) -- and takes every one-category call
+  // (MI_PHYLO_WALK3_K1=0: the old rule).  (Two and three categories: look-up walk 0.462 / 0.490
+  // and 0.831 / 0.868 ms per 1000 DS1 trees.)
   const bool walk3 = walk2 && walk3_possible(e) && !analytic && groups == 1 &&
                      (tile_regs || (arena ? e->walk3_arena : (e->K > 1 || e->walk3_k1_lds || fuse_possible)));
   const bool fuse_setup = walk3 && fuse_possible;
@@ -855,7 +859,7 @@ static int32_t create_engine(const mi_engine_spec* spec, const double* exchangea
     e->fused_spin_ticks = (int)std::min(2.0e9, std::max(0.01, atof(env)) * 1.0e5);
   // MI_PHYLO_WALK3_ARENA=0: arena-variant calls stay with the second / first generation (A/B)
   if (const char* env = getenv("MI_PHYLO_WALK3_ARENA")) e->walk3_arena = std::string(env) != "0";
-  // MI_PHYLO_WALK3_K1=1: one-category calls with the vectors in LDS take the third generation too (A/B)
+  // MI_PHYLO_WALK3_K1=0: one-category calls with the vectors in LDS take the third generation only where the one-launch call applies (A/B)
   if (const char* env = getenv("MI_PHYLO_WALK3_K1")) e->walk3_k1_lds = std::string(env) != "0";
   if (const char* env = getenv("MI_PHYLO_GRADIENT_PATH")) {  // force one gradient kernel
     const std::string v(env);

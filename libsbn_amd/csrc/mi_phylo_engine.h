@@ -159,7 +159,7 @@ struct mi_engine {
   bool analytic_subst = false;       // MI_PHYLO_SUBST_GRADIENT=analytic (opt-in)
   int gradient_path = 0;  // 0 auto, 2 hbm, 3 mfma (MI_PHYLO_GRADIENT_PATH)
   bool walk3 = true;      // third generation where it applies (tip children looked up; MI_PHYLO_GRADIENT_WALK=v2: off)
-  bool walk3_k1_lds = false;  // MI_PHYLO_WALK3_K1=1: one category, vectors in LDS: third generation too
+  bool walk3_k1_lds = true;  // one category, vectors in LDS: third generation for every batch size (MI_PHYLO_WALK3_K1=0: only where the one-launch call applies, the second generation beyond -- the rule until the tip codes were pre-tiled)
   bool walk3_arena = true;  // ... for arena-variant calls too (MI_PHYLO_WALK3_ARENA=0: off)
   int tile_regs = -1;  // look-up walk: the engine's tile width (0: default, 4: wide; -1: not decided yet -- engine_tile_regs)
   // a sharded handle (mi_engine_create_sharded): the per-device / per-shard engines it

@@ -71,10 +71,10 @@ for n, P, K, T in grid:
     else:
         variants = [(f"{walk}/{store}", {"MI_PHYLO_GRADIENT_WALK": walk, "MI_PHYLO_GRADIENT_STORE": store})
                     for walk, store in itertools.product(("v2", "v3"), ("lds", "arena"))]
-        # (round 6: one category in LDS keeps the second generation unless told otherwise; the
-        # arena's non-temporal accesses are chosen by tiles per tree)
+        # (round 6: the arena's non-temporal accesses are chosen by tiles per tree)
         if K == 1:
-            variants.append(("v3k1/lds", {"MI_PHYLO_GRADIENT_WALK": "v3", "MI_PHYLO_GRADIENT_STORE": "lds", "MI_PHYLO_WALK3_K1": "1"}))
+            # (until the tip codes were pre-tiled: the look-up walk only where its one-launch call applies)
+            variants.append(("v3k1old/lds", {"MI_PHYLO_GRADIENT_STORE": "lds", "MI_PHYLO_WALK3_K1": "0"}))
         # (and its tile width by the engine's tile counts)
         variants += [("v3/%s/r%s" % (store, regs), {"MI_PHYLO_GRADIENT_WALK": "v3", "MI_PHYLO_GRADIENT_STORE": store,
                                                    "MI_PHYLO_WALK_TILE_REGS": regs})

@@ -185,23 +185,29 @@ int gradient_mfma_tiles(int P, int K, int regs) {
   return (P + per_wave - 1) / per_wave;
 }
 // Tile width of the look-up walk for an engine whose batches take the arena: four registers per
-// vector where that leaves enough fewer tiles, else the default.  A wide tile costs 1.14-1.25
-// default tiles of two to four categories (a visit's fixed costs are spread over a third more
-// columns) and 1.2-1.45 of one category -- 29 shapes both ways, profiles/r06_wide_tiles.txt: 36
-// taxa x 1812 patterns x 4 categories 151 -> 114 tiles, 2.72 -> 2.34 ms per 1000 trees; fluA's
-// 69 x 238 x 1, five tiles filled to 99 % against four filled to 93 %, 0.255 -> 0.293.  Wide
-// where the tile count falls by more than a fifth.  The width is the ENGINE's (all its look-up
-// calls take it, and with it the arena): sums over patterns are formed tile by tile, and a
-// tree's outputs must not depend on the size of the batch it came in.
-// MI_PHYLO_WALK_TILE_REGS=3|4 forces a width (read at engine creation).
-int gradient_walk_tile_regs(int P, int K) {
+// vector where that leaves enough fewer tiles, else the default.  Measured both ways on 29 + 17
+// shapes (profiles/r06_wide_tiles.txt; the second table after the tip codes were pre-tiled): a
+// wide tile costs 1.14-1.2 default tiles (a visit's fixed costs are spread over a third more
+// columns) -- 36 taxa x 1812 patterns x 4 categories 151 -> 114 tiles, 2.72 -> 2.34 ms per 1000
+// trees -- unless its LDS footprint costs a wave per CU (64 taxa and more: eight 2-KB slots and
+// the tip words pass 20 KB) AND the tree has few tiles: then 1.3-1.45 (fluA's 69 x 238 x 1, five
+// tiles against four: 0.245 -> 0.260).  So: wide where tiles x cost falls, cost 1.16 or 1.33, and
+// never below five default tiles.  The width is the ENGINE's (all its look-up calls take it):
+// sums over patterns are formed tile by tile, and a tree's outputs must not depend on the size
+// of the batch it came in.  MI_PHYLO_WALK_TILE_REGS=3|4 forces a width (read at engine creation).
+int gradient_walk_tile_regs(int n, int P, int K) {
   if (kLlR >= 4) return kLlR;
   if (const char* env = getenv("MI_PHYLO_WALK_TILE_REGS")) {
     const int r = atoi(env);
     if (r == 4 || r == kLlR) return r;
   }
   const int t3 = gradient_mfma_tiles(P, K, kLlR), t4 = gradient_mfma_tiles(P, K, 4);
-  const bool wide = 5 * t4 < 4 * t3;
+  auto waves = [&](int regs) {
+    const size_t lds = gradient_walk_lds_bytes_for(n, K, false, false, gradient_arena_slots_usual(n), regs);
+    return std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+  };
+  const bool cheap = waves(4) == waves(kLlR) || t4 >= 12;
+  const bool wide = t3 >= 5 && (cheap ? 116 : 133) * t4 < 100 * t3;
   return wide ? 4 : kLlR;
 }
 // ---- arena variant: LDS slots of the two launches ----

@@ -99,7 +99,7 @@ int engine_tile_regs(mi_engine* e) {
   if (e->tile_regs < 0) {
     const bool lut = walk3_possible(e) && e->walk3_arena && gradient_mfma_groups(e->K) == 1;
     const bool forced = getenv("MI_PHYLO_WALK_TILE_REGS") != nullptr;
-    const int r = lut && (forced || gradient_walk_batches_take_arena(e->n, e->K, true)) ? gradient_walk_tile_regs(e->P, e->K) : 0;
+    const int r = lut && (forced || gradient_walk_batches_take_arena(e->n, e->K, true)) ? gradient_walk_tile_regs(e->n, e->P, e->K) : 0;
     e->tile_regs = r > kLlR ? r : 0;
   }
   return e->tile_regs;

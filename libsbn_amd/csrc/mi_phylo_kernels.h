@@ -185,7 +185,7 @@ size_t tip_code_tiles_bytes(int n, int P, int K, int regs);
 void launch_tip_code_tiles(const uint8_t* codes, uint8_t* out, int n, int P, int K, int regs, hipStream_t s);
 // tile width of the look-up walk for an engine whose batches take the arena (kLlR or 4:
 // kernels_walk3.hip, RR)
-int gradient_walk_tile_regs(int P, int K);
+int gradient_walk_tile_regs(int n, int P, int K);
 // Gradient, partial-likelihood vectors streamed through HBM (any tree size, rescaling)
 void launch_gradient_hbm(const LikArgs& a, int count, bool rescale, hipStream_t s);
 // The matrix-core gradient walks (kernels_walk.hip: second generation, kernels_walk3.hip: third;

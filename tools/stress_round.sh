@@ -3,12 +3,12 @@
 # is most of their time); summaries -- trial counts, mismatches, the histogram of the paths the
 # trials took (mi_engine_last_call_path) -- land in gpurun_out/<tag>_stress_*.txt, from where
 # they are copied to profiles/.
-#   bash tools/stress_round.sh r05
+#   bash tools/stress_round.sh r05      (STRESS_SEED_SHIFT=<k>: every sweep's seed + k -- another pass)
 tag=${1:-rXX}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 run() {  # name, tool, seed, trials, [ENV=value ...]
-  local name=$1 tool=$2 seed=$3 trials=$4; shift 4
+  local name=$1 tool=$2 seed=$(($3 + ${STRESS_SEED_SHIFT:-0})) trials=$4; shift 4
   env STRESS_SEED=$seed STRESS_TRIALS=$trials "$@" timeout 3000 python3 tools/stress_$tool.py > gpurun_out/stress_$name.log 2>&1
   {
     echo "stress_$tool ($name) seed $seed trials $trials $* rc=$?"

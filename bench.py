@@ -19,7 +19,7 @@ Output.  The LAST line of stdout is ONE compact JSON object (< 4 KB, asserted: f
 the contract's fields, the dominant kernel's `roofline`, `cpu_baseline`, the parity of the timed
 outputs, `small_batch_ms` (the 125-tree step one GPU of eight runs, from a hipGraph), the
 host-pointer / C++ adapter / fused-reduction legs, and one short entry per other configuration
-in `also` (GTR+4G full and branch-only, log-likelihoods, the 1949-pattern shape, fluA rooted,
+in `also` (GTR+4G full and branch-only, log-likelihoods, the 1949-pattern shape, a 36-taxon arena shape, fluA rooted,
 the 20-state 512 x 50 000 case).  Everything behind those numbers -- second rooflines, phase
 tables, notes, samples -- is written to bench_also.json and printed before the last line as
 `BENCH_ALSO <name> <json>` lines.
@@ -703,6 +703,48 @@ def also_workloads(torch, dev, L, steps):
                 "short": "S-DS1 1949 patterns x1000 gradients", "trees_per_s": T / (ms * 1e-3),
                 "ms_per_step": ms, "kernel": kname,
                 "kernel_ms": k_ms, "roofline": roofline(kname, k_ms, T, f2_g, b2_g, shape=(n, 1949, K)),
+                "parity_checked": S, "parity_max_rel_err": err})
+    eng.close()
+
+    # --- a standard alignment's SHAPE beyond what LDS holds (DS3: 36 taxa, 1812 patterns): random
+    # topologies, synthetic alignment -- the look-up walk's arena variant with wide pattern tiles
+    rng = np.random.default_rng(46)
+    n3, P3 = 36, 1812
+    top3 = np.stack([random_unrooted_topology(n3, rng) for _ in range(50)])
+    pid3 = np.ascontiguousarray(np.tile(top3, (T // 50 + 1, 1))[:T]).astype(np.int32)
+    bl3 = rng.exponential(0.1, size=(T, 2 * n3 - 2))
+    bl3[:, -1] = 0
+    tips3 = evolved_alignment(pid3[0], bl3[0], P3, rng)
+    w3 = np.ones(P3)
+    d_pid3, d_bl3 = dev_arrays(pid3, bl3)
+    N3 = 2 * n3 - 1
+    ll3 = torch.empty(T, dtype=torch.float64, device=dev)
+    g3 = torch.empty((T, N3), dtype=torch.float64, device=dev)
+    eng = L.Engine(L.PhyloModelSpecification("JC69", "weibull+4", "strict"), tips3, w3,
+                   device=dev.index)
+    eng.reserve(T, True)
+    tm = Timed(torch, eng, stream)
+    ms, k_ms = tm.run(lambda: eng.gradients_device(
+        stream, T, d_pid3.data_ptr(), d_bl3.data_ptr(), d_jc.data_ptr(), ll3.data_ptr(),
+        g3.data_ptr(), site.data_ptr(), None), steps, 1)
+    kname = eng.last_call_info()[0]
+    path3 = eng.last_call_path()
+    b3_ll, b3_g = algorithmic_bytes(n3, P3, K)
+    f3_ll, f3_g = algorithmic_flops(n3, P3, K)
+    S = 4
+    og = O.unrooted_gradients(O.make_spec(n3, P3, "JC69", "weibull+4"), tips3, w3, pid3[:S],
+                              bl3[:S], jc[:S], False, min(S, cores))
+    err = parity([("logL", host(ll3, S), og["log_likelihood"]),
+                  ("branch gradient", host(g3, S), og["branch_lengths"]),
+                  ("site gradient", host(site, S), og["site_model"])])
+    out.append({"workload": f"S-DS3 shape: {n3} taxa x {P3} patterns (synthetic, evolved under JC), {T} "
+                            f"trees of 50 random topologies, JC69+weibull+4, phylo_gradients [{path3}]",
+                "short": "S-DS3 36x1812 x1000 gradients", "trees_per_s": T / (ms * 1e-3),
+                "ms_per_step": ms, "kernel": kname,
+                "kernel_ms": k_ms,
+                "roofline": roofline(kname, k_ms, T, f3_g, b3_g, pipe=False,
+                                     exec_flops_per_unit=executed_flops_per_tree(
+                                         kname, n3, P3, K, R=4 if "tile=wide" in path3 else 3)),
                 "parity_checked": S, "parity_max_rel_err": err})
     eng.close()
 
